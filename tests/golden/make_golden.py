@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the reference's own Python on CPU (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference with the shims of SURVEY.md §8c (nothing from the reference is copied
+into the repo; only tensors -- inputs and the outputs the reference computed -- are stored):
+
+* stub modules ``mcubes``, ``torchvision`` and ``models.modules.grid_sample_cuda.cuda_gridsample``
+  are inserted in ``sys.modules`` before the import (the real ones need PyMCubes / torchvision /
+  nvcc, all absent);
+* ``cug.grid_sample_3d`` (CUDA, cuda_gridsample.py:12-14) is replaced by ``_sampler3d_zeros`` below,
+  a zeros-padding trilinear sampler written with differentiable torch ops so the double backward of
+  sdf_network.py:146 can run on CPU.  It is checked here against ``F.grid_sample`` (value + 1st
+  order, every point) and against the reference's own pure-torch ``projector.grid_sample_3d``
+  (projector.py:62-214; 2nd order, in-cube points) before any golden is written;
+* ``torch.Tensor.cuda`` is made the identity (implicit_surface.py:270 hard-codes ``.cuda()``);
+* a dict subclass stands in for pyhocon's ConfigTree.
+
+Outputs: tests/golden/*.npz (a few MB in total).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from gens_amd import synthetic  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------------------
+# shims
+# --------------------------------------------------------------------------------------
+def _sampler3d_zeros(input, grid, padding_mode="zeros", align_corners=True):
+    """Trilinear, zeros padding, align_corners=True; differentiable to any order in torch."""
+    assert padding_mode == "zeros" and align_corners
+    n, c, d, h, w = input.shape
+    assert n == 1
+    g = grid.reshape(-1, 3)
+    size = torch.tensor([w, h, d], dtype=g.dtype)
+    pos = (g + 1) * 0.5 * (size - 1)
+    base = torch.floor(pos.detach())
+    frac = pos - base
+    base = base.long()
+    flat = input.reshape(c, -1)
+    out = 0
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                ix, iy, iz = base[:, 0] + dx, base[:, 1] + dy, base[:, 2] + dz
+                wx = frac[:, 0] if dx else 1 - frac[:, 0]
+                wy = frac[:, 1] if dy else 1 - frac[:, 1]
+                wz = frac[:, 2] if dz else 1 - frac[:, 2]
+                ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h) & (iz >= 0) & (iz < d)
+                lin = (iz.clamp(0, d - 1) * h + iy.clamp(0, h - 1)) * w + ix.clamp(0, w - 1)
+                val = flat[:, lin] * ok.to(input.dtype)[None]
+                out = out + val * (wx * wy * wz)[None]
+    return out.reshape(1, c, 1, 1, -1)
+
+
+def _install_shims():
+    for name in ("mcubes", "torchvision", "torchvision.models"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["mcubes"].marching_cubes = lambda u, t: (np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64))
+    cug = types.ModuleType("models.modules.grid_sample_cuda.cuda_gridsample")
+    cug.grid_sample_3d = _sampler3d_zeros
+    sys.modules["models.modules.grid_sample_cuda.cuda_gridsample"] = cug
+    pkg = types.ModuleType("models.modules.grid_sample_cuda")
+    pkg.__path__ = []
+    pkg.cuda_gridsample = cug
+    sys.modules["models.modules.grid_sample_cuda"] = pkg
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    os.chdir("/tmp")
+
+
+class Conf(dict):
+    """Duck-typed pyhocon ConfigTree: dotted keys + get_int/get_float/get_list/get_bool."""
+
+    def _walk(self, key):
+        node = self
+        for part in key.split("."):
+            node = dict.__getitem__(node, part)
+        return node
+
+    def __getitem__(self, key):
+        v = self._walk(key)
+        return Conf(v) if isinstance(v, dict) and not isinstance(v, Conf) else v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    get_int = get_float = get_list = get_bool = get
+
+
+def surf_conf(n_levels_vol, n_levels_feat):
+    return Conf({
+        "sdf_network": dict(d_out=129, d_in=3, d_hidden=128, n_layers=6, skip_in=[3], multires=4, bias=0.5,
+                            scale=1.0, geometric_init=True, weight_norm=True, feat_channels=4 * n_levels_vol),
+        "color_network": dict(d_feature=4 * n_levels_feat),
+        "variance_network": dict(init_val=0.3),
+        "render": dict(n_samples=64, n_importance=64, up_sample_steps=4, perturb=1.0),
+    })
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+# --------------------------------------------------------------------------------------
+# goldens
+# --------------------------------------------------------------------------------------
+def g1_volume(Volume):
+    # (a) BASELINE config 1: 3 views, coarsest (16^3) volume only, level-4 map, intrinsics * 2^-4 (Q2)
+    sc = synthetic.make_scene(nv=3, h=480, w=640, n_levels=5, seed=11)
+    intr = sc["intrs"].clone()
+    intr[:, :2] *= 0.5 ** 4
+    feat = sc["features"][4].clone().requires_grad_(True)
+    vol = Volume(Conf({"volume_dims": [16]}))
+    v, m = vol.agg_mean_var([feat], intr, sc["c2ws"])
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(v[0].shape, generator=g)
+    (v[0] * cot).sum().backward()
+    npz("g1a_volume_c1", feat=feat, intrs=intr, c2ws=sc["c2ws"], volume=v[0], mask=m[0], cot=cot, gfeat=feat.grad)
+
+    # (b) 5 views, three scales, 60x80 pyramid
+    sc = synthetic.make_scene(nv=5, h=60, w=80, n_levels=3, seed=12)
+    feats = [f.clone().requires_grad_(True) for f in sc["features"]]
+    dims = [24, 12, 6]
+    vol = Volume(Conf({"volume_dims": dims}))
+    v, m = vol.agg_mean_var(feats, sc["intrs"], sc["c2ws"])
+    cots = [torch.randn(x.shape, generator=g) for x in v]
+    sum((a * b).sum() for a, b in zip(v, cots)).backward()
+    d = dict(intrs=sc["intrs"], c2ws=sc["c2ws"], dims=np.array(dims))
+    for i in range(3):
+        d.update({f"feat{i}": feats[i], f"volume{i}": v[i], f"mask{i}": m[i], f"cot{i}": cots[i], f"gfeat{i}": feats[i].grad})
+    npz("g1b_volume_ms", **d)
+
+
+def g2_lookup(projector):
+    g = torch.Generator().manual_seed(21)
+    dims = [12, 8, 5]
+    vols = [torch.randn(1, 4, d, d, d, generator=g).requires_grad_(True) for d in dims]
+    pts = (torch.rand(300, 3, generator=g) * 2.6 - 1.3)
+    pts[:8] = torch.tensor([[1, 1, 1], [-1, -1, -1], [1, -1, 0.3], [0, 0, 0], [1.0001, 0, 0], [-1.0001, 0.5, 0.5],
+                            [0.999, 0.999, -0.999], [0.2, -1, 1]], dtype=torch.float32)
+    pts.requires_grad_(True)
+    incube = (pts.detach().abs() < 0.999).all(-1)
+
+    # value + first order from the op the reference's forward/backward really calls (F.grid_sample /
+    # aten::grid_sampler_3d_backward; cuda_gridsample.py:79,97)
+    x = pts.unsqueeze(0).unsqueeze(0).unsqueeze(0).flip(dims=[-1])
+    feats = torch.cat([F.grid_sample(v, x, padding_mode="zeros", align_corners=True).reshape(-1, 300).permute(1, 0)
+                       for v in vols], -1)
+    gO = torch.randn(feats.shape, generator=g)
+    grads = torch.autograd.grad(feats, vols + [pts], gO)
+    gV, gP = grads[:3], grads[3]
+
+    # same through the shimmed lookup_volume (the path the model takes) -> must agree
+    feats_s = projector.lookup_volume(pts, vols)
+    assert torch.allclose(feats_s, feats, atol=1e-6), "shim sampler forward != F.grid_sample"
+    gp_s = torch.autograd.grad(feats_s, pts, gO, create_graph=True)[0]
+    assert torch.allclose(gp_s, gP, atol=1e-5), "shim sampler d/dpts != aten backward"
+
+    # second order: cotangent ggG on gp  ->  (ggO, gV', gp')   [what grad2_3d returns, gridsample_cuda.cpp:42-56]
+    ggG = torch.randn(300, 3, generator=g)
+    gO_leaf = gO.clone().requires_grad_(True)
+    gp_l = torch.autograd.grad(projector.lookup_volume(pts, vols), pts, gO_leaf, create_graph=True)[0]
+    outs = torch.autograd.grad(gp_l, [gO_leaf] + vols + [pts], ggG, allow_unused=True)
+    ggO, gV2, gP2 = outs[0], outs[1:4], outs[4]
+
+    # cross-check the in-cube part against the reference's own pure-torch sampler (projector.py:62-214)
+    def ref_lookup(p, vs):
+        xx = p.unsqueeze(0).unsqueeze(0).unsqueeze(0).flip(dims=[-1])
+        return torch.cat([projector.grid_sample_3d(v, xx).reshape(-1, p.shape[0]).permute(1, 0) for v in vs], -1)
+    pin = pts.detach()[incube].clone().requires_grad_(True)
+    gO_in = gO[incube].clone().requires_grad_(True)
+    gp_r = torch.autograd.grad(ref_lookup(pin, vols), pin, gO_in, create_graph=True)[0]
+    outs_r = torch.autograd.grad(gp_r, [gO_in, pin], ggG[incube])
+    assert torch.allclose(outs_r[0], ggO[incube], atol=1e-4), "2nd order ggO differs from reference pure-torch sampler"
+    assert torch.allclose(outs_r[1], gP2[incube], atol=1e-4), "2nd order gp' differs from reference pure-torch sampler"
+
+    d = dict(pts=pts, feats=feats, gO=gO, gP=gP, ggG=ggG, ggO=ggO, gP2=gP2, incube=incube, dims=np.array(dims))
+    for i in range(3):
+        d.update({f"vol{i}": vols[i], f"gV{i}": gV[i], f"gV2_{i}": gV2[i]})
+    npz("g2_lookup", **d)
+
+
+def g3_nearest(projector):
+    g = torch.Generator().manual_seed(31)
+    dims = [12, 8, 5]
+    masks = [(torch.rand(1, 1, d, d, d, generator=g) > 0.5).float() for d in dims]
+    pts = torch.rand(400, 3, generator=g) * 2.4 - 1.2
+    # half-integer ties of the align_corners=False index ((p+1)*D-1)/2 = k+.5  (Q6)
+    k = 0
+    for d in dims:
+        for idx in range(d):
+            pts[k % 200, k % 3] = (2.0 * idx + 2.0) / d - 1.0
+            k += 1
+    pts[200:206] = torch.tensor([[1, 1, 1], [-1, -1, -1], [1, 0, -1], [0.99999, 0, 0], [-1, 1, 0], [0, 0, 0]], dtype=torch.float32)
+    val = projector.lookup_volume(pts, masks, sample_mode="nearest")
+    d = dict(pts=pts, val=val, any=val.any(dim=-1), dims=np.array(dims))
+    for i in range(3):
+        d[f"mask{i}"] = masks[i]
+    npz("g3_nearest", **d)
+
+
+def g4_feature(projector):
+    sc = synthetic.make_scene(nv=4, h=48, w=64, n_levels=5, seed=41)
+    g = torch.Generator().manual_seed(42)
+    pts = torch.rand(256, 3, generator=g) * 2 - 1
+    pts[:4] = torch.tensor([[0, 0, -3.0], [0, 0, -2.2], [2.5, 0, -2.0], [0.9, 0.9, 0.9]])
+    feats = [f.clone().requires_grad_(True) for f in sc["features"]]
+    imgs = sc["imgs"].clone().requires_grad_(True)
+    fv, rd, mk = projector.lookup_feature(pts, imgs, sc["intrs"], sc["c2ws"], feats)
+    cot = torch.randn(fv.shape, generator=g)
+    fv_f = torch.nan_to_num(fv, nan=0.0, posinf=0.0, neginf=0.0)
+    grads = torch.autograd.grad((fv_f * cot).sum(), feats + [imgs])
+    d = dict(pts=pts, imgs=imgs, intrs=sc["intrs"], c2ws=sc["c2ws"], feat_views=fv, ray_diff=rd, mask=mk, cot=cot, gimgs=grads[5])
+    for i in range(5):
+        d.update({f"feat{i}": feats[i], f"gfeat{i}": grads[i]})
+    npz("g4_feature", **d)
+
+
+def g5_upsample(isurf_mod, projector):
+    g = torch.Generator().manual_seed(51)
+    surf = isurf_mod.ImplicitSurface(surf_conf(3, 5))
+    sc = synthetic.make_scene(nv=3, h=48, w=64, n_levels=5, seed=52)
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], 48, 64, pixels=torch.tensor([[3, 5], [20, 20], [32, 24], [40, 30], [60, 44], [31, 23], [10, 40]]))
+    b = rays_o.shape[0]
+    dims = [16, 8, 4]
+    masks = [(torch.rand(1, 1, d, d, d, generator=g) > 0.3).float() for d in dims]
+    d = dict(rays_o=rays_o, rays_d=rays_d, dims=np.array(dims))
+    for i in range(3):
+        d[f"mask{i}"] = masks[i]
+    for r, n in enumerate([64, 80, 96, 112]):
+        z = torch.sort(torch.rand(b, n, generator=g) * 2.2 + 1.1, dim=-1)[0]
+        pts = rays_o[:, None] + rays_d[:, None] * z[..., None]
+        sdf = torch.linalg.norm(pts, dim=-1) - 0.6 + 0.05 * torch.randn(b, n, generator=g)
+        sdf[0, 5:9] = 100.0  # masked-out samples carry the constant 100 (Q8)
+        inv_s = 64 * 2 ** r
+        zs = surf.up_sample(rays_o, rays_d, z, sdf, 16, masks, inv_s)
+        z2, _ = surf.cat_z_vals(rays_o, rays_d, z, zs, sdf, None, masks, last=True)
+        d.update({f"z{r}": z, f"sdf{r}": sdf, f"znew{r}": zs, f"zcat{r}": z2})
+    # sample_pdf alone (det=True), incl. a flat pdf and an all-zero weight row
+    bins = torch.sort(torch.rand(5, 33, generator=g), dim=-1)[0]
+    w = torch.rand(5, 32, generator=g)
+    w[1] = 0.0
+    w[2] = 1.0
+    w[3, :30] = 0.0
+    d.update(pdf_bins=bins, pdf_w=w, pdf_out=isurf_mod.sample_pdf(bins, w, 16, det=True))
+    npz("g5_upsample", **d)
+
+
+def g7_patchwarp(projector):
+    sc = synthetic.make_scene(nv=3, h=48, w=64, n_levels=1, channels=12, seed=71)
+    g = torch.Generator().manual_seed(72)
+    imgs = sc["features"][0]
+    pts = (torch.rand(10, 1, 3, generator=g) - 0.5) * 0.8
+    pts[0, 0] = sc["c2ws"][0, :3, 3]  # "no crossing" rays sample at the camera centre (implicit_surface.py:301-305)
+    pts.requires_grad_(True)
+    nrm = torch.randn(10, 1, 3, generator=g)
+    nrm = nrm / torch.linalg.norm(nrm, dim=-1, keepdim=True)
+    ref, smp = projector.surface_patch_warp(pts, nrm, imgs, sc["intrs"], sc["c2ws"])
+    cot = torch.randn(smp.shape, generator=g)
+    gp = torch.autograd.grad((smp[:, 1:] * cot[:, 1:]).sum(), pts)[0]
+    npz("g7_patchwarp", pts=pts, normals=nrm, images=imgs, intrs=sc["intrs"], c2ws=sc["c2ws"], ref_val=ref, src_val=smp, cot=cot, gpts=gp)
+
+
+def g8_tv(isurf_mod):
+    g = torch.Generator().manual_seed(81)
+    surf = isurf_mod.ImplicitSurface(surf_conf(2, 5))
+    dims = [9, 5]
+    vols = [torch.randn(1, 4, d, d, d, generator=g).requires_grad_(True) for d in dims]
+    masks = [(torch.rand(1, 1, d, d, d, generator=g) > 0.3).float() for d in dims]
+    tv = surf.tv_regularization(vols, masks)
+    gv = torch.autograd.grad(tv, vols)
+    npz("g8_tv", vol0=vols[0], vol1=vols[1], mask0=masks[0], mask1=masks[1], tv=tv, gvol0=gv[0], gvol1=gv[1], dims=np.array(dims))
+
+
+def _perturb(module, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(scale * torch.randn(p.shape, generator=g) * (p.abs().mean() + 0.02))
+
+
+def g9_render(isurf_mod, Volume, tag, seed, cos_anneal, step, n_rays, variance=0.3):
+    """End-to-end ImplicitSurface.render (all 18 keys) + recorded intermediates."""
+    torch.manual_seed(seed)
+    h, w, nv = 48, 64, 3
+    sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=5, seed=seed)
+    dims = [24, 16, 8]
+    vols = synthetic.make_volumes(dims, seed=seed + 1)
+    with torch.no_grad():
+        _, masks = Volume(Conf({"volume_dims": dims})).agg_mean_var(sc["features"][:3], sc["intrs"], sc["c2ws"])
+    surf = isurf_mod.ImplicitSurface(surf_conf(3, 5))
+    _perturb(surf.sdf_network, seed + 2, 0.04)
+    with torch.no_grad():
+        surf.deviation_network.variance.fill_(variance)
+    _perturb(surf.color_network, seed + 3, 0.05)
+    g = torch.Generator().manual_seed(seed + 4)
+    pix = torch.stack([torch.randint(0, w, (n_rays,), generator=g), torch.randint(0, h, (n_rays,), generator=g)], -1)
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w, pixels=pix)
+    match_feats = [f + 0.01 for f in sc["features"]]
+
+    rec = {}
+    orig_core = surf.render_core
+
+    def core(rays_o_, rays_d_, z_vals, *a, **k):
+        rec["z_final"] = z_vals.detach().clone()
+        return orig_core(rays_o_, rays_d_, z_vals, *a, **k)
+    surf.render_core = core
+    orig_rand = torch.rand
+    draws = []
+
+    def rand(*a, **k):
+        r = orig_rand(*a, **k)
+        draws.append(r.clone())
+        return r
+    torch.rand = rand
+    torch.manual_seed(seed + 100)
+    try:
+        out = surf.render(rays_o, rays_d, sc["near"], sc["far"], vols, masks, sc["imgs"], sc["features"], match_feats,
+                          sc["intrs"], sc["c2ws"], cos_anneal, step)
+    finally:
+        torch.rand = orig_rand
+    d = dict(rays_o=rays_o, rays_d=rays_d, near=sc["near"], far=sc["far"], imgs=sc["imgs"], intrs=sc["intrs"], c2ws=sc["c2ws"],
+             dims=np.array(dims), cos_anneal=np.float32(cos_anneal), step=np.float32(-1 if step is None else step),
+             rng_seed=np.int64(seed + 100), draw_trand=draws[0], draw_ptsrand=draws[1], z_final=rec["z_final"])
+    for i in range(5):
+        d[f"feat{i}"] = sc["features"][i]
+    for i in range(3):
+        d[f"vol{i}"] = vols[i]
+        d[f"mask{i}"] = masks[i]
+    for k, v in surf.state_dict().items():
+        d["sd." + k] = v
+    for k, v in out.items():
+        d["out." + k] = v
+    npz(tag, **d)
+    return surf, sc, vols, masks
+
+
+def g10_geometry(surf, vols):
+    import mcubes
+    grabbed = {}
+    mcubes.marching_cubes = lambda u, t: (grabbed.setdefault("u", u.copy()), (np.zeros((1, 3)), np.zeros((0, 3), dtype=np.int64)))[1]
+    bmin, bmax = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0])
+    surf.extract_geometry(vols, bmin, bmax, 65, 0.0)
+    npz("g10_geometry", u=grabbed["u"].astype(np.float32), resolution=np.int64(65))
+
+
+def main():
+    _install_shims()
+    from models.modules.volume import Volume
+    from models.modules import projector
+    from models.modules import implicit_surface as isurf_mod
+
+    g1_volume(Volume)
+    g2_lookup(projector)
+    g3_nearest(projector)
+    g4_feature(projector)
+    g5_upsample(isurf_mod, projector)
+    g7_patchwarp(projector)
+    g8_tv(isurf_mod)
+    g9_render(isurf_mod, Volume, "g9a_render", seed=90, cos_anneal=0.5, step=None, n_rays=24)
+    surf, sc, vols, masks = g9_render(isurf_mod, Volume, "g9b_render", seed=95, cos_anneal=1.0, step=7, n_rays=16, variance=0.55)
+    g10_geometry(surf, vols)
+    leaked = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
+    assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
+
+
+if __name__ == "__main__":
+    main()
