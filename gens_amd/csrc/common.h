@@ -1,0 +1,161 @@
+// Internal helpers shared by the gfx950 kernels of libgens_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gens_hip.h"
+
+#define GENS_WAVE 64
+
+void gens_set_error(const char* fmt, ...);
+
+#define GENS_CHECK_ARG(cond, code, ...)  \
+    do {                                 \
+        if (!(cond)) {                   \
+            gens_set_error(__VA_ARGS__); \
+            return (code);               \
+        }                                \
+    } while (0)
+
+static inline int gens_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gens_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+static inline unsigned gens_blocks(int64_t work, int per_block) { return (unsigned)((work + per_block - 1) / per_block); }
+
+// Up to GENS_MAX_LEVELS volumes / maps passed by value in the kernel argument block (scalar loads, no indirection
+// through HBM).
+struct LevelSet {
+    const float* data[GENS_MAX_LEVELS];
+    float* grad[GENS_MAX_LEVELS];
+    const float* aux[GENS_MAX_LEVELS];
+    int dx[GENS_MAX_LEVELS], dy[GENS_MAX_LEVELS], dz[GENS_MAX_LEVELS];
+    int n;
+};
+
+// torch.linspace(start, end, steps)[i] in float32 (ATen's symmetric formula: the upper half counts down from end).
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// 4x4 row-major matrix times (x,y,z,1): full homogeneous result.
+__device__ __forceinline__ float4 mat4_point(const float* __restrict__ m, float x, float y, float z) {
+    float4 r;
+    r.x = m[0] * x + m[1] * y + m[2] * z + m[3];
+    r.y = m[4] * x + m[5] * y + m[6] * z + m[7];
+    r.z = m[8] * x + m[9] * y + m[10] * z + m[11];
+    r.w = m[12] * x + m[13] * y + m[14] * z + m[15];
+    return r;
+}
+
+// wave-level helpers (wave = 64 lanes on gfx950)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// inclusive prefix product / sum across the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// nearest-neighbour mask read with grid_sample(align_corners=False) index math: ((p+1)*D-1)/2 rounded half-to-even (Q6)
+__device__ __forceinline__ float mask_nearest(const float* __restrict__ m, int dx, int dy, int dz, float px, float py,
+                                              float pz) {
+    float fx = rintf(((px + 1.0f) * (float)dx - 1.0f) / 2.0f);
+    float fy = rintf(((py + 1.0f) * (float)dy - 1.0f) / 2.0f);
+    float fz = rintf(((pz + 1.0f) * (float)dz - 1.0f) / 2.0f);
+    if (!(fx >= 0.0f && fx < (float)dx && fy >= 0.0f && fy < (float)dy && fz >= 0.0f && fz < (float)dz)) return 0.0f;
+    return m[((int64_t)(int)fx * dy + (int)fy) * dz + (int)fz];
+}
+
+__device__ __forceinline__ bool any_mask(const LevelSet& ms, float px, float py, float pz) {
+    bool ok = false;
+    for (int l = 0; l < ms.n; ++l) ok = ok || (mask_nearest(ms.data[l], ms.dx[l], ms.dy[l], ms.dz[l], px, py, pz) > 0.0f);
+    return ok;
+}
+
+// Bilinear taps of a zero-padded texel image: pixel coordinates (ix, iy) may be anything, incl. NaN/inf.
+struct Taps2 {
+    int x0, y0;
+    float w00, w01, w10, w11;  // (y,x): 00 = north-west
+    bool ok00, ok01, ok10, ok11;
+};
+__device__ __forceinline__ Taps2 bilinear_taps(float ix, float iy, int h, int w) {
+    Taps2 t;
+    bool fin = isfinite(ix) && isfinite(iy);
+    float sx = fin ? ix : 0.0f, sy = fin ? iy : 0.0f;
+    float fx = floorf(sx), fy = floorf(sy);
+    fx = fminf(fmaxf(fx, -4.0f), (float)w + 4.0f);
+    fy = fminf(fmaxf(fy, -4.0f), (float)h + 4.0f);
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    float wx1 = sx - fx, wx0 = (fx + 1.0f) - sx;
+    float wy1 = sy - fy, wy0 = (fy + 1.0f) - sy;
+    t.w00 = wx0 * wy0;
+    t.w01 = wx1 * wy0;
+    t.w10 = wx0 * wy1;
+    t.w11 = wx1 * wy1;
+    bool xin0 = t.x0 >= 0 && t.x0 < w, xin1 = t.x0 + 1 >= 0 && t.x0 + 1 < w;
+    bool yin0 = t.y0 >= 0 && t.y0 < h, yin1 = t.y0 + 1 >= 0 && t.y0 + 1 < h;
+    t.ok00 = fin && xin0 && yin0;
+    t.ok01 = fin && xin1 && yin0;
+    t.ok10 = fin && xin0 && yin1;
+    t.ok11 = fin && xin1 && yin1;
+    return t;
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_madd(float4 acc, float4 v, float s) {
+    acc.x += v.x * s;
+    acc.y += v.y * s;
+    acc.z += v.z * s;
+    acc.w += v.w * s;
+    return acc;
+}
+
+// texel (float4) bilinear read from img (h, w, cpad/4 float4s), texel slot q
+__device__ __forceinline__ float4 sample_texel(const float4* __restrict__ img, int h, int w, int q4, int q, const Taps2& t) {
+    float4 acc = f4_zero();
+    int64_t base = ((int64_t)t.y0 * w + t.x0) * q4 + q;
+    if (t.ok00) acc = f4_madd(acc, img[base], t.w00);
+    if (t.ok01) acc = f4_madd(acc, img[base + q4], t.w01);
+    if (t.ok10) acc = f4_madd(acc, img[base + (int64_t)w * q4], t.w10);
+    if (t.ok11) acc = f4_madd(acc, img[base + (int64_t)w * q4 + q4], t.w11);
+    return acc;
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v, float s) {
+    atomicAdd(p + 0, v.x * s);
+    atomicAdd(p + 1, v.y * s);
+    atomicAdd(p + 2, v.z * s);
+    atomicAdd(p + 3, v.w * s);
+}

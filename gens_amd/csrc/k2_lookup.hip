@@ -1,0 +1,327 @@
+// K2 / K2'' / K3: multi-level trilinear volume look-up with first- and second-order derivatives, and the
+// nearest-neighbour visibility-mask look-up.
+//
+//   forward     lookup_volume(..., "grad")  projector.py:217-245 -> cuda_gridsample.py:71-84 (F.grid_sample 3-D)
+//   backward    aten::grid_sampler_3d_backward through cuda_gridsample.py:94-108
+//   backward^2  grid_sampler_3d_grad2_kernel, gridsample_cuda.cu:212-533 (the reference's only native kernel)
+//   nearest     lookup_volume(..., "nearest"), projector.py:231,240
+//
+// MI355X design: ALL levels of the pyramid are served by one launch (the reference issues one grid_sampler launch
+// plus reshape/permute/cat per level).  The forward runs one thread per (point, level) with the level fastest, so
+// a wavefront's 64 results are 64 consecutive float4 of the (N, 4L) output: fully coalesced 1-KiB stores, and the
+// 8 corner reads of a "packed" volume are 8 independent 16-B gathers in flight per lane.  Backward passes run one
+// thread per point and loop over the levels so d/dpts accumulates in registers (no atomics on it); only the
+// scatter into volume gradients uses atomics, and it is skipped entirely when the caller passes no gradient
+// buffers (inference, or frozen volumes) -- the reference zero-fills and scatters into a volume-sized tensor on
+// every call (gridsample_cuda.cu:620-622, cuda_gridsample.py:113-114).
+//
+// Axis convention (Q1): p = (px,py,pz) reads element [ix(px)][iy(py)][iz(pz)]; align_corners=True, zeros padding.
+#include "common.h"
+
+template <int LAYOUT>
+__device__ __forceinline__ float4 vox_load(const float* __restrict__ v, int64_t nvox, int64_t lin) {
+    if (LAYOUT == GENS_LAYOUT_PACKED) return ((const float4*)v)[lin];
+    return make_float4(v[lin], v[nvox + lin], v[2 * nvox + lin], v[3 * nvox + lin]);
+}
+template <int LAYOUT>
+__device__ __forceinline__ void vox_atomic_add(float* __restrict__ v, int64_t nvox, int64_t lin, float4 g, float s) {
+    if (LAYOUT == GENS_LAYOUT_PACKED) {
+        atomic_add4(v + lin * 4, g, s);
+    } else {
+        atomicAdd(v + lin, g.x * s);
+        atomicAdd(v + nvox + lin, g.y * s);
+        atomicAdd(v + 2 * nvox + lin, g.z * s);
+        atomicAdd(v + 3 * nvox + lin, g.w * s);
+    }
+}
+
+// Per-axis cell: base index, the two weights ((i0+1)-pos, pos-i0 as ATen forms them) and bounds flags.
+struct Cell {
+    int i0;
+    float w0, w1;
+    bool in0, in1;
+};
+__device__ __forceinline__ Cell axis_cell(float p, int size) {
+    float pos = (p + 1.0f) / 2.0f * (float)(size - 1);
+    float f = floorf(pos);
+    f = fminf(fmaxf(f, -2.0f), (float)size + 1.0f);  // far-away points: every tap out of bounds, no int overflow
+    Cell c;
+    c.i0 = (int)f;
+    c.w0 = (f + 1.0f) - pos;
+    c.w1 = pos - f;
+    c.in0 = c.i0 >= 0 && c.i0 < size;
+    c.in1 = c.i0 + 1 >= 0 && c.i0 + 1 < size;
+    if (!(pos == pos)) { c.in0 = c.in1 = false; c.w0 = c.w1 = 0.0f; }  // NaN point
+    return c;
+}
+
+#define FOR_CORNERS(body)                                                                     \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                        \
+        bool ok = (a ? cx.in1 : cx.in0) && (b ? cy.in1 : cy.in0) && (c ? cz.in1 : cz.in0);    \
+        int64_t lin = ((int64_t)(cx.i0 + a) * Y + (cy.i0 + b)) * Z + (cz.i0 + c);            \
+        float wx = a ? cx.w1 : cx.w0, wy = b ? cy.w1 : cy.w0, wz = c ? cz.w1 : cz.w0;         \
+        float sx = a ? 1.0f : -1.0f, sy = b ? 1.0f : -1.0f, sz = c ? 1.0f : -1.0f;            \
+        body                                                                                   \
+    }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: one thread per (point, level)
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void lookup_fwd_k(LevelSet vs, const float* __restrict__ pts, int64_t n,
+                                                    float4* __restrict__ out) {
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int L = vs.n;
+    if (gid >= n * L) return;
+    int l = (int)(gid % L);
+    int64_t i = gid / L;
+    float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
+    int64_t nvox = (int64_t)X * Y * Z;
+    const float* v = vs.data[l];
+    Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
+    float4 acc = f4_zero();
+    FOR_CORNERS({
+        (void)sx; (void)sy; (void)sz;
+        if (ok) acc = f4_madd(acc, vox_load<LAYOUT>(v, nvox, lin), wx * wy * wz);
+    })
+    out[gid] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: one thread per point, loops levels.  g_pts always written; volume scatter only if vs.grad[l] != NULL.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void lookup_bwd_k(LevelSet vs, const float* __restrict__ pts,
+                                                    const float4* __restrict__ g_out, int64_t n, float* __restrict__ g_pts) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    for (int l = 0; l < vs.n; ++l) {
+        int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
+        int64_t nvox = (int64_t)X * Y * Z;
+        const float* v = vs.data[l];
+        float* gv = vs.grad[l];
+        Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
+        float4 go = g_out[i * vs.n + l];
+        float lx = 0.0f, ly = 0.0f, lz = 0.0f;
+        FOR_CORNERS({
+            if (ok) {
+                float4 val = vox_load<LAYOUT>(v, nvox, lin);
+                float dot = val.x * go.x + val.y * go.y + val.z * go.z + val.w * go.w;
+                lx += dot * (sx * wy * wz);
+                ly += dot * (wx * sy * wz);
+                lz += dot * (wx * wy * sz);
+                if (gv) vox_atomic_add<LAYOUT>(gv, nvox, lin, go, wx * wy * wz);
+            }
+        })
+        gx += lx * ((float)(X - 1) / 2.0f);
+        gy += ly * ((float)(Y - 1) / 2.0f);
+        gz += lz * ((float)(Z - 1) / 2.0f);
+    }
+    if (g_pts) {
+        g_pts[3 * i] = gx;
+        g_pts[3 * i + 1] = gy;
+        g_pts[3 * i + 2] = gz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the backward.  Cotangents: gg_pts on g_pts, optional gg_vols (vs.aux) on g_vols.
+//   gg_out[c]  = sum_k V_c[k] * T[k]            (+ sum_k ggV_c[k] * w[k])
+//   g_vols2    += g_out[c] * T[k]                         T[k] = e . grad_pos(w[k]),  e = gg_pts * (size-1)/2
+//   g_pts2[x]  = sx_scale * sum_c g_out[c] * ( e_y * Mxy_c + e_z * Mxz_c   (+ sum_k ggV_c[k] d w[k]/dx) ) ...
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void lookup_bwd2_k(LevelSet vs, const float* __restrict__ pts,
+                                                     const float4* __restrict__ g_out, const float* __restrict__ gg_pts,
+                                                     int64_t n, float4* __restrict__ gg_out, float* __restrict__ g_pts2) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    float qx = gg_pts[3 * i], qy = gg_pts[3 * i + 1], qz = gg_pts[3 * i + 2];
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    for (int l = 0; l < vs.n; ++l) {
+        int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
+        int64_t nvox = (int64_t)X * Y * Z;
+        const float* v = vs.data[l];
+        const float* ggv = vs.aux[l];
+        float* gv2 = vs.grad[l];
+        float mx = (float)(X - 1) / 2.0f, my = (float)(Y - 1) / 2.0f, mz = (float)(Z - 1) / 2.0f;
+        float ex = qx * mx, ey = qy * my, ez = qz * mz;
+        Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
+        float4 go = g_out[i * vs.n + l];
+        float4 acc = f4_zero();
+        float lx = 0.0f, ly = 0.0f, lz = 0.0f;
+        FOR_CORNERS({
+            if (ok) {
+                float4 val = vox_load<LAYOUT>(v, nvox, lin);
+                float t = ex * (sx * wy * wz) + ey * (wx * sy * wz) + ez * (wx * wy * sz);
+                acc = f4_madd(acc, val, t);
+                float dot = val.x * go.x + val.y * go.y + val.z * go.z + val.w * go.w;
+                lx += dot * (ey * (sx * sy * wz) + ez * (sx * wy * sz));
+                ly += dot * (ex * (sx * sy * wz) + ez * (wx * sy * sz));
+                lz += dot * (ex * (sx * wy * sz) + ey * (wx * sy * sz));
+                if (gv2) vox_atomic_add<LAYOUT>(gv2, nvox, lin, go, t);
+                if (ggv) {
+                    float4 g2 = vox_load<LAYOUT>(ggv, nvox, lin);
+                    acc = f4_madd(acc, g2, wx * wy * wz);
+                    float d2 = g2.x * go.x + g2.y * go.y + g2.z * go.z + g2.w * go.w;
+                    lx += d2 * (sx * wy * wz);
+                    ly += d2 * (wx * sy * wz);
+                    lz += d2 * (wx * wy * sz);
+                }
+            }
+        })
+        gg_out[i * vs.n + l] = acc;
+        ox += lx * mx;
+        oy += ly * my;
+        oz += lz * mz;
+    }
+    g_pts2[3 * i] = ox;
+    g_pts2[3 * i + 1] = oy;
+    g_pts2[3 * i + 2] = oz;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3 nearest mask + fused ray-point generation
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_nearest_k(LevelSet ms, const float* __restrict__ pts, int64_t n,
+                                                      uint8_t* __restrict__ valid, float* __restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    bool any = false;
+    for (int l = 0; l < ms.n; ++l) {
+        float m = mask_nearest(ms.data[l], ms.dx[l], ms.dy[l], ms.dz[l], px, py, pz);
+        if (vals) vals[i * ms.n + l] = m;
+        any = any || (m > 0.0f);
+    }
+    if (valid) valid[i] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ray_points_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const float* __restrict__ z, int64_t total, int n, int mid,
+                                                    float sample_dist, LevelSet ms, float* __restrict__ pts,
+                                                    uint8_t* __restrict__ valid) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i / n;
+    int j = (int)(i % n);
+    float t = z[i];
+    if (mid) {
+        float dist = (j + 1 < n) ? z[i + 1] - t : sample_dist;               // (Q10)
+        t = t + dist * 0.5f;
+    }
+    float px = rays_o[3 * r] + rays_d[3 * r] * t;
+    float py = rays_o[3 * r + 1] + rays_d[3 * r + 1] * t;
+    float pz = rays_o[3 * r + 2] + rays_d[3 * r + 2] * t;
+    pts[3 * i] = px;
+    pts[3 * i + 1] = py;
+    pts[3 * i + 2] = pz;
+    if (valid) valid[i] = any_mask(ms, px, py, pz) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels) {
+    GENS_CHECK_ARG(data && dims, GENS_EINVAL, "%s: null level table", who);
+    GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "%s: n_levels=%d not in 1..%d", who, n_levels,
+                   GENS_MAX_LEVELS);
+    ls->n = n_levels;
+    for (int l = 0; l < GENS_MAX_LEVELS; ++l) {
+        ls->data[l] = nullptr;
+        ls->grad[l] = nullptr;
+        ls->aux[l] = nullptr;
+        ls->dx[l] = ls->dy[l] = ls->dz[l] = 1;
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        GENS_CHECK_ARG(data[l], GENS_EINVAL, "%s: level %d is null", who, l);
+        GENS_CHECK_ARG(dims[3 * l] > 0 && dims[3 * l + 1] > 0 && dims[3 * l + 2] > 0, GENS_EINVAL, "%s: level %d has a zero dim", who, l);
+        ls->data[l] = data[l];
+        ls->dx[l] = dims[3 * l];
+        ls->dy[l] = dims[3 * l + 1];
+        ls->dz[l] = dims[3 * l + 2];
+    }
+    return 0;
+}
+
+#define DISPATCH_LAYOUT(layout, KERNEL, grid, stream, ...)                                                     \
+    do {                                                                                                       \
+        if ((layout) == GENS_LAYOUT_PACKED)                                                                    \
+            KERNEL<GENS_LAYOUT_PACKED><<<(grid), 256, 0, (hipStream_t)(stream)>>>(__VA_ARGS__);                \
+        else                                                                                                   \
+            KERNEL<GENS_LAYOUT_PLANAR><<<(grid), 256, 0, (hipStream_t)(stream)>>>(__VA_ARGS__);                \
+    } while (0)
+
+extern "C" int gens_lookup_volume_fwd(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                      int64_t n, float* out, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_lookup_volume_fwd", &vs, vols, dims, n_levels)) return e;
+    GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_fwd: bad layout %d", layout);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out)), GENS_EINVAL, "gens_lookup_volume_fwd: null pts/out");
+    if (n == 0) return 0;
+    DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out);
+    return gens_launch_status("gens_lookup_volume_fwd");
+}
+
+extern "C" int gens_lookup_volume_bwd(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                      const float* g_out, int64_t n, float* const* g_vols, float* g_pts, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_lookup_volume_bwd", &vs, vols, dims, n_levels)) return e;
+    GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_bwd: bad layout %d", layout);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out)), GENS_EINVAL, "gens_lookup_volume_bwd: null pts/g_out");
+    GENS_CHECK_ARG(g_vols || g_pts, GENS_EINVAL, "gens_lookup_volume_bwd: no output requested");
+    if (n == 0) return 0;
+    if (g_vols)
+        for (int l = 0; l < n_levels; ++l) vs.grad[l] = g_vols[l];
+    DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts);
+    return gens_launch_status("gens_lookup_volume_bwd");
+}
+
+extern "C" int gens_lookup_volume_bwd2(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                       const float* g_out, const float* gg_pts, const float* const* gg_vols, int64_t n,
+                                       float* gg_out, float* const* g_vols2, float* g_pts2, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_lookup_volume_bwd2", &vs, vols, dims, n_levels)) return e;
+    GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_bwd2: bad layout %d", layout);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out && gg_pts && gg_out && g_pts2)), GENS_EINVAL,
+                   "gens_lookup_volume_bwd2: null pointer");
+    if (n == 0) return 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (g_vols2) vs.grad[l] = g_vols2[l];
+        if (gg_vols) vs.aux[l] = gg_vols[l];
+    }
+    DISPATCH_LAYOUT(layout, lookup_bwd2_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, gg_pts, n,
+                    (float4*)gg_out, g_pts2);
+    return gens_launch_status("gens_lookup_volume_bwd2");
+}
+
+extern "C" int gens_lookup_mask_nearest(const float* const* masks, const int* dims, int n_levels, const float* pts, int64_t n,
+                                        uint8_t* valid, float* vals, void* stream) {
+    LevelSet ms;
+    if (int e = gens_fill_levels("gens_lookup_mask_nearest", &ms, masks, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || pts) && (valid || vals), GENS_EINVAL, "gens_lookup_mask_nearest: null pointer");
+    if (n == 0) return 0;
+    mask_nearest_k<<<gens_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(ms, pts, n, valid, vals);
+    return gens_launch_status("gens_lookup_mask_nearest");
+}
+
+extern "C" int gens_ray_points(const float* rays_o, const float* rays_d, const float* z, int64_t n_rays, int n_samples, int mid,
+                               float sample_dist, const float* const* masks, const int* dims, int n_levels, float* pts,
+                               uint8_t* valid, void* stream) {
+    LevelSet ms;
+    ms.n = 0;
+    if (valid)
+        if (int e = gens_fill_levels("gens_ray_points", &ms, masks, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n_rays >= 0 && n_samples > 0 && (n_rays == 0 || (rays_o && rays_d && z && pts)), GENS_EINVAL,
+                   "gens_ray_points: bad argument");
+    if (n_rays == 0) return 0;
+    int64_t total = n_rays * n_samples;
+    ray_points_k<<<gens_blocks(total, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, z, total, n_samples, mid, sample_dist,
+                                                                          ms, pts, valid);
+    return gens_launch_status("gens_ray_points");
+}

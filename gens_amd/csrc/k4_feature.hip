@@ -1,0 +1,189 @@
+// K4: lookup_feature + compute_angle (/root/reference/models/modules/projector.py:278-349): re-project N sample points
+// into the S source views at every pyramid level, bilinearly read features (+RGB at level 0), build the in-frustum
+// mask and the IBRNet ray-direction-difference feature -- in ONE launch (the reference issues, per level, an
+// inverse, two matmuls, a divide, a grid_sample, a permute, and a final cat).
+//
+// One thread per (point, source view); pyramid levels are a register loop, every tap is one 16-B texel load from
+// the NHWC-packed maps.  The (N, S, 3+4L) row a thread produces is first parked in LDS and then written by the whole
+// block as one contiguous, coalesced span (a row is 92 B for L=5 -- direct per-lane stores would touch a new
+// 128-B line each).
+//
+// Quirks kept: no epsilon in the perspective divide and the half-open pixel test (Q3); coordinates are normalised
+// with (W-1)/2 but READ with align_corners=False, i.e. pixel = ((g+1)*W-1)/2 (Q6).
+#include "common.h"
+
+struct MapSet {
+    const float4* data[GENS_MAX_LEVELS];
+    float* grad[GENS_MAX_LEVELS];
+    int h[GENS_MAX_LEVELS], w[GENS_MAX_LEVELS];
+    int n;
+};
+
+struct SrcProj {
+    float ix, iy;   // read position (align_corners=False un-normalisation)
+    bool inside;    // mask term of this level
+};
+__device__ __forceinline__ SrcProj project_src(const float* __restrict__ w2c, const float* __restrict__ k, float s, int h,
+                                               int w, float x, float y, float z) {
+    float cx = w2c[0] * x + w2c[1] * y + w2c[2] * z + w2c[3];
+    float cy = w2c[4] * x + w2c[5] * y + w2c[6] * z + w2c[7];
+    float cz = w2c[8] * x + w2c[9] * y + w2c[10] * z + w2c[11];
+    float u = (k[0] * s) * cx + (k[1] * s) * cy + (k[2] * s) * cz;
+    float v = (k[4] * s) * cx + (k[5] * s) * cy + (k[6] * s) * cz;
+    float d = k[8] * cx + k[9] * cy + k[10] * cz;
+    float px = u / d, py = v / d;
+    float nx = px / ((float)(w - 1) / 2.0f) - 1.0f, ny = py / ((float)(h - 1) / 2.0f) - 1.0f;
+    SrcProj p;
+    p.inside = (d > 0.0f) && (px >= 0.0f) && (px < (float)w) && (py >= 0.0f) && (py < (float)h);
+    p.ix = ((nx + 1.0f) * (float)w - 1.0f) / 2.0f;
+    p.iy = ((ny + 1.0f) * (float)h - 1.0f) / 2.0f;
+    return p;
+}
+
+#define K4_BLOCK 256
+#define K4_MAX_ROW (3 + 4 * GENS_MAX_LEVELS)
+
+__global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, const float4* __restrict__ imgs,
+                                                                 const float* __restrict__ w2c, const float* __restrict__ intr,
+                                                                 const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
+                                                                 int64_t n, float* __restrict__ out, float4* __restrict__ ray_diff,
+                                                                 uint8_t* __restrict__ vis) {
+    extern __shared__ float row_lds[];  // K4_BLOCK rows of `row` floats, row stride padded to an odd count
+    const int S = nv - 1;
+    const int row = 3 + 4 * fs.n;
+    const int stride = row | 1;
+    int64_t gid = (int64_t)blockIdx.x * K4_BLOCK + threadIdx.x;
+    int64_t total = n * S;
+    float* mine = row_lds + threadIdx.x * stride;
+    if (gid < total) {
+        int sv = (int)(gid % S) + 1;  // source view index in [1, nv)
+        int64_t i = gid / S;
+        float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        bool inside = true;
+        for (int l = 0; l < fs.n; ++l) {
+            int h = fs.h[l], w = fs.w[l];
+            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+            inside = inside && p.inside;
+            Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+            float4 f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+            mine[3 + 4 * l] = f.x;
+            mine[4 + 4 * l] = f.y;
+            mine[5 + 4 * l] = f.z;
+            mine[6 + 4 * l] = f.w;
+            if (l == 0) {
+                float4 c = sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+                mine[0] = c.x;
+                mine[1] = c.y;
+                mine[2] = c.z;
+            }
+        }
+        vis[gid] = inside ? 1 : 0;
+        // compute_angle (projector.py:278-291)
+        float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
+        float rn = sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f;
+        rx /= rn; ry /= rn; rz /= rn;
+        const float* cs = c2w + 16 * sv;
+        float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
+        float sn = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
+        sx /= sn; sy /= sn; sz /= sn;
+        float dx = rx - sx, dy = ry - sy, dz = rz - sz;
+        float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+        ray_diff[gid] = make_float4(dx / dn, dy / dn, dz / dn, rx * sx + ry * sy + rz * sz);
+    }
+    __syncthreads();
+    // cooperative, coalesced write of this block's rows
+    int64_t first = (int64_t)blockIdx.x * K4_BLOCK;
+    int rows_here = (int)min((int64_t)K4_BLOCK, total - first);
+    int span = rows_here * row;
+    float* dst = out + first * row;
+    for (int e = threadIdx.x; e < span; e += K4_BLOCK) dst[e] = row_lds[(e / row) * stride + (e % row)];
+}
+
+__global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __restrict__ g_imgs, const float* __restrict__ w2c,
+                                                            const float* __restrict__ intr, int nv, const float* __restrict__ pts,
+                                                            const float* __restrict__ g_out, int64_t n) {
+    const int S = nv - 1;
+    const int row = 3 + 4 * fs.n;
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * S) return;
+    int sv = (int)(gid % S) + 1;
+    int64_t i = gid / S;
+    float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    const float* g = g_out + gid * row;
+    for (int l = 0; l < fs.n; ++l) {
+        int h = fs.h[l], w = fs.w[l];
+        SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+        int64_t off = (((int64_t)sv * h + t.y0) * w + t.x0) * 4;
+        if (fs.grad[l]) {
+            float4 gf = make_float4(g[3 + 4 * l], g[4 + 4 * l], g[5 + 4 * l], g[6 + 4 * l]);
+            float* base = fs.grad[l] + off;
+            if (t.ok00) atomic_add4(base, gf, t.w00);
+            if (t.ok01) atomic_add4(base + 4, gf, t.w01);
+            if (t.ok10) atomic_add4(base + (int64_t)w * 4, gf, t.w10);
+            if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, gf, t.w11);
+        }
+        if (l == 0 && g_imgs) {
+            float4 gc = make_float4(g[0], g[1], g[2], 0.0f);
+            float* base = g_imgs + off;
+            if (t.ok00) atomic_add4(base, gc, t.w00);
+            if (t.ok01) atomic_add4(base + 4, gc, t.w01);
+            if (t.ok10) atomic_add4(base + (int64_t)w * 4, gc, t.w10);
+            if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, gc, t.w11);
+        }
+    }
+}
+
+static int fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels) {
+    GENS_CHECK_ARG(hw, GENS_EINVAL, "%s: null hw table", who);
+    GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "%s: n_levels=%d not in 1..%d", who, n_levels,
+                   GENS_MAX_LEVELS);
+    ms->n = n_levels;
+    for (int l = 0; l < GENS_MAX_LEVELS; ++l) {
+        ms->data[l] = nullptr;
+        ms->grad[l] = nullptr;
+        ms->h[l] = ms->w[l] = 2;
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        GENS_CHECK_ARG(hw[2 * l] > 1 && hw[2 * l + 1] > 1, GENS_EINVAL, "%s: level %d map smaller than 2x2", who, l);
+        if (feats) {
+            GENS_CHECK_ARG(feats[l], GENS_EINVAL, "%s: level %d is null", who, l);
+            ms->data[l] = (const float4*)feats[l];
+        }
+        ms->h[l] = hw[2 * l];
+        ms->w[l] = hw[2 * l + 1];
+    }
+    return 0;
+}
+
+extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c,
+                                       const float* intr, const float* c2w, int nv, const float* pts, int64_t n, float* out,
+                                       float* ray_diff, uint8_t* vis, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats, GENS_EINVAL, "gens_lookup_feature_fwd: null feature table");
+    if (int e = fill_maps("gens_lookup_feature_fwd", &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_lookup_feature_fwd: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_lookup_feature_fwd: null camera / image pointer");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out && ray_diff && vis)), GENS_EINVAL, "gens_lookup_feature_fwd: null pts / output");
+    if (n == 0) return 0;
+    int row = 3 + 4 * n_levels;
+    size_t lds = (size_t)K4_BLOCK * (row | 1) * sizeof(float);
+    lookup_feature_fwd_k<<<gens_blocks(n * (nv - 1), K4_BLOCK), K4_BLOCK, lds, (hipStream_t)stream>>>(
+        fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis);
+    return gens_launch_status("gens_lookup_feature_fwd");
+}
+
+extern "C" int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts,
+                                       const float* g_out, int64_t n, float* const* g_feats, float* g_imgs, void* stream) {
+    MapSet fs;
+    if (int e = fill_maps("gens_lookup_feature_bwd", &fs, nullptr, hw, n_levels)) return e;
+    GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_lookup_feature_bwd: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
+    GENS_CHECK_ARG(w2c && intr, GENS_EINVAL, "gens_lookup_feature_bwd: null camera pointer");
+    GENS_CHECK_ARG(g_feats || g_imgs, GENS_EINVAL, "gens_lookup_feature_bwd: no output requested");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out)), GENS_EINVAL, "gens_lookup_feature_bwd: null pts / g_out");
+    if (n == 0) return 0;
+    if (g_feats)
+        for (int l = 0; l < n_levels; ++l) fs.grad[l] = g_feats[l];
+    lookup_feature_bwd_k<<<gens_blocks(n * (nv - 1), 256), 256, 0, (hipStream_t)stream>>>(fs, g_imgs, w2c, intr, nv, pts, g_out, n);
+    return gens_launch_status("gens_lookup_feature_bwd");
+}

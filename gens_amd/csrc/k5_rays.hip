@@ -1,0 +1,512 @@
+// K5-K8: the per-ray kernels of the NeuS-style renderer, one 64-lane wavefront per ray.
+//
+//   K5 up_sample        implicit_surface.py:60-109      K6 sample_pdf(det=True)   implicit_surface.py:14-44
+//   K7 cat_z_vals       implicit_surface.py:111-133     K8 render_core composite  implicit_surface.py:160-168, 202-303
+//
+// A ray never has more than 128 samples (64 coarse + 4 x 16), so a wavefront keeps the whole ray in registers: lane l
+// owns samples l and l+64.  The along-ray transmittance (torch.cumprod) and the CDF (torch.cumsum) are wavefront
+// shuffle scans, searchsorted is a binary search over a 128-entry LDS row, torch.sort of [z | z_new] is a rank
+// computation (both inputs are already sorted), and every reduction over samples (colour, normal, depth, eikonal,
+// smoothness, visibility count, first sign change) is a wavefront reduction -- the reference spends ~40 (K5), ~10
+// (K6/K7) and ~120 (K8) elementwise launches on (B,128) tensors for the same work.
+#include "common.h"
+
+#define RAYS_PER_BLOCK 4
+#define MAX_SAMPLES 128
+
+// value of a two-slot per-lane array at sample index idx (wave-uniform or per-lane idx)
+__device__ __forceinline__ float pick2(float v0, float v1, int idx) {
+    float a = __shfl(v0, idx & 63, 64), b = __shfl(v1, idx & 63, 64);
+    return idx < 64 ? a : b;
+}
+// element j+1 of the two-slot array, seen from the owner of element j
+__device__ __forceinline__ void next2(float v0, float v1, int lane, float& n0, float& n1) {
+    n0 = __shfl_down(v0, 1, 64);
+    float first1 = __shfl(v1, 0, 64);
+    if (lane == 63) n0 = first1;
+    n1 = __shfl_down(v1, 1, 64);
+}
+// element j-1 (zero for j = 0)
+__device__ __forceinline__ void prev2(float v0, float v1, int lane, float& p0, float& p1) {
+    p0 = __shfl_up(v0, 1, 64);
+    if (lane == 0) p0 = 0.0f;
+    p1 = __shfl_up(v1, 1, 64);
+    float last0 = __shfl(v0, 63, 64);
+    if (lane == 0) p1 = last0;
+}
+// exclusive prefix product over the 128 slots
+__device__ __forceinline__ void excl_cumprod2(float f0, float f1, int lane, float& t0, float& t1) {
+    float p0 = wave_scan_mul(f0, lane);
+    float p1 = wave_scan_mul(f1, lane);
+    float tot0 = __shfl(p0, 63, 64);
+    t0 = __shfl_up(p0, 1, 64);
+    if (lane == 0) t0 = 1.0f;
+    t1 = __shfl_up(p1, 1, 64);
+    if (lane == 0) t1 = 1.0f;
+    t1 *= tot0;
+}
+// number of entries <= u in a sorted LDS row (torch.searchsorted(..., right=True))
+__device__ __forceinline__ int upper_bound_lds(const float* row, int n, float u) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (row[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5 + K6
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                  const float* __restrict__ z, const float* __restrict__ sdf,
+                                                                  int64_t n_rays, int n, int n_new, float inv_s, LevelSet ms,
+                                                                  float* __restrict__ z_new, float* __restrict__ pts_new,
+                                                                  uint8_t* __restrict__ valid_new) {
+    __shared__ float s_cdf[RAYS_PER_BLOCK][MAX_SAMPLES];
+    __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    const bool active = r < n_rays;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    if (active) {
+        ox = rays_o[3 * r]; oy = rays_o[3 * r + 1]; oz = rays_o[3 * r + 2];
+        dx = rays_d[3 * r]; dy = rays_d[3 * r + 1]; dz = rays_d[3 * r + 2];
+    }
+    float zj[2], sj[2], rad[2], vm[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        bool have = active && j < n;
+        zj[s] = have ? z[r * n + j] : 0.0f;
+        sj[s] = have ? sdf[r * n + j] : 0.0f;
+        float px = ox + dx * zj[s], py = oy + dy * zj[s], pz = oz + dz * zj[s];
+        rad[s] = sqrtf(px * px + py * py + pz * pz);
+        vm[s] = (have && any_mask(ms, px, py, pz)) ? 1.0f : 0.0f;
+    }
+    float zn[2], sn[2], rn[2], vn[2];
+    next2(zj[0], zj[1], lane, zn[0], zn[1]);
+    next2(sj[0], sj[1], lane, sn[0], sn[1]);
+    next2(rad[0], rad[1], lane, rn[0], rn[1]);
+    next2(vm[0], vm[1], lane, vn[0], vn[1]);
+    float cosv[2], dzv[2], midv[2], ins[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bool seg = (lane + 64 * s) < n - 1;
+        dzv[s] = zn[s] - zj[s];
+        midv[s] = (sj[s] + sn[s]) * 0.5f;
+        cosv[s] = seg ? (sn[s] - sj[s]) / (dzv[s] + 1e-5f) : 0.0f;
+        ins[s] = (seg && ((rad[s] < 1.0f) || (rn[s] < 1.0f)) && (vm[s] * vn[s] > 0.0f)) ? 1.0f : 0.0f;
+    }
+    float pc[2];
+    prev2(cosv[0], cosv[1], lane, pc[0], pc[1]);
+    float alpha[2], fac[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bool seg = (lane + 64 * s) < n - 1;
+        float c = fminf(pc[s], cosv[s]);
+        c = fminf(fmaxf(c, -1e3f), 0.0f) * ins[s];
+        float e_prev = midv[s] - c * dzv[s] * 0.5f;
+        float e_next = midv[s] + c * dzv[s] * 0.5f;
+        float c_prev = sigmoidf_(e_prev * inv_s), c_next = sigmoidf_(e_next * inv_s);
+        alpha[s] = seg ? (c_prev - c_next + 1e-5f) / (c_prev + 1e-5f) : 0.0f;
+        fac[s] = seg ? 1.0f - alpha[s] + 1e-7f : 1.0f;
+    }
+    float tr[2];
+    excl_cumprod2(fac[0], fac[1], lane, tr[0], tr[1]);
+    // sample_pdf: weights + 1e-5, normalise, cumulative sum
+    float wp[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) wp[s] = ((lane + 64 * s) < n - 1) ? alpha[s] * tr[s] + 1e-5f : 0.0f;
+    float total = wave_sum(wp[0] + wp[1]);
+    float c0 = wave_scan_add(wp[0] / total, lane);
+    float c1 = wave_scan_add(wp[1] / total, lane) + __shfl(c0, 63, 64);
+    if (active) {
+        if (lane == 0) s_cdf[wave][0] = 0.0f;
+        if (lane < n - 1) s_cdf[wave][lane + 1] = c0;
+        if (lane + 64 < n - 1) s_cdf[wave][lane + 65] = c1;
+        if (lane < n) s_z[wave][lane] = zj[0];
+        if (lane + 64 < n) s_z[wave][lane + 64] = zj[1];
+    }
+    __syncthreads();
+    if (active && lane < n_new) {
+        float u = linspace_at(0.5f / (float)n_new, 1.0f - 0.5f / (float)n_new, n_new, lane);
+        int cnt = upper_bound_lds(s_cdf[wave], n, u);
+        int lo = max(cnt - 1, 0), hi = min(cnt, n - 1);
+        float c_lo = s_cdf[wave][lo], c_hi = s_cdf[wave][hi];
+        float b_lo = s_z[wave][lo], b_hi = s_z[wave][hi];
+        float den = c_hi - c_lo;
+        if (den < 1e-5f) den = 1.0f;
+        float t = (u - c_lo) / den;
+        float zs = b_lo + t * (b_hi - b_lo);
+        int64_t o = r * n_new + lane;
+        z_new[o] = zs;
+        float px = ox + dx * zs, py = oy + dy * zs, pz = oz + dz * zs;
+        if (pts_new) {
+            pts_new[3 * o] = px;
+            pts_new[3 * o + 1] = py;
+            pts_new[3 * o + 2] = pz;
+        }
+        if (valid_new) valid_new[o] = any_mask(ms, px, py, pz) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: sorted merge by rank (ties keep the older sample first)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_k(const float* __restrict__ z, const float* __restrict__ sdf,
+                                                               const float* __restrict__ z_new, const float* __restrict__ sdf_new,
+                                                               int64_t n_rays, int n, int n_new, float* __restrict__ z_out,
+                                                               float* __restrict__ sdf_out) {
+    __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    const bool active = r < n_rays;
+    const int m = n + n_new;
+    float zj[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        zj[s] = (active && j < n) ? z[r * n + j] : 0.0f;
+        if (active && j < n) s_z[wave][j] = zj[s];
+    }
+    float zk = (active && lane < n_new) ? z_new[r * n_new + lane] : 0.0f;
+    __syncthreads();
+    if (!active) return;
+    int less[2] = {0, 0}, before = 0;
+    for (int k = 0; k < n_new; ++k) {
+        float v = __shfl(zk, k, 64);
+        less[0] += (v < zj[0]) ? 1 : 0;
+        less[1] += (v < zj[1]) ? 1 : 0;
+        before += (v < zk || (v == zk && k < lane)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        if (j < n) {
+            int64_t o = r * m + j + less[s];
+            z_out[o] = zj[s];
+            if (sdf_out) sdf_out[o] = sdf[r * n + j];
+        }
+    }
+    if (lane < n_new) {
+        int64_t o = r * m + upper_bound_lds(s_z[wave], n, zk) + before;
+        z_out[o] = zk;
+        if (sdf_out) sdf_out[o] = sdf_new[r * n_new + lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8 forward
+// ---------------------------------------------------------------------------------------------------------------
+struct RaySample {  // everything the forward and backward share, per slot
+    float z, dist, mid, vm, inside, relax, sdf, gx, gy, gz, gn, tc, ic, ep, en, cp, cn, q, alpha, fac;
+};
+
+__device__ __forceinline__ void ray_setup(const gens_composite_in& in, int64_t r, int lane, bool active, float inv_s, float d[3],
+                                          float o[3], RaySample smp[2]) {
+    const int n = in.n;
+    if (active) {
+        for (int a = 0; a < 3; ++a) { o[a] = in.rays_o[3 * r + a]; d[a] = in.rays_d[3 * r + a]; }
+    } else {
+        for (int a = 0; a < 3; ++a) { o[a] = 0.0f; d[a] = 0.0f; }
+    }
+    float zj[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        zj[s] = (active && j < n) ? in.z[r * n + j] : 0.0f;
+    }
+    float zn[2];
+    next2(zj[0], zj[1], lane, zn[0], zn[1]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        bool have = active && j < n;
+        RaySample& p = smp[s];
+        p.z = zj[s];
+        p.dist = (j + 1 < n) ? zn[s] - zj[s] : in.sample_dist;                       // (Q10)
+        p.mid = p.z + p.dist * 0.5f;
+        float px = o[0] + d[0] * p.mid, py = o[1] + d[1] * p.mid, pz = o[2] + d[2] * p.mid;
+        float norm = sqrtf(px * px + py * py + pz * pz);
+        int64_t e = r * n + j;
+        p.vm = (have && in.voxel_mask[e]) ? 1.0f : 0.0f;
+        p.inside = (norm < 1.0f ? 1.0f : 0.0f) * p.vm;
+        p.relax = (norm < 1.2f ? 1.0f : 0.0f) * p.vm;
+        p.sdf = have ? in.sdf[e] : 0.0f;
+        p.gx = have ? in.grad[3 * e] : 0.0f;
+        p.gy = have ? in.grad[3 * e + 1] : 0.0f;
+        p.gz = have ? in.grad[3 * e + 2] : 0.0f;
+        p.gn = sqrtf(p.gx * p.gx + p.gy * p.gy + p.gz * p.gz);
+        p.tc = d[0] * p.gx + d[1] * p.gy + d[2] * p.gz;
+        float a = in.cos_anneal;
+        p.ic = -(fmaxf(-p.tc * 0.5f + 0.5f, 0.0f) * (1.0f - a) + fmaxf(-p.tc, 0.0f) * a);
+        p.ic *= p.vm;
+        float icc = fminf(fmaxf(p.ic, -10.0f), 10.0f);
+        p.en = p.sdf + icc * p.dist * 0.5f;
+        p.ep = p.sdf - icc * p.dist * 0.5f;
+        p.cp = sigmoidf_(p.ep * inv_s);
+        p.cn = sigmoidf_(p.en * inv_s);
+        p.q = (p.cp - p.cn + 1e-5f) / (p.cp + 1e-5f);
+        p.alpha = have ? fminf(fmaxf(p.q, 0.0f), 1.0f) * p.vm : 0.0f;                // (Q9)
+        p.fac = have ? 1.0f - p.alpha + 1e-7f : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_fwd_k(gens_composite_in in, gens_composite_out out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    if (r >= in.n_rays) return;  // no block-level sync in this kernel: whole waves may leave
+    const int n = in.n;
+    const float inv_s = in.inv_s[0];
+    float d[3], o[3];
+    RaySample smp[2];
+    ray_setup(in, r, lane, true, inv_s, d, o, smp);
+    float tr[2];
+    excl_cumprod2(smp[0].fac, smp[1].fac, lane, tr[0], tr[1]);
+    float acc[16];
+    for (int a = 0; a < 16; ++a) acc[a] = 0.0f;
+    float wmax = 0.0f, wv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        const RaySample& p = smp[s];
+        float w = p.alpha * tr[s];
+        wv[s] = w;
+        if (j < n) {
+            int64_t e = r * n + j;
+            out.weights[e] = w;
+            out.inside[e] = p.inside;
+            acc[0] += in.color[3 * e] * w;
+            acc[1] += in.color[3 * e + 1] * w;
+            acc[2] += in.color[3 * e + 2] * w;
+            acc[3] += p.gx * w;
+            acc[4] += p.gy * w;
+            acc[5] += p.gz * w;
+            acc[6] += p.mid * w;
+            acc[7] += w;
+            acc[8] += p.relax * (p.gn - 1.0f) * (p.gn - 1.0f);
+            acc[9] += p.relax;
+            if (in.smooth) {
+                float k = w * p.inside;
+                acc[10] += in.smooth[3 * e] * k;
+                acc[11] += in.smooth[3 * e + 1] * k;
+                acc[12] += in.smooth[3 * e + 2] * k;
+            }
+            if (in.src_vis) {
+                int c = 0;
+                for (int v = 0; v < in.n_src; ++v) c += in.src_vis[e * in.n_src + v] ? 1 : 0;
+                acc[13] += (c > 1) ? 1.0f : 0.0f;                                       // (Q12)
+            }
+            wmax = fmaxf(wmax, w);
+        }
+    }
+    for (int a = 0; a < 14; ++a) acc[a] = wave_sum(acc[a]);
+    wmax = wave_max(wmax);
+    // first masked sign change (implicit_surface.py:262-275): argmax(sign * reversed_index * pair_ok)
+    float sn[2], vn[2];
+    next2(smp[0].sdf, smp[1].sdf, lane, sn[0], sn[1]);
+    next2(smp[0].vm, smp[1].vm, lane, vn[0], vn[1]);
+    bool f0 = (lane < n - 1) && (smp[0].sdf * sn[0] <= 0.0f) && (smp[0].vm * vn[0] > 0.0f);
+    bool f1 = (lane + 64 < n - 1) && (smp[1].sdf * sn[1] <= 0.0f) && (smp[1].vm * vn[1] > 0.0f);
+    unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+    bool any = (b0 | b1) != 0ull;
+    int i0 = b0 ? __ffsll((long long)b0) - 1 : (b1 ? 63 + __ffsll((long long)b1) : 0);
+    int i1 = i0 + 1;
+    float in0 = pick2(smp[0].inside, smp[1].inside, i0), in1 = pick2(smp[0].inside, smp[1].inside, i1);
+    float g0x = pick2(smp[0].gx, smp[1].gx, i0), g0y = pick2(smp[0].gy, smp[1].gy, i0), g0z = pick2(smp[0].gz, smp[1].gz, i0);
+    float g1x = pick2(smp[0].gx, smp[1].gx, i1), g1y = pick2(smp[0].gy, smp[1].gy, i1), g1z = pick2(smp[0].gz, smp[1].gz, i1);
+    float n0 = pick2(smp[0].gn, smp[1].gn, i0), n1 = pick2(smp[0].gn, smp[1].gn, i1);
+    float s0 = pick2(smp[0].sdf, smp[1].sdf, i0), s1 = pick2(smp[0].sdf, smp[1].sdf, i1);
+    float z0 = pick2(smp[0].mid, smp[1].mid, i0), z1 = pick2(smp[0].mid, smp[1].mid, i1);
+    if (lane == 0) {
+        const float* R = in.rot;
+        float camz = R[6] * d[0] + R[7] * d[1] + R[8] * d[2];
+        out.color[3 * r] = acc[0];
+        out.color[3 * r + 1] = acc[1];
+        out.color[3 * r + 2] = acc[2];
+        out.normal[3 * r] = R[0] * acc[3] + R[1] * acc[4] + R[2] * acc[5];
+        out.normal[3 * r + 1] = R[3] * acc[3] + R[4] * acc[4] + R[5] * acc[5];
+        out.normal[3 * r + 2] = R[6] * acc[3] + R[7] * acc[4] + R[8] * acc[5];
+        out.depth[r] = acc[6] * camz;                                                   // (Q11)
+        out.wsum[r] = acc[7];
+        out.wmax[r] = wmax;
+        out.eik_num[r] = acc[8];
+        out.eik_den[r] = acc[9];
+        out.smooth_vec[3 * r] = acc[10];
+        out.smooth_vec[3 * r + 1] = acc[11];
+        out.smooth_vec[3 * r + 2] = acc[12];
+        out.valid[r] = acc[13] > 8.0f ? 1 : 0;
+        float mid_in = (0.5f * (in0 + in1) > 0.5f) ? 1.0f : 0.0f;
+        mid_in *= any ? 1.0f : 0.0f;
+        float cosd = (g0x * g1x + g0y * g1y + g0z * g1z) / (n0 * n1 + 1e-8f);
+        mid_in *= (cosd > 0.5f) ? 1.0f : 0.0f;
+        float zc = (s0 * z1 - s1 * z0) / (s0 - s1 + 1e-10f);
+        out.mid_in[r] = mid_in;
+        out.sdf_depth[r] = zc * camz * mid_in;
+        if (zc < 0.0f) zc = 0.0f;
+        if (zc > in.z_max[0]) zc = 0.0f;
+        out.z_cross[r] = zc;
+        out.cross_idx[r] = i0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8 backward
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_composite_in in, gens_composite_grad g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    if (r >= in.n_rays) return;
+    const int n = in.n;
+    const float inv_s = in.inv_s[0];
+    float d[3], o[3];
+    RaySample smp[2];
+    ray_setup(in, r, lane, true, inv_s, d, o, smp);
+    float tr[2];
+    excl_cumprod2(smp[0].fac, smp[1].fac, lane, tr[0], tr[1]);
+    const float* R = in.rot;
+    float camz = R[6] * d[0] + R[7] * d[1] + R[8] * d[2];
+    float gc[3] = {0, 0, 0}, gnr[3] = {0, 0, 0}, gsv[3] = {0, 0, 0};
+    if (g.g_color) for (int a = 0; a < 3; ++a) gc[a] = g.g_color[3 * r + a];
+    if (g.g_normal) {  // normal = R * nsum  ->  d/dnsum = R^T g
+        float t0 = g.g_normal[3 * r], t1 = g.g_normal[3 * r + 1], t2 = g.g_normal[3 * r + 2];
+        gnr[0] = R[0] * t0 + R[3] * t1 + R[6] * t2;
+        gnr[1] = R[1] * t0 + R[4] * t1 + R[7] * t2;
+        gnr[2] = R[2] * t0 + R[5] * t1 + R[8] * t2;
+    }
+    if (g.g_smooth_vec) for (int a = 0; a < 3; ++a) gsv[a] = g.g_smooth_vec[3 * r + a];
+    float gd = g.g_depth ? g.g_depth[r] * camz : 0.0f;
+    float gws = g.g_wsum ? g.g_wsum[r] : 0.0f;
+    float geik = g.g_eik_num ? g.g_eik_num[r] : 0.0f;
+
+    float gw[2], w[2], gww[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        const RaySample& p = smp[s];
+        w[s] = p.alpha * tr[s];
+        gw[s] = 0.0f;
+        if (j < n) {
+            int64_t e = r * n + j;
+            gw[s] = gc[0] * in.color[3 * e] + gc[1] * in.color[3 * e + 1] + gc[2] * in.color[3 * e + 2] + gnr[0] * p.gx +
+                    gnr[1] * p.gy + gnr[2] * p.gz + gd * p.mid + gws + (g.g_weights ? g.g_weights[e] : 0.0f);
+        }
+        gww[s] = gw[s] * w[s];
+    }
+    // S_j = sum_{k>j} gw_k w_k
+    float inc0 = wave_scan_add(gww[0], lane), inc1 = wave_scan_add(gww[1], lane);
+    float tot0 = __shfl(inc0, 63, 64), tot1 = __shfl(inc1, 63, 64);
+    float suf[2] = {tot0 + tot1 - inc0, tot1 - inc1};
+    float gs_acc = 0.0f;
+    const int i0 = g.cross_idx ? g.cross_idx[r] : 0;
+    float gz0 = 0.0f, gz1 = 0.0f;
+    if (g.g_z_cross) {
+        float s0 = pick2(smp[0].sdf, smp[1].sdf, i0), s1 = pick2(smp[0].sdf, smp[1].sdf, i0 + 1);
+        float z0 = pick2(smp[0].mid, smp[1].mid, i0), z1 = pick2(smp[0].mid, smp[1].mid, i0 + 1);
+        float den = s0 - s1 + 1e-10f, num = s0 * z1 - s1 * z0;
+        float zc = num / den;
+        float up = (zc < 0.0f || zc > in.z_max[0]) ? 0.0f : g.g_z_cross[r];
+        gz0 = up * (z1 * den - num) / (den * den);
+        gz1 = up * (-z0 * den + num) / (den * den);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        if (j >= n) continue;
+        const RaySample& p = smp[s];
+        int64_t e = r * n + j;
+        float ga = gw[s] * tr[s] - suf[s] / p.fac;
+        float gq = (p.q >= 0.0f && p.q <= 1.0f) ? ga * p.vm : 0.0f;
+        float gcp = gq * p.cn / ((p.cp + 1e-5f) * (p.cp + 1e-5f));
+        float gcn = -gq / (p.cp + 1e-5f);
+        float dcp = p.cp * (1.0f - p.cp), dcn = p.cn * (1.0f - p.cn);
+        float gep = gcp * inv_s * dcp, gen = gcn * inv_s * dcn;
+        gs_acc += gcp * p.ep * dcp + gcn * p.en * dcn;
+        float gsdf = gep + gen;
+        float gicc = (gen - gep) * p.dist * 0.5f;
+        float gic = (p.ic >= -10.0f && p.ic <= 10.0f) ? gicc * p.vm : 0.0f;
+        float a = in.cos_anneal;
+        float dic = ((-p.tc * 0.5f + 0.5f) > 0.0f ? 0.5f * (1.0f - a) : 0.0f) + ((-p.tc) > 0.0f ? a : 0.0f);
+        float gtc = gic * dic;
+        float ek = (p.gn > 0.0f) ? geik * p.relax * 2.0f * (p.gn - 1.0f) / p.gn : 0.0f;
+        if (j == i0) gsdf += gz0;
+        if (j == i0 + 1) gsdf += gz1;
+        g.g_sdf[e] = gsdf;
+        g.g_grad[3 * e] = gtc * d[0] + w[s] * gnr[0] + ek * p.gx;
+        g.g_grad[3 * e + 1] = gtc * d[1] + w[s] * gnr[1] + ek * p.gy;
+        g.g_grad[3 * e + 2] = gtc * d[2] + w[s] * gnr[2] + ek * p.gz;
+        g.g_col[3 * e] = w[s] * gc[0];
+        g.g_col[3 * e + 1] = w[s] * gc[1];
+        g.g_col[3 * e + 2] = w[s] * gc[2];
+        if (g.g_smooth) {
+            float k = w[s] * p.inside;
+            g.g_smooth[3 * e] = gsv[0] * k;
+            g.g_smooth[3 * e + 1] = gsv[1] * k;
+            g.g_smooth[3 * e + 2] = gsv[2] * k;
+        }
+    }
+    gs_acc = wave_sum(gs_acc);
+    if (lane == 0 && g.g_inv_s) g.g_inv_s[r] = gs_acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
+
+extern "C" int gens_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t n_rays, int n,
+                             int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, float* z_new,
+                             float* pts_new, uint8_t* valid_new, void* stream) {
+    LevelSet ms;
+    if (int e = gens_fill_levels("gens_upsample", &ms, masks, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n >= 2 && n <= MAX_SAMPLES && n_new >= 1 && n_new <= 64, GENS_ELIMIT, "gens_upsample: n=%d (2..128) n_new=%d (1..64)", n, n_new);
+    GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (rays_o && rays_d && z && sdf && z_new)), GENS_EINVAL, "gens_upsample: null pointer");
+    if (n_rays == 0) return 0;
+    upsample_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, z, sdf, n_rays, n, n_new, inv_s, ms, z_new, pts_new, valid_new);
+    return gens_launch_status("gens_upsample");
+}
+
+extern "C" int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, int64_t n_rays, int n,
+                                  int n_new, float* z_out, float* sdf_out, void* stream) {
+    GENS_CHECK_ARG(n >= 1 && n_new >= 1 && n_new <= 64 && n + n_new <= MAX_SAMPLES, GENS_ELIMIT,
+                   "gens_merge_samples: n=%d n_new=%d (n_new <= 64, n+n_new <= 128)", n, n_new);
+    GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (z && z_new && z_out)), GENS_EINVAL, "gens_merge_samples: null pointer");
+    GENS_CHECK_ARG(!sdf_out || (sdf && sdf_new), GENS_EINVAL, "gens_merge_samples: sdf_out needs sdf and sdf_new");
+    if (n_rays == 0) return 0;
+    merge_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(z, sdf, z_new, sdf_new, n_rays, n, n_new,
+                                                                                              z_out, sdf_out);
+    return gens_launch_status("gens_merge_samples");
+}
+
+static int check_composite_in(const char* who, const gens_composite_in* in) {
+    GENS_CHECK_ARG(in, GENS_EINVAL, "%s: null input block", who);
+    GENS_CHECK_ARG(in->n >= 2 && in->n <= MAX_SAMPLES, GENS_ELIMIT, "%s: n=%d not in 2..128", who, in->n);
+    GENS_CHECK_ARG(in->n_rays >= 0, GENS_EINVAL, "%s: negative ray count", who);
+    GENS_CHECK_ARG(in->n_rays == 0 || (in->rays_o && in->rays_d && in->z && in->sdf && in->grad && in->color && in->voxel_mask &&
+                                       in->inv_s && in->z_max),
+                   GENS_EINVAL, "%s: null input pointer", who);
+    GENS_CHECK_ARG(!in->src_vis || (in->n_src >= 1 && in->n_src < GENS_MAX_VIEWS), GENS_ELIMIT, "%s: n_src=%d", who, in->n_src);
+    return 0;
+}
+
+extern "C" int gens_composite_fwd(const gens_composite_in* in, const gens_composite_out* out, void* stream) {
+    if (int e = check_composite_in("gens_composite_fwd", in)) return e;
+    GENS_CHECK_ARG(out && out->color && out->normal && out->depth && out->wsum && out->wmax && out->mid_in && out->sdf_depth &&
+                       out->z_cross && out->eik_num && out->eik_den && out->smooth_vec && out->valid && out->cross_idx &&
+                       out->weights && out->inside,
+                   GENS_EINVAL, "gens_composite_fwd: null output pointer");
+    if (in->n_rays == 0) return 0;
+    composite_fwd_k<<<gens_blocks(in->n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(*in, *out);
+    return gens_launch_status("gens_composite_fwd");
+}
+
+extern "C" int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g, void* stream) {
+    if (int e = check_composite_in("gens_composite_bwd", in)) return e;
+    GENS_CHECK_ARG(g && g->g_sdf && g->g_grad && g->g_col, GENS_EINVAL, "gens_composite_bwd: null gradient output");
+    GENS_CHECK_ARG(!g->g_z_cross || g->cross_idx, GENS_EINVAL, "gens_composite_bwd: g_z_cross needs cross_idx");
+    if (in->n_rays == 0) return 0;
+    composite_bwd_k<<<gens_blocks(in->n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(*in, *g);
+    return gens_launch_status("gens_composite_bwd");
+}

@@ -1,0 +1,223 @@
+// K9 (patch reads of surface_patch_warp), K10 (total-variation regulariser), K11 (SDF lattice), and the error slot.
+//   K9  projector.py:406-416 (+ the F.interpolate of implicit_surface.py:316-325)
+//   K10 implicit_surface.py:135-150        K11 implicit_surface.py:407-418
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// error slot
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+void gens_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* gens_last_error(void) { return g_err; }
+extern "C" int gens_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K9: bilinear read of a texel image at pixel coordinates (align_corners=True after the reference's own
+// normalisation cancels), forward and d/d(xy).  One thread per (point, texel) forward, per point backward.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_fwd_k(const float4* __restrict__ img, int h, int w, int c, int q4,
+                                                   const float* __restrict__ xy, int64_t p, float* __restrict__ out) {
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= p * q4) return;
+    int q = (int)(gid % q4);
+    int64_t i = gid / q4;
+    Taps2 t = bilinear_taps(xy[2 * i], xy[2 * i + 1], h, w);
+    float4 v = sample_texel(img, h, w, q4, q, t);
+    float* o = out + i * c + 4 * q;
+    o[0] = v.x;
+    if (4 * q + 1 < c) o[1] = v.y;
+    if (4 * q + 2 < c) o[2] = v.z;
+    if (4 * q + 3 < c) o[3] = v.w;
+}
+
+__device__ __forceinline__ float dot_c(float4 v, const float* g, int c, int q) {
+    float s = v.x * g[0];
+    if (4 * q + 1 < c) s += v.y * g[1];
+    if (4 * q + 2 < c) s += v.z * g[2];
+    if (4 * q + 3 < c) s += v.w * g[3];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void patch_bwd_k(const float4* __restrict__ img, int h, int w, int c, int q4,
+                                                   const float* __restrict__ xy, const float* __restrict__ g_out, int64_t p,
+                                                   float* __restrict__ g_xy) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p) return;
+    float ix = xy[2 * i], iy = xy[2 * i + 1];
+    Taps2 t = bilinear_taps(ix, iy, h, w);
+    bool fin = isfinite(ix) && isfinite(iy);
+    float fx = (float)t.x0, fy = (float)t.y0;
+    float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    float gx = 0.0f, gy = 0.0f;
+    if (fin) {
+        int64_t base = ((int64_t)t.y0 * w + t.x0) * q4;
+        for (int q = 0; q < q4; ++q) {
+            const float* g = g_out + i * c + 4 * q;
+            float d00 = t.ok00 ? dot_c(img[base + q], g, c, q) : 0.0f;
+            float d01 = t.ok01 ? dot_c(img[base + q4 + q], g, c, q) : 0.0f;
+            float d10 = t.ok10 ? dot_c(img[base + (int64_t)w * q4 + q], g, c, q) : 0.0f;
+            float d11 = t.ok11 ? dot_c(img[base + (int64_t)w * q4 + q4 + q], g, c, q) : 0.0f;
+            gx += (d01 - d00) * wy0 + (d11 - d10) * wy1;
+            gy += (d10 - d00) * wx0 + (d11 - d01) * wx1;
+        }
+    }
+    g_xy[2 * i] = gx;
+    g_xy[2 * i + 1] = gy;
+}
+
+// F.interpolate(mode="bilinear", align_corners=False) of an NCHW map, written into a channel slice of a texel tensor
+__global__ __launch_bounds__(256) void upsample2d_into_k(const float* __restrict__ src, int c, int hs, int ws, float* __restrict__ dst,
+                                                         int h, int w, int cpad, int c_off, int64_t total) {
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    int ch = (int)(gid % c);
+    int x = (int)((gid / c) % w);
+    int y = (int)((gid / ((int64_t)c * w)) % h);
+    int64_t img = gid / ((int64_t)c * w * h);
+    float sy = fmaxf(((float)y + 0.5f) * ((float)hs / (float)h) - 0.5f, 0.0f);
+    float sx = fmaxf(((float)x + 0.5f) * ((float)ws / (float)w) - 0.5f, 0.0f);
+    int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
+    int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+    float ty = sy - (float)y0, tx = sx - (float)x0;
+    const float* s = src + (img * c + ch) * (int64_t)hs * ws;
+    float top = s[(int64_t)y0 * ws + x0] * (1.0f - tx) + s[(int64_t)y0 * ws + x1] * tx;
+    float bot = s[(int64_t)y1 * ws + x0] * (1.0f - tx) + s[(int64_t)y1 * ws + x1] * tx;
+    dst[((img * h + y) * (int64_t)w + x) * cpad + c_off + ch] = top * (1.0f - ty) + bot * ty;
+}
+
+extern "C" int gens_patch_sample_fwd(const float* image, int h, int w, int c, const float* xy, int64_t p, float* out, void* stream) {
+    GENS_CHECK_ARG(image && h > 1 && w > 1 && c > 0, GENS_EINVAL, "gens_patch_sample_fwd: bad image");
+    GENS_CHECK_ARG(p >= 0 && (p == 0 || (xy && out)), GENS_EINVAL, "gens_patch_sample_fwd: null xy/out");
+    if (p == 0) return 0;
+    int q4 = (c + 3) / 4;
+    patch_fwd_k<<<gens_blocks(p * q4, 256), 256, 0, (hipStream_t)stream>>>((const float4*)image, h, w, c, q4, xy, p, out);
+    return gens_launch_status("gens_patch_sample_fwd");
+}
+
+extern "C" int gens_patch_sample_bwd(const float* image, int h, int w, int c, const float* xy, const float* g_out, int64_t p,
+                                     float* g_xy, void* stream) {
+    GENS_CHECK_ARG(image && h > 1 && w > 1 && c > 0, GENS_EINVAL, "gens_patch_sample_bwd: bad image");
+    GENS_CHECK_ARG(p >= 0 && (p == 0 || (xy && g_out && g_xy)), GENS_EINVAL, "gens_patch_sample_bwd: null pointer");
+    if (p == 0) return 0;
+    patch_bwd_k<<<gens_blocks(p, 256), 256, 0, (hipStream_t)stream>>>((const float4*)image, h, w, c, (c + 3) / 4, xy, g_out, p, g_xy);
+    return gens_launch_status("gens_patch_sample_bwd");
+}
+
+extern "C" int gens_upsample2d_into(const float* src, int n, int c, int hs, int ws, float* dst, int h, int w, int c_pad_dst, int c_off,
+                                    void* stream) {
+    GENS_CHECK_ARG(src && dst && n > 0 && c > 0 && hs > 0 && ws > 0 && h > 0 && w > 0, GENS_EINVAL, "gens_upsample2d_into: bad argument");
+    GENS_CHECK_ARG(c_off >= 0 && c_off + c <= c_pad_dst, GENS_EINVAL, "gens_upsample2d_into: channel slice [%d,%d) outside %d", c_off,
+                   c_off + c, c_pad_dst);
+    int64_t total = (int64_t)n * h * w * c;
+    upsample2d_into_k<<<gens_blocks(total, 256), 256, 0, (hipStream_t)stream>>>(src, c, hs, ws, dst, h, w, c_pad_dst, c_off, total);
+    return gens_launch_status("gens_upsample2d_into");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K10: TV.  One thread per voxel (z fastest => coalesced), forward differences along the three axes for the four
+// channels, block reduction to one float4 per block (deterministic; the host sums the partials).
+// ---------------------------------------------------------------------------------------------------------------
+#define TV_BLOCK 256
+extern "C" int gens_tv_blocks(int64_t n_voxels) { return (int)gens_blocks(n_voxels, TV_BLOCK); }
+
+__global__ __launch_bounds__(TV_BLOCK) void tv_fwd_k(const float* __restrict__ vol, const float* __restrict__ mask, int X, int Y, int Z,
+                                                     float4* __restrict__ partial) {
+    __shared__ float4 red[TV_BLOCK / 64];
+    int64_t n = (int64_t)X * Y * Z;
+    int64_t i = (int64_t)blockIdx.x * TV_BLOCK + threadIdx.x;
+    float4 acc = f4_zero();
+    if (i < n) {
+        int kz = (int)(i % Z), jy = (int)((i / Z) % Y), ix = (int)(i / ((int64_t)Z * Y));
+        float m = mask[i];
+        bool mx = (ix + 1 < X) && (m * mask[i + (int64_t)Y * Z] > 0.0f);
+        bool my = (jy + 1 < Y) && (m * mask[i + Z] > 0.0f);
+        bool mz = (kz + 1 < Z) && (m * mask[i + 1] > 0.0f);
+        for (int c = 0; c < 4; ++c) {
+            const float* v = vol + c * n + i;
+            float v0 = v[0];
+            if (mx) { float d = v[(int64_t)Y * Z] - v0; acc.x += d * d; }
+            if (my) { float d = v[Z] - v0; acc.y += d * d; }
+            if (mz) { float d = v[1] - v0; acc.z += d * d; }
+        }
+        acc.w = mx ? 1.0f : 0.0f;
+    }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = red[0];
+        for (int k = 1; k < TV_BLOCK / 64; ++k) { t.x += red[k].x; t.y += red[k].y; t.z += red[k].z; t.w += red[k].w; }
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(TV_BLOCK) void tv_bwd_k(const float* __restrict__ vol, const float* __restrict__ mask, int X, int Y, int Z,
+                                                     float coef, float* __restrict__ g_vol) {
+    int64_t n = (int64_t)X * Y * Z;
+    int64_t i = (int64_t)blockIdx.x * TV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int kz = (int)(i % Z), jy = (int)((i / Z) % Y), ix = (int)(i / ((int64_t)Z * Y));
+    int64_t sx = (int64_t)Y * Z, sy = Z;
+    float m = mask[i];
+    bool px = (ix + 1 < X) && (m * mask[i + sx] > 0.0f), nx = (ix > 0) && (m * mask[i - sx] > 0.0f);
+    bool py = (jy + 1 < Y) && (m * mask[i + sy] > 0.0f), ny = (jy > 0) && (m * mask[i - sy] > 0.0f);
+    bool pz = (kz + 1 < Z) && (m * mask[i + 1] > 0.0f), nz = (kz > 0) && (m * mask[i - 1] > 0.0f);
+    for (int c = 0; c < 4; ++c) {
+        const float* v = vol + c * n + i;
+        float v0 = v[0], g = 0.0f;
+        if (px) g -= 2.0f * (v[sx] - v0);
+        if (nx) g += 2.0f * (v0 - v[-sx]);
+        if (py) g -= 2.0f * (v[sy] - v0);
+        if (ny) g += 2.0f * (v0 - v[-sy]);
+        if (pz) g -= 2.0f * (v[1] - v0);
+        if (nz) g += 2.0f * (v0 - v[-1]);
+        g_vol[c * n + i] = coef * g;
+    }
+}
+
+extern "C" int gens_tv_fwd(const float* vol, const float* mask, int x, int y, int z, float* partial, void* stream) {
+    GENS_CHECK_ARG(vol && mask && partial && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_fwd: bad argument");
+    int64_t n = (int64_t)x * y * z;
+    tv_fwd_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, (float4*)partial);
+    return gens_launch_status("gens_tv_fwd");
+}
+
+extern "C" int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float coef, float* g_vol, void* stream) {
+    GENS_CHECK_ARG(vol && mask && g_vol && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_bwd: bad argument");
+    int64_t n = (int64_t)x * y * z;
+    tv_bwd_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, g_vol);
+    return gens_launch_status("gens_tv_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K11: lattice points
+// ---------------------------------------------------------------------------------------------------------------
+struct Box { float lo[3], hi[3]; };
+__global__ __launch_bounds__(256) void lattice_k(Box b, int res, int64_t first, int64_t count, float* __restrict__ pts) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    int64_t i = first + t;
+    int kz = (int)(i % res), jy = (int)((i / res) % res), ix = (int)(i / ((int64_t)res * res));
+    pts[3 * t] = linspace_at(b.lo[0], b.hi[0], res, ix);
+    pts[3 * t + 1] = linspace_at(b.lo[1], b.hi[1], res, jy);
+    pts[3 * t + 2] = linspace_at(b.lo[2], b.hi[2], res, kz);
+}
+
+extern "C" int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int res, int64_t first, int64_t count, float* pts,
+                                   void* stream) {
+    GENS_CHECK_ARG(bmin3_host && bmax3_host && res > 0 && first >= 0 && count >= 0, GENS_EINVAL, "gens_lattice_points: bad argument");
+    GENS_CHECK_ARG(first + count <= (int64_t)res * res * res, GENS_EINVAL, "gens_lattice_points: range beyond res^3");
+    if (count == 0) return 0;
+    GENS_CHECK_ARG(pts, GENS_EINVAL, "gens_lattice_points: null output");
+    Box b;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = bmin3_host[a]; b.hi[a] = bmax3_host[a]; }
+    lattice_k<<<gens_blocks(count, 256), 256, 0, (hipStream_t)stream>>>(b, res, first, count, pts);
+    return gens_launch_status("gens_lattice_points");
+}

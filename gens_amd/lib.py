@@ -1,0 +1,131 @@
+"""ctypes binding of libgens_hip.so (C ABI declared in include/gens_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this module raises.  PyTorch is used by
+the callers only to own device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgens_hip.so")
+
+MAX_LEVELS = 8
+MAX_VIEWS = 8
+LAYOUT_PLANAR = 0
+LAYOUT_PACKED = 1
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_pp = C.POINTER(C.c_void_p)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+
+class CompositeIn(C.Structure):
+    _fields_ = [(n, _p) for n in ("rays_o", "rays_d", "z", "sdf", "grad", "color", "smooth", "voxel_mask", "src_vis", "inv_s", "z_max")] + [
+        ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9)]
+
+
+class CompositeOut(C.Structure):
+    _fields_ = [(n, _p) for n in ("color", "normal", "depth", "wsum", "wmax", "mid_in", "sdf_depth", "z_cross", "eik_num", "eik_den",
+                                  "smooth_vec", "valid", "cross_idx", "weights", "inside")]
+
+
+class CompositeGrad(C.Structure):
+    _fields_ = [(n, _p) for n in ("g_color", "g_normal", "g_depth", "g_weights", "g_wsum", "g_eik_num", "g_smooth_vec", "g_z_cross",
+                                  "weights", "cross_idx", "smooth_vec", "g_sdf", "g_grad", "g_col", "g_smooth", "g_inv_s")]
+
+
+# name -> argtypes, mirroring include/gens_hip.h declaration by declaration
+SIGNATURES = {
+    "gens_pack_nchw": [_p, _p, _i, _i, _i, _i, _p],
+    "gens_unpack_nhwc": [_p, _p, _i, _i, _i, _i, _p],
+    "gens_pack_volume": [_p, _p, _i, _i, _i, _p],
+    "gens_volume_build_fwd": [_p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _p, _p],
+    "gens_volume_build_bwd": [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
+    "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],
+    "gens_lookup_volume_bwd": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p],
+    "gens_lookup_volume_bwd2": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p],
+    "gens_lookup_mask_nearest": [_pp, _ip, _i, _p, _l, _p, _p, _p],
+    "gens_ray_points": [_p, _p, _p, _l, _i, _i, _f, _pp, _ip, _i, _p, _p, _p],
+    "gens_lookup_feature_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "gens_lookup_feature_bwd": [_ip, _i, _p, _p, _i, _p, _p, _l, _pp, _p, _p],
+    "gens_upsample": [_p, _p, _p, _p, _l, _i, _i, _f, _pp, _ip, _i, _p, _p, _p, _p],
+    "gens_merge_samples": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p],
+    "gens_composite_fwd": [C.POINTER(CompositeIn), C.POINTER(CompositeOut), _p],
+    "gens_composite_bwd": [C.POINTER(CompositeIn), C.POINTER(CompositeGrad), _p],
+    "gens_patch_sample_fwd": [_p, _i, _i, _i, _p, _l, _p, _p],
+    "gens_patch_sample_bwd": [_p, _i, _i, _i, _p, _p, _l, _p, _p],
+    "gens_upsample2d_into": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
+    "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
+    "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
+    "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C gens_amd/csrc` (or __graft_entry__.build()); "
+                           "gens_amd has no CPU / PyTorch fallback for the hot path")
+    lib = C.CDLL(LIB_PATH)
+    lib.gens_last_error.restype = C.c_char_p
+    lib.gens_last_error.argtypes = []
+    lib.gens_abi_version.restype = _i
+    lib.gens_abi_version.argtypes = []
+    lib.gens_tv_blocks.restype = _i
+    lib.gens_tv_blocks.argtypes = [_l]
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _i
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.gens_last_error().decode()}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("gens_amd kernels need device tensors (no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_table(tensors, dtype=torch.float32):
+    """HOST array of device pointers (None -> NULL table)."""
+    if tensors is None:
+        return None
+    arr = (C.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = None if t is None else ptr(t, dtype).value
+    return C.cast(arr, _pp)
+
+
+def int_table(values):
+    flat = [int(v) for v in values]
+    return (C.c_int * len(flat))(*flat)

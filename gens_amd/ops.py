@@ -1,0 +1,505 @@
+"""Autograd-aware operators of the GenS hot path, each a thin shim over one C-ABI entry point of libgens_hip.so.
+
+The shims allocate outputs with torch (device memory + current stream only) and wire first / second order
+derivatives the way the reference's Function pair does (models/modules/grid_sample_cuda/cuda_gridsample.py:71-123):
+twice differentiable, outputs of the second backward are constants.  Citations are relative to /root/reference.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+_f32 = torch.float32
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _dev_f32(t, device):
+    return _c(t.to(device=device, dtype=_f32))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# texel layout (NHWC, channels padded to a multiple of 4)
+# ------------------------------------------------------------------------------------------------------------------
+class _PackNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        ctx.shape = (n, c, h, w)
+        out = torch.empty(n, h, w, 4 * ((c + 3) // 4), device=x.device, dtype=_f32)
+        L.call("gens_pack_nchw", L.ptr(_c(x)), L.ptr(out), n, c, h, w, L.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        out = torch.empty(n, c, h, w, device=g.device, dtype=_f32)
+        L.call("gens_unpack_nhwc", L.ptr(_c(g)), L.ptr(out), n, c, h, w, L.stream())
+        return out
+
+
+def pack_nchw(x):
+    """(n,C,H,W) -> (n,H,W,C_pad) texels; differentiable."""
+    return _PackNCHW.apply(x)
+
+
+def pack_volume(v):
+    """(1,4,X,Y,Z) or (4,X,Y,Z) -> (X,Y,Z,4) texels (inference fast path; not differentiable)."""
+    v = v.detach()
+    if v.dim() == 5:
+        v = v[0]
+    assert v.shape[0] == 4, "only 4-channel volume levels are supported"
+    _, x, y, z = v.shape
+    out = torch.empty(x, y, z, 4, device=v.device, dtype=_f32)
+    L.call("gens_pack_volume", L.ptr(_c(v)), L.ptr(out), x, y, z, L.stream())
+    return out
+
+
+class VolumeSet:
+    """A pyramid of volumes as the kernels see it: host pointer table + dims + layout."""
+
+    def __init__(self, tensors, layout):
+        self.layout = layout
+        self.tensors = [_c(t) for t in tensors]
+        if layout == L.LAYOUT_PACKED:
+            dims = [tuple(t.shape[:3]) for t in self.tensors]
+        else:
+            for t in self.tensors:
+                assert t.shape[-4] == 4, "only 4-channel volume levels are supported (confs/gens.conf:63-67)"
+            dims = [tuple(t.shape[-3:]) for t in self.tensors]
+        self.dims = dims
+        self.n = len(self.tensors)
+        assert 1 <= self.n <= L.MAX_LEVELS
+        self.table = L.ptr_table(self.tensors)
+        self.dim_table = L.int_table([d for dd in dims for d in dd])
+
+    @staticmethod
+    def packed(volumes):
+        return VolumeSet([pack_volume(v) for v in volumes], L.LAYOUT_PACKED)
+
+    @staticmethod
+    def masks(mask_volumes):
+        """Mask pyramid (1,1,X,Y,Z) floats for the nearest look-up (K3)."""
+        vs = VolumeSet.__new__(VolumeSet)
+        vs.layout = L.LAYOUT_PLANAR
+        vs.tensors = [_c(m.detach().reshape(m.shape[-3:])) for m in mask_volumes]
+        vs.dims = [tuple(t.shape) for t in vs.tensors]
+        vs.n = len(vs.tensors)
+        vs.table = L.ptr_table(vs.tensors)
+        vs.dim_table = L.int_table([d for dd in vs.dims for d in dd])
+        return vs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K1  Volume.agg_mean_var (volume.py:13-63)
+# ------------------------------------------------------------------------------------------------------------------
+class _VolumeBuild(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat_tex, w2c, intr, scale, d, min_vis):
+        nv, h, w, cp = feat_tex.shape
+        assert cp == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
+        vol = torch.empty(1, 8, d, d, d, device=feat_tex.device, dtype=_f32)
+        mask = torch.empty(1, 1, d, d, d, device=feat_tex.device, dtype=_f32)
+        L.call("gens_volume_build_fwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
+               L.ptr(mask), L.stream())
+        ctx.save_for_backward(feat_tex, w2c, intr)
+        ctx.meta = (scale, d)
+        ctx.mark_non_differentiable(mask)
+        return vol, mask
+
+    @staticmethod
+    def backward(ctx, g_vol, _g_mask):
+        feat_tex, w2c, intr = ctx.saved_tensors
+        scale, d = ctx.meta
+        nv, h, w, _ = feat_tex.shape
+        g = torch.zeros_like(feat_tex)
+        L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
+               L.stream())
+        return g, None, None, None, None, None
+
+
+def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
+    """features: list of (nv,4,H_i,W_i) NCHW -> (volumes [(1,8,D,D,D)], masks [(1,1,D,D,D)])."""
+    dev = features[0].device
+    w2c = _dev_f32(torch.linalg.inv(c2ws.to(_f32)), dev)
+    intr = _dev_f32(intrs, dev)
+    vols, masks = [], []
+    for lvl, d in enumerate(dims):
+        v, m = _VolumeBuild.apply(pack_nchw(features[lvl].to(_f32)), w2c, intr, 0.5 ** lvl, int(d), int(min_vis_view))
+        vols.append(v)
+        masks.append(m)
+    return vols, masks
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K2 / K2''  lookup_volume(..., "grad") with first and second derivatives
+# ------------------------------------------------------------------------------------------------------------------
+def _vset(layout, vols):
+    return VolumeSet(list(vols), layout)
+
+
+class _Lookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, layout, *vols):
+        vs = _vset(layout, [v.detach() for v in vols])
+        pts_c = _c(pts.detach().to(_f32))
+        n = pts_c.shape[0]
+        out = torch.empty(n, 4 * vs.n, device=pts.device, dtype=_f32)
+        L.call("gens_lookup_volume_fwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), n, L.ptr(out), L.stream())
+        ctx.save_for_backward(pts, *vols)   # the INPUT tensors: the second backward must reach their producers
+        ctx.layout = layout
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        pts, *vols = ctx.saved_tensors
+        want_vol = any(ctx.needs_input_grad[2:])
+        res = _LookupBwd.apply(g_out, pts, ctx.layout, want_vol, *vols)
+        return (res[0], None) + tuple(res[1:])
+
+
+class _LookupBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_out, pts, layout, want_vol, *vols):
+        vs = _vset(layout, [v.detach() for v in vols])
+        n = pts.shape[0]
+        g_out_c = _c(g_out.detach().to(_f32))
+        pts_c = _c(pts.detach().to(_f32))
+        g_pts = torch.empty(n, 3, device=pts.device, dtype=_f32)
+        g_vols = [torch.zeros_like(v) for v in vs.tensors] if want_vol else None
+        L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), L.ptr(g_out_c), n, L.ptr_table(g_vols),
+               L.ptr(g_pts), L.stream())
+        ctx.save_for_backward(g_out_c, pts_c, *vols)
+        ctx.layout, ctx.want_vol = layout, want_vol
+        if want_vol:
+            return (g_pts,) + tuple(g.reshape(v.shape) for g, v in zip(g_vols, vols))
+        return (g_pts,) + tuple(None for _ in vols)
+
+    @staticmethod
+    def backward(ctx, gg_pts, *gg_vols):
+        g_out, pts, *vols = ctx.saved_tensors
+        layout = ctx.layout
+        vs = _vset(layout, [v.detach() for v in vols])
+        n = pts.shape[0]
+        if gg_pts is None:
+            gg_pts = torch.zeros(n, 3, device=pts.device, dtype=_f32)
+        have_ggv = any(g is not None for g in gg_vols)
+        ggv = None
+        if have_ggv:  # cuda_gridsample.py:113-114 allocates zeros here; missing levels are simply NULL-safe zeros
+            ggv = [_c(g.detach().reshape(t.shape)) if g is not None else torch.zeros_like(t) for g, t in zip(gg_vols, vs.tensors)]
+        want_vol = any(ctx.needs_input_grad[4:])
+        g_vols2 = [torch.zeros_like(t) for t in vs.tensors] if want_vol else None
+        gg_out = torch.empty_like(g_out)
+        g_pts2 = torch.empty(n, 3, device=pts.device, dtype=_f32)
+        L.call("gens_lookup_volume_bwd2", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), L.ptr(_c(gg_pts.detach())),
+               L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.stream())
+        # outputs are plain tensors: third order through the sampler is dropped, as in the reference (cuda_gridsample.py:110-123)
+        if want_vol:
+            gv = tuple(g.reshape(v.shape) for g, v in zip(g_vols2, vols))
+        else:
+            gv = tuple(None for _ in vols)
+        return (gg_out, g_pts2, None, None) + gv
+
+
+def lookup_volume(pts, volumes):
+    """pts (N,3), volumes: list of (1,4,X,Y,Z) tensors (planar) or a packed VolumeSet -> (N, 4L).  Twice differentiable."""
+    pts = pts.reshape(-1, 3)
+    if isinstance(volumes, VolumeSet):
+        return _Lookup.apply(pts, volumes.layout, *volumes.tensors)
+    return _Lookup.apply(pts, L.LAYOUT_PLANAR, *[_c(v.to(_f32)) for v in volumes])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K3  nearest visibility look-up, ray point generation
+# ------------------------------------------------------------------------------------------------------------------
+def lookup_mask(pts, masks, return_values=False):
+    """-> valid (N,) bool [, values (N,L) float]: lookup_volume(pts, mask_volumes, 'nearest') (projector.py:231,240)."""
+    ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
+    pts = _c(pts.detach().reshape(-1, 3).to(_f32))
+    n = pts.shape[0]
+    valid = torch.empty(n, device=pts.device, dtype=torch.uint8)
+    vals = torch.empty(n, ms.n, device=pts.device, dtype=_f32) if return_values else None
+    L.call("gens_lookup_mask_nearest", ms.table, ms.dim_table, ms.n, L.ptr(pts), n, L.ptr(valid, torch.uint8), L.ptr(vals), L.stream())
+    return (valid.bool(), vals) if return_values else valid.bool()
+
+
+def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
+    """pts (B*n,3) = o + d * (z or section mid-points), valid (B*n,) bool."""
+    ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
+    b, n = z.shape
+    pts = torch.empty(b * n, 3, device=z.device, dtype=_f32)
+    valid = torch.empty(b * n, device=z.device, dtype=torch.uint8)
+    L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), ms.table,
+           ms.dim_table, ms.n, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream())
+    return pts, valid.bool()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K4  lookup_feature (projector.py:294-349)
+# ------------------------------------------------------------------------------------------------------------------
+class _LookupFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, w2c, intr, c2w, imgs_tex, *feat_tex):
+        nv = imgs_tex.shape[0]
+        nl = len(feat_tex)
+        n = pts.shape[0]
+        s = nv - 1
+        hw = [d for f in feat_tex for d in f.shape[1:3]]
+        assert tuple(imgs_tex.shape[1:3]) == tuple(feat_tex[0].shape[1:3]), "RGB images must match feature level 0"
+        out = torch.empty(n, s, 3 + 4 * nl, device=pts.device, dtype=_f32)
+        ray_diff = torch.empty(n, s, 4, device=pts.device, dtype=_f32)
+        vis = torch.empty(n, s, device=pts.device, dtype=torch.uint8)
+        feats = [_c(f.detach()) for f in feat_tex]
+        L.call("gens_lookup_feature_fwd", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(imgs_tex.detach())), L.ptr(w2c), L.ptr(intr),
+               L.ptr(c2w), nv, L.ptr(pts), n, L.ptr(out), L.ptr(ray_diff), L.ptr(vis, torch.uint8), L.stream())
+        ctx.save_for_backward(pts, w2c, intr)
+        ctx.meta = (nv, hw, [f.shape for f in feat_tex], imgs_tex.shape)
+        ctx.mark_non_differentiable(ray_diff, vis)
+        return out, ray_diff, vis
+
+    @staticmethod
+    def backward(ctx, g_out, _g_rd, _g_vis):
+        pts, w2c, intr = ctx.saved_tensors
+        nv, hw, fshapes, ishape = ctx.meta
+        nl = len(fshapes)
+        want_img = ctx.needs_input_grad[4]
+        want_feat = any(ctx.needs_input_grad[5:])
+        g_feats = [torch.zeros(s, device=pts.device, dtype=_f32) for s in fshapes] if want_feat else None
+        g_imgs = torch.zeros(ishape, device=pts.device, dtype=_f32) if want_img else None
+        if want_feat or want_img:
+            L.call("gens_lookup_feature_bwd", L.int_table(hw), nl, L.ptr(w2c), L.ptr(intr), nv, L.ptr(pts), L.ptr(_c(g_out)), pts.shape[0],
+                   L.ptr_table(g_feats), L.ptr(g_imgs), L.stream())
+        return (None, None, None, None, g_imgs) + (tuple(g_feats) if want_feat else tuple(None for _ in fshapes))
+
+
+class SceneViews:
+    """Per-scene camera matrices + texel copies of the images and the feature pyramid (built once per scene)."""
+
+    def __init__(self, imgs, intrs, c2ws, features):
+        dev = imgs.device
+        self.nv = imgs.shape[0]
+        self.c2w = _dev_f32(c2ws, dev)
+        self.w2c = _c(torch.linalg.inv(self.c2w))
+        self.intr = _dev_f32(intrs, dev)
+        self.imgs_tex = pack_nchw(imgs.to(_f32))
+        self.feat_tex = [pack_nchw(f.to(_f32)) for f in features]
+
+
+def lookup_feature(pts, views):
+    """-> feat_views (N,S,3+4L), ray_diff (N,S,4), mask (N,S) bool.  Differentiable w.r.t. images / features."""
+    pts = _c(pts.detach().reshape(-1, 3).to(_f32))
+    out, rd, vis = _LookupFeature.apply(pts, views.w2c, views.intr, views.c2w, views.imgs_tex, *views.feat_tex)
+    return out, rd, vis.bool()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K5-K7  hierarchical sampling
+# ------------------------------------------------------------------------------------------------------------------
+def upsample(rays_o, rays_d, z, sdf, n_new, masks, inv_s):
+    """up_sample + sample_pdf(det) (implicit_surface.py:60-109): -> z_new (B,n_new), pts_new (B*n_new,3), valid_new bool."""
+    ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
+    b, n = z.shape
+    z_new = torch.empty(b, n_new, device=z.device, dtype=_f32)
+    pts_new = torch.empty(b * n_new, 3, device=z.device, dtype=_f32)
+    valid = torch.empty(b * n_new, device=z.device, dtype=torch.uint8)
+    L.call("gens_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), b, n, n_new, float(inv_s), ms.table,
+           ms.dim_table, ms.n, L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream())
+    return z_new, pts_new, valid.bool()
+
+
+def merge_samples(z, z_new, sdf=None, sdf_new=None):
+    """cat + sort of cat_z_vals (implicit_surface.py:111-133)."""
+    b, n = z.shape
+    n_new = z_new.shape[1]
+    z_out = torch.empty(b, n + n_new, device=z.device, dtype=_f32)
+    sdf_out = torch.empty_like(z_out) if sdf is not None else None
+    L.call("gens_merge_samples", L.ptr(_c(z)), L.ptr(_c(sdf)) if sdf is not None else None, L.ptr(_c(z_new)),
+           L.ptr(_c(sdf_new)) if sdf_new is not None else None, b, n, n_new, L.ptr(z_out), L.ptr(sdf_out), L.stream())
+    return z_out, sdf_out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K8  compositing (implicit_surface.py:160-168, 202-303)
+# ------------------------------------------------------------------------------------------------------------------
+def _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot):
+    ci = L.CompositeIn()
+    ci.rays_o, ci.rays_d, ci.z = L.ptr(rays_o), L.ptr(rays_d), L.ptr(z)
+    ci.sdf, ci.grad, ci.color, ci.smooth = L.ptr(sdf), L.ptr(grad), L.ptr(color), L.ptr(smooth)
+    ci.voxel_mask = L.ptr(voxel_mask, torch.uint8)
+    ci.src_vis = L.ptr(src_vis, torch.uint8)
+    ci.inv_s, ci.z_max = L.ptr(inv_s), L.ptr(z_max)
+    ci.n_rays, ci.n = z.shape
+    ci.n_src = src_vis.shape[-1] if src_vis is not None else 0
+    ci.sample_dist, ci.cos_anneal = float(sample_dist), float(cos_anneal)
+    for k in range(9):
+        ci.rot[k] = rot[k]
+    return ci
+
+
+class _Composite(torch.autograd.Function):
+    """inputs with gradient: sdf (B,n), grad (B,n,3), color (B,n,3), smooth (B,n,3)|None, inv_s (1,)"""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, sample_dist, cos_anneal, rot):
+        b, n = z.shape
+        dev = z.device
+        sdf, grad, color = _c(sdf.detach()), _c(grad.detach()), _c(color.detach())
+        smooth = _c(smooth.detach()) if smooth is not None else None
+        inv_s = _c(inv_s.detach().reshape(1))
+        ci = _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=_f32)  # noqa: E731
+        o = dict(color=f(b, 3), normal=f(b, 3), depth=f(b), wsum=f(b), wmax=f(b), mid_in=f(b), sdf_depth=f(b), z_cross=f(b), eik_num=f(b),
+                 eik_den=f(b), smooth_vec=f(b, 3), weights=f(b, n), inside=f(b, n))
+        valid = torch.empty(b, device=dev, dtype=torch.uint8)
+        cross_idx = torch.empty(b, device=dev, dtype=torch.int32)
+        co = L.CompositeOut()
+        for k, t in o.items():
+            setattr(co, k, L.ptr(t))
+        co.valid = L.ptr(valid, torch.uint8)
+        co.cross_idx = L.ptr(cross_idx, torch.int32)
+        L.call("gens_composite_fwd", C.byref(ci), C.byref(co), L.stream())
+        ctx.save_for_backward(sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, o["weights"], cross_idx,
+                              o["smooth_vec"])
+        ctx.meta = (sample_dist, cos_anneal, rot)
+        ctx.mark_non_differentiable(o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx)
+        return (o["color"], o["normal"], o["depth"], o["weights"], o["wsum"], o["eik_num"], o["smooth_vec"], o["z_cross"], o["sdf_depth"],
+                o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx)
+
+    @staticmethod
+    def backward(ctx, g_color, g_normal, g_depth, g_weights, g_wsum, g_eik, g_smv, g_zc, _g_sdfdepth, *_unused):
+        (sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, weights, cross_idx, smooth_vec) = ctx.saved_tensors
+        sample_dist, cos_anneal, rot = ctx.meta
+        b, n = z.shape
+        ci = _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot)
+        cg = L.CompositeGrad()
+        keep = []
+
+        def cot(t):
+            if t is None:
+                return None
+            t = _c(t.to(_f32))
+            keep.append(t)
+            return L.ptr(t)
+        cg.g_color, cg.g_normal, cg.g_depth, cg.g_weights = cot(g_color), cot(g_normal), cot(g_depth), cot(g_weights)
+        cg.g_wsum, cg.g_eik_num, cg.g_smooth_vec, cg.g_z_cross = cot(g_wsum), cot(g_eik), cot(g_smv), cot(g_zc)
+        cg.weights, cg.smooth_vec = L.ptr(weights), L.ptr(smooth_vec)
+        cg.cross_idx = L.ptr(cross_idx, torch.int32)
+        g_sdf = torch.empty_like(sdf)
+        g_grad = torch.empty_like(grad)
+        g_col = torch.empty_like(color)
+        g_smooth = torch.empty_like(smooth) if smooth is not None else None
+        g_inv_s = torch.empty(b, device=z.device, dtype=_f32)
+        cg.g_sdf, cg.g_grad, cg.g_col, cg.g_smooth, cg.g_inv_s = L.ptr(g_sdf), L.ptr(g_grad), L.ptr(g_col), L.ptr(g_smooth), L.ptr(g_inv_s)
+        L.call("gens_composite_bwd", C.byref(ci), C.byref(cg), L.stream())
+        return (g_sdf, g_grad, g_col, g_smooth, g_inv_s.sum().reshape(1)) + (None,) * 9
+
+
+COMPOSITE_KEYS = ("color", "normal", "depth", "weights", "wsum", "eik_num", "smooth_vec", "z_cross", "sdf_depth", "wmax", "mid_in", "eik_den",
+                  "inside", "valid", "cross_idx")
+
+
+def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, voxel_mask, src_vis, inv_s, cos_anneal, c2w_ref):
+    """Everything render_core computes after the networks have run; returns a dict keyed by COMPOSITE_KEYS."""
+    b, n = z.shape
+    rot = torch.linalg.inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()       # implicit_surface.py:242,245
+    z = _c(z.detach().to(_f32))
+    z_max = z.max().reshape(1)                                                  # implicit_surface.py:301
+    vm = _c(voxel_mask.reshape(b * n).to(torch.uint8))
+    sv = _c(src_vis.reshape(b * n, -1).to(torch.uint8)) if src_vis is not None else None
+    outs = _Composite.apply(sdf.reshape(b, n), gradients.reshape(b, n, 3), color.reshape(b, n, 3),
+                            smooth.reshape(b, n, 3) if smooth is not None else None, inv_s.reshape(1), _c(rays_o.to(_f32)),
+                            _c(rays_d.to(_f32)), z, vm, sv, z_max, float(sample_dist), float(cos_anneal), rot)
+    return dict(zip(COMPOSITE_KEYS, outs))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K9  patch reads (projector.py:406-416) and the feature up-sampling that feeds them (implicit_surface.py:313-326)
+# ------------------------------------------------------------------------------------------------------------------
+class _PatchSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xy, image_tex, c):
+        h, w, _ = image_tex.shape
+        xy_c = _c(xy.detach().to(_f32))
+        p = xy_c.shape[0]
+        out = torch.empty(p, c, device=xy.device, dtype=_f32)
+        L.call("gens_patch_sample_fwd", L.ptr(image_tex), h, w, c, L.ptr(xy_c), p, L.ptr(out), L.stream())
+        ctx.save_for_backward(xy_c, image_tex)
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xy, image_tex = ctx.saved_tensors
+        h, w, _ = image_tex.shape
+        g_xy = torch.empty_like(xy)
+        L.call("gens_patch_sample_bwd", L.ptr(image_tex), h, w, ctx.c, L.ptr(xy), L.ptr(_c(g_out)), xy.shape[0], L.ptr(g_xy), L.stream())
+        return g_xy, None, None
+
+
+def patch_sample(image_tex, xy, channels):
+    """image_tex (H,W,C_pad) texels (constant), xy (P,2) pixel coordinates -> (P,C); differentiable in xy."""
+    return _PatchSample.apply(xy, image_tex, channels)
+
+
+def build_warp_features(levels):
+    """cat([f0, up(f1), up(f2)], 1) of implicit_surface.py:313-326 as (nv,H,W,12) texels; inputs (nv,4,h_i,w_i) NCHW, detached."""
+    f0 = levels[0].detach()
+    nv, c, h, w = f0.shape
+    ctot = sum(f.shape[1] for f in levels)
+    cpad = 4 * ((ctot + 3) // 4)
+    dst = torch.zeros(nv, h, w, cpad, device=f0.device, dtype=_f32)
+    off = 0
+    for f in levels:
+        f = _c(f.detach().to(_f32))
+        L.call("gens_upsample2d_into", L.ptr(f), nv, f.shape[1], f.shape[2], f.shape[3], L.ptr(dst), h, w, cpad, off, L.stream())
+        off += f.shape[1]
+    return dst, ctot
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K10  tv_regularization (implicit_surface.py:135-150)
+# ------------------------------------------------------------------------------------------------------------------
+class _TVLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, mask):
+        _, c, x, y, z = vol.shape
+        assert c == 4
+        vol_c, mask_c = _c(vol.detach()), _c(mask.detach())
+        nb = L.load().gens_tv_blocks(x * y * z)
+        partial = torch.empty(nb, 4, device=vol.device, dtype=_f32)
+        L.call("gens_tv_fwd", L.ptr(vol_c), L.ptr(mask_c), x, y, z, L.ptr(partial), L.stream())
+        sums = partial.double().sum(0)
+        den = sums[3] + 1e-8                                                   # (Q13): all three axes use mx's count
+        tv = torch.sqrt((sums[0] + sums[1] + sums[2]) / den).to(_f32)
+        ctx.save_for_backward(vol_c, mask_c, tv, den.to(_f32))
+        return tv
+
+    @staticmethod
+    def backward(ctx, g):
+        vol, mask, tv, den = ctx.saved_tensors
+        _, _, x, y, z = vol.shape
+        coef = float(g / (2.0 * tv * den))
+        g_vol = torch.empty_like(vol)
+        L.call("gens_tv_bwd", L.ptr(vol), L.ptr(mask), x, y, z, coef, L.ptr(g_vol), L.stream())
+        return g_vol, None
+
+
+def tv_regularization(volumes, masks):
+    total = 0
+    for lvl, (v, m) in enumerate(zip(volumes, masks)):
+        total = total + _TVLevel.apply(v, m) * 0.5 ** lvl
+    return total
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K11  lattice (implicit_surface.py:407-418)
+# ------------------------------------------------------------------------------------------------------------------
+def lattice_points(bound_min, bound_max, resolution, first, count, device):
+    lo = (C.c_float * 3)(*[float(v) for v in bound_min])
+    hi = (C.c_float * 3)(*[float(v) for v in bound_max])
+    pts = torch.empty(count, 3, device=device, dtype=_f32)
+    L.call("gens_lattice_points", lo, hi, int(resolution), int(first), int(count), L.ptr(pts), L.stream())
+    return pts

@@ -1,0 +1,207 @@
+/*
+ * gens_hip.h -- C ABI of libgens_hip.so: the GenS hot path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * Drop-in boundary.  The reference's only native ABI is the pybind pair
+ *     grad2_2d / grad2_3d                (models/modules/grid_sample_cuda/gridsample_cuda.cpp:26-56)
+ * reached through cuda_gridsample.grid_sample_3d (cuda_gridsample.py:12-14, 71-123); everything else on the
+ * path is PyTorch tensor code.  Each entry point below names the reference code it replaces.  All citations are
+ * relative to /root/reference.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless its comment says otherwise (host arrays of
+ *     device pointers are spelled `const float* const*` and documented as host);
+ *   - inputs are borrowed and never written; outputs are caller-allocated; outputs documented "accumulates" must
+ *     be zero-filled by the caller (they are atomically added to);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work, they never
+ *     synchronise;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative GENS_E* argument error.
+ *     gens_last_error() returns a static description of the last failure on the calling thread;
+ *   - volumes are (C, X, Y, Z) with world x <-> X ("planar", the reference's (1,C,D,D,D) tensor, Q1) or
+ *     (X, Y, Z, 4) ("packed": one 16-byte texel per voxel, built by gens_pack_volume);
+ *   - feature maps / images consumed by the samplers are NHWC with the channel count padded to a multiple of 4
+ *     ("texel" layout, built by gens_pack_nchw); C_pad below always means 4*ceil(C/4);
+ *   - only C = 4 channels per volume level are supported (every shipped config: confs/gens.conf:63-67).
+ */
+#ifndef GENS_HIP_H
+#define GENS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENS_MAX_LEVELS 8
+#define GENS_MAX_VIEWS 8
+
+#define GENS_EINVAL (-1)   /* bad argument (null pointer, size out of range)          */
+#define GENS_ELIMIT (-2)   /* more levels / views / channels than the build supports */
+
+#define GENS_LAYOUT_PLANAR 0
+#define GENS_LAYOUT_PACKED 1
+
+const char* gens_last_error(void);
+int gens_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* src (n, C, H, W) -> dst (n, H, W, C_pad), pad channels are zero. */
+int gens_pack_nchw(const float* src, float* dst, int n, int c, int h, int w, void* stream);
+/* adjoint: dst (n, C, H, W) = channels 0..C-1 of src (n, H, W, C_pad)   (overwrites dst). */
+int gens_unpack_nhwc(const float* src, float* dst, int n, int c, int h, int w, void* stream);
+/* src (4, X, Y, Z) -> dst (X, Y, Z, 4). */
+int gens_pack_volume(const float* src, float* dst, int x, int y, int z, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K1  Volume.agg_mean_var, one level per call          (models/modules/volume.py:21-61)
+ *   feat    (nv, H, W, 4) texels of features[level]
+ *   w2c     (nv, 4, 4) = inverse(c2ws)                   (volume.py:34)
+ *   intr    (nv, 4, 4) level-0 intrinsics; rows 0-1 are multiplied by intr_scale = 0.5^level in-kernel (:24-25)
+ *   volume  (8, D, D, D) = [mean(4) | var(4)], mask (D, D, D) float 0/1 = (count > min_vis_view)   (:53-58)
+ * bwd: g_volume (8, D, D, D) -> g_feat (nv, H, W, 4), accumulates (gradient w.r.t. features only, :27-44).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
+                          int w, int d, int min_vis_view, float* volume, float* mask, void* stream);
+int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
+                          int w, int d, const float* g_volume, float* g_feat, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K2  lookup_volume(pts, volumes, "grad"): all levels in one launch
+ *     forward            projector.py:217-245 -> cuda_gridsample._GridSample3dForward (cuda_gridsample.py:71-84)
+ *     backward           aten::grid_sampler_3d_backward via _GridSample3dBackward.forward (:94-108)
+ *     backward-backward  gridsample_grad2.grad2_3d (gridsample_cuda.cpp:42-56, gridsample_cuda.cu:212-533, 601-666)
+ *   vols     HOST array of n_levels device pointers; dims HOST int[3*n_levels] = (X,Y,Z) per level
+ *   pts      (N, 3) world points in [-1,1] (no flip: x indexes X)
+ *   out / g_out / gg_out   (N, 4*n_levels), level-major like torch.cat(feats, -1)
+ *   g_vols / g_vols2       HOST arrays of device pointers (same layout as vols), accumulate; NULL = not wanted
+ *   gg_vols                HOST array or NULL (the reference's `grad2_grad_input is None`, cuda_gridsample.py:113)
+ *   g_pts / gg_pts / g_pts2  (N, 3); g_pts, g_pts2 are overwritten
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_lookup_volume_fwd(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                           int64_t n, float* out, void* stream);
+int gens_lookup_volume_bwd(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                           const float* g_out, int64_t n, float* const* g_vols, float* g_pts, void* stream);
+int gens_lookup_volume_bwd2(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                            const float* g_out, const float* gg_pts, const float* const* gg_vols, int64_t n,
+                            float* gg_out, float* const* g_vols2, float* g_pts2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K3  lookup_volume(pts, mask_volumes, "nearest").any(-1)        (projector.py:231,240; Q6, Q7)
+ *   masks  HOST array of device pointers to (X,Y,Z) float masks; valid (N) uint8; vals (N, n_levels) or NULL.
+ * gens_ray_points fuses the point generation of render / render_core (implicit_surface.py:160-174, 367-371):
+ *   z (B, n); mid != 0 -> samples at z + 0.5*dist with the last dist = sample_dist (Q10)
+ *   pts (B*n, 3), valid (B*n) uint8.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_lookup_mask_nearest(const float* const* masks, const int* dims, int n_levels, const float* pts, int64_t n,
+                             uint8_t* valid, float* vals, void* stream);
+int gens_ray_points(const float* rays_o, const float* rays_d, const float* z, int64_t n_rays, int n_samples, int mid,
+                    float sample_dist, const float* const* masks, const int* dims, int n_levels, float* pts,
+                    uint8_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K4  lookup_feature + compute_angle                              (projector.py:278-349)
+ *   feats   HOST array of n_levels device pointers to (nv, H_l, W_l, 4) texels, hw HOST int[2*n_levels]
+ *   imgs    (nv, H_0, W_0, 4) texels of the RGB images (channel 3 = pad)
+ *   w2c, intr, c2w  (nv, 4, 4); view 0 is the reference view, sources are views 1..nv-1
+ *   out (N, S, 3 + 4*n_levels), ray_diff (N, S, 4), vis (N, S) uint8       S = nv - 1
+ * bwd: g_out -> g_feats[l] (nv, H_l, W_l, 4), g_imgs (nv, H_0, W_0, 4); accumulate; either may be NULL.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_lookup_feature_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs,
+                            const float* w2c, const float* intr, const float* c2w, int nv, const float* pts,
+                            int64_t n, float* out, float* ray_diff, uint8_t* vis, void* stream);
+int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const float* intr, int nv,
+                            const float* pts, const float* g_out, int64_t n, float* const* g_feats, float* g_imgs,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K5 + K6  ImplicitSurface.up_sample + sample_pdf(det=True)      (implicit_surface.py:14-44, 60-109)
+ *   one wavefront per ray; z, sdf (B, n) with n <= 128; inv_s = 64 * 2^round; n_new <= 64
+ *   z_new (B, n_new); pts_new (B*n_new, 3) and valid_new (B*n_new) uint8 feed the next SDF evaluation (:117-121).
+ * K7  cat_z_vals: sorted merge of (z, sdf) with (z_new, sdf_new)  (:111-133); sdf / sdf_new / sdf_out may be NULL
+ *   together (the `last` round).  n + n_new <= 128.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t n_rays, int n,
+                  int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, float* z_new,
+                  float* pts_new, uint8_t* valid_new, void* stream);
+int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, int64_t n_rays,
+                       int n, int n_new, float* z_out, float* sdf_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K8  render_core compositing                                     (implicit_surface.py:160-168, 202-303)
+ *   per-sample inputs (B, n[, 3]); n <= 128; voxel_mask (B*n) uint8; src_vis (B*n, S) uint8 or NULL
+ *   smooth may be NULL (inference).  rot = inverse(c2ws[0,:3,:3]) (3,3) HOST floats passed by value as 9 floats
+ *   inv_s: DEVICE pointer to one float (already clipped, :206); z_max: DEVICE pointer to max(z) (:301)
+ *   per-ray outputs: color (B,3) normal (B,3) depth (B) wsum (B) wmax (B) valid (B) uint8 mid_in (B)
+ *                    sdf_depth (B) z_cross (B) [clamped, :300-302] cross_idx (B) int32
+ *                    eik_num (B) eik_den (B) smooth_vec (B,3)
+ *   per-sample outputs: weights (B,n) inside (B,n)
+ * bwd: cotangents (NULL = zero) g_color (B,3) g_normal (B,3) g_depth (B) g_weights (B,n) g_wsum (B) g_eik_num (B)
+ *      g_smooth_vec (B,3) g_z_cross (B)  ->  g_sdf (B,n) g_grad (B,n,3) g_col (B,n,3) g_smooth (B,n,3 or NULL)
+ *      g_inv_s (B) per-ray partials (sum them).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *rays_o, *rays_d, *z, *sdf, *grad, *color, *smooth;
+    const uint8_t *voxel_mask, *src_vis;
+    const float *inv_s, *z_max;
+    int64_t n_rays;
+    int n, n_src;
+    float sample_dist, cos_anneal;
+    float rot[9];
+} gens_composite_in;
+
+typedef struct {
+    float *color, *normal, *depth, *wsum, *wmax, *mid_in, *sdf_depth, *z_cross, *eik_num, *eik_den, *smooth_vec;
+    uint8_t* valid;
+    int32_t* cross_idx;
+    float *weights, *inside;
+} gens_composite_out;
+
+typedef struct {
+    const float *g_color, *g_normal, *g_depth, *g_weights, *g_wsum, *g_eik_num, *g_smooth_vec, *g_z_cross;
+    const float* weights;      /* forward output */
+    const int32_t* cross_idx;  /* forward output */
+    const float* smooth_vec;   /* forward output */
+    float *g_sdf, *g_grad, *g_col, *g_smooth, *g_inv_s;
+} gens_composite_grad;
+
+int gens_composite_fwd(const gens_composite_in* in, const gens_composite_out* out, void* stream);
+int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)
+ *   image (H, W, C_pad) texels of one view; xy (P, 2) PIXEL coordinates (the normalise/un-normalise pair of
+ *   :404-405 and align_corners=True cancel); out (P, C).  bwd: g_out (P, C) -> g_xy (P, 2), overwritten.
+ *   gens_upsample2d_into restates F.interpolate(mode="bilinear") (implicit_surface.py:316-325) writing channels
+ *   [c_off, c_off+C) of a (n, H, W, C_pad_dst) texel tensor from src (n, C, hs, ws) NCHW.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_patch_sample_fwd(const float* image, int h, int w, int c, const float* xy, int64_t p, float* out,
+                          void* stream);
+int gens_patch_sample_bwd(const float* image, int h, int w, int c, const float* xy, const float* g_out, int64_t p,
+                          float* g_xy, void* stream);
+int gens_upsample2d_into(const float* src, int n, int c, int hs, int ws, float* dst, int h, int w, int c_pad_dst,
+                         int c_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K10  tv_regularization, one level per call                      (implicit_surface.py:135-150)
+ *   vol (4, X, Y, Z), mask (X, Y, Z); partial (n_blocks, 4) per-block sums [tx_num, ty_num, tz_num, mx_count]
+ *   (n_blocks = gens_tv_blocks(x*y*z)); the host finishes sqrt((tx+ty+tz)/(count+1e-8)) * 0.5^level (Q13).
+ * bwd: g_vol (4,X,Y,Z) = coef * d(tx_num+ty_num+tz_num)/d vol, overwritten; coef = g * 0.5^level / (2*tv*(count+1e-8)).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_tv_blocks(int64_t n_voxels);
+int gens_tv_fwd(const float* vol, const float* mask, int x, int y, int z, float* partial, void* stream);
+int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float coef, float* g_vol, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K11  the lattice of extract_geometry                            (implicit_surface.py:407-418)
+ *   pts (count, 3): lattice points first .. first+count-1 of a res^3 grid in x-major order, coordinates equal to
+ *   torch.linspace(bmin, bmax, res).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int res, int64_t first, int64_t count,
+                        float* pts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENS_HIP_H */

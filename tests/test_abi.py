@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol that
+include/gens_hip.h declares; the ctypes table mirrors the header; the product package never touches oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gens_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gens_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    path = os.path.join(ROOT, "gens_amd", "csrc", "libgens_hip.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.dirname(path), "-j4"])
+    return path
+
+
+def test_header_declares_the_hot_path():
+    names = declared_functions()
+    for must in ["gens_volume_build_fwd", "gens_volume_build_bwd", "gens_lookup_volume_fwd", "gens_lookup_volume_bwd",
+                 "gens_lookup_volume_bwd2", "gens_lookup_mask_nearest", "gens_lookup_feature_fwd", "gens_lookup_feature_bwd",
+                 "gens_upsample", "gens_merge_samples", "gens_composite_fwd", "gens_composite_bwd", "gens_patch_sample_fwd",
+                 "gens_patch_sample_bwd", "gens_tv_fwd", "gens_tv_bwd", "gens_lattice_points"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in gens_hip.h but not exported"
+    lib.gens_abi_version.restype = ctypes.c_int
+    assert lib.gens_abi_version() == 1
+
+
+def test_ctypes_table_covers_header(libpath):
+    from gens_amd import lib as L
+    declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks"}
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    L.load()
+
+
+def test_argument_errors_are_reported_without_a_gpu(libpath):
+    """Argument validation happens before any launch, so it can be exercised on the CPU box."""
+    from gens_amd import lib as L
+    lib = L.load()
+    rc = lib.gens_volume_build_fwd(None, None, None, 1.0, 3, 30, 40, 16, 1, None, None, None)
+    assert rc == -1 and b"null" in lib.gens_last_error()
+    rc = lib.gens_merge_samples(None, None, None, None, 4, 120, 16, None, None, None)
+    assert rc == -2
+    with pytest.raises(RuntimeError):
+        L.call("gens_tv_fwd", None, None, 0, 0, 0, None, None)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gens_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_product_fails_loudly_without_device_tensors(libpath):
+    import torch
+    from gens_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.lookup_mask(torch.zeros(4, 3), [torch.ones(1, 1, 4, 4, 4)])

@@ -1,0 +1,359 @@
+"""GPU parity: every HIP kernel (through the C ABI, via gens_amd.ops) against the reference's golden vectors and
+against the CPU oracle on seeded inputs.  Tolerances: float32 round-off (1e-5 abs/rel unless a comment says why)."""
+import pytest
+import torch
+
+from oracle import gens_oracle as K
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(t):
+    if isinstance(t, (list, tuple)):
+        return [dev(x) for x in t]
+    return t.cuda()
+
+
+def close(a, b, atol=1e-5, rtol=1e-5, what="", frac=0.0):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if a.numel() == 0:
+        return
+    bad = (a - b).abs() > atol + rtol * b.abs()
+    assert bad.float().mean().item() <= frac, f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {(a - b).abs().max().item():.3e}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gens_amd import ops
+    return ops
+
+
+# --------------------------------------------------------------------------------------------------- K1
+def test_k1_volume_golden_c1(ops, golden):
+    g = golden("g1a_volume_c1")
+    feat = dev(g["feat"]).requires_grad_(True)
+    v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [16])
+    close(v[0], g["volume"], atol=5e-5, rtol=1e-4, what="volume")  # var = E[x^2]-E[x]^2 cancels
+    close(m[0], g["mask"], atol=0, rtol=0, what="mask")
+    (v[0] * dev(g["cot"])).sum().backward()
+    close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat")
+
+
+def test_k1_volume_golden_multiscale(ops, golden):
+    g = golden("g1b_volume_ms")
+    dims = [int(d) for d in g["dims"]]
+    feats = [dev(g[f"feat{i}"]).requires_grad_(True) for i in range(3)]
+    v, m = ops.volume_build(feats, dev(g["intrs"]), dev(g["c2ws"]), dims)
+    for i in range(3):
+        close(v[i], g[f"volume{i}"], atol=5e-5, rtol=1e-4, what=f"volume{i}")
+        close(m[i], g[f"mask{i}"], atol=0, rtol=0, what=f"mask{i}")
+    sum((a * dev(g[f"cot{i}"])).sum() for i, a in enumerate(v)).backward()
+    for i in range(3):
+        close(feats[i].grad, g[f"gfeat{i}"], atol=5e-5, what=f"gfeat{i}")
+
+
+def test_k1_volume_vs_oracle_480x640(ops):
+    from gens_amd import synthetic
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=3)
+    # band-limited features (period >= 40 px): white noise has O(1)/px gradients, which turns the 1e-4 px float32
+    # uncertainty of a projected coordinate near x=640 into 1e-3 value differences between ANY two implementations
+    for i, f in enumerate(sc["features"]):
+        nv, c, h, w = f.shape
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        ph = torch.arange(nv * c, dtype=torch.float32).reshape(nv, c, 1, 1)
+        sc["features"][i] = torch.sin(xx * (0.15 * 2 ** i / (1 + ph % 3)) + yy * (0.11 * 2 ** i) + ph) * (1 + 0.1 * ph)
+    dims = [48, 32, 24, 16, 8]
+    ref_v, ref_m = K.volume_build(sc["features"], sc["intrs"], sc["c2ws"], dims)
+    v, m = ops.volume_build(dev(sc["features"]), dev(sc["intrs"]), dev(sc["c2ws"]), dims)
+    for i in range(5):
+        # a voxel projecting within an ulp of the image border may flip visibility in one view
+        close(m[i], ref_m[i], atol=0, rtol=0, what=f"mask{i}", frac=1e-4)
+        close(v[i], ref_v[i], atol=5e-5, rtol=1e-4, what=f"volume{i}", frac=1e-4)
+
+
+# --------------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("packed", [False, True])
+def test_k2_lookup_golden(ops, golden, packed):
+    g = golden("g2_lookup")
+    vols = [dev(g[f"vol{i}"]) for i in range(3)]
+    pts = dev(g["pts"]).requires_grad_(True)
+    if packed:
+        vol_arg = ops.VolumeSet.packed(vols)
+    else:
+        vols = [v.requires_grad_(True) for v in vols]
+        vol_arg = vols
+    y = ops.lookup_volume(pts, vol_arg)
+    close(y, g["feats"], what="fwd")
+    go = dev(g["gO"]).requires_grad_(True)
+    targets = [pts] if packed else [pts] + vols
+    grads = torch.autograd.grad(y, targets, go, create_graph=True)
+    close(grads[0], g["gP"], atol=2e-5, what="gP")
+    if not packed:
+        for i in range(3):
+            close(grads[1 + i], g[f"gV{i}"], atol=2e-5, what=f"gV{i}")
+    outs = torch.autograd.grad(grads[0], [go, pts] + ([] if packed else vols), dev(g["ggG"]))
+    close(outs[0], g["ggO"], atol=5e-5, what="ggO")
+    close(outs[1], g["gP2"], atol=2e-4, rtol=1e-4, what="gP2")
+    if not packed:
+        for i in range(3):
+            close(outs[2 + i], g[f"gV2_{i}"], atol=5e-5, what=f"gV2_{i}")
+
+
+def test_k2_second_order_with_volume_cotangent_vs_oracle(ops):
+    """grad2_3d's `grad2_grad_input` branch (gridsample_cuda.cu:345, 449-452): cotangent on the volume gradient."""
+    g = torch.Generator().manual_seed(7)
+    dims = [9, 6]
+    vols = [torch.randn(1, 4, d, d, d, generator=g) for d in dims]
+    pts = torch.rand(500, 3, generator=g) * 2.4 - 1.2
+    go = torch.randn(500, 8, generator=g)
+    ggp = torch.randn(500, 3, generator=g)
+    ggv = [torch.randn(1, 4, d, d, d, generator=g) for d in dims]
+    ref = K.lookup_volume_bwd2(ggv, ggp, go, vols, pts)
+    dv = [dev(v).requires_grad_(True) for v in vols]
+    dp = dev(pts).requires_grad_(True)
+    dgo = dev(go).requires_grad_(True)
+    grads = torch.autograd.grad(ops.lookup_volume(dp, dv), [dp] + dv, dgo, create_graph=True)
+    phi = (grads[0] * dev(ggp)).sum() + sum((a * dev(b)).sum() for a, b in zip(grads[1:], ggv))
+    outs = torch.autograd.grad(phi, [dgo, dp] + dv)
+    close(outs[0], ref[0], atol=5e-5, what="ggO")
+    close(outs[1], ref[2], atol=3e-4, rtol=1e-4, what="gP2")
+    for i in range(2):
+        close(outs[2 + i], ref[1][i], atol=5e-5, what=f"gV2_{i}")
+
+
+def test_k2_lookup_large_vs_oracle(ops):
+    g = torch.Generator().manual_seed(8)
+    dims = [64, 32, 16, 8, 4]
+    vols = [0.1 * torch.randn(1, 4, d, d, d, generator=g) for d in dims]
+    pts = torch.rand(20000, 3, generator=g) * 2.2 - 1.1
+    ref = K.lookup_volume(vols, pts)
+    close(ops.lookup_volume(dev(pts), dev(vols)), ref, what="planar")
+    close(ops.lookup_volume(dev(pts), ops.VolumeSet.packed(dev(vols))), ref, what="packed")
+    assert ops.lookup_volume(dev(pts[:0]), dev(vols)).shape == (0, 20)   # empty input
+
+
+# --------------------------------------------------------------------------------------------------- K3
+def test_k3_nearest_golden(ops, golden):
+    g = golden("g3_nearest")
+    masks = [dev(g[f"mask{i}"]) for i in range(3)]
+    valid, vals = ops.lookup_mask(dev(g["pts"]), masks, return_values=True)
+    close(vals, g["val"], atol=0, rtol=0, what="values")
+    assert torch.equal(valid.cpu(), g["any"])
+
+
+def test_k3_ray_points_vs_oracle(ops):
+    from gens_amd import synthetic
+    g = torch.Generator().manual_seed(9)
+    sc = synthetic.make_scene(nv=3, h=48, w=64, n_levels=1, seed=4)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 48, 64, step=4)
+    masks = [(torch.rand(1, 1, d, d, d, generator=g) > 0.4).float() for d in (32, 16, 8)]
+    z = torch.sort(torch.rand(ro.shape[0], 37, generator=g) * 2.2 + 1.1, -1)[0]
+    for mid in (False, True):
+        if mid:
+            dist = torch.cat([z[:, 1:] - z[:, :-1], torch.full((z.shape[0], 1), 1 / 32)], -1)
+            zz = z + dist * 0.5
+        else:
+            zz = z
+        ref_pts = (ro[:, None] + rd[:, None] * zz[..., None]).reshape(-1, 3)
+        pts, valid = ops.ray_points(dev(ro), dev(rd), dev(z), dev(masks), mid=mid, sample_dist=1 / 32)
+        close(pts, ref_pts, atol=1e-6, what="pts")
+        ref_valid = K.point_valid(masks, pts.cpu())
+        assert torch.equal(valid.cpu(), ref_valid)
+
+
+# --------------------------------------------------------------------------------------------------- K4
+def test_k4_lookup_feature_golden(ops, golden):
+    g = golden("g4_feature")
+    feats = [dev(g[f"feat{i}"]).requires_grad_(True) for i in range(5)]
+    imgs = dev(g["imgs"]).requires_grad_(True)
+    views = ops.SceneViews(imgs, dev(g["intrs"]), dev(g["c2ws"]), feats)
+    fv, rd, mk = ops.lookup_feature(dev(g["pts"]), views)
+    assert torch.equal(mk.cpu(), g["mask"])
+    close(rd, g["ray_diff"], atol=2e-5, what="ray_diff")
+    close(fv, g["feat_views"], atol=2e-5, rtol=1e-4, what="feat_views")
+    grads = torch.autograd.grad((fv * dev(g["cot"])).sum(), feats + [imgs])
+    for i in range(5):
+        close(grads[i], g[f"gfeat{i}"], atol=1e-4, what=f"gfeat{i}")
+    close(grads[5], g["gimgs"], atol=1e-4, what="gimgs")
+
+
+def test_k4_ragged_and_empty(ops, golden):
+    g = golden("g4_feature")
+    feats = [dev(g[f"feat{i}"]) for i in range(5)]
+    views = ops.SceneViews(dev(g["imgs"]), dev(g["intrs"]), dev(g["c2ws"]), feats)
+    for n in (0, 1, 85, 256):     # 85*3 rows is not a multiple of the 256-row block
+        fv, rd, mk = ops.lookup_feature(dev(g["pts"][:n]), views)
+        close(fv, g["feat_views"][:n], atol=2e-5, rtol=1e-4, what=f"n={n}")
+        assert torch.equal(mk.cpu(), g["mask"][:n])
+
+
+# --------------------------------------------------------------------------------------------------- K5-K7
+def test_k5_k7_golden(ops, golden):
+    g = golden("g5_upsample")
+    masks = [dev(g[f"mask{i}"]) for i in range(3)]
+    ro, rd = dev(g["rays_o"]), dev(g["rays_d"])
+    for r in range(4):
+        zn, pts_new, valid_new = ops.upsample(ro, rd, dev(g[f"z{r}"]), dev(g[f"sdf{r}"]), 16, masks, 64 * 2 ** r)
+        close(zn, g[f"znew{r}"], atol=5e-5, what=f"z_new round {r}")
+        ref_pts = (g["rays_o"][:, None] + g["rays_d"][:, None] * zn.cpu()[..., None]).reshape(-1, 3)
+        close(pts_new, ref_pts, atol=1e-6, what="pts_new")
+        assert torch.equal(valid_new.cpu(), K.point_valid([g[f"mask{i}"] for i in range(3)], pts_new.cpu()))
+        zc, _ = ops.merge_samples(dev(g[f"z{r}"]), dev(g[f"znew{r}"]))
+        close(zc, g[f"zcat{r}"], atol=0, rtol=0, what="merged z")
+
+
+def test_k7_merge_with_sdf_and_ties_vs_oracle(ops):
+    g = torch.Generator().manual_seed(11)
+    for n, n_new in ((64, 16), (112, 16), (5, 3), (100, 28)):
+        z = torch.sort(torch.rand(9, n, generator=g), -1)[0]
+        zn = torch.sort(torch.rand(9, n_new, generator=g), -1)[0]
+        zn[0, :2] = z[0, 3]            # ties between old and new, and among new
+        zn[1] = z[1, -1] + 1.0         # all new samples after the last old one
+        zn[2] = z[2, 0] - 1.0          # all before
+        zn[0] = torch.sort(zn[0])[0]
+        s, sn = torch.randn(9, n, generator=g), torch.randn(9, n_new, generator=g)
+        rz, rs = K.merge_samples(z, zn, s, sn)
+        oz, os_ = ops.merge_samples(dev(z), dev(zn), dev(s), dev(sn))
+        close(oz, rz, atol=0, rtol=0, what="z")
+        close(os_, rs, atol=0, rtol=0, what="sdf")
+
+
+# --------------------------------------------------------------------------------------------------- K8
+def _composite_case(b, n, s, seed, smooth=True):
+    from gens_amd import synthetic
+    g = torch.Generator().manual_seed(seed)
+    sc = synthetic.make_scene(nv=s + 1, h=48, w=64, n_levels=1, seed=seed)
+    pix = torch.stack([torch.randint(0, 64, (b,), generator=g), torch.randint(0, 48, (b,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 48, 64, pixels=pix)
+    z = torch.sort(torch.rand(b, n, generator=g) * 2.3 + 1.1, -1)[0]
+    mid = (ro[:, None] + rd[:, None] * z[..., None])
+    vm = (torch.rand(b, n, generator=g) > 0.25).float()
+    vm[0] = 0                       # a ray with no valid sample at all
+    vm[1] = 1
+    sdf = torch.linalg.norm(mid, dim=-1) - 0.55 + 0.03 * torch.randn(b, n, generator=g)
+    sdf = torch.where(vm > 0, sdf, torch.full_like(sdf, 100.0))
+    grad = torch.nn.functional.normalize(mid, dim=-1) + 0.2 * torch.randn(b, n, 3, generator=g)
+    grad = grad * vm[..., None]
+    col = torch.rand(b, n, 3, generator=g) * vm[..., None]
+    sm = torch.randn(b, n, 3, generator=g) * vm[..., None] if smooth else None
+    vis = (torch.rand(b, n, s, generator=g) > 0.3) & (vm[..., None] > 0)
+    return dict(ro=ro, rd=rd, z=z, sdf=sdf, grad=grad, col=col, sm=sm, vm=vm, vis=vis, c2w=sc["c2ws"][0])
+
+
+@pytest.mark.parametrize("n,cos_anneal,inv_s", [(128, 0.5, 20.0), (128, 1.0, 300.0), (70, 0.0, 64.0)])
+def test_k8_composite_fwd_bwd_vs_oracle(ops, n, cos_anneal, inv_s):
+    c = _composite_case(b=37, n=n, s=3, seed=20 + n)
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    # oracle
+    o_in = [leaf(c["sdf"]), leaf(c["grad"]), leaf(c["sm"]), leaf(c["col"]), torch.tensor(inv_s, requires_grad=True)]
+    ref = K.composite(c["ro"], c["rd"], c["z"], 1 / 32, o_in[0], o_in[1], o_in[2], o_in[3], c["vm"], c["vis"], o_in[4], cos_anneal, c["c2w"])
+    # HIP
+    d_in = [leaf(dev(c["sdf"])), leaf(dev(c["grad"])), leaf(dev(c["sm"])), leaf(dev(c["col"])), torch.tensor([inv_s], device="cuda", requires_grad=True)]
+    out = ops.composite(dev(c["ro"]), dev(c["rd"]), dev(c["z"]), 1 / 32, d_in[0], d_in[1], d_in[2], d_in[3], dev(c["vm"]) > 0,
+                        dev(c["vis"]), d_in[4], cos_anneal, dev(c["c2w"]))
+    b = c["z"].shape[0]
+    close(out["color"], ref["color_fine"], atol=2e-5, rtol=1e-4, what="color")
+    close(out["normal"], ref["normal"], atol=2e-5, rtol=1e-4, what="normal")
+    close(out["depth"], ref["render_depth"], atol=2e-5, rtol=1e-4, what="depth")
+    close(out["weights"], ref["weights"], atol=1e-5, rtol=1e-4, what="weights")
+    close(out["wsum"], ref["weight_sum"][:, 0], atol=2e-5, rtol=1e-4, what="wsum")
+    close(out["wmax"], ref["weight_max"][:, 0], atol=1e-5, rtol=1e-4, what="wmax")
+    close(out["inside"], ref["inside_sphere"], atol=0, rtol=0, what="inside")
+    assert torch.equal(out["valid"].cpu().bool(), ref["valid_mask"][:, 0])
+    close(out["mid_in"], ref["mid_inside_sphere"][:, 0], atol=0, rtol=0, what="mid_inside_sphere")
+    close(out["sdf_depth"], ref["sdf_depth"][:, 0], atol=2e-5, rtol=1e-4, what="sdf_depth")
+    ge = out["eik_num"].sum() / (out["eik_den"].sum() + 1e-5)
+    close(ge, ref["gradient_error"], atol=1e-5, rtol=1e-4, what="gradient_error")
+    se = torch.linalg.norm(out["smooth_vec"], dim=-1).abs().mean()
+    close(se, ref["smooth_error"], atol=1e-5, rtol=1e-4, what="smooth_error")
+    ref_zc = ((ref["pts_sdf0"][:, 0] - c["ro"]) * c["rd"]).sum(-1)
+    close(out["z_cross"], ref_zc, atol=1e-4, rtol=1e-4, what="z_cross")
+
+    # backward: one scalar made of every differentiable output
+    g = torch.Generator().manual_seed(5)
+    wc, wn, wd, ww, wz = (torch.randn(b, 3, generator=g), torch.randn(b, 3, generator=g), torch.randn(b, generator=g),
+                          torch.randn(b, n, generator=g), torch.randn(b, generator=g))
+    loss_ref = ((ref["color_fine"] * wc).sum() + (ref["normal"] * wn).sum() + (ref["render_depth"] * wd).sum() + (ref["weights"] * ww).sum()
+                + 0.3 * ref["weight_sum"].sum() + 2.0 * ref["gradient_error"] + 1.5 * ref["smooth_error"]
+                + (((ref["pts_sdf0"][:, 0] - c["ro"]) * c["rd"]).sum(-1) * wz).sum())
+    loss_hip = ((out["color"] * dev(wc)).sum() + (out["normal"] * dev(wn)).sum() + (out["depth"] * dev(wd)).sum()
+                + (out["weights"] * dev(ww)).sum() + 0.3 * out["wsum"].sum() + 2.0 * ge + 1.5 * se + (out["z_cross"] * dev(wz)).sum())
+    g_ref = torch.autograd.grad(loss_ref, o_in)
+    g_hip = torch.autograd.grad(loss_hip, d_in)
+    names = ["d/dsdf", "d/dgradients", "d/dsmooth", "d/dcolor", "d/dinv_s"]
+    for a, r_, nm in zip(g_hip, g_ref, names):
+        scale = float(r_.abs().max()) + 1e-12
+        # the cumprod backward divides by (1 - alpha + 1e-7): error grows where alpha ~ 1, so compare relative to the tensor's scale
+        close(a.reshape(r_.shape) / scale, r_ / scale, atol=2e-4, rtol=2e-3, what=nm)
+
+
+def test_k8_inference_without_smooth_or_visibility(ops):
+    c = _composite_case(b=9, n=128, s=2, seed=77, smooth=False)
+    ref = K.composite(c["ro"], c["rd"], c["z"], 1 / 32, c["sdf"], c["grad"], torch.zeros_like(c["grad"]), c["col"], c["vm"], c["vis"],
+                      torch.tensor(50.0), 1.0, c["c2w"])
+    out = ops.composite(dev(c["ro"]), dev(c["rd"]), dev(c["z"]), 1 / 32, dev(c["sdf"]), dev(c["grad"]), None, dev(c["col"]), dev(c["vm"]) > 0,
+                        None, torch.tensor([50.0], device="cuda"), 1.0, dev(c["c2w"]))
+    close(out["color"], ref["color_fine"], atol=2e-5, rtol=1e-4, what="color")
+    close(out["depth"], ref["render_depth"], atol=2e-5, rtol=1e-4, what="depth")
+    assert not out["valid"].any()
+
+
+# --------------------------------------------------------------------------------------------------- K9
+def test_k9_patch_sample_golden(ops, golden):
+    """The sampling half of surface_patch_warp: feed the oracle's homography coordinates, compare with the reference patches."""
+    g = golden("g7_patchwarp")
+    imgs = g["images"]
+    nv, c, h, w = imgs.shape
+    tex = ops.pack_nchw(dev(imgs))
+    ref, src = g["ref_val"], g["src_val"]
+    # coordinates of the reference patch: the pixel of each surface point + the 11x11 offsets
+    from oracle.gens_oracle import patch_warp
+    pts = g["pts"].clone().requires_grad_(True)
+    r_or, s_or = patch_warp(pts, g["normals"], imgs, g["intrs"], g["c2ws"])
+    close(r_or, ref, atol=2e-4, rtol=1e-4, what="oracle sanity")
+    from gens_amd.models.modules import projector
+    r_hip, s_hip = projector.surface_patch_warp(dev(g["pts"]).requires_grad_(True), dev(g["normals"]), (tex, c), dev(g["intrs"]), dev(g["c2ws"]))
+    close(r_hip, ref, atol=2e-4, rtol=1e-4, what="ref patch")
+    close(s_hip[:, 1:], src[:, 1:], atol=2e-3, rtol=1e-3, what="src patch")
+
+
+def test_k9_patch_warp_gradient_golden(ops, golden):
+    g = golden("g7_patchwarp")
+    from gens_amd.models.modules import projector
+    tex = ops.pack_nchw(dev(g["images"]))
+    pts = dev(g["pts"]).requires_grad_(True)
+    _, s_hip = projector.surface_patch_warp(pts, dev(g["normals"]), (tex, 12), dev(g["intrs"]), dev(g["c2ws"]))
+    gp = torch.autograd.grad((s_hip[:, 1:] * dev(g["cot"])[:, 1:]).sum(), pts)[0]
+    close(gp, g["gpts"], atol=2e-2, rtol=2e-3, what="d/dpts")
+
+
+def test_k9_warp_feature_upsampling_vs_oracle(ops):
+    g = torch.Generator().manual_seed(13)
+    lv = [torch.randn(3, 4, 48 >> i, 64 >> i, generator=g) for i in range(3)]
+    tex, c = ops.build_warp_features(dev(lv))
+    ref = torch.cat([lv[0], K.upsample_bilinear_half_pixel(lv[1], 48, 64), K.upsample_bilinear_half_pixel(lv[2], 48, 64)], 1)
+    close(tex.permute(0, 3, 1, 2)[:, :c], ref, atol=1e-6, what="warp feats")
+    torch_ref = torch.nn.functional.interpolate(lv[2], size=(48, 64), mode="bilinear")
+    close(tex.permute(0, 3, 1, 2)[:, 8:12], torch_ref, atol=1e-6, what="vs F.interpolate")
+
+
+# --------------------------------------------------------------------------------------------------- K10 / K11
+def test_k10_tv_golden(ops, golden):
+    g = golden("g8_tv")
+    vols = [dev(g["vol0"]).requires_grad_(True), dev(g["vol1"]).requires_grad_(True)]
+    tv = ops.tv_regularization(vols, [dev(g["mask0"]), dev(g["mask1"])])
+    close(tv, g["tv"], what="tv")
+    gv = torch.autograd.grad(tv, vols)
+    close(gv[0], g["gvol0"], atol=1e-6, what="gvol0")
+    close(gv[1], g["gvol1"], atol=1e-6, what="gvol1")
+
+
+def test_k11_lattice_vs_oracle(ops):
+    res = 37
+    ref = K.lattice_points([-1, -0.5, -1], [1, 1, 0.75], res)
+    pts = ops.lattice_points([-1, -0.5, -1], [1, 1, 0.75], res, 0, res ** 3, "cuda")
+    # torch.linspace on CPU is vectorised (base + step*lane), so its last bit depends on the host's SIMD width; 1 ulp
+    close(pts, ref, atol=1.2e-7, rtol=0, what="lattice")
+    part = ops.lattice_points([-1, -0.5, -1], [1, 1, 0.75], res, 1000, 4321, "cuda")
+    close(part, ref[1000:5321], atol=1.2e-7, rtol=0, what="lattice slice")
