@@ -1,0 +1,314 @@
+"""Mirror of the reference's models/modules/implicit_surface.py (NeuS-style renderer), re-organised around the
+per-ray HIP kernels of libgens_hip.so:
+
+    reference method (file:line)              here
+    ----------------------------------------  -----------------------------------------------------------------
+    sample_pdf            :14-44              fused into ops.upsample (K6)
+    up_sample             :60-109             ImplicitSurface.up_sample      -> ops.upsample (K5+K6, one wave per ray)
+    cat_z_vals            :111-133            ImplicitSurface.cat_z_vals     -> ops.merge_samples (K7)
+    tv_regularization     :135-150            ops.tv_regularization (K10)
+    render_core           :152-349            ImplicitSurface.render_core    -> K3, K2(+K2''), K4, K8, K9
+    render                :351-405            ImplicitSurface.render
+    extract_geometry      :407-427            ImplicitSurface.extract_geometry (device lattice, one D2H copy)
+    validate              :429-470            ImplicitSurface.validate
+    forward               :472-499            ImplicitSurface.forward
+
+Same constructor, method names, argument order and output keys as the reference, so models/gens.py drives it
+unchanged.  Host RNG draws (`torch.rand([B,1])`, `torch.rand([1024,3])` from the CPU generator, :256,:362) are
+kept in the reference's order so a seeded run renders the same jitter.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from .blending_network import BlendingNetwork
+from .projector import lookup_feature, surface_patch_warp
+from .sdf_network import SDFNetwork
+from .variance_network import SingleVarianceNetwork
+
+REFERENCE_CHUNK = 256      # rays per render() call in the reference's validate (:437-438)
+N_RANDOM_PTS = 1024        # sparse-SDF probe points per render_core call (:256)
+
+
+class Scene:
+    """Per-scene device state shared by every ray chunk: mask pyramid, packed volumes, texel views, warp features."""
+
+    def __init__(self, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws):
+        self.volumes = list(volumes)
+        self.mask_volumes = list(mask_volumes)
+        self.masks = ops.VolumeSet.masks(self.mask_volumes)
+        self.imgs, self.features, self.match_features = imgs, features, match_features
+        self.intrs, self.c2ws = intrs, c2ws
+        self.views = ops.SceneViews(imgs, intrs, c2ws, features)
+        self._packed = None
+        self._warp = {}
+
+    def volumes_nograd(self):
+        """Packed (X,Y,Z,4) texel copy for passes that never need d/dvolume (sampling rounds, inference)."""
+        if self._packed is None:
+            self._packed = ops.VolumeSet.packed(self.volumes)
+        return self._packed
+
+    def warp_features(self, use_match):
+        """cat([f0, up(f1), up(f2)]) texels, built once per scene (the reference rebuilds them per chunk, :313-326)."""
+        if use_match not in self._warp:
+            src = self.match_features if use_match else self.features
+            self._warp[use_match] = ops.build_warp_features(src[:3])
+        return self._warp[use_match]
+
+
+def reference_jitter(n_rays, chunk=REFERENCE_CHUNK):
+    """The (n_rays,1) stratified-jitter draws `validate` would make chunk by chunk, including the 1024x3 draw that
+    render_core makes in between (implicit_surface.py:256,362), so any chunking here renders the same image."""
+    out = []
+    for start in range(0, n_rays, chunk):
+        out.append(torch.rand([min(chunk, n_rays - start), 1]))
+        torch.rand([N_RANDOM_PTS, 3])
+    return torch.cat(out, 0)
+
+
+class ImplicitSurface(nn.Module):
+    def __init__(self, confs):
+        super().__init__()
+        self.n_samples = confs.get_int("render.n_samples")
+        self.n_importance = confs.get_int("render.n_importance")
+        self.up_sample_steps = confs.get_int("render.up_sample_steps")
+        self.perturb = confs.get_float("render.perturb")
+        self.sdf_network = SDFNetwork(**confs["sdf_network"])
+        self.color_network = BlendingNetwork(**confs["color_network"])
+        self.deviation_network = SingleVarianceNetwork(**confs["variance_network"])
+        self.val_chunk = 8192          # rays per chunk in validate(); rays are independent, so this is a free knob
+
+    # ----------------------------------------------------------------------------------------------------------
+    # masked SDF evaluation (Q7, Q8)
+    # ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _select(valid):
+        """Indices of valid points; if none is valid the first 10 are used (:123-124,176-177,372-373)."""
+        idx = torch.nonzero(valid, as_tuple=False)[:, 0]
+        if idx.numel() < 1:
+            idx = torch.arange(min(10, valid.numel()), device=valid.device)
+        return idx
+
+    def _masked_sdf(self, pts, valid, volumes):
+        idx = self._select(valid)
+        sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
+        sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
+        return sdf
+
+    # ----------------------------------------------------------------------------------------------------------
+    # hierarchical sampling
+    # ----------------------------------------------------------------------------------------------------------
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, mask_volumes, inv_s):
+        """Importance samples for a fixed inv_s (:60-109) -> (B, n_importance)."""
+        return ops.upsample(rays_o, rays_d, z_vals, sdf.reshape(z_vals.shape), n_importance, mask_volumes, inv_s)[0]
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, volumes, mask_volumes, last=False):
+        """Merge new depths (and, unless `last`, their SDF values) into the sorted sample list (:111-133)."""
+        if last:
+            return ops.merge_samples(z_vals, new_z_vals)[0], sdf
+        pts, valid = ops.ray_points(rays_o, rays_d, new_z_vals, mask_volumes)
+        new_sdf = self._masked_sdf(pts, valid, volumes).reshape(new_z_vals.shape)
+        return ops.merge_samples(z_vals, new_z_vals, sdf.reshape(z_vals.shape), new_sdf)
+
+    def tv_regularization(self, volume_feat_cas, volume_mask_cas=None):
+        if volume_mask_cas is None:
+            volume_mask_cas = [torch.ones_like(v[:, :1]) for v in volume_feat_cas]
+        return ops.tv_regularization(list(volume_feat_cas), list(volume_mask_cas))
+
+    @torch.no_grad()
+    def _sample_rays(self, rays_o, rays_d, z_vals, scene):
+        masks, vols = scene.masks, scene.volumes_nograd()
+        b = rays_o.shape[0]
+        pts, valid = ops.ray_points(rays_o, rays_d, z_vals, masks)
+        sdf = self._masked_sdf(pts, valid, vols).reshape(b, -1)
+        n_new = self.n_importance // self.up_sample_steps
+        for i in range(self.up_sample_steps):
+            z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64 * 2 ** i)
+            if i + 1 == self.up_sample_steps:
+                z_vals, _ = ops.merge_samples(z_vals, z_new)
+            else:
+                sdf_new = self._masked_sdf(pts_new, valid_new, vols).reshape(b, n_new)
+                z_vals, sdf = ops.merge_samples(z_vals, z_new, sdf, sdf_new)
+        return z_vals
+
+    # ----------------------------------------------------------------------------------------------------------
+    # render_core
+    # ----------------------------------------------------------------------------------------------------------
+    def render_core(self, rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
+                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None):
+        """Everything after sampling (:152-349).  `lean` (validate only) skips the quantities validate discards:
+        second derivatives, random-point SDF, TV, the surface-point gradient and the patch warp."""
+        if scene is None:
+            scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        b, n = z_vals.shape
+        dev = z_vals.device
+        need_vol_grad = torch.is_grad_enabled() and any(v.requires_grad for v in scene.volumes)
+        vols = scene.volumes if need_vol_grad else scene.volumes_nograd()
+
+        pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
+        idx = self._select(valid)
+        pts_v = pts[idx]
+
+        if lean:
+            with torch.enable_grad():
+                x = pts_v.clone().requires_grad_(True)
+                sdf_v = self.sdf_network.sdf(x, vols)
+                grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
+            sdf_v, smooth_v = sdf_v.detach(), None
+        else:
+            sdf_v = self.sdf_network(pts_v, vols)[:, :1]
+            grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
+        sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
+        gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
+        smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
+
+        feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
+        color_v = self.color_network(feat_views, ray_diff, vis_v)
+        sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
+        src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
+
+        inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
+        comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, sdf, gradients, smooth, sampled_color, valid, src_vis, inv_s,
+                             cos_anneal_ratio, c2ws[0])
+        gradients = gradients.reshape(b, n, 3)
+        out = {
+            "color_fine": comp["color"],
+            "render_depth": comp["depth"],
+            "normal": comp["normal"],
+            "weights": comp["weights"],
+            "weight_sum": comp["wsum"][:, None],
+            "weight_max": comp["wmax"][:, None],
+            "inside_sphere": comp["inside"],
+            "valid_mask": comp["valid"].bool()[:, None],
+            "mid_inside_sphere": comp["mid_in"][:, None],
+            "sdf_depth": comp["sdf_depth"][:, None],
+            "gradients": gradients,
+            "s_val": (1.0 / inv_s).expand(b * n, 1),
+            "gradient_error": comp["eik_num"].sum() / (comp["eik_den"].sum() + 1e-5),
+        }
+        if lean:
+            return out
+        out["smooth_error"] = torch.linalg.norm(comp["smooth_vec"], ord=2, dim=-1).abs().mean()
+
+        if pts_random is None:
+            pts_random = torch.rand([N_RANDOM_PTS, 3]).to(dev) * 2 - 1                     # CPU generator, :256
+        out["sparse_sdf"] = torch.cat([self.sdf_network.sdf(pts_random, vols), sdf])
+        out["tv_reg"] = self.tv_regularization(scene.volumes, scene.mask_volumes)
+
+        # surface point of the first sign change and the plane-induced patch warp (:288-328)
+        pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
+        g0, _ = self.sdf_network.gradient(pts_sdf0.reshape(-1, 3), vols)
+        g0 = g0.reshape(b, 1, 3)
+        g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
+        g0 = g0 / torch.where(g0_norm <= 0, torch.full_like(g0_norm, 1e-8), g0_norm)
+        normals_ref = (g0 @ c2ws[0, :3, :3]).detach()                                       # R^T n as row vectors
+        warp = scene.warp_features(use_match=not (step is None or step < 5))
+        out["ref_gray_val"], out["sampled_gray_val"] = surface_patch_warp(pts_sdf0, normals_ref, warp, intrs, c2ws)
+        return out
+
+    # ----------------------------------------------------------------------------------------------------------
+    # render
+    # ----------------------------------------------------------------------------------------------------------
+    def render(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, cos_anneal_ratio, step,
+               scene=None, lean=False, t_rand=None, pts_random=None):
+        if scene is None:
+            scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        b = len(rays_o)
+        dev = rays_o.device
+        rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
+        sample_dist = 2.0 / self.n_samples                                                  # unit-sphere assumption (:355)
+        steps = torch.linspace(0.0, 1.0, self.n_samples).to(dev)
+        z_vals = near.reshape(-1, 1) + (far - near).reshape(-1, 1) * steps[None, :]
+        z_vals = z_vals.expand(b, self.n_samples)
+        if self.perturb > 0:
+            if t_rand is None:
+                t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
+            z_vals = z_vals + (t_rand.to(dev) - 0.5) * 2.0 / self.n_samples
+        z_vals = z_vals.contiguous()
+        if self.n_importance > 0:
+            z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene)
+        return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
+                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random)
+
+    # ----------------------------------------------------------------------------------------------------------
+    # geometry + validation
+    # ----------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sdf_grid(self, volumes, bound_min, bound_max, resolution, chunk=1 << 21):
+        """u = -sdf on the resolution^3 lattice (:407-421), kept on the device."""
+        vols = volumes if isinstance(volumes, ops.VolumeSet) else ops.VolumeSet.packed(volumes)
+        dev = vols.tensors[0].device
+        total = resolution ** 3
+        u = torch.empty(total, device=dev)
+        for first in range(0, total, chunk):
+            count = min(chunk, total - first)
+            pts = ops.lattice_points(bound_min.tolist(), bound_max.tolist(), resolution, first, count, dev)
+            u[first:first + count] = -self.sdf_network.sdf(pts, vols)[:, 0]
+        return u.reshape(resolution, resolution, resolution)
+
+    def extract_geometry(self, volumes, bound_min, bound_max, resolution, threshold):
+        u = self.sdf_grid(volumes, bound_min, bound_max, resolution).cpu().numpy()          # one D2H copy (reference: 512)
+        try:
+            import mcubes
+        except ImportError as e:                                                             # iso-surfacing is §8(f) rank 3
+            raise RuntimeError("PyMCubes is needed for marching cubes (requirements.txt:11); the SDF lattice itself is "
+                               "available from ImplicitSurface.sdf_grid") from e
+        vertices, triangles = mcubes.marching_cubes(u, threshold)
+        b_max, b_min = bound_max.detach().cpu().numpy(), bound_min.detach().cpu().numpy()
+        vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
+        return vertices, triangles
+
+    @torch.no_grad()
+    def validate(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, bound_min, bound_max,
+                 hw, cos_anneal_ratio=1.0, step=None, extract_geometry=True, mesh_resolution=512, threshold=0.0, scene=None):
+        outputs = {}
+        if scene is None:
+            scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        if extract_geometry:
+            outputs["vertices"], outputs["triangles"] = self.extract_geometry(scene.volumes_nograd(), bound_min, bound_max, mesh_resolution,
+                                                                              threshold)
+        height, width = int(hw[0]), int(hw[1])
+        n_rays = rays_o.shape[0]
+        t_rand = reference_jitter(n_rays) if self.perturb > 0 else None
+        rgb, normals, sdf_depth, render_depth = [], [], [], []
+        for s in range(0, n_rays, self.val_chunk):
+            e = min(s + self.val_chunk, n_rays)
+            r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                            cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if t_rand is None else t_rand[s:e])
+            rgb.append(r["color_fine"])
+            normals.append((r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1))
+            sdf_depth.append(r["sdf_depth"])
+            render_depth.append(r["render_depth"])
+        color_fine = torch.cat(rgb, 0).cpu()                                                # D2H once per image, not per chunk
+        normal_img = torch.cat(normals, 0).cpu().numpy()
+        rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())
+        outputs["color_fine"] = color_fine
+        outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
+        outputs["normal_img"] = (np.matmul(rot[None, :, :], normal_img[:, :, None]).reshape([height, width, 3]) * 128 + 128).clip(0, 255)
+        outputs["sdf_depth"] = torch.cat(sdf_depth, 0).cpu().numpy().reshape([height, width])
+        outputs["render_depth"] = torch.cat(render_depth, 0).cpu().numpy().reshape([height, width])
+        return outputs
+
+    def forward(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):
+        imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
+        rays_o, rays_d, near, far = ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"]
+        scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        if mode == "val":
+            outputs = self.validate(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                    ipts["bound_min"], ipts["bound_max"], ipts["hw"], cos_anneal_ratio, step, scene=scene)
+        else:
+            outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                  cos_anneal_ratio, step, scene=scene)
+        if "pseudo_pts" in ipts:
+            pseudo_pts = ipts["pseudo_pts"].float()
+            valid = ops.lookup_mask(pseudo_pts, scene.masks)
+            if int(valid.sum()) < 1:
+                raise RuntimeError("No valid pseudo pts!")                                  # the reference raises a str (:494-495)
+            idx = torch.nonzero(valid)[:, 0]
+            vols = scene.volumes if any(v.requires_grad for v in scene.volumes) else scene.volumes_nograd()
+            pseudo_sdf = torch.zeros_like(pseudo_pts[:, :1]).index_put((idx,), self.sdf_network.sdf(pseudo_pts[idx], vols))
+            outputs["pseudo_sdf"] = pseudo_sdf
+        return outputs
