@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the GenS hot path on MI355X: SDF ray-samples / second (BASELINE.json metric).
+
+One step = one scene of BASELINE config[1] ("5-view 480x640, full 3-scale volumes, inference"):
+    K1  cost-volume build for the 5-view feature pyramid, volume_dims = [256, 128, 64]
+    +   rendering of every pixel ray of the reference view (307 200 rays x 128 final samples) through
+        ImplicitSurface.validate's path: hierarchical sampling (4 rounds), SDF MLP + first derivatives,
+        source-view feature look-up, blending MLP, compositing -> colour / depth / normal / SDF-depth buffers.
+Inputs are synthetic (gens_amd/synthetic.py: DTU-like cameras, random images / features, seeded geometric-init
+MLPs) and are resident in HBM before the timed region.  The 2-D CNN and the 3-D U-Net are outside the accelerated
+path: the renderer reads a synthetic stand-in for the regularised volumes, while K1 still
+runs inside every timed step and supplies the visibility masks.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (one scene per rank, weak scaling)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant HIP kernel, HIP-event
+timed inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded ray sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--rays", type=int, default=480 * 640, help="rays per step and rank (default: the full 480x640 image)")
+    p.add_argument("--chunk", type=int, default=32768, help="rays per render() chunk")
+    p.add_argument("--dims", type=int, nargs="+", default=[256, 128, 64])
+    p.add_argument("--views", type=int, default=5)
+    p.add_argument("--cpu-rays", type=int, default=96, help="rays of the CPU-oracle baseline sample (0 = skip)")
+    p.add_argument("--no-kernel-timing", action="store_true")
+    return p.parse_args()
+
+
+def build_model(dims, device):
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface
+    from gens_amd.models.modules.volume import Volume
+    torch.manual_seed(0)
+    conf = gens_model_conf(volume_dims=tuple(dims), n_feature_levels=5)
+    surf = ImplicitSurface(conf["implicit_surface"]).to(device).eval()
+    vol = Volume(conf["volume"])
+    return surf, vol
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://")      # 'nccl' is RCCL on ROCm
+
+    from gens_amd import lib as L
+    from gens_amd import synthetic
+    from gens_amd.models.modules.implicit_surface import Scene
+    L.load()
+
+    h, w = 480, 640
+    sc = synthetic.make_scene(nv=args.views, h=h, w=w, n_levels=5, seed=rank)    # one scene per rank
+    imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
+    feats = [f.to(dev) for f in sc["features"]]
+    near, far = sc["near"].to(dev), sc["far"].to(dev)
+    vols = [v.to(dev) for v in synthetic.make_volumes(args.dims, seed=100 + rank)]
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w)
+    rays_o, rays_d = rays_o[:args.rays].to(dev), rays_d[:args.rays].to(dev)
+    n_rays = rays_o.shape[0]
+    surf, volume = build_model(args.dims, dev)
+    surf.val_chunk = args.chunk
+    n_final = surf.n_samples + surf.n_importance
+    hw = (1, n_rays)
+
+    state = {}
+
+    def step():
+        with torch.no_grad():
+            cost_volumes, masks = volume.agg_mean_var(feats, intrs, c2ws)                # K1 (cost volumes feed the U-Net upstream)
+            scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
+            out = surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, hw,
+                                extract_geometry=False, scene=scene)
+        if dist is not None:                                                             # config 4: gather of rendered buffers
+            buf = torch.cat([out["color_fine"].reshape(-1, 3), torch.from_numpy(out["render_depth"]).reshape(-1, 1),
+                             torch.from_numpy(out["sdf_depth"]).reshape(-1, 1)], 1).to(dev)
+            gathered = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(gathered, buf)
+        state["out"], state["masks"], state["cost"] = out, masks, cost_volumes
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(1234)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_kernel_timing:
+        L.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernels = L.profile_end() if not args.no_kernel_timing else {}
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_ray_samples = world * n_rays * n_final * args.steps
+    value = total_ray_samples / elapsed
+    # sanity of the rendered buffers (a bench that renders garbage is not a bench)
+    col = state["out"]["color_fine"]
+    assert torch.isfinite(col).all() and float(state["masks"][0].mean()) > 0.01
+
+    roofline = None
+    table = {}
+    if kernels:
+        hip_ms = sum(k["ms"] for k in kernels.values())
+        for name, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
+            table[name] = {"launches": k["launches"], "ms_per_step": round(k["ms"] / args.steps, 3),
+                           "algo_GBs": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1) if k["ms"] > 0 and k["bytes"] else None}
+        dom_name, dom = max(((n, k) for n, k in kernels.items() if k["bytes"]), key=lambda kv: kv[1]["ms"])
+        achieved = dom["bytes"] / 1e9 / (dom["ms"] / 1e3)
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                    "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
+                    "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
+
+    cpu = None
+    if world == 1 and args.cpu_rays > 0:
+        cpu = cpu_baseline(args, surf, sc, vols, state["masks"], n_final)
+
+    line = {
+        "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config[1]: 5-view 480x640, volume_dims=%s, inference of %d rays x %d samples per scene "
+                               "(K1 volume build + hierarchical sampling + SDF/blend MLPs + compositing); one scene per GPU"
+                               % (args.dims, n_rays, n_final),
+                   "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
+                   "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
+                   "parallelism": "scenes sharded across ranks, all_gather of rendered buffers" if world > 1 else "single GPU"},
+        "roofline": roofline, "cpu_baseline": cpu, "hip_kernels": table,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, surf, sc, vols, masks, n_final):
+    """The CPU oracle (restatement of the reference's render(), validated against its goldens) on a bounded sample."""
+    from oracle import render_oracle as R
+    n = args.cpu_rays
+    threads = torch.get_num_threads()
+    sd = {k: v.detach().cpu() for k, v in surf.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, 480 * 640, (n,), generator=g)
+    from gens_amd import synthetic
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
+    ro, rd = ro[idx], rd[idx]
+    cvols = [v.cpu() for v in vols]
+    cmasks = [m.cpu() for m in masks]
+    t_rand, pts_rand = torch.rand(n, 1, generator=g), torch.rand(1024, 3, generator=g) * 2 - 1
+    t0 = time.perf_counter()
+    R.render(sd, ro, rd, sc["near"], sc["far"], cvols, cmasks, sc["imgs"], sc["features"], sc["features"], sc["intrs"], sc["c2ws"], 1.0,
+             None, t_rand, pts_rand)
+    dt = time.perf_counter() - t0
+    return {"value": n * n_final / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "sample": "%d random rays of the same scene x %d samples through oracle.render_oracle.render "
+                      "(full render_core as the reference's validate runs it), %.1f s" % (n, n_final, dt)}
+
+
+if __name__ == "__main__":
+    main()

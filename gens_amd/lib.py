@@ -92,9 +92,40 @@ def load():
     return lib
 
 
-def call(name, *args):
+_profile = None   # None, or a list of (name, start_event, end_event, algorithmic_bytes)
+
+
+def profile_begin():
+    """Start recording a HIP event pair around every kernel launch (on the stream the kernel is enqueued on)."""
+    global _profile
+    _profile = []
+
+
+def profile_end():
+    """Stop recording; -> {kernel: {"launches", "ms", "bytes"}} (synchronises)."""
+    global _profile
+    rec, _profile = _profile or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, s, e, nbytes in rec:
+        d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+        d["launches"] += 1
+        d["ms"] += s.elapsed_time(e)
+        d["bytes"] += nbytes
+    return out
+
+
+def call(name, *args, nbytes=0):
+    """Invoke one C-ABI entry point; `nbytes` = algorithmic HBM bytes of this launch, for the roofline."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _profile is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args)
+        e.record()
+        _profile.append((name, s, e, int(nbytes)))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.gens_last_error().decode()}")
 

@@ -104,7 +104,7 @@ class _VolumeBuild(torch.autograd.Function):
         vol = torch.empty(1, 8, d, d, d, device=feat_tex.device, dtype=_f32)
         mask = torch.empty(1, 1, d, d, d, device=feat_tex.device, dtype=_f32)
         L.call("gens_volume_build_fwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
-               L.ptr(mask), L.stream())
+               L.ptr(mask), L.stream(), nbytes=nv * h * w * 16 + 36 * d ** 3)
         ctx.save_for_backward(feat_tex, w2c, intr)
         ctx.meta = (scale, d)
         ctx.mark_non_differentiable(mask)
@@ -148,7 +148,8 @@ class _Lookup(torch.autograd.Function):
         pts_c = _c(pts.detach().to(_f32))
         n = pts_c.shape[0]
         out = torch.empty(n, 4 * vs.n, device=pts.device, dtype=_f32)
-        L.call("gens_lookup_volume_fwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), n, L.ptr(out), L.stream())
+        L.call("gens_lookup_volume_fwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), n, L.ptr(out), L.stream(),
+               nbytes=n * (12 + 16 * vs.n))
         ctx.save_for_backward(pts, *vols)   # the INPUT tensors: the second backward must reach their producers
         ctx.layout = layout
         return out
@@ -171,7 +172,7 @@ class _LookupBwd(torch.autograd.Function):
         g_pts = torch.empty(n, 3, device=pts.device, dtype=_f32)
         g_vols = [torch.zeros_like(v) for v in vs.tensors] if want_vol else None
         L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), L.ptr(g_out_c), n, L.ptr_table(g_vols),
-               L.ptr(g_pts), L.stream())
+               L.ptr(g_pts), L.stream(), nbytes=n * (24 + 16 * vs.n))
         ctx.save_for_backward(g_out_c, pts_c, *vols)
         ctx.layout, ctx.want_vol = layout, want_vol
         if want_vol:
@@ -195,7 +196,7 @@ class _LookupBwd(torch.autograd.Function):
         gg_out = torch.empty_like(g_out)
         g_pts2 = torch.empty(n, 3, device=pts.device, dtype=_f32)
         L.call("gens_lookup_volume_bwd2", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), L.ptr(_c(gg_pts.detach())),
-               L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.stream())
+               L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.stream(), nbytes=n * (36 + 32 * vs.n))
         # outputs are plain tensors: third order through the sampler is dropped, as in the reference (cuda_gridsample.py:110-123)
         if want_vol:
             gv = tuple(g.reshape(v.shape) for g, v in zip(g_vols2, vols))
@@ -233,7 +234,7 @@ def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
     pts = torch.empty(b * n, 3, device=z.device, dtype=_f32)
     valid = torch.empty(b * n, device=z.device, dtype=torch.uint8)
     L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), ms.table,
-           ms.dim_table, ms.n, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream())
+           ms.dim_table, ms.n, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * n * 17 + b * 24)
     return pts, valid.bool()
 
 
@@ -254,7 +255,8 @@ class _LookupFeature(torch.autograd.Function):
         vis = torch.empty(n, s, device=pts.device, dtype=torch.uint8)
         feats = [_c(f.detach()) for f in feat_tex]
         L.call("gens_lookup_feature_fwd", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(imgs_tex.detach())), L.ptr(w2c), L.ptr(intr),
-               L.ptr(c2w), nv, L.ptr(pts), n, L.ptr(out), L.ptr(ray_diff), L.ptr(vis, torch.uint8), L.stream())
+               L.ptr(c2w), nv, L.ptr(pts), n, L.ptr(out), L.ptr(ray_diff), L.ptr(vis, torch.uint8), L.stream(),
+               nbytes=n * 12 + n * s * (4 * (3 + 4 * nl) + 17))
         ctx.save_for_backward(pts, w2c, intr)
         ctx.meta = (nv, hw, [f.shape for f in feat_tex], imgs_tex.shape)
         ctx.mark_non_differentiable(ray_diff, vis)
@@ -306,7 +308,7 @@ def upsample(rays_o, rays_d, z, sdf, n_new, masks, inv_s):
     pts_new = torch.empty(b * n_new, 3, device=z.device, dtype=_f32)
     valid = torch.empty(b * n_new, device=z.device, dtype=torch.uint8)
     L.call("gens_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), b, n, n_new, float(inv_s), ms.table,
-           ms.dim_table, ms.n, L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream())
+           ms.dim_table, ms.n, L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * (8 * n + 17 * n_new + 24))
     return z_new, pts_new, valid.bool()
 
 
@@ -317,7 +319,8 @@ def merge_samples(z, z_new, sdf=None, sdf_new=None):
     z_out = torch.empty(b, n + n_new, device=z.device, dtype=_f32)
     sdf_out = torch.empty_like(z_out) if sdf is not None else None
     L.call("gens_merge_samples", L.ptr(_c(z)), L.ptr(_c(sdf)) if sdf is not None else None, L.ptr(_c(z_new)),
-           L.ptr(_c(sdf_new)) if sdf_new is not None else None, b, n, n_new, L.ptr(z_out), L.ptr(sdf_out), L.stream())
+           L.ptr(_c(sdf_new)) if sdf_new is not None else None, b, n, n_new, L.ptr(z_out), L.ptr(sdf_out), L.stream(),
+           nbytes=b * (n + n_new) * (8 if sdf is None else 16))
     return z_out, sdf_out
 
 
@@ -360,7 +363,9 @@ class _Composite(torch.autograd.Function):
             setattr(co, k, L.ptr(t))
         co.valid = L.ptr(valid, torch.uint8)
         co.cross_idx = L.ptr(cross_idx, torch.int32)
-        L.call("gens_composite_fwd", C.byref(ci), C.byref(co), L.stream())
+        n_src = src_vis.shape[-1] if src_vis is not None else 0
+        L.call("gens_composite_fwd", C.byref(ci), C.byref(co), L.stream(),
+               nbytes=b * n * (4 + 4 + 12 + 12 + 1 + n_src + (12 if smooth is not None else 0) + 8) + b * 100)
         ctx.save_for_backward(sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, o["weights"], cross_idx,
                               o["smooth_vec"])
         ctx.meta = (sample_dist, cos_anneal, rot)
