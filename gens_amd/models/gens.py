@@ -65,7 +65,7 @@ class GenS(nn.Module):
         return groups
 
     def load_params_vol(self, path, device):
-        model = torch.load(path)["model"]
+        model = torch.load(path, weights_only=False)["model"]   # ParameterLists, as saved by runner.py:332-341
         self.volumes = model["volumes"].to(device)
         self.mask_volmes = model["mask_volmes"].to(device)
         self.features = model["features"].to(device)

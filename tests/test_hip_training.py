@@ -1,0 +1,164 @@
+"""GPU tests of the training path (BASELINE config 3 / 5): backward through the HIP look-up (first + second order),
+compositing, feature-warp, patch-warp and TV kernels; GenS.forward in train and fine-tune mode with stand-in CNNs."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss(out):
+    hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+    mfc = (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
+    return (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
+            + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + mfc + 0.1 * out["render_depth"].sum() + 0.05 * out["normal"].sum())
+
+
+def test_render_gradients_match_oracle(golden):
+    """d loss / d {SDF-MLP, colour-MLP, variance, volumes, feature maps} : HIP path vs the CPU oracle whose sampler is
+    truncated at second order exactly like the reference's Function pair (cuda_gridsample.py:110-123)."""
+    from oracle import render_oracle as R
+    from tests.test_hip_render import build_surface, scene_inputs
+    g = golden("g9a_render")
+    feats_c = [g[f"feat{i}"].clone().requires_grad_(True) for i in range(5)]
+    vols_c = [g[f"vol{i}"].clone().requires_grad_(True) for i in range(3)]
+    masks_c = [g[f"mask{i}"] for i in range(3)]
+    sd = {k[3:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+    pts_rand = g["draw_ptsrand"] * 2 - 1
+    ref = R.render(sd, g["rays_o"], g["rays_d"], g["near"], g["far"], vols_c, masks_c, g["imgs"], feats_c, feats_c, g["intrs"], g["c2ws"],
+                   0.5, None, g["draw_trand"], pts_rand, truncated=True, z=g["z_final"])
+    _loss(ref).backward()
+
+    surf = build_surface(g)
+    c = lambda t: t.cuda()  # noqa: E731
+    feats = [c(g[f"feat{i}"]).requires_grad_(True) for i in range(5)]
+    vols = [c(g[f"vol{i}"]).requires_grad_(True) for i in range(3)]
+    masks = [c(m) for m in masks_c]
+    out = surf.render_core(c(g["rays_o"]), c(g["rays_d"]), c(g["z_final"]), 2.0 / 64, vols, masks, feats, feats, c(g["imgs"]), c(g["intrs"]),
+                           c(g["c2ws"]), 0.5, None, pts_random=c(pts_rand))
+    _loss(out).backward()
+
+    top = max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+
+    def check(name, a, b, tol=2e-3):
+        a, b = a.detach().cpu(), b.detach().cpu()
+        # gradients that are zero by symmetry (e.g. the bias in front of a softmax) are pure round-off on both sides
+        scale = max(b.abs().max().item(), 1e-4 * top)
+        err = (a - b).abs().max().item() / scale
+        assert err < tol, f"{name}: relative-to-max error {err:.2e}"
+    for name, p in surf.named_parameters():
+        assert p.grad is not None, name
+        # single scalars (anti-alias temperature, variance) are sums of cancelling per-sample terms: compare loosely
+        check(name, p.grad, sd[name].grad, tol=2e-3 if p.numel() > 4 else 0.15)
+    for i in range(3):
+        check(f"volume{i}", vols[i].grad, vols_c[i].grad)
+    for i in range(5):
+        check(f"feature{i}", feats[i].grad, feats_c[i].grad)
+
+
+class TinyFeatureNet(nn.Module):
+    """Stand-in for the MnasNet encoder/decoder (out of scope): 5-level pyramid, 4 channels each."""
+
+    def __init__(self, confs):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Conv2d(3, 4, 3, padding=1) for _ in range(5)])
+
+    def forward(self, imgs):
+        outs, x = [], imgs
+        for i, conv in enumerate(self.convs):
+            outs.append(conv(x))
+            x = nn.functional.avg_pool2d(x, 2)
+        return outs
+
+
+class TinyRegNet(nn.Module):
+    """Stand-in for the 3-D U-Net (out of scope): one 1x1x1 conv per level, 8 -> 4 channels."""
+
+    def __init__(self, confs):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Conv3d(8, 4, 1) for _ in confs.get_list("d_out")])
+
+    def forward(self, volumes):
+        return [conv(v) for conv, v in zip(self.convs, volumes)]
+
+
+def _gens(dims=(16, 8, 4)):
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models import gens
+    gens.register_backbones(TinyFeatureNet, TinyRegNet)
+    torch.manual_seed(0)
+    return gens.GenS(gens_model_conf(volume_dims=dims)).cuda()
+
+
+def _inputs(n_rays=64, nv=4):
+    from gens_amd import synthetic
+    sc = synthetic.make_scene(nv=nv, h=48, w=64, n_levels=1, seed=5)
+    g = torch.Generator().manual_seed(2)
+    pix = torch.stack([torch.randint(4, 60, (n_rays,), generator=g), torch.randint(4, 44, (n_rays,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 48, 64, pixels=pix)
+    ipts = {"imgs": sc["imgs"], "intrs": sc["intrs"], "c2ws": sc["c2ws"], "rays_o": ro, "rays_d": rd, "near": sc["near"], "far": sc["far"],
+            "pseudo_pts": torch.rand(256, 3, generator=g) - 0.5}
+    return {k: v.cuda() for k, v in ipts.items()}
+
+
+def test_gens_train_step_backward_reaches_every_trainable_parameter():
+    model = _gens().train()
+    ipts = _inputs()
+    out = model("train", ipts, cos_anneal_ratio=0.3, step=1.0)
+    assert set(out) >= {"color_fine", "gradient_error", "sparse_sdf", "smooth_error", "tv_reg", "ref_gray_val", "sampled_gray_val",
+                        "mid_inside_sphere", "pseudo_sdf", "render_depth", "valid_mask", "weights", "gradients", "normal", "s_val",
+                        "weight_sum", "weight_max", "inside_sphere", "sdf_depth"}
+    loss = _loss(out) + out["pseudo_sdf"].abs().mean()
+    loss.backward()
+    for name, p in model.named_parameters():
+        if name.startswith("match_feature_network"):
+            assert p.grad is None                      # frozen copy (gens.py:22-24)
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert model.feature_network.convs[0].weight.grad.abs().sum() > 0      # through K4 (and K1 -> reg net -> K2)
+    assert model.feature_network.convs[2].weight.grad.abs().sum() > 0      # level 2 feeds K1 and K4
+    assert model.reg_network.convs[0].weight.grad.abs().sum() > 0          # through K2 / K2'' / K10
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+    opt.step()
+
+
+def test_gens_finetune_volumes_are_parameters_and_checkpoint_roundtrip(tmp_path):
+    model = _gens()
+    ipts = _inputs(nv=3)
+    model.init_volumes({k: ipts[k] for k in ("imgs", "intrs", "c2ws")})
+    assert model.has_vol and len(model.volumes) == 3 and not model.mask_volmes[0].requires_grad
+    groups = model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]})
+    assert len(groups) == 4
+    ipts["view_ids"] = [0, 1, 2]
+    out = model("finetune", ipts, 1.0, None)
+    _loss(out).backward()
+    for v in model.volumes:
+        assert v.grad is not None and v.grad.abs().sum() > 0
+    path = tmp_path / "vol.ckpt"
+    torch.save({"model": model.get_params_vol()}, path)
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models import gens
+    fresh = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4), has_vol=True)).cuda()
+    fresh.load_params_vol(str(path), "cuda")
+    with torch.no_grad():
+        torch.manual_seed(4)                           # same ray jitter in both renders
+        a = fresh("finetune", ipts, 1.0, None)["sparse_sdf"][1024:]
+        torch.manual_seed(4)
+        b = model("finetune", ipts, 1.0, None)["sparse_sdf"][1024:]
+    assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_gens_val_mode_returns_image_buffers():
+    model = _gens().eval()
+    ipts = _inputs(n_rays=48)
+    ipts.update(bound_min=torch.tensor([-1.0, -1, -1]).cuda(), bound_max=torch.tensor([1.0, 1, 1]).cuda(), hw=torch.tensor([6, 8]).int())
+    ipts.pop("pseudo_pts")
+    surf = model.implicit_surface
+    with torch.no_grad():
+        feats = model.feature_network(ipts["imgs"])
+        vols, masks = model.volume.agg_mean_var(feats, ipts["intrs"], ipts["c2ws"])
+        vols = model.reg_network(vols)
+        out = surf.validate(ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"], vols, masks, ipts["imgs"], feats, feats, ipts["intrs"],
+                            ipts["c2ws"], ipts["bound_min"], ipts["bound_max"], ipts["hw"], extract_geometry=False)
+    assert out["img_fine"].shape == (6, 8, 3) and out["normal_img"].shape == (6, 8, 3)
+    assert out["sdf_depth"].shape == (6, 8) and out["render_depth"].shape == (6, 8) and tuple(out["color_fine"].shape) == (48, 3)
