@@ -1,0 +1,330 @@
+// K6: the SDF network evaluated in ONE kernel -- multi-level volume look-up (K2) as
+// prologue, positional encodings, the 7 weight-normed layers on the fp32 matrix cores, and (optionally) the exact
+// first derivative d sdf / d x by reverse mode, without any activation ever leaving the CU.
+//
+// Replaces, for inference, SDFNetwork.forward / .sdf / .gradient(first order)
+// (/root/reference/models/modules/sdf_network.py:98-146) as driven by implicit_surface.py:125,179-191,375.
+// Architecture is the shipped one (confs/gens.conf:69-86): d_hidden 128, 6 hidden layers, skip at layer 3,
+// multires 4 (27-wide point encoding), feat_multires 2 (5x volume channels), Softplus(beta=100), scale folded by the host.
+//
+// MI355X mapping.  v_mfma_f32_32x32x2_f32 is exact float32 (an fmaf chain) at the full fp32 rate, so parity with the
+// rocBLAS path is float32 round-off.  A workgroup = 4 wavefronts = 32 points; wave w owns output columns
+// [32w, 32w+32) of every layer, so its pre-activations -- and therefore softplus' = sigmoid(100 pre), all that the
+// reverse pass needs -- stay in ITS registers (16 VGPRs per layer): no activation stash in LDS or HBM.  LDS holds one
+// 32 x (128+FE) row-padded tile (A operand, odd stride => conflict-free ds_read_b32 for the MFMA A layout); weights
+// are pre-packed by the host in MFMA B-fragment order, so every B operand is one coalesced 256-B load from L2
+// (the whole network is < 1 MB).  HBM traffic per point: 12 B in, 4 or 16 B out (+ 8 texel gathers per level).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MLP_M 32            // points per workgroup
+#define MLP_H 128           // hidden width
+#define MLP_PE 27           // 3 * (1 + 2*4)
+#define MLP_PE_STRIDE 29
+#define MLP_SKIP_H 101      // hidden columns produced by layer 2 (128 - 27)
+#define MLP_NLAYER 6        // GEMM layers 0..5; layer 6 is a dot product (only the sdf row is needed)
+
+struct SdfMlpWeights {
+    const float* wf[MLP_NLAYER];   // forward B fragments  [n_tile(4)][kk][64]
+    const float* bias[MLP_NLAYER]; // (128) zero padded
+    const float* wb[MLP_NLAYER];   // backward B fragments [n_tile][kk(64)][64]; wb[0]: 1 tile (27 -> 32 columns)
+    const float* w_last;           // (128 + FE) row 0 of layer 6
+    float b_last;
+    float inv_scale;               // 1 / scale  (sdf_network.py:123)
+    float scale;
+};
+
+__device__ __forceinline__ float softplus100(float x, float& dsig) {
+    float t = 100.0f * x;
+    if (t > 20.0f) { dsig = 1.0f; return x; }
+    float e = expf(t);
+    dsig = e / (e + 1.0f);
+    return log1pf(e) / 100.0f;
+}
+
+// C = A(32 x 2KK, LDS row-major stride rs, starting at column 0) * B(packed fragments) accumulated into acc
+template <int UNROLL>
+__device__ __forceinline__ f32x16 mfma_rows(const float* __restrict__ a_lds, int rs, const float* __restrict__ wp, int kk_count,
+                                            f32x16 acc, int lane) {
+    const float* a = a_lds + (lane & 31) * rs + (lane >> 5);
+    const float* b = wp + lane;
+#pragma unroll UNROLL
+    for (int kk = 0; kk < kk_count; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[64 * kk], acc, 0, 0, 0);
+    return acc;
+}
+
+// row of accumulator register r for this lane (C/D layout of 32x32 MFMA)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int FE, bool GRAD>
+__global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet vols, const float* __restrict__ pts,
+                                                     const int64_t* __restrict__ index, int64_t n, float* __restrict__ sdf_out,
+                                                     float* __restrict__ grad_out) {
+    constexpr int CF = FE / 5;            // raw volume channels (4 per level)
+    constexpr int KIN = MLP_H + FE;       // input width of layers 1..6
+    constexpr int RS = KIN + 1;           // odd row stride
+    constexpr int NT_B = (KIN + 31) / 32; // backward n-tiles (h part: 4, conditioning part: the rest)
+    __shared__ float X[MLP_M * RS];                      // [h | fe] tile; reused as the G buffer in the reverse pass
+    __shared__ float PE[MLP_M * MLP_PE_STRIDE];          // point encoding (27, col 27 = 0)
+    __shared__ float GPE[GRAD ? MLP_M * MLP_PE_STRIDE : 1];   // d/d(point encoding) from the skip connection
+    __shared__ float JAC[GRAD ? MLP_M * CF * 3 : 1];     // d feat_c / d x_a
+    __shared__ float XYZ[MLP_M * 3];
+    __shared__ float RED[MLP_M * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * MLP_M;
+
+    // ------------------------------------------------------------------ prologue: look-up, encodings
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        const int64_t row = m0 + p;
+        const bool live = row < n;
+        const int64_t src = live ? (index ? index[row] : row) : 0;
+        float x[3] = {0.f, 0.f, 0.f};
+        if (live) { x[0] = pts[3 * src]; x[1] = pts[3 * src + 1]; x[2] = pts[3 * src + 2]; }
+        if (sub < 3) {
+            const int a = sub;
+            float v = x[a] * W.scale;
+            float* pe = PE + p * MLP_PE_STRIDE;
+            XYZ[p * 3 + a] = v;
+            pe[a] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f = (float)(1 << k);
+                pe[3 + 6 * k + a] = sinf(v * f);
+                pe[6 + 6 * k + a] = cosf(v * f);
+            }
+            if (a == 0) { pe[27] = 0.0f; pe[28] = 0.0f; }
+        }
+        if (sub < vols.n) {   // one thread per (point, level): 8 texel gathers
+            const int l = sub;
+            const int Xd = vols.dx[l], Yd = vols.dy[l], Zd = vols.dz[l];
+            const float4* v = (const float4*)vols.data[l];
+            float pos[3], w0[3], w1[3];
+            int i0[3];
+            bool in0[3], in1[3];
+            const int sz[3] = {Xd, Yd, Zd};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                pos[a] = (x[a] + 1.0f) / 2.0f * (float)(sz[a] - 1);
+                float f = fminf(fmaxf(floorf(pos[a]), -2.0f), (float)sz[a] + 1.0f);
+                i0[a] = (int)f;
+                w0[a] = (f + 1.0f) - pos[a];
+                w1[a] = pos[a] - f;
+                in0[a] = i0[a] >= 0 && i0[a] < sz[a];
+                in1[a] = i0[a] + 1 >= 0 && i0[a] + 1 < sz[a];
+            }
+            float4 acc = f4_zero(), jx = f4_zero(), jy = f4_zero(), jz = f4_zero();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
+                bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+                if (!ok) continue;
+                float4 t = v[((int64_t)(i0[0] + a) * Yd + (i0[1] + b)) * Zd + (i0[2] + d)];
+                float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
+                acc = f4_madd(acc, t, wx * wy * wz);
+                if constexpr (GRAD) {
+                    jx = f4_madd(jx, t, (a ? 1.0f : -1.0f) * wy * wz);
+                    jy = f4_madd(jy, t, wx * (b ? 1.0f : -1.0f) * wz);
+                    jz = f4_madd(jz, t, wx * wy * (d ? 1.0f : -1.0f));
+                }
+            }
+            const float fv[4] = {acc.x, acc.y, acc.z, acc.w};
+            float* xr = X + p * RS + MLP_H;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * l + c;
+                xr[ch] = fv[c];
+                xr[CF + ch] = sinf(fv[c]);
+                xr[2 * CF + ch] = cosf(fv[c]);
+                xr[3 * CF + ch] = sinf(2.0f * fv[c]);
+                xr[4 * CF + ch] = cosf(2.0f * fv[c]);
+            }
+            if constexpr (GRAD) {
+                const float sx = (float)(Xd - 1) / 2.0f, sy = (float)(Yd - 1) / 2.0f, sz_ = (float)(Zd - 1) / 2.0f;
+                const float gx[4] = {jx.x, jx.y, jx.z, jx.w}, gy[4] = {jy.x, jy.y, jy.z, jy.w}, gz[4] = {jz.x, jz.y, jz.z, jz.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float* j = JAC + (p * CF + 4 * l + c) * 3;
+                    j[0] = gx[c] * sx;
+                    j[1] = gy[c] * sy;
+                    j[2] = gz[c] * sz_;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ forward: layers 0..5
+    f32x16 dsig[GRAD ? MLP_NLAYER : 1];
+    const int col = 32 * wave + (lane & 31);
+#pragma unroll
+    for (int l = 0; l < MLP_NLAYER; ++l) {
+        const int kk_count = (l == 0) ? (MLP_PE + 1) / 2 : KIN / 2;
+        const float* a_lds = (l == 0) ? PE : X;
+        const int rs = (l == 0) ? MLP_PE_STRIDE : RS;
+        f32x16 acc;
+        const float bias = W.bias[l][col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        acc = mfma_rows<8>(a_lds, rs, W.wf[l] + (size_t)wave * kk_count * 64, kk_count, acc, lane);
+        __syncthreads();   // every wave has finished reading this layer's input tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            float ds;
+            float h = softplus100(acc[r], ds);
+            if (l == 2) {   // skip connection feeding layer 3: x = cat([h, pe]) / sqrt(2)   (sdf_network.py:111-112)
+                if (col < MLP_SKIP_H) {
+                    h *= 0.70710678118654752440f;
+                } else {
+                    h = PE[row * MLP_PE_STRIDE + (col - MLP_SKIP_H)] * 0.70710678118654752440f;
+                    ds = 0.0f;
+                }
+            }
+            X[row * RS + col] = h;
+            if constexpr (GRAD) dsig[l][r] = ds;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ layer 6, sdf row only: a dot product per point
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        const float* xr = X + p * RS;
+        float s = 0.0f;
+        for (int k = sub; k < KIN; k += 8) s += xr[k] * W.w_last[k];
+        RED[p * 8 + sub] = s;
+    }
+    __syncthreads();
+    if (tid < MLP_M) {
+        const int64_t row = m0 + tid;
+        if (row < n) {
+            float s = W.b_last;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += RED[tid * 8 + k];
+            sdf_out[index ? index[row] : row] = s * W.inv_scale;
+        }
+    }
+    if constexpr (!GRAD) return;
+
+    // ------------------------------------------------------------------ reverse pass
+    // G_5[m][j] = w_last[j] * softplus'(pre_5[m][j]) ; conditioning part of d/d input accumulates in registers
+    f32x16 gfe;     // this wave's 32-column tile of d sdf / d fe  (tiles 4.. of the backward GEMM output)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gfe[r] = 0.0f;
+    const int fe_tile = 4 + wave;
+    const bool has_fe_tile = fe_tile < NT_B;
+    __syncthreads();
+    {
+        const float wl = W.w_last[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[acc_row(r, lane) * RS + col] = wl * dsig[5][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 5; l >= 1; --l) {
+        f32x16 gh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
+        gh = mfma_rows<8>(X, RS, W.wb[l] + (size_t)wave * 64 * 64, 64, gh, lane);
+        if (has_fe_tile) gfe = mfma_rows<8>(X, RS, W.wb[l] + (size_t)fe_tile * 64 * 64, 64, gfe, lane);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            float g = gh[r];
+            if (l == 3) {
+                g *= 0.70710678118654752440f;
+                if (col >= MLP_SKIP_H) GPE[row * MLP_PE_STRIDE + (col - MLP_SKIP_H)] = g;
+            }
+            X[row * RS + col] = g * dsig[l - 1][r];
+        }
+        __syncthreads();
+    }
+    // layer 0: d/d(point encoding) = G_0 (32x128) * W_0 (128 x 27): one n-tile, wave 0
+    if (wave == 0) {
+        f32x16 gp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gp[r] = 0.0f;
+        gp = mfma_rows<8>(X, RS, W.wb[0], 64, gp, lane);
+        const int c = lane & 31;
+        if (c < MLP_PE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, lane);
+                GPE[row * MLP_PE_STRIDE + c] += gp[r];   // columns written by the l == 3 step are the same 27
+            }
+        }
+    }
+    __syncthreads();
+    // conditioning gradient tiles -> LDS (reuse the h part of X: it is dead now)
+    if (has_fe_tile) {
+        const int c = 32 * wave + (lane & 31);          // column inside the fe block
+        if (c < FE) {
+            const float wl = W.w_last[MLP_H + c];       // layer 6 contributes the same vector for every point
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[acc_row(r, lane) * RS + c] = gfe[r] + wl;
+        }
+    }
+    __syncthreads();
+    if (tid < MLP_M * 3) {
+        const int p = tid / 3, a = tid % 3;
+        const int64_t row = m0 + p;
+        if (row < n) {
+            const float* gpe = GPE + p * MLP_PE_STRIDE;
+            const float* pe = PE + p * MLP_PE_STRIDE;
+            float g = gpe[a];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = (float)(1 << k);
+                g += f * (gpe[3 + 6 * k + a] * pe[6 + 6 * k + a] - gpe[6 + 6 * k + a] * pe[3 + 6 * k + a]);
+            }
+            g *= W.scale;
+            const float* gf = X + p * RS;               // d/d fe  (FE values)
+            const float* fe = X + p * RS + MLP_H;       // fe = [f, sin f, cos f, sin 2f, cos 2f]
+            for (int c = 0; c < CF; ++c) {
+                float df = gf[c] + gf[CF + c] * fe[2 * CF + c] - gf[2 * CF + c] * fe[CF + c] +
+                           2.0f * (gf[3 * CF + c] * fe[4 * CF + c] - gf[4 * CF + c] * fe[3 * CF + c]);
+                g += df * JAC[(p * CF + c) * 3 + a];
+            }
+            grad_out[3 * (index ? index[row] : row) + a] = g * W.inv_scale;
+        }
+    }
+}
+
+int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
+
+extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                            const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
+                            const float* pts, const int64_t* index, int64_t n, float* sdf_out, float* grad_out, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_sdf_mlp", &vs, vols_packed, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(wf && bias && w_last && (wb || !grad_out), GENS_EINVAL, "gens_sdf_mlp: null weight table");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out)), GENS_EINVAL, "gens_sdf_mlp: null pts / output");
+    GENS_CHECK_ARG(scale != 0.0f, GENS_EINVAL, "gens_sdf_mlp: scale must be non-zero");
+    if (n == 0) return 0;
+    SdfMlpWeights W;
+    for (int l = 0; l < MLP_NLAYER; ++l) {
+        GENS_CHECK_ARG(wf[l] && bias[l] && (!grad_out || wb[l]), GENS_EINVAL, "gens_sdf_mlp: layer %d weights are null", l);
+        W.wf[l] = wf[l];
+        W.bias[l] = bias[l];
+        W.wb[l] = grad_out ? wb[l] : nullptr;
+    }
+    W.w_last = w_last;
+    W.b_last = b_last;
+    W.scale = scale;
+    W.inv_scale = 1.0f / scale;
+    unsigned grid = gens_blocks(n, MLP_M);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_levels == 3) {
+        if (grad_out) sdf_mlp_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        else sdf_mlp_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+    } else {
+        if (grad_out) sdf_mlp_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        else sdf_mlp_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+    }
+    return gens_launch_status("gens_sdf_mlp");
+}

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
+    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p],
 }
 
 _lib = None
@@ -107,23 +108,24 @@ def profile_end():
     rec, _profile = _profile or [], None
     torch.cuda.synchronize()
     out = {}
-    for name, s, e, nbytes in rec:
-        d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+    for name, s, e, nbytes, flops in rec:
+        d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
         d["launches"] += 1
         d["ms"] += s.elapsed_time(e)
         d["bytes"] += nbytes
+        d["flops"] += flops
     return out
 
 
-def call(name, *args, nbytes=0):
-    """Invoke one C-ABI entry point; `nbytes` = algorithmic HBM bytes of this launch, for the roofline."""
+def call(name, *args, nbytes=0, flops=0):
+    """Invoke one C-ABI entry point; `nbytes` / `flops` = algorithmic HBM bytes / FLOPs of this launch."""
     lib = load()
     if _profile is not None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()
-        _profile.append((name, s, e, int(nbytes)))
+        _profile.append((name, s, e, int(nbytes), int(flops)))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

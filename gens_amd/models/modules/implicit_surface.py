@@ -80,6 +80,8 @@ class ImplicitSurface(nn.Module):
         self.color_network = BlendingNetwork(**confs["color_network"])
         self.deviation_network = SingleVarianceNetwork(**confs["variance_network"])
         self.val_chunk = 8192          # rays per chunk in validate(); rays are independent, so this is a free knob
+        self.fused_sdf = True          # inference: evaluate the SDF network with the fused MFMA kernel (gens_sdf_mlp)
+        self._sdf_plan = None
 
     # ----------------------------------------------------------------------------------------------------------
     # masked SDF evaluation (Q7, Q8)
@@ -92,10 +94,28 @@ class ImplicitSurface(nn.Module):
             idx = torch.arange(min(10, valid.numel()), device=valid.device)
         return idx
 
+    def _fused_plan(self, volumes):
+        """The packed-weight plan for gens_sdf_mlp, or None when the fused kernel does not apply (autograd needed,
+        planar volumes, or a non-shipped architecture) -- then the PyTorch layers run on top of the K2 kernels."""
+        if not self.fused_sdf or torch.is_grad_enabled():
+            return None
+        if not (isinstance(volumes, ops.VolumeSet) and volumes.layout == 1 and volumes.n in (3, 5)):
+            return None
+        net = self.sdf_network
+        if not ops.SdfMlpPlan.supported(net) or net.init_feat_channels != 4 * volumes.n:
+            return None
+        if self._sdf_plan is None or self._sdf_plan.key != ops.SdfMlpPlan.version(net):
+            self._sdf_plan = ops.SdfMlpPlan(net)
+        return self._sdf_plan
+
     def _masked_sdf(self, pts, valid, volumes):
         idx = self._select(valid)
         sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
-        sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
+        plan = self._fused_plan(volumes)
+        if plan is not None:
+            ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf)
+        else:
+            sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
         return sdf
 
     # ----------------------------------------------------------------------------------------------------------
@@ -152,18 +172,25 @@ class ImplicitSurface(nn.Module):
         idx = self._select(valid)
         pts_v = pts[idx]
 
-        if lean:
-            with torch.enable_grad():
-                x = pts_v.clone().requires_grad_(True)
-                sdf_v = self.sdf_network.sdf(x, vols)
-                grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
-            sdf_v, smooth_v = sdf_v.detach(), None
+        plan = self._fused_plan(vols) if lean else None
+        if plan is not None:                       # fused look-up + MLP + d/dx, scattered straight into the dense arrays
+            sdf = torch.full((b * n, 1), 100.0, device=dev)
+            gradients = torch.zeros(b * n, 3, device=dev)
+            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients)
+            smooth = None
         else:
-            sdf_v = self.sdf_network(pts_v, vols)[:, :1]
-            grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
-        sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
-        gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
-        smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
+            if lean:
+                with torch.enable_grad():
+                    x = pts_v.clone().requires_grad_(True)
+                    sdf_v = self.sdf_network.sdf(x, vols)
+                    grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
+                sdf_v, smooth_v = sdf_v.detach(), None
+            else:
+                sdf_v = self.sdf_network(pts_v, vols)[:, :1]
+                grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
+            sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
+            gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
+            smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
 
         feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
         color_v = self.color_network(feat_views, ray_diff, vis_v)
@@ -246,7 +273,9 @@ class ImplicitSurface(nn.Module):
         for first in range(0, total, chunk):
             count = min(chunk, total - first)
             pts = ops.lattice_points(bound_min.tolist(), bound_max.tolist(), resolution, first, count, dev)
-            u[first:first + count] = -self.sdf_network.sdf(pts, vols)[:, 0]
+            plan = self._fused_plan(vols)
+            sdf = ops.sdf_mlp(plan, vols, pts) if plan is not None else self.sdf_network.sdf(pts, vols)
+            u[first:first + count] = -sdf[:, 0]
         return u.reshape(resolution, resolution, resolution)
 
     def extract_geometry(self, volumes, bound_min, bound_max, resolution, threshold):

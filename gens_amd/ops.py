@@ -508,3 +508,76 @@ def lattice_points(bound_min, bound_max, resolution, first, count, device):
     pts = torch.empty(count, 3, device=device, dtype=_f32)
     L.call("gens_lattice_points", lo, hi, int(resolution), int(first), int(count), L.ptr(pts), L.stream())
     return pts
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K6  fused SDF network (inference): look-up + encodings + 7 layers on fp32 MFMA (+ d sdf/dx)   (sdf_network.py:98-146)
+# ------------------------------------------------------------------------------------------------------------------
+def _pack_b_fragments(w):
+    """(J, K) matrix -> MFMA 32x32x2 B fragments [ceil(J/32)][ceil(K/2)][64]: lane l of fragment (nt, kk) holds
+    w[32 nt + (l & 31)][2 kk + (l >> 5)] (zero padded), so one B operand is one contiguous 256-B load."""
+    j, k = w.shape
+    nt, kk = (j + 31) // 32, (k + 1) // 2
+    wp = torch.zeros(nt * 32, kk * 2, device=w.device, dtype=_f32)
+    wp[:j, :k] = w
+    return wp.view(nt, 32, kk, 2).permute(0, 2, 3, 1).contiguous()
+
+
+class SdfMlpPlan:
+    """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
+    (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
+
+    @staticmethod
+    def supported(net):
+        return (net.num_layers == 8 and tuple(net.skip_in) == (3,) and net.embed_fn_fine is not None and net.embed_fn_feat is not None
+                and net.lin0.weight_v.shape == (128, 27) and net.init_feat_channels in (12, 20)
+                and net.lin6.weight_v.shape[1] == 128 + 5 * net.init_feat_channels and net.lin2.weight_v.shape[0] == 101)
+
+    @staticmethod
+    def version(net):
+        return tuple(p._version for p in net.parameters()) + tuple(p.data_ptr() for p in net.parameters())
+
+    def __init__(self, net):
+        assert SdfMlpPlan.supported(net), "gens_sdf_mlp is built for the architecture of confs/gens.conf:69-86"
+        with torch.no_grad():
+            ws, bs = [], []
+            for l in range(7):
+                lin = getattr(net, f"lin{l}")
+                v, g = lin.weight_v.detach().to(_f32), lin.weight_g.detach().to(_f32)
+                ws.append(v * (g / torch.linalg.norm(v, dim=1, keepdim=True)))
+                bs.append(lin.bias.detach().to(_f32))
+            dev = ws[0].device
+            self.n_levels = net.init_feat_channels // 4
+            self.wf, self.wb, self.bias = [], [], []
+            for l in range(6):
+                w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+                w[:ws[l].shape[0]] = ws[l]
+                b = torch.zeros(128, device=dev, dtype=_f32)
+                b[:bs[l].shape[0]] = bs[l]
+                self.wf.append(_pack_b_fragments(w))
+                self.wb.append(_pack_b_fragments(w.t().contiguous()))
+                self.bias.append(b)
+            self.w_last = _c(ws[6][0].clone())
+            self.b_last = float(bs[6][0])
+            self.scale = float(net.scale)
+        self.wf_table, self.wb_table, self.bias_table = L.ptr_table(self.wf), L.ptr_table(self.wb), L.ptr_table(self.bias)
+        self.key = SdfMlpPlan.version(net)
+
+
+def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None):
+    """sdf (and d sdf/dx) of pts[index] written to sdf_out[index] / grad_out[index] (fresh, densely indexed outputs if
+    no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference)."""
+    assert isinstance(volumes, VolumeSet) and volumes.layout == L.LAYOUT_PACKED and volumes.n == plan.n_levels
+    pts = _c(pts.detach().reshape(-1, 3).to(_f32))
+    n = pts.shape[0] if index is None else index.shape[0]
+    if sdf_out is None:
+        sdf_out = torch.empty(pts.shape[0], 1, device=pts.device, dtype=_f32)
+    if want_grad and grad_out is None:
+        grad_out = torch.empty(pts.shape[0], 3, device=pts.device, dtype=_f32)
+    idx = None if index is None else _c(index.to(torch.int64))
+    fe = 20 * plan.n_levels
+    flops = 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1)) * (2 if want_grad else 1)
+    L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.bias_table, plan.wb_table, L.ptr(plan.w_last),
+           plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None,
+           L.stream(), nbytes=n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0)), flops=n * flops)
+    return (sdf_out, grad_out) if want_grad else sdf_out

@@ -170,6 +170,20 @@ int gens_composite_fwd(const gens_composite_in* in, const gens_composite_out* ou
 int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K6  SDFNetwork.forward(...)[:, :1] and its first derivative, inference only   (sdf_network.py:98-146)
+ *   One launch = volume look-up (K2, packed volumes) + both positional encodings + 7 layers on the fp32 matrix
+ *   cores (+ reverse-mode d sdf/d x when grad_out != NULL).  Architecture: d_hidden 128, n_layers 6, skip_in [3],
+ *   multires 4, feat_multires 2, Softplus(beta=100); n_levels must be 3 or 5 (feat_channels 12 / 20).
+ *   wf / bias / wb: HOST arrays of 6 device pointers, weights pre-packed in MFMA B-fragment order by
+ *   gens_amd.ops.SdfMlpPlan (layout documented in k6_sdfmlp.hip); w_last (128 + 5*4*n_levels) = row 0 of lin6.
+ *   index: optional (N) int64 gather/scatter map: point i is pts[index[i]] and results go to sdf_out[index[i]],
+ *   grad_out[3*index[i]..] (the masked evaluation of implicit_surface.py:125,179-191); NULL = identity.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                 const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
+                 const float* pts, const int64_t* index, int64_t n, float* sdf_out, float* grad_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)
  *   image (H, W, C_pad) texels of one view; xy (P, 2) PIXEL coordinates (the normalise/un-normalise pair of
  *   :404-405 and align_corners=True cancel); out (P, C).  bwd: g_out (P, C) -> g_xy (P, 2), overwritten.

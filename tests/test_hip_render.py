@@ -104,8 +104,15 @@ def test_lean_validation_path_equals_full_render(golden):
     full = surf.render_core(*args)
     with torch.no_grad():
         lean = surf.render_core(*args, lean=True)
+    # lean runs the fused MFMA SDF kernel, full the PyTorch layers: same float32 arithmetic, different summation order
+    for k in ["color_fine", "render_depth", "sdf_depth", "weights", "inside_sphere"]:
+        close(lean[k], full[k], atol=2e-5, rtol=1e-4, what=k)
+    close(lean["gradients"], full["gradients"], atol=2e-4, rtol=1e-3, what="gradients")
+    surf.fused_sdf = False
+    with torch.no_grad():
+        lean_torch = surf.render_core(*args, lean=True)
     for k in ["color_fine", "render_depth", "sdf_depth", "weights", "gradients", "inside_sphere"]:
-        close(lean[k], full[k], atol=1e-6, rtol=1e-5, what=k)
+        close(lean_torch[k], full[k], atol=1e-6, rtol=1e-5, what=k + " (torch layers)")
 
 
 def test_sdf_grid_matches_reference(golden):
