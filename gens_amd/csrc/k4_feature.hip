@@ -12,33 +12,7 @@
 // with (W-1)/2 but READ with align_corners=False, i.e. pixel = ((g+1)*W-1)/2 (Q6).
 #include "common.h"
 
-struct MapSet {
-    const float4* data[GENS_MAX_LEVELS];
-    float* grad[GENS_MAX_LEVELS];
-    int h[GENS_MAX_LEVELS], w[GENS_MAX_LEVELS];
-    int n;
-};
-
-struct SrcProj {
-    float ix, iy;   // read position (align_corners=False un-normalisation)
-    bool inside;    // mask term of this level
-};
-__device__ __forceinline__ SrcProj project_src(const float* __restrict__ w2c, const float* __restrict__ k, float s, int h,
-                                               int w, float x, float y, float z) {
-    float cx = w2c[0] * x + w2c[1] * y + w2c[2] * z + w2c[3];
-    float cy = w2c[4] * x + w2c[5] * y + w2c[6] * z + w2c[7];
-    float cz = w2c[8] * x + w2c[9] * y + w2c[10] * z + w2c[11];
-    float u = (k[0] * s) * cx + (k[1] * s) * cy + (k[2] * s) * cz;
-    float v = (k[4] * s) * cx + (k[5] * s) * cy + (k[6] * s) * cz;
-    float d = k[8] * cx + k[9] * cy + k[10] * cz;
-    float px = u / d, py = v / d;
-    float nx = px / ((float)(w - 1) / 2.0f) - 1.0f, ny = py / ((float)(h - 1) / 2.0f) - 1.0f;
-    SrcProj p;
-    p.inside = (d > 0.0f) && (px >= 0.0f) && (px < (float)w) && (py >= 0.0f) && (py < (float)h);
-    p.ix = ((nx + 1.0f) * (float)w - 1.0f) / 2.0f;
-    p.iy = ((ny + 1.0f) * (float)h - 1.0f) / 2.0f;
-    return p;
-}
+#include "k4_common.h"
 
 #define K4_BLOCK 256
 #define K4_MAX_ROW (3 + 4 * GENS_MAX_LEVELS)
@@ -134,7 +108,7 @@ __global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __
     }
 }
 
-static int fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels) {
+int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels) {
     GENS_CHECK_ARG(hw, GENS_EINVAL, "%s: null hw table", who);
     GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "%s: n_levels=%d not in 1..%d", who, n_levels,
                    GENS_MAX_LEVELS);
@@ -161,7 +135,7 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
                                        float* ray_diff, uint8_t* vis, void* stream) {
     MapSet fs;
     GENS_CHECK_ARG(feats, GENS_EINVAL, "gens_lookup_feature_fwd: null feature table");
-    if (int e = fill_maps("gens_lookup_feature_fwd", &fs, feats, hw, n_levels)) return e;
+    if (int e = gens_fill_maps("gens_lookup_feature_fwd", &fs, feats, hw, n_levels)) return e;
     GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_lookup_feature_fwd: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
     GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_lookup_feature_fwd: null camera / image pointer");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out && ray_diff && vis)), GENS_EINVAL, "gens_lookup_feature_fwd: null pts / output");
@@ -176,7 +150,7 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
 extern "C" int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts,
                                        const float* g_out, int64_t n, float* const* g_feats, float* g_imgs, void* stream) {
     MapSet fs;
-    if (int e = fill_maps("gens_lookup_feature_bwd", &fs, nullptr, hw, n_levels)) return e;
+    if (int e = gens_fill_maps("gens_lookup_feature_bwd", &fs, nullptr, hw, n_levels)) return e;
     GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_lookup_feature_bwd: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
     GENS_CHECK_ARG(w2c && intr, GENS_EINVAL, "gens_lookup_feature_bwd: null camera pointer");
     GENS_CHECK_ARG(g_feats || g_imgs, GENS_EINVAL, "gens_lookup_feature_bwd: no output requested");

@@ -1,0 +1,307 @@
+// K7: source-view feature look-up (K4) + the whole IBRNet-style BlendingNetwork in ONE kernel, inference only.
+//
+// Replaces, for validation rendering, lookup_feature + compute_angle (/root/reference/models/modules/projector.py:278-349)
+// followed by BlendingNetwork.forward (models/modules/blending_network.py:69-118) as called from
+// implicit_surface.py:196-199.  The (N, S, 23) feature tensor, the (N, S, 4) ray-difference tensor and every
+// activation of the eleven small linear layers stay in LDS / registers; HBM sees 12 B per point in and 12 + S bytes out.
+//
+// Mapping: one wavefront owns 32 (point, source-view) rows = floor(32/S) points and runs every layer on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact float32) with the rows as the M dimension; waves are independent.
+// Cross-view operations (softmax over views, weighted mean / variance, min over views) read the sibling rows from
+// the wave's LDS tile.  Weights (43 KB) are pre-packed in B-fragment order and stay in L1/L2.
+#include "k4_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BL_WAVES 2          // wavefronts per workgroup
+#define BL_TS 73            // row stride of the wide tile (K <= 70)
+#define BL_VS 65            // row stride of the 64-wide tile
+#define BL_HS 33            // row stride of the hidden tile
+#define BL_MAXF 23          // 3 + 4*5 feature columns
+
+struct BlendWeights {
+    const float *rd1, *rd1_b, *rd2, *rd2_b;   // ray_dir_fc: 4 -> 16 -> F
+    const float *b1, *b1_b, *b2, *b2_b;       // base_fc:    3F -> 64 -> 32
+    const float *v1, *v1_b, *v2, *v2_b;       // vis_fc:     32 -> 32 -> 33 (rows 0..31 packed; row 32 = v2_last)
+    const float *v2_last;                     // (32) weights of vis_fc output 32, bias v2_last_b
+    const float *u1, *u1_b, *u2;              // vis_fc2:    32 -> 32 -> 1
+    const float *r1, *r1_b, *r2, *r2_b, *r3;  // rgb_fc:     37 -> 16 -> 8 -> 1
+    float v2_last_b, u2_b, r3_b, s_abs;
+};
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int rs, const float* __restrict__ wp, int kk_count,
+                                            float bias, int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias;
+    const float* a = a_lds + (lane & 31) * rs + (lane >> 5);
+    const float* b = wp + lane;
+#pragma unroll 4
+    for (int kk = 0; kk < kk_count; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[64 * kk], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet fs, const float4* __restrict__ imgs,
+                                                         const float* __restrict__ w2c, const float* __restrict__ intr,
+                                                         const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
+                                                         const int64_t* __restrict__ index, int64_t n, float* __restrict__ rgb_out,
+                                                         uint8_t* __restrict__ vis_out) {
+    __shared__ float T_[BL_WAVES][32 * BL_TS];
+    __shared__ float V_[BL_WAVES][32 * BL_VS];
+    __shared__ float H_[BL_WAVES][32 * BL_HS];
+    __shared__ float RD_[BL_WAVES][32 * 5];
+    __shared__ float R_[BL_WAVES][32 * 8];     // per-row scalars: 0 mask, 1 e, 2 w, 3 w normalised, 4 vis, 5 vis2, 6 score
+    __shared__ float C_[BL_WAVES][32 * 3];     // rgb_in
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* T = T_[wave];
+    float* V = V_[wave];
+    float* H = H_[wave];
+    float* RD = RD_[wave];
+    float* R = R_[wave];
+    float* C = C_[wave];
+    const int S = nv - 1, PPW = 32 / S, F = 3 + 4 * fs.n;
+    const int64_t first = ((int64_t)blockIdx.x * BL_WAVES + wave) * PPW;
+    const int row = lane & 31, half = lane >> 5;
+    const int pl = row / S, sv = row % S + 1;
+    const bool live = pl < PPW && first + pl < n;
+    const int64_t src = live ? (index ? index[first + pl] : first + pl) : 0;
+    const int col = lane & 31;
+
+    // ---------------------------------------------------------------- phase 0: K4 look-up into T[:, 2F..3F)
+    {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (live) { x = pts[3 * src]; y = pts[3 * src + 1]; z = pts[3 * src + 2]; }
+        bool inside = true;
+        const int l_begin = half ? 2 : 0, l_end = half ? fs.n : min(2, fs.n);
+        float* xr = T + row * BL_TS + 2 * F;
+        for (int l = l_begin; l < l_end; ++l) {
+            const int h = fs.h[l], w = fs.w[l];
+            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+            inside = inside && p.inside;
+            float4 f = f4_zero(), c = f4_zero();
+            if (live) {
+                Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+                f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+                if (l == 0) c = sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+            }
+            xr[3 + 4 * l] = f.x; xr[4 + 4 * l] = f.y; xr[5 + 4 * l] = f.z; xr[6 + 4 * l] = f.w;
+            if (l == 0) {
+                xr[0] = c.x; xr[1] = c.y; xr[2] = c.z;
+                C[row * 3] = c.x; C[row * 3 + 1] = c.y; C[row * 3 + 2] = c.z;
+            }
+        }
+        const bool other = __shfl_xor((int)inside, 32, 64) != 0;
+        inside = inside && other;
+        if (half == 0) {
+            R[row * 8] = (live && inside) ? 1.0f : 0.0f;
+            if (live && vis_out) vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
+            // compute_angle (projector.py:278-291)
+            float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
+            float rn = sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f;
+            rx /= rn; ry /= rn; rz /= rn;
+            const float* cs = c2w + 16 * sv;
+            float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
+            float sn = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
+            sx /= sn; sy /= sn; sz /= sn;
+            float dx = rx - sx, dy = ry - sy, dz = rz - sz;
+            float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+            float* rd = RD + row * 5;
+            rd[0] = live ? dx / dn : 0.0f;
+            rd[1] = live ? dy / dn : 0.0f;
+            rd[2] = live ? dz / dn : 0.0f;
+            rd[3] = live ? rx * sx + ry * sy + rz * sz : 0.0f;
+            rd[4] = 0.0f;
+            T[row * BL_TS + 3 * F] = 0.0f;            // K padding column of base_fc.0 when 3F is odd
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- ray_dir_fc (blending_network.py:36-39, 87)
+    {
+        f32x16 a = tile_mfma(RD, 5, W.rd1, 2, W.rd1_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (col < 16) V[crow(r, lane) * BL_VS + col] = elu1(a[r]);
+    }
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(V, BL_VS, W.rd2, 8, W.rd2_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (col < F) T[crow(r, lane) * BL_TS + 2 * F + col] += elu1(a[r]);        // x = rgb_feat + direction_feat (:89)
+        if (half == 0) R[row * 8 + 1] = expf(W.s_abs * (RD[row * 5 + 3] - 1.0f));     // exp(|s| (dot - 1))  (:93)
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- view weights, weighted mean / variance (:94-101)
+    if (half == 0) {
+        const int base = pl * S;
+        float mn = 3.4e38f;
+        if (pl < PPW) for (int v = 0; v < S; ++v) mn = fminf(mn, R[(base + v) * 8 + 1]);
+        R[row * 8 + 2] = (pl < PPW) ? (R[row * 8 + 1] - mn) * R[row * 8] : 0.0f;
+    }
+    __syncthreads();
+    if (half == 0) {
+        const int base = pl * S;
+        float sum = 0.0f;
+        if (pl < PPW) for (int v = 0; v < S; ++v) sum += R[(base + v) * 8 + 2];
+        R[row * 8 + 3] = R[row * 8 + 2] / (sum + 1e-8f);
+    }
+    __syncthreads();
+    for (int it = lane; it < PPW * F; it += 64) {
+        const int p = it / F, c = it % F, base = p * S;
+        float mean = 0.0f, var = 0.0f;
+        for (int v = 0; v < S; ++v) mean += T[(base + v) * BL_TS + 2 * F + c] * R[(base + v) * 8 + 3];
+        for (int v = 0; v < S; ++v) {
+            float d = T[(base + v) * BL_TS + 2 * F + c] - mean;
+            var += R[(base + v) * 8 + 3] * (d * d);
+        }
+        for (int v = 0; v < S; ++v) {
+            T[(base + v) * BL_TS + c] = mean;
+            T[(base + v) * BL_TS + F + c] = var;
+        }
+    }
+    for (int it = lane; it < (32 - PPW * S) * 2 * F; it += 64) {      // unused rows (32 % S != 0): keep them finite
+        const int rr = PPW * S + it / (2 * F);
+        T[rr * BL_TS + it % (2 * F)] = 0.0f;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- base_fc (:103-104)
+    const int kk_base = (3 * F + 1) / 2;
+    {
+        f32x16 a0 = tile_mfma(T, BL_TS, W.b1, kk_base, W.b1_b[col], lane);
+        f32x16 a1 = tile_mfma(T, BL_TS, W.b1 + (size_t)kk_base * 64, kk_base, W.b1_b[32 + col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            V[crow(r, lane) * BL_VS + col] = elu1(a0[r]);
+            V[crow(r, lane) * BL_VS + 32 + col] = elu1(a1[r]);
+        }
+    }
+    __syncthreads();
+    f32x16 h = tile_mfma(V, BL_VS, W.b2, 32, W.b2_b[col], lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[r] = elu1(h[r]);
+    __syncthreads();                                           // every lane has finished reading V
+    // ---------------------------------------------------------------- vis_fc on x * weight (:106-109)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + col] = h[r] * R[crow(r, lane) * 8 + 3];
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(V, BL_VS, W.v1, 16, W.v1_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + 32 + col] = elu1(a[r]);
+    }
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(V + 32, BL_VS, W.v2, 16, W.v2_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] += elu1(a[r]);                          // x = x + x_res
+        if (half == 0) {                                                         // 33rd output -> vis
+            float s = W.v2_last_b;
+            for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.v2_last[k];
+            R[row * 8 + 4] = sigmoidf_(elu1(s)) * R[row * 8];
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- vis_fc2 on x * vis (:110)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = crow(r, lane);
+        V[rr * BL_VS + col] = h[r] * R[rr * 8 + 4];
+        H[rr * BL_HS + col] = h[r];
+    }
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(V, BL_VS, W.u1, 16, W.u1_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + 32 + col] = elu1(a[r]);
+    }
+    __syncthreads();
+    if (half == 0) {
+        float s = W.u2_b;
+        for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.u2[k];
+        R[row * 8 + 5] = sigmoidf_(s) * R[row * 8];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + col] = h[r];
+    if (half == 0) {
+        float* vr = V + row * BL_VS;
+        vr[32] = R[row * 8 + 5];
+        vr[33] = RD[row * 5]; vr[34] = RD[row * 5 + 1]; vr[35] = RD[row * 5 + 2]; vr[36] = RD[row * 5 + 3];
+        vr[37] = 0.0f;
+    }
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(V, BL_VS, W.r1, 19, W.r1_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (col < 16) T[crow(r, lane) * BL_TS + col] = elu1(a[r]);
+    }
+    __syncthreads();
+    {
+        f32x16 a = tile_mfma(T, BL_TS, W.r2, 8, W.r2_b[col], lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (col < 8) T[crow(r, lane) * BL_TS + 32 + col] = elu1(a[r]);
+    }
+    __syncthreads();
+    if (half == 0) {
+        float s = W.r3_b;
+        for (int k = 0; k < 8; ++k) s += T[row * BL_TS + 32 + k] * W.r3[k];
+        R[row * 8 + 6] = (R[row * 8] == 0.0f) ? -1e9f : s;                          // masked_fill(mask == 0, -1e9)  (:115)
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- softmax over views, colour (:116-117)
+    if (lane < PPW && first + lane < n) {
+        const int base = lane * S;
+        float mx = -3.4e38f;
+        for (int v = 0; v < S; ++v) mx = fmaxf(mx, R[(base + v) * 8 + 6]);
+        float den = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        for (int v = 0; v < S; ++v) {
+            float e = expf(R[(base + v) * 8 + 6] - mx);
+            den += e;
+            cr += C[(base + v) * 3] * e;
+            cg += C[(base + v) * 3 + 1] * e;
+            cb += C[(base + v) * 3 + 2] * e;
+        }
+        const int64_t dst = index ? index[first + lane] : first + lane;
+        rgb_out[3 * dst] = cr / den;
+        rgb_out[3 * dst + 1] = cg / den;
+        rgb_out[3 * dst + 2] = cb / den;
+    }
+}
+
+int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels);
+
+extern "C" int gens_blend_views(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c,
+                                const float* intr, const float* c2w, int nv, const float* const* weights, const float* scalars,
+                                const float* pts, const int64_t* index, int64_t n, float* rgb_out, uint8_t* vis_out, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats && weights && scalars, GENS_EINVAL, "gens_blend_views: null table");
+    if (int e = gens_fill_maps("gens_blend_views", &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels <= 5, GENS_ELIMIT, "gens_blend_views: at most 5 feature levels (d_feature <= 20), got %d", n_levels);
+    GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_blend_views: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_blend_views: null camera / image pointer");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_views: null pts / output");
+    if (n == 0) return 0;
+    for (int k = 0; k < 21; ++k) GENS_CHECK_ARG(weights[k], GENS_EINVAL, "gens_blend_views: weight %d is null", k);
+    BlendWeights W;
+    const float* const* w = weights;
+    W.rd1 = w[0]; W.rd1_b = w[1]; W.rd2 = w[2]; W.rd2_b = w[3];
+    W.b1 = w[4]; W.b1_b = w[5]; W.b2 = w[6]; W.b2_b = w[7];
+    W.v1 = w[8]; W.v1_b = w[9]; W.v2 = w[10]; W.v2_b = w[11]; W.v2_last = w[12];
+    W.u1 = w[13]; W.u1_b = w[14]; W.u2 = w[15];
+    W.r1 = w[16]; W.r1_b = w[17]; W.r2 = w[18]; W.r2_b = w[19]; W.r3 = w[20];
+    W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
+    const int ppw = 32 / (nv - 1);
+    const int64_t waves = (n + ppw - 1) / ppw;
+    blend_k<<<gens_blocks(waves, BL_WAVES), 64 * BL_WAVES, 0, (hipStream_t)stream>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, nv, pts,
+                                                                                    index, n, rgb_out, vis_out);
+    return gens_launch_status("gens_blend_views");
+}

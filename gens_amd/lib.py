@@ -64,6 +64,7 @@ SIGNATURES = {
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
+    "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p],
     "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p],
 }
 

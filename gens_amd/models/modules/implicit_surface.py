@@ -82,6 +82,8 @@ class ImplicitSurface(nn.Module):
         self.val_chunk = 8192          # rays per chunk in validate(); rays are independent, so this is a free knob
         self.fused_sdf = True          # inference: evaluate the SDF network with the fused MFMA kernel (gens_sdf_mlp)
         self._sdf_plan = None
+        self.fused_blend = True        # inference: source-view look-up + colour network in one kernel (gens_blend_views)
+        self._blend_plan = None
 
     # ----------------------------------------------------------------------------------------------------------
     # masked SDF evaluation (Q7, Q8)
@@ -107,6 +109,16 @@ class ImplicitSurface(nn.Module):
         if self._sdf_plan is None or self._sdf_plan.key != ops.SdfMlpPlan.version(net):
             self._sdf_plan = ops.SdfMlpPlan(net)
         return self._sdf_plan
+
+    def _fused_blend_plan(self, views):
+        if not self.fused_blend or torch.is_grad_enabled():
+            return None
+        net = self.color_network
+        if not ops.BlendPlan.supported(net) or len(views.feat_tex) > 5 or net.rgb_fc[0].weight.shape[1] != 37:
+            return None
+        if self._blend_plan is None or self._blend_plan.key != ops.BlendPlan.version(net):
+            self._blend_plan = ops.BlendPlan(net)
+        return self._blend_plan if self._blend_plan.n_feat == 3 + 4 * len(views.feat_tex) else None
 
     def _masked_sdf(self, pts, valid, volumes):
         idx = self._select(valid)
@@ -192,10 +204,14 @@ class ImplicitSurface(nn.Module):
             gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
             smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
 
-        feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
-        color_v = self.color_network(feat_views, ray_diff, vis_v)
-        sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
-        src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
+        bplan = self._fused_blend_plan(scene.views) if lean else None
+        if bplan is not None:                      # K4 + colour network fused, scattered into the dense arrays
+            sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx)
+        else:
+            feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
+            color_v = self.color_network(feat_views, ray_diff, vis_v)
+            sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
+            src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
 
         inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
         comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, sdf, gradients, smooth, sampled_color, valid, src_vis, inv_s,

@@ -581,3 +581,65 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
            plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None,
            L.stream(), nbytes=n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0)), flops=n * flops)
     return (sdf_out, grad_out) if want_grad else sdf_out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K7  fused source-view look-up + BlendingNetwork (inference)   (projector.py:278-349 + blending_network.py:69-118)
+# ------------------------------------------------------------------------------------------------------------------
+def _pad32(b):
+    out = torch.zeros(32 * ((b.numel() + 31) // 32), device=b.device, dtype=_f32)
+    out[:b.numel()] = b.reshape(-1)
+    return out
+
+
+class BlendPlan:
+    """Weights of a BlendingNetwork re-packed for gens_blend_views (anti_alias_pooling=True, d_feature <= 20)."""
+
+    @staticmethod
+    def supported(net):
+        return bool(getattr(net, "anti_alias_pooling", False)) and net.base_fc[0].weight.shape[0] == 64 and net.rgb_fc[0].weight.shape[1] == 37
+
+    @staticmethod
+    def version(net):
+        return tuple(p._version for p in net.parameters()) + tuple(p.data_ptr() for p in net.parameters())
+
+    def __init__(self, net):
+        assert BlendPlan.supported(net)
+        g = lambda m: (m.weight.detach().to(_f32), m.bias.detach().to(_f32))  # noqa: E731
+        with torch.no_grad():
+            rd1, rd2 = g(net.ray_dir_fc[0]), g(net.ray_dir_fc[2])
+            b1, b2 = g(net.base_fc[0]), g(net.base_fc[2])
+            v1, v2 = g(net.vis_fc[0]), g(net.vis_fc[2])
+            u1, u2 = g(net.vis_fc2[0]), g(net.vis_fc2[2])
+            r1, r2, r3 = g(net.rgb_fc[0]), g(net.rgb_fc[2]), g(net.rgb_fc[4])
+            self.n_feat = rd2[0].shape[0]                  # 3 + d_feature
+            P = _pack_b_fragments
+            self.tensors = [P(rd1[0]), _pad32(rd1[1]), P(rd2[0]), _pad32(rd2[1]), P(b1[0]), _pad32(b1[1]), P(b2[0]), _pad32(b2[1]),
+                            P(v1[0]), _pad32(v1[1]), P(v2[0][:32]), _pad32(v2[1][:32]), _c(v2[0][32].clone()),
+                            P(u1[0]), _pad32(u1[1]), _c(u2[0][0].clone()),
+                            P(r1[0]), _pad32(r1[1]), P(r2[0]), _pad32(r2[1]), _c(r3[0][0].clone())]
+            self.scalars = (C.c_float * 4)(float(v2[1][32]), float(u2[1][0]), float(r3[1][0]), float(net.s.detach().abs()))
+        self.table = L.ptr_table(self.tensors)
+        self.key = BlendPlan.version(net)
+
+
+def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None):
+    """Blended colour of pts[index] (N,3) and the per-source in-frustum flags (N,S) written at index (dense outputs)."""
+    pts = _c(pts.detach().reshape(-1, 3).to(_f32))
+    n = pts.shape[0] if index is None else index.shape[0]
+    s = views.nv - 1
+    nl = len(views.feat_tex)
+    assert plan.n_feat == 3 + 4 * nl, "colour network width does not match the feature pyramid"
+    if rgb_out is None:
+        rgb_out = torch.zeros(pts.shape[0], 3, device=pts.device, dtype=_f32)
+    if vis_out is None:
+        vis_out = torch.zeros(pts.shape[0], s, device=pts.device, dtype=torch.uint8)
+    idx = None if index is None else _c(index.to(torch.int64))
+    hw = [d for f in views.feat_tex for d in f.shape[1:3]]
+    feats = [_c(f.detach()) for f in views.feat_tex]
+    f = plan.n_feat
+    flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
+    L.call("gens_blend_views", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(views.imgs_tex.detach())), L.ptr(views.w2c), L.ptr(views.intr),
+           L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(rgb_out),
+           L.ptr(vis_out, torch.uint8), L.stream(), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
+    return rgb_out, vis_out

@@ -184,6 +184,21 @@ int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels,
                  const float* pts, const int64_t* index, int64_t n, float* sdf_out, float* grad_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K7  lookup_feature + BlendingNetwork.forward fused, inference only
+ *     (projector.py:278-349 followed by blending_network.py:69-118, as called from implicit_surface.py:196-199)
+ *   feats / hw / imgs / w2c / intr / c2w / nv as in gens_lookup_feature_fwd (n_levels <= 5).
+ *   weights: HOST array of 21 device pointers in the order
+ *     ray_dir_fc.0 W,b  ray_dir_fc.2 W,b  base_fc.0 W,b  base_fc.2 W,b  vis_fc.0 W,b  vis_fc.2 W[0:32],b[0:32]  vis_fc.2 W[32]
+ *     vis_fc2.0 W,b  vis_fc2.2 W  rgb_fc.0 W,b  rgb_fc.2 W,b  rgb_fc.4 W
+ *   (matrices in MFMA B-fragment order, biases zero-padded to a multiple of 32; gens_amd.ops.BlendPlan builds them);
+ *   scalars: HOST float[4] = { vis_fc.2 bias[32], vis_fc2.2 bias, rgb_fc.4 bias, |s| }.
+ *   index as in gens_sdf_mlp.  rgb_out (N_total, 3); vis_out (N_total, S) uint8 or NULL, written at index[i].
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_blend_views(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c,
+                     const float* intr, const float* c2w, int nv, const float* const* weights, const float* scalars,
+                     const float* pts, const int64_t* index, int64_t n, float* rgb_out, uint8_t* vis_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)
  *   image (H, W, C_pad) texels of one view; xy (P, 2) PIXEL coordinates (the normalise/un-normalise pair of
  *   :404-405 and align_corners=True cancel); out (P, C).  bwd: g_out (P, C) -> g_xy (P, 2), overwritten.

@@ -108,7 +108,7 @@ def test_lean_validation_path_equals_full_render(golden):
     for k in ["color_fine", "render_depth", "sdf_depth", "weights", "inside_sphere"]:
         close(lean[k], full[k], atol=2e-5, rtol=1e-4, what=k)
     close(lean["gradients"], full["gradients"], atol=2e-4, rtol=1e-3, what="gradients")
-    surf.fused_sdf = False
+    surf.fused_sdf = surf.fused_blend = False
     with torch.no_grad():
         lean_torch = surf.render_core(*args, lean=True)
     for k in ["color_fine", "render_depth", "sdf_depth", "weights", "gradients", "inside_sphere"]:
