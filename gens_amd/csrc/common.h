@@ -87,6 +87,21 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sin_f32 / v_cos_f32: ~1 ulp, one instruction each) for
+// the fused MLP kernels, whose accurate-libm activations would otherwise out-weigh the MFMA work 1:1 in issue slots.
+__device__ __forceinline__ float hw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float hw_sigmoid(float x) { return hw_rcp(1.0f + hw_exp(-x)); }
+// sin / cos with a two-term Cody-Waite reduction to revolutions in [-0.5, 0.5] (argument error < 2e-7 rad for |x| < 1e4)
+__device__ __forceinline__ void hw_sincos(float x, float& s, float& c) {
+    const float inv2pi_hi = 0.15915494309189535f, inv2pi_lo = 6.4206322e-9f;
+    float k = rintf(x * inv2pi_hi);
+    float v = fmaf(x, inv2pi_lo, fmaf(x, inv2pi_hi, -k));
+    s = __builtin_amdgcn_sinf(v);
+    c = __builtin_amdgcn_cosf(v);
+}
+
 // nearest-neighbour mask read with grid_sample(align_corners=False) index math: ((p+1)*D-1)/2 rounded half-to-even (Q6)
 __device__ __forceinline__ float mask_nearest(const float* __restrict__ m, int dx, int dy, int dz, float px, float py,
                                               float pz) {

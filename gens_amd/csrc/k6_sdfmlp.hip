@@ -37,10 +37,11 @@ struct SdfMlpWeights {
 
 __device__ __forceinline__ float softplus100(float x, float& dsig) {
     float t = 100.0f * x;
-    if (t > 20.0f) { dsig = 1.0f; return x; }
-    float e = expf(t);
-    dsig = e / (e + 1.0f);
-    return log1pf(e) / 100.0f;
+    float e = hw_exp(fminf(t, 20.0f));
+    float u = 1.0f + e;
+    bool lin = t > 20.0f;                      // torch.nn.Softplus threshold
+    dsig = lin ? 1.0f : e * hw_rcp(u);
+    return lin ? x : hw_log(u) * 0.01f;
 }
 
 // C = A(32 x 2KK, LDS row-major stride rs, starting at column 0) * B(packed fragments) accumulated into acc
@@ -92,8 +93,7 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float f = (float)(1 << k);
-                pe[3 + 6 * k + a] = sinf(v * f);
-                pe[6 + 6 * k + a] = cosf(v * f);
+                hw_sincos(v * f, pe[3 + 6 * k + a], pe[6 + 6 * k + a]);
             }
             if (a == 0) { pe[27] = 0.0f; pe[28] = 0.0f; }
         }
@@ -136,10 +136,8 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
             for (int c = 0; c < 4; ++c) {
                 const int ch = 4 * l + c;
                 xr[ch] = fv[c];
-                xr[CF + ch] = sinf(fv[c]);
-                xr[2 * CF + ch] = cosf(fv[c]);
-                xr[3 * CF + ch] = sinf(2.0f * fv[c]);
-                xr[4 * CF + ch] = cosf(2.0f * fv[c]);
+                hw_sincos(fv[c], xr[CF + ch], xr[2 * CF + ch]);
+                hw_sincos(2.0f * fv[c], xr[3 * CF + ch], xr[4 * CF + ch]);
             }
             if constexpr (GRAD) {
                 const float sx = (float)(Xd - 1) / 2.0f, sy = (float)(Yd - 1) / 2.0f, sz_ = (float)(Zd - 1) / 2.0f;

@@ -29,7 +29,7 @@ struct BlendWeights {
     float v2_last_b, u2_b, r3_b, s_abs;
 };
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int rs, const float* __restrict__ wp, int kk_count,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < F) T[crow(r, lane) * BL_TS + 2 * F + col] += elu1(a[r]);        // x = rgb_feat + direction_feat (:89)
-        if (half == 0) R[row * 8 + 1] = expf(W.s_abs * (RD[row * 5 + 3] - 1.0f));     // exp(|s| (dot - 1))  (:93)
+        if (half == 0) R[row * 8 + 1] = hw_exp(W.s_abs * (RD[row * 5 + 3] - 1.0f));     // exp(|s| (dot - 1))  (:93)
     }
     __syncthreads();
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         if (half == 0) {                                                         // 33rd output -> vis
             float s = W.v2_last_b;
             for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.v2_last[k];
-            R[row * 8 + 4] = sigmoidf_(elu1(s)) * R[row * 8];
+            R[row * 8 + 4] = hw_sigmoid(elu1(s)) * R[row * 8];
         }
     }
     __syncthreads();
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     if (half == 0) {
         float s = W.u2_b;
         for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.u2[k];
-        R[row * 8 + 5] = sigmoidf_(s) * R[row * 8];
+        R[row * 8 + 5] = hw_sigmoid(s) * R[row * 8];
     }
     __syncthreads();
     // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         for (int v = 0; v < S; ++v) mx = fmaxf(mx, R[(base + v) * 8 + 6]);
         float den = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         for (int v = 0; v < S; ++v) {
-            float e = expf(R[(base + v) * 8 + 6] - mx);
+            float e = hw_exp(R[(base + v) * 8 + 6] - mx);
             den += e;
             cr += C[(base + v) * 3] * e;
             cg += C[(base + v) * 3 + 1] * e;
