@@ -212,8 +212,12 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
     f32x16 gfe;     // this wave's 32-column tile of d sdf / d fe  (tiles 4.. of the backward GEMM output)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gfe[r] = 0.0f;
-    const int fe_tile = 4 + wave;
-    const bool has_fe_tile = fe_tile < NT_B;
+    // FE = 100: four conditioning tiles, one per wave.  FE = 60: two tiles; waves w and w+2 share tile 4 + (w & 1) and
+    // each reduces half of the 128-long K range (partials are summed in the epilogue), so all four waves stay busy.
+    constexpr bool SPLIT_K = (NT_B - 4) == 2;
+    const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
+    const int fe_kk0 = SPLIT_K ? 32 * (wave >> 1) : 0;
+    constexpr int FE_KK = SPLIT_K ? 32 : 64;
     __syncthreads();
     {
         const float wl = W.w_last[col];
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
 #pragma unroll
         for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
         gh = mfma_rows<8>(X, RS, W.wb[l] + (size_t)wave * 64 * 64, 64, gh, lane);
-        if (has_fe_tile) gfe = mfma_rows<8>(X, RS, W.wb[l] + (size_t)fe_tile * 64 * 64, 64, gfe, lane);
+        gfe = mfma_rows<8>(X + 2 * fe_kk0, RS, W.wb[l] + ((size_t)fe_tile * 64 + fe_kk0) * 64, FE_KK, gfe, lane);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -258,12 +262,19 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
     }
     __syncthreads();
     // conditioning gradient tiles -> LDS (reuse the h part of X: it is dead now)
-    if (has_fe_tile) {
-        const int c = 32 * wave + (lane & 31);          // column inside the fe block
-        if (c < FE) {
+    {
+        const int c = 32 * (fe_tile - 4) + (lane & 31); // column inside the fe block
+        if (c < FE && (!SPLIT_K || wave < 2)) {
             const float wl = W.w_last[MLP_H + c];       // layer 6 contributes the same vector for every point
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[acc_row(r, lane) * RS + c] = gfe[r] + wl;
+        }
+        if (SPLIT_K) {
+            __syncthreads();
+            if (c < FE && wave >= 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X[acc_row(r, lane) * RS + c] += gfe[r];
+            }
         }
     }
     __syncthreads();

@@ -51,14 +51,12 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
                                                          uint8_t* __restrict__ vis_out) {
     __shared__ float T_[BL_WAVES][32 * BL_TS];
     __shared__ float V_[BL_WAVES][32 * BL_VS];
-    __shared__ float H_[BL_WAVES][32 * BL_HS];
     __shared__ float RD_[BL_WAVES][32 * 5];
     __shared__ float R_[BL_WAVES][32 * 8];     // per-row scalars: 0 mask, 1 e, 2 w, 3 w normalised, 4 vis, 5 vis2, 6 score
     __shared__ float C_[BL_WAVES][32 * 3];     // rgb_in
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* T = T_[wave];
     float* V = V_[wave];
-    float* H = H_[wave];
     float* RD = RD_[wave];
     float* R = R_[wave];
     float* C = C_[wave];
@@ -212,7 +210,6 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     for (int r = 0; r < 16; ++r) {
         const int rr = crow(r, lane);
         V[rr * BL_VS + col] = h[r] * R[rr * 8 + 4];
-        H[rr * BL_HS + col] = h[r];
     }
     __syncthreads();
     {
