@@ -13,7 +13,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BL_WAVES 2          // wavefronts per workgroup
+#define BL_WAVES 1          // wavefronts per workgroup: waves are independent, a 1-wave workgroup makes every barrier free
 #define BL_TS 73            // row stride of the wide tile (K <= 70)
 #define BL_VS 65            // row stride of the 64-wide tile
 #define BL_HS 33            // row stride of the hidden tile
@@ -44,23 +44,28 @@ __device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int
     return acc;
 }
 
+template <int NLEV>
 __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet fs, const float4* __restrict__ imgs,
                                                          const float* __restrict__ w2c, const float* __restrict__ intr,
                                                          const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
                                                          const int64_t* __restrict__ index, int64_t n, float* __restrict__ rgb_out,
                                                          uint8_t* __restrict__ vis_out) {
     __shared__ float T_[BL_WAVES][32 * BL_TS];
-    __shared__ float V_[BL_WAVES][32 * BL_VS];
+    __shared__ float D_[BL_WAVES][32 * 17];    // ray_dir_fc hidden layer
     __shared__ float RD_[BL_WAVES][32 * 5];
     __shared__ float R_[BL_WAVES][32 * 8];     // per-row scalars: 0 mask, 1 e, 2 w, 3 w normalised, 4 vis, 5 vis2, 6 score
     __shared__ float C_[BL_WAVES][32 * 3];     // rgb_in
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* T = T_[wave];
-    float* V = V_[wave];
+    // V (64-wide tile, stride BL_VS) ALIASES T: a wave finishes every MFMA read of a tile before its epilogue writes, and
+    // the two layouts are never live together (T: until base_fc.0 has been read; again from rgb_fc.0's output on).
+    float* V = T_[wave];
+    float* D = D_[wave];
     float* RD = RD_[wave];
     float* R = R_[wave];
     float* C = C_[wave];
-    const int S = nv - 1, PPW = 32 / S, F = 3 + 4 * fs.n;
+    constexpr int F = 3 + 4 * NLEV;
+    const int S = nv - 1, PPW = 32 / S;
     const int64_t first = ((int64_t)blockIdx.x * BL_WAVES + wave) * PPW;
     const int row = lane & 31, half = lane >> 5;
     const int pl = row / S, sv = row % S + 1;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         float x = 0.f, y = 0.f, z = 0.f;
         if (live) { x = pts[3 * src]; y = pts[3 * src + 1]; z = pts[3 * src + 2]; }
         bool inside = true;
-        const int l_begin = half ? 2 : 0, l_end = half ? fs.n : min(2, fs.n);
+        const int l_begin = half ? 2 : 0, l_end = half ? NLEV : min(2, NLEV);
         float* xr = T + row * BL_TS + 2 * F;
         for (int l = l_begin; l < l_end; ++l) {
             const int h = fs.h[l], w = fs.w[l];
@@ -122,11 +127,11 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         f32x16 a = tile_mfma(RD, 5, W.rd1, 2, W.rd1_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (col < 16) V[crow(r, lane) * BL_VS + col] = elu1(a[r]);
+            if (col < 16) D[crow(r, lane) * 17 + col] = elu1(a[r]);
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(V, BL_VS, W.rd2, 8, W.rd2_b[col], lane);
+        f32x16 a = tile_mfma(D, 17, W.rd2, 8, W.rd2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < F) T[crow(r, lane) * BL_TS + 2 * F + col] += elu1(a[r]);        // x = rgb_feat + direction_feat (:89)
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     __syncthreads();
 
     // ---------------------------------------------------------------- base_fc (:103-104)
-    const int kk_base = (3 * F + 1) / 2;
+    constexpr int kk_base = (3 * F + 1) / 2;
     {
         f32x16 a0 = tile_mfma(T, BL_TS, W.b1, kk_base, W.b1_b[col], lane);
         f32x16 a1 = tile_mfma(T, BL_TS, W.b1 + (size_t)kk_base * 64, kk_base, W.b1_b[32 + col], lane);
@@ -298,7 +303,16 @@ extern "C" int gens_blend_views(const float* const* feats, const int* hw, int n_
     W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
     const int ppw = 32 / (nv - 1);
     const int64_t waves = (n + ppw - 1) / ppw;
-    blend_k<<<gens_blocks(waves, BL_WAVES), 64 * BL_WAVES, 0, (hipStream_t)stream>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, nv, pts,
-                                                                                    index, n, rgb_out, vis_out);
+    const unsigned grid = gens_blocks(waves, BL_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+#define BLEND_LAUNCH(NL) blend_k<NL><<<grid, 64 * BL_WAVES, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, index, n, rgb_out, vis_out)
+    switch (n_levels) {
+        case 1: BLEND_LAUNCH(1); break;
+        case 2: BLEND_LAUNCH(2); break;
+        case 3: BLEND_LAUNCH(3); break;
+        case 4: BLEND_LAUNCH(4); break;
+        default: BLEND_LAUNCH(5); break;
+    }
+#undef BLEND_LAUNCH
     return gens_launch_status("gens_blend_views");
 }
