@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--views", type=int, default=5)
     p.add_argument("--cpu-rays", type=int, default=96, help="rays of the CPU-oracle baseline sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--sdf-precision", default="f32", choices=["f32", "f16x2"],
+                   help="f32: exact float32 MFMA (headline); f16x2: split-half operands on the f16 matrix cores (~1e-6 relative)")
     return p.parse_args()
 
 
@@ -87,6 +89,7 @@ def main():
     n_rays = rays_o.shape[0]
     surf, volume = build_model(args.dims, dev)
     surf.val_chunk = args.chunk
+    surf.sdf_precision = args.sdf_precision
     n_final = surf.n_samples + surf.n_importance
     hw = (1, n_rays)
 
@@ -173,7 +176,8 @@ def main():
     line = {
         "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.sdf_precision == "f32" else "f32 (SDF-MLP operands as split f16 hi+lo pairs, f32 accumulate)", "data": "synthetic",
         "config": {"workload": "BASELINE config[1]: 5-view 480x640, volume_dims=%s, inference of %d rays x %d samples per scene "
                                "(K1 volume build + hierarchical sampling + SDF/blend MLPs + compositing); one scene per GPU"
                                % (args.dims, n_rays, n_final),

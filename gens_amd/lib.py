@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgens_hip.so")
+LIB_PATH = os.environ.get("GENS_HIP_LIB", os.path.join(_HERE, "csrc", "libgens_hip.so"))   # env override: development builds
 
 MAX_LEVELS = 8
 MAX_VIEWS = 8
@@ -65,6 +65,7 @@ SIGNATURES = {
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
     "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p],
+    "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p],
 }
 

@@ -81,6 +81,7 @@ class ImplicitSurface(nn.Module):
         self.deviation_network = SingleVarianceNetwork(**confs["variance_network"])
         self.val_chunk = 8192          # rays per chunk in validate(); rays are independent, so this is a free knob
         self.fused_sdf = True          # inference: evaluate the SDF network with the fused MFMA kernel (gens_sdf_mlp)
+        self.sdf_precision = "f32"     # "f32": exact float32 MFMA; "f16x2": split-half operands (~1e-6 rel.), float32 fallback on overflow
         self._sdf_plan = None
         self.fused_blend = True        # inference: source-view look-up + colour network in one kernel (gens_blend_views)
         self._blend_plan = None
@@ -120,12 +121,19 @@ class ImplicitSurface(nn.Module):
             self._blend_plan = ops.BlendPlan(net)
         return self._blend_plan if self._blend_plan.n_feat == 3 + 4 * len(views.feat_tex) else None
 
+    def _precision(self, plan):
+        return "f16x2" if (self.sdf_precision == "f16x2" and plan.f16_ok) else "f32"
+
+    def _split_half_overflowed(self):
+        """True if a split-half launch met a value outside the half range since the last check (one device sync)."""
+        return self.sdf_precision == "f16x2" and self._sdf_plan is not None and self._sdf_plan.overflowed()
+
     def _masked_sdf(self, pts, valid, volumes):
         idx = self._select(valid)
         sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
         plan = self._fused_plan(volumes)
         if plan is not None:
-            ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf)
+            ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf, precision=self._precision(plan))
         else:
             sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
         return sdf
@@ -188,7 +196,7 @@ class ImplicitSurface(nn.Module):
         if plan is not None:                       # fused look-up + MLP + d/dx, scattered straight into the dense arrays
             sdf = torch.full((b * n, 1), 100.0, device=dev)
             gradients = torch.zeros(b * n, 3, device=dev)
-            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients)
+            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan))
             smooth = None
         else:
             if lean:
@@ -290,7 +298,7 @@ class ImplicitSurface(nn.Module):
             count = min(chunk, total - first)
             pts = ops.lattice_points(bound_min.tolist(), bound_max.tolist(), resolution, first, count, dev)
             plan = self._fused_plan(vols)
-            sdf = ops.sdf_mlp(plan, vols, pts) if plan is not None else self.sdf_network.sdf(pts, vols)
+            sdf = ops.sdf_mlp(plan, vols, pts, precision=self._precision(plan)) if plan is not None else self.sdf_network.sdf(pts, vols)
             u[first:first + count] = -sdf[:, 0]
         return u.reshape(resolution, resolution, resolution)
 
@@ -327,6 +335,13 @@ class ImplicitSurface(nn.Module):
             normals.append((r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1))
             sdf_depth.append(r["sdf_depth"])
             render_depth.append(r["render_depth"])
+        if self._split_half_overflowed():              # a value left the half range: render this image again in float32
+            saved, self.sdf_precision = self.sdf_precision, "f32"
+            try:
+                return self.validate(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                     bound_min, bound_max, hw, cos_anneal_ratio, step, extract_geometry, mesh_resolution, threshold, scene)
+            finally:
+                self.sdf_precision = saved
         color_fine = torch.cat(rgb, 0).cpu()                                                # D2H once per image, not per chunk
         normal_img = torch.cat(normals, 0).cpu().numpy()
         rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())

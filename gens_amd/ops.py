@@ -523,6 +523,19 @@ def _pack_b_fragments(w):
     return wp.view(nt, 32, kk, 2).permute(0, 2, 3, 1).contiguous()
 
 
+def _pack_b_fragments_f16(w):
+    """(J, K) matrix -> split-half MFMA 32x32x16 B fragments: two (hi, lo) tensors [ceil(J/32)][ceil(K/16)][64][8] of halfs;
+    lane l of fragment (nt, kb) holds w[32 nt + (l & 31)][16 kb + 8 (l >> 5) + 0..7]."""
+    j, k = w.shape
+    nt, kb = (j + 31) // 32, (k + 15) // 16
+    wp = torch.zeros(nt * 32, kb * 16, device=w.device, dtype=_f32)
+    wp[:j, :k] = w
+    wp = wp.view(nt, 32, kb, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    return hi, lo
+
+
 class SdfMlpPlan:
     """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
     (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
@@ -548,7 +561,7 @@ class SdfMlpPlan:
                 bs.append(lin.bias.detach().to(_f32))
             dev = ws[0].device
             self.n_levels = net.init_feat_channels // 4
-            self.wf, self.wb, self.bias = [], [], []
+            self.wf, self.wb, self.bias, self.hf, self.hb = [], [], [], [], []
             for l in range(6):
                 w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
                 w[:ws[l].shape[0]] = ws[l]
@@ -557,16 +570,32 @@ class SdfMlpPlan:
                 self.wf.append(_pack_b_fragments(w))
                 self.wb.append(_pack_b_fragments(w.t().contiguous()))
                 self.bias.append(b)
+                pf, pb = _pack_b_fragments_f16(w), _pack_b_fragments_f16(w.t().contiguous())
+                self.hf.append(pf)
+                self.hb.append(pb)
             self.w_last = _c(ws[6][0].clone())
             self.b_last = float(bs[6][0])
             self.scale = float(net.scale)
+            self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
+            self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
         self.wf_table, self.wb_table, self.bias_table = L.ptr_table(self.wf), L.ptr_table(self.wb), L.ptr_table(self.bias)
+        h16 = torch.float16
+        self.hf_hi, self.hf_lo = L.ptr_table([t[0] for t in self.hf], h16), L.ptr_table([t[1] for t in self.hf], h16)
+        self.hb_hi, self.hb_lo = L.ptr_table([t[0] for t in self.hb], h16), L.ptr_table([t[1] for t in self.hb], h16)
         self.key = SdfMlpPlan.version(net)
 
+    def overflowed(self):
+        """True if any split-half launch since the last call met a value outside the half range (synchronises)."""
+        hit = bool(self.overflow.item())
+        if hit:
+            self.overflow.zero_()
+        return hit
 
-def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None):
+
+def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None, precision="f32"):
     """sdf (and d sdf/dx) of pts[index] written to sdf_out[index] / grad_out[index] (fresh, densely indexed outputs if
-    no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference)."""
+    no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference).
+    precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed())."""
     assert isinstance(volumes, VolumeSet) and volumes.layout == L.LAYOUT_PACKED and volumes.n == plan.n_levels
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
     n = pts.shape[0] if index is None else index.shape[0]
@@ -577,9 +606,16 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     idx = None if index is None else _c(index.to(torch.int64))
     fe = 20 * plan.n_levels
     flops = 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1)) * (2 if want_grad else 1)
-    L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.bias_table, plan.wb_table, L.ptr(plan.w_last),
-           plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None,
-           L.stream(), nbytes=n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0)), flops=n * flops)
+    nbytes = n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0))
+    if precision == "f16x2":
+        assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
+        L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
+               plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out),
+               L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes, flops=n * flops)
+    else:
+        L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.bias_table, plan.wb_table, L.ptr(plan.w_last),
+               plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None,
+               L.stream(), nbytes=nbytes, flops=n * flops)
     return (sdf_out, grad_out) if want_grad else sdf_out
 
 

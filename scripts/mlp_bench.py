@@ -40,6 +40,12 @@ def main():
         t2 = timeit(lambda: ops.sdf_mlp(plan, vols, pts, want_grad=True, sdf_out=sdf, grad_out=grad))
         print(f"L={len(dims)} sdf fwd : {t1:7.2f} ms  {n / t1 / 1e3:7.1f} Mpts/s  {n * f_fwd / t1 / 1e9:6.1f} TFLOP/s")
         print(f"L={len(dims)} sdf grad: {t2:7.2f} ms  {n / t2 / 1e3:7.1f} Mpts/s  {n * 2 * f_fwd / t2 / 1e9:6.1f} TFLOP/s")
+        s32, g32 = sdf.clone(), grad.clone()
+        t1 = timeit(lambda: ops.sdf_mlp(plan, vols, pts, sdf_out=sdf, precision="f16x2"))
+        t2 = timeit(lambda: ops.sdf_mlp(plan, vols, pts, want_grad=True, sdf_out=sdf, grad_out=grad, precision="f16x2"))
+        print(f"L={len(dims)} f16x2 fwd : {t1:7.2f} ms  {n / t1 / 1e3:7.1f} Mpts/s  (equiv {n * f_fwd / t1 / 1e9:6.1f} TFLOP/s)")
+        print(f"L={len(dims)} f16x2 grad: {t2:7.2f} ms  {n / t2 / 1e3:7.1f} Mpts/s  (equiv {n * 2 * f_fwd / t2 / 1e9:6.1f} TFLOP/s)"
+              f"  max|dsdf| {float((sdf - s32).abs().max()):.2e} max|dgrad| {float((grad - g32).abs().max()):.2e} overflow {plan.overflowed()}")
     sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
     views = ops.SceneViews(sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev), [f.to(dev) for f in sc["features"]])
     bp = ops.BlendPlan(surf.color_network)

@@ -140,3 +140,19 @@ def test_partition_invariance_of_validate(golden):
     for k in ["color_fine", "sdf_depth", "render_depth", "normal_img"]:
         # not bit-identical: rocBLAS picks GEMM tilings by batch size, and the resampling amplifies that round-off
         close(torch.as_tensor(outs[0][k]), torch.as_tensor(outs[1][k]), atol=1e-4, rtol=1e-4, what=k)
+
+
+def test_validate_with_split_half_sdf_matches_float32(golden):
+    g = golden("g9a_render")
+    surf = build_surface(g)
+    feats, vols, masks, match, step = scene_inputs(g)
+    c = lambda t: t.cuda()  # noqa: E731
+    outs = {}
+    for prec in ("f32", "f16x2"):
+        surf.sdf_precision = prec
+        torch.manual_seed(3)
+        outs[prec] = surf.validate(c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match,
+                                   c(g["intrs"]), c(g["c2ws"]), None, None, (4, 6), extract_geometry=False)
+    for k in ["color_fine", "render_depth", "sdf_depth"]:
+        a, b = torch.as_tensor(outs["f16x2"][k]), torch.as_tensor(outs["f32"][k])
+        assert (a - b).abs().mean() < 1e-4, k

@@ -72,3 +72,28 @@ def test_fused_matches_cpu_oracle(golden):
     s, gr = ops.sdf_mlp(plan, ops.VolumeSet.packed([v.cuda() for v in vols]), pts.cuda(), want_grad=True)
     assert (s.cpu() - ref).abs().max() < 2e-5
     assert (gr.cpu() - ref_g.detach()).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 33)])
+def test_split_half_kernel_matches_float32_kernel(n_levels, n):
+    """gens_sdf_mlp_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation."""
+    from gens_amd import ops, synthetic
+    net, dims = _net(n_levels, seed=10 + n_levels)
+    vols = ops.VolumeSet.packed([v.cuda() * 3 for v in synthetic.make_volumes(dims, seed=9)])
+    pts = (torch.rand(n, 3, generator=torch.Generator().manual_seed(n)) * 2.2 - 1.1).cuda()
+    plan = ops.SdfMlpPlan(net)
+    s32, g32 = ops.sdf_mlp(plan, vols, pts, want_grad=True)
+    s16, g16 = ops.sdf_mlp(plan, vols, pts, want_grad=True, precision="f16x2")
+    only = ops.sdf_mlp(plan, vols, pts, precision="f16x2")
+    assert not plan.overflowed()
+    assert (s16 - s32).abs().max() < 1e-5 and (only - s32).abs().max() < 1e-5
+    assert (g16 - g32).abs().max() < 1e-4 * max(1.0, g32.abs().max().item())
+
+
+def test_split_half_overflow_is_flagged():
+    from gens_amd import ops, synthetic
+    net, dims = _net(3, seed=1)
+    big = [v.cuda() * 1e6 for v in synthetic.make_volumes(dims, seed=9)]     # features far outside the half range
+    plan = ops.SdfMlpPlan(net)
+    ops.sdf_mlp(plan, ops.VolumeSet.packed(big), torch.zeros(64, 3, device="cuda"), precision="f16x2")
+    assert plan.overflowed() and not plan.overflowed()                      # reading the flag clears it
