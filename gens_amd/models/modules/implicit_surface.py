@@ -59,14 +59,55 @@ class Scene:
         return self._warp[use_match]
 
 
-def reference_jitter(n_rays, chunk=REFERENCE_CHUNK):
-    """The (n_rays,1) stratified-jitter draws `validate` would make chunk by chunk, including the 1024x3 draw that
-    render_core makes in between (implicit_surface.py:256,362), so any chunking here renders the same image."""
+def _jitter_block(n_rays, chunk=REFERENCE_CHUNK):
+    """Jitter of `n_rays` rays (a whole number of reference chunks, except possibly the last) in the reference's draw order:
+    per chunk `torch.rand([chunk, 1])` followed by the `torch.rand([1024, 3])` of render_core (implicit_surface.py:256,362).
+    The CPU generator produces one float per 32-bit draw, so ONE large call yields the same stream as the 2*k small ones."""
+    full, rem = divmod(n_rays, chunk)
     out = []
-    for start in range(0, n_rays, chunk):
-        out.append(torch.rand([min(chunk, n_rays - start), 1]))
+    if full:
+        per = chunk + 3 * N_RANDOM_PTS
+        out.append(torch.rand(full * per).reshape(full, per)[:, :chunk].reshape(-1, 1))
+    if rem:
+        out.append(torch.rand([rem, 1]))
         torch.rand([N_RANDOM_PTS, 3])
-    return torch.cat(out, 0)
+    return torch.cat(out, 0) if out else torch.zeros(0, 1)
+
+
+def reference_jitter(n_rays, chunk=REFERENCE_CHUNK):
+    """The (n_rays,1) stratified-jitter draws `validate` would make chunk by chunk, so any chunking here renders the same image."""
+    return _jitter_block(n_rays, chunk)
+
+
+class JitterStream:
+    """reference_jitter() produced group by group on a helper thread, so the ~4 M host RNG draws of a 480x640 image overlap
+    with GPU work instead of preceding it.  Only this thread touches the default CPU generator while it runs."""
+
+    def __init__(self, n_rays, group):
+        import threading
+        group = max(REFERENCE_CHUNK, group // REFERENCE_CHUNK * REFERENCE_CHUNK)
+        self.bounds = [(s, min(s + group, n_rays)) for s in range(0, n_rays, group)]
+        self.parts = [None] * len(self.bounds)
+        self.ready = [threading.Event() for _ in self.bounds]
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        for k, (s, e) in enumerate(self.bounds):
+            self.parts[k] = _jitter_block(e - s)
+            self.ready[k].set()
+
+    def slice(self, s, e):
+        out = []
+        for k, (bs, be) in enumerate(self.bounds):
+            if be <= s or bs >= e:
+                continue
+            self.ready[k].wait()
+            out.append(self.parts[k][max(s, bs) - bs:min(e, be) - bs])
+        return torch.cat(out, 0) if len(out) != 1 else out[0]
+
+    def join(self):
+        self.thread.join()
 
 
 class ImplicitSurface(nn.Module):
@@ -325,16 +366,18 @@ class ImplicitSurface(nn.Module):
                                                                               threshold)
         height, width = int(hw[0]), int(hw[1])
         n_rays = rays_o.shape[0]
-        t_rand = reference_jitter(n_rays) if self.perturb > 0 else None
+        jitter = JitterStream(n_rays, self.val_chunk) if self.perturb > 0 else None
         rgb, normals, sdf_depth, render_depth = [], [], [], []
         for s in range(0, n_rays, self.val_chunk):
             e = min(s + self.val_chunk, n_rays)
             r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
-                            cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if t_rand is None else t_rand[s:e])
+                            cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
             rgb.append(r["color_fine"])
             normals.append((r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1))
             sdf_depth.append(r["sdf_depth"])
             render_depth.append(r["render_depth"])
+        if jitter is not None:
+            jitter.join()
         if self._split_half_overflowed():              # a value left the half range: render this image again in float32
             saved, self.sdf_precision = self.sdf_precision, "f32"
             try:
