@@ -152,7 +152,13 @@ def main():
             if k.get("flops"):
                 table[name]["TFLOPs"] = round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1)
         dom_name, dom = max(((n, k) for n, k in kernels.items() if k["bytes"]), key=lambda kv: kv[1]["ms"])
-        common = {"kernel": dom_name, "traffic": None, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+        traffic = None      # HBM bytes per launch from the committed PMC passes (same command, ray chunk 32768); see the file's note
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.chunk == 32768:
+            t = json.load(open(tpath))["kernels"].get(dom_name)
+            if t:
+                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+        common = {"kernel": dom_name, "traffic": traffic, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                   "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
         if dom.get("flops"):      # the fused MLP is matrix-core bound: price it against the dense fp32 MFMA peak
             achieved = dom["flops"] / 1e12 / (dom["ms"] / 1e3)
