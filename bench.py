@@ -69,7 +69,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GENS_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", init_method="env://")      # 'nccl' is RCCL on ROCm
 

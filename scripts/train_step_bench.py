@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Timing of one training step of the hot path (BASELINE config 3 shape): 5 views 480x640, volume_dims 256/128/64,
+512 rays + 2048 pseudo points, forward through ImplicitSurface (all 18 keys) + a reference-like loss + backward into
+the SDF/colour MLPs, the volumes and the feature pyramid.  CNNs are out of scope: features / volumes are leaf tensors."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gens_amd import ops, synthetic  # noqa: E402
+from gens_amd.config import gens_model_conf  # noqa: E402
+from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    dims = [256, 128, 64]
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
+    imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
+    feats = [f.to(dev).requires_grad_(True) for f in sc["features"]]
+    vols = [v.to(dev).requires_grad_(True) for v in synthetic.make_volumes(dims, seed=1)]
+    torch.manual_seed(0)
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    pix = torch.stack([torch.randint(0, 640, (512,), generator=g), torch.randint(0, 480, (512,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640, pixels=pix)
+    ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": sc["near"].to(dev),
+            "far": sc["far"].to(dev), "pseudo_pts": (torch.rand(2048, 3, generator=g) - 0.5).to(dev)}
+    target = torch.rand(512, 3, device=dev)
+    opt = torch.optim.Adam(surf.parameters(), lr=5e-4)
+
+    def step():
+        with torch.no_grad():
+            _, masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
+        cost, _ = ops.volume_build(feats[:3], intrs, c2ws, dims)            # K1 with autograd to the features
+        out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
+        hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+        loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
+            + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
+            + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean() + out["pseudo_sdf"].abs().mean() \
+            + 1e-6 * sum(c.mean() for c in cost)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"train step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+
+
+if __name__ == "__main__":
+    main()
