@@ -1,0 +1,129 @@
+"""GPU property tests at BASELINE.json's FULL sizes (5 views, 480x640, volume_dims 256/128/64[/32/16], 128 samples per ray),
+where the CPU oracle is too slow to be the checker: size-independent properties of the domain instead."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from gens_amd import ops, synthetic
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
+    dev = torch.device("cuda")
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    d["features"] = [f.to(dev) for f in sc["features"]]
+    d["dims"] = [256, 128, 64, 32, 16]
+    with torch.no_grad():
+        d["cost"], d["masks"] = ops.volume_build(d["features"], d["intrs"], d["c2ws"], d["dims"])
+    d["vols"] = [v.to(dev) for v in synthetic.make_volumes(d["dims"], seed=1)]
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
+    d["rays_o"], d["rays_d"] = ro.to(dev), rd.to(dev)
+    return d
+
+
+def test_k1_full_size_statistics_and_view_permutation(scene):
+    """mean/variance over views do not depend on the order of the views; var >= -eps; empty voxels are exactly zero;
+    mask == (count >= 2) is monotone: removing a view can only clear mask voxels."""
+    from gens_amd import ops
+    cost, masks = scene["cost"], scene["masks"]
+    perm = [0, 3, 1, 4, 2]
+    feats_p = [f[perm].contiguous() for f in scene["features"]]
+    cost_p, masks_p = ops.volume_build(feats_p, scene["intrs"][perm].contiguous(), scene["c2ws"][perm].contiguous(), scene["dims"])
+    for lvl in range(5):
+        assert torch.equal(masks[lvl], masks_p[lvl])
+        assert (cost[lvl] - cost_p[lvl]).abs().max() < 2e-5          # summation order only
+        assert cost[lvl][:, 4:].min() > -1e-4                        # E[x^2]-E[x]^2 in float32
+        assert masks[lvl].min() >= 0 and masks[lvl].max() <= 1
+    frac = float(masks[0].mean())
+    assert 0.2 < frac < 0.8, frac
+    _, masks4 = ops.volume_build([f[:4].contiguous() for f in scene["features"]], scene["intrs"][:4].contiguous(),
+                                 scene["c2ws"][:4].contiguous(), scene["dims"])
+    for lvl in range(5):
+        assert (masks4[lvl] <= masks[lvl]).all()
+    empty = (cost[0][:, :4].abs().sum(1, keepdim=True) == 0) & (masks[0] == 0)
+    assert (cost[0][:, 4:][empty.expand(-1, 4, -1, -1, -1)] == 0).all()
+
+
+def test_k2_full_size_linearity_and_lattice_identity(scene):
+    """The look-up is linear in the volume, exact at voxel centres, and packed == planar layout."""
+    from gens_amd import ops
+    vols = scene["vols"]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pts = torch.rand(2_000_000, 3, device="cuda", generator=g) * 2 - 1
+    a = ops.lookup_volume(pts, vols)
+    b = ops.lookup_volume(pts, ops.VolumeSet.packed(vols))
+    assert torch.equal(a, b)
+    other = [torch.randn_like(v) for v in vols]
+    lin = ops.lookup_volume(pts, [2.0 * v + 0.5 * o for v, o in zip(vols, other)])
+    assert (lin - (2.0 * a + 0.5 * ops.lookup_volume(pts, other))).abs().max() < 1e-4
+    d = 256
+    idx = torch.randint(0, d, (100000, 3), device="cuda", generator=g)
+    centres = idx.float() / (d - 1) * 2 - 1
+    at = ops.lookup_volume(centres, [vols[0]])
+    ref = vols[0][0][:, idx[:, 0], idx[:, 1], idx[:, 2]].t()
+    assert (at - ref).abs().max() < 2e-5
+
+
+def test_sampling_full_image_sorted_bounded_and_new_samples_inside_their_bins(scene):
+    from gens_amd import ops
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene
+    torch.manual_seed(0)
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(scene["dims"]))["implicit_surface"]).cuda().eval()
+    sc = Scene(scene["vols"], scene["masks"], scene["imgs"], scene["features"], scene["features"], scene["intrs"], scene["c2ws"])
+    n = 65536
+    ro, rd = scene["rays_o"][100000:100000 + n].contiguous(), scene["rays_d"][100000:100000 + n].contiguous()
+    z0 = (scene["near"] + (scene["far"] - scene["near"]) * torch.linspace(0, 1, 64, device="cuda")[None]).expand(n, 64).contiguous()
+    z = surf._sample_rays(ro, rd, z0, sc)
+    assert z.shape == (n, 128)
+    assert (z[:, 1:] >= z[:, :-1]).all()                                     # sorted
+    assert z.min() >= z0.min() - 1e-6 and z.max() <= z0.max() + 1e-6          # importance samples stay inside [near, far]
+    # every coarse sample survives the four merges
+    pos = torch.searchsorted(z.contiguous(), z0.contiguous())
+    assert torch.equal(torch.gather(z, 1, pos.clamp(max=127)), z0)
+
+
+def test_render_full_chunk_weights_are_a_sub_probability_and_partition_invariant(scene):
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene
+    torch.manual_seed(0)
+    dims = scene["dims"][:3]
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).cuda().eval()
+    sc = Scene(scene["vols"][:3], scene["masks"][:3], scene["imgs"], scene["features"], scene["features"], scene["intrs"], scene["c2ws"])
+    n = 32768
+    ro, rd = scene["rays_o"][120000:120000 + n].contiguous(), scene["rays_d"][120000:120000 + n].contiguous()
+    t_rand = torch.rand(n, 1, generator=torch.Generator().manual_seed(1))
+    args = (scene["near"], scene["far"], scene["vols"][:3], scene["masks"][:3], scene["imgs"], scene["features"], scene["features"],
+            scene["intrs"], scene["c2ws"], 1.0, None)
+    with torch.no_grad():
+        full = surf.render(ro, rd, *args, scene=sc, lean=True, t_rand=t_rand)
+        parts = [surf.render(ro[s:s + 8192], rd[s:s + 8192], *args, scene=sc, lean=True, t_rand=t_rand[s:s + 8192]) for s in range(0, n, 8192)]
+    w = full["weights"]
+    assert w.min() >= 0 and w.max() <= 1 + 1e-6
+    assert full["weight_sum"].max() <= 1 + 1e-4                              # transmittance never goes negative
+    assert torch.isfinite(full["color_fine"]).all() and full["color_fine"].min() >= -1e-5 and full["color_fine"].max() <= 1 + 1e-4
+    inside = full["inside_sphere"]
+    assert ((inside == 0) | (inside == 1)).all()
+    for k in ("color_fine", "render_depth", "sdf_depth", "weights"):
+        cat = torch.cat([p[k] for p in parts], 0)
+        assert (cat - full[k]).abs().max() < 1e-5, k                         # rays are independent (fused kernels: batch-shape free)
+
+
+def test_blend_is_invariant_to_source_view_order(scene):
+    """Softmax / weighted mean / variance over source views cannot depend on the order of the sources."""
+    from gens_amd import ops
+    from gens_amd.models.modules.blending_network import BlendingNetwork
+    torch.manual_seed(2)
+    net = BlendingNetwork(d_feature=20).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pts = torch.rand(200000, 3, device="cuda", generator=g) * 1.6 - 0.8
+    views = ops.SceneViews(scene["imgs"], scene["intrs"], scene["c2ws"], scene["features"])
+    perm = [0, 4, 2, 1, 3]
+    views_p = ops.SceneViews(scene["imgs"][perm].contiguous(), scene["intrs"][perm].contiguous(), scene["c2ws"][perm].contiguous(),
+                             [f[perm].contiguous() for f in scene["features"]])
+    plan = ops.BlendPlan(net)
+    rgb, vis = ops.blend_views(plan, views, pts)
+    rgb_p, vis_p = ops.blend_views(plan, views_p, pts)
+    assert (rgb - rgb_p).abs().max() < 2e-5
+    assert torch.equal(vis[:, [3, 1, 0, 2]], vis_p)                          # source k of the permuted scene is view perm[k+1]
