@@ -225,6 +225,105 @@ __global__ __launch_bounds__(256) void ray_points_k(const float* __restrict__ ra
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Device-side, order-preserving compaction of the valid points (the boolean-mask gather of implicit_surface.py:121-126,
+// 174-179, 370-375 without its host synchronisation), including the "no valid point -> first 10" rescue (Q7).
+//   pass 1: per 1024-element block, number of set flags          pass 2 (one block): exclusive scan + total + rescue
+//   pass 3: each block writes its indices at block_offset + rank (ballot / popcount inside the wave)
+// ---------------------------------------------------------------------------------------------------------------
+#define CP_BLOCK 1024
+__global__ __launch_bounds__(256) void compact_count_k(const uint8_t* __restrict__ valid, int64_t n, int32_t* __restrict__ block_cnt) {
+    __shared__ int red[4];
+    int64_t base = (int64_t)blockIdx.x * CP_BLOCK;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int64_t i = base + k * 256 + threadIdx.x;
+        c += (i < n && valid[i]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_k(int32_t* __restrict__ block_cnt, int n_blocks, int64_t n, int64_t* __restrict__ idx,
+                                                       int32_t* __restrict__ count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (n_blocks + 1023) / 1024;
+    int local = 0;
+    for (int k = 0; k < per; ++k) {
+        int b = t * per + k;
+        if (b < n_blocks) local += block_cnt[b];
+    }
+    part[t] = local;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan over the 1024 partials
+        int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - local;                           // exclusive prefix of this thread's first block
+    for (int k = 0; k < per; ++k) {
+        int b = t * per + k;
+        if (b < n_blocks) {
+            int c = block_cnt[b];
+            block_cnt[b] = run;
+            run += c;
+        }
+    }
+    if (t == 1023) {
+        int total = part[1023];
+        if (total < 1) {                                 // implicit_surface.py:123-124: nothing valid -> the first 10 points
+            total = (int)min((int64_t)10, n);
+            for (int k = 0; k < total; ++k) idx[k] = k;
+        }
+        count[0] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_write_k(const uint8_t* __restrict__ valid, int64_t n, const int32_t* __restrict__ block_off,
+                                                       int64_t* __restrict__ idx) {
+    __shared__ int wave_cnt[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t base = (int64_t)blockIdx.x * CP_BLOCK;
+    bool f[4];
+    int rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int64_t i = base + k * 256 + threadIdx.x;
+        f[k] = i < n && valid[i];
+        unsigned long long m = __ballot(f[k]);
+        rank[k] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[k][wave] = __popcll(m);
+    }
+    __syncthreads();
+    int off = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int before = 0;
+        for (int kk = 0; kk < k; ++kk) before += wave_cnt[kk][0] + wave_cnt[kk][1] + wave_cnt[kk][2] + wave_cnt[kk][3];
+        for (int w = 0; w < wave; ++w) before += wave_cnt[k][w];
+        if (f[k]) idx[off + before + rank[k]] = base + k * 256 + threadIdx.x;
+    }
+}
+
+extern "C" int gens_compact_valid(const uint8_t* valid, int64_t n, int64_t* idx, int32_t* count, int32_t* scratch, void* stream) {
+    GENS_CHECK_ARG(n >= 0 && count && (n == 0 || (valid && idx && scratch)), GENS_EINVAL, "gens_compact_valid: null pointer");
+    GENS_CHECK_ARG(n < ((int64_t)1 << 31), GENS_ELIMIT, "gens_compact_valid: at most 2^31-1 points per call");
+    hipStream_t s = (hipStream_t)stream;
+    int n_blocks = (int)gens_blocks(n, CP_BLOCK);
+    if (n_blocks == 0) n_blocks = 1;
+    if (n > 0) compact_count_k<<<n_blocks, 256, 0, s>>>(valid, n, scratch);
+    else hipMemsetAsync(scratch, 0, sizeof(int32_t), s);
+    compact_scan_k<<<1, 1024, 0, s>>>(scratch, n > 0 ? n_blocks : 0, n, idx, count);
+    if (n > 0) compact_write_k<<<n_blocks, 256, 0, s>>>(valid, n, scratch, idx);
+    return gens_launch_status("gens_compact_valid");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels) {

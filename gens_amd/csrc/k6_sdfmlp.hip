@@ -60,8 +60,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 
 template <int FE, bool GRAD>
 __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet vols, const float* __restrict__ pts,
-                                                     const int64_t* __restrict__ index, int64_t n, float* __restrict__ sdf_out,
-                                                     float* __restrict__ grad_out) {
+                                                     const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                     float* __restrict__ sdf_out, float* __restrict__ grad_out) {
     constexpr int CF = FE / 5;            // raw volume channels (4 per level)
     constexpr int KIN = MLP_H + FE;       // input width of layers 1..6
     constexpr int RS = KIN + 1;           // odd row stride
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * MLP_M;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;   // device-side point count (no host sync after compaction)
+    if (m0 >= n) return;
 
     // ------------------------------------------------------------------ prologue: look-up, encodings
     {
@@ -307,7 +309,8 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
 
 extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
                             const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
-                            const float* pts, const int64_t* index, int64_t n, float* sdf_out, float* grad_out, void* stream) {
+                            const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                            void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_mlp", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp: built for 3 or 5 volume levels, got %d", n_levels);
@@ -329,11 +332,11 @@ extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, in
     unsigned grid = gens_blocks(n, MLP_M);
     hipStream_t s = (hipStream_t)stream;
     if (n_levels == 3) {
-        if (grad_out) sdf_mlp_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
-        else sdf_mlp_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        if (grad_out) sdf_mlp_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
+        else sdf_mlp_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
     } else {
-        if (grad_out) sdf_mlp_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
-        else sdf_mlp_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        if (grad_out) sdf_mlp_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
+        else sdf_mlp_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
     }
     return gens_launch_status("gens_sdf_mlp");
 }

@@ -111,8 +111,8 @@ __device__ __forceinline__ void gemm_split(const BFrag& pre, const _Float16* __r
 
 template <int FE, bool GRAD>
 __global__ __launch_bounds__(256, GRAD ? HM_MINW_G : HM_MINW_F) void sdf_mlp_h_k(SdfMlpWeightsH W, LevelSet vols, const float* __restrict__ pts,
-                                                   const int64_t* __restrict__ index, int64_t n, float* __restrict__ sdf_out,
-                                                   float* __restrict__ grad_out) {
+                                                   const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                   float* __restrict__ sdf_out, float* __restrict__ grad_out) {
     constexpr int CF = FE / 5;
     constexpr int KIN = HM_H + FE;
     constexpr int KP = (KIN + 15) / 16 * 16;     // 192 / 240
@@ -133,6 +133,8 @@ __global__ __launch_bounds__(256, GRAD ? HM_MINW_G : HM_MINW_F) void sdf_mlp_h_k
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * HM_M;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
+    if (m0 >= n) return;
     bool big = false;
 
     // ------------------------------------------------------------------ prologue
@@ -394,7 +396,7 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
 extern "C" int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* const* wf_hi,
                                 const void* const* wf_lo, const float* const* bias, const void* const* wb_hi, const void* const* wb_lo,
                                 const float* w_last, float b_last, float scale, const float* pts, const int64_t* index, int64_t n,
-                                float* sdf_out, float* grad_out, int* overflow_flag, void* stream) {
+                                const int32_t* n_device, float* sdf_out, float* grad_out, int* overflow_flag, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_mlp_f16", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp_f16: built for 3 or 5 volume levels, got %d", n_levels);
@@ -421,11 +423,11 @@ extern "C" int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims
     unsigned grid = gens_blocks(n, HM_M);
     hipStream_t s = (hipStream_t)stream;
     if (n_levels == 3) {
-        if (grad_out) sdf_mlp_h_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
-        else sdf_mlp_h_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        if (grad_out) sdf_mlp_h_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
+        else sdf_mlp_h_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
     } else {
-        if (grad_out) sdf_mlp_h_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
-        else sdf_mlp_h_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, sdf_out, grad_out);
+        if (grad_out) sdf_mlp_h_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
+        else sdf_mlp_h_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
     }
     return gens_launch_status("gens_sdf_mlp_f16");
 }

@@ -48,8 +48,8 @@ template <int NLEV>
 __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet fs, const float4* __restrict__ imgs,
                                                          const float* __restrict__ w2c, const float* __restrict__ intr,
                                                          const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
-                                                         const int64_t* __restrict__ index, int64_t n, float* __restrict__ rgb_out,
-                                                         uint8_t* __restrict__ vis_out) {
+                                                         const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                         float* __restrict__ rgb_out, uint8_t* __restrict__ vis_out) {
     __shared__ float T_[BL_WAVES][32 * BL_TS];
     __shared__ float D_[BL_WAVES][32 * 17];    // ray_dir_fc hidden layer
     __shared__ float RD_[BL_WAVES][32 * 5];
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     constexpr int F = 3 + 4 * NLEV;
     const int S = nv - 1, PPW = 32 / S;
     const int64_t first = ((int64_t)blockIdx.x * BL_WAVES + wave) * PPW;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
+    if ((int64_t)blockIdx.x * BL_WAVES * PPW >= n) return;
     const int row = lane & 31, half = lane >> 5;
     const int pl = row / S, sv = row % S + 1;
     const bool live = pl < PPW && first + pl < n;
@@ -283,7 +285,8 @@ int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const
 
 extern "C" int gens_blend_views(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c,
                                 const float* intr, const float* c2w, int nv, const float* const* weights, const float* scalars,
-                                const float* pts, const int64_t* index, int64_t n, float* rgb_out, uint8_t* vis_out, void* stream) {
+                                const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out,
+                                void* stream) {
     MapSet fs;
     GENS_CHECK_ARG(feats && weights && scalars, GENS_EINVAL, "gens_blend_views: null table");
     if (int e = gens_fill_maps("gens_blend_views", &fs, feats, hw, n_levels)) return e;
@@ -305,7 +308,7 @@ extern "C" int gens_blend_views(const float* const* feats, const int* hw, int n_
     const int64_t waves = (n + ppw - 1) / ppw;
     const unsigned grid = gens_blocks(waves, BL_WAVES);
     hipStream_t st = (hipStream_t)stream;
-#define BLEND_LAUNCH(NL) blend_k<NL><<<grid, 64 * BL_WAVES, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, index, n, rgb_out, vis_out)
+#define BLEND_LAUNCH(NL) blend_k<NL><<<grid, 64 * BL_WAVES, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, index, n, n_device, rgb_out, vis_out)
     switch (n_levels) {
         case 1: BLEND_LAUNCH(1); break;
         case 2: BLEND_LAUNCH(2); break;

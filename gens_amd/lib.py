@@ -64,9 +64,10 @@ SIGNATURES = {
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
-    "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p],
-    "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
-    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p],
+    "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p, _p],
+    "gens_compact_valid": [_p, _l, _p, _p, _p, _p],
+    "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
+    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
 }
 
 _lib = None
@@ -110,16 +111,19 @@ def profile_end():
     rec, _profile = _profile or [], None
     torch.cuda.synchronize()
     out = {}
-    for name, s, e, nbytes, flops in rec:
+    for name, s, e, nbytes, flops, live in rec:
         d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+        frac = 1.0
+        if live is not None:        # (device count tensor, launched points): algorithmic work is that of the points really evaluated
+            frac = min(1.0, float(live[0].item()) / max(1, live[1]))
         d["launches"] += 1
         d["ms"] += s.elapsed_time(e)
-        d["bytes"] += nbytes
-        d["flops"] += flops
+        d["bytes"] += int(nbytes * frac)
+        d["flops"] += int(flops * frac)
     return out
 
 
-def call(name, *args, nbytes=0, flops=0):
+def call(name, *args, nbytes=0, flops=0, live=None):
     """Invoke one C-ABI entry point; `nbytes` / `flops` = algorithmic HBM bytes / FLOPs of this launch."""
     lib = load()
     if _profile is not None:
@@ -127,7 +131,7 @@ def call(name, *args, nbytes=0, flops=0):
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()
-        _profile.append((name, s, e, int(nbytes), int(flops)))
+        _profile.append((name, s, e, int(nbytes), int(flops), (live[0].clone(), live[1]) if live is not None else None))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

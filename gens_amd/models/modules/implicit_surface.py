@@ -170,12 +170,13 @@ class ImplicitSurface(nn.Module):
         return self.sdf_precision == "f16x2" and self._sdf_plan is not None and self._sdf_plan.overflowed()
 
     def _masked_sdf(self, pts, valid, volumes):
-        idx = self._select(valid)
         sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
         plan = self._fused_plan(volumes)
-        if plan is not None:
-            ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf, precision=self._precision(plan))
+        if plan is not None:              # compaction + count stay on the device: no host synchronisation
+            idx, count = ops.compact_valid(valid)
+            ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf, precision=self._precision(plan), count=count)
         else:
+            idx = self._select(valid)
             sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
         return sdf
 
@@ -230,37 +231,43 @@ class ImplicitSurface(nn.Module):
         vols = scene.volumes if need_vol_grad else scene.volumes_nograd()
 
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
-        idx = self._select(valid)
-        pts_v = pts[idx]
-
         plan = self._fused_plan(vols) if lean else None
-        if plan is not None:                       # fused look-up + MLP + d/dx, scattered straight into the dense arrays
+        bplan = self._fused_blend_plan(scene.views) if lean else None
+        if plan is not None and bplan is not None:     # fully fused inference: nothing in this branch synchronises with the host
+            idx, count = ops.compact_valid(valid)
             sdf = torch.full((b * n, 1), 100.0, device=dev)
             gradients = torch.zeros(b * n, 3, device=dev)
-            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan))
+            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan), count=count)
             smooth = None
+            sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx, count=count)
         else:
-            if lean:
-                with torch.enable_grad():
-                    x = pts_v.clone().requires_grad_(True)
-                    sdf_v = self.sdf_network.sdf(x, vols)
-                    grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
-                sdf_v, smooth_v = sdf_v.detach(), None
+            idx = self._select(valid)
+            pts_v = pts[idx]
+            if plan is not None:                       # fused look-up + MLP + d/dx, scattered straight into the dense arrays
+                sdf = torch.full((b * n, 1), 100.0, device=dev)
+                gradients = torch.zeros(b * n, 3, device=dev)
+                ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan))
+                smooth = None
             else:
-                sdf_v = self.sdf_network(pts_v, vols)[:, :1]
-                grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
-            sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
-            gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
-            smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
-
-        bplan = self._fused_blend_plan(scene.views) if lean else None
-        if bplan is not None:                      # K4 + colour network fused, scattered into the dense arrays
-            sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx)
-        else:
-            feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
-            color_v = self.color_network(feat_views, ray_diff, vis_v)
-            sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
-            src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
+                if lean:
+                    with torch.enable_grad():
+                        x = pts_v.clone().requires_grad_(True)
+                        sdf_v = self.sdf_network.sdf(x, vols)
+                        grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
+                    sdf_v, smooth_v = sdf_v.detach(), None
+                else:
+                    sdf_v = self.sdf_network(pts_v, vols)[:, :1]
+                    grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
+                sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
+                gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
+                smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
+            if bplan is not None:                      # K4 + colour network fused, scattered into the dense arrays
+                sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx)
+            else:
+                feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
+                color_v = self.color_network(feat_views, ray_diff, vis_v)
+                sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
+                src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
 
         inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
         comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, sdf, gradients, smooth, sampled_color, valid, src_vis, inv_s,

@@ -227,6 +227,20 @@ def lookup_mask(pts, masks, return_values=False):
     return (valid.bool(), vals) if return_values else valid.bool()
 
 
+def compact_valid(valid):
+    """Device-side `nonzero` with the reference's rescue (no valid point -> the first 10): -> (idx (N,) int64, count (1,) int32).
+    Only idx[:count] is meaningful; nothing is copied to the host, so the caller never synchronises."""
+    v = _c(valid.reshape(-1))
+    v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+    n = v.shape[0]
+    idx = torch.empty(max(n, 10), device=v.device, dtype=torch.int64)
+    count = torch.empty(1, device=v.device, dtype=torch.int32)
+    scratch = torch.empty((n + 1023) // 1024 + 1, device=v.device, dtype=torch.int32)
+    L.call("gens_compact_valid", L.ptr(v, torch.uint8), n, L.ptr(idx, torch.int64), L.ptr(count, torch.int32), L.ptr(scratch, torch.int32),
+           L.stream(), nbytes=n * 9)
+    return idx, count
+
+
 def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
     """pts (B*n,3) = o + d * (z or section mid-points), valid (B*n,) bool."""
     ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
@@ -235,7 +249,7 @@ def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
     valid = torch.empty(b * n, device=z.device, dtype=torch.uint8)
     L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), ms.table,
            ms.dim_table, ms.n, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * n * 17 + b * 24)
-    return pts, valid.bool()
+    return pts, valid.view(torch.bool)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -309,7 +323,7 @@ def upsample(rays_o, rays_d, z, sdf, n_new, masks, inv_s):
     valid = torch.empty(b * n_new, device=z.device, dtype=torch.uint8)
     L.call("gens_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), b, n, n_new, float(inv_s), ms.table,
            ms.dim_table, ms.n, L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * (8 * n + 17 * n_new + 24))
-    return z_new, pts_new, valid.bool()
+    return z_new, pts_new, valid.view(torch.bool)
 
 
 def merge_samples(z, z_new, sdf=None, sdf_new=None):
@@ -592,10 +606,11 @@ class SdfMlpPlan:
         return hit
 
 
-def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None, precision="f32"):
+def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None, precision="f32", count=None):
     """sdf (and d sdf/dx) of pts[index] written to sdf_out[index] / grad_out[index] (fresh, densely indexed outputs if
     no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference).
-    precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed())."""
+    precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed()).
+    count: optional (1,) int32 device tensor from compact_valid(): only the first `count` entries of `index` are evaluated."""
     assert isinstance(volumes, VolumeSet) and volumes.layout == L.LAYOUT_PACKED and volumes.n == plan.n_levels
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
     n = pts.shape[0] if index is None else index.shape[0]
@@ -610,12 +625,13 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     if precision == "f16x2":
         assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
         L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
-               plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out),
-               L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes, flops=n * flops)
+               plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
+               L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
+               flops=n * flops, live=None if count is None else (count, n))
     else:
         L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.bias_table, plan.wb_table, L.ptr(plan.w_last),
-               plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None,
-               L.stream(), nbytes=nbytes, flops=n * flops)
+               plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
+               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n))
     return (sdf_out, grad_out) if want_grad else sdf_out
 
 
@@ -659,7 +675,7 @@ class BlendPlan:
         self.key = BlendPlan.version(net)
 
 
-def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None):
+def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=None):
     """Blended colour of pts[index] (N,3) and the per-source in-frustum flags (N,S) written at index (dense outputs)."""
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
     n = pts.shape[0] if index is None else index.shape[0]
@@ -676,6 +692,6 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None):
     f = plan.n_feat
     flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
     L.call("gens_blend_views", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(views.imgs_tex.detach())), L.ptr(views.w2c), L.ptr(views.intr),
-           L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(rgb_out),
-           L.ptr(vis_out, torch.uint8), L.stream(), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
+           L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
+           L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
     return rgb_out, vis_out

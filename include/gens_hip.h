@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);
+int gens_abi_version(void);   /* 2 */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -99,6 +99,11 @@ int gens_lookup_mask_nearest(const float* const* masks, const int* dims, int n_l
 int gens_ray_points(const float* rays_o, const float* rays_d, const float* z, int64_t n_rays, int n_samples, int mid,
                     float sample_dist, const float* const* masks, const int* dims, int n_levels, float* pts,
                     uint8_t* valid, void* stream);
+
+/* Order-preserving compaction of the valid flags written by gens_ray_points / gens_upsample: idx[0..count) = positions of
+ * the non-zero flags in increasing order; if no flag is set, count = min(10, n) and idx = 0..count-1 (Q7,
+ * implicit_surface.py:123-124,176-177,372-373).  idx (n) int64, count (1) int32, scratch (ceil(n/1024)+1) int32: DEVICE. */
+int gens_compact_valid(const uint8_t* valid, int64_t n, int64_t* idx, int32_t* count, int32_t* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K4  lookup_feature + compute_angle                              (projector.py:278-349)
@@ -178,10 +183,13 @@ int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g
  *   gens_amd.ops.SdfMlpPlan (layout documented in k6_sdfmlp.hip); w_last (128 + 5*4*n_levels) = row 0 of lin6.
  *   index: optional (N) int64 gather/scatter map: point i is pts[index[i]] and results go to sdf_out[index[i]],
  *   grad_out[3*index[i]..] (the masked evaluation of implicit_surface.py:125,179-191); NULL = identity.
+ *   n_device: optional DEVICE int32: the number of points actually evaluated is min(n, *n_device) (written by
+ *   gens_compact_valid), so the masked evaluation needs no host synchronisation; NULL = n.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
                  const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
-                 const float* pts, const int64_t* index, int64_t n, float* sdf_out, float* grad_out, void* stream);
+                 const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                 void* stream);
 
 /* Same computation as gens_sdf_mlp on the f16 matrix cores with split operands: every float32 operand is an (hi, lo)
  * pair of halfs and every product is hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error, 5.3x
@@ -191,7 +199,7 @@ int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels,
 int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* const* wf_hi,
                      const void* const* wf_lo, const float* const* bias, const void* const* wb_hi, const void* const* wb_lo,
                      const float* w_last, float b_last, float scale, const float* pts, const int64_t* index, int64_t n,
-                     float* sdf_out, float* grad_out, int* overflow_flag, void* stream);
+                     const int32_t* n_device, float* sdf_out, float* grad_out, int* overflow_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K7  lookup_feature + BlendingNetwork.forward fused, inference only
@@ -206,7 +214,8 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_blend_views(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c,
                      const float* intr, const float* c2w, int nv, const float* const* weights, const float* scalars,
-                     const float* pts, const int64_t* index, int64_t n, float* rgb_out, uint8_t* vis_out, void* stream);
+                     const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)

@@ -357,3 +357,16 @@ def test_k11_lattice_vs_oracle(ops):
     close(pts, ref, atol=1.2e-7, rtol=0, what="lattice")
     part = ops.lattice_points([-1, -0.5, -1], [1, 1, 0.75], res, 1000, 4321, "cuda")
     close(part, ref[1000:5321], atol=1.2e-7, rtol=0, what="lattice slice")
+
+
+# --------------------------------------------------------------------------------------------------- compaction
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (7, 0.0), (1000, 0.5), (1024, 1.0), (123457, 0.94), (3_000_001, 0.3), (5000, 0.0)])
+def test_device_compaction_matches_nonzero_and_rescue(ops, n, frac):
+    g = torch.Generator().manual_seed(n)
+    valid = (torch.rand(n, generator=g) < frac).cuda()
+    idx, count = ops.compact_valid(valid)
+    ref = torch.nonzero(valid)[:, 0]
+    if ref.numel() < 1:
+        ref = torch.arange(min(10, n), device="cuda")          # implicit_surface.py:123-124
+    assert int(count) == ref.numel()
+    assert torch.equal(idx[:ref.numel()], ref)
