@@ -397,7 +397,8 @@ class ImplicitSurface(nn.Module):
         rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())
         outputs["color_fine"] = color_fine
         outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
-        outputs["normal_img"] = (np.matmul(rot[None, :, :], normal_img[:, :, None]).reshape([height, width, 3]) * 128 + 128).clip(0, 255)
+        # rot @ n per pixel (implicit_surface.py:462-463), as one (P,3)x(3,3) product instead of P batched 3x3 matmuls
+        outputs["normal_img"] = ((normal_img @ rot.T.astype(normal_img.dtype)).reshape([height, width, 3]) * 128 + 128).clip(0, 255)
         outputs["sdf_depth"] = torch.cat(sdf_depth, 0).cpu().numpy().reshape([height, width])
         outputs["render_depth"] = torch.cat(render_depth, 0).cpu().numpy().reshape([height, width])
         return outputs
