@@ -317,7 +317,7 @@ extern "C" int gens_compact_valid(const uint8_t* valid, int64_t n, int64_t* idx,
     int n_blocks = (int)gens_blocks(n, CP_BLOCK);
     if (n_blocks == 0) n_blocks = 1;
     if (n > 0) compact_count_k<<<n_blocks, 256, 0, s>>>(valid, n, scratch);
-    else hipMemsetAsync(scratch, 0, sizeof(int32_t), s);
+    else if (hipMemsetAsync(scratch, 0, sizeof(int32_t), s) != hipSuccess) return gens_launch_status("gens_compact_valid");
     compact_scan_k<<<1, 1024, 0, s>>>(scratch, n > 0 ? n_blocks : 0, n, idx, count);
     if (n > 0) compact_write_k<<<n_blocks, 256, 0, s>>>(valid, n, scratch, idx);
     return gens_launch_status("gens_compact_valid");

@@ -21,53 +21,93 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MLP_M 32            // points per workgroup
 #define MLP_H 128           // hidden width
 #define MLP_PE 27           // 3 * (1 + 2*4)
-#define MLP_PE_STRIDE 29
+#define MLP_PE_K 32         // layer-0 reduction length, padded to whole 8-wide groups (zero columns / zero weights)
+#define MLP_PE_STRIDE 36    // 16-B aligned rows, stride = 4 (mod 8) words => conflict-free ds_read_b128 of the A operand
 #define MLP_SKIP_H 101      // hidden columns produced by layer 2 (128 - 27)
 #define MLP_NLAYER 6        // GEMM layers 0..5; layer 6 is a dot product (only the sdf row is needed)
 
+// Operand streams.  The reduction index of every GEMM is consumed in groups of 8: within group j the four MFMAs i = 0..3
+// take k = 8j + 4h + i from lane half h (any fixed permutation of k is a valid order of the fp32 sum), so a lane's
+// A values for a group are 4 consecutive floats of its LDS row (ONE ds_read_b128) and its B values are 4 consecutive
+// floats of the host-packed weight stream (ONE global_load_dwordx4, 1 KB per wave, fully coalesced): 2 memory
+// instructions per 4 MFMAs instead of 8.  B groups are software-prefetched 4 groups (1024 MFMA cycles) ahead, across
+// layer boundaries and barriers (weights do not depend on activations).
 struct SdfMlpWeights {
-    const float* wf[MLP_NLAYER];   // forward B fragments  [n_tile(4)][kk][64]
-    const float* bias[MLP_NLAYER]; // (128) zero padded
-    const float* wb[MLP_NLAYER];   // backward B fragments [n_tile][kk(64)][64]; wb[0]: 1 tile (27 -> 32 columns)
+    const float4* wf[MLP_NLAYER];  // forward B groups  [n_tile(4)][group][64]   (float4 per lane)
+    const float4* wb[MLP_NLAYER];  // backward B groups [n_tile][16][64]; wb[0]: 1 tile (27 -> 32 columns)
     const float* w_last;           // (128 + FE) row 0 of layer 6
     float b_last;
     float inv_scale;               // 1 / scale  (sdf_network.py:123)
     float scale;
 };
 
+// Softplus(beta = 100) and its derivative, branch-free: 5 VALU + 2 transcendental issues (+3 with the derivative).
+// fp32 MFMA shares the SIMD's FMA datapath with the vector ALU (the two peaks are the same 157.3 TFLOP/s and the PMC
+// busy cycles add up), so every VALU cycle of the epilogue is a matrix cycle lost.  Overflow needs no clamp: above the
+// torch threshold (100 x > 20) both results are replaced by the linear branch through v_cndmask, which discards inf/NaN.
+template <bool DERIV>
 __device__ __forceinline__ float softplus100(float x, float& dsig) {
-    float t = 100.0f * x;
-    float e = hw_exp(fminf(t, 20.0f));
-    float u = 1.0f + e;
-    bool lin = t > 20.0f;                      // torch.nn.Softplus threshold
-    dsig = lin ? 1.0f : e * hw_rcp(u);
-    return lin ? x : hw_log(u) * 0.01f;
+    const float e = __builtin_amdgcn_exp2f(x * 144.269504088896340736f);     // e^{100 x}
+    const float u = 1.0f + e;
+    const bool lin = x > 0.2f;
+    if constexpr (DERIV) dsig = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
+    return lin ? x : __builtin_amdgcn_logf(u) * 0.0069314718055994530942f;   // log2(u) * ln2 / 100
 }
 
-// C = A(32 x 2KK, LDS row-major stride rs, starting at column 0) * B(packed fragments) accumulated into acc
-template <int UNROLL>
-__device__ __forceinline__ f32x16 mfma_rows(const float* __restrict__ a_lds, int rs, const float* __restrict__ wp, int kk_count,
-                                            f32x16 acc, int lane) {
-    const float* a = a_lds + (lane & 31) * rs + (lane >> 5);
-    const float* b = wp + lane;
-#pragma unroll UNROLL
-    for (int kk = 0; kk < kk_count; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[64 * kk], acc, 0, 0, 0);
+// acc += A(32 x 8G, LDS rows of stride rs; `a` already points at this lane's row + 4 * half) * B(packed groups; `b`
+// already points at this lane's float4 of group 0).  pre[] holds groups 0..3 of THIS product (loads in flight); on
+// return it holds groups 0..3 of the NEXT product `bn` (NEXT = false: nothing more to fetch).
+template <int G, int MLP_PF, bool NEXT = true>
+__device__ __forceinline__ f32x16 mfma_groups(const float* __restrict__ a, const float4* __restrict__ b, f32x16 acc, float4 (&pre)[MLP_PF],
+                                              const float4* __restrict__ bn) {
+    float4 av = *(const float4*)a;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const float4 bv = pre[j % MLP_PF];
+        const float4 ac = av;
+        if (j + 1 < G) av = *(const float4*)(a + 8 * (j + 1));
+        if (j + MLP_PF < G) pre[j % MLP_PF] = b[64 * (j + MLP_PF)];
+        else if (NEXT) pre[j % MLP_PF] = bn[64 * (j + MLP_PF - G)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w, bv.w, acc, 0, 0, 0);
+#ifndef K6_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   // keep the 4-group prefetch distance: hipcc otherwise sinks the loads next to their use
+#endif
+    }
+    if constexpr (NEXT && G % MLP_PF != 0) {   // (L = 5: 29 groups) bring the next product's group 0 back to slot 0
+        float4 t[MLP_PF];
+#pragma unroll
+        for (int i = 0; i < MLP_PF; ++i) t[i] = pre[(i + G) % MLP_PF];
+#pragma unroll
+        for (int i = 0; i < MLP_PF; ++i) pre[i] = t[i];
+    }
     return acc;
+}
+
+template <int MLP_PF>
+__device__ __forceinline__ void prefetch_groups(float4 (&pre)[MLP_PF], const float4* __restrict__ b) {
+#pragma unroll
+    for (int j = 0; j < MLP_PF; ++j) pre[j] = b[64 * j];
 }
 
 // row of accumulator register r for this lane (C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 template <int FE, bool GRAD>
-__global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet vols, const float* __restrict__ pts,
+__global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, LevelSet vols, const float* __restrict__ pts,
                                                      const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                      float* __restrict__ sdf_out, float* __restrict__ grad_out) {
     constexpr int CF = FE / 5;            // raw volume channels (4 per level)
+    constexpr int MLP_PF = 4;             // B prefetch depth in groups (6 and 8 measured no faster)
     constexpr int KIN = MLP_H + FE;       // input width of layers 1..6
-    constexpr int RS = KIN + 1;           // odd row stride
+    constexpr int KP = (KIN + 7) / 8 * 8; // ... padded to whole groups (pad columns are zero)
+    constexpr int GIN = KP / 8;           // groups per forward product of layers 1..5
+    constexpr int RS = KP + 4;            // row stride: 16-B aligned, = 4 (mod 8) words
     constexpr int NT_B = (KIN + 31) / 32; // backward n-tiles (h part: 4, conditioning part: the rest)
-    __shared__ float X[MLP_M * RS];                      // [h | fe] tile; reused as the G buffer in the reverse pass
-    __shared__ float PE[MLP_M * MLP_PE_STRIDE];          // point encoding (27, col 27 = 0)
+    __shared__ __attribute__((aligned(16))) float X[MLP_M * RS];              // [h | fe | 0] tile; reused as the G buffer in the reverse pass
+    __shared__ __attribute__((aligned(16))) float PE[MLP_M * MLP_PE_STRIDE];  // point encoding (27, cols 27..31 = 0)
     __shared__ float GPE[GRAD ? MLP_M * MLP_PE_STRIDE : 1];   // d/d(point encoding) from the skip connection
     __shared__ float JAC[GRAD ? MLP_M * CF * 3 : 1];     // d feat_c / d x_a
     __shared__ float XYZ[MLP_M * 3];
@@ -77,6 +117,9 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
     const int64_t m0 = (int64_t)blockIdx.x * MLP_M;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;   // device-side point count (no host sync after compaction)
     if (m0 >= n) return;
+    const int a_lane = (lane & 31), a_half = 4 * (lane >> 5);
+    float4 pre[MLP_PF];
+    prefetch_groups(pre, W.wf[0] + (size_t)wave * (MLP_PE_K / 8) * 64 + lane);   // layer 0 weights fly during the prologue
 
     // ------------------------------------------------------------------ prologue: look-up, encodings
     {
@@ -97,7 +140,17 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
                 float f = (float)(1 << k);
                 hw_sincos(v * f, pe[3 + 6 * k + a], pe[6 + 6 * k + a]);
             }
-            if (a == 0) { pe[27] = 0.0f; pe[28] = 0.0f; }
+            if (a == 0) {
+                pe[MLP_PE] = 1.0f;                                   // bias column of layer 0
+#pragma unroll
+                for (int k = MLP_PE + 1; k < MLP_PE_K; ++k) pe[k] = 0.0f;
+            }
+        }
+        if (sub == 7) {
+            static_assert(KP > KIN, "a pad column carries the bias");
+            X[p * RS + KIN] = 1.0f;                                  // bias column of layers 1..5
+#pragma unroll
+            for (int k = KIN + 1; k < KP; ++k) X[p * RS + k] = 0.0f;
         }
         if (sub < vols.n) {   // one thread per (point, level): 8 texel gathers
             const int l = sub;
@@ -161,20 +214,24 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
     const int col = 32 * wave + (lane & 31);
 #pragma unroll
     for (int l = 0; l < MLP_NLAYER; ++l) {
-        const int kk_count = (l == 0) ? (MLP_PE + 1) / 2 : KIN / 2;
-        const float* a_lds = (l == 0) ? PE : X;
-        const int rs = (l == 0) ? MLP_PE_STRIDE : RS;
-        f32x16 acc;
-        const float bias = W.bias[l][col];
+        f32x16 acc;   // the bias rides in the GEMM: input column K (first pad column) is 1, weight row K holds the bias
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
-        acc = mfma_rows<8>(a_lds, rs, W.wf[l] + (size_t)wave * kk_count * 64, kk_count, acc, lane);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // what to prefetch while this product runs: the next layer's first groups, or the reverse pass' first tile
+        const float4* nxt = (l + 1 < MLP_NLAYER) ? W.wf[l + 1] + (size_t)wave * GIN * 64 + lane
+                                                 : (GRAD ? W.wb[5] + (size_t)wave * 16 * 64 + lane : nullptr);
+        if (l == 0)
+            acc = mfma_groups<MLP_PE_K / 8, MLP_PF>(PE + a_lane * MLP_PE_STRIDE + a_half, W.wf[0] + (size_t)wave * (MLP_PE_K / 8) * 64 + lane, acc, pre, nxt);
+        else if (l + 1 < MLP_NLAYER || GRAD)
+            acc = mfma_groups<GIN, MLP_PF>(X + a_lane * RS + a_half, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc, pre, nxt);
+        else
+            acc = mfma_groups<GIN, MLP_PF, false>(X + a_lane * RS + a_half, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc, pre, nxt);
         __syncthreads();   // every wave has finished reading this layer's input tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, lane);
-            float ds;
-            float h = softplus100(acc[r], ds);
+            float ds = 0.0f;
+            float h = softplus100<GRAD>(acc[r], ds);
             if (l == 2) {   // skip connection feeding layer 3: x = cat([h, pe]) / sqrt(2)   (sdf_network.py:111-112)
                 if (col < MLP_SKIP_H) {
                     h *= 0.70710678118654752440f;
@@ -218,8 +275,8 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
     // each reduces half of the 128-long K range (partials are summed in the epilogue), so all four waves stay busy.
     constexpr bool SPLIT_K = (NT_B - 4) == 2;
     const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
-    const int fe_kk0 = SPLIT_K ? 32 * (wave >> 1) : 0;
-    constexpr int FE_KK = SPLIT_K ? 32 : 64;
+    const int fe_g0 = SPLIT_K ? 8 * (wave >> 1) : 0;          // first group of this wave's share of the 16-group reduction
+    constexpr int FE_G = SPLIT_K ? 8 : 16;
     __syncthreads();
     {
         const float wl = W.w_last[col];
@@ -232,8 +289,10 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
         f32x16 gh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
-        gh = mfma_rows<8>(X, RS, W.wb[l] + (size_t)wave * 64 * 64, 64, gh, lane);
-        gfe = mfma_rows<8>(X + 2 * fe_kk0, RS, W.wb[l] + ((size_t)fe_tile * 64 + fe_kk0) * 64, FE_KK, gfe, lane);
+        const float4* b_fe = W.wb[l] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane;
+        const float4* nxt = (l > 1) ? W.wb[l - 1] + (size_t)wave * 16 * 64 + lane : W.wb[0] + lane;   // (only wave 0 uses wb[0])
+        gh = mfma_groups<16, MLP_PF>(X + a_lane * RS + a_half, W.wb[l] + (size_t)wave * 16 * 64 + lane, gh, pre, b_fe);
+        gfe = mfma_groups<FE_G, MLP_PF>(X + a_lane * RS + a_half + 8 * fe_g0, b_fe, gfe, pre, nxt);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -252,7 +311,7 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
         f32x16 gp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gp[r] = 0.0f;
-        gp = mfma_rows<8>(X, RS, W.wb[0], 64, gp, lane);
+        gp = mfma_groups<16, MLP_PF, false>(X + a_lane * RS + a_half, W.wb[0] + lane, gp, pre, nullptr);
         const int c = lane & 31;
         if (c < MLP_PE) {
 #pragma unroll
@@ -308,22 +367,21 @@ __global__ __launch_bounds__(128 * 2) void sdf_mlp_k(SdfMlpWeights W, LevelSet v
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
 extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                            const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
+                            const float* const* wb, const float* w_last, float b_last, float scale,
                             const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                             void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_mlp", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp: built for 3 or 5 volume levels, got %d", n_levels);
-    GENS_CHECK_ARG(wf && bias && w_last && (wb || !grad_out), GENS_EINVAL, "gens_sdf_mlp: null weight table");
+    GENS_CHECK_ARG(wf && w_last && (wb || !grad_out), GENS_EINVAL, "gens_sdf_mlp: null weight table");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out)), GENS_EINVAL, "gens_sdf_mlp: null pts / output");
     GENS_CHECK_ARG(scale != 0.0f, GENS_EINVAL, "gens_sdf_mlp: scale must be non-zero");
     if (n == 0) return 0;
     SdfMlpWeights W;
     for (int l = 0; l < MLP_NLAYER; ++l) {
-        GENS_CHECK_ARG(wf[l] && bias[l] && (!grad_out || wb[l]), GENS_EINVAL, "gens_sdf_mlp: layer %d weights are null", l);
-        W.wf[l] = wf[l];
-        W.bias[l] = bias[l];
-        W.wb[l] = grad_out ? wb[l] : nullptr;
+        GENS_CHECK_ARG(wf[l] && (!grad_out || wb[l]), GENS_EINVAL, "gens_sdf_mlp: layer %d weights are null", l);
+        W.wf[l] = (const float4*)wf[l];
+        W.wb[l] = grad_out ? (const float4*)wb[l] : nullptr;
     }
     W.w_last = w_last;
     W.b_last = b_last;

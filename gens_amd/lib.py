@@ -67,7 +67,7 @@ SIGNATURES = {
     "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p, _p],
     "gens_compact_valid": [_p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
-    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
 }
 
 _lib = None
@@ -105,11 +105,14 @@ def profile_begin():
     _profile = []
 
 
-def profile_end():
-    """Stop recording; -> {kernel: {"launches", "ms", "bytes"}} (synchronises)."""
+def profile_end(raw=False):
+    """Stop recording; -> {kernel: {"launches", "ms", "bytes"}} (synchronises).  raw=True: the per-launch list
+    [(kernel, ms, algorithmic bytes, flops)] in launch order instead."""
     global _profile
     rec, _profile = _profile or [], None
     torch.cuda.synchronize()
+    if raw:
+        return [(name, s.elapsed_time(e), nbytes, flops) for name, s, e, nbytes, flops, _live in rec]
     out = {}
     for name, s, e, nbytes, flops, live in rec:
         d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})

@@ -537,6 +537,16 @@ def _pack_b_fragments(w):
     return wp.view(nt, 32, kk, 2).permute(0, 2, 3, 1).contiguous()
 
 
+def _pack_b_groups(w):
+    """(J, K) matrix -> grouped fp32 MFMA B stream for gens_sdf_mlp: [ceil(J/32)][ceil(K/8)][64][4]; lane l of group
+    (nt, g) holds w[32 nt + (l & 31)][8 g + 4 (l >> 5) + 0..3] (zero padded): one global_load_dwordx4 feeds 4 MFMAs."""
+    j, k = w.shape
+    nt, g = (j + 31) // 32, (k + 7) // 8
+    wp = torch.zeros(nt * 32, g * 8, device=w.device, dtype=_f32)
+    wp[:j, :k] = w
+    return wp.view(nt, 32, g, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def _pack_b_fragments_f16(w):
     """(J, K) matrix -> split-half MFMA 32x32x16 B fragments: two (hi, lo) tensors [ceil(J/32)][ceil(K/16)][64][8] of halfs;
     lane l of fragment (nt, kb) holds w[32 nt + (l & 31)][16 kb + 8 (l >> 5) + 0..7]."""
@@ -581,8 +591,8 @@ class SdfMlpPlan:
                 w[:ws[l].shape[0]] = ws[l]
                 b = torch.zeros(128, device=dev, dtype=_f32)
                 b[:bs[l].shape[0]] = bs[l]
-                self.wf.append(_pack_b_fragments(w))
-                self.wb.append(_pack_b_fragments(w.t().contiguous()))
+                self.wf.append(_pack_b_groups(torch.cat([w, b[:, None]], 1)))      # bias = extra reduction row K_l (constant-1 input column)
+                self.wb.append(_pack_b_groups(w.t().contiguous()))
                 self.bias.append(b)
                 pf, pb = _pack_b_fragments_f16(w), _pack_b_fragments_f16(w.t().contiguous())
                 self.hf.append(pf)
@@ -629,7 +639,7 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
                flops=n * flops, live=None if count is None else (count, n))
     else:
-        L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.bias_table, plan.wb_table, L.ptr(plan.w_last),
+        L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
                plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n))
     return (sdf_out, grad_out) if want_grad else sdf_out

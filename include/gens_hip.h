@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 2 */
+int gens_abi_version(void);   /* 3 */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -179,15 +179,17 @@ int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g
  *   One launch = volume look-up (K2, packed volumes) + both positional encodings + 7 layers on the fp32 matrix
  *   cores (+ reverse-mode d sdf/d x when grad_out != NULL).  Architecture: d_hidden 128, n_layers 6, skip_in [3],
  *   multires 4, feat_multires 2, Softplus(beta=100); n_levels must be 3 or 5 (feat_channels 12 / 20).
- *   wf / bias / wb: HOST arrays of 6 device pointers, weights pre-packed in MFMA B-fragment order by
- *   gens_amd.ops.SdfMlpPlan (layout documented in k6_sdfmlp.hip); w_last (128 + 5*4*n_levels) = row 0 of lin6.
+ *   wf / wb: HOST arrays of 6 device pointers: forward / transposed weights as grouped MFMA B streams
+ *   [n_tile][ceil(K/8)][64 lanes][4] (lane l of group g holds W[32 n_tile + (l & 31)][8 g + 4 (l >> 5) + 0..3]), built by
+ *   gens_amd.ops.SdfMlpPlan.  The bias of layer l is row K_l of the forward stream (K_0 = 27, else 128 + 20 n_levels):
+ *   the kernel feeds a constant-1 input in that (padding) column.  w_last (128 + 5*4*n_levels) = row 0 of lin6.
  *   index: optional (N) int64 gather/scatter map: point i is pts[index[i]] and results go to sdf_out[index[i]],
  *   grad_out[3*index[i]..] (the masked evaluation of implicit_surface.py:125,179-191); NULL = identity.
  *   n_device: optional DEVICE int32: the number of points actually evaluated is min(n, *n_device) (written by
  *   gens_compact_valid), so the masked evaluation needs no host synchronisation; NULL = n.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                 const float* const* bias, const float* const* wb, const float* w_last, float b_last, float scale,
+                 const float* const* wb, const float* w_last, float b_last, float scale,
                  const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                  void* stream);
 
