@@ -374,15 +374,17 @@ class ImplicitSurface(nn.Module):
         height, width = int(hw[0]), int(hw[1])
         n_rays = rays_o.shape[0]
         jitter = JitterStream(n_rays, self.val_chunk) if self.perturb > 0 else None
-        rgb, normals, sdf_depth, render_depth = [], [], [], []
+        # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
+        # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
+        image = torch.empty(n_rays, 8, device=rays_o.device, dtype=torch.float32)
         for s in range(0, n_rays, self.val_chunk):
             e = min(s + self.val_chunk, n_rays)
             r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                             cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
-            rgb.append(r["color_fine"])
-            normals.append((r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1))
-            sdf_depth.append(r["sdf_depth"])
-            render_depth.append(r["render_depth"])
+            image[s:e, 0:3] = r["color_fine"]
+            image[s:e, 3:6] = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1)
+            image[s:e, 6] = r["sdf_depth"].reshape(-1)
+            image[s:e, 7] = r["render_depth"].reshape(-1)
         if jitter is not None:
             jitter.join()
         if self._split_half_overflowed():              # a value left the half range: render this image again in float32
@@ -392,16 +394,28 @@ class ImplicitSurface(nn.Module):
                                      bound_min, bound_max, hw, cos_anneal_ratio, step, extract_geometry, mesh_resolution, threshold, scene)
             finally:
                 self.sdf_precision = saved
-        color_fine = torch.cat(rgb, 0).cpu()                                                # D2H once per image, not per chunk
-        normal_img = torch.cat(normals, 0).cpu().numpy()
-        rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())
+        host = self._pinned(n_rays)
+        host.copy_(image, non_blocking=True)
+        rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())                         # (synchronises: the image has landed too)
+        torch.cuda.current_stream().synchronize()
+        host_np = host.numpy()
+        color_fine = torch.from_numpy(host_np[:, 0:3].copy())
+        normal_img = host_np[:, 3:6]
         outputs["color_fine"] = color_fine
         outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
         # rot @ n per pixel (implicit_surface.py:462-463), as one (P,3)x(3,3) product instead of P batched 3x3 matmuls
         outputs["normal_img"] = ((normal_img @ rot.T.astype(normal_img.dtype)).reshape([height, width, 3]) * 128 + 128).clip(0, 255)
-        outputs["sdf_depth"] = torch.cat(sdf_depth, 0).cpu().numpy().reshape([height, width])
-        outputs["render_depth"] = torch.cat(render_depth, 0).cpu().numpy().reshape([height, width])
+        outputs["sdf_depth"] = host_np[:, 6].reshape([height, width]).copy()
+        outputs["render_depth"] = host_np[:, 7].reshape([height, width]).copy()
         return outputs
+
+    def _pinned(self, n_rays):
+        """Page-locked (P, 8) staging buffer for the rendered image, kept between validate() calls."""
+        buf = getattr(self, "_pinned_image", None)
+        if buf is None or buf.shape[0] != n_rays:
+            buf = torch.empty(n_rays, 8, dtype=torch.float32, pin_memory=True)
+            self._pinned_image = buf
+        return buf
 
     def forward(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):
         imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
