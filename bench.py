@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--chunk", type=int, default=32768, help="rays per render() chunk")
     p.add_argument("--dims", type=int, nargs="+", default=[256, 128, 64])
     p.add_argument("--views", type=int, default=5)
-    p.add_argument("--cpu-rays", type=int, default=320, help="rays of the CPU-oracle baseline sample (0 = skip); ~12 s")
+    p.add_argument("--cpu-rays", type=int, default=640, help="rays of the CPU-oracle baseline sample (0 = skip); ~15 s on a 128-core host")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--sdf-precision", default="f32", choices=["f32", "f16x2"],
                    help="f32: exact float32 MFMA (headline); f16x2: split-half operands on the f16 matrix cores (~1e-6 relative)")
