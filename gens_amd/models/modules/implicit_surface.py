@@ -351,13 +351,11 @@ class ImplicitSurface(nn.Module):
         return u.reshape(resolution, resolution, resolution)
 
     def extract_geometry(self, volumes, bound_min, bound_max, resolution, threshold):
-        u = self.sdf_grid(volumes, bound_min, bound_max, resolution).cpu().numpy()          # one D2H copy (reference: 512)
-        try:
-            import mcubes
-        except ImportError as e:                                                             # iso-surfacing is §8(f) rank 3
-            raise RuntimeError("PyMCubes is needed for marching cubes (requirements.txt:11); the SDF lattice itself is "
-                               "available from ImplicitSurface.sdf_grid") from e
-        vertices, triangles = mcubes.marching_cubes(u, threshold)
+        """-> vertices (V,3) float64, triangles (T,3) int32 as numpy arrays (implicit_surface.py:407-427).  The SDF lattice and
+        the marching cubes both run on the device (the reference: 512 D2H copies + PyMCubes on the host); only the mesh is copied."""
+        u = self.sdf_grid(volumes, bound_min, bound_max, resolution)
+        vertices, triangles = ops.marching_cubes(u, threshold)
+        vertices, triangles = vertices.cpu().numpy(), triangles.cpu().numpy()
         b_max, b_min = bound_max.detach().cpu().numpy(), bound_min.detach().cpu().numpy()
         vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
         return vertices, triangles

@@ -234,6 +234,25 @@ int gens_upsample2d_into(const float* src, int n, int c, int hs, int ws, float* 
                          int c_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K12  iso-surface extraction of the SDF lattice: replaces mcubes.marching_cubes(u, threshold)
+ *      (implicit_surface.py:423; PyMCubes==0.1.4, requirements.txt:11 -- third-party, classic marching cubes)
+ *   u (X, Y, Z) float32, z fastest (the lattice of implicit_surface.py:407-421); iso = threshold.
+ *   gens_mc_classify: per lattice point p  vmask[p] bit a = the edge p -> p + e_a straddles iso (a = x, y, z),
+ *     vcount[p] = popcount, cases[p] = Bourke case index of the cell with origin p (bit n: u[corner n] < iso),
+ *     tcount[p] = tri_count[cases[p]] (0 where p is not a cell origin).  tri_count: DEVICE (256) uint8.
+ *   The caller turns vcount / tcount into exclusive scans voff / toff (int32) and allocates
+ *     vertices (V, 3) float64 in INDEX coordinates and triangles (T, 3) int32.
+ *   gens_mc_emit: vertex of edge (p, a) = p + e_a (iso - u_p) / (u_q - u_p) in float64, stored at voff[p] + rank of a;
+ *     triangles of cell p from tri_table (DEVICE (256, table_stride) int8 edge ids, -1 padded; gens_amd/mc_tables.py)
+ *     at toff[p].  Order: vertices by (p, a), triangles by (p, table order).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_mc_classify(const float* u, int x, int y, int z, float iso, const uint8_t* tri_count, uint8_t* vmask,
+                     uint8_t* vcount, uint8_t* cases, uint8_t* tcount, void* stream);
+int gens_mc_emit(const float* u, int x, int y, int z, float iso, const int8_t* tri_table, int table_stride,
+                 const uint8_t* vmask, const int32_t* voff, const uint8_t* cases, const uint8_t* tcount, const int32_t* toff,
+                 double* vertices, int32_t* triangles, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K10  tv_regularization, one level per call                      (implicit_surface.py:135-150)
  *   vol (4, X, Y, Z), mask (X, Y, Z); partial (n_blocks, 4) per-block sums [tx_num, ty_num, tz_num, mx_count]
  *   (n_blocks = gens_tv_blocks(x*y*z)); the host finishes sqrt((tx+ty+tz)/(count+1e-8)) * 0.5^level (Q13).

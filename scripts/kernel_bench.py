@@ -164,6 +164,16 @@ def main():
         per = measure(lambda: ops.lattice_points([-1, -1, -1], [1, 1, 1], 512, 0, cnt, dev), args.iters)
         add(f"K11 lattice points N={cnt}", "gens_lattice_points", per, cnt * 12)
 
+    with torch.no_grad():
+        # ---- K12 marching cubes on a 512^3 lattice (the reference's mesh resolution): sphere field, ~0.8 M vertices
+        n = 512
+        ax = torch.arange(n, device=dev, dtype=torch.float32) - (n - 1) / 2
+        u = 180.3 - torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+        per = measure(lambda: ops.marching_cubes(u, 0.0), 20, warm=3)
+        add("K12 mc classify 512^3", "gens_mc_classify", per, n ** 3 * 8)
+        add("K12 mc emit 512^3", "gens_mc_emit", per, n ** 3 * 15)
+        del u
+
     smi = ""
     try:
         smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30).stdout
