@@ -1,5 +1,6 @@
 """GPU tests of the training path (BASELINE config 3 / 5): backward through the HIP look-up (first + second order),
 compositing, feature-warp, patch-warp and TV kernels; GenS.forward in train and fine-tune mode with stand-in CNNs."""
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -162,3 +163,19 @@ def test_gens_val_mode_returns_image_buffers():
                             ipts["c2ws"], ipts["bound_min"], ipts["bound_max"], ipts["hw"], extract_geometry=False)
     assert out["img_fine"].shape == (6, 8, 3) and out["normal_img"].shape == (6, 8, 3)
     assert out["sdf_depth"].shape == (6, 8) and out["render_depth"].shape == (6, 8) and tuple(out["color_fine"].shape) == (48, 3)
+
+
+def test_gens_forward_val_returns_mesh_and_images():
+    """GenS.forward('val') end to end (gens.py:86-122 -> implicit_surface.py:429-470): the 7 output keys of the reference,
+    with the 512^3 mesh extraction running on the device (no PyMCubes)."""
+    model = _gens().eval()
+    ipts = _inputs(n_rays=48)
+    ipts.update(bound_min=torch.tensor([-1.0, -1, -1]).cuda(), bound_max=torch.tensor([1.0, 1, 1]).cuda(), hw=torch.tensor([6, 8]).int())
+    ipts.pop("pseudo_pts")
+    with torch.no_grad():
+        out = model("val", ipts, 1.0, None)
+    assert set(out) >= {"vertices", "triangles", "color_fine", "img_fine", "normal_img", "sdf_depth", "render_depth"}
+    v, t = out["vertices"], out["triangles"]
+    assert v.ndim == 2 and v.shape[1] == 3 and t.ndim == 2 and t.shape[1] == 3 and v.dtype.kind == "f"
+    if len(t):
+        assert t.min() >= 0 and t.max() < len(v) and np.abs(v).max() <= 1.0 + 1e-6
