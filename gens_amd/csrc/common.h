@@ -37,6 +37,7 @@ struct LevelSet {
     const float* aux[GENS_MAX_LEVELS];
     int dx[GENS_MAX_LEVELS], dy[GENS_MAX_LEVELS], dz[GENS_MAX_LEVELS];
     int n;
+    int bits;   // mask pyramids only: data[] are bit-packed words (gens_pack_mask_bits), bit i = voxel i (C order) is set
 };
 
 // torch.linspace(start, end, steps)[i] in float32 (ATen's symmetric formula: the upper half counts down from end).
@@ -56,34 +57,50 @@ __device__ __forceinline__ float4 mat4_point(const float* __restrict__ m, float 
     return r;
 }
 
-// wave-level helpers (wave = 64 lanes on gfx950)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// wave-level helpers (wave = 64 lanes on gfx950).  Cross-lane traffic goes through DPP (data-parallel primitives: the
+// operand of a VALU instruction is taken from a neighbouring lane, no LDS round trip as with ds_bpermute / __shfl):
+// row_shr:n inside the 16-lane rows, then row_bcast:15 / row_bcast:31 to carry the row totals -- 6 VALU steps per scan.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {   // lanes without a source (or in masked-off rows) get `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+#define GENS_DPP_SCAN(v, ident, OP)                          \
+    do {                                                     \
+        v = OP(v, dpp_move<0x111, 0xF>(ident, v)); /* row_shr:1 */    \
+        v = OP(v, dpp_move<0x112, 0xF>(ident, v)); /* row_shr:2 */    \
+        v = OP(v, dpp_move<0x114, 0xF>(ident, v)); /* row_shr:4 */    \
+        v = OP(v, dpp_move<0x118, 0xF>(ident, v)); /* row_shr:8 */    \
+        v = OP(v, dpp_move<0x142, 0xA>(ident, v)); /* row_bcast:15 -> rows 1, 3 */ \
+        v = OP(v, dpp_move<0x143, 0xC>(ident, v)); /* row_bcast:31 -> rows 2, 3 */ \
+    } while (0)
+__device__ __forceinline__ float op_add_(float a, float b) { return a + b; }
+__device__ __forceinline__ float op_mul_(float a, float b) { return a * b; }
+__device__ __forceinline__ float op_max_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float lane_value(float v, int lane) {   // lane must be wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 // inclusive prefix product / sum across the 64 lanes
 __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(v, o, 64);
-        if (lane >= o) v *= t;
-    }
+    (void)lane;
+    GENS_DPP_SCAN(v, 1.0f, op_mul_);
     return v;
 }
 __device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
+    (void)lane;
+    GENS_DPP_SCAN(v, 0.0f, op_add_);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    GENS_DPP_SCAN(v, 0.0f, op_add_);
+    return lane_value(v, 63);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    GENS_DPP_SCAN(v, -3.402823466e38f, op_max_);
+    return lane_value(v, 63);
+}
+// value of the next / previous lane (wave_shl:1 / wave_shr:1); the lane without a neighbour gets `edge`
+__device__ __forceinline__ float lane_next(float v, float edge) { return dpp_move<0x130, 0xF>(edge, v); }
+__device__ __forceinline__ float lane_prev(float v, float edge) { return dpp_move<0x138, 0xF>(edge, v); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -112,9 +129,23 @@ __device__ __forceinline__ float mask_nearest(const float* __restrict__ m, int d
     return m[((int64_t)(int)fx * dy + (int)fy) * dz + (int)fz];
 }
 
+// the same read from a bit-packed mask (1 bit per voxel: the 256^3 level is 2 MB and stays in L2)
+__device__ __forceinline__ bool mask_nearest_bit(const uint32_t* __restrict__ m, int dx, int dy, int dz, float px, float py, float pz) {
+    float fx = rintf(((px + 1.0f) * (float)dx - 1.0f) / 2.0f);
+    float fy = rintf(((py + 1.0f) * (float)dy - 1.0f) / 2.0f);
+    float fz = rintf(((pz + 1.0f) * (float)dz - 1.0f) / 2.0f);
+    if (!(fx >= 0.0f && fx < (float)dx && fy >= 0.0f && fy < (float)dy && fz >= 0.0f && fz < (float)dz)) return false;
+    const int64_t i = ((int64_t)(int)fx * dy + (int)fy) * dz + (int)fz;
+    return (m[i >> 5] >> (unsigned)(i & 31)) & 1u;
+}
+
 __device__ __forceinline__ bool any_mask(const LevelSet& ms, float px, float py, float pz) {
     bool ok = false;
-    for (int l = 0; l < ms.n; ++l) ok = ok || (mask_nearest(ms.data[l], ms.dx[l], ms.dy[l], ms.dz[l], px, py, pz) > 0.0f);
+    if (ms.bits) {
+        for (int l = 0; l < ms.n; ++l) ok = ok || mask_nearest_bit((const uint32_t*)ms.data[l], ms.dx[l], ms.dy[l], ms.dz[l], px, py, pz);
+    } else {
+        for (int l = 0; l < ms.n; ++l) ok = ok || (mask_nearest(ms.data[l], ms.dx[l], ms.dy[l], ms.dz[l], px, py, pz) > 0.0f);
+    }
     return ok;
 }
 

@@ -331,6 +331,7 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
     GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "%s: n_levels=%d not in 1..%d", who, n_levels,
                    GENS_MAX_LEVELS);
     ls->n = n_levels;
+    ls->bits = 0;
     for (int l = 0; l < GENS_MAX_LEVELS; ++l) {
         ls->data[l] = nullptr;
         ls->grad[l] = nullptr;
@@ -409,13 +410,31 @@ extern "C" int gens_lookup_mask_nearest(const float* const* masks, const int* di
     return gens_launch_status("gens_lookup_mask_nearest");
 }
 
+// mask (n floats, > 0 = set) -> n bits, 32 voxels per word in C order (one ballot per wavefront)
+__global__ __launch_bounds__(256) void pack_mask_bits_k(const float* __restrict__ mask, int64_t n, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && mask[i] > 0.0f);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && i < n) bits[i >> 5] = (uint32_t)b;
+    if (lane == 32 && i < n) bits[i >> 5] = (uint32_t)(b >> 32);
+}
+
+extern "C" int gens_pack_mask_bits(const float* mask, int64_t n, uint32_t* bits, void* stream) {
+    GENS_CHECK_ARG(mask && bits && n > 0, GENS_EINVAL, "gens_pack_mask_bits: bad argument");
+    pack_mask_bits_k<<<gens_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(mask, n, bits);
+    return gens_launch_status("gens_pack_mask_bits");
+}
+
 extern "C" int gens_ray_points(const float* rays_o, const float* rays_d, const float* z, int64_t n_rays, int n_samples, int mid,
-                               float sample_dist, const float* const* masks, const int* dims, int n_levels, float* pts,
-                               uint8_t* valid, void* stream) {
+                               float sample_dist, const float* const* masks, const int* dims, int n_levels, int mask_bits,
+                               float* pts, uint8_t* valid, void* stream) {
     LevelSet ms;
     ms.n = 0;
-    if (valid)
+    ms.bits = 0;
+    if (valid) {
         if (int e = gens_fill_levels("gens_ray_points", &ms, masks, dims, n_levels)) return e;
+        ms.bits = mask_bits ? 1 : 0;
+    }
     GENS_CHECK_ARG(n_rays >= 0 && n_samples > 0 && (n_rays == 0 || (rays_o && rays_d && z && pts)), GENS_EINVAL,
                    "gens_ray_points: bad argument");
     if (n_rays == 0) return 0;

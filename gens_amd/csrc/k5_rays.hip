@@ -21,29 +21,22 @@ __device__ __forceinline__ float pick2(float v0, float v1, int idx) {
 }
 // element j+1 of the two-slot array, seen from the owner of element j
 __device__ __forceinline__ void next2(float v0, float v1, int lane, float& n0, float& n1) {
-    n0 = __shfl_down(v0, 1, 64);
-    float first1 = __shfl(v1, 0, 64);
-    if (lane == 63) n0 = first1;
-    n1 = __shfl_down(v1, 1, 64);
+    (void)lane;
+    n0 = lane_next(v0, lane_value(v1, 0));
+    n1 = lane_next(v1, v1);
 }
 // element j-1 (zero for j = 0)
 __device__ __forceinline__ void prev2(float v0, float v1, int lane, float& p0, float& p1) {
-    p0 = __shfl_up(v0, 1, 64);
-    if (lane == 0) p0 = 0.0f;
-    p1 = __shfl_up(v1, 1, 64);
-    float last0 = __shfl(v0, 63, 64);
-    if (lane == 0) p1 = last0;
+    (void)lane;
+    p0 = lane_prev(v0, 0.0f);
+    p1 = lane_prev(v1, lane_value(v0, 63));
 }
 // exclusive prefix product over the 128 slots
 __device__ __forceinline__ void excl_cumprod2(float f0, float f1, int lane, float& t0, float& t1) {
     float p0 = wave_scan_mul(f0, lane);
     float p1 = wave_scan_mul(f1, lane);
-    float tot0 = __shfl(p0, 63, 64);
-    t0 = __shfl_up(p0, 1, 64);
-    if (lane == 0) t0 = 1.0f;
-    t1 = __shfl_up(p1, 1, 64);
-    if (lane == 0) t1 = 1.0f;
-    t1 *= tot0;
+    t0 = lane_prev(p0, 1.0f);
+    t1 = lane_prev(p1, 1.0f) * lane_value(p0, 63);
 }
 // number of entries <= u in a sorted LDS row (torch.searchsorted(..., right=True))
 __device__ __forceinline__ int upper_bound_lds(const float* row, int n, float u) {
@@ -61,8 +54,8 @@ __device__ __forceinline__ int upper_bound_lds(const float* row, int n, float u)
 __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                                   const float* __restrict__ z, const float* __restrict__ sdf,
                                                                   int64_t n_rays, int n, int n_new, float inv_s, LevelSet ms,
-                                                                  float* __restrict__ z_new, float* __restrict__ pts_new,
-                                                                  uint8_t* __restrict__ valid_new) {
+                                                                  const uint8_t* __restrict__ valid_in, float* __restrict__ z_new,
+                                                                  float* __restrict__ pts_new, uint8_t* __restrict__ valid_new) {
     __shared__ float s_cdf[RAYS_PER_BLOCK][MAX_SAMPLES];
     __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -82,7 +75,8 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* _
         sj[s] = have ? sdf[r * n + j] : 0.0f;
         float px = ox + dx * zj[s], py = oy + dy * zj[s], pz = oz + dz * zj[s];
         rad[s] = sqrtf(px * px + py * py + pz * pz);
-        vm[s] = (have && any_mask(ms, px, py, pz)) ? 1.0f : 0.0f;
+        // validity of the existing samples: carried from the launches that created them (valid_in) or looked up again
+        vm[s] = (have && (valid_in ? valid_in[r * n + j] != 0 : any_mask(ms, px, py, pz))) ? 1.0f : 0.0f;
     }
     float zn[2], sn[2], rn[2], vn[2];
     next2(zj[0], zj[1], lane, zn[0], zn[1]);
@@ -120,7 +114,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* _
     for (int s = 0; s < 2; ++s) wp[s] = ((lane + 64 * s) < n - 1) ? alpha[s] * tr[s] + 1e-5f : 0.0f;
     float total = wave_sum(wp[0] + wp[1]);
     float c0 = wave_scan_add(wp[0] / total, lane);
-    float c1 = wave_scan_add(wp[1] / total, lane) + __shfl(c0, 63, 64);
+    float c1 = wave_scan_add(wp[1] / total, lane) + lane_value(c0, 63);
     if (active) {
         if (lane == 0) s_cdf[wave][0] = 0.0f;
         if (lane < n - 1) s_cdf[wave][lane + 1] = c0;
@@ -156,8 +150,9 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* _
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_k(const float* __restrict__ z, const float* __restrict__ sdf,
                                                                const float* __restrict__ z_new, const float* __restrict__ sdf_new,
+                                                               const uint8_t* __restrict__ valid, const uint8_t* __restrict__ valid_new,
                                                                int64_t n_rays, int n, int n_new, float* __restrict__ z_out,
-                                                               float* __restrict__ sdf_out) {
+                                                               float* __restrict__ sdf_out, uint8_t* __restrict__ valid_out) {
     __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_k(const float* __re
     if (!active) return;
     int less[2] = {0, 0}, before = 0;
     for (int k = 0; k < n_new; ++k) {
-        float v = __shfl(zk, k, 64);
+        float v = lane_value(zk, k);
         less[0] += (v < zj[0]) ? 1 : 0;
         less[1] += (v < zj[1]) ? 1 : 0;
         before += (v < zk || (v == zk && k < lane)) ? 1 : 0;
@@ -187,12 +182,14 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_k(const float* __re
             int64_t o = r * m + j + less[s];
             z_out[o] = zj[s];
             if (sdf_out) sdf_out[o] = sdf[r * n + j];
+            if (valid_out) valid_out[o] = valid[r * n + j];
         }
     }
     if (lane < n_new) {
         int64_t o = r * m + upper_bound_lds(s_z[wave], n, zk) + before;
         z_out[o] = zk;
         if (sdf_out) sdf_out[o] = sdf_new[r * n_new + lane];
+        if (valid_out) valid_out[o] = valid_new[r * n_new + lane];
     }
 }
 
@@ -396,7 +393,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_comp
     }
     // S_j = sum_{k>j} gw_k w_k
     float inc0 = wave_scan_add(gww[0], lane), inc1 = wave_scan_add(gww[1], lane);
-    float tot0 = __shfl(inc0, 63, 64), tot1 = __shfl(inc1, 63, 64);
+    float tot0 = lane_value(inc0, 63), tot1 = lane_value(inc1, 63);
     float suf[2] = {tot0 + tot1 - inc0, tot1 - inc1};
     float gs_acc = 0.0f;
     const int i0 = g.cross_idx ? g.cross_idx[r] : 0;
@@ -456,27 +453,30 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_comp
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
 extern "C" int gens_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t n_rays, int n,
-                             int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, float* z_new,
-                             float* pts_new, uint8_t* valid_new, void* stream) {
+                             int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, int mask_bits,
+                             const uint8_t* valid_in, float* z_new, float* pts_new, uint8_t* valid_new, void* stream) {
     LevelSet ms;
     if (int e = gens_fill_levels("gens_upsample", &ms, masks, dims, n_levels)) return e;
+    ms.bits = mask_bits ? 1 : 0;
     GENS_CHECK_ARG(n >= 2 && n <= MAX_SAMPLES && n_new >= 1 && n_new <= 64, GENS_ELIMIT, "gens_upsample: n=%d (2..128) n_new=%d (1..64)", n, n_new);
     GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (rays_o && rays_d && z && sdf && z_new)), GENS_EINVAL, "gens_upsample: null pointer");
     if (n_rays == 0) return 0;
     upsample_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(
-        rays_o, rays_d, z, sdf, n_rays, n, n_new, inv_s, ms, z_new, pts_new, valid_new);
+        rays_o, rays_d, z, sdf, n_rays, n, n_new, inv_s, ms, valid_in, z_new, pts_new, valid_new);
     return gens_launch_status("gens_upsample");
 }
 
-extern "C" int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, int64_t n_rays, int n,
-                                  int n_new, float* z_out, float* sdf_out, void* stream) {
+extern "C" int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, const uint8_t* valid,
+                                  const uint8_t* valid_new, int64_t n_rays, int n, int n_new, float* z_out, float* sdf_out,
+                                  uint8_t* valid_out, void* stream) {
     GENS_CHECK_ARG(n >= 1 && n_new >= 1 && n_new <= 64 && n + n_new <= MAX_SAMPLES, GENS_ELIMIT,
                    "gens_merge_samples: n=%d n_new=%d (n_new <= 64, n+n_new <= 128)", n, n_new);
     GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (z && z_new && z_out)), GENS_EINVAL, "gens_merge_samples: null pointer");
     GENS_CHECK_ARG(!sdf_out || (sdf && sdf_new), GENS_EINVAL, "gens_merge_samples: sdf_out needs sdf and sdf_new");
+    GENS_CHECK_ARG(!valid_out || (valid && valid_new), GENS_EINVAL, "gens_merge_samples: valid_out needs valid and valid_new");
     if (n_rays == 0) return 0;
-    merge_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(z, sdf, z_new, sdf_new, n_rays, n, n_new,
-                                                                                              z_out, sdf_out);
+    merge_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(z, sdf, z_new, sdf_new, valid, valid_new,
+                                                                                              n_rays, n, n_new, z_out, sdf_out, valid_out);
     return gens_launch_status("gens_merge_samples");
 }
 

@@ -207,13 +207,14 @@ class ImplicitSurface(nn.Module):
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, masks)
         sdf = self._masked_sdf(pts, valid, vols).reshape(b, -1)
         n_new = self.n_importance // self.up_sample_steps
+        valid = valid.reshape(b, -1)                       # mask decisions travel with the samples through the merges
         for i in range(self.up_sample_steps):
-            z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64 * 2 ** i)
+            z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64 * 2 ** i, valid_in=valid)
             if i + 1 == self.up_sample_steps:
                 z_vals, _ = ops.merge_samples(z_vals, z_new)
             else:
                 sdf_new = self._masked_sdf(pts_new, valid_new, vols).reshape(b, n_new)
-                z_vals, sdf = ops.merge_samples(z_vals, z_new, sdf, sdf_new)
+                z_vals, sdf, valid = ops.merge_samples(z_vals, z_new, sdf, sdf_new, valid, valid_new)
         return z_vals
 
     # ----------------------------------------------------------------------------------------------------------

@@ -90,7 +90,20 @@ class VolumeSet:
         vs.n = len(vs.tensors)
         vs.table = L.ptr_table(vs.tensors)
         vs.dim_table = L.int_table([d for dd in vs.dims for d in dd])
+        vs._bits = None
         return vs
+
+    def bit_table(self):
+        """Bit-packed copy of a mask pyramid (built once, on first use): HOST pointer table for mask_bits=1 calls."""
+        if getattr(self, "_bits", None) is None:
+            words = []
+            for t in self.tensors:
+                n = t.numel()
+                w = torch.empty((n + 31) // 32, device=t.device, dtype=torch.int32)
+                L.call("gens_pack_mask_bits", L.ptr(t), n, L.ptr(w, torch.int32), L.stream())
+                words.append(w)
+            self._bits = (words, L.ptr_table(words, torch.int32))
+        return self._bits[1]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -241,14 +254,22 @@ def compact_valid(valid):
     return idx, count
 
 
+def _mask_args(masks):
+    """(pointer table, dims, levels, mask_bits): a scene's VolumeSet is read through its bit-packed copy (built once)."""
+    if isinstance(masks, VolumeSet):
+        return masks.bit_table(), masks.dim_table, masks.n, 1
+    ms = VolumeSet.masks(masks)
+    return ms.table, ms.dim_table, ms.n, 0
+
+
 def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
     """pts (B*n,3) = o + d * (z or section mid-points), valid (B*n,) bool."""
-    ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
+    table, dims, nl, bits = _mask_args(masks)
     b, n = z.shape
     pts = torch.empty(b * n, 3, device=z.device, dtype=_f32)
     valid = torch.empty(b * n, device=z.device, dtype=torch.uint8)
-    L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), ms.table,
-           ms.dim_table, ms.n, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * n * 17 + b * 24)
+    L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), table,
+           dims, nl, bits, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * n * 17 + b * 24)
     return pts, valid.view(torch.bool)
 
 
@@ -314,28 +335,38 @@ def lookup_feature(pts, views):
 # ------------------------------------------------------------------------------------------------------------------
 # K5-K7  hierarchical sampling
 # ------------------------------------------------------------------------------------------------------------------
-def upsample(rays_o, rays_d, z, sdf, n_new, masks, inv_s):
-    """up_sample + sample_pdf(det) (implicit_surface.py:60-109): -> z_new (B,n_new), pts_new (B*n_new,3), valid_new bool."""
-    ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
+def upsample(rays_o, rays_d, z, sdf, n_new, masks, inv_s, valid_in=None):
+    """up_sample + sample_pdf(det) (implicit_surface.py:60-109): -> z_new (B,n_new), pts_new (B*n_new,3), valid_new bool.
+    valid_in (B,n) bool/uint8: mask decisions of the existing samples carried from earlier rounds (None: looked up again)."""
+    table, dims, nl, bits = _mask_args(masks)
     b, n = z.shape
     z_new = torch.empty(b, n_new, device=z.device, dtype=_f32)
     pts_new = torch.empty(b * n_new, 3, device=z.device, dtype=_f32)
     valid = torch.empty(b * n_new, device=z.device, dtype=torch.uint8)
-    L.call("gens_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), b, n, n_new, float(inv_s), ms.table,
-           ms.dim_table, ms.n, L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * (8 * n + 17 * n_new + 24))
+    vin = None if valid_in is None else _c(valid_in.reshape(b, n).view(torch.uint8))
+    L.call("gens_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), b, n, n_new, float(inv_s), table,
+           dims, nl, bits, L.ptr(vin, torch.uint8), L.ptr(z_new), L.ptr(pts_new), L.ptr(valid, torch.uint8), L.stream(),
+           nbytes=b * (8 * n + 17 * n_new + 24 + (n if vin is not None else 0)))
     return z_new, pts_new, valid.view(torch.bool)
 
 
-def merge_samples(z, z_new, sdf=None, sdf_new=None):
-    """cat + sort of cat_z_vals (implicit_surface.py:111-133)."""
+def merge_samples(z, z_new, sdf=None, sdf_new=None, valid=None, valid_new=None):
+    """cat + sort of cat_z_vals (implicit_surface.py:111-133); the per-sample mask decisions ride along when given.
+    -> (z, sdf) or (z, sdf, valid)."""
     b, n = z.shape
     n_new = z_new.shape[1]
     z_out = torch.empty(b, n + n_new, device=z.device, dtype=_f32)
     sdf_out = torch.empty_like(z_out) if sdf is not None else None
+    u8 = torch.uint8
+    v_in = None if valid is None else _c(valid.reshape(b, n).view(u8))
+    v_new = None if valid is None else _c(valid_new.reshape(b, n_new).view(u8))
+    v_out = None if valid is None else torch.empty(b, n + n_new, device=z.device, dtype=u8)
     L.call("gens_merge_samples", L.ptr(_c(z)), L.ptr(_c(sdf)) if sdf is not None else None, L.ptr(_c(z_new)),
-           L.ptr(_c(sdf_new)) if sdf_new is not None else None, b, n, n_new, L.ptr(z_out), L.ptr(sdf_out), L.stream(),
-           nbytes=b * (n + n_new) * (8 if sdf is None else 16))
-    return z_out, sdf_out
+           L.ptr(_c(sdf_new)) if sdf_new is not None else None, L.ptr(v_in, u8), L.ptr(v_new, u8), b, n, n_new, L.ptr(z_out), L.ptr(sdf_out),
+           L.ptr(v_out, u8), L.stream(), nbytes=b * (n + n_new) * ((8 if sdf is None else 16) + (2 if valid is not None else 0)))
+    if valid is None:
+        return z_out, sdf_out
+    return z_out, sdf_out, v_out.view(torch.bool)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -93,12 +93,16 @@ int gens_lookup_volume_bwd2(const float* const* vols, const int* dims, int n_lev
  * gens_ray_points fuses the point generation of render / render_core (implicit_surface.py:160-174, 367-371):
  *   z (B, n); mid != 0 -> samples at z + 0.5*dist with the last dist = sample_dist (Q10)
  *   pts (B*n, 3), valid (B*n) uint8.
+ * gens_pack_mask_bits: (n) float mask -> ceil(n/32) uint32 words, bit i%32 of word i/32 = (mask[i] > 0) -- the 256^3
+ *   level becomes 2 MB and stays in L2.  gens_ray_points / gens_upsample read such words when mask_bits != 0
+ *   (masks[] then point to the words); the decisions are identical to the float masks.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_lookup_mask_nearest(const float* const* masks, const int* dims, int n_levels, const float* pts, int64_t n,
                              uint8_t* valid, float* vals, void* stream);
 int gens_ray_points(const float* rays_o, const float* rays_d, const float* z, int64_t n_rays, int n_samples, int mid,
-                    float sample_dist, const float* const* masks, const int* dims, int n_levels, float* pts,
-                    uint8_t* valid, void* stream);
+                    float sample_dist, const float* const* masks, const int* dims, int n_levels, int mask_bits,
+                    float* pts, uint8_t* valid, void* stream);
+int gens_pack_mask_bits(const float* mask, int64_t n, uint32_t* bits, void* stream);
 
 /* Order-preserving compaction of the valid flags written by gens_ray_points / gens_upsample: idx[0..count) = positions of
  * the non-zero flags in increasing order; if no flag is set, count = min(10, n) and idx = 0..count-1 (Q7,
@@ -124,14 +128,18 @@ int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const
  * K5 + K6  ImplicitSurface.up_sample + sample_pdf(det=True)      (implicit_surface.py:14-44, 60-109)
  *   one wavefront per ray; z, sdf (B, n) with n <= 128; inv_s = 64 * 2^round; n_new <= 64
  *   z_new (B, n_new); pts_new (B*n_new, 3) and valid_new (B*n_new) uint8 feed the next SDF evaluation (:117-121).
+ *   valid_in (B, n) uint8 or NULL: the mask decisions of the existing samples as written by gens_ray_points /
+ *   gens_upsample and carried through gens_merge_samples (the reference looks all n of them up again every round, :66-67;
+ *   the values are the same because the samples are); NULL = look them up here.
  * K7  cat_z_vals: sorted merge of (z, sdf) with (z_new, sdf_new)  (:111-133); sdf / sdf_new / sdf_out may be NULL
- *   together (the `last` round).  n + n_new <= 128.
+ *   together (the `last` round); valid / valid_new / valid_out (uint8) likewise.  n + n_new <= 128.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t n_rays, int n,
-                  int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, float* z_new,
-                  float* pts_new, uint8_t* valid_new, void* stream);
-int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, int64_t n_rays,
-                       int n, int n_new, float* z_out, float* sdf_out, void* stream);
+                  int n_new, float inv_s, const float* const* masks, const int* dims, int n_levels, int mask_bits,
+                  const uint8_t* valid_in, float* z_new, float* pts_new, uint8_t* valid_new, void* stream);
+int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, const uint8_t* valid,
+                       const uint8_t* valid_new, int64_t n_rays, int n, int n_new, float* z_out, float* sdf_out,
+                       uint8_t* valid_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K8  render_core compositing                                     (implicit_surface.py:160-168, 202-303)

@@ -122,8 +122,9 @@ def main():
         for rnd, n in enumerate((64, 80, 96, 112)):
             zz = z128[:, :n].contiguous()
             ss = sdf[:, :n].contiguous()
-            per = measure(lambda: ops.upsample(ro, rd, zz, ss, 16, mset, 64.0 * 2 ** rnd), args.iters)
-            add(f"K5/K6 upsample B={b} n={n}->16", "gens_upsample", per, b * (8 * n + 17 * 16 + 24))
+            _, vin = ops.ray_points(ro, rd, zz, mset)
+            per = measure(lambda: ops.upsample(ro, rd, zz, ss, 16, mset, 64.0 * 2 ** rnd, valid_in=vin), args.iters)
+            add(f"K5/K6 upsample B={b} n={n}->16", "gens_upsample", per, b * (9 * n + 17 * 16 + 24), "mask decisions of the n old samples carried in")
         znew = (zz[:, :16] + 1e-3).contiguous()
         snew = ss[:, :16].contiguous()
         per = measure(lambda: ops.merge_samples(zz, znew, ss, snew), args.iters)

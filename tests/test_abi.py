@@ -55,7 +55,7 @@ def test_argument_errors_are_reported_without_a_gpu(libpath):
     lib = L.load()
     rc = lib.gens_volume_build_fwd(None, None, None, 1.0, 3, 30, 40, 16, 1, None, None, None)
     assert rc == -1 and b"null" in lib.gens_last_error()
-    rc = lib.gens_merge_samples(None, None, None, None, 4, 120, 16, None, None, None)
+    rc = lib.gens_merge_samples(None, None, None, None, None, None, 4, 120, 16, None, None, None, None)
     assert rc == -2
     with pytest.raises(RuntimeError):
         L.call("gens_tv_fwd", None, None, 0, 0, 0, None, None)
@@ -74,3 +74,11 @@ def test_product_fails_loudly_without_device_tensors(libpath):
     from gens_amd import ops
     with pytest.raises(RuntimeError):
         ops.lookup_mask(torch.zeros(4, 3), [torch.ones(1, 1, 4, 4, 4)])
+
+
+def test_new_entry_points_validate_their_arguments(libpath):
+    from gens_amd import lib as L
+    lib = L.load()
+    assert lib.gens_mc_classify(None, 1, 8, 8, 0.0, None, None, None, None, None, None) == -1      # lattice must be >= 2 per axis
+    assert lib.gens_mc_emit(None, 8, 8, 8, 0.0, None, 3, None, None, None, None, None, None, None, None) == -1
+    assert lib.gens_pack_mask_bits(None, 0, None, None) == -1

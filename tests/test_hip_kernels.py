@@ -219,6 +219,37 @@ def test_k7_merge_with_sdf_and_ties_vs_oracle(ops):
         close(os_, rs, atol=0, rtol=0, what="sdf")
 
 
+def test_bit_packed_masks_and_carried_validity_change_nothing(ops, golden):
+    """The scene path reads masks as 1 bit per voxel and carries each sample's mask decision through the merges instead of
+    looking all n samples up again every round (implicit_surface.py:66-67): decisions and samples must be identical."""
+    g = golden("g5_upsample")
+    mask_list = [dev(g[f"mask{i}"]) for i in range(3)]
+    mset = ops.VolumeSet.masks(mask_list)
+    ro, rd = dev(g["rays_o"]), dev(g["rays_d"])
+    # K3: float masks vs bit masks, incl. points outside the cube and half-integer ties (scaled rays leave [-1, 1]^3)
+    for scale in (1.0, 1.7):
+        z = dev(g["z0"]) * scale
+        p0, v0 = ops.ray_points(ro, rd, z, mask_list, mid=True, sample_dist=1 / 32)
+        p1, v1 = ops.ray_points(ro, rd, z, mset, mid=True, sample_dist=1 / 32)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1) and 0 < int(v0.sum()) < v0.numel()
+    # K5-K7: four rounds, once as the reference does it and once with bits + carried validity
+    z_a = z_b = dev(g["z0"])
+    s_a = s_b = dev(g["sdf0"])
+    _, valid = ops.ray_points(ro, rd, z_b, mset)
+    valid = valid.reshape(z_b.shape)
+    gen = torch.Generator().manual_seed(3)
+    for r in range(4):
+        za, pa, va = ops.upsample(ro, rd, z_a, s_a, 16, mask_list, 64 * 2 ** r)
+        zb, pb, vb = ops.upsample(ro, rd, z_b, s_b, 16, mset, 64 * 2 ** r, valid_in=valid)
+        assert torch.equal(za, zb) and torch.equal(pa, pb) and torch.equal(va, vb)
+        s_new = dev(torch.randn(za.shape, generator=gen) * 0.1)
+        z_a, s_a = ops.merge_samples(z_a, za, s_a, s_new)
+        z_b, s_b, valid = ops.merge_samples(z_b, zb, s_b, s_new, valid, vb)
+        assert torch.equal(z_a, z_b) and torch.equal(s_a, s_b)
+        _, again = ops.ray_points(ro, rd, z_b, mask_list)
+        assert torch.equal(valid.reshape(-1), again)            # the carried flags ARE the look-up of the merged samples
+
+
 # --------------------------------------------------------------------------------------------------- K8
 def _composite_case(b, n, s, seed, smooth=True):
     from gens_amd import synthetic
