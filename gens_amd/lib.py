@@ -102,10 +102,15 @@ def load():
 _profile = None   # None, or a list of (name, start_event, end_event, algorithmic_bytes)
 
 
-def profile_begin():
-    """Start recording a HIP event pair around every kernel launch (on the stream the kernel is enqueued on)."""
-    global _profile
+_profile_only = None
+
+
+def profile_begin(only=None):
+    """Start recording a HIP event pair around every kernel launch (on the stream the kernel is enqueued on).
+    only: optional set of entry-point names to restrict the recording to (an event pair costs ~15 us of host time)."""
+    global _profile, _profile_only
     _profile = []
+    _profile_only = set(only) if only else None
 
 
 def profile_end(raw=False):
@@ -132,7 +137,7 @@ def profile_end(raw=False):
 def call(name, *args, nbytes=0, flops=0, live=None):
     """Invoke one C-ABI entry point; `nbytes` / `flops` = algorithmic HBM bytes / FLOPs of this launch."""
     lib = load()
-    if _profile is not None:
+    if _profile is not None and (_profile_only is None or name in _profile_only):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = getattr(lib, name)(*args)

@@ -44,6 +44,15 @@ class Scene:
         self.views = ops.SceneViews(imgs, intrs, c2ws, features)
         self._packed = None
         self._warp = {}
+        self._rot = None
+        self.ref_rotation()          # read back now, while the launch queue is short, not in the middle of the first ray chunk
+
+    def ref_rotation(self):
+        """Row-major inverse of the reference camera's rotation (implicit_surface.py:242,245) as 9 host floats, read back once
+        per scene (the compositing kernel takes it by value)."""
+        if self._rot is None:
+            self._rot = torch.linalg.inv(self.c2ws[0][:3, :3].to(torch.float32)).reshape(-1).tolist()
+        return self._rot
 
     def volumes_nograd(self):
         """Packed (X,Y,Z,4) texel copy for passes that never need d/dvolume (sampling rounds, inference)."""
@@ -83,28 +92,27 @@ class JitterStream:
     """reference_jitter() produced group by group on a helper thread, so the ~4 M host RNG draws of a 480x640 image overlap
     with GPU work instead of preceding it.  Only this thread touches the default CPU generator while it runs."""
 
-    def __init__(self, n_rays, group):
+    def __init__(self, n_rays, group, buf=None):
+        """buf: optional (n_rays, 1) host buffer to fill -- a page-locked one makes the per-chunk upload asynchronous."""
         import threading
         group = max(REFERENCE_CHUNK, group // REFERENCE_CHUNK * REFERENCE_CHUNK)
         self.bounds = [(s, min(s + group, n_rays)) for s in range(0, n_rays, group)]
-        self.parts = [None] * len(self.bounds)
+        self.buf = buf if buf is not None else torch.empty(n_rays, 1)
         self.ready = [threading.Event() for _ in self.bounds]
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
     def _run(self):
         for k, (s, e) in enumerate(self.bounds):
-            self.parts[k] = _jitter_block(e - s)
+            self.buf[s:e] = _jitter_block(e - s)
             self.ready[k].set()
 
     def slice(self, s, e):
-        out = []
         for k, (bs, be) in enumerate(self.bounds):
             if be <= s or bs >= e:
                 continue
             self.ready[k].wait()
-            out.append(self.parts[k][max(s, bs) - bs:min(e, be) - bs])
-        return torch.cat(out, 0) if len(out) != 1 else out[0]
+        return self.buf[s:e]
 
     def join(self):
         self.thread.join()
@@ -272,7 +280,7 @@ class ImplicitSurface(nn.Module):
 
         inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
         comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, sdf, gradients, smooth, sampled_color, valid, src_vis, inv_s,
-                             cos_anneal_ratio, c2ws[0])
+                             cos_anneal_ratio, scene.ref_rotation())
         gradients = gradients.reshape(b, n, 3)
         out = {
             "color_fine": comp["color"],
@@ -326,7 +334,7 @@ class ImplicitSurface(nn.Module):
         if self.perturb > 0:
             if t_rand is None:
                 t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
-            z_vals = z_vals + (t_rand.to(dev) - 0.5) * 2.0 / self.n_samples
+            z_vals = z_vals + (t_rand.to(dev, non_blocking=True) - 0.5) * 2.0 / self.n_samples
         z_vals = z_vals.contiguous()
         if self.n_importance > 0:
             z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene)
@@ -372,7 +380,7 @@ class ImplicitSurface(nn.Module):
                                                                               threshold)
         height, width = int(hw[0]), int(hw[1])
         n_rays = rays_o.shape[0]
-        jitter = JitterStream(n_rays, self.val_chunk) if self.perturb > 0 else None
+        jitter = JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter")) if self.perturb > 0 else None
         # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
         # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
         image = torch.empty(n_rays, 8, device=rays_o.device, dtype=torch.float32)
@@ -408,12 +416,13 @@ class ImplicitSurface(nn.Module):
         outputs["render_depth"] = host_np[:, 7].reshape([height, width]).copy()
         return outputs
 
-    def _pinned(self, n_rays):
-        """Page-locked (P, 8) staging buffer for the rendered image, kept between validate() calls."""
-        buf = getattr(self, "_pinned_image", None)
+    def _pinned(self, n_rays, cols=8, slot="_pinned_image"):
+        """Page-locked (P, cols) staging buffer (rendered image / ray jitter), kept between validate() calls, which end with a
+        stream synchronisation, so reuse is safe."""
+        buf = getattr(self, slot, None)
         if buf is None or buf.shape[0] != n_rays:
-            buf = torch.empty(n_rays, 8, dtype=torch.float32, pin_memory=True)
-            self._pinned_image = buf
+            buf = torch.empty(n_rays, cols, dtype=torch.float32, pin_memory=True)
+            setattr(self, slot, buf)
         return buf
 
     def forward(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):

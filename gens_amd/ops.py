@@ -454,7 +454,9 @@ COMPOSITE_KEYS = ("color", "normal", "depth", "weights", "wsum", "eik_num", "smo
 def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, voxel_mask, src_vis, inv_s, cos_anneal, c2w_ref):
     """Everything render_core computes after the networks have run; returns a dict keyed by COMPOSITE_KEYS."""
     b, n = z.shape
-    rot = torch.linalg.inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()       # implicit_surface.py:242,245
+    # R_ref^-1 (implicit_surface.py:242,245) travels by value in the launch block; a list from Scene.ref_rotation() avoids the
+    # device->host read (a synchronisation) on every ray chunk
+    rot = c2w_ref if isinstance(c2w_ref, (list, tuple)) else torch.linalg.inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()
     z = _c(z.detach().to(_f32))
     z_max = z.max().reshape(1)                                                  # implicit_surface.py:301
     vm = _c(voxel_mask.reshape(b * n).to(torch.uint8))
