@@ -188,14 +188,21 @@ __device__ __forceinline__ float4 f4_madd(float4 acc, float4 v, float s) {
     return acc;
 }
 
-// texel (float4) bilinear read from img (h, w, cpad/4 float4s), texel slot q
+// texel (float4) bilinear read from img (h, w, cpad/4 float4s), texel slot q.  Branch-free: the four loads are issued
+// back to back from coordinates clamped into the image (one s_waitcnt for all of them instead of four serialised
+// load-use pairs under exec-mask branches); a tap outside the image keeps grid_sample's zero padding through a zero
+// weight (image values are finite, so 0 * v adds exactly nothing).
 __device__ __forceinline__ float4 sample_texel(const float4* __restrict__ img, int h, int w, int q4, int q, const Taps2& t) {
+    const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
+    const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
+    const float4* r0 = img + (int64_t)y0 * w * q4 + q;
+    const float4* r1 = img + (int64_t)y1 * w * q4 + q;
+    const float4 v00 = r0[(int64_t)x0 * q4], v01 = r0[(int64_t)x1 * q4], v10 = r1[(int64_t)x0 * q4], v11 = r1[(int64_t)x1 * q4];
     float4 acc = f4_zero();
-    int64_t base = ((int64_t)t.y0 * w + t.x0) * q4 + q;
-    if (t.ok00) acc = f4_madd(acc, img[base], t.w00);
-    if (t.ok01) acc = f4_madd(acc, img[base + q4], t.w01);
-    if (t.ok10) acc = f4_madd(acc, img[base + (int64_t)w * q4], t.w10);
-    if (t.ok11) acc = f4_madd(acc, img[base + (int64_t)w * q4 + q4], t.w11);
+    acc = f4_madd(acc, v00, t.ok00 ? t.w00 : 0.0f);
+    acc = f4_madd(acc, v01, t.ok01 ? t.w01 : 0.0f);
+    acc = f4_madd(acc, v10, t.ok10 ? t.w10 : 0.0f);
+    acc = f4_madd(acc, v11, t.ok11 ? t.w11 : 0.0f);
     return acc;
 }
 

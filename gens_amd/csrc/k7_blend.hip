@@ -14,10 +14,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BL_WAVES 1          // wavefronts per workgroup: waves are independent, a 1-wave workgroup makes every barrier free
-#define BL_TS 73            // row stride of the wide tile (K <= 70)
+#define BL_TS 73            // row stride of the wide tile (K <= 72: 3F = 69 padded to whole groups of 8)
 #define BL_VS 65            // row stride of the 64-wide tile
 #define BL_HS 33            // row stride of the hidden tile
 #define BL_MAXF 23          // 3 + 4*5 feature columns
+#define BL_RS 9             // row stride of the ray-difference tile (4 values + 4 zero columns: one group of 8)
 
 struct BlendWeights {
     const float *rd1, *rd1_b, *rd2, *rd2_b;   // ray_dir_fc: 4 -> 16 -> F
@@ -32,15 +33,33 @@ struct BlendWeights {
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int rs, const float* __restrict__ wp, int kk_count,
-                                            float bias, int lane) {
+// One 32 x 32 output tile: acc = bias + A(32 x 8G, LDS rows of stride rs) * B.  The reduction index runs in groups of 8:
+// within group j the four MFMAs i = 0..3 take k = 8j + 4h + i from lane half h, so a lane's B values for a group are ONE
+// global_load_dwordx4 of the host-packed stream (gens_amd.ops._pack_b_groups); all G loads of a tile are issued before its
+// first MFMA (one exposed L2 latency per tile instead of one per four MFMAs).
+template <int G>
+struct BGroups {
+    float4 v[G];
+};
+template <int G>
+__device__ __forceinline__ void load_b(BGroups<G>& b, const float* __restrict__ wp, int lane) {
+    const float4* p = (const float4*)wp + lane;
+#pragma unroll
+    for (int j = 0; j < G; ++j) b.v[j] = p[64 * j];
+}
+template <int G>
+__device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int rs, const BGroups<G>& b, float bias, int lane) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias;
-    const float* a = a_lds + (lane & 31) * rs + (lane >> 5);
-    const float* b = wp + lane;
-#pragma unroll 4
-    for (int kk = 0; kk < kk_count; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[64 * kk], acc, 0, 0, 0);
+    const float* a = a_lds + (lane & 31) * rs + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * j + 0], b.v[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * j + 1], b.v[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * j + 2], b.v[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * j + 3], b.v[j].w, acc, 0, 0, 0);
+    }
     return acc;
 }
 
@@ -51,8 +70,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
                                                          const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                          float* __restrict__ rgb_out, uint8_t* __restrict__ vis_out) {
     __shared__ float T_[BL_WAVES][32 * BL_TS];
-    __shared__ float D_[BL_WAVES][32 * 17];    // ray_dir_fc hidden layer
-    __shared__ float RD_[BL_WAVES][32 * 5];
+    __shared__ float RD_[BL_WAVES][32 * BL_RS];
     __shared__ float R_[BL_WAVES][32 * 8];     // per-row scalars: 0 mask, 1 e, 2 w, 3 w normalised, 4 vis, 5 vis2, 6 score
     __shared__ float C_[BL_WAVES][32 * 3];     // rgb_in
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -60,11 +78,13 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     // V (64-wide tile, stride BL_VS) ALIASES T: a wave finishes every MFMA read of a tile before its epilogue writes, and
     // the two layouts are never live together (T: until base_fc.0 has been read; again from rgb_fc.0's output on).
     float* V = T_[wave];
-    float* D = D_[wave];
+    // D (ray_dir_fc hidden layer, 16 columns) lives in T's columns 0..15, which are free until the mean / variance are written
     float* RD = RD_[wave];
     float* R = R_[wave];
     float* C = C_[wave];
     constexpr int F = 3 + 4 * NLEV;
+    constexpr int G_B1 = (3 * F + 7) / 8;      // reduction groups of base_fc.0
+    static_assert(8 * G_B1 <= BL_TS, "wide tile too narrow");
     const int S = nv - 1, PPW = 32 / S;
     const int64_t first = ((int64_t)blockIdx.x * BL_WAVES + wave) * PPW;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
@@ -105,81 +125,116 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
             if (live && vis_out) vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
             // compute_angle (projector.py:278-291)
             float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
-            float rn = sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f;
-            rx /= rn; ry /= rn; rz /= rn;
+            // normalisations with v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt / division sequences (3 + 9 of them)
+            float rn = hw_rcp(__builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f);
+            rx *= rn; ry *= rn; rz *= rn;
             const float* cs = c2w + 16 * sv;
             float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
-            float sn = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
-            sx /= sn; sy /= sn; sz /= sn;
+            float sn = hw_rcp(__builtin_amdgcn_sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
+            sx *= sn; sy *= sn; sz *= sn;
             float dx = rx - sx, dy = ry - sy, dz = rz - sz;
-            float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
-            float* rd = RD + row * 5;
-            rd[0] = live ? dx / dn : 0.0f;
-            rd[1] = live ? dy / dn : 0.0f;
-            rd[2] = live ? dz / dn : 0.0f;
+            float dn = hw_rcp(fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f));
+            float* rd = RD + row * BL_RS;
+            rd[0] = live ? dx * dn : 0.0f;
+            rd[1] = live ? dy * dn : 0.0f;
+            rd[2] = live ? dz * dn : 0.0f;
             rd[3] = live ? rx * sx + ry * sy + rz * sz : 0.0f;
-            rd[4] = 0.0f;
-            T[row * BL_TS + 3 * F] = 0.0f;            // K padding column of base_fc.0 when 3F is odd
+            rd[4] = rd[5] = rd[6] = rd[7] = 0.0f;                                       // K padding of ray_dir_fc.0 (4 -> 8)
+#pragma unroll
+            for (int k = 3 * F; k < 8 * G_B1; ++k) T[row * BL_TS + k] = 0.0f;          // K padding of base_fc.0 (3F -> whole groups)
         }
     }
     __syncthreads();
 
     // ---------------------------------------------------------------- ray_dir_fc (blending_network.py:36-39, 87)
     {
-        f32x16 a = tile_mfma(RD, 5, W.rd1, 2, W.rd1_b[col], lane);
+        BGroups<1> w;
+        load_b(w, W.rd1, lane);
+        f32x16 a = tile_mfma(RD, BL_RS, w, W.rd1_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (col < 16) D[crow(r, lane) * 17 + col] = elu1(a[r]);
+            if (col < 16) T[crow(r, lane) * BL_TS + col] = elu1(a[r]);
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(D, 17, W.rd2, 8, W.rd2_b[col], lane);
+        BGroups<2> w;
+        load_b(w, W.rd2, lane);
+        f32x16 a = tile_mfma(T, BL_TS, w, W.rd2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < F) T[crow(r, lane) * BL_TS + 2 * F + col] += elu1(a[r]);        // x = rgb_feat + direction_feat (:89)
-        if (half == 0) R[row * 8 + 1] = hw_exp(W.s_abs * (RD[row * 5 + 3] - 1.0f));     // exp(|s| (dot - 1))  (:93)
+        if (half == 0) R[row * 8 + 1] = hw_exp(W.s_abs * (RD[row * BL_RS + 3] - 1.0f));     // exp(|s| (dot - 1))  (:93)
     }
     __syncthreads();
 
     // ---------------------------------------------------------------- view weights, weighted mean / variance (:94-101)
-    if (half == 0) {
-        const int base = pl * S;
-        float mn = 3.4e38f;
-        if (pl < PPW) for (int v = 0; v < S; ++v) mn = fminf(mn, R[(base + v) * 8 + 1]);
-        R[row * 8 + 2] = (pl < PPW) ? (R[row * 8 + 1] - mn) * R[row * 8] : 0.0f;
-    }
-    __syncthreads();
-    if (half == 0) {
-        const int base = pl * S;
-        float sum = 0.0f;
-        if (pl < PPW) for (int v = 0; v < S; ++v) sum += R[(base + v) * 8 + 2];
-        R[row * 8 + 3] = R[row * 8 + 2] / (sum + 1e-8f);
-    }
-    __syncthreads();
-    for (int it = lane; it < PPW * F; it += 64) {
-        const int p = it / F, c = it % F, base = p * S;
-        float mean = 0.0f, var = 0.0f;
-        for (int v = 0; v < S; ++v) mean += T[(base + v) * BL_TS + 2 * F + c] * R[(base + v) * 8 + 3];
-        for (int v = 0; v < S; ++v) {
-            float d = T[(base + v) * BL_TS + 2 * F + c] - mean;
-            var += R[(base + v) * 8 + 3] * (d * d);
+    if (S == 4) {
+        // four source views = the four lanes of a DPP quad: min / sum over the views are two quad_perm butterflies in
+        // registers (all four lanes end with the same value), no LDS round trips and no barriers
+        const float e = R[row * 8 + 1], m = R[row * 8];
+        float mn = fminf(e, dpp_move<0xB1, 0xF>(e, e));                 // quad_perm:[1,0,3,2]
+        mn = fminf(mn, dpp_move<0x4E, 0xF>(mn, mn));                    // quad_perm:[2,3,0,1]
+        const float wr = (e - mn) * m;
+        float sum = wr + dpp_move<0xB1, 0xF>(wr, wr);
+        sum = sum + dpp_move<0x4E, 0xF>(sum, sum);
+        const float wn = wr / (sum + 1e-8f);
+        if (half == 0) R[row * 8 + 3] = wn;
+        // each lane owns its (point, view) row and every second feature column: mean / variance through the same butterflies
+        for (int c = half; c < F; c += 2) {
+            const float x = T[row * BL_TS + 2 * F + c];
+            float mean = wn * x;
+            mean += dpp_move<0xB1, 0xF>(mean, mean);
+            mean += dpp_move<0x4E, 0xF>(mean, mean);
+            const float d = x - mean;
+            float var = wn * (d * d);
+            var += dpp_move<0xB1, 0xF>(var, var);
+            var += dpp_move<0x4E, 0xF>(var, var);
+            T[row * BL_TS + c] = mean;
+            T[row * BL_TS + F + c] = var;
         }
-        for (int v = 0; v < S; ++v) {
-            T[(base + v) * BL_TS + c] = mean;
-            T[(base + v) * BL_TS + F + c] = var;
+        __syncthreads();
+    } else {
+        if (half == 0) {
+            const int base = pl * S;
+            float mn = 3.4e38f;
+            if (pl < PPW) for (int v = 0; v < S; ++v) mn = fminf(mn, R[(base + v) * 8 + 1]);
+            R[row * 8 + 2] = (pl < PPW) ? (R[row * 8 + 1] - mn) * R[row * 8] : 0.0f;
         }
+        __syncthreads();
+        if (half == 0) {
+            const int base = pl * S;
+            float sum = 0.0f;
+            if (pl < PPW) for (int v = 0; v < S; ++v) sum += R[(base + v) * 8 + 2];
+            R[row * 8 + 3] = R[row * 8 + 2] / (sum + 1e-8f);
+        }
+        __syncthreads();
+        for (int it = lane; it < PPW * F; it += 64) {
+            const int p = it / F, c = it % F, base = p * S;
+            float mean = 0.0f, var = 0.0f;
+            for (int v = 0; v < S; ++v) mean += T[(base + v) * BL_TS + 2 * F + c] * R[(base + v) * 8 + 3];
+            for (int v = 0; v < S; ++v) {
+                float d = T[(base + v) * BL_TS + 2 * F + c] - mean;
+                var += R[(base + v) * 8 + 3] * (d * d);
+            }
+            for (int v = 0; v < S; ++v) {
+                T[(base + v) * BL_TS + c] = mean;
+                T[(base + v) * BL_TS + F + c] = var;
+            }
+        }
+        for (int it = lane; it < (32 - PPW * S) * 2 * F; it += 64) {      // unused rows (32 % S != 0): keep them finite
+            const int rr = PPW * S + it / (2 * F);
+            T[rr * BL_TS + it % (2 * F)] = 0.0f;
+        }
+        __syncthreads();
     }
-    for (int it = lane; it < (32 - PPW * S) * 2 * F; it += 64) {      // unused rows (32 % S != 0): keep them finite
-        const int rr = PPW * S + it / (2 * F);
-        T[rr * BL_TS + it % (2 * F)] = 0.0f;
-    }
-    __syncthreads();
 
     // ---------------------------------------------------------------- base_fc (:103-104)
-    constexpr int kk_base = (3 * F + 1) / 2;
     {
-        f32x16 a0 = tile_mfma(T, BL_TS, W.b1, kk_base, W.b1_b[col], lane);
-        f32x16 a1 = tile_mfma(T, BL_TS, W.b1 + (size_t)kk_base * 64, kk_base, W.b1_b[32 + col], lane);
+        BGroups<G_B1> w0, w1;
+        load_b(w0, W.b1, lane);
+        load_b(w1, W.b1 + (size_t)G_B1 * 256, lane);
+        f32x16 a0 = tile_mfma(T, BL_TS, w0, W.b1_b[col], lane);
+        f32x16 a1 = tile_mfma(T, BL_TS, w1, W.b1_b[32 + col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             V[crow(r, lane) * BL_VS + col] = elu1(a0[r]);
@@ -187,7 +242,12 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         }
     }
     __syncthreads();
-    f32x16 h = tile_mfma(V, BL_VS, W.b2, 32, W.b2_b[col], lane);
+    f32x16 h;
+    {
+        BGroups<8> w;
+        load_b(w, W.b2, lane);
+        h = tile_mfma(V, BL_VS, w, W.b2_b[col], lane);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[r] = elu1(h[r]);
     __syncthreads();                                           // every lane has finished reading V
@@ -196,13 +256,17 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + col] = h[r] * R[crow(r, lane) * 8 + 3];
     __syncthreads();
     {
-        f32x16 a = tile_mfma(V, BL_VS, W.v1, 16, W.v1_b[col], lane);
+        BGroups<4> w;
+        load_b(w, W.v1, lane);
+        f32x16 a = tile_mfma(V, BL_VS, w, W.v1_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + 32 + col] = elu1(a[r]);
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(V + 32, BL_VS, W.v2, 16, W.v2_b[col], lane);
+        BGroups<4> w;
+        load_b(w, W.v2, lane);
+        f32x16 a = tile_mfma(V + 32, BL_VS, w, W.v2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[r] += elu1(a[r]);                          // x = x + x_res
         if (half == 0) {                                                         // 33rd output -> vis
@@ -220,7 +284,9 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(V, BL_VS, W.u1, 16, W.u1_b[col], lane);
+        BGroups<4> w;
+        load_b(w, W.u1, lane);
+        f32x16 a = tile_mfma(V, BL_VS, w, W.u1_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + 32 + col] = elu1(a[r]);
     }
@@ -237,19 +303,23 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     if (half == 0) {
         float* vr = V + row * BL_VS;
         vr[32] = R[row * 8 + 5];
-        vr[33] = RD[row * 5]; vr[34] = RD[row * 5 + 1]; vr[35] = RD[row * 5 + 2]; vr[36] = RD[row * 5 + 3];
-        vr[37] = 0.0f;
+        vr[33] = RD[row * BL_RS]; vr[34] = RD[row * BL_RS + 1]; vr[35] = RD[row * BL_RS + 2]; vr[36] = RD[row * BL_RS + 3];
+        vr[37] = vr[38] = vr[39] = 0.0f;                                             // K padding of rgb_fc.0 (37 -> 40)
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(V, BL_VS, W.r1, 19, W.r1_b[col], lane);
+        BGroups<5> w;
+        load_b(w, W.r1, lane);
+        f32x16 a = tile_mfma(V, BL_VS, w, W.r1_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < 16) T[crow(r, lane) * BL_TS + col] = elu1(a[r]);
     }
     __syncthreads();
     {
-        f32x16 a = tile_mfma(T, BL_TS, W.r2, 8, W.r2_b[col], lane);
+        BGroups<2> w;
+        load_b(w, W.r2, lane);
+        f32x16 a = tile_mfma(T, BL_TS, w, W.r2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < 8) T[crow(r, lane) * BL_TS + 32 + col] = elu1(a[r]);

@@ -747,7 +747,7 @@ class BlendPlan:
             u1, u2 = g(net.vis_fc2[0]), g(net.vis_fc2[2])
             r1, r2, r3 = g(net.rgb_fc[0]), g(net.rgb_fc[2]), g(net.rgb_fc[4])
             self.n_feat = rd2[0].shape[0]                  # 3 + d_feature
-            P = _pack_b_fragments
+            P = _pack_b_groups      # grouped B streams: one global_load_dwordx4 per 4 MFMAs (layout in k7_blend.hip)
             self.tensors = [P(rd1[0]), _pad32(rd1[1]), P(rd2[0]), _pad32(rd2[1]), P(b1[0]), _pad32(b1[1]), P(b2[0]), _pad32(b2[1]),
                             P(v1[0]), _pad32(v1[1]), P(v2[0][:32]), _pad32(v2[1][:32]), _c(v2[0][32].clone()),
                             P(u1[0]), _pad32(u1[1]), _c(u2[0][0].clone()),

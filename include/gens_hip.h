@@ -218,7 +218,8 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
  *   weights: HOST array of 21 device pointers in the order
  *     ray_dir_fc.0 W,b  ray_dir_fc.2 W,b  base_fc.0 W,b  base_fc.2 W,b  vis_fc.0 W,b  vis_fc.2 W[0:32],b[0:32]  vis_fc.2 W[32]
  *     vis_fc2.0 W,b  vis_fc2.2 W  rgb_fc.0 W,b  rgb_fc.2 W,b  rgb_fc.4 W
- *   (matrices in MFMA B-fragment order, biases zero-padded to a multiple of 32; gens_amd.ops.BlendPlan builds them);
+ *   (matrices as grouped MFMA B streams -- the layout documented at gens_sdf_mlp, K padded to a multiple of 8 --
+ *   biases zero-padded to a multiple of 32; gens_amd.ops.BlendPlan builds them);
  *   scalars: HOST float[4] = { vis_fc.2 bias[32], vis_fc2.2 bias, rgb_fc.4 bias, |s| }.
  *   index as in gens_sdf_mlp.  rgb_out (N_total, 3); vis_out (N_total, S) uint8 or NULL, written at index[i].
  * ---------------------------------------------------------------------------------------------------------- */
