@@ -82,9 +82,15 @@ __global__ __launch_bounds__(256) void lookup_fwd_k(LevelSet vs, const float* __
     const float* v = vs.data[l];
     Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
     float4 acc = f4_zero();
+    // branch-free zero padding: read from clamped indices (8 loads in flight), drop out-of-volume corners by a select
     FOR_CORNERS({
-        (void)sx; (void)sy; (void)sz;
-        if (ok) acc = f4_madd(acc, vox_load<LAYOUT>(v, nvox, lin), wx * wy * wz);
+        (void)sx; (void)sy; (void)sz; (void)lin;
+        const int qx = min(max(cx.i0 + a, 0), X - 1);
+        const int qy = min(max(cy.i0 + b, 0), Y - 1);
+        const int qz = min(max(cz.i0 + c, 0), Z - 1);
+        float4 val = vox_load<LAYOUT>(v, nvox, ((int64_t)qx * Y + qy) * Z + qz);
+        if (!ok) val = f4_zero();
+        acc = f4_madd(acc, val, wx * wy * wz);
     })
     out[gid] = acc;
 }

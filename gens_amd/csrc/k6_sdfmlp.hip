@@ -174,9 +174,12 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
-                bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
-                if (!ok) continue;
-                float4 t = v[((int64_t)(i0[0] + a) * Yd + (i0[1] + b)) * Zd + (i0[2] + d)];
+                // branch-free zero padding: the texel is read from clamped indices (8 loads in flight, one wait) and dropped
+                // by a select when the corner lies outside the volume
+                const bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+                const int cx = min(max(i0[0] + a, 0), Xd - 1), cy = min(max(i0[1] + b, 0), Yd - 1), cz = min(max(i0[2] + d, 0), Zd - 1);
+                float4 t = v[((int64_t)cx * Yd + cy) * Zd + cz];
+                if (!ok) t = f4_zero();
                 float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
                 acc = f4_madd(acc, t, wx * wy * wz);
                 if constexpr (GRAD) {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
         const float4* b_fe = W.wb[l] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane;
-        const float4* nxt = (l > 1) ? W.wb[l - 1] + (size_t)wave * 16 * 64 + lane : W.wb[0] + lane;   // (only wave 0 uses wb[0])
+        const float4* nxt = (l > 1) ? W.wb[l - 1] + (size_t)wave * 16 * 64 + lane : W.wb[0] + (size_t)(4 * wave) * 64 + lane;
         gh = mfma_groups<16, MLP_PF>(X + a_lane * RS + a_half, W.wb[l] + (size_t)wave * 16 * 64 + lane, gh, pre, b_fe);
         gfe = mfma_groups<FE_G, MLP_PF>(X + a_lane * RS + a_half + 8 * fe_g0, b_fe, gfe, pre, nxt);
         __syncthreads();
@@ -306,18 +309,22 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
         }
         __syncthreads();
     }
-    // layer 0: d/d(point encoding) = G_0 (32x128) * W_0 (128 x 27): one n-tile, wave 0
-    if (wave == 0) {
+    // layer 0: d/d(point encoding) = G_0 (32x128) * W_0 (128 x 27): one n-tile; the four waves split the reduction (4 groups
+    // each) and the partial tiles are summed in a fixed order through the (now dead) h part of X -- deterministic
+    {
         f32x16 gp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gp[r] = 0.0f;
-        gp = mfma_groups<16, MLP_PF, false>(X + a_lane * RS + a_half, W.wb[0] + lane, gp, pre, nullptr);
-        const int c = lane & 31;
-        if (c < MLP_PE) {
+        gp = mfma_groups<4, MLP_PF, false>(X + a_lane * RS + a_half + 32 * wave, W.wb[0] + (size_t)(4 * wave) * 64 + lane, gp, pre, nullptr);
+        __syncthreads();                                   // every wave has read G_0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, lane);
-                GPE[row * MLP_PE_STRIDE + c] += gp[r];   // columns written by the l == 3 step are the same 27
+        for (int r = 0; r < 16; ++r) X[acc_row(r, lane) * RS + col] = gp[r];
+        __syncthreads();
+        for (int i = tid; i < MLP_M * 32; i += 256) {
+            const int row = i >> 5, c = i & 31;
+            if (c < MLP_PE) {
+                const float* xr = X + row * RS + c;
+                GPE[row * MLP_PE_STRIDE + c] += ((xr[0] + xr[32]) + xr[64]) + xr[96];   // columns written by the l == 3 step are the same 27
             }
         }
     }

@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256, GRAD ? HM_MINW_G : HM_MINW_F) void sdf_mlp_h_k
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
-                bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
-                if (!ok) continue;
-                float4 t = v[((int64_t)(i0[0] + a) * Yd + (i0[1] + b)) * Zd + (i0[2] + d)];
+                // branch-free zero padding: the texel is read from clamped indices (8 loads in flight, one wait) and dropped
+                // by a select when the corner lies outside the volume
+                const bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+                const int cx = min(max(i0[0] + a, 0), Xd - 1), cy = min(max(i0[1] + b, 0), Yd - 1), cz = min(max(i0[2] + d, 0), Zd - 1);
+                float4 t = v[((int64_t)cx * Yd + cy) * Zd + cz];
+                if (!ok) t = f4_zero();
                 float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
                 acc = f4_madd(acc, t, wx * wy * wz);
                 if constexpr (GRAD) {
