@@ -168,12 +168,12 @@ def main():
                 table[name]["TFLOPs"] = round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1)
         dom_name, dom = max(((n, k) for n, k in kernels.items() if k["bytes"]), key=lambda kv: kv[1]["ms"] / timed_steps[kv[0]])
         assert dom_name == DOMINANT, f"dominant kernel is {dom_name}, not {DOMINANT}: update bench.DOMINANT"
-        traffic = None      # HBM bytes per launch from the committed PMC passes (same command, ray chunk 32768); see the file's note
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        traffic = None      # HBM bytes per launch from the committed PMC passes (same command, ray chunk 32768): scripts/pmc_traffic.py
+        tpath = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
         if os.path.exists(tpath) and args.chunk == 32768:
             t = json.load(open(tpath))["kernels"].get(dom_name)
             if t:
-                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                traffic = t["traffic_bytes_per_launch_corrected"]      # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)
         common = {"kernel": dom_name, "traffic": traffic, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                   "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
         if dom.get("flops"):      # the fused MLP is matrix-core bound: price it against the dense MFMA peak of the operand type

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950):
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE -d <out>/fetch --output-format csv -- python3 <repo>/bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing
+    rocprofv3 --pmc WRITE_SIZE -d <out>/write --output-format csv -- python3 <repo>/bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing
+    python scripts/pmc_traffic.py <out>/fetch <out>/write profiles/rNN_pmc_traffic.json
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KB (x 1024); on gfx950
+FETCH_SIZE reports half the bytes of wide coalesced reads, so the corrected figure is 2 x FETCH_SIZE + WRITE_SIZE (an upper
+estimate for gather-dominated kernels, whose 16-B accesses the guide calls uncalibrated).  Infinity-Cache hits are counted."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_mlp_h_k": "gens_sdf_mlp_f16", "blend_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
+         "upsample_k": "gens_upsample", "merge_k": "gens_merge_samples", "volume_build_fwd_k": "gens_volume_build_fwd",
+         "ray_points_k": "gens_ray_points", "compact_count_k": "gens_compact_valid", "compact_write_k": "gens_compact_valid",
+         "compact_scan_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit"}
+
+
+def collect(root, counter):
+    tot, disp = defaultdict(float), defaultdict(set)
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"].replace("void ", "").split("<")[0].split("(")[0].strip()
+            if name in ENTRY:
+                tot[name] += float(r["Counter_Value"]) * 1024.0
+                disp[name].add(r["Dispatch_Id"])
+    return tot, disp
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    ft, fd = collect(fetch_dir, "FETCH_SIZE")
+    wt, wd = collect(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(ft) | set(wt)):
+        e = ENTRY[k]
+        d = kernels.setdefault(e, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches_f": 0, "launches_w": 0, "device_kernels": []})
+        d["fetch_bytes"] += ft.get(k, 0.0)
+        d["write_bytes"] += wt.get(k, 0.0)
+        d["device_kernels"].append(k)
+        if not k.startswith("compact_") or k == "compact_scan_k":      # one entry-point launch = 3 device kernels for the compaction
+            d["launches_f"] += len(fd.get(k, ()))
+            d["launches_w"] += len(wd.get(k, ()))
+    res = {}
+    for e, d in kernels.items():
+        nf, nw = max(1, d["launches_f"]), max(1, d["launches_w"])
+        f, w = d["fetch_bytes"] / nf, d["write_bytes"] / nw
+        res[e] = {"fetch_bytes_per_launch_raw": int(f), "write_bytes_per_launch_raw": int(w),
+                  "traffic_bytes_per_launch_corrected": int(2 * f + w), "launches": nf, "device_kernels": d["device_kernels"]}
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing`, "
+            "ray chunk 32768; KB x 1024; launch-weighted mean over the kernel's template instances; corrected = 2 x FETCH + WRITE "
+            "(MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reports half of wide coalesced reads; 16-B gathers uncalibrated, so the "
+            "corrected figure is an upper estimate there); Infinity-Cache hits are counted")
+    json.dump({"_note": note, "kernels": res}, open(out, "w"), indent=1)
+    for e, r in res.items():
+        print(f"{e:24s} fetch {r['fetch_bytes_per_launch_raw'] / 1e6:9.2f} MB  write {r['write_bytes_per_launch_raw'] / 1e6:9.2f} MB  corrected {r['traffic_bytes_per_launch_corrected'] / 1e6:9.2f} MB  x{r['launches']}")
+
+
+if __name__ == "__main__":
+    main()
