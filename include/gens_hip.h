@@ -243,6 +243,18 @@ int gens_upsample2d_into(const float* src, int n, int c, int hs, int ws, float* 
                          int c_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K13  compute_LNCC, the photometric patch statistic of the loss     (models/losses/ncc.py:7-55, loss.py:36)
+ *   ref (1, B, P, C), src (S, B, P, C) contiguous float32 (render_core's ref_gray_val / sampled_gray_val; P = 121, C = 12);
+ *   S * C <= 64.  ncc (B): mean over channels of clamp(1 - cc, 0, 2), mean of the two smallest source views;
+ *   sel (B, 2) int32: the two selected source indices (consumed by the backward).
+ *   bwd: g_ncc (B) -> g_ref like ref, g_src like src, both overwritten.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_lncc_fwd(const float* ref, const float* src, int64_t n_rays, int n_src, int n_patch, int n_ch, float* ncc, int32_t* sel,
+                  void* stream);
+int gens_lncc_bwd(const float* ref, const float* src, const float* g_ncc, const int32_t* sel, int64_t n_rays, int n_src, int n_patch,
+                  int n_ch, float* g_ref, float* g_src, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K12  iso-surface extraction of the SDF lattice: replaces mcubes.marching_cubes(u, threshold)
  *      (implicit_surface.py:423; PyMCubes==0.1.4, requirements.txt:11 -- third-party, classic marching cubes)
  *   u (X, Y, Z) float32, z fastest (the lattice of implicit_surface.py:407-421); iso = threshold.

@@ -457,3 +457,26 @@ def lattice_points(bound_min, bound_max, resolution):
     zs = torch.linspace(float(bound_min[2]), float(bound_max[2]), resolution)
     xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
     return torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+
+
+# ----------------------------------------------------------------------------------------------
+# K13  compute_LNCC  (/root/reference/models/losses/ncc.py:7-55)
+# ----------------------------------------------------------------------------------------------
+def lncc(ref_gray, src_grays):
+    """ref_gray (1,B,P,C), src_grays (S,B,P,C) -> (B,1).  The five grouped all-ones convolutions read at the centre tap
+    (ncc.py:29-33) are sums over the P = 11x11 patch samples; the rest follows ncc.py:35-53 operation by operation.
+    Differentiable (plain torch ops), so the gradients of the golden can be checked through autograd."""
+    p = ref_gray.shape[2]
+    r = ref_gray.permute(1, 0, 3, 2)            # (B,1,C,P)
+    s = src_grays.permute(1, 0, 3, 2)           # (B,S,C,P)
+    ref_sum, src_sum = r.sum(-1), s.sum(-1)
+    ref_sq_sum, src_sq_sum = (r * r).sum(-1), (s * s).sum(-1)
+    ref_src_sum = (r * s).sum(-1)
+    u_ref, u_src = ref_sum / p, src_sum / p
+    cross = ref_src_sum - u_src * ref_sum - u_ref * src_sum + u_ref * u_src * p
+    ref_var = ref_sq_sum - 2 * u_ref * ref_sum + u_ref * u_ref * p
+    src_var = src_sq_sum - 2 * u_src * src_sum + u_src * u_src * p
+    cc = cross * cross / (ref_var * src_var + 1e-5)
+    ncc = torch.clamp(1 - cc, 0.0, 2.0).mean(dim=2)                          # (B,S)
+    ncc, _ = torch.topk(ncc, 2, dim=1, largest=False)
+    return ncc.mean(dim=1, keepdim=True)

@@ -165,6 +165,18 @@ def main():
         per = measure(lambda: ops.lattice_points([-1, -1, -1], [1, 1, 1], 512, 0, cnt, dev), args.iters)
         add(f"K11 lattice points N={cnt}", "gens_lattice_points", per, cnt * 12)
 
+    # ---- K13 LNCC patch statistic, one training step's worth (512 rays, 4 source views, 121 samples, 12 channels)
+    from gens_amd.losses import compute_LNCC
+    rg = torch.rand(1, 512, 121, 12, device=dev, requires_grad=True)
+    sg = torch.rand(4, 512, 121, 12, device=dev, requires_grad=True)
+
+    def lncc_step():
+        compute_LNCC(rg, sg).sum().backward()
+        rg.grad = sg.grad = None
+    per = measure(lncc_step, args.iters)
+    add("K13 lncc fwd B=512 S=4", "gens_lncc_fwd", per, 512 * 121 * 12 * 5 * 4)
+    add("K13 lncc bwd B=512 S=4", "gens_lncc_bwd", per, 2 * 512 * 121 * 12 * 5 * 4)
+
     with torch.no_grad():
         # ---- K12 marching cubes on a 512^3 lattice (the reference's mesh resolution): sphere field, ~0.8 M vertices
         n = 512

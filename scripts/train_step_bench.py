@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gens_amd import ops, synthetic  # noqa: E402
 from gens_amd.config import gens_model_conf  # noqa: E402
+from gens_amd.losses import compute_LNCC  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E402
 
 
@@ -36,10 +37,11 @@ def main():
             _, masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
         cost, _ = ops.volume_build(feats[:3], intrs, c2ws, dims)            # K1 with autograd to the features
         out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
-        hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+        ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]                     # loss.py:36-38
         loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
             + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
-            + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean() + out["pseudo_sdf"].abs().mean() \
+            + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
+            + out["pseudo_sdf"].abs().mean() \
             + 1e-6 * sum(c.mean() for c in cost)
         opt.zero_grad(set_to_none=True)
         loss.backward()

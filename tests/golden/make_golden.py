@@ -372,8 +372,29 @@ def g10_geometry(surf, vols):
     npz("g10_geometry", u=grabbed["u"].astype(np.float32), resolution=np.int64(65))
 
 
+def g11_lncc():
+    """compute_LNCC (models/losses/ncc.py:7-55): forward + gradients w.r.t. both patch tensors for a fixed cotangent."""
+    from models.losses.ncc import compute_LNCC
+    g = torch.Generator().manual_seed(110)
+    b, s = 24, 4
+    base = torch.rand(1, b, 121, 12, generator=g)
+    src = (base * (0.6 + 0.8 * torch.rand(s, b, 1, 12, generator=g)) + 0.25 * torch.rand(s, b, 121, 12, generator=g))
+    src[1, :6] = torch.rand(6, 121, 12, generator=g)            # uncorrelated patches: ncc near 1
+    src[2, 3] = base[0, 3] * 2.0 + 0.1                           # perfectly correlated: cc = 1
+    src[:, 5] = 0.37                                             # constant patches: zero variance -> the 1e-5 guard
+    ref = base.clone().requires_grad_(True)
+    src = src.clone().requires_grad_(True)
+    ncc = compute_LNCC(ref, src)
+    cot = torch.rand(ncc.shape, generator=g)
+    g_ref, g_src = torch.autograd.grad((ncc * cot).sum(), [ref, src])
+    npz("g11_lncc", ref=ref, src=src, ncc=ncc, cot=cot, g_ref=g_ref, g_src=g_src)
+
+
 def main():
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
+        g11_lncc()
+        return
     from models.modules.volume import Volume
     from models.modules import projector
     from models.modules import implicit_surface as isurf_mod
@@ -388,6 +409,7 @@ def main():
     g9_render(isurf_mod, Volume, "g9a_render", seed=90, cos_anneal=0.5, step=None, n_rays=24)
     surf, sc, vols, masks = g9_render(isurf_mod, Volume, "g9b_render", seed=95, cos_anneal=1.0, step=7, n_rays=16, variance=0.55)
     g10_geometry(surf, vols)
+    g11_lncc()
     leaked = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

@@ -179,3 +179,31 @@ def test_gens_forward_val_returns_mesh_and_images():
     assert v.ndim == 2 and v.shape[1] == 3 and t.ndim == 2 and t.shape[1] == 3 and v.dtype.kind == "f"
     if len(t):
         assert t.min() >= 0 and t.max() < len(v) and np.abs(v).max() <= 1.0 + 1e-6
+
+
+def test_lncc_on_render_outputs_backpropagates_like_the_oracle():
+    """loss.py:36-38 on the patch tensors render_core returns: K13 forward value and the gradient reaching the patch tensors."""
+    from gens_amd.losses import compute_LNCC
+    from oracle import gens_oracle as K
+    model = _gens().train()
+    ipts = _inputs(n_rays=32)
+    out = model("train", ipts, 1.0, None)
+    ref, src = out["ref_gray_val"], out["sampled_gray_val"]
+    assert ref.shape[0] == 1 and ref.shape[2:] == (121, 12) and src.shape[1:] == ref.shape[1:]
+    ncc = compute_LNCC(ref, src)
+    mask = out["valid_mask"] * out["mid_inside_sphere"]
+    loss = 0.5 * ((ncc * mask).sum(0) / (mask.sum(0) + 1e-8)).squeeze(-1)
+    wrt = [t for t in (ref, src) if t.requires_grad]
+    assert src.requires_grad                                   # the patch samples depend on the SDF network through the surface point
+    got = dict(zip([id(t) for t in wrt], torch.autograd.grad(loss, wrt, retain_graph=True)))
+    r_o, s_o = ref.detach().cpu().requires_grad_(True), src.detach().cpu().requires_grad_(True)
+    want = K.lncc(r_o, s_o)
+    assert torch.allclose(ncc.detach().cpu(), want.detach(), atol=1e-5)
+    loss_o = 0.5 * ((want * mask.detach().cpu()).sum(0) / (mask.detach().cpu().sum(0) + 1e-8)).squeeze(-1)
+    w_ref, w_src = torch.autograd.grad(loss_o, [r_o, s_o])
+    scale = float(w_src.abs().max()) + 1e-12
+    assert float((got[id(src)].cpu() - w_src).abs().max()) <= 1e-3 * scale + 1e-9
+    if ref.requires_grad:
+        assert float((got[id(ref)].cpu() - w_ref).abs().max()) <= 1e-3 * scale + 1e-9
+    loss.backward()                                            # reaches the colour-independent path: features / intrinsics side is detached, MLPs get grads
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
