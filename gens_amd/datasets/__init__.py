@@ -1,0 +1,25 @@
+"""Dataset front-end: DTU item dictionaries without OpenCV.  `get_loader` mirrors
+/root/reference/datasets/__init__.py:16-38 for the DTU dataset; the BlendedMVS and fine-tune variants are not rebuilt."""
+import torch.distributed as dist
+from torch.utils.data import DataLoader, DistributedSampler, RandomSampler, SequentialSampler
+
+from .dtu import DTUDataset  # noqa: F401
+
+
+def collect_fn(data):
+    return data[0]
+
+
+def get_loader(conf, mode, distributed):
+    name = conf.get_string("dataset_name")
+    if name != "DTUDataset":
+        raise NotImplementedError(f"gens_amd.datasets rebuilds DTUDataset only (got {name}); use the reference's datasets/ for the others")
+    dataset = DTUDataset(conf, mode)
+    if mode == "finetune":
+        return dataset
+    if distributed:
+        sampler = DistributedSampler(dataset, num_replicas=dist.get_world_size(), rank=dist.get_rank())
+    else:
+        sampler = RandomSampler(dataset) if mode == "train" else SequentialSampler(dataset)
+    loader = DataLoader(dataset, 1, sampler=sampler, num_workers=8, drop_last=(mode == "train"), pin_memory=False, collate_fn=collect_fn)
+    return loader, sampler, dataset

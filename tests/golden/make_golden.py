@@ -390,8 +390,70 @@ def g11_lncc():
     npz("g11_lncc", ref=ref, src=src, ncc=ncc, cot=cot, g_ref=g_ref, g_src=g_src)
 
 
+def g12_dtu_dataset():
+    """The reference's DTUDataset (datasets/dtu.py) on the synthetic tree of tests/dtu_fixture.py, one val and one train item.
+    cv2 is absent here: a stub provides the two calls the dataset makes -- INTER_NEAREST resize (OpenCV's documented index
+    rule) and decomposeProjectionMatrix (scipy.linalg.rq + the null vector of P by SVD; the product code uses a different
+    route, numpy QR + a linear solve)."""
+    import random
+    import tempfile
+    import scipy.linalg
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dtu_fixture
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST = 0
+
+    def resize(img, dsize, fx=None, fy=None, interpolation=0):
+        w, h = dsize
+        sh, sw = img.shape[:2]
+        ys = np.minimum(np.floor(np.arange(h) * (float(sh) / h)).astype(int), sh - 1)
+        xs = np.minimum(np.floor(np.arange(w) * (float(sw) / w)).astype(int), sw - 1)
+        return img[ys[:, None], xs[None, :]]
+
+    def decomposeProjectionMatrix(P):
+        Pd = np.asarray(P, dtype=np.float64)
+        K, R = scipy.linalg.rq(Pd[:, :3])
+        D = np.diag(np.sign(np.diag(K)))
+        K, R = K @ D, D @ R
+        c = np.linalg.svd(Pd)[2][-1]
+        return K.astype(P.dtype), R.astype(P.dtype), c.reshape(4, 1).astype(P.dtype), None, None, None, None
+
+    cv2.resize, cv2.decomposeProjectionMatrix = resize, decomposeProjectionMatrix
+    sys.modules["cv2"] = cv2
+    from datasets.dtu import DTUDataset
+
+    class Conf(dict):
+        def get_int(self, k, default=None): return int(self.get(k, default))
+        def get_float(self, k, default=None): return float(self.get(k, default))
+        def get_string(self, k, default=None): return self.get(k, default)
+        def get_list(self, k, default=None): return self.get(k, default)
+
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        dtu_fixture.make_dtu_tree(root)
+        for mode, idx in (("val", 1), ("train", 0)):
+            ds = DTUDataset(Conf(dtu_fixture.conf_values(root, mode)), mode)
+            random.seed(5)
+            np.random.seed(6)
+            torch.manual_seed(7)
+            item = ds[idx]
+            out[f"{mode}_len"] = len(ds)
+            for k, v in item.items():
+                if isinstance(v, torch.Tensor):
+                    out[f"{mode}.{k}"] = v.numpy()
+                elif isinstance(v, (int, np.integer)):
+                    out[f"{mode}.{k}"] = np.int64(v)
+                elif isinstance(v, str):
+                    out[f"{mode}.{k}"] = np.array(v)
+    npz("g12_dtu_dataset", **out)
+
+
 def main():
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+        g12_dtu_dataset()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
         g11_lncc()
         return
@@ -410,6 +472,7 @@ def main():
     surf, sc, vols, masks = g9_render(isurf_mod, Volume, "g9b_render", seed=95, cos_anneal=1.0, step=7, n_rays=16, variance=0.55)
     g10_geometry(surf, vols)
     g11_lncc()
+    g12_dtu_dataset()
     leaked = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

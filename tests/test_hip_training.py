@@ -207,3 +207,29 @@ def test_lncc_on_render_outputs_backpropagates_like_the_oracle():
         assert float((got[id(ref)].cpu() - w_ref).abs().max()) <= 1e-3 * scale + 1e-9
     loss.backward()                                            # reaches the colour-independent path: features / intrinsics side is detached, MLPs get grads
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_dataset_item_drives_train_and_val_end_to_end(tmp_path):
+    """Caller side of the path: a DTUDataset item goes through GenS.forward unchanged, as in runner.py:150-160."""
+    from gens_amd.config import Conf
+    from gens_amd.datasets import DTUDataset
+    from tests import dtu_fixture
+    root = dtu_fixture.make_dtu_tree(str(tmp_path / "dtu"))
+    model = _gens().train()
+    to_dev = lambda item: {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in item.items()}  # noqa: E731
+    conf = dtu_fixture.conf_values(root, "train")
+    conf["img_hw"] = [64, 80]                                  # five pyramid levels need sizes divisible by 16
+    torch.manual_seed(1)
+    item = to_dev(DTUDataset(Conf(conf), "train")[0])
+    out = model("train", item, 0.5, 10.0)
+    assert out["color_fine"].shape == (64, 3) and out["pseudo_sdf"].shape == (2048, 1)
+    loss = _loss(out) + out["pseudo_sdf"].abs().mean()
+    loss.backward()
+    assert torch.isfinite(loss)
+    conf = dtu_fixture.conf_values(root, "val")
+    conf["img_hw"] = [64, 80]
+    conf["val_res_level"] = 4
+    item = to_dev(DTUDataset(Conf(conf), "val")[0])
+    with torch.no_grad():
+        val = model.eval()("val", item, 1.0, None)
+    assert val["img_fine"].shape == (16, 20, 3) and val["render_depth"].shape == (16, 20) and val["vertices"].shape[1] == 3
