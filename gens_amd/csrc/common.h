@@ -180,11 +180,14 @@ __device__ __forceinline__ Taps2 bilinear_taps(float ix, float iy, int h, int w)
 }
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// acc + v * s with fused multiply-adds (the file is compiled with -ffp-contract=off so that index / mask DECISIONS keep
+// their reference rounding; interpolated VALUES may use the FMA the reference's own CUDA kernels are compiled to: half the
+// instructions of the gather kernels' inner loops, and one rounding less)
 __device__ __forceinline__ float4 f4_madd(float4 acc, float4 v, float s) {
-    acc.x += v.x * s;
-    acc.y += v.y * s;
-    acc.z += v.z * s;
-    acc.w += v.w * s;
+    acc.x = __builtin_fmaf(v.x, s, acc.x);
+    acc.y = __builtin_fmaf(v.y, s, acc.y);
+    acc.z = __builtin_fmaf(v.z, s, acc.z);
+    acc.w = __builtin_fmaf(v.w, s, acc.w);
     return acc;
 }
 

@@ -141,7 +141,11 @@ def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
     intr = _dev_f32(intrs, dev)
     vols, masks = [], []
     for lvl, d in enumerate(dims):
-        v, m = _VolumeBuild.apply(pack_nchw(features[lvl].to(_f32)), w2c, intr, 0.5 ** lvl, int(d), int(min_vis_view))
+        # rows 0-1 of the intrinsics times 0.5^lvl (Q2), multiplied here once in float32 -- the same product the kernel would
+        # form per voxel and view -- and handed over with scale 1 (the kernel's pre-scaled fast path)
+        k = intr.clone()
+        k[:, :2] = k[:, :2] * torch.tensor(0.5 ** lvl, device=dev, dtype=_f32)
+        v, m = _VolumeBuild.apply(pack_nchw(features[lvl].to(_f32)), w2c, k, 1.0, int(d), int(min_vis_view))
         vols.append(v)
         masks.append(m)
     return vols, masks

@@ -71,7 +71,9 @@ def main():
         for lvl, d in enumerate(dims):
             tex = ops.pack_nchw(feats[lvl])
             nv, h, w, _ = tex.shape
-            per = measure(lambda: ops._VolumeBuild.apply(tex, w2c, intrs, 0.5 ** lvl, d, 1), max(20, args.iters // 4))
+            k = intrs.clone()
+            k[:, :2] = k[:, :2] * 0.5 ** lvl                     # pre-scaled intrinsics, as ops.volume_build passes them
+            per = measure(lambda: ops._VolumeBuild.apply(tex, w2c, k, 1.0, d, 1), max(20, args.iters // 4))
             add(f"K1 volume build D={d} ({nv} views {h}x{w})", "gens_volume_build_fwd", per, nv * h * w * 16 + 36 * d ** 3)
         _, masks = ops.volume_build(feats[:3], intrs, c2ws, dims)
         mset = ops.VolumeSet.masks(masks)
