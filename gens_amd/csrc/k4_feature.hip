@@ -36,7 +36,7 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
         bool inside = true;
         for (int l = 0; l < fs.n; ++l) {
             int h = fs.h[l], w = fs.w[l];
-            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
             inside = inside && p.inside;
             Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
             float4 f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __
     const float* g = g_out + gid * row;
     for (int l = 0; l < fs.n; ++l) {
         int h = fs.h[l], w = fs.w[l];
-        SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+        SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
         Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
         int64_t off = (((int64_t)sv * h + t.y0) * w + t.x0) * 4;
         if (fs.grad[l]) {
@@ -117,6 +117,8 @@ int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const
         ms->data[l] = nullptr;
         ms->grad[l] = nullptr;
         ms->h[l] = ms->w[l] = 2;
+        ms->cw[l] = ms->ch[l] = 0.5f;
+        ms->rcw[l] = ms->rch[l] = 2.0f;
     }
     for (int l = 0; l < n_levels; ++l) {
         GENS_CHECK_ARG(hw[2 * l] > 1 && hw[2 * l + 1] > 1, GENS_EINVAL, "%s: level %d map smaller than 2x2", who, l);
@@ -126,6 +128,10 @@ int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const
         }
         ms->h[l] = hw[2 * l];
         ms->w[l] = hw[2 * l + 1];
+        ms->cw[l] = (float)(ms->w[l] - 1) / 2.0f;
+        ms->ch[l] = (float)(ms->h[l] - 1) / 2.0f;
+        ms->rcw[l] = 1.0f / ms->cw[l];
+        ms->rch[l] = 1.0f / ms->ch[l];
     }
     return 0;
 }

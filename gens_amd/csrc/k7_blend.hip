@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         float* xr = T + row * BL_TS + 2 * F;
         for (int l = l_begin; l < l_end; ++l) {
             const int h = fs.h[l], w = fs.w[l];
-            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, x, y, z);
+            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
             inside = inside && p.inside;
             float4 f = f4_zero(), c = f4_zero();
             if (live) {
