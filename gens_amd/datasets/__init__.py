@@ -1,9 +1,10 @@
 """Dataset front-end: DTU item dictionaries without OpenCV.  `get_loader` mirrors
-/root/reference/datasets/__init__.py:16-38 for the DTU dataset; the BlendedMVS and fine-tune variants are not rebuilt."""
+/root/reference/datasets/__init__.py:16-38 for the two DTU datasets (generalisation and per-scene fine-tune); the BlendedMVS variants are not rebuilt."""
 import torch.distributed as dist
 from torch.utils.data import DataLoader, DistributedSampler, RandomSampler, SequentialSampler
 
 from .dtu import DTUDataset  # noqa: F401
+from .dtu_finetune import DTUDatasetFinetune  # noqa: F401
 
 
 def collect_fn(data):
@@ -12,9 +13,12 @@ def collect_fn(data):
 
 def get_loader(conf, mode, distributed):
     name = conf.get_string("dataset_name")
-    if name != "DTUDataset":
-        raise NotImplementedError(f"gens_amd.datasets rebuilds DTUDataset only (got {name}); use the reference's datasets/ for the others")
-    dataset = DTUDataset(conf, mode)
+    if name == "DTUDataset":
+        dataset = DTUDataset(conf, mode)
+    elif name == "DTUDatasetFinetune":
+        dataset = DTUDatasetFinetune(conf, mode)
+    else:
+        raise NotImplementedError(f"gens_amd.datasets rebuilds the DTU datasets only (got {name}); use the reference's datasets/ for BlendedMVS")
     if mode == "finetune":
         return dataset
     if distributed:

@@ -82,3 +82,9 @@ def conf_values(root, mode):
     else:
         c["val_res_level"] = 2
     return c
+
+
+def finetune_conf_values(root):
+    """The finetune_dataset section of confs/gens_finetune.conf for this tree."""
+    return {"dataset_name": "DTUDatasetFinetune", "data_dir": root, "interval_scale": 1.06, "num_interval": 192, "img_hw": [60, 80], "n_rays": 48,
+            "factor": 0.8, "num_views": 3, "scene": SCAN, "ref_view": 24, "val_res_level": 2}

@@ -446,6 +446,20 @@ def g12_dtu_dataset():
                     out[f"{mode}.{k}"] = np.int64(v)
                 elif isinstance(v, str):
                     out[f"{mode}.{k}"] = np.array(v)
+        from datasets.dtu_finetune import DTUDatasetFinetune
+        torch.manual_seed(11)
+        ft = DTUDatasetFinetune(Conf(dtu_fixture.finetune_conf_values(root)), "finetune")
+        items = {"all": ft.get_all_images(), "rand": ft.get_random_rays(torch.tensor(1)), "at": ft.get_rays_at(2)}
+        out["ft.pseudo_ptses"] = ft.pseudo_ptses.numpy()
+        out["ft.scale_mat"] = ft.scale_mat.numpy()
+        for name, item in items.items():
+            for k, v in item.items():
+                if isinstance(v, torch.Tensor):
+                    out[f"ft.{name}.{k}"] = v.numpy()
+                elif isinstance(v, list):
+                    out[f"ft.{name}.{k}"] = np.array(v, dtype=np.int64)
+                elif isinstance(v, str):
+                    out[f"ft.{name}.{k}"] = np.array(v)
     npz("g12_dtu_dataset", **out)
 
 

@@ -98,3 +98,30 @@ def test_get_loader_runs_a_val_pass(tree):
     assert len(items) == 2 and items[0]["rays_o"].shape == (30 * 40, 3) and tuple(items[0]["hw"].tolist()) == (30, 40)
     with pytest.raises(NotImplementedError):
         get_loader(Conf({"dataset_name": "BMVSDataset"}), "val", False)
+
+
+def test_finetune_dataset_matches_the_reference(tree, golden):
+    """DTUDatasetFinetune: resident views, get_all_images / get_random_rays / get_rays_at (runner.py:91,296,346)."""
+    from gens_amd.datasets import DTUDatasetFinetune
+    torch.manual_seed(11)
+    ft = DTUDatasetFinetune(Conf(dtu_fixture.finetune_conf_values(tree)), "finetune")
+    items = {"all": ft.get_all_images(), "rand": ft.get_random_rays(torch.tensor(1)), "at": ft.get_rays_at(2)}
+
+    def same(got, want, what):
+        if isinstance(got, str):
+            assert got == str(want), what
+        elif isinstance(got, list):
+            assert got == [int(x) for x in want], what
+        else:
+            got = got.numpy()
+            assert got.shape == want.shape, (what, got.shape, want.shape)
+            scale = max(1.0, float(np.abs(want).max()))
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-5 * scale, what
+
+    same(ft.pseudo_ptses, golden["ft.pseudo_ptses"], "pseudo_ptses")
+    same(ft.scale_mat, golden["ft.scale_mat"], "scale_mat")
+    for name, item in items.items():
+        want_keys = {k.split(".", 2)[2] for k in golden.files if k.startswith(f"ft.{name}.")}
+        assert set(item) == want_keys, (name, set(item) ^ want_keys)
+        for k in want_keys:
+            same(item[k], golden[f"ft.{name}.{k}"], f"{name}.{k}")

@@ -233,3 +233,27 @@ def test_dataset_item_drives_train_and_val_end_to_end(tmp_path):
     with torch.no_grad():
         val = model.eval()("val", item, 1.0, None)
     assert val["img_fine"].shape == (16, 20, 3) and val["render_depth"].shape == (16, 20) and val["vertices"].shape[1] == 3
+
+
+def test_finetune_dataset_drives_the_per_scene_path(tmp_path):
+    """BASELINE config 5 plumbing as runner.py does it (:88-96, :294-300, :346): init_volumes from get_all_images, a fine-tune step on
+    get_random_rays, validation rays from get_rays_at."""
+    from gens_amd.config import Conf
+    from gens_amd.datasets import DTUDatasetFinetune
+    from tests import dtu_fixture
+    root = dtu_fixture.make_dtu_tree(str(tmp_path / "dtu"))
+    conf = dtu_fixture.finetune_conf_values(root)
+    conf["img_hw"] = [64, 80]
+    ds = DTUDatasetFinetune(Conf(conf), "finetune")
+    model = _gens()
+    dev = lambda item: {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in item.items()}  # noqa: E731
+    model.init_volumes(dev(ds.get_all_images()))
+    assert model.has_vol and len(model.volumes) == 3
+    out = model("finetune", dev(ds.get_random_rays(torch.tensor(1))), 1.0, None)
+    loss = _loss(out) + out["pseudo_sdf"].abs().mean()
+    loss.backward()
+    assert torch.isfinite(loss) and all(v.grad is not None for v in model.volumes)
+    item = dev(ds.get_rays_at(0))
+    with torch.no_grad():
+        val = model.eval()("val", item, 1.0, None)
+    assert val["img_fine"].shape == (32, 40, 3)
