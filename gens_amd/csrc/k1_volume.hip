@@ -202,15 +202,244 @@ __global__ __launch_bounds__(256) void volume_build_fwd_pow2_k(const float4* __r
     const float den = cnt <= 0.0f ? 1e-8f : cnt;                                  // (Q5)
     const float yn = 1.0f / den;
     const float4 mm = make_float4(div_rn(s1.x, den, yn), div_rn(s1.y, den, yn), div_rn(s1.z, den, yn), div_rn(s1.w, den, yn));
-    vol[idx] = mm.x;
-    vol[n + idx] = mm.y;
-    vol[2 * n + idx] = mm.z;
-    vol[3 * n + idx] = mm.w;
-    vol[4 * n + idx] = div_rn(s2.x, den, yn) - mm.x * mm.x;
-    vol[5 * n + idx] = div_rn(s2.y, den, yn) - mm.y * mm.y;
-    vol[6 * n + idx] = div_rn(s2.z, den, yn) - mm.z * mm.z;
-    vol[7 * n + idx] = div_rn(s2.w, den, yn) - mm.w * mm.w;
-    mask[idx] = cnt > (float)min_vis ? 1.0f : 0.0f;                               // (Q4)
+    // streaming (non-temporal) stores: keep the texels in L2
+    __builtin_nontemporal_store(mm.x, vol + idx);
+    __builtin_nontemporal_store(mm.y, vol + n + idx);
+    __builtin_nontemporal_store(mm.z, vol + 2 * n + idx);
+    __builtin_nontemporal_store(mm.w, vol + 3 * n + idx);
+    __builtin_nontemporal_store(div_rn(s2.x, den, yn) - mm.x * mm.x, vol + 4 * n + idx);
+    __builtin_nontemporal_store(div_rn(s2.y, den, yn) - mm.y * mm.y, vol + 5 * n + idx);
+    __builtin_nontemporal_store(div_rn(s2.z, den, yn) - mm.z * mm.z, vol + 6 * n + idx);
+    __builtin_nontemporal_store(div_rn(s2.w, den, yn) - mm.w * mm.w, vol + 7 * n + idx);
+    __builtin_nontemporal_store(cnt > (float)min_vis ? 1.0f : 0.0f, mask + idx);   // (Q4)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Production forward kernel (power-of-two D >= 8, pre-scaled intrinsics): volume_build_fwd_pow2_k with fewer operations, every
+// float32 result still bit-identical (tests compare the kernels bit for bit at full size).
+// What bounds it (scripts/probe/k1_probe.py, D = 256, warm clocks): arithmetic alone 152 us, + texel reads 182 us, + stores
+// 248 us; 30 us of that are the stores sweeping the texels out of L2, which streaming (non-temporal) stores avoid (222 us).
+// Issuing all views' gathers before the first use (one exposed memory latency per wave instead of nv) was measured SLOWER
+// (249 us): it gives up the skip of views no lane of the wave sees and half the occupancy.  So the lever is the instruction count:
+//   * RN(1/b) as y0 = v_rcp_f32(b) (<= 1 ulp), e = fma(-b, y0, 1), y = fma(e, y0, y0): the correctly rounded reciprocal of every
+//     normal b (gens_selftest_division compares all 2^32 bit patterns with the IEEE division), 3 instructions instead of 10;
+//   * pinhole matrices (w2c row 3 = 0 0 0 1, intrinsics [[fx 0 cx 0] [0 fy cy 0] [0 0 1 0]], tested per view on the scalar unit)
+//     skip the products with an exact 0 / 1 (x + (+-0) = x, 1 * x = x in IEEE arithmetic);
+//   * texel reads through a buffer descriptor: a 32-bit byte offset per lane, the view's offset in an SGPR (no 64-bit address
+//     arithmetic, one multiply-add per tap).
+// Packed float32 instructions (two voxels per lane, v_pk_*_f32) were tried and are no faster here: a packed operation issues at
+// half the rate of a scalar one on this chip.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rcp_rn(float b) {                    // RN(1 / b), see above
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// One affine constraint g(t) >= 0 on the row parameter t in [0, 1] (g0 = g(0), g1 = g(1), `scale` bounds the magnitude of the
+// terms g was summed from): narrows [lo, hi] conservatively.  Anything doubtful (flat or NaN g) leaves the interval alone.
+__device__ __forceinline__ void row_constraint(float g0, float g1, float scale, float& lo, float& hi, bool& empty) {
+    const float tol = 1e-5f * scale;
+    if (g0 < -tol && g1 < -tol) { empty = true; return; }
+    if (!(fabsf(g0 - g1) >= 1e-2f * scale)) return;
+    const float t = g0 / (g0 - g1);                                               // zero crossing, |error| < 1e-3 (a quarter voxel at d = 256)
+    if (g0 < g1) lo = fmaxf(lo, t); else hi = fminf(hi, t);
+}
+
+__device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
+                                                   const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
+                                                   float* __restrict__ vol, float* __restrict__ mask) {
+    // Chunk -> voxels.  d >= 64: the four waves take the SAME 64 z of four x-adjacent rows (ix = 4 g + wave), whose image footprints
+    // overlap, so most of a wave's texel lines are already in the CU's L1 (the z-contiguous 256-voxel chunk sent 3-4x as many requests
+    // to L2); smaller volumes: 256 consecutive voxels = 256 / d whole rows.
+    const uint32_t dm = (uint32_t)d - 1u;
+    const bool tiled = lc.log2d >= 6;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t zq_bits = (uint32_t)lc.log2d - 6u;                              // (tiled) a row is 2^zq_bits pieces of 64 voxels
+    const uint32_t t_kz0 = (chunk & ((1u << zq_bits) - 1u)) << 6, t_jy = (chunk >> zq_bits) & dm, t_ix0 = (chunk >> (zq_bits + lc.log2d)) << 2;
+    const uint32_t idx = tiled ? (((t_ix0 + wv) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + lane)) : chunk * 256u + threadIdx.x;
+    const int kz = (int)(idx & dm), jy = (int)((idx >> lc.log2d) & dm), ix = (int)(idx >> (2 * lc.log2d));
+    const int half = d >> 1;
+    // ---- frustum culling per (z-row, view).  Along a z-row the homogeneous image coordinates (u, v, depth) are affine in z, so the
+    // voxels of the row a view can see form ONE interval of kz.  Thread (row r, view v) of the workgroup intersects the five half-lines
+    // depth > 0, 0 <= u <= (w-1) depth, 0 <= v <= (h-1) depth from their values at the two ends of the row, widens the result by two
+    // voxels, and leaves it in LDS; in the view loop a wave whose lanes all sit outside the interval skips the view before any per-voxel
+    // arithmetic (64 % of all (wave, view) pairs at the benchmark geometry, where that arithmetic was 55 % of the kernel's instructions).
+    // The exact per-voxel test below still decides visibility; the intervals only have to be supersets, and the bit-for-bit
+    // comparisons with the unculled kernels check that they are.
+    __shared__ int2 row_span[32][GENS_MAX_VIEWS];
+    {
+        const int rows = tiled ? 4 : 256 >> lc.log2d;                             // z-rows the workgroup touches (d <= 256)
+        const int r = threadIdx.x >> 3, v = threadIdx.x & 7;
+        if (r < rows && v < nv) {
+            const uint32_t row = tiled ? (((t_ix0 + (uint32_t)r) << lc.log2d) | t_jy) : chunk * (uint32_t)rows + (uint32_t)r;   // = ix * d + jy
+            const int rj = (int)(row & dm), ri = (int)(row >> lc.log2d);
+            const float rx = ri < half ? -1.0f + lc.step * (float)ri : 1.0f - lc.step * (float)(d - 1 - ri);
+            const float ry = rj < half ? -1.0f + lc.step * (float)rj : 1.0f - lc.step * (float)(d - 1 - rj);
+            const float* m = w2c + 16 * v;
+            const float* k = intr + 16 * v;
+            float c0[4], c1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float base = m[4 * q] * rx + m[4 * q + 1] * ry + m[4 * q + 3];
+                c0[q] = base - m[4 * q + 2];                                      // z = -1
+                c1[q] = base + m[4 * q + 2];                                      // z = +1
+            }
+            const float u0 = k[0] * c0[0] + k[1] * c0[1] + k[2] * c0[2] + k[3] * c0[3], u1 = k[0] * c1[0] + k[1] * c1[1] + k[2] * c1[2] + k[3] * c1[3];
+            const float v0 = k[4] * c0[0] + k[5] * c0[1] + k[6] * c0[2] + k[7] * c0[3], v1 = k[4] * c1[0] + k[5] * c1[1] + k[6] * c1[2] + k[7] * c1[3];
+            const float d0 = k[8] * c0[0] + k[9] * c0[1] + k[10] * c0[2] + k[11] * c0[3], d1 = k[8] * c1[0] + k[9] * c1[1] + k[10] * c1[2] + k[11] * c1[3];
+            const float wm = (float)(w - 1), hm = (float)(h - 1);
+            const float sd = fabsf(d0) + fabsf(d1) + 1e-6f;
+            const float su = fabsf(u0) + fabsf(u1) + wm * sd, sv = fabsf(v0) + fabsf(v1) + hm * sd;
+            float lo = 0.0f, hi = 1.0f;
+            bool empty = false;
+            row_constraint(d0, d1, sd, lo, hi, empty);
+            row_constraint(u0, u1, su, lo, hi, empty);
+            row_constraint(wm * d0 - u0, wm * d1 - u1, su, lo, hi, empty);
+            row_constraint(v0, v1, sv, lo, hi, empty);
+            row_constraint(hm * d0 - v0, hm * d1 - v1, sv, lo, hi, empty);
+            int2 span;
+            span.x = max((int)floorf(lo * (float)(d - 1)) - 2, 0);
+            span.y = min((int)ceilf(hi * (float)(d - 1)) + 2, d - 1);
+            if (empty) span = make_int2(1, 0);
+            row_span[r][v] = span;
+        }
+    }
+    __syncthreads();
+    const int my_row = tiled ? (int)wv : (int)(threadIdx.x >> lc.log2d);
+    // torch.linspace(-1, 1, d)[i]: lower half counts up from the start, upper half down from the end
+    const float x = ix < half ? -1.0f + lc.step * (float)ix : 1.0f - lc.step * (float)(d - 1 - ix);
+    const float y = jy < half ? -1.0f + lc.step * (float)jy : 1.0f - lc.step * (float)(d - 1 - jy);
+    const float z = kz < half ? -1.0f + lc.step * (float)kz : 1.0f - lc.step * (float)(d - 1 - kz);
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const uint32_t row_bytes = (uint32_t)w * 16u, view_bytes = (uint32_t)h * row_bytes;
+    const __amdgpu_buffer_rsrc_t texels = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)((uint32_t)nv * view_bytes), 0x00020000);
+    float4 s1 = f4_zero(), s2 = f4_zero();
+    float cnt = 0.0f;
+    for (int v = 0; v < nv; ++v) {
+        const int2 span = row_span[my_row][v];
+        if (kz < span.x || kz > span.y) continue;                                 // outside the view's frustum for sure
+        const float* m = w2c + 16 * v;
+        const float* k = intr + 16 * v;
+        const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
+        const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
+        const float cz = m[8] * x + m[9] * y + m[10] * z + m[11];
+        // integer tests on the scalar unit (a float compare would be a VALU instruction + vcc branch per matrix entry)
+        const uint32_t* mb = (const uint32_t*)m;
+        const uint32_t* kb = (const uint32_t*)k;
+        const uint32_t must_be_zero = (mb[12] | mb[13] | mb[14] | kb[1] | kb[3] | kb[4] | kb[7] | kb[8] | kb[9] | kb[11]) << 1;   // +-0
+        const uint32_t must_be_one = (mb[15] ^ 0x3f800000u) | (kb[10] ^ 0x3f800000u);
+        float u, vv, dd;
+        if ((must_be_zero | must_be_one) == 0u) {
+            u = k[0] * cx + k[2] * cz;
+            vv = k[5] * cy + k[6] * cz;
+            dd = cz;
+        } else {
+            const float cw = m[12] * x + m[13] * y + m[14] * z + m[15];
+            u = k[0] * cx + k[1] * cy + k[2] * cz + k[3] * cw;
+            vv = k[4] * cx + k[5] * cy + k[6] * cz + k[7] * cw;
+            dd = k[8] * cx + k[9] * cy + k[10] * cz + k[11] * cw;
+        }
+        const float dn = dd + 1e-8f;                                              // (Q3)
+        const float yd = rcp_rn(dn);
+        const float px = div_rn(u, dn, yd), py = div_rn(vv, dn, yd);
+        const float nx = div_rn(px, lc.cw, lc.rcw) - 1.0f, ny = div_rn(py, lc.ch, lc.rch) - 1.0f;
+        const bool vis = (fmaxf(fabsf(nx), fabsf(ny)) <= 1.0f) && (dd > 0.0f);    // a NaN coordinate implies dn == 0, i.e. dd < 0
+        if (!vis) continue;
+        // A visible voxel reads inside the image (fx in [0, w-1], fy in [0, h-1]): the +1 tap may sit on column w / row h, where its
+        // weight is exactly 0 -- read it from the clamped index.  Same weights and order of accumulation as sample_texel.
+        const float fx = (nx + 1.0f) / 2.0f * wm1, fy = (ny + 1.0f) / 2.0f * hm1; // align_corners=True (volume.py:46)
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const uint32_t xo0 = (uint32_t)x0 << 4, xo1 = (uint32_t)min(x0 + 1, w - 1) << 4;
+        const uint32_t y1 = (uint32_t)min(y0 + 1, h - 1);
+        const uint32_t view_off = (uint32_t)v * view_bytes;
+        const f4 v00 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(texels, __umul24((uint32_t)y0, row_bytes) + xo0, view_off, 0));
+        const f4 v01 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(texels, __umul24((uint32_t)y0, row_bytes) + xo1, view_off, 0));
+        const f4 v10 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(texels, __umul24(y1, row_bytes) + xo0, view_off, 0));
+        const f4 v11 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(texels, __umul24(y1, row_bytes) + xo1, view_off, 0));
+        const float wx1 = fx - x0f, wx0 = (x0f + 1.0f) - fx, wy1 = fy - y0f, wy0 = (y0f + 1.0f) - fy;
+        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+        float4 f;
+        f.x = __builtin_fmaf(v11.x, w11, __builtin_fmaf(v10.x, w10, __builtin_fmaf(v01.x, w01, __builtin_fmaf(v00.x, w00, 0.0f))));
+        f.y = __builtin_fmaf(v11.y, w11, __builtin_fmaf(v10.y, w10, __builtin_fmaf(v01.y, w01, __builtin_fmaf(v00.y, w00, 0.0f))));
+        f.z = __builtin_fmaf(v11.z, w11, __builtin_fmaf(v10.z, w10, __builtin_fmaf(v01.z, w01, __builtin_fmaf(v00.z, w00, 0.0f))));
+        f.w = __builtin_fmaf(v11.w, w11, __builtin_fmaf(v10.w, w10, __builtin_fmaf(v01.w, w01, __builtin_fmaf(v00.w, w00, 0.0f))));
+        s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
+        s2 = make_float4(__builtin_fmaf(f.x, f.x, s2.x), __builtin_fmaf(f.y, f.y, s2.y), __builtin_fmaf(f.z, f.z, s2.z), __builtin_fmaf(f.w, f.w, s2.w));
+        cnt += 1.0f;
+    }
+    const float den = cnt <= 0.0f ? 1e-8f : cnt;                                  // (Q5)
+    const float yn = rcp_rn(den);
+    const float4 mm = make_float4(div_rn(s1.x, den, yn), div_rn(s1.y, den, yn), div_rn(s1.z, den, yn), div_rn(s1.w, den, yn));
+    // Output: the workgroup's 256 voxels are 256 consecutive floats in each of the 9 planes.  Staged through LDS so that a store
+    // instruction carries 16 B per lane (one plane's 1 KiB per wave-store: 9 store instructions per workgroup instead of 36 -- the
+    // texture path of a CU was busy 72 % of the kernel with 4-byte stores); streaming (non-temporal), so that the 36 B / voxel do not
+    // sweep the texels out of L2; through buffer descriptors (lane offset in 32 bits; d^3 <= 2^24 voxels: 8 planes are 512 MiB).
+    __shared__ float stage[9][256];
+    const int tid = threadIdx.x;
+    stage[0][tid] = mm.x;
+    stage[1][tid] = mm.y;
+    stage[2][tid] = mm.z;
+    stage[3][tid] = mm.w;
+    stage[4][tid] = div_rn(s2.x, den, yn) - mm.x * mm.x;
+    stage[5][tid] = div_rn(s2.y, den, yn) - mm.y * mm.y;
+    stage[6][tid] = div_rn(s2.z, den, yn) - mm.z * mm.z;
+    stage[7][tid] = div_rn(s2.w, den, yn) - mm.w * mm.w;
+    stage[8][tid] = cnt > (float)min_vis ? 1.0f : 0.0f;                            // (Q4)
+    __syncthreads();
+    const uint32_t plane = (uint32_t)d << (2 * lc.log2d + 2);                      // bytes per plane
+    const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc((void*)vol, 0, (int)(8u * plane), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mplane = __builtin_amdgcn_make_buffer_rsrc((void*)mask, 0, (int)plane, 0x00020000);
+    constexpr int NT = 2;                                                          // cache policy bits of the buffer builtins: 2 = nt
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t q = (uint32_t)tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: an SGPR plane offset
+    // lane q stores four consecutive voxels of plane `wave`, `wave + 4` and (wave 0) the mask: staged floats [4q, 4q+4), which are
+    // voxels 4 (q & 15) .. of row-piece q >> 4 when tiled (four 256-B pieces per plane), else voxels 4q .. of the 1-KiB chunk
+    const uint32_t off = tiled ? ((((t_ix0 + (q >> 4)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 15u) << 2))) << 2) : chunk * 1024u + q * 16u;
+    __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[wave][4 * q], planes, off, wave * plane, NT);
+    __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[wave + 4][4 * q], planes, off, (wave + 4u) * plane, NT);
+    if (wave == 0) __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[8][4 * q], mplane, off, 0u, NT);
+}
+
+__global__ __launch_bounds__(256) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
+                                                               const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc,
+                                                               int min_vis, float* __restrict__ vol, float* __restrict__ mask) {
+    volume_build_chunk(blockIdx.x, feat, w2c, intr, nv, h, w, d, lc, min_vis, vol, mask);
+}
+
+// Self-test of the exact-division shortcuts used above: every float32 bit pattern b with a normal, finite reciprocal is
+// compared with the IEEE division (counts[0]: RN(1/b) mismatches), and for each b a pseudo-random numerator a is divided both
+// ways (counts[1]: a/b mismatches among quotients in the normal range).  Both must be 0.
+__global__ __launch_bounds__(256) void selftest_division_k(unsigned long long* __restrict__ counts) {
+    unsigned long long bad_rcp = 0, bad_div = 0;
+    for (uint32_t part = 0; part < 16u; ++part) {                                  // 2^28 threads x 16 bit patterns each
+        const uint32_t bits = (part << 28) | (blockIdx.x * 256u + threadIdx.x);
+        const float b = __uint_as_float(bits);
+        const float ab = fabsf(b);
+        if (!(ab >= 1.1754944e-38f * 4.0f && ab <= 8.5e37f)) continue;             // 1/b normal (NaN fails the test too)
+        const float ref = 1.0f / b;
+        bad_rcp += __float_as_uint(rcp_rn(b)) != __float_as_uint(ref);
+        // numerator: hash of the bit pattern, exponent within 2^+-16 of b's so the quotient stays normal
+        uint32_t hsh = bits * 2654435761u + 0x9e3779b9u;
+        hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        const int eb = (int)((bits >> 23) & 0xffu);
+        const int ea = min(max(eb + (int)(hsh >> 27) - 16, 30), 220);
+        const float a = __uint_as_float((hsh & 0x807fffffu) | ((uint32_t)ea << 23));
+        const float q_ref = a / b;
+        if (!(fabsf(q_ref) >= 1.1754944e-38f * 4.0f && fabsf(q_ref) <= 8.5e37f)) continue;
+        bad_div += __float_as_uint(div_rn(a, b, ref)) != __float_as_uint(q_ref);
+    }
+    if (bad_rcp) atomicAdd(counts + 0, bad_rcp);
+    if (bad_div) atomicAdd(counts + 1, bad_div);
+}
+
+extern "C" int gens_selftest_division(unsigned long long* counts, void* stream) {
+    GENS_CHECK_ARG(counts, GENS_EINVAL, "gens_selftest_division: null pointer");
+    selftest_division_k<<<1u << 20, 256, 0, (hipStream_t)stream>>>(counts);
+    return gens_launch_status("gens_selftest_division");
 }
 
 // d(volume)/d(features): recompute the projections, then scatter with the bilinear weights.
@@ -277,6 +506,11 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
         lc.rch = 1.0f / lc.ch;
         lc.log2d = 0;
         while ((1 << lc.log2d) < d) ++lc.log2d;
+        if (d >= 8 && nv <= GENS_MAX_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
+            volume_build_fwd_lean_k<<<(unsigned)(n / 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
+                                                                                     min_vis_view, volume, mask);
+            return gens_launch_status("gens_volume_build_fwd");
+        }
         const unsigned rows_per_block = 256u >> lc.log2d;
         const unsigned grid = ((unsigned)d * (unsigned)d + rows_per_block - 1) / rows_per_block;
         if (intr_scale == 1.0f)

@@ -66,6 +66,10 @@ int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr
                           int w, int d, int min_vis_view, float* volume, float* mask, void* stream);
 int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
                           int w, int d, const float* g_volume, float* g_feat, void* stream);
+/* Self-test of K1's exact-division shortcuts (RN(1/b) from v_rcp_f32 + one FMA refinement; a/b from that reciprocal + FMA
+ * correction) against the IEEE division over all 2^32 float32 bit patterns: counts[0] += reciprocal mismatches,
+ * counts[1] += quotient mismatches (device array of 2, zeroed by the caller).  Both stay 0. */
+int gens_selftest_division(unsigned long long* counts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K2  lookup_volume(pts, volumes, "grad"): all levels in one launch

@@ -16,7 +16,9 @@ w2c = torch.linalg.inv(c2ws).contiguous()
 for lvl, d in enumerate([256, 128, 64]):
     tex = ops.pack_nchw(feats[lvl])
     nv, h, w, _ = tex.shape
-    fn = lambda: ops._VolumeBuild.apply(tex, w2c, intrs, 0.5 ** lvl, d, 1)  # noqa: E731
+    k = intrs.clone()
+    k[:, :2] *= 0.5 ** lvl                                                    # pre-scaled, as ops.volume_build hands them over
+    fn = lambda: ops._VolumeBuild.apply(tex, w2c, k, 1.0, d, 1)  # noqa: E731
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -129,6 +129,15 @@ def test_blend_is_invariant_to_source_view_order(scene):
     assert torch.equal(vis[:, [3, 1, 0, 2]], vis_p)                          # source k of the permuted scene is view perm[k+1]
 
 
+def test_k1_exact_division_shortcuts_cover_every_float32():
+    """RN(1/b) = v_rcp_f32 + one FMA refinement, and a/b = reciprocal multiply + FMA correction, against the IEEE division for all
+    2^32 bit patterns of b (and one hashed numerator each): not one mismatch, so K1's quotients are the reference's."""
+    from gens_amd import lib as L
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    L.call("gens_selftest_division", L.ptr(counts, torch.int64), L.stream())
+    assert counts.tolist() == [0, 0]
+
+
 def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
     """The power-of-two forward kernel replaces IEEE divisions by reciprocal + FMA-corrected quotients and index divisions by
     shifts; every output must equal the generic kernel's bit for bit (full size: 19 M voxels x 5 views, incl. border voxels)."""
@@ -136,11 +145,55 @@ def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
     from gens_amd import ops
     feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
     dims = [256, 128, 64, 32, 16]
-    fast_v, fast_m = ops.volume_build(feats, intrs, c2ws, dims)
+    fast_v, fast_m = ops.volume_build(feats, intrs, c2ws, dims)          # two voxels per lane (production)
+    outs = []
+    for switch in ("GENS_K1_SINGLE", "GENS_K1_GENERIC"):                 # one voxel per lane, then the plain IEEE kernel
+        os.environ[switch] = "1"
+        try:
+            outs.append(ops.volume_build(feats, intrs, c2ws, dims))
+        finally:
+            del os.environ[switch]
+    for ref_v, ref_m in outs:
+        for a, b in zip(fast_v + fast_m, ref_v + ref_m):
+            assert torch.equal(a, b)
+    # a non-pinhole camera (skewed intrinsics, projective last row of w2c is still 0 0 0 1) takes the general branch per view
+    skew = intrs.clone()
+    skew[1:, 0, 1] = 3.0
+    skew[2, 1, 3] = 0.25
+    fast = ops.volume_build(feats, skew, c2ws, dims[:3])
     os.environ["GENS_K1_GENERIC"] = "1"
     try:
-        ref_v, ref_m = ops.volume_build(feats, intrs, c2ws, dims)
+        ref = ops.volume_build(feats, skew, c2ws, dims[:3])
     finally:
         del os.environ["GENS_K1_GENERIC"]
-    for a, b in zip(fast_v + fast_m, ref_v + ref_m):
+    for a, b in zip(fast[0] + fast[1], ref[0] + ref[1]):
         assert torch.equal(a, b)
+    # the production kernel culls (z-row, view) pairs from a conservative frustum interval: cameras inside / beside / behind the cube,
+    # rolled and tilted, narrow and wide fields of view -- every voxel the exact test accepts must survive the culling
+    g = torch.Generator().manual_seed(11)
+    seen = 0.0
+    for trial in range(6):
+        rig_c2w, rig_k = [], []
+        for v in range(5):
+            q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+            if torch.det(q) < 0:
+                q[:, 0] = -q[:, 0]
+            c2w = torch.eye(4, dtype=torch.float64)
+            c2w[:3, :3] = q
+            c2w[:3, 3] = torch.randn(3, generator=g, dtype=torch.float64) * [0.3, 1.0, 2.5][trial % 3]
+            k = intrs[0].double().clone()
+            k[0, 0] *= [0.2, 1.0, 3.0][(trial + v) % 3]
+            k[1, 1] *= [0.2, 1.0, 3.0][(trial + v) % 3]
+            rig_c2w.append(c2w)
+            rig_k.append(k)
+        rig_c2w, rig_k = torch.stack(rig_c2w).float().cuda(), torch.stack(rig_k).float().cuda()
+        fast = ops.volume_build(feats, rig_k, rig_c2w, dims[:4])
+        os.environ["GENS_K1_GENERIC"] = "1"
+        try:
+            ref = ops.volume_build(feats, rig_k, rig_c2w, dims[:4])
+        finally:
+            del os.environ["GENS_K1_GENERIC"]
+        seen += sum(float(m.sum()) for m in ref[1])
+        for a, b in zip(fast[0] + fast[1], ref[0] + ref[1]):
+            assert torch.equal(a, b)
+    assert seen > 1e5                                                        # the rigs do see the cube
