@@ -66,4 +66,4 @@ for lvl, d in enumerate([256, 128]):
     a = nv * h * w * 16 + 36 * d ** 3
     for name, _, _ in cases:
         us = statistics.median(times[name])
-        print(f"D={d} {name}: {us:8.1f} us (min {min(times[name]):.1f})  {a / us / 1e6 / 8000 * 100:5.1f}% of 8 TB/s")
+        print(f"D={d} {name}: {us:8.1f} us (min {min(times[name]):.1f})  {a / us / 8e6 * 100:5.1f}% of 8 TB/s")
