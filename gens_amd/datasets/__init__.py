@@ -1,8 +1,10 @@
-"""Dataset front-end: DTU item dictionaries without OpenCV.  `get_loader` mirrors
-/root/reference/datasets/__init__.py:16-38 for the two DTU datasets (generalisation and per-scene fine-tune); the BlendedMVS variants are not rebuilt."""
+"""Dataset front-end: DTU and BlendedMVS item dictionaries without OpenCV.  `get_loader` mirrors
+/root/reference/datasets/__init__.py:16-38 (the four datasets it knows: generalisation and per-scene fine-tune, DTU and BlendedMVS)."""
 import torch.distributed as dist
 from torch.utils.data import DataLoader, DistributedSampler, RandomSampler, SequentialSampler
 
+from .bmvs import BMVSDataset  # noqa: F401
+from .bmvs_finetune import BMVSDatasetFinetune  # noqa: F401
 from .dtu import DTUDataset  # noqa: F401
 from .dtu_finetune import DTUDatasetFinetune  # noqa: F401
 
@@ -17,8 +19,12 @@ def get_loader(conf, mode, distributed):
         dataset = DTUDataset(conf, mode)
     elif name == "DTUDatasetFinetune":
         dataset = DTUDatasetFinetune(conf, mode)
+    elif name == "BMVSDataset":
+        dataset = BMVSDataset(conf, mode)
+    elif name == "BMVSDatasetFinetune":
+        dataset = BMVSDatasetFinetune(conf, mode)
     else:
-        raise NotImplementedError(f"gens_amd.datasets rebuilds the DTU datasets only (got {name}); use the reference's datasets/ for BlendedMVS")
+        raise NotImplementedError(name)
     if mode == "finetune":
         return dataset
     if distributed:

@@ -13,6 +13,25 @@ from . import camera as C
 
 
 class DTUDatasetFinetune(Dataset):
+    RAW_WH = (1600, 1200)                       # pixel size the intrinsics of the cam files refer to (dtu_finetune.py:171-172)
+    HAS_PSEUDO_POINTS = True
+
+    # where one scene's files live (overridden by the BlendedMVS variant)
+    def pair_file(self):
+        return os.path.join(self.data_dir, "Cameras/pair.txt")
+
+    def cam_file(self, vid):
+        return os.path.join(self.data_dir, "Cameras/{:0>8}_cam.txt".format(vid))
+
+    def image_file(self, vid):
+        return os.path.join(self.data_dir, "Rectified_raw/{}/rect_{:0>3}_3_r5000.png".format(self.scene, vid + 1))
+
+    def mask_file(self, vid):
+        return os.path.join(self.data_dir, "Depths_raw/{}/depth_visual_{:0>4}.png".format(self.scene, vid))
+
+    def mask_from_pixels(self, m):
+        return (m > 10).astype(np.float32)
+
     def __init__(self, confs, mode):
         super().__init__()
         self.mode = mode
@@ -26,23 +45,27 @@ class DTUDatasetFinetune(Dataset):
         self.scene = confs.get_string("scene")
         self.ref_view = confs.get_int("ref_view")
         self.val_res_level = confs.get_int("val_res_level", default=1)
-        self.pairs = C.read_pair_file(os.path.join(self.data_dir, "Cameras/pair.txt"))
+        self.pairs = C.read_pair_file(self.pair_file())
         self.all_views = [self.ref_view] + list(self.pairs[self.ref_view])[:(self.num_views - 1)]
         intrs, c2ws, near_fars, self.scale_factor, self.trans_mat, scale_mat = self.read_cam_info()
         self.intrs = torch.from_numpy(np.stack(intrs).astype(np.float32))
         self.c2ws = torch.from_numpy(np.stack(c2ws).astype(np.float32))
         self.near_fars = torch.from_numpy(np.stack(near_fars).astype(np.float32))
         self.scale_mat = torch.from_numpy(self.trans_mat @ scale_mat)
-        self.pseudo_scale = 0.0037506045743823813                      # dtu_finetune.py:99
         hw = self.img_hw
-        scene = self.scene
-        self.images_lis = [os.path.join(self.data_dir, "Rectified_raw/{}/rect_{:0>3}_3_r5000.png".format(scene, v + 1)) for v in self.all_views]
-        self.masks_lis = [os.path.join(self.data_dir, "Depths_raw/{}/depth_visual_{:0>4}.png".format(scene, v)) for v in self.all_views]
-        self.pseudo_dense_lis = [os.path.join(self.data_dir, "pseudo_depths/{}/{}_epoch0.npy".format(scene, v)) for v in self.all_views]
+        self.images_lis = [self.image_file(v) for v in self.all_views]
+        self.masks_lis = [self.mask_file(v) for v in self.all_views]
         images = [np.array(Image.open(f), dtype=np.float32) / 256.0 for f in self.images_lis]
         self.images = torch.from_numpy(np.stack([C.resize_nearest(im, hw) for im in images]).astype(np.float32))
         masks = [np.array(Image.open(f), dtype=np.float32) for f in self.masks_lis]
-        self.masks = torch.from_numpy(np.stack([(C.resize_nearest(m, hw) > 10).astype(np.float32) for m in masks]).astype(np.float32))
+        self.masks = torch.from_numpy(np.stack([self.mask_from_pixels(C.resize_nearest(m, hw)) for m in masks]).astype(np.float32))
+        if self.HAS_PSEUDO_POINTS:
+            self._load_pseudo_points()
+
+    def _load_pseudo_points(self):
+        hw = self.img_hw
+        self.pseudo_scale = 0.0037506045743823813                      # dtu_finetune.py:99
+        self.pseudo_dense_lis = [os.path.join(self.data_dir, "pseudo_depths/{}/{}_epoch0.npy".format(self.scene, v)) for v in self.all_views]
         dense = np.stack([np.load(f).astype(np.float32) / self.pseudo_scale for f in self.pseudo_dense_lis])   # kept at file resolution
         self.dense_pseudo_depths = torch.from_numpy(dense.astype(np.float32)) * self.scale_factor
         pts = []
@@ -64,10 +87,9 @@ class DTUDatasetFinetune(Dataset):
         """Cameras of `all_views` relative to the reference view, normalised to the unit sphere (:149-199)."""
         intrs, w2cs, near_fars = [], [], []
         for vid in self.all_views:
-            intr, w2c, near_far = C.read_cam_file(os.path.join(self.data_dir, "Cameras/{:0>8}_cam.txt".format(vid)), self.interval_scale,
-                                                  self.num_interval)
-            intr[0] *= self.img_hw[1] / 1600
-            intr[1] *= self.img_hw[0] / 1200
+            intr, w2c, near_far = C.read_cam_file(self.cam_file(vid), self.interval_scale, self.num_interval)
+            intr[0] *= self.img_hw[1] / self.RAW_WH[0]
+            intr[1] *= self.img_hw[0] / self.RAW_WH[1]
             intrs.append(intr)
             w2cs.append(w2c)
             near_fars.append(near_far)
@@ -104,7 +126,8 @@ class DTUDatasetFinetune(Dataset):
         pixels_x = torch.randint(low=0, high=self.img_hw[1], size=[self.n_rays])
         pixels_y = torch.randint(low=0, high=self.img_hw[0], size=[self.n_rays])
         out = self._rays(vid, pixels_x, pixels_y)
-        out["pseudo_pts"] = self.pseudo_ptses[torch.randint(low=0, high=self.pseudo_ptses.shape[0], size=[2048])]
+        if self.HAS_PSEUDO_POINTS:
+            out["pseudo_pts"] = self.pseudo_ptses[torch.randint(low=0, high=self.pseudo_ptses.shape[0], size=[2048])]
         return out
 
     def get_rays_at(self, vid):

@@ -390,17 +390,11 @@ def g11_lncc():
     npz("g11_lncc", ref=ref, src=src, ncc=ncc, cot=cot, g_ref=g_ref, g_src=g_src)
 
 
-def g12_dtu_dataset():
-    """The reference's DTUDataset (datasets/dtu.py) on the synthetic tree of tests/dtu_fixture.py, one val and one train item.
-    cv2 is absent here: a stub provides the two calls the dataset makes -- INTER_NEAREST resize (OpenCV's documented index
+def _install_cv2_stub():
+    """cv2 is absent here: a stub provides the two calls the datasets make -- INTER_NEAREST resize (OpenCV's documented index
     rule) and decomposeProjectionMatrix (scipy.linalg.rq + the null vector of P by SVD; the product code uses a different
     route, numpy QR + a linear solve)."""
-    import random
-    import tempfile
     import scipy.linalg
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import dtu_fixture
-
     cv2 = types.ModuleType("cv2")
     cv2.INTER_NEAREST = 0
 
@@ -421,52 +415,96 @@ def g12_dtu_dataset():
 
     cv2.resize, cv2.decomposeProjectionMatrix = resize, decomposeProjectionMatrix
     sys.modules["cv2"] = cv2
+
+
+class _Conf(dict):
+    def get_int(self, k, default=None): return int(self.get(k, default))
+    def get_float(self, k, default=None): return float(self.get(k, default))
+    def get_string(self, k, default=None): return self.get(k, default)
+    def get_list(self, k, default=None): return self.get(k, default)
+
+
+def _dump_item(out, prefix, item):
+    for k, v in item.items():
+        if isinstance(v, torch.Tensor):
+            out[f"{prefix}.{k}"] = v.numpy()
+        elif isinstance(v, (int, np.integer)):
+            out[f"{prefix}.{k}"] = np.int64(v)
+        elif isinstance(v, list):
+            out[f"{prefix}.{k}"] = np.array(v, dtype=np.int64)
+        elif isinstance(v, str):
+            out[f"{prefix}.{k}"] = np.array(v)
+
+
+def g12_dtu_dataset():
+    """The reference's DTUDataset / DTUDatasetFinetune (datasets/dtu.py, dtu_finetune.py) on the synthetic tree of tests/dtu_fixture.py:
+    one val and one train item, and the fine-tune dataset's three accessors (cv2 stubbed, see _install_cv2_stub)."""
+    import random
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dtu_fixture
+    _install_cv2_stub()
     from datasets.dtu import DTUDataset
-
-    class Conf(dict):
-        def get_int(self, k, default=None): return int(self.get(k, default))
-        def get_float(self, k, default=None): return float(self.get(k, default))
-        def get_string(self, k, default=None): return self.get(k, default)
-        def get_list(self, k, default=None): return self.get(k, default)
-
     out = {}
     with tempfile.TemporaryDirectory() as root:
         dtu_fixture.make_dtu_tree(root)
         for mode, idx in (("val", 1), ("train", 0)):
-            ds = DTUDataset(Conf(dtu_fixture.conf_values(root, mode)), mode)
+            ds = DTUDataset(_Conf(dtu_fixture.conf_values(root, mode)), mode)
             random.seed(5)
             np.random.seed(6)
             torch.manual_seed(7)
             item = ds[idx]
             out[f"{mode}_len"] = len(ds)
-            for k, v in item.items():
-                if isinstance(v, torch.Tensor):
-                    out[f"{mode}.{k}"] = v.numpy()
-                elif isinstance(v, (int, np.integer)):
-                    out[f"{mode}.{k}"] = np.int64(v)
-                elif isinstance(v, str):
-                    out[f"{mode}.{k}"] = np.array(v)
+            _dump_item(out, mode, item)
         from datasets.dtu_finetune import DTUDatasetFinetune
         torch.manual_seed(11)
-        ft = DTUDatasetFinetune(Conf(dtu_fixture.finetune_conf_values(root)), "finetune")
+        ft = DTUDatasetFinetune(_Conf(dtu_fixture.finetune_conf_values(root)), "finetune")
         items = {"all": ft.get_all_images(), "rand": ft.get_random_rays(torch.tensor(1)), "at": ft.get_rays_at(2)}
         out["ft.pseudo_ptses"] = ft.pseudo_ptses.numpy()
         out["ft.scale_mat"] = ft.scale_mat.numpy()
         for name, item in items.items():
-            for k, v in item.items():
-                if isinstance(v, torch.Tensor):
-                    out[f"ft.{name}.{k}"] = v.numpy()
-                elif isinstance(v, list):
-                    out[f"ft.{name}.{k}"] = np.array(v, dtype=np.int64)
-                elif isinstance(v, str):
-                    out[f"ft.{name}.{k}"] = np.array(v)
+            _dump_item(out, f"ft.{name}", item)
     npz("g12_dtu_dataset", **out)
+
+
+def g13_bmvs_dataset():
+    """The reference's BMVSDataset / BMVSDatasetFinetune (datasets/bmvs.py, bmvs_finetune.py) on the synthetic tree of
+    tests/bmvs_fixture.py: one val and one train item, and the fine-tune dataset's three accessors."""
+    import random
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import bmvs_fixture
+    _install_cv2_stub()
+    from datasets.bmvs import BMVSDataset
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        bmvs_fixture.make_bmvs_tree(root)
+        for mode, idx in (("val", 1), ("train", 0)):
+            ds = BMVSDataset(_Conf(bmvs_fixture.conf_values(root, mode)), mode)
+            random.seed(5)
+            np.random.seed(6)
+            torch.manual_seed(7)
+            item = ds[idx]
+            out[f"{mode}_len"] = len(ds)
+            _dump_item(out, mode, item)
+        from datasets.bmvs_finetune import BMVSDatasetFinetune
+        torch.manual_seed(11)
+        ft = BMVSDatasetFinetune(_Conf(bmvs_fixture.finetune_conf_values(root)), "finetune")
+        items = {"all": ft.get_all_images(), "rand": ft.get_random_rays(torch.tensor(1)), "at": ft.get_rays_at(2)}
+        out["ft.scale_mat"] = ft.scale_mat.numpy()
+        out["ft.masks"] = ft.masks.numpy()
+        for name, item in items.items():
+            _dump_item(out, f"ft.{name}", item)
+    npz("g13_bmvs_dataset", **out)
 
 
 def main():
     _install_shims()
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_dtu_dataset()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":
+        g13_bmvs_dataset()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
         g11_lncc()
@@ -487,6 +525,7 @@ def main():
     g10_geometry(surf, vols)
     g11_lncc()
     g12_dtu_dataset()
+    g13_bmvs_dataset()
     leaked = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

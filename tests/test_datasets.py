@@ -1,6 +1,7 @@
-"""Dataset front-end: gens_amd.datasets.DTUDataset against the reference's DTUDataset
-(/root/reference/datasets/dtu.py) run on the same synthetic tree (tests/dtu_fixture.py) with the same RNG seeds --
-golden g12 (tests/golden/make_golden.py::g12_dtu_dataset; cv2 stubbed there, see its docstring)."""
+"""Dataset front-end: gens_amd.datasets.{DTUDataset, DTUDatasetFinetune, BMVSDataset, BMVSDatasetFinetune}
+against the reference's classes (/root/reference/datasets/*.py) run on the same synthetic trees (tests/dtu_fixture.py,
+tests/bmvs_fixture.py) with the same RNG seeds -- goldens g12 / g13 (tests/golden/make_golden.py; cv2 stubbed there, see
+_install_cv2_stub)."""
 import os
 import random
 
@@ -10,7 +11,10 @@ import torch
 
 from gens_amd.config import Conf
 from gens_amd.datasets import DTUDataset, camera
-from tests import dtu_fixture
+import sys
+sys.path.insert(0, os.path.dirname(__file__))          # the fixtures import each other by bare name (the golden generator does too)
+import bmvs_fixture  # noqa: E402
+import dtu_fixture  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -97,7 +101,7 @@ def test_get_loader_runs_a_val_pass(tree):
     items = list(loader)
     assert len(items) == 2 and items[0]["rays_o"].shape == (30 * 40, 3) and tuple(items[0]["hw"].tolist()) == (30, 40)
     with pytest.raises(NotImplementedError):
-        get_loader(Conf({"dataset_name": "BMVSDataset"}), "val", False)
+        get_loader(Conf({"dataset_name": "NoSuchDataset"}), "val", False)
 
 
 def test_finetune_dataset_matches_the_reference(tree, golden):
@@ -125,3 +129,62 @@ def test_finetune_dataset_matches_the_reference(tree, golden):
         assert set(item) == want_keys, (name, set(item) ^ want_keys)
         for k in want_keys:
             same(item[k], golden[f"ft.{name}.{k}"], f"{name}.{k}")
+
+
+# ------------------------------------------------------------------------------------------------------- BlendedMVS
+@pytest.fixture(scope="module")
+def bmvs_tree(tmp_path_factory):
+    return bmvs_fixture.make_bmvs_tree(str(tmp_path_factory.mktemp("bmvs")))
+
+
+@pytest.fixture(scope="module")
+def bmvs_golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_bmvs_dataset.npz"))
+
+
+def _same(got, want, what):
+    if isinstance(got, str):
+        assert got == str(want), what
+    elif isinstance(got, (int, np.integer)):
+        assert int(got) == int(want), what
+    elif isinstance(got, list):
+        assert got == [int(x) for x in want], what
+    else:
+        got = got.numpy()
+        assert got.shape == want.shape and str(got.dtype) == str(want.dtype), (what, got.shape, got.dtype, want.shape, want.dtype)
+        if got.dtype.kind in "iu":
+            assert np.array_equal(got, want), what
+        else:          # the camera decomposition runs through a different factorisation (QR vs scipy RQ / SVD): float32 round-off
+            scale = max(1.0, float(np.abs(want).max()))
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-5 * scale, what
+
+
+@pytest.mark.parametrize("mode,idx", [("val", 1), ("train", 0)])
+def test_bmvs_item_matches_the_reference(bmvs_tree, bmvs_golden, mode, idx):
+    from gens_amd.datasets import BMVSDataset
+    ds = BMVSDataset(Conf(bmvs_fixture.conf_values(bmvs_tree, mode)), mode)
+    assert len(ds) == int(bmvs_golden[f"{mode}_len"])
+    random.seed(5)
+    np.random.seed(6)
+    torch.manual_seed(7)
+    item = ds[idx]
+    want_keys = {k.split(".", 1)[1] for k in bmvs_golden.files if k.startswith(mode + ".")}
+    assert set(item) == want_keys
+    for k in sorted(want_keys):
+        _same(item[k], bmvs_golden[f"{mode}.{k}"], k)
+    assert float(item["masks"].mean()) > 0.2 and float(item["masks"].mean()) < 0.9       # the object mask is neither empty nor full
+
+
+def test_bmvs_finetune_dataset_matches_the_reference(bmvs_tree, bmvs_golden):
+    from gens_amd.datasets import BMVSDatasetFinetune, get_loader
+    torch.manual_seed(11)
+    ft = get_loader(Conf(bmvs_fixture.finetune_conf_values(bmvs_tree)), "finetune", False)
+    assert isinstance(ft, BMVSDatasetFinetune) and not hasattr(ft, "pseudo_ptses")
+    items = {"all": ft.get_all_images(), "rand": ft.get_random_rays(torch.tensor(1)), "at": ft.get_rays_at(2)}
+    _same(ft.scale_mat, bmvs_golden["ft.scale_mat"], "scale_mat")
+    _same(ft.masks, bmvs_golden["ft.masks"], "masks")
+    for name, item in items.items():
+        want_keys = {k.split(".", 2)[2] for k in bmvs_golden.files if k.startswith(f"ft.{name}.")}
+        assert set(item) == want_keys, (name, set(item) ^ want_keys)
+        for k in want_keys:
+            _same(item[k], bmvs_golden[f"ft.{name}.{k}"], f"{name}.{k}")
