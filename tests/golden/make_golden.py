@@ -498,6 +498,41 @@ def g13_bmvs_dataset():
     npz("g13_bmvs_dataset", **out)
 
 
+def g14_clean_mesh():
+    """The reference's clean_mesh_by_mask (utils/clean_mesh.py:9-35) on a lattice mesh seen by the synthetic cameras.  Its module
+    imports skimage / trimesh / open3d, none of which the function uses: empty stubs; the mesh is a stand-in with the three
+    members the function touches (vertices, faces, update_faces)."""
+    for name in ("skimage", "skimage.morphology", "trimesh", "open3d"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["skimage"].morphology = sys.modules["skimage.morphology"]
+    from utils.clean_mesh import clean_mesh_by_mask
+    sys.path.insert(0, REPO)
+    from gens_amd import synthetic
+    intrs, c2ws, _, _ = synthetic.make_cameras(5, 48, 64)
+    g = torch.Generator().manual_seed(140)
+    n = 14
+    lin = torch.linspace(-1.2, 1.2, n)
+    vx, vy = torch.meshgrid(lin, lin, indexing="ij")
+    verts = torch.stack([vx, vy, 0.4 * torch.sin(3 * vx) * torch.cos(2 * vy)], -1).reshape(-1, 3) + 0.01 * torch.randn(n * n, 3, generator=g)
+    idx = torch.arange(n * n).reshape(n, n)
+    faces = torch.cat([torch.stack([idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:]], -1).reshape(-1, 3),
+                       torch.stack([idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]], -1).reshape(-1, 3)]).numpy()
+    yy, xx = torch.meshgrid(torch.arange(48.0), torch.arange(64.0), indexing="ij")
+    masks = torch.stack([(((xx - 32 - 4 * v) / 22) ** 2 + ((yy - 24) / 17) ** 2 < 1).float() for v in range(5)])
+
+    class Mesh:
+        def __init__(self):
+            self.vertices, self.faces = verts.double().numpy(), faces.copy()
+
+        def update_faces(self, keep):
+            self.faces = self.faces[keep]
+
+    out = {"vertices": verts.double().numpy(), "faces": faces, "masks": masks, "intrs": intrs, "c2ws": c2ws}
+    for nb in (1, 2):
+        out[f"kept{nb}"] = clean_mesh_by_mask(Mesh(), masks, intrs, c2ws, min_nb_visible=nb).faces
+    npz("g14_clean_mesh", **out)
+
+
 def main():
     _install_shims()
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
@@ -505,6 +540,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g13":
         g13_bmvs_dataset()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_clean_mesh()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
         g11_lncc()
@@ -526,6 +564,7 @@ def main():
     g11_lncc()
     g12_dtu_dataset()
     g13_bmvs_dataset()
+    g14_clean_mesh()
     leaked = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 
