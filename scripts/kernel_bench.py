@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Isolated per-kernel measurement of the gather / per-ray kernels (SURVEY.md section 8d timing protocol):
->= 20 warm-up + >= 100 timed launches each, HIP events on the launch stream, median / p10 / p90 and the algorithmic
-HBM fraction (A / t against 8 TB/s).  Shapes are those of one bench.py ray chunk (32 768 rays, 5 views, dims 256/128/64).
+>= 20 warm-up + >= 100 timed launches each (after ~60 ms of work that brings the clocks up), HIP events on the launch stream,
+median / p10 / p90 and the algorithmic HBM fraction (A / t against 8 TB/s).  Shapes are those of one bench.py ray chunk (32 768 rays, 5 views, dims 256/128/64).
 
     python scripts/kernel_bench.py [--out profiles/rNN_kernels_isolated.json] [--iters 100]
 """
@@ -67,6 +67,11 @@ def main():
               f"{r['GBs']:8.1f} GB/s  {100 * r['hbm_frac']:5.1f} %", flush=True)
 
     with torch.no_grad():
+        # clocks up first: the first ~10 ms of work after idle run up to 25 % slower (scripts/probe/README.md)
+        tex0 = ops.pack_nchw(feats[0])
+        for _ in range(300):
+            ops._VolumeBuild.apply(tex0, w2c, intrs, 1.0, dims[0], 1)
+        torch.cuda.synchronize()
         # ---- K1 per level
         for lvl, d in enumerate(dims):
             tex = ops.pack_nchw(feats[lvl])
