@@ -320,6 +320,16 @@ class ImplicitSurface(nn.Module):
     # ----------------------------------------------------------------------------------------------------------
     # render
     # ----------------------------------------------------------------------------------------------------------
+    def _coarse_steps(self, dev):
+        """torch.linspace(0, 1, n_samples) as the reference computes it (on the host, implicit_surface.py:357), uploaded ONCE per
+        device: a pageable host-to-device copy waits for the stream to drain on ROCm, which put the host in lock-step with the GPU
+        once per ray chunk (10 ms of idle GPU per 480x640 image)."""
+        cached = getattr(self, "_steps_cache", None)
+        if cached is None or cached[0] != self.n_samples or cached[1].device != dev:
+            cached = (self.n_samples, torch.linspace(0.0, 1.0, self.n_samples).to(dev))
+            self._steps_cache = cached
+        return cached[1]
+
     def render(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, cos_anneal_ratio, step,
                scene=None, lean=False, t_rand=None, pts_random=None):
         if scene is None:
@@ -328,7 +338,7 @@ class ImplicitSurface(nn.Module):
         dev = rays_o.device
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         sample_dist = 2.0 / self.n_samples                                                  # unit-sphere assumption (:355)
-        steps = torch.linspace(0.0, 1.0, self.n_samples).to(dev)
+        steps = self._coarse_steps(dev)
         z_vals = near.reshape(-1, 1) + (far - near).reshape(-1, 1) * steps[None, :]
         z_vals = z_vals.expand(b, self.n_samples)
         if self.perturb > 0:
