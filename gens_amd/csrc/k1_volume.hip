@@ -406,6 +406,25 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     if (wave == 0) __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[8][4 * q], mplane, off, 0u, NT);
 }
 
+// All levels of a scene in ONE launch: the small levels (a few hundred workgroups, latency-bound on their own: 28 + 10 us for
+// 128^3 + 64^3) run in the shadow of the large one.  Blocks [first[l], first[l + 1]) belong to level l.
+struct VolumeLevels {
+    const float4* feat[GENS_MAX_LEVELS];
+    const float* intr[GENS_MAX_LEVELS];          // (nv, 4, 4) per level, rows 0-1 pre-scaled by 0.5^level
+    float* vol[GENS_MAX_LEVELS];
+    float* mask[GENS_MAX_LEVELS];
+    int h[GENS_MAX_LEVELS], w[GENS_MAX_LEVELS], d[GENS_MAX_LEVELS];
+    LevelConst lc[GENS_MAX_LEVELS];
+    uint32_t first[GENS_MAX_LEVELS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis) {
+    int l = 0;
+    while (l + 1 < lv.n && blockIdx.x >= lv.first[l + 1]) ++l;                     // scalar: blockIdx and the table are uniform
+    volume_build_chunk(blockIdx.x - lv.first[l], lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l]);
+}
+
 __global__ __launch_bounds__(256) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                                const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc,
                                                                int min_vis, float* __restrict__ vol, float* __restrict__ mask) {
@@ -493,6 +512,18 @@ static int check_volume_args(const char* who, const void* a, const void* b, cons
     return 0;
 }
 
+static LevelConst level_const(int h, int w, int d) {      // the float32 operations the reference performs per voxel, done once
+    LevelConst lc;
+    lc.step = (1.0f - (-1.0f)) / (float)(d - 1);
+    lc.cw = (float)(w - 1) / 2.0f;
+    lc.ch = (float)(h - 1) / 2.0f;
+    lc.rcw = 1.0f / lc.cw;
+    lc.rch = 1.0f / lc.ch;
+    lc.log2d = 0;
+    while ((1 << lc.log2d) < d) ++lc.log2d;
+    return lc;
+}
+
 extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,
                                      int h, int w, int d, int min_vis_view, float* volume, float* mask, void* stream) {
     if (int e = check_volume_args("gens_volume_build_fwd", feat, w2c, intr, nv, h, w, d)) return e;
@@ -500,14 +531,7 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
     int64_t n = (int64_t)d * d * d;
     const bool pow2 = d >= 2 && d <= 256 && (d & (d - 1)) == 0;
     if (pow2 && !getenv("GENS_K1_GENERIC")) {                 // (the environment switch keeps the generic kernel reachable for A/B tests)
-        LevelConst lc;
-        lc.step = (1.0f - (-1.0f)) / (float)(d - 1);
-        lc.cw = (float)(w - 1) / 2.0f;
-        lc.ch = (float)(h - 1) / 2.0f;
-        lc.rcw = 1.0f / lc.cw;
-        lc.rch = 1.0f / lc.ch;
-        lc.log2d = 0;
-        while ((1 << lc.log2d) < d) ++lc.log2d;
+        const LevelConst lc = level_const(h, w, d);
         if (d >= 8 && nv <= GENS_MAX_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
             volume_build_fwd_lean_k<<<(unsigned)(n / 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
                                                                                      min_vis_view, volume, mask);
@@ -526,6 +550,43 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
     volume_build_fwd_k<<<gens_blocks(n, 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, intr_scale, nv,
                                                                             h, w, d, min_vis_view, volume, mask);
     return gens_launch_status("gens_volume_build_fwd");
+}
+
+extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                        const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
+                                        void* stream) {
+    GENS_CHECK_ARG(feat && hw && dims && w2c && intr && volumes && masks, GENS_EINVAL, "gens_volume_build_levels: null table");
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_volume_build_levels: %d levels (1..%d)", n_levels, GENS_MAX_LEVELS);
+    bool one_launch = nv <= GENS_MAX_VIEWS && !getenv("GENS_K1_GENERIC") && !getenv("GENS_K1_SINGLE") && !getenv("GENS_K1_PER_LEVEL");
+    for (int l = 0; l < n_levels; ++l) {
+        if (int e = check_volume_args("gens_volume_build_levels", feat[l], w2c, intr[l], nv, hw[2 * l], hw[2 * l + 1], dims[l])) return e;
+        GENS_CHECK_ARG(volumes[l] && masks[l], GENS_EINVAL, "gens_volume_build_levels: null output (level %d)", l);
+        const int d = dims[l];
+        one_launch = one_launch && d >= 8 && d <= 256 && (d & (d - 1)) == 0;
+    }
+    if (!one_launch) {                                                             // sizes the fused kernel does not cover: level by level
+        for (int l = 0; l < n_levels; ++l)
+            if (int e = gens_volume_build_fwd(feat[l], w2c, intr[l], 1.0f, nv, hw[2 * l], hw[2 * l + 1], dims[l], min_vis_view, volumes[l], masks[l], stream))
+                return e;
+        return 0;
+    }
+    VolumeLevels lv;
+    lv.n = n_levels;
+    lv.first[0] = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int d = dims[l];
+        lv.feat[l] = (const float4*)feat[l];
+        lv.intr[l] = intr[l];
+        lv.vol[l] = volumes[l];
+        lv.mask[l] = masks[l];
+        lv.h[l] = hw[2 * l];
+        lv.w[l] = hw[2 * l + 1];
+        lv.d[l] = d;
+        lv.lc[l] = level_const(hw[2 * l], hw[2 * l + 1], d);
+        lv.first[l + 1] = lv.first[l] + (uint32_t)(((int64_t)d * d * d) / 256);
+    }
+    volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view);
+    return gens_launch_status("gens_volume_build_levels");
 }
 
 extern "C" int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,

@@ -134,21 +134,61 @@ class _VolumeBuild(torch.autograd.Function):
         return g, None, None, None, None, None
 
 
+class _VolumeBuildLevels(torch.autograd.Function):
+    """All levels of a scene in one launch (gens_volume_build_levels); the backward runs level by level."""
+
+    @staticmethod
+    def forward(ctx, w2c, dims, min_vis, *tex_and_intr):
+        n = len(dims)
+        texs, intrs = tex_and_intr[:n], tex_and_intr[n:]
+        dev = w2c.device
+        nv = texs[0].shape[0]
+        vols = [torch.empty(1, 8, d, d, d, device=dev, dtype=_f32) for d in dims]
+        masks = [torch.empty(1, 1, d, d, d, device=dev, dtype=_f32) for d in dims]
+        hw = [x for t in texs for x in (t.shape[1], t.shape[2])]
+        for t in texs:
+            assert t.shape[0] == nv and t.shape[3] == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
+        texs_c = [_c(t) for t in texs]
+        L.call("gens_volume_build_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv, min_vis,
+               L.ptr_table(vols), L.ptr_table(masks), L.stream(), nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)))
+        ctx.save_for_backward(w2c, *texs, *intrs)
+        ctx.dims = list(dims)
+        ctx.mark_non_differentiable(*masks)
+        return (*vols, *masks)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = len(ctx.dims)
+        w2c, rest = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        texs, intrs = rest[:n], rest[n:]
+        out = []
+        for l, d in enumerate(ctx.dims):
+            if grads[l] is None or not ctx.needs_input_grad[3 + l]:
+                out.append(None)
+                continue
+            nv, h, w, _ = texs[l].shape
+            g = torch.zeros_like(texs[l])
+            L.call("gens_volume_build_bwd", L.ptr(_c(texs[l])), L.ptr(w2c), L.ptr(intrs[l]), 1.0, nv, h, w, d, L.ptr(_c(grads[l])), L.ptr(g), L.stream())
+            out.append(g)
+        return (None, None, None, *out, *([None] * n))
+
+
 def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
-    """features: list of (nv,4,H_i,W_i) NCHW -> (volumes [(1,8,D,D,D)], masks [(1,1,D,D,D)])."""
+    """features: list of (nv,4,H_i,W_i) NCHW -> (volumes [(1,8,D,D,D)], masks [(1,1,D,D,D)]).  One launch for all levels."""
     dev = features[0].device
     w2c = _dev_f32(torch.linalg.inv(c2ws.to(_f32)), dev)
     intr = _dev_f32(intrs, dev)
-    vols, masks = [], []
-    for lvl, d in enumerate(dims):
-        # rows 0-1 of the intrinsics times 0.5^lvl (Q2), multiplied here once in float32 -- the same product the kernel would
-        # form per voxel and view -- and handed over with scale 1 (the kernel's pre-scaled fast path)
+    ks = []
+    for lvl in range(len(dims)):
+        # rows 0-1 of the intrinsics times 0.5^lvl (Q2), multiplied here once in float32 -- the same product the reference forms
+        # per level (volume.py:24-25)
         k = intr.clone()
         k[:, :2] = k[:, :2] * torch.tensor(0.5 ** lvl, device=dev, dtype=_f32)
-        v, m = _VolumeBuild.apply(pack_nchw(features[lvl].to(_f32)), w2c, k, 1.0, int(d), int(min_vis_view))
-        vols.append(v)
-        masks.append(m)
-    return vols, masks
+        ks.append(k)
+    texs = [pack_nchw(features[lvl].to(_f32)) for lvl in range(len(dims))]
+    out = _VolumeBuildLevels.apply(w2c, [int(d) for d in dims], int(min_vis_view), *texs, *ks)
+    n = len(dims)
+    return list(out[:n]), list(out[n:])
 
 
 # ------------------------------------------------------------------------------------------------------------------

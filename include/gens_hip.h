@@ -66,6 +66,12 @@ int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr
                           int w, int d, int min_vis_view, float* volume, float* mask, void* stream);
 int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
                           int w, int d, const float* g_volume, float* g_feat, void* stream);
+/* All levels of one scene in a single launch (volume.py:21-61 is a loop over the levels): feat[l] (nv, H_l, W_l, 4) texels,
+ * hw = {H_0, W_0, H_1, W_1, ...}, intr[l] (nv, 4, 4) with rows 0-1 already multiplied by 0.5^l, volumes[l] (8, D_l^3), masks[l] (D_l^3).
+ * Same results as n_levels calls of gens_volume_build_fwd with intr_scale = 1 (which it falls back to for sizes the fused kernel
+ * does not cover). */
+int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                             const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks, void* stream);
 /* Self-test of K1's exact-division shortcuts (RN(1/b) from v_rcp_f32 + one FMA refinement; a/b from that reciprocal + FMA
  * correction) against the IEEE division over all 2^32 float32 bit patterns: counts[0] += reciprocal mismatches,
  * counts[1] += quotient mismatches (device array of 2, zeroed by the caller).  Both stay 0. */

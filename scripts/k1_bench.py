@@ -31,3 +31,28 @@ for lvl, d in enumerate([256, 128, 64]):
     ms = s.elapsed_time(e) / 20
     a = nv * h * w * 16 + 36 * d ** 3
     print(f"K1 D={d}: {ms * 1e3:8.1f} us  {a / 1e6:7.1f} MB algorithmic  {a / ms / 1e6:7.1f} GB/s  ({a / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)")
+
+# the whole scene (3 levels): one launch (production) against level-by-level launches (GENS_K1_PER_LEVEL=1)
+import statistics  # noqa: E402
+dims = [256, 128, 64]
+a = sum(5 * (480 >> i) * (640 >> i) * 16 + 36 * d ** 3 for i, d in enumerate(dims))
+with torch.no_grad():
+    for _ in range(100):
+        ops.volume_build(feats[:3], intrs, c2ws, dims)
+    for env in (None, "GENS_K1_PER_LEVEL"):
+        if env:
+            os.environ[env] = "1"
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                ops.volume_build(feats[:3], intrs, c2ws, dims)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e) / 20 * 1e3)
+        us = statistics.median(ts)
+        print(f"K1 scene ({'per level' if env else 'one launch'}, incl. texel packing + matrix inverse): {us:8.1f} us  {a / 1e6:7.1f} MB algorithmic  {a / us / 8e6 * 100:.1f}% of 8 TB/s")
+        if env:
+            del os.environ[env]
