@@ -197,3 +197,25 @@ def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
         for a, b in zip(fast[0] + fast[1], ref[0] + ref[1]):
             assert torch.equal(a, b)
     assert seen > 1e5                                                        # the rigs do see the cube
+    # structured worst cases for the interval arithmetic: optical axis along the z-rows (image coordinates constant along a row),
+    # perpendicular to them, a camera inside the cube, one in a corner looking at the far corner, one looking away
+    def look(eye, target, up=(0.0, 1.0, 0.0)):
+        eye, target, up = (torch.tensor(v, dtype=torch.float64) for v in (eye, target, up))
+        z = (target - eye) / torch.linalg.norm(target - eye)
+        x = torch.linalg.cross(up, z)
+        x = x / torch.linalg.norm(x)
+        y = torch.linalg.cross(z, x)
+        c2w = torch.eye(4, dtype=torch.float64)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = x, y, z, eye
+        return c2w
+    rig = torch.stack([look((0.0, 0.0, -2.2), (0.0, 0.0, 0.0)), look((2.2, 0.0, 0.0), (0.0, 0.0, 0.0)), look((0.1, -0.2, 0.3), (1.0, 0.3, -0.5)),
+                       look((1.0, 1.0, 1.0), (-1.0, -1.0, -1.0), up=(0.0, 0.0, 1.0)), look((0.0, 0.0, -2.2), (0.0, 0.0, -5.0))]).float().cuda()
+    fast = ops.volume_build(feats, intrs, rig, dims[:4])
+    os.environ["GENS_K1_GENERIC"] = "1"
+    try:
+        ref = ops.volume_build(feats, intrs, rig, dims[:4])
+    finally:
+        del os.environ["GENS_K1_GENERIC"]
+    assert float(ref[1][0].mean()) > 0.05
+    for a, b in zip(fast[0] + fast[1], ref[0] + ref[1]):
+        assert torch.equal(a, b)
