@@ -372,6 +372,35 @@ def g10_geometry(surf, vols):
     npz("g10_geometry", u=grabbed["u"].astype(np.float32), resolution=np.int64(65))
 
 
+def g15_validate(surf, sc, vols, masks):
+    """The reference's ImplicitSurface.validate (implicit_surface.py:429-470) on a 24 x 32 image: three 256-ray chunks, each drawing
+    its jitter and its 1024 random points from the CPU generator, image assembly, normal rotation, the * 256 / * 128 + 128 scalings
+    and clips (Q15); the SDF lattice handed to marching cubes (PyMCubes is absent: a stub records it)."""
+    import mcubes
+    grabbed = {}
+    mcubes.marching_cubes = lambda u, t: (grabbed.setdefault("u", u.copy()), (np.zeros((1, 3)), np.zeros((0, 3), dtype=np.int64)))[1]
+    h, w = 48, 64
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w, step=2)
+    bmin, bmax = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0])
+    match_feats = [f + 0.01 for f in sc["features"]]
+    torch.manual_seed(1500)
+    with torch.no_grad():
+        out = surf.validate(rays_o, rays_d, sc["near"], sc["far"], vols, masks, sc["imgs"], sc["features"], match_feats, sc["intrs"], sc["c2ws"],
+                            bmin, bmax, (h // 2, w // 2), cos_anneal_ratio=1.0, step=None, extract_geometry=True, mesh_resolution=33, threshold=0.0)
+    d = dict(rays_o=rays_o, rays_d=rays_d, near=sc["near"], far=sc["far"], imgs=sc["imgs"], intrs=sc["intrs"], c2ws=sc["c2ws"],
+             rng_seed=np.int64(1500), u=grabbed["u"].astype(np.float32), hw=np.array([h // 2, w // 2]))
+    for i in range(5):
+        d[f"feat{i}"] = sc["features"][i]
+    for i in range(3):
+        d[f"vol{i}"] = vols[i]
+        d[f"mask{i}"] = masks[i]
+    for k, v in surf.state_dict().items():
+        d["sd." + k] = v
+    for k in ("color_fine", "img_fine", "normal_img", "sdf_depth", "render_depth"):
+        d["out." + k] = out[k]
+    npz("g15_validate", **d)
+
+
 def g11_lncc():
     """compute_LNCC (models/losses/ncc.py:7-55): forward + gradients w.r.t. both patch tensors for a fixed cotangent."""
     from models.losses.ncc import compute_LNCC
@@ -544,6 +573,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14_clean_mesh()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g15":           # the validate golden (needs the model of g9b)
+        from models.modules.volume import Volume
+        from models.modules import implicit_surface as isurf_mod
+        surf, sc, vols, masks = g9_render(isurf_mod, Volume, "g9b_render", seed=95, cos_anneal=1.0, step=7, n_rays=16, variance=0.55)
+        g15_validate(surf, sc, vols, masks)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
         g11_lncc()
         return
@@ -561,6 +596,7 @@ def main():
     g9_render(isurf_mod, Volume, "g9a_render", seed=90, cos_anneal=0.5, step=None, n_rays=24)
     surf, sc, vols, masks = g9_render(isurf_mod, Volume, "g9b_render", seed=95, cos_anneal=1.0, step=7, n_rays=16, variance=0.55)
     g10_geometry(surf, vols)
+    g15_validate(surf, sc, vols, masks)
     g11_lncc()
     g12_dtu_dataset()
     g13_bmvs_dataset()

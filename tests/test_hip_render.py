@@ -124,6 +124,39 @@ def test_sdf_grid_matches_reference(golden):
     close(u, g["u"], atol=2e-5, rtol=1e-4, what="-sdf lattice")
 
 
+@pytest.mark.parametrize("chunk,precision", [(512, "f32"), (8192, "f32"), (256, "f16x2")])
+def test_validate_matches_the_reference_validate(golden, chunk, precision):
+    """The reference's own ImplicitSurface.validate (implicit_surface.py:429-470; three 256-ray chunks, golden g15) against the
+    fused inference path with a different chunking: the jitter of every ray is the reference's (reference_jitter reproduces its
+    chunk-by-chunk draws), colour / depth L1 within the north-star 1e-4, the images with their * 256 / * 128 + 128 scalings and
+    clips (Q15), the SDF lattice handed to the iso-surface extraction."""
+    g = golden("g15_validate")
+    gg = dict(g)
+    gg["step"] = torch.tensor(-1.0)
+    surf = build_surface(gg)
+    feats, vols, masks, match, _ = scene_inputs(gg)
+    c = lambda t: t.cuda()  # noqa: E731
+    surf.val_chunk = chunk
+    surf.sdf_precision = precision
+    h, w = (int(x) for x in g["hw"])
+    torch.manual_seed(int(g["rng_seed"]))
+    out = surf.validate(c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]), c(g["c2ws"]),
+                        torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1]), torch.tensor([h, w]).int(), extract_geometry=True, mesh_resolution=33)
+    assert set(out) == {"vertices", "triangles", "color_fine", "img_fine", "normal_img", "sdf_depth", "render_depth"}
+    for k in ("color_fine", "render_depth", "sdf_depth"):
+        assert tuple(out[k].shape) == tuple(g["out." + k].shape), k
+        assert (torch.as_tensor(out[k]) - g["out." + k]).abs().mean() < 1e-4, k
+    assert (torch.as_tensor(out["img_fine"]) - g["out.img_fine"]).abs().mean() < 256e-4
+    assert (torch.as_tensor(out["normal_img"]) - g["out.normal_img"]).abs().mean() < 2e-2          # 128 x the normal's 1e-4
+    assert out["img_fine"].min() >= 0 and out["img_fine"].max() <= 255 and out["normal_img"].min() >= 0 and out["normal_img"].max() <= 255
+    close(torch.as_tensor(out["sdf_depth"]) > 0, g["out.sdf_depth"] > 0, atol=0, rtol=0, what="rays with a surface crossing", frac=0.005)
+    # the lattice the reference hands to marching cubes, and a mesh through it
+    u = surf.sdf_grid(vols, torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1]), 33)
+    close(u, g["u"], atol=2e-5, rtol=1e-4, what="-sdf lattice")
+    assert out["vertices"].shape[1] == 3 and out["triangles"].shape[1] == 3 and len(out["triangles"]) > 0
+    assert out["vertices"].min() >= -1.0 - 1e-6 and out["vertices"].max() <= 1.0 + 1e-6
+
+
 def test_partition_invariance_of_validate(golden):
     """Rays are independent: any chunking of validate() renders the same image (property tests)."""
     g = golden("g9a_render")
