@@ -106,10 +106,10 @@ def main():
             out = surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, hw,
                                 extract_geometry=False, scene=scene)
         if dist is not None:                                                             # config 4: gather of rendered buffers
-            buf = torch.cat([out["color_fine"].reshape(-1, 3), torch.from_numpy(out["render_depth"]).reshape(-1, 1),
-                             torch.from_numpy(out["sdf_depth"]).reshape(-1, 1)], 1).to(dev)
-            gathered = [torch.empty_like(buf) for _ in range(world)]
-            dist.all_gather(gathered, buf)
+            buf = surf.last_device_image                                                 # (P, 8) rgb | normal | sdf depth | rendered depth, on the device
+            gathered = torch.empty(world * buf.shape[0], buf.shape[1], device=dev, dtype=buf.dtype)
+            dist.all_gather_into_tensor(gathered, buf)                                   # RCCL over xGMI, device to device
+            state["gathered"] = gathered
         state["out"], state["masks"], state["cost"] = out, masks, cost_volumes
 
     def sync():

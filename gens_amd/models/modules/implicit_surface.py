@@ -404,6 +404,7 @@ class ImplicitSurface(nn.Module):
             image[s:e, 7] = r["render_depth"].reshape(-1)
         if jitter is not None:
             jitter.join()
+        self.last_device_image = image      # (P, 8) [rgb | normal | sdf_depth | render_depth] on the device: what a multi-GPU driver gathers
         if self._split_half_overflowed():              # a value left the half range: render this image again in float32
             saved, self.sdf_precision = self.sdf_precision, "f32"
             try:
