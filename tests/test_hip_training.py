@@ -1,5 +1,7 @@
 """GPU tests of the training path (BASELINE config 3 / 5): backward through the HIP look-up (first + second order),
 compositing, feature-warp, patch-warp and TV kernels; GenS.forward in train and fine-tune mode with stand-in CNNs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -257,3 +259,38 @@ def test_finetune_dataset_drives_the_per_scene_path(tmp_path):
     with torch.no_grad():
         val = model.eval()("val", item, 1.0, None)
     assert val["img_fine"].shape == (32, 40, 3)
+
+
+def test_bmvs_datasets_drive_val_finetune_and_the_writers(tmp_path):
+    """BlendedMVS front-ends (BASELINE config 5's evaluation set) through the same plumbing: a BMVSDataset val item through
+    GenS.forward("val"), the per-scene fine-tune path on BMVSDatasetFinetune (no pseudo points there), and the validation outputs
+    stored the way runner.py:229-246 stores them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import bmvs_fixture
+    from gens_amd import io
+    from gens_amd.config import Conf
+    from gens_amd.datasets import BMVSDataset, BMVSDatasetFinetune
+    root = bmvs_fixture.make_bmvs_tree(str(tmp_path / "bmvs"))
+    dev = lambda item: {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in item.items()}  # noqa: E731
+    conf = bmvs_fixture.conf_values(root, "val")
+    conf["img_hw"] = [64, 80]
+    conf["val_res_level"] = 4
+    item = dev(BMVSDataset(Conf(conf), "val")[0])
+    model = _gens().eval()
+    with torch.no_grad():
+        val = model("val", item, 1.0, None)
+    assert val["img_fine"].shape == (16, 20, 3) and val["sdf_depth"].shape == (16, 20) and val["triangles"].shape[1] == 3
+    paths = io.save_validation_outputs(str(tmp_path / "exp"), val, item, "epoch0", clean=True)
+    v, t = io.read_ply(paths["mesh"])
+    assert len(t) <= len(val["triangles"]) and v.shape[0] == val["vertices"].shape[0] and os.path.getsize(paths["normal"]) > 0
+    ft_conf = bmvs_fixture.finetune_conf_values(root)
+    ft_conf["img_hw"] = [64, 80]
+    ds = BMVSDatasetFinetune(Conf(ft_conf), "finetune")
+    model = _gens()
+    model.init_volumes(dev(ds.get_all_images()))
+    out = model("finetune", dev(ds.get_random_rays(torch.tensor(2))), 1.0, None)
+    assert "pseudo_sdf" not in out                                  # BlendedMVS has no pseudo-depth points (bmvs_finetune.py:233-266)
+    loss = _loss(out)
+    loss.backward()
+    assert torch.isfinite(loss) and all(vol.grad is not None for vol in model.volumes)
