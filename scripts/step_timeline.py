@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gens_amd import ops, synthetic
 from gens_amd.config import gens_model_conf
 from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene, JitterStream

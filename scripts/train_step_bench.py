@@ -17,6 +17,8 @@ from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E4
 
 def main():
     dev = torch.device("cuda:0")
+    if os.environ.get("GENS_BLAS"):                                     # "hipblaslt" / "cublas" (rocBLAS): which GEMM library torch uses
+        torch.backends.cuda.preferred_blas_library(os.environ["GENS_BLAS"])
     dims = [256, 128, 64]
     sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
     imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
