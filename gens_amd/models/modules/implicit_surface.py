@@ -385,33 +385,38 @@ class ImplicitSurface(nn.Module):
         outputs = {}
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        height, width = int(hw[0]), int(hw[1])
+        n_rays = rays_o.shape[0]
+        # the jitter thread starts first: its ~1.5 ms per 32 768 rays (the reference's draw order costs 13 draws per ray) then hide behind
+        # the mesh extraction, which draws nothing from the generator
+        jitter = JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter")) if self.perturb > 0 else None
         if extract_geometry:
             outputs["vertices"], outputs["triangles"] = self.extract_geometry(scene.volumes_nograd(), bound_min, bound_max, mesh_resolution,
                                                                               threshold)
-        height, width = int(hw[0]), int(hw[1])
-        n_rays = rays_o.shape[0]
-        jitter = JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter")) if self.perturb > 0 else None
         # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
         # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
         image = torch.empty(n_rays, 8, device=rays_o.device, dtype=torch.float32)
-        for s in range(0, n_rays, self.val_chunk):
-            e = min(s + self.val_chunk, n_rays)
-            r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
-                            cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
-            image[s:e, 0:3] = r["color_fine"]
-            image[s:e, 3:6] = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1)
-            image[s:e, 6] = r["sdf_depth"].reshape(-1)
-            image[s:e, 7] = r["render_depth"].reshape(-1)
+
+        def render_image():
+            for s in range(0, n_rays, self.val_chunk):
+                e = min(s + self.val_chunk, n_rays)
+                r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
+                image[s:e, 0:3] = r["color_fine"]
+                image[s:e, 3:6] = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1)
+                image[s:e, 6] = r["sdf_depth"].reshape(-1)
+                image[s:e, 7] = r["render_depth"].reshape(-1)
+
+        render_image()
         if jitter is not None:
             jitter.join()
-        self.last_device_image = image      # (P, 8) [rgb | normal | sdf_depth | render_depth] on the device: what a multi-GPU driver gathers
-        if self._split_half_overflowed():              # a value left the half range: render this image again in float32
+        if self._split_half_overflowed():              # a value left the half range: the same image, same jitter, in float32
             saved, self.sdf_precision = self.sdf_precision, "f32"
             try:
-                return self.validate(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
-                                     bound_min, bound_max, hw, cos_anneal_ratio, step, extract_geometry, mesh_resolution, threshold, scene)
+                render_image()
             finally:
                 self.sdf_precision = saved
+        self.last_device_image = image      # (P, 8) [rgb | normal | sdf_depth | render_depth] on the device: what a multi-GPU driver gathers
         host = self._pinned(n_rays)
         host.copy_(image, non_blocking=True)
         rot = np.linalg.inv(c2ws[0, :3, :3].detach().cpu().numpy())                         # (synchronises: the image has landed too)

@@ -189,3 +189,29 @@ def test_validate_with_split_half_sdf_matches_float32(golden):
     for k in ["color_fine", "render_depth", "sdf_depth"]:
         a, b = torch.as_tensor(outs["f16x2"][k]), torch.as_tensor(outs["f32"][k])
         assert (a - b).abs().mean() < 1e-4, k
+
+
+def test_split_half_overflow_renders_the_image_again_in_float32_with_the_same_jitter(golden):
+    """A volume feature beyond the half range raises the split-half kernel's overflow flag; validate() then renders the SAME image (the
+    jitter already drawn, not a fresh draw from the generator) with the float32 kernel."""
+    g = golden("g9a_render")
+    surf = build_surface(g)
+    feats, vols, masks, match, step = scene_inputs(g)
+    vols = [v.clone() for v in vols]
+    vols[1][0, 2, 3:9, 3:9, 3:9] = 4.0e4                                          # > 3e4: not representable as a half pair
+    c = lambda t: t.cuda()  # noqa: E731
+    outs = {}
+    flagged = []
+    probe = surf._split_half_overflowed
+    surf._split_half_overflowed = lambda: flagged.append(probe()) or flagged[-1]
+    for prec in ("f32", "f16x2"):
+        surf.sdf_precision = prec
+        torch.manual_seed(3)
+        outs[prec] = surf.validate(c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match,
+                                   c(g["intrs"]), c(g["c2ws"]), None, None, (4, 6), extract_geometry=False)
+        after = torch.rand(1)                                                     # the generator is where the reference would leave it
+        outs[prec + ".next_draw"] = after
+    assert flagged == [False, True]                                               # the float32 run never asks; the split-half run overflowed
+    assert torch.equal(outs["f32.next_draw"], outs["f16x2.next_draw"])
+    for k in ["color_fine", "render_depth", "sdf_depth", "normal_img"]:
+        close(torch.as_tensor(outs["f16x2"][k]), torch.as_tensor(outs["f32"][k]), atol=1e-6, rtol=1e-6, what=k)
