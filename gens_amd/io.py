@@ -5,8 +5,8 @@
     val_render_depth/…png, val_sdf_depth/… depth maps through the magma colour map, fixed range [0, 2.5]          (runner.py:245-246, 379-392)
 
 and the mask-based mesh cleaning of utils/clean_mesh.py:9-35 (drop faces with a vertex that fewer than two source masks see).
-The ray-casting step of the reference's cleaning (clean_mesh_outside_frustum, utils/clean_mesh.py:38-106: pyembree through
-trimesh) is not rebuilt."""
+The ray-casting step of the reference's cleaning (clean_mesh_outside_frustum, utils/clean_mesh.py:38-99: pyembree through
+trimesh) is not rebuilt; its tail, the removal of small connected components (:101-106), is `drop_small_components`."""
 import os
 
 import numpy as np
@@ -85,6 +85,31 @@ def clean_mesh_by_mask(vertices, triangles, masks, intrs, c2ws, min_nb_visible=1
     valid = ((warp_mask > 0) * in_mask).sum(dim=0) > min_nb_visible
     tri = torch.from_numpy(np.asarray(triangles).astype(np.int64))
     return np.asarray(triangles)[valid[tri].all(dim=-1).numpy()]
+
+
+def drop_small_components(vertices, triangles, min_faces=500):
+    """utils/clean_mesh.py:101-106 without trimesh: keep the connected components (faces sharing an edge) of at least `min_faces`
+    faces and drop the vertices nothing references any more -> (vertices, triangles) re-indexed."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    tri = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
+    v = np.asarray(vertices)
+    if len(tri) == 0:
+        return v[:0], tri
+    # faces adjacent through a shared (undirected) edge: sort the three edges of every face, group equal edges
+    edges = np.sort(np.stack([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], 1).reshape(-1, 2), axis=1)
+    face_of = np.repeat(np.arange(len(tri)), 3)
+    order = np.lexsort((edges[:, 1], edges[:, 0]))
+    e, f = edges[order], face_of[order]
+    same = (e[1:] == e[:-1]).all(axis=1)
+    a, b = f[:-1][same], f[1:][same]
+    n_comp, label = connected_components(coo_matrix((np.ones(len(a), dtype=np.int8), (a, b)), shape=(len(tri), len(tri))), directed=False)
+    keep = np.bincount(label, minlength=n_comp)[label] >= min_faces
+    tri = tri[keep]
+    used = np.zeros(len(v), dtype=bool)
+    used[tri.reshape(-1)] = True
+    remap = np.cumsum(used) - 1
+    return v[used], remap[tri].astype(np.asarray(triangles).dtype if len(tri) else np.int64)
 
 
 def dilate_masks(masks, radius=11):

@@ -78,3 +78,24 @@ def test_depth_colour_map_and_validation_layout(tmp_path):
     assert np.array_equal(np.array(Image.open(paths["sdf_depth"])), rgb)
     step = io.save_validation_outputs(str(tmp_path), outputs, inputs, "step99", image_tag=0)          # fine-tune naming (runner.py:373)
     assert step["normal"].endswith("val_normal/0_step99.png")
+
+
+def test_drop_small_components_keeps_the_large_sheets():
+    def sheet(n, offset):
+        idx = np.arange(n * n).reshape(n, n) + offset
+        return np.concatenate([np.stack([idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:]], -1).reshape(-1, 3),
+                               np.stack([idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]], -1).reshape(-1, 3)])
+    big, small = sheet(20, 0), sheet(4, 400)                                     # 722 and 18 faces, no shared vertices
+    rng = np.random.default_rng(3)
+    verts = rng.standard_normal((400 + 16 + 5, 3))                               # + five vertices nothing references
+    tris = np.concatenate([small, big])
+    v, t = io.drop_small_components(verts, tris, min_faces=500)
+    assert len(t) == len(big) and len(v) == 400 and t.max() == 399
+    assert np.allclose(v[t], verts[big])                                         # same triangles, re-indexed
+    v2, t2 = io.drop_small_components(verts, tris, min_faces=10)
+    assert len(t2) == len(tris) and len(v2) == 416
+    v3, t3 = io.drop_small_components(verts, tris[:0], min_faces=10)
+    assert len(t3) == 0 and len(v3) == 0
+    # two triangles that only touch in ONE vertex are different components (trimesh's face_adjacency is edge adjacency)
+    bow = np.array([[0, 1, 2], [2, 3, 4]])
+    assert len(io.drop_small_components(verts, bow, min_faces=2)[1]) == 0
