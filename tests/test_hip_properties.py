@@ -145,9 +145,9 @@ def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
     from gens_amd import ops
     feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
     dims = [256, 128, 64, 32, 16]
-    fast_v, fast_m = ops.volume_build(feats, intrs, c2ws, dims)          # two voxels per lane (production)
+    fast_v, fast_m = ops.volume_build(feats, intrs, c2ws, dims)          # production: one launch, culled, exact-division shortcuts
     outs = []
-    for switch in ("GENS_K1_SINGLE", "GENS_K1_GENERIC"):                 # one voxel per lane, then the plain IEEE kernel
+    for switch in ("GENS_K1_SINGLE", "GENS_K1_GENERIC"):                 # the previous power-of-two kernel, then the plain IEEE kernel
         os.environ[switch] = "1"
         try:
             outs.append(ops.volume_build(feats, intrs, c2ws, dims))
