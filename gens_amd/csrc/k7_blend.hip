@@ -63,6 +63,30 @@ __device__ __forceinline__ f32x16 tile_mfma(const float* __restrict__ a_lds, int
     return acc;
 }
 
+// Narrow layers (<= 16 output columns: ray_dir_fc.0, rgb_fc.0, rgb_fc.2): the 32 rows x 16 columns are TWO 16 x 16 tiles of
+// v_mfma_f32_16x16x4_f32 (same exact float32, 32 cycles each) instead of one half-empty 32 x 32 tile -- half the matrix cycles and half
+// the activation evaluations (4 + 4 accumulator registers per lane instead of 16).  The reduction runs in groups of 4 S columns: at
+// step s lane (q = lane / 16, j = lane % 16) contributes k = k0 + S q + s, so its S values of A are consecutive floats of its LDS row
+// and its S values of B consecutive floats of the host-packed stream (gens_amd.ops._pack_b16).  Tile t, register r of a lane is
+// output (row 16 t + 4 q + r, column j).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int S>
+__device__ __forceinline__ void narrow_group(const float* __restrict__ a_lds, int rs, int k0, const float* __restrict__ wp, int lane, f32x4& c0,
+                                             f32x4& c1) {
+    const int q = lane >> 4, j = lane & 15;
+    const float* a0 = a_lds + j * rs + k0 + S * q;
+    const float* a1 = a0 + 16 * rs;
+    float b[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) b[s] = wp[lane * S + s];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[s], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[s], c1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ int nrow(int t, int r, int lane) { return 16 * t + 4 * (lane >> 4) + r; }
+
 template <int NLEV>
 __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet fs, const float4* __restrict__ imgs,
                                                          const float* __restrict__ w2c, const float* __restrict__ intr,
@@ -148,12 +172,16 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
 
     // ---------------------------------------------------------------- ray_dir_fc (blending_network.py:36-39, 87)
     {
-        BGroups<1> w;
-        load_b(w, W.rd1, lane);
-        f32x16 a = tile_mfma(RD, BL_RS, w, W.rd1_b[col], lane);
+        const int j = lane & 15;
+        f32x4 c0, c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (col < 16) T[crow(r, lane) * BL_TS + col] = elu1(a[r]);
+        for (int r = 0; r < 4; ++r) c0[r] = c1[r] = W.rd1_b[j];
+        narrow_group<2>(RD, BL_RS, 0, W.rd1, lane, c0, c1);                              // K = 4 (+4 zero columns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T[nrow(0, r, lane) * BL_TS + j] = elu1(c0[r]);
+            T[nrow(1, r, lane) * BL_TS + j] = elu1(c1[r]);
+        }
     }
     __syncthreads();
     {
@@ -308,21 +336,34 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     }
     __syncthreads();
     {
-        BGroups<5> w;
-        load_b(w, W.r1, lane);
-        f32x16 a = tile_mfma(V, BL_VS, w, W.r1_b[col], lane);
+        const int j = lane & 15;
+        f32x4 c0, c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (col < 16) T[crow(r, lane) * BL_TS + col] = elu1(a[r]);
+        for (int r = 0; r < 4; ++r) c0[r] = c1[r] = W.r1_b[j];
+        narrow_group<4>(V, BL_VS, 0, W.r1, lane, c0, c1);                                // K = 37 (+3 zero columns) = 16 + 16 + 8
+        narrow_group<4>(V, BL_VS, 16, W.r1 + 256, lane, c0, c1);
+        narrow_group<2>(V, BL_VS, 32, W.r1 + 512, lane, c0, c1);
+        // (T aliases V: a wave's LDS instructions execute in order, so the A reads above precede the writes below)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T[nrow(0, r, lane) * BL_TS + j] = elu1(c0[r]);
+            T[nrow(1, r, lane) * BL_TS + j] = elu1(c1[r]);
+        }
     }
     __syncthreads();
     {
-        BGroups<2> w;
-        load_b(w, W.r2, lane);
-        f32x16 a = tile_mfma(T, BL_TS, w, W.r2_b[col], lane);
+        const int j = lane & 15;
+        f32x4 c0, c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (col < 8) T[crow(r, lane) * BL_TS + 32 + col] = elu1(a[r]);
+        for (int r = 0; r < 4; ++r) c0[r] = c1[r] = W.r2_b[j];
+        narrow_group<4>(T, BL_TS, 0, W.r2, lane, c0, c1);                                // K = 16, 8 output columns
+        if (j < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T[nrow(0, r, lane) * BL_TS + 32 + j] = elu1(c0[r]);
+                T[nrow(1, r, lane) * BL_TS + 32 + j] = elu1(c1[r]);
+            }
+        }
     }
     __syncthreads();
     if (half == 0) {

@@ -663,6 +663,21 @@ def _pack_b_groups(w):
     return wp.view(nt, 32, g, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def _pack_b16(w, groups):
+    """(J <= 16, K) matrix -> B stream of a narrow layer for two 16x16x4 fp32 MFMA tiles (k7_blend.hip::narrow_group): for every group
+    (k0, S) of 4 S reduction columns, 64 lanes x S floats; lane l holds w[l % 16][k0 + S (l // 16) + 0..S-1] (zero padded)."""
+    j, k = w.shape
+    assert j <= 16
+    kmax = max(k0 + 4 * s for k0, s in groups)
+    wp = torch.zeros(16, kmax, device=w.device, dtype=_f32)
+    wp[:j, :k] = w
+    parts = []
+    for k0, s in groups:
+        blk = wp[:, k0:k0 + 4 * s].reshape(16, 4, s)           # [j][q][s]
+        parts.append(blk.permute(1, 0, 2).reshape(-1))         # lane = q * 16 + j
+    return torch.cat(parts).contiguous()
+
+
 def _pack_b_fragments_f16(w):
     """(J, K) matrix -> split-half MFMA 32x32x16 B fragments: two (hi, lo) tensors [ceil(J/32)][ceil(K/16)][64][8] of halfs;
     lane l of fragment (nt, kb) holds w[32 nt + (l & 31)][16 kb + 8 (l >> 5) + 0..7]."""
@@ -792,10 +807,11 @@ class BlendPlan:
             r1, r2, r3 = g(net.rgb_fc[0]), g(net.rgb_fc[2]), g(net.rgb_fc[4])
             self.n_feat = rd2[0].shape[0]                  # 3 + d_feature
             P = _pack_b_groups      # grouped B streams: one global_load_dwordx4 per 4 MFMAs (layout in k7_blend.hip)
-            self.tensors = [P(rd1[0]), _pad32(rd1[1]), P(rd2[0]), _pad32(rd2[1]), P(b1[0]), _pad32(b1[1]), P(b2[0]), _pad32(b2[1]),
+            N = _pack_b16           # narrow layers (<= 16 outputs): 16x16x4 tiles, reduction groups (k0, S)
+            self.tensors = [N(rd1[0], [(0, 2)]), _pad32(rd1[1]), P(rd2[0]), _pad32(rd2[1]), P(b1[0]), _pad32(b1[1]), P(b2[0]), _pad32(b2[1]),
                             P(v1[0]), _pad32(v1[1]), P(v2[0][:32]), _pad32(v2[1][:32]), _c(v2[0][32].clone()),
                             P(u1[0]), _pad32(u1[1]), _c(u2[0][0].clone()),
-                            P(r1[0]), _pad32(r1[1]), P(r2[0]), _pad32(r2[1]), _c(r3[0][0].clone())]
+                            N(r1[0], [(0, 4), (16, 4), (32, 2)]), _pad32(r1[1]), N(r2[0], [(0, 4)]), _pad32(r2[1]), _c(r3[0][0].clone())]
             self.scalars = (C.c_float * 4)(float(v2[1][32]), float(u2[1][0]), float(r3[1][0]), float(net.s.detach().abs()))
         self.table = L.ptr_table(self.tensors)
         self.key = BlendPlan.version(net)
