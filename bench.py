@@ -169,7 +169,7 @@ def main():
         dom_name, dom = max(((n, k) for n, k in kernels.items() if k["bytes"]), key=lambda kv: kv[1]["ms"] / timed_steps[kv[0]])
         assert dom_name == DOMINANT, f"dominant kernel is {dom_name}, not {DOMINANT}: update bench.DOMINANT"
         traffic = None      # HBM bytes per launch from the committed PMC passes (same command, ray chunk 32768): scripts/pmc_traffic.py
-        tpath = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
         if os.path.exists(tpath) and args.chunk == 32768:
             t = json.load(open(tpath))["kernels"].get(dom_name)
             if t:
