@@ -264,9 +264,8 @@ class ImplicitSurface(nn.Module):
                         sdf_v = self.sdf_network.sdf(x, vols)
                         grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
                     sdf_v, smooth_v = sdf_v.detach(), None
-                else:
-                    sdf_v = self.sdf_network(pts_v, vols)[:, :1]
-                    grad_v, smooth_v = self.sdf_network.gradient(pts_v.clone(), vols)
+                else:                                      # one forward pass for :179 (sdf) and :188 (gradient, smooth)
+                    sdf_v, grad_v, smooth_v = self.sdf_network.sdf_gradient_smooth(pts_v.clone(), vols)
                 sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
                 gradients = torch.zeros(b * n, 3, device=dev).index_put((idx,), grad_v)
                 smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
@@ -308,7 +307,8 @@ class ImplicitSurface(nn.Module):
 
         # surface point of the first sign change and the plane-induced patch warp (:288-328)
         pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
-        g0, _ = self.sdf_network.gradient(pts_sdf0.reshape(-1, 3), vols)
+        # the reference builds the second-order graph here too and throws it away: the normal is used detached (:306-310)
+        g0, _ = self.sdf_network.gradient(pts_sdf0.detach().reshape(-1, 3).clone(), vols, second_order=False)
         g0 = g0.reshape(b, 1, 3)
         g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
         g0 = g0 / torch.where(g0_norm <= 0, torch.full_like(g0_norm, 1e-8), g0_norm)

@@ -95,16 +95,25 @@ class SDFNetwork(nn.Module):
         return self.forward(x, volumes)
 
     @torch.enable_grad()
+    def sdf_gradient_smooth(self, x, volumes):
+        """-> (sdf (N,1), d sdf/dx (N,3), d(sum_k d sdf/dx_k)/dx (N,3)) from ONE forward pass.  The reference evaluates the network twice
+        on the same points (implicit_surface.py:179 and, inside `gradient`, :188); the second pass reproduces the first bit for bit, so
+        sharing it changes no value and removes a seventh of the training step's launches."""
+        x.requires_grad_(True)
+        y = self.sdf(x, volumes)
+        gradients = torch.autograd.grad(y, x, torch.ones_like(y, requires_grad=False), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        smooth = torch.autograd.grad(gradients, x, torch.ones_like(gradients), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        return y, gradients, smooth
+
+    @torch.enable_grad()
     def gradient(self, x, volumes, second_order=True):
         """-> (d sdf/dx, d(sum_k d sdf/dx_k)/dx), both (N,3), built with create_graph like sdf_network.py:131-154.
 
-        second_order=False (inference) skips the double backward and returns (gradient, None).
+        second_order=False (results that are used detached, or inference) skips the double backward and returns (gradient, None).
         """
-        x.requires_grad_(True)
-        y = self.sdf(x, volumes)
-        ones = torch.ones_like(y, requires_grad=False)
         if not second_order:
-            return torch.autograd.grad(y, x, ones, create_graph=False, retain_graph=False)[0], None
-        gradients = torch.autograd.grad(y, x, ones, create_graph=True, retain_graph=True, only_inputs=True)[0]
-        smooth = torch.autograd.grad(gradients, x, torch.ones_like(gradients), create_graph=True, retain_graph=True, only_inputs=True)[0]
+            x.requires_grad_(True)
+            y = self.sdf(x, volumes)
+            return torch.autograd.grad(y, x, torch.ones_like(y, requires_grad=False), create_graph=False, retain_graph=False)[0], None
+        _, gradients, smooth = self.sdf_gradient_smooth(x, volumes)
         return gradients, smooth
