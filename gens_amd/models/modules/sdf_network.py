@@ -68,8 +68,8 @@ class SDFNetwork(nn.Module):
             setattr(self, f"lin{l}", lin)
         self.activation = nn.Softplus(beta=100)
 
-    def forward(self, inputs, volumes):
-        """inputs (N,3) world points, volumes: list of (1,4,X,Y,Z) / packed VolumeSet -> (N, d_out)."""
+    def _hidden(self, inputs, volumes):
+        """Input of the last layer: (N, d_hidden + feat_channels)."""
         feats = lookup_volume(inputs.clone(), volumes)
         if self.embed_fn_feat is not None:
             feats = self.embed_fn_feat(feats)
@@ -78,18 +78,35 @@ class SDFNetwork(nn.Module):
             pe = self.embed_fn_fine(pe)
         x = pe
         n_lin = self.num_layers - 1
-        for l in range(n_lin):
+        for l in range(n_lin - 1):
             if l in self.skip_in:
                 x = torch.cat([x, pe], -1) / math.sqrt(2)
             if l > 0:
                 x = torch.cat([x, feats], -1)
-            x = getattr(self, f"lin{l}")(x)
-            if l < n_lin - 1:
-                x = self.activation(x)
+            x = self.activation(getattr(self, f"lin{l}")(x))
+        l = n_lin - 1
+        if l in self.skip_in:
+            x = torch.cat([x, pe], -1) / math.sqrt(2)
+        if l > 0:
+            x = torch.cat([x, feats], -1)
+        return x
+
+    def forward(self, inputs, volumes):
+        """inputs (N,3) world points, volumes: list of (1,4,X,Y,Z) / packed VolumeSet -> (N, d_out)."""
+        x = getattr(self, f"lin{self.num_layers - 2}")(self._hidden(inputs, volumes))
         return torch.cat([x[:, :1] / self.scale, x[:, 1:]], -1)
 
     def sdf(self, x, volumes):
-        return self.forward(x, volumes)[:, :1]
+        """forward(x)[:, :1] (sdf_network.py:125-126) without the 128 feature columns nobody reads: only row 0 of the last layer is
+        evaluated (its weight-normed row is the same g v / |v| the full layer forms), and no slice / cat / slice of an (N, 129) tensor
+        enters the autograd graph the training step differentiates three times."""
+        lin = getattr(self, f"lin{self.num_layers - 2}")
+        h = self._hidden(x, volumes)
+        if hasattr(lin, "weight_g"):
+            w = torch._weight_norm(lin.weight_v[:1], lin.weight_g[:1], 0)
+        else:
+            w = lin.weight[:1]
+        return torch.nn.functional.linear(h, w, lin.bias[:1]) / self.scale
 
     def sdf_hidden_appearance(self, x, volumes):
         return self.forward(x, volumes)
