@@ -464,44 +464,114 @@ extern "C" int gens_selftest_division(unsigned long long* counts, void* stream) 
 }
 
 // d(volume)/d(features): recompute the projections, then scatter with the bilinear weights.
+//
+// The scatter is bound by float atomics (~30 G/s on this chip: 0.48 G of them, 15.6 ms, at 256^3).  Neighbouring voxels have overlapping
+// 2 x 2 footprints: along z a projection moves 0 .. 1.4 pixels per voxel at the benchmark geometry (all on the same texels in the
+// reference view), between x-adjacent rows ~4 pixels.  A wave therefore owns a compact tile of the volume -- 16 consecutive z of four
+// x-adjacent rows -- whose footprints in one view cover a few dozen pixels of two or three image rows: it first adds its 64 x 4 taps into
+// a window of LDS over the bounding box of those footprints (LDS atomics; a wave's LDS operations execute in order, so no barrier is
+// needed), then sends ONE global atomic per touched texel and channel.  Bounding boxes larger than BWD_CAP texels (very wide or very
+// oblique views) fall back to direct atomics, lane by lane.
+#define BWD_CAP 512          // texels per wave window (8 KB; 32 KB per workgroup)
+
+__device__ __forceinline__ void lds_add4(float* p, float4 v, float s) {
+    atomicAdd(p + 0, v.x * s);
+    atomicAdd(p + 1, v.y * s);
+    atomicAdd(p + 2, v.z * s);
+    atomicAdd(p + 3, v.w * s);
+}
+
 __global__ __launch_bounds__(256) void volume_build_bwd_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                           const float* __restrict__ intr, float s, int nv, int h, int w,
-                                                          int d, const float* __restrict__ gvol, float* __restrict__ gfeat) {
-    int64_t n = (int64_t)d * d * d;
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    int kz = (int)(idx % d), jy = (int)((idx / d) % d), ix = (int)(idx / ((int64_t)d * d));
-    float x = linspace_at(-1.0f, 1.0f, d, ix), y = linspace_at(-1.0f, 1.0f, d, jy), z = linspace_at(-1.0f, 1.0f, d, kz);
+                                                          int d, int cap, const float* __restrict__ gvol, float* __restrict__ gfeat) {
+    __shared__ float4 window[4][BWD_CAP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    float4* win = window[tid >> 6];
+    const int64_t n = (int64_t)d * d * d;
+    // wave -> voxels: d a multiple of 16 (and of 4): 16 consecutive z of 4 x-adjacent rows (lane = 16 row + z); otherwise 64 consecutive voxels
+    int64_t idx = (int64_t)blockIdx.x * 256 + tid;
+    if ((d & 15) == 0) {
+        const int zp = d >> 4;                                                      // 16-voxel pieces per row
+        const int64_t q = (int64_t)blockIdx.x * 4 + (tid >> 6);                     // wave number: (ix / 4, jy, z piece), z piece fastest
+        const int kz0 = (int)(q % zp) * 16, jy_ = (int)((q / zp) % d), ix0 = (int)(q / ((int64_t)zp * d)) * 4;
+        idx = ((int64_t)(ix0 + (lane >> 4)) * d + jy_) * d + kz0 + (lane & 15);
+    }
+    const bool in = idx < n;                                                        // (no early return: the wave scatters together)
+    const int64_t vox = in ? idx : 0;
+    const int kz = (int)(vox % d), jy = (int)((vox / d) % d), ix = (int)(vox / ((int64_t)d * d));
+    const float x = linspace_at(-1.0f, 1.0f, d, ix), y = linspace_at(-1.0f, 1.0f, d, jy), z = linspace_at(-1.0f, 1.0f, d, kz);
     float4 s1 = f4_zero();
     float cnt = 0.0f;
-    for (int v = 0; v < nv; ++v) {
-        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
-        if (!p.vis) continue;
-        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-        float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
-        s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
-        cnt += 1.0f;
+    if (in) {
+        for (int v = 0; v < nv; ++v) {
+            Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
+            if (!p.vis) continue;
+            Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+            float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
+            s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
+            cnt += 1.0f;
+        }
     }
-    if (cnt <= 0.0f) return;
-    float inv = 1.0f / cnt;
-    float4 mean = make_float4(s1.x * inv, s1.y * inv, s1.z * inv, s1.w * inv);
-    float4 gm = make_float4(gvol[idx], gvol[n + idx], gvol[2 * n + idx], gvol[3 * n + idx]);
-    float4 gv = make_float4(gvol[4 * n + idx], gvol[5 * n + idx], gvol[6 * n + idx], gvol[7 * n + idx]);
+    const bool live = in && cnt > 0.0f;
+    const float inv = live ? 1.0f / cnt : 0.0f;
+    const float4 mean = make_float4(s1.x * inv, s1.y * inv, s1.z * inv, s1.w * inv);
+    float4 gm = f4_zero(), gv = f4_zero();
+    if (live) {
+        gm = make_float4(gvol[vox], gvol[n + vox], gvol[2 * n + vox], gvol[3 * n + vox]);
+        gv = make_float4(gvol[4 * n + vox], gvol[5 * n + vox], gvol[6 * n + vox], gvol[7 * n + vox]);
+    }
     for (int v = 0; v < nv; ++v) {
-        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
-        if (!p.vis) continue;
-        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-        float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
-        float4 g;
-        g.x = (gm.x + 2.0f * gv.x * (f.x - mean.x)) * inv;
-        g.y = (gm.y + 2.0f * gv.y * (f.y - mean.y)) * inv;
-        g.z = (gm.z + 2.0f * gv.z * (f.z - mean.z)) * inv;
-        g.w = (gm.w + 2.0f * gv.w * (f.w - mean.w)) * inv;
-        float* base = gfeat + (((int64_t)v * h + t.y0) * w + t.x0) * 4;
-        if (t.ok00) atomic_add4(base, g, t.w00);
-        if (t.ok01) atomic_add4(base + 4, g, t.w01);
-        if (t.ok10) atomic_add4(base + (int64_t)w * 4, g, t.w10);
-        if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, g, t.w11);
+        bool vis = false;
+        Taps2 t;
+        float4 g = f4_zero();
+        t.x0 = t.y0 = 0;
+        t.ok00 = t.ok01 = t.ok10 = t.ok11 = false;
+        t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+        if (live) {
+            Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
+            vis = p.vis;
+            if (vis) {
+                t = bilinear_taps(p.ix, p.iy, h, w);
+                float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
+                g.x = (gm.x + 2.0f * gv.x * (f.x - mean.x)) * inv;
+                g.y = (gm.y + 2.0f * gv.y * (f.y - mean.y)) * inv;
+                g.z = (gm.z + 2.0f * gv.z * (f.z - mean.z)) * inv;
+                g.w = (gm.w + 2.0f * gv.w * (f.w - mean.w)) * inv;
+            }
+        }
+        if (!__any(vis)) continue;
+        float* img = gfeat + (int64_t)v * h * w * 4;
+        // bounding box of the wave's footprints, clipped to the image (taps outside it are dropped by their ok flags)
+        const float big = 1.0e9f;
+        const int x_lo = max((int)-wave_max(vis ? -(float)t.x0 : -big), 0), x_hi = min((int)wave_max(vis ? (float)(t.x0 + 1) : -big), w - 1);
+        const int y_lo = max((int)-wave_max(vis ? -(float)t.y0 : -big), 0), y_hi = min((int)wave_max(vis ? (float)(t.y0 + 1) : -big), h - 1);
+        const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+        if (bw > 0 && bh > 0 && bw * bh <= cap) {                                    // (wave-uniform)
+            for (int i = lane; i < bw * bh; i += 64) win[i] = f4_zero();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                  // (program order is execution order for a wave's LDS operations)
+            if (vis) {
+                float* b = (float*)&win[(t.y0 - y_lo) * bw + (t.x0 - x_lo)];
+                if (t.ok00) lds_add4(b, g, t.w00);
+                if (t.ok01) lds_add4(b + 4, g, t.w01);
+                if (t.ok10) lds_add4(b + 4 * bw, g, t.w10);
+                if (t.ok11) lds_add4(b + 4 * bw + 4, g, t.w11);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (int i = lane; i < bw * bh; i += 64) {
+                const float4 a = win[i];
+                if (a.x != 0.0f || a.y != 0.0f || a.z != 0.0f || a.w != 0.0f) {
+                    const int r = i / bw, c = i - r * bw;
+                    atomic_add4(img + ((int64_t)(y_lo + r) * w + x_lo + c) * 4, a, 1.0f);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        } else if (vis) {
+            float* base = img + ((int64_t)t.y0 * w + t.x0) * 4;
+            if (t.ok00) atomic_add4(base, g, t.w00);
+            if (t.ok01) atomic_add4(base + 4, g, t.w01);
+            if (t.ok10) atomic_add4(base + (int64_t)w * 4, g, t.w10);
+            if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, g, t.w11);
+        }
     }
 }
 
@@ -594,7 +664,8 @@ extern "C" int gens_volume_build_bwd(const float* feat, const float* w2c, const 
     if (int e = check_volume_args("gens_volume_build_bwd", feat, w2c, intr, nv, h, w, d)) return e;
     GENS_CHECK_ARG(g_volume && g_feat, GENS_EINVAL, "gens_volume_build_bwd: null gradient buffer");
     int64_t n = (int64_t)d * d * d;
+    const int cap = getenv("GENS_K1_BWD_DIRECT") ? 0 : BWD_CAP;                    // (switch: every tap a global atomic, for A/B runs)
     volume_build_bwd_k<<<gens_blocks(n, 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, intr_scale, nv,
-                                                                            h, w, d, g_volume, g_feat);
+                                                                            h, w, d, cap, g_volume, g_feat);
     return gens_launch_status("gens_volume_build_bwd");
 }

@@ -219,3 +219,30 @@ def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
     assert float(ref[1][0].mean()) > 0.05
     for a, b in zip(fast[0] + fast[1], ref[0] + ref[1]):
         assert torch.equal(a, b)
+
+
+def test_k1_backward_window_scatter_equals_direct_atomics(scene):
+    """The backward's LDS-window scatter (one global atomic per touched texel and channel of a wave's 4 x 16 voxel tile) against one
+    global atomic per tap, at full size (19 M voxels x 5 views): the same sums in a different order."""
+    import os
+    from gens_amd import lib as L, ops
+    feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
+    w2c = torch.linalg.inv(c2ws).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for lvl, d in enumerate([256, 128, 64, 32]):
+        tex = ops.pack_nchw(feats[lvl])
+        nv, h, w, _ = tex.shape
+        gvol = torch.randn(8, d, d, d, device="cuda", generator=g)
+        outs = []
+        for direct in (False, True):
+            if direct:
+                os.environ["GENS_K1_BWD_DIRECT"] = "1"
+            try:
+                gf = torch.zeros_like(tex)
+                L.call("gens_volume_build_bwd", L.ptr(tex), L.ptr(w2c), L.ptr(intrs), 0.5 ** lvl, nv, h, w, d, L.ptr(gvol), L.ptr(gf), L.stream())
+                outs.append(gf)
+            finally:
+                os.environ.pop("GENS_K1_BWD_DIRECT", None)
+        scale = float(outs[1].abs().max())
+        assert scale > 1.0
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * scale + 1e-6, (d, float((outs[0] - outs[1]).abs().max()), scale)
