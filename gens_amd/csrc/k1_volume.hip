@@ -261,7 +261,9 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t zq_bits = (uint32_t)lc.log2d - 6u;                              // (tiled) a row is 2^zq_bits pieces of 64 voxels
     const uint32_t t_kz0 = (chunk & ((1u << zq_bits) - 1u)) << 6, t_jy = (chunk >> zq_bits) & dm, t_ix0 = (chunk >> (zq_bits + lc.log2d)) << 2;
-    const uint32_t idx = tiled ? (((t_ix0 + wv) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + lane)) : chunk * 256u + threadIdx.x;
+    // within the tile a wave takes 16 z of all four rows (lane = 16 row + z): its footprints in a view then span ~30 pixels instead of ~90
+    const uint32_t t_row = lane >> 4, t_z = (wv << 4) | (lane & 15u);
+    const uint32_t idx = tiled ? (((t_ix0 + t_row) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + t_z)) : chunk * 256u + threadIdx.x;
     const int kz = (int)(idx & dm), jy = (int)((idx >> lc.log2d) & dm), ix = (int)(idx >> (2 * lc.log2d));
     const int half = d >> 1;
     // ---- frustum culling per (z-row, view).  Along a z-row the homogeneous image coordinates (u, v, depth) are affine in z, so the
@@ -310,7 +312,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
         }
     }
     __syncthreads();
-    const int my_row = tiled ? (int)wv : (int)(threadIdx.x >> lc.log2d);
+    const int my_row = tiled ? (int)t_row : (int)(threadIdx.x >> lc.log2d);
     // torch.linspace(-1, 1, d)[i]: lower half counts up from the start, upper half down from the end
     const float x = ix < half ? -1.0f + lc.step * (float)ix : 1.0f - lc.step * (float)(d - 1 - ix);
     const float y = jy < half ? -1.0f + lc.step * (float)jy : 1.0f - lc.step * (float)(d - 1 - jy);
@@ -382,15 +384,16 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // sweep the texels out of L2; through buffer descriptors (lane offset in 32 bits; d^3 <= 2^24 voxels: 8 planes are 512 MiB).
     __shared__ float stage[9][256];
     const int tid = threadIdx.x;
-    stage[0][tid] = mm.x;
-    stage[1][tid] = mm.y;
-    stage[2][tid] = mm.z;
-    stage[3][tid] = mm.w;
-    stage[4][tid] = div_rn(s2.x, den, yn) - mm.x * mm.x;
-    stage[5][tid] = div_rn(s2.y, den, yn) - mm.y * mm.y;
-    stage[6][tid] = div_rn(s2.z, den, yn) - mm.z * mm.z;
-    stage[7][tid] = div_rn(s2.w, den, yn) - mm.w * mm.w;
-    stage[8][tid] = cnt > (float)min_vis ? 1.0f : 0.0f;                            // (Q4)
+    const int slot = tiled ? (int)(t_row * 64u + t_z) : tid;                        // position in the workgroup's tile: row-piece, then z
+    stage[0][slot] = mm.x;
+    stage[1][slot] = mm.y;
+    stage[2][slot] = mm.z;
+    stage[3][slot] = mm.w;
+    stage[4][slot] = div_rn(s2.x, den, yn) - mm.x * mm.x;
+    stage[5][slot] = div_rn(s2.y, den, yn) - mm.y * mm.y;
+    stage[6][slot] = div_rn(s2.z, den, yn) - mm.z * mm.z;
+    stage[7][slot] = div_rn(s2.w, den, yn) - mm.w * mm.w;
+    stage[8][slot] = cnt > (float)min_vis ? 1.0f : 0.0f;                            // (Q4)
     __syncthreads();
     const uint32_t plane = (uint32_t)d << (2 * lc.log2d + 2);                      // bytes per plane
     const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc((void*)vol, 0, (int)(8u * plane), 0x00020000);
