@@ -34,7 +34,28 @@ def main():
     target = torch.rand(512, 3, device=dev)
     opt = torch.optim.Adam(surf.parameters(), lr=5e-4)
 
+    finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
+    if finetune:
+        with torch.no_grad():
+            _, ft_masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
+        ft_feats = [f.detach() for f in feats]
+        ft_opt = torch.optim.Adam(list(surf.parameters()) + vols, lr=5e-4)
+
+    def ft_step():
+        out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
+        ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]
+        loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
+            + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
+            + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
+            + out["pseudo_sdf"].abs().mean()
+        ft_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        ft_opt.step()
+        return float(loss)
+
     def step():
+        if finetune:
+            return ft_step()
         with torch.no_grad():
             _, masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
         cost, _ = ops.volume_build(feats[:3], intrs, c2ws, dims)            # K1 with autograd to the features
@@ -59,7 +80,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"train step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    print(f"{'fine-tune' if finetune else 'train'} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
 
 
 if __name__ == "__main__":
