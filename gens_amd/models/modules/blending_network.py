@@ -4,6 +4,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .linear import Linear
+
 
 def _kaiming(m):
     if isinstance(m, nn.Linear):
@@ -15,7 +17,7 @@ def _kaiming(m):
 def _mlp(*widths, last=None):
     layers = []
     for i in range(len(widths) - 1):
-        layers.append(nn.Linear(widths[i], widths[i + 1]))
+        layers.append(Linear(widths[i], widths[i + 1]))
         if i < len(widths) - 2 or last == "elu":
             layers.append(nn.ELU(inplace=True))
     if last == "sigmoid":

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .embedder import get_embedder
+from .linear import Linear
 from .projector import lookup_volume
 
 
@@ -60,7 +61,7 @@ class SDFNetwork(nn.Module):
                 out_dim -= widths[0]            # room for the re-injected positional encoding
             if l < n_lin - 1:
                 out_dim -= feat_channels        # room for the volume features concatenated before every hidden layer
-            lin = nn.Linear(widths[l], out_dim)
+            lin = Linear(widths[l], out_dim)
             if geometric_init:
                 _geometric_init(lin, l, n_lin, widths[l], out_dim, widths[0], feat_channels, multires, self.skip_in, bias, inside_outside)
             if weight_norm:
