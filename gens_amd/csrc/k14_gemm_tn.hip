@@ -1,0 +1,106 @@
+// K14: C (M x N) = A^T B for tall operands A (K x M), B (K x N), K >> M, N -- the weight-gradient GEMM of the training step
+// (dW = dY^T X with K = number of points: 61 835 x {128, 101} x {188, 27}; 247 340 x {64, 33, 32, 23, 16, 8} x {69, 64, 37, 32, 16}).
+// hipBLASLt runs these without splitting K: 160 us for 128 x 61 835 x 188 (18 TFLOP/s) and 0.5 ms for 32 x 247 340 x 32
+// (1 TFLOP/s, a 64 MB read) -- 8 ms of a 44 ms training step.
+//
+// Mapping.  K is cut into slabs; a unit of work is one (slab, 32 x 32 tile of C) pair and belongs to ONE wave (four units per
+// workgroup), the slab length chosen so that the launch has ~8 000 units whatever the shape.  For v_mfma_f32_32x32x2_f32 (exact float32)
+// lane l supplies A[k + l / 32][m0 + l % 32] and B[k + l / 32][n0 + l % 32]: both operands are read ALONG the rows of A and B, 128
+// contiguous bytes per half wave, straight from global memory (the re-reads of a row by the other tiles hit L1 / L2) -- no
+// transposition, no LDS.  Every unit writes its partial tile into a workspace; a second kernel adds the partials in slab order, so the
+// result does not depend on scheduling (no atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void gemm_tn_partial_k(const float* __restrict__ a, const float* __restrict__ b, int64_t kk, int m, int n,
+                                                         int64_t slab, int64_t n_units, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int mt = (m + 31) >> 5, nt = (n + 31) >> 5;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int64_t s = unit / (mt * nt);
+    const int t = (int)(unit % (mt * nt));
+    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int m0 = (t / nt) << 5, n0 = (t % nt) << 5;
+    const bool am = m0 + i < m, bn = n0 + i < n;
+    const float* ap = a + (k_begin + h) * m + (am ? m0 + i : 0);
+    const float* bp = b + (k_begin + h) * n + (bn ? n0 + i : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    int64_t k = k_begin;
+    for (; k + 16 <= k_end; k += 16) {                        // eight MFMAs (16 rows of K) per trip, their sixteen loads issued together
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            av[q] = ap[(int64_t)(2 * q) * m];
+            bv[q] = bp[(int64_t)(2 * q) * n];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(am ? av[q] : 0.0f, bn ? bv[q] : 0.0f, acc, 0, 0, 0);
+        ap += 16 * (int64_t)m;
+        bp += 16 * (int64_t)n;
+    }
+    for (; k < k_end; k += 2) {                               // tail: the second row of a pair may lie beyond the slab
+        const bool row = k + h < k_end;
+        const float av = (am && row) ? ap[0] : 0.0f, bv = (bn && row) ? bp[0] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        ap += 2 * (int64_t)m;
+        bp += 2 * (int64_t)n;
+    }
+    if (bn) {
+        float* w = ws + s * (int64_t)m * n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < m) w[(int64_t)row * n + n0 + i] = acc[r];
+        }
+    }
+}
+
+// partial sums in fixed order: out[g][e] = sum of in[q][e] over the g-th group of `per` consecutive slabs (coalesced over e)
+__global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ in, int n_in, int per, int64_t mn, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= mn) return;
+    const int q0 = blockIdx.y * per, q1 = min(n_in, q0 + per);
+    float s = 0.0f;
+    for (int q = q0; q < q1; ++q) s += in[(int64_t)q * mn + e];
+    out[(int64_t)blockIdx.y * mn + e] = s;
+}
+
+#define GEMM_TN_GROUPS 64     // second-stage groups: the workspace holds (slabs + GEMM_TN_GROUPS) partial results
+
+static int64_t gemm_tn_slab(int64_t k, int m, int n) {      // rows of K per unit: ~8 000 units per launch, multiples of 16 rows, at least 64
+    const int64_t tiles = (int64_t)((m + 31) / 32) * ((n + 31) / 32);
+    int64_t slab = (k * tiles + 8191) / 8192;
+    slab = (slab + 15) / 16 * 16;
+    return slab < 64 ? 64 : slab;
+}
+
+extern "C" int gens_gemm_tn_slabs(int64_t k, int m, int n) {
+    if (k <= 0 || m <= 0 || n <= 0) return 0;
+    const int64_t slab = gemm_tn_slab(k, m, n);
+    return (int)((k + slab - 1) / slab) + GEMM_TN_GROUPS;     // slabs + room for the second reduction stage
+}
+
+extern "C" int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float* workspace, float* c, void* stream) {
+    GENS_CHECK_ARG(a && b && workspace && c, GENS_EINVAL, "gens_gemm_tn: null pointer");
+    GENS_CHECK_ARG(k > 0 && m > 0 && n > 0 && m <= 1024 && n <= 1024, GENS_ELIMIT, "gens_gemm_tn: k=%lld m=%d n=%d (1 <= m, n <= 1024)", (long long)k, m, n);
+    const int64_t slab = gemm_tn_slab(k, m, n);
+    const int n_slabs = (int)((k + slab - 1) / slab);
+    const int64_t units = (int64_t)n_slabs * ((m + 31) / 32) * ((n + 31) / 32);
+    hipStream_t s = (hipStream_t)stream;
+    gemm_tn_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(a, b, k, m, n, slab, units, workspace);
+    const int64_t mn = (int64_t)m * n;
+    if (n_slabs <= GEMM_TN_GROUPS) {
+        gemm_tn_reduce_k<<<dim3(gens_blocks(mn, 256), 1), 256, 0, s>>>(workspace, n_slabs, n_slabs, mn, c);
+    } else {                                                                       // two stages, both in slab order
+        const int per = (n_slabs + GEMM_TN_GROUPS - 1) / GEMM_TN_GROUPS, groups = (n_slabs + per - 1) / per;
+        float* stage = workspace + (int64_t)n_slabs * mn;
+        gemm_tn_reduce_k<<<dim3(gens_blocks(mn, 256), groups), 256, 0, s>>>(workspace, n_slabs, per, mn, stage);
+        gemm_tn_reduce_k<<<dim3(gens_blocks(mn, 256), 1), 256, 0, s>>>(stage, groups, groups, mn, c);
+    }
+    return gens_launch_status("gens_gemm_tn");
+}

@@ -49,6 +49,8 @@ SIGNATURES = {
     "gens_volume_build_bwd": [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
     "gens_selftest_division": [_p, _p],
     "gens_volume_build_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _p],
+    "gens_gemm_tn_slabs": [_l, _i, _i],
+    "gens_gemm_tn": [_p, _p, _l, _i, _i, _p, _p, _p],
     "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],
     "gens_lookup_volume_bwd": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p],
     "gens_lookup_volume_bwd2": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p],

@@ -1,29 +1,40 @@
-"""nn.Linear whose bias gradient is a GEMV.
+"""nn.Linear whose parameter gradients go through the tall-operand product of libgens_hip.so (K14, gens_gemm_tn).
 
-`F.linear`'s backward forms grad_bias = grad_out.sum(0).  For output widths that are not a multiple of 4 (the shipped networks have
-101, 33 and 23) that column reduction runs on PyTorch's scalar path: 1.2 ms for a (247 344, 33) gradient on MI355X, 2.5 ms per
-training step in all, more than the layers' GEMMs.  Here the bias is added by a small autograd Function whose backward computes
-ones(1, N) @ grad_out instead -- the same sums through the BLAS library.  Its backward is written with differentiable torch ops, so the
-second and third derivatives the SDF network needs keep working.  Forward values are those of `F.linear` (a float32 GEMM result plus
-the bias); parameter names and shapes are nn.Linear's, so checkpoints and `weight_norm` are unaffected."""
+In a training step every layer is applied to N = 60 000 .. 250 000 rows, so `F.linear`'s backward forms dW = dY^T X and
+db = dY^T 1 with a reduction length of N and a tiny result.  The BLAS library does not split that reduction over the chip: 160 us
+for 128 x 61 835 x 188 (18 TFLOP/s), 0.5 ms for 32 x 247 340 x 32 (a 64 MB read), and PyTorch's column sum for the bias takes
+1.2 ms on a (247 344, 33) gradient -- 8 ms of a 44 ms step in all.  Here the layer is an autograd Function whose backward calls
+`ops.matmul_tn` for both; the backward is written with differentiable operations, so the second and third derivatives the SDF network
+takes through its layers keep working.  Forward values are `F.linear`'s; parameter names and shapes are nn.Linear's, so checkpoints
+and `weight_norm` are unaffected.  Small batches (and CPU tensors) use `F.linear` as it is."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 
-class _AddBias(torch.autograd.Function):
+
+class _LinearFn(torch.autograd.Function):
+    """y = x w^T + b on 2-D x (the caller reshapes: a custom Function must not hand out views that are modified in place later)."""
+
     @staticmethod
-    def forward(ctx, x, bias):
-        return x + bias
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
-        g2 = g.reshape(-1, g.shape[-1])
-        return g, torch.matmul(g2.new_ones(1, g2.shape[0]), g2)[0]
+        x, weight = ctx.saved_tensors
+        gx = (g @ weight) if ctx.needs_input_grad[0] else None
+        gw = ops.matmul_tn(g, x) if ctx.needs_input_grad[1] else None
+        gb = ops.matmul_tn(g, g.new_ones(g.shape[0], 1))[:, 0] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
 
 
 class Linear(nn.Linear):
     def forward(self, x):
-        if self.bias is None or self.out_features % 4 == 0 or self.out_features == 1 or not x.is_cuda:
-            return F.linear(x, self.weight, self.bias)
-        return _AddBias.apply(F.linear(x, self.weight), self.bias)
+        if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= ops.MATMUL_TN_MIN_ROWS and torch.is_grad_enabled():
+            y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias)
+            return y.reshape(*x.shape[:-1], self.out_features)
+        return F.linear(x, self.weight, self.bias)

@@ -777,6 +777,46 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# K14  a^T b for tall operands: the weight-gradient product of the training step
+# ------------------------------------------------------------------------------------------------------------------
+MATMUL_TN_MIN_ROWS = 8192      # below this the library GEMM is as good
+
+
+def _gemm_tn(a, b):
+    a, b = _c(a.detach().to(_f32)), _c(b.detach().to(_f32))
+    k, m = a.shape
+    n = b.shape[1]
+    slabs = L.load().gens_gemm_tn_slabs(k, m, n)
+    ws = torch.empty(slabs * m * n, device=a.device, dtype=_f32)
+    c = torch.empty(m, n, device=a.device, dtype=_f32)
+    L.call("gens_gemm_tn", L.ptr(a), L.ptr(b), k, m, n, L.ptr(ws), L.ptr(c), L.stream(), nbytes=4 * (k * (m + n) + m * n), flops=2 * k * m * n)
+    return c
+
+
+class _MatmulTN(torch.autograd.Function):
+    """c = a^T b; its derivatives are ordinary (large-output) products, written with differentiable torch ops so that the second and
+    third derivatives the SDF network takes through its layers keep working."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _gemm_tn(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (b @ g.t()) if ctx.needs_input_grad[0] else None, (a @ g) if ctx.needs_input_grad[1] else None
+
+
+def matmul_tn(a, b):
+    """a (K, M), b (K, N) -> a^T b (M, N).  Tall float32 device operands go to gens_gemm_tn (K split over the chip, fp32 MFMA);
+    anything else to torch."""
+    if a.is_cuda and a.dtype == _f32 and b.dtype == _f32 and a.shape[0] >= MATMUL_TN_MIN_ROWS and a.shape[1] <= 1024 and b.shape[1] <= 1024:
+        return _MatmulTN.apply(a, b)
+    return a.t() @ b
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # K7  fused source-view look-up + BlendingNetwork (inference)   (projector.py:278-349 + blending_network.py:69-118)
 # ------------------------------------------------------------------------------------------------------------------
 def _pad32(b):

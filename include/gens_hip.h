@@ -301,6 +301,15 @@ int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float 
 int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int res, int64_t first, int64_t count,
                         float* pts, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K14  C (m x n) = A^T B for tall row-major operands A (k x m), B (k x n), k >> m, n: the weight-gradient product of the training
+ *      step (dW = dY^T X, what aten::mm computes inside torch.nn.functional.linear's backward; the reference reaches it through
+ *      autograd from sdf_network.py:98-123 and blending_network.py:69-118).  Exact float32 (fp32 MFMA), K split into slabs whose
+ *      partial results are added in a fixed order (deterministic).  workspace: gens_gemm_tn_slabs(k, m, n) * m * n floats.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_gemm_tn_slabs(int64_t k, int m, int n);
+int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float* workspace, float* c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
