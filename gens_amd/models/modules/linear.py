@@ -26,7 +26,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        gx = (g @ weight) if ctx.needs_input_grad[0] else None
+        gx = ops.matmul_nn(g, weight) if ctx.needs_input_grad[0] else None
         gw = ops.matmul_tn(g, x) if ctx.needs_input_grad[1] else None
         gb = ops.matmul_tn(g, g.new_ones(g.shape[0], 1))[:, 0] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb

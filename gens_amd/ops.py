@@ -794,8 +794,8 @@ def _gemm_tn(a, b):
 
 
 class _MatmulTN(torch.autograd.Function):
-    """c = a^T b; its derivatives are ordinary (large-output) products, written with differentiable torch ops so that the second and
-    third derivatives the SDF network takes through its layers keep working."""
+    """c = a^T b.  Its derivatives are tall-times-small products (_MatmulNN), whose derivatives are again a^T b products: every
+    reduction over the rows stays on K14 through the second and third derivatives the SDF network takes through its layers."""
 
     @staticmethod
     def forward(ctx, a, b):
@@ -805,15 +805,40 @@ class _MatmulTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        return (b @ g.t()) if ctx.needs_input_grad[0] else None, (a @ g) if ctx.needs_input_grad[1] else None
+        return matmul_nn(b, g.t()) if ctx.needs_input_grad[0] else None, matmul_nn(a, g) if ctx.needs_input_grad[1] else None
+
+
+class _MatmulNN(torch.autograd.Function):
+    """y = x w for a tall x (K, M) and a small w (M, N): the library product, with d/dw = x^T g routed to K14."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return matmul_nn(g, w.t()) if ctx.needs_input_grad[0] else None, matmul_tn(x, g) if ctx.needs_input_grad[1] else None
+
+
+def _tall(a, *others):
+    return a.is_cuda and a.dim() == 2 and a.shape[0] >= MATMUL_TN_MIN_ROWS and all(t.dtype == _f32 for t in (a, *others))
 
 
 def matmul_tn(a, b):
     """a (K, M), b (K, N) -> a^T b (M, N).  Tall float32 device operands go to gens_gemm_tn (K split over the chip, fp32 MFMA);
     anything else to torch."""
-    if a.is_cuda and a.dtype == _f32 and b.dtype == _f32 and a.shape[0] >= MATMUL_TN_MIN_ROWS and a.shape[1] <= 1024 and b.shape[1] <= 1024:
+    if _tall(a, b) and a.shape[1] <= 1024 and b.shape[1] <= 1024:
         return _MatmulTN.apply(a, b)
     return a.t() @ b
+
+
+def matmul_nn(x, w):
+    """x (K, M) @ w (M, N): torch's product; for tall x the gradient w.r.t. w is a K14 product."""
+    if _tall(x, w) and x.shape[1] <= 1024 and w.shape[1] <= 1024 and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _MatmulNN.apply(x, w)
+    return x @ w
 
 
 # ------------------------------------------------------------------------------------------------------------------
