@@ -1,0 +1,271 @@
+// K15: 3 x 3 x 3 convolutions of the cost-volume U-Net (reference: nn.Conv3d / nn.ConvTranspose3d inside
+// models/modules/reg_network.py:7-50,105-169; padding 1, stride 1 or 2, transposed: stride 2 with output_padding 1), forward, data
+// gradient and weight gradient.  Few channels (8 ... 32) on up to 256^3 voxels: MIOpen's immediate-mode choice for the BACKWARD of
+// these shapes takes 2.4 s per 256^3 layer on this machine (forward 9 ms), 6.2 s per training step for the whole U-Net against 41 ms
+// for everything else -- scripts/probe/cnn_probe.py.
+//
+// One relation, three kernels.  A coarse tensor P (cp channels, X x Y x Z) and a fine tensor Q (cq channels, sX x sY x sZ, s = stride)
+// are tied by W[cp][cq][3][3][3]:
+//     gather    P[a][o]    = bias[a] + sum_{b, t} W[a][b][t] Q[b][s o + t - 1]        Conv3d forward;      ConvTranspose3d data gradient
+//     scatter   Q[b][i]    = sum_{a, t : s | i + 1 - t} W[a][b][t] P[a][(i + 1 - t) / s]   Conv3d data gradient; ConvTranspose3d forward
+//     wgrad     dW[a][b][t] = sum_o P[a][o] Q[b][s o + t - 1]                            both weight gradients
+// (nn.Conv3d(in, out).weight is W with a = out, b = in; nn.ConvTranspose3d(in, out).weight is W with a = in, b = out.)  A stride-1
+// scatter is a gather with the taps reversed and the channel roles swapped, which the host does on the 7-110 KB weight tensor.
+//
+// Mapping: a thread owns one voxel of P (lanes along z, the contiguous axis) and a block of OB output channels in registers; the tap
+// offsets are computed once per voxel and reused for every input channel; taps that fall into the zero padding get an out-of-range
+// buffer offset, for which the hardware returns 0 -- no masks in the inner loop, which is `loads + OB fused multiply-adds per load`
+// with the weights as scalar operands (wave-uniform indices: s_load through the constant cache).  Arithmetic intensity is
+// 27 cp cq MACs per voxel against 4 (cp + cq) bytes: 54 FLOP / B at 8 -> 8 channels, i.e. bound by the vector ALUs (78 TFLOP/s
+// float32 FMA), not HBM: 58 GFLOP per 256^3 layer = 0.74 ms at that peak.
+#include "common.h"
+
+#define CONV_OOB 0x7fffffffu     // beyond num_records of every buffer this file makes (< 2 GiB): the load returns 0
+
+struct ConvGeom {
+    int x, y, z;                 // extent of P
+    int cp, cq;                  // channels of P, Q
+    int cpp, cqp;                // the same, rounded up to the channel blocking of the weight tensor handed in
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const float* p, int64_t floats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(floats * 4), 0x00020000);
+}
+__device__ __forceinline__ float conv_load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+}
+
+// gather: w laid out (cq, 27, cpp)
+template <int OB, int S>
+__global__ __launch_bounds__(256) void conv3d_gather_k(const float* __restrict__ q, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       ConvGeom g, float* __restrict__ p) {
+    const int pn = g.x * g.y * g.z;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= pn) return;
+    const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+    const int qx = g.x * S, qy = g.y * S, qz = g.z * S;
+    const uint32_t qn_bytes = (uint32_t)qx * qy * qz * 4u;
+    uint32_t off[27];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int ix = ox * S + dx - 1, iy = oy * S + dy - 1, iz = oz * S + dz - 1;
+                const bool ok = (unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy && (unsigned)iz < (unsigned)qz;
+                off[(dx * 3 + dy) * 3 + dz] = ok ? (uint32_t)((ix * qy + iy) * qz + iz) * 4u : CONV_OOB;
+            }
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * qx * qy * qz);
+    const int cb = blockIdx.y * OB;
+    float acc[OB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) acc[o] = (bias != nullptr && cb + o < g.cp) ? bias[cb + o] : 0.0f;
+    const float* wc = w + cb;
+    uint32_t soff = 0;
+    for (int b = 0; b < g.cq; ++b) {
+        float xv[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) xv[t] = conv_load(qr, off[t], soff);
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[t * g.cpp + o], xv[t], acc[o]);
+        wc += 27 * g.cpp;
+        soff += qn_bytes;
+    }
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+        if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
+}
+
+// scatter, stride 2: w laid out (cp, 27, cqp).  The thread of coarse voxel o produces the 2 x 2 x 2 fine voxels 2 o + e; along each axis
+// an even fine index takes tap 1 from P[o], an odd one tap 2 from P[o] and tap 0 from P[o + 1].
+template <int OB>
+__global__ __launch_bounds__(256) void conv3d_scatter2_k(const float* __restrict__ p, const float* __restrict__ w, ConvGeom g, float* __restrict__ q) {
+    const int pn = g.x * g.y * g.z;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= pn) return;
+    const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+    uint32_t off[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int ix = ox + (n >> 2), iy = oy + ((n >> 1) & 1), iz = oz + (n & 1);
+        off[n] = (ix < g.x && iy < g.y && iz < g.z) ? (uint32_t)((ix * g.y + iy) * g.z + iz) * 4u : CONV_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * pn);
+    const int cb = blockIdx.y * OB;
+    float acc[8][OB];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[e][o] = 0.0f;
+    const float* wc = w + cb;
+    uint32_t soff = 0;
+    for (int a = 0; a < g.cp; ++a) {
+        float pv[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) pv[n] = conv_load(pr, off[n], soff);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tz = 0; tz < 3; ++tz) {
+                    // tap 1 -> (even output, source o); tap 2 -> (odd, o); tap 0 -> (odd, o + 1)
+                    const int ex = tx != 1, ey = ty != 1, ez = tz != 1;
+                    const int sx = tx == 0, sy = ty == 0, sz = tz == 0;
+                    const float src = pv[(sx << 2) | (sy << 1) | sz];
+                    const float* wt = wc + ((tx * 3 + ty) * 3 + tz) * g.cqp;
+#pragma unroll
+                    for (int o = 0; o < OB; ++o) acc[(ex << 2) | (ey << 1) | ez][o] = __builtin_fmaf(wt[o], src, acc[(ex << 2) | (ey << 1) | ez][o]);
+                }
+        wc += 27 * g.cqp;
+        soff += (uint32_t)pn * 4u;
+    }
+    const int qy = 2 * g.y, qz = 2 * g.z;
+    const int64_t qn = (int64_t)pn * 8;
+#pragma unroll
+    for (int o = 0; o < OB; ++o) {
+        if (cb + o >= g.cq) break;
+        float* qc = q + (int64_t)(cb + o) * qn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ix = 2 * ox + (e >> 1), iy = 2 * oy + (e & 1);
+            *(float2*)(qc + ((int64_t)ix * qy + iy) * qz + 2 * oz) = make_float2(acc[2 * e][o], acc[2 * e + 1][o]);
+        }
+    }
+}
+
+// wgrad: one (dx, dy) tap row (three taps along z), four channels of P and eight of Q per workgroup column; every wave leaves its 96
+// partial sums in ws (parts, cpp, cqp, 27); the host adds the parts (a fixed order: no atomics).
+template <int S>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, float* __restrict__ ws) {
+    constexpr int PB = 4, QB = 8;
+    const int pn = g.x * g.y * g.z;
+    const int qx = g.x * S, qy = g.y * S, qz = g.z * S;
+    const uint32_t qn_bytes = (uint32_t)qx * qy * qz * 4u;
+    const int nqb = g.cqp / QB, npb = g.cpp / PB;
+    const int row = blockIdx.y % 9, qb = (blockIdx.y / 9) % nqb * QB, pb = blockIdx.y / (9 * nqb) * PB;
+    (void)npb;
+    const int dx = row / 3, dy = row % 3;
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * qx * qy * qz);
+    const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * pn);
+    float acc[PB][QB][3];
+#pragma unroll
+    for (int a = 0; a < PB; ++a)
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[a][b][t] = 0.0f;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < pn; v += gridDim.x * 256) {
+        const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+        const int ix = ox * S + dx - 1, iy = oy * S + dy - 1, iz = oz * S - 1;
+        const bool okr = (unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy;
+        const uint32_t base = (uint32_t)((ix * qy + iy) * qz + iz) * 4u;
+        uint32_t off[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) off[t] = (okr && (unsigned)(iz + t) < (unsigned)qz) ? base + 4u * t : CONV_OOB;
+        float pv[PB];
+#pragma unroll
+        for (int a = 0; a < PB; ++a) pv[a] = pb + a < g.cp ? conv_load(pr, (uint32_t)v * 4u, (uint32_t)(pb + a) * (uint32_t)pn * 4u) : 0.0f;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            if (qb + b >= g.cq) break;                                           // (uniform) padding channels of the last block
+            const uint32_t soff = (uint32_t)(qb + b) * qn_bytes;
+            float qv[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) qv[t] = conv_load(qr, off[t], soff);
+#pragma unroll
+            for (int a = 0; a < PB; ++a)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
+        }
+    }
+    const int lane = threadIdx.x & 63, part = blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll
+    for (int a = 0; a < PB; ++a)
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float s = acc[a][b][t];
+                GENS_DPP_SCAN(s, 0.0f, op_add_);                                 // lane 63 holds the wave's total
+                if (lane == 63) ws[(((int64_t)part * g.cpp + pb + a) * g.cqp + qb + b) * 27 + row * 3 + t] = s;
+            }
+}
+
+static int conv_geom(const int* dims_p, int cp, int cq, int stride, ConvGeom& g, const char* what) {
+    GENS_CHECK_ARG(dims_p && dims_p[0] > 0 && dims_p[1] > 0 && dims_p[2] > 0 && cp > 0 && cq > 0, GENS_EINVAL, "%s: bad shape", what);
+    GENS_CHECK_ARG(stride == 1 || stride == 2, GENS_EINVAL, "%s: stride %d (1 or 2)", what, stride);
+    const int64_t pn = (int64_t)dims_p[0] * dims_p[1] * dims_p[2], qn = pn * stride * stride * stride;
+    GENS_CHECK_ARG(pn * (cp + 8) * 4 < (int64_t)CONV_OOB && qn * (cq + 8) * 4 < (int64_t)CONV_OOB, GENS_EINVAL,
+                   "%s: a tensor of 2 GiB or more (32-bit buffer offsets)", what);
+    g.x = dims_p[0]; g.y = dims_p[1]; g.z = dims_p[2];
+    g.cp = cp; g.cq = cq;
+    return 0;
+}
+
+extern "C" int gens_conv3d_gather(const float* q, const float* w, const float* bias, int cp, int cq, const int* dims_p, int stride,
+                                  float* p, void* stream) {
+    ConvGeom g;
+    if (int rc = conv_geom(dims_p, cp, cq, stride, g, "gens_conv3d_gather")) return rc;
+    GENS_CHECK_ARG(q && w && p, GENS_EINVAL, "gens_conv3d_gather: null pointer");
+    const int ob = cp > 4 ? 8 : 4;
+    g.cpp = (cp + ob - 1) / ob * ob;
+    g.cqp = cq;
+    const dim3 grid(gens_blocks((int64_t)g.x * g.y * g.z, 256), g.cpp / ob);
+    hipStream_t s = (hipStream_t)stream;
+    if (ob == 8) {
+        if (stride == 1) hipLaunchKernelGGL((conv3d_gather_k<8, 1>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        else hipLaunchKernelGGL((conv3d_gather_k<8, 2>), grid, dim3(256), 0, s, q, w, bias, g, p);
+    } else {
+        if (stride == 1) hipLaunchKernelGGL((conv3d_gather_k<4, 1>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        else hipLaunchKernelGGL((conv3d_gather_k<4, 2>), grid, dim3(256), 0, s, q, w, bias, g, p);
+    }
+    return gens_launch_status("gens_conv3d_gather");
+}
+
+extern "C" int gens_conv3d_scatter2(const float* p, const float* w, int cp, int cq, const int* dims_p, float* q, void* stream) {
+    ConvGeom g;
+    if (int rc = conv_geom(dims_p, cp, cq, 2, g, "gens_conv3d_scatter2")) return rc;
+    GENS_CHECK_ARG(p && w && q, GENS_EINVAL, "gens_conv3d_scatter2: null pointer");
+    const int ob = cq > 4 ? 8 : 4;
+    g.cqp = (cq + ob - 1) / ob * ob;
+    g.cpp = cp;
+    const dim3 grid(gens_blocks((int64_t)g.x * g.y * g.z, 256), g.cqp / ob);
+    hipStream_t s = (hipStream_t)stream;
+    if (ob == 8) hipLaunchKernelGGL((conv3d_scatter2_k<8>), grid, dim3(256), 0, s, p, w, g, q);
+    else hipLaunchKernelGGL((conv3d_scatter2_k<4>), grid, dim3(256), 0, s, p, w, g, q);
+    return gens_launch_status("gens_conv3d_scatter2");
+}
+
+static void wgrad_shape(int cp, int cq, int64_t pn, int& cpp, int& cqp, int& ny, int& nblk) {
+    cpp = (cp + 3) / 4 * 4;
+    cqp = (cq + 7) / 8 * 8;
+    ny = 9 * (cpp / 4) * (cqp / 8);
+    const int64_t chunks = (pn + 255) / 256;
+    int64_t want = (4096 + ny - 1) / ny;                         // ~4096 workgroups per launch, each with >= 4 chunks of voxels if there are that many
+    if (want > (chunks + 3) / 4) want = (chunks + 3) / 4;
+    nblk = (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p) {
+    if (!dims_p || cp <= 0 || cq <= 0) return 0;
+    int cpp, cqp, ny, nblk;
+    wgrad_shape(cp, cq, (int64_t)dims_p[0] * dims_p[1] * dims_p[2], cpp, cqp, ny, nblk);
+    return nblk * 4;
+}
+
+extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream) {
+    ConvGeom g;
+    if (int rc = conv_geom(dims_p, cp, cq, stride, g, "gens_conv3d_wgrad")) return rc;
+    GENS_CHECK_ARG(p && q && workspace, GENS_EINVAL, "gens_conv3d_wgrad: null pointer");
+    int ny, nblk;
+    wgrad_shape(cp, cq, (int64_t)g.x * g.y * g.z, g.cpp, g.cqp, ny, nblk);
+    const dim3 grid(nblk, ny);
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1>), grid, dim3(256), 0, s, p, q, g, workspace);
+    else hipLaunchKernelGGL((conv3d_wgrad_k<2>), grid, dim3(256), 0, s, p, q, g, workspace);
+    return gens_launch_status("gens_conv3d_wgrad");
+}

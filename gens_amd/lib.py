@@ -51,6 +51,10 @@ SIGNATURES = {
     "gens_volume_build_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _p],
     "gens_gemm_tn_slabs": [_l, _i, _i],
     "gens_gemm_tn": [_p, _p, _l, _i, _i, _p, _p, _p],
+    "gens_conv3d_gather": [_p, _p, _p, _i, _i, _ip, _i, _p, _p],
+    "gens_conv3d_scatter2": [_p, _p, _i, _i, _ip, _p, _p],
+    "gens_conv3d_wgrad_parts": [_i, _i, _ip],
+    "gens_conv3d_wgrad": [_p, _p, _i, _i, _ip, _i, _p, _p],
     "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],
     "gens_lookup_volume_bwd": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p],
     "gens_lookup_volume_bwd2": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p],

@@ -2,9 +2,11 @@
 keys (gens.py:12-157), with the volume build and the renderer running on libgens_hip.so.
 
 The 2-D feature CNN (MnasNet) and the 3-D regularisation U-Net are outside the accelerated path (SURVEY.md
-section 2 rows 4h, 4i: dense convolutions, MIOpen through PyTorch).  They are taken from the host application:
-either registered explicitly with `register_backbones`, or imported from the reference tree this package is
-dropped into (`models.modules.feature_network_mnasnet.FeatureNetwork`, `models.modules.reg_network.RegNetwork`).
+section 2 rows 4h, 4i: dense convolutions, MIOpen through PyTorch).  In order of preference: classes
+registered with `register_backbones`; the reference tree this package is dropped into
+(`models.modules.feature_network_mnasnet.FeatureNetwork`, `models.modules.reg_network.RegNetwork`); this package's own
+restatements with the same parameter names (`modules/feature_network.py`, `modules/reg_network.py`), so that `GenS(confs)`
+also runs stand-alone.
 """
 import importlib
 
@@ -32,9 +34,9 @@ def _backbone(kind):
                     "reg": ("models.modules.reg_network", "RegNetwork")}[kind]
     try:
         return getattr(importlib.import_module(module), name)
-    except ImportError as e:
-        raise ImportError(f"GenS needs {module}.{name} from the host application (it is outside the accelerated path); "
-                          "put the reference tree on sys.path or call gens_amd.models.gens.register_backbones()") from e
+    except ImportError:                    # stand-alone: this package's own restatement (same parameter names, MIOpen convolutions)
+        from .modules import feature_network, reg_network
+        return {"feature": feature_network.FeatureNetwork, "reg": reg_network.RegNetwork}[kind]
 
 
 class GenS(nn.Module):

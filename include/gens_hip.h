@@ -310,6 +310,25 @@ int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int re
 int gens_gemm_tn_slabs(int64_t k, int m, int n);
 int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float* workspace, float* c, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K15  the 3 x 3 x 3 convolutions of the cost-volume U-Net (reg_network.py:7-50: nn.Conv3d(k=3, padding=1, stride 1 | 2) and
+ *      nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), i.e. aten::convolution / convolution_backward as MIOpen runs
+ *      them), batch 1, float32.  A coarse tensor P (cp, X, Y, Z) and a fine tensor Q (cq, sX, sY, sZ) are tied by W[cp][cq][27]:
+ *        gather    P[a][o] = bias[a] + sum W[a][b][t] Q[b][s o + t - 1]      Conv3d forward (a = out, b = in), ConvTranspose3d dgrad
+ *        scatter2  Q[b][i] = sum W[a][b][t] P[a][(i + 1 - t) / 2]            ConvTranspose3d forward (a = in, b = out), Conv3d(s=2) dgrad
+ *        wgrad     dW[a][b][t] = sum_o P[a][o] Q[b][s o + t - 1]             both weight gradients, in W's own layout
+ *      dims_p = {X, Y, Z} (host).  Weight layouts (the host permutes the small tensor): gather w (cq, 27, cpp), cpp = cp rounded up
+ *      to 8 (cp > 4) or 4, zero-filled; scatter2 w (cp, 27, cqp), cqp likewise from cq.  bias may be NULL.  A stride-1 scatter is a
+ *      gather with the 27 taps reversed and the channel roles swapped.  wgrad writes partial sums (parts, cpp4, cqp8, 27) with
+ *      parts = gens_conv3d_wgrad_parts(...), cpp4 = cp rounded up to 4, cqp8 = cq rounded up to 8; the caller adds over `parts`
+ *      (fixed order: deterministic).  Every tensor must be smaller than 2 GiB.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_conv3d_gather(const float* q, const float* w, const float* bias, int cp, int cq, const int* dims_p, int stride,
+                       float* p, void* stream);
+int gens_conv3d_scatter2(const float* p, const float* w, int cp, int cq, const int* dims_p, float* q, void* stream);
+int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p);
+int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

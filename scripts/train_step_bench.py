@@ -71,6 +71,25 @@ def main():
         opt.step()
         return float(loss)
 
+    full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen
+    if full:                                     # matching copy too) and the 3-D U-Net inside the step
+        from gens_amd.models import gens
+        torch.manual_seed(0)
+        model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
+        full_opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+
+        def step():  # noqa: F811
+            out = model("train", ipts, cos_anneal_ratio=0.5, step=1)
+            ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]
+            loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
+                + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
+                + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
+                + out["pseudo_sdf"].abs().mean()
+            full_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            full_opt.step()
+            return float(loss)
+
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -80,7 +99,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"{'fine-tune' if finetune else 'train'} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    print(f"{'full (CNNs + hot path)' if full else 'fine-tune' if finetune else 'train'} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
 
 
 if __name__ == "__main__":

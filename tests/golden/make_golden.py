@@ -562,8 +562,54 @@ def g14_clean_mesh():
     npz("g14_clean_mesh", **out)
 
 
+def g16_backbones():
+    """The reference's RegNetwork (models/modules/reg_network.py:105-169) and FeatureNetwork (feature_network_mnasnet.py:53-103) with
+    seeded random weights.  RegNetwork imports nothing but torch; FeatureNetwork takes its trunk from torchvision (absent): the stub's
+    `mnasnet1_0` hands it gens_amd's restatement of the MnasNet-1.0 `layers`, so this golden pins the reference's wiring around the
+    trunk (stage cuts, decoder, heads, parameter names), not the trunk against torchvision."""
+    import torch.nn as nn
+    from models.modules.reg_network import RegNetwork
+    out = {}
+    torch.manual_seed(160)
+    net = RegNetwork(_Conf(d_voluem=[8, 8, 8], d_out=[4, 4, 4], d_base=8)).eval()
+    g = torch.Generator().manual_seed(161)
+    vols = [torch.randn(1, 8, d, d, d, generator=g).requires_grad_(True) for d in (16, 8, 4)]
+    cots = [torch.randn(1, 4, d, d, d, generator=g) for d in (16, 8, 4)]
+    outs = net(vols)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    for i in range(3):
+        out[f"reg.in{i}"], out[f"reg.cot{i}"], out[f"reg.out{i}"], out[f"reg.gin{i}"] = vols[i].detach(), cots[i], outs[i].detach(), vols[i].grad
+    out["reg.keys"] = np.array(list(net.state_dict().keys()))
+    for k, v in net.state_dict().items():
+        out[f"reg.w.{k}"] = v
+    out["reg.gw.conv0"] = net.conv0.conv.weight.grad
+
+    from gens_amd.models.modules.feature_network import _mnasnet_trunk
+    sys.modules["torchvision.models"].mnasnet1_0 = lambda pretrained=True: types.SimpleNamespace(
+        layers=nn.Sequential(*_mnasnet_trunk(), nn.Identity(), nn.Identity(), nn.Identity()))
+    from models.modules.feature_network_mnasnet import FeatureNetwork
+    torch.manual_seed(162)
+    fnet = FeatureNetwork(_Conf(d_out=[4, 4, 4, 4, 4]))
+    imgs = torch.rand(2, 3, 64, 96, generator=g)
+    out["feat.imgs"] = imgs
+    with torch.no_grad():
+        for i, o in enumerate(fnet.eval()(imgs)):
+            out[f"feat.eval{i}"] = o
+        for i, o in enumerate(fnet.train()(imgs)):            # BatchNorm on batch statistics; updates the running ones
+            out[f"feat.train{i}"] = o
+    sd = fnet.state_dict()
+    out["feat.keys"] = np.array(list(sd.keys()))
+    out["feat.shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+    out["feat.sums"] = np.array([float(v.double().sum()) for v in sd.values()])
+    out["feat.abs_sums"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    npz("g16_backbones", **out)
+
+
 def main():
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "g16":
+        g16_backbones()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_dtu_dataset()
         return

@@ -125,6 +125,39 @@ def test_gens_train_step_backward_reaches_every_trainable_parameter():
     opt.step()
 
 
+def test_gens_stand_alone_train_step_with_its_own_backbones():
+    """GenS with this package's FeatureNetwork (MnasNet trunk) and RegNetwork (3-D U-Net), nothing registered and no reference tree:
+    one train step at 64x96, gradients through K4 / K1 into the 2-D CNN and through K2 / K2'' / K10 into the 3-D one."""
+    from gens_amd import synthetic
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models import gens
+    saved = dict(gens._BACKBONES)
+    gens._BACKBONES.clear()
+    try:
+        torch.manual_seed(0)
+        model = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4))).cuda().train()
+    finally:
+        gens._BACKBONES.update(saved)
+    sc = synthetic.make_scene(nv=4, h=64, w=96, n_levels=1, seed=5)
+    g = torch.Generator().manual_seed(2)
+    pix = torch.stack([torch.randint(4, 92, (64,), generator=g), torch.randint(4, 60, (64,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 64, 96, pixels=pix)
+    ipts = {k: v.cuda() for k, v in {"imgs": sc["imgs"], "intrs": sc["intrs"], "c2ws": sc["c2ws"], "rays_o": ro, "rays_d": rd, "near": sc["near"],
+                                     "far": sc["far"], "pseudo_pts": torch.rand(256, 3, generator=g) - 0.5}.items()}
+    out = model("train", ipts, cos_anneal_ratio=0.3, step=5)               # step % 5 == 0: the matching network takes the weights (gens.py:133-138)
+    (_loss(out) + out["pseudo_sdf"].abs().mean()).backward()
+    for name, p in model.named_parameters():
+        if name.startswith("match_feature_network"):
+            assert p.grad is None
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert model.feature_network.layer1[0].weight.grad.abs().sum() > 0 and model.feature_network.out_layer5.weight.grad.abs().sum() > 0
+    assert model.reg_network.conv0.conv.weight.grad.abs().sum() > 0 and model.reg_network.out_layers[2].weight.grad.abs().sum() > 0
+    for a, b in zip(model.feature_network.parameters(), model.match_feature_network.parameters()):
+        assert torch.equal(a, b)                       # (the BatchNorm running statistics have moved on with the matching pass)
+    torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3})).step()
+
+
 def test_gens_finetune_volumes_are_parameters_and_checkpoint_roundtrip(tmp_path):
     model = _gens()
     ipts = _inputs(nv=3)
