@@ -55,6 +55,11 @@ SIGNATURES = {
     "gens_conv3d_scatter2": [_p, _p, _i, _i, _ip, _p, _p],
     "gens_conv3d_wgrad_parts": [_i, _i, _ip],
     "gens_conv3d_wgrad": [_p, _p, _i, _i, _ip, _i, _p, _p],
+    "gens_instnorm_blocks": [_i, _l],
+    "gens_instnorm_stats": [_p, _i, _l, _p, _p],
+    "gens_instnorm_relu_fwd": [_p, _p, _i, _l, _p, _p],
+    "gens_instnorm_relu_bwd_stats": [_p, _p, _p, _i, _l, _p, _p],
+    "gens_instnorm_relu_bwd": [_p, _p, _p, _p, _i, _l, _p, _p],
     "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],
     "gens_lookup_volume_bwd": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p],
     "gens_lookup_volume_bwd2": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p],

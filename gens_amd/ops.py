@@ -948,6 +948,49 @@ def conv_transpose3d(x, weight):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# K16  InstanceNorm3d (no affine) + ReLU of the U-Net blocks (reg_network.py:16-17,39-40)
+# ------------------------------------------------------------------------------------------------------------------
+_f64 = torch.float64
+
+
+class _InstNormRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x2 = _c(x.detach().to(_f32)).reshape(x.shape[1], -1)
+        c, n = x2.shape
+        blocks = L.load().gens_instnorm_blocks(c, n)
+        part = torch.empty(c, blocks, 2, device=x.device, dtype=_f64)
+        L.call("gens_instnorm_stats", L.ptr(x2), c, n, L.ptr(part, _f64), L.stream(), nbytes=4 * c * n)
+        s = part.sum(1) / n                                                        # float64: mean, mean of squares
+        mean = s[:, 0]
+        mr = torch.stack([mean, torch.rsqrt((s[:, 1] - mean * mean).clamp_min(0.0) + eps)], 1).to(_f32)
+        y = torch.empty_like(x2)
+        L.call("gens_instnorm_relu_fwd", L.ptr(x2), L.ptr(mr), c, n, L.ptr(y), L.stream(), nbytes=8 * c * n)
+        ctx.save_for_backward(x2, mr)
+        ctx.blocks = blocks
+        return y.reshape(x.shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x2, mr = ctx.saved_tensors
+        c, n = x2.shape
+        g2 = _c(gy.to(_f32)).reshape(c, n)
+        part = torch.empty(c, ctx.blocks, 2, device=x2.device, dtype=_f64)
+        L.call("gens_instnorm_relu_bwd_stats", L.ptr(x2), L.ptr(g2), L.ptr(mr), c, n, L.ptr(part, _f64), L.stream(), nbytes=8 * c * n)
+        m12 = (part.sum(1) / n).to(_f32)
+        gx = torch.empty_like(x2)
+        L.call("gens_instnorm_relu_bwd", L.ptr(x2), L.ptr(g2), L.ptr(mr), L.ptr(m12), c, n, L.ptr(gx), L.stream(), nbytes=12 * c * n)
+        return gx.reshape(gy.shape), None
+
+
+def instnorm_relu(x, eps=1e-5):
+    """relu(instance_norm(x)) for x (1, c, ...): per-channel statistics over the plane, biased variance, no affine parameters."""
+    assert x.shape[0] == 1 and x.dim() >= 3
+    return _InstNormRelu.apply(x, float(eps))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # K7  fused source-view look-up + BlendingNetwork (inference)   (projector.py:278-349 + blending_network.py:69-118)
 # ------------------------------------------------------------------------------------------------------------------
 def _pad32(b):

@@ -329,6 +329,22 @@ int gens_conv3d_scatter2(const float* p, const float* w, int cp, int cq, const i
 int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p);
 int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K16  InstanceNorm3d (affine=False, biased variance) + ReLU after every convolution of the U-Net (reg_network.py:16-17,39-40:
+ *      aten::instance_norm + aten::relu_ and their backward), batch 1, float32 planes x (c, n).
+ *        gens_instnorm_stats           partials (c, blocks, 2) float64: sums of x and x^2 per workgroup, blocks = gens_instnorm_blocks(c, n)
+ *        gens_instnorm_relu_fwd        y = max((x - mean) * rstd, 0), mean_rstd (c, 2) float32
+ *        gens_instnorm_relu_bwd_stats  partials (c, blocks, 2) float64: sums of g and g xhat, g = gy [xhat > 0], xhat = (x - mean) * rstd
+ *        gens_instnorm_relu_bwd        gx = rstd (g - m1 - xhat m2), g_means (c, 2) float32 = {m1 = mean(g), m2 = mean(g xhat)}
+ *      The caller adds the partials (float64) and forms mean / rstd / m1 / m2.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_instnorm_blocks(int c, int64_t n);
+int gens_instnorm_stats(const float* x, int c, int64_t n, double* partials, void* stream);
+int gens_instnorm_relu_fwd(const float* x, const float* mean_rstd, int c, int64_t n, float* y, void* stream);
+int gens_instnorm_relu_bwd_stats(const float* x, const float* gy, const float* mean_rstd, int c, int64_t n, double* partials, void* stream);
+int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rstd, const float* g_means, int c, int64_t n, float* gx,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

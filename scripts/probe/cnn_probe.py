@@ -53,6 +53,10 @@ for name, m in (("conv3d 8->8 s1 256^3", rnet.conv0.conv), ("conv3d 8->8 s2 256^
 import torch.nn.functional as F  # noqa: E402
 wt = rnet.conv0.conv.weight.detach()
 timed("torch (MIOpen) conv3d 8->8 s1 256^3 fwd", lambda: F.conv3d(x, wt, None, 1, 1))
+from gens_amd import ops  # noqa: E402
+xr0 = x.clone().requires_grad_(True)
+timed("K16 instnorm+relu 8ch 256^3 fwd", lambda: ops.instnorm_relu(xr0))
+timed("K16 instnorm+relu 8ch 256^3 fwd+bwd", lambda: ops.instnorm_relu(xr0).sum().backward())
 inorm = torch.nn.InstanceNorm3d(8)
 xr = x.clone().requires_grad_(True)
 timed("InstanceNorm3d 8ch 256^3 fwd", lambda: inorm(xr))

@@ -93,3 +93,32 @@ def test_reg_network_on_the_device_matches_the_cpu_module():
         _close(f"gin{i}", dvols[i].grad, vols[i].grad, 2e-4)
     for (name, p), q in zip(net.named_parameters(), dnet.parameters()):
         _close(name, q.grad, p.grad, 5e-4)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 16, 16, 16), (1, 3, 5, 7, 9), (1, 32, 4, 4, 4), (1, 1, 1, 1, 3), (1, 8, 64, 64, 64)])
+def test_instnorm_relu_matches_torch(shape):
+    """K16 against torch's float64 instance_norm + relu on the CPU: value and gradient."""
+    from gens_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    cot = torch.randn(shape, generator=g)
+    y = torch.relu(F.instance_norm(x.double(), eps=1e-5))
+    (gx,) = torch.autograd.grad(y, x, cot.double())
+    xd = x.detach().cuda().requires_grad_(True)
+    yd = ops.instnorm_relu(xd, 1e-5)
+    _close("value", yd, y, 1e-5)
+    # an element whose xhat is within rounding of 0 may take the other ReLU branch: compare away from the kink
+    (gd,) = torch.autograd.grad(yd, xd, cot.cuda())
+    xh = F.instance_norm(x.detach().double(), eps=1e-5)
+    keep = xh.abs() > 1e-5
+    err = ((gd.cpu().double() - gx) * keep).abs().max().item() / gx.abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_instnorm_relu_statistics_survive_a_large_offset():
+    """Sums are accumulated in float64: mean 1000, standard deviation 1 (E[x^2] - E[x]^2 in float32 would keep no digit)."""
+    from gens_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 2, 32, 32, 32, generator=g) + 1000.0
+    y = torch.relu(F.instance_norm(x.double()))
+    _close("value", ops.instnorm_relu(x.cuda()), y, 2e-4)                            # x itself carries 6e-5 of rounding at 1000
