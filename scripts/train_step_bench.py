@@ -94,7 +94,7 @@ def main():
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 20
+    n = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
     for _ in range(n):
         step()
     torch.cuda.synchronize()
