@@ -137,17 +137,24 @@ __global__ __launch_bounds__(256) void conv3d_scatter2_k(const float* __restrict
     }
 }
 
-// wgrad: one (dx, dy) tap row (three taps along z), four channels of P and eight of Q per workgroup column; every wave leaves its 96
-// partial sums in ws (parts, cpp, cqp, 27); the host adds the parts (a fixed order: no atomics).
-template <int S>
-__global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, float* __restrict__ ws) {
-    constexpr int PB = 4, QB = 8;
+// wgrad: one (dx, dy) tap row (three taps along z), PB = 8 (or 4) channels of P and eight of Q per workgroup column; every wave leaves its
+// 3 PB QB partial sums in ws (parts, cpp, cqp, 27); the host adds the parts (a fixed order: no atomics).
+template <int S, int PB>
+__global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int n_ranges, int chunks_per_range,
+                                                      float* __restrict__ ws) {
+    constexpr int QB = 8;
     const int pn = g.x * g.y * g.z;
     const int qx = g.x * S, qy = g.y * S, qz = g.z * S;
     const uint32_t qn_bytes = (uint32_t)qx * qy * qz * 4u;
-    const int nqb = g.cqp / QB, npb = g.cpp / PB;
-    const int row = blockIdx.y % 9, qb = (blockIdx.y / 9) % nqb * QB, pb = blockIdx.y / (9 * nqb) * PB;
-    (void)npb;
+    // Work item = (range of consecutive voxel chunks, column) with column = (tap row, Q block, P block).  All columns of a range
+    // re-read the same planes of P and Q: they are given consecutive slots on ONE XCD (workgroup id % 8), so that the range comes
+    // from HBM once and from that XCD's L2 for the other columns (with the columns spread over the launch, each streamed the
+    // planes from HBM again: 14.5 GB per 8 -> 8 layer at 256^3, 5 TB/s -- HBM-bound).
+    const int nqb = g.cqp / QB, ny = 9 * nqb * (g.cpp / PB);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int col = slot % ny, range = xcd + 8 * (slot / ny);
+    if (range >= n_ranges) return;
+    const int row = col % 9, qb = (col / 9) % nqb * QB, pb = col / (9 * nqb) * PB;
     const int dx = row / 3, dy = row % 3;
     const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * qx * qy * qz);
     const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * pn);
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
         for (int b = 0; b < QB; ++b)
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[a][b][t] = 0.0f;
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < pn; v += gridDim.x * 256) {
+    const int v_end = min(pn, (range + 1) * chunks_per_range * 256);
+    for (int v = range * chunks_per_range * 256 + threadIdx.x; v < v_end; v += 256) {
         const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
         const int ix = ox * S + dx - 1, iy = oy * S + dy - 1, iz = oz * S - 1;
         const bool okr = (unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
                 for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
         }
     }
-    const int lane = threadIdx.x & 63, part = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, part = range * 4 + (threadIdx.x >> 6);
 #pragma unroll
     for (int a = 0; a < PB; ++a)
 #pragma unroll
@@ -240,32 +248,37 @@ extern "C" int gens_conv3d_scatter2(const float* p, const float* w, int cp, int 
     return gens_launch_status("gens_conv3d_scatter2");
 }
 
-static void wgrad_shape(int cp, int cq, int64_t pn, int& cpp, int& cqp, int& ny, int& nblk) {
-    cpp = (cp + 3) / 4 * 4;
+static int wgrad_pb(int cp) { (void)cp; return 4; }             // channels of P per column (8 x 8 x 3 accumulators: 264 VGPRs, one wave per SIMD, 1.4x slower)
+
+static void wgrad_shape(int cp, int cq, int64_t pn, int& cpp, int& cqp, int& ny, int& n_ranges, int& chunks_per_range) {
+    const int pb = wgrad_pb(cp);
+    cpp = (cp + pb - 1) / pb * pb;
     cqp = (cq + 7) / 8 * 8;
-    ny = 9 * (cpp / 4) * (cqp / 8);
+    ny = 9 * (cpp / pb) * (cqp / 8);
     const int64_t chunks = (pn + 255) / 256;
-    int64_t want = (4096 + ny - 1) / ny;                         // ~4096 workgroups per launch, each with >= 4 chunks of voxels if there are that many
+    int64_t want = (8192 + ny - 1) / ny;                         // ~8 000 work items per launch, each with >= 4 chunks of voxels if there are that many
     if (want > (chunks + 3) / 4) want = (chunks + 3) / 4;
-    nblk = (int)(want < 1 ? 1 : want);
+    if (want < 1) want = 1;
+    chunks_per_range = (int)((chunks + want - 1) / want);
+    n_ranges = (int)((chunks + chunks_per_range - 1) / chunks_per_range);
 }
 
 extern "C" int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p) {
     if (!dims_p || cp <= 0 || cq <= 0) return 0;
-    int cpp, cqp, ny, nblk;
-    wgrad_shape(cp, cq, (int64_t)dims_p[0] * dims_p[1] * dims_p[2], cpp, cqp, ny, nblk);
-    return nblk * 4;
+    int cpp, cqp, ny, n_ranges, cpr;
+    wgrad_shape(cp, cq, (int64_t)dims_p[0] * dims_p[1] * dims_p[2], cpp, cqp, ny, n_ranges, cpr);
+    return n_ranges * 4;
 }
 
 extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream) {
     ConvGeom g;
     if (int rc = conv_geom(dims_p, cp, cq, stride, g, "gens_conv3d_wgrad")) return rc;
     GENS_CHECK_ARG(p && q && workspace, GENS_EINVAL, "gens_conv3d_wgrad: null pointer");
-    int ny, nblk;
-    wgrad_shape(cp, cq, (int64_t)g.x * g.y * g.z, g.cpp, g.cqp, ny, nblk);
-    const dim3 grid(nblk, ny);
+    int ny, n_ranges, cpr;
+    wgrad_shape(cp, cq, (int64_t)g.x * g.y * g.z, g.cpp, g.cqp, ny, n_ranges, cpr);
+    const dim3 grid(8u * (unsigned)ny * (unsigned)((n_ranges + 7) / 8));
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1>), grid, dim3(256), 0, s, p, q, g, workspace);
-    else hipLaunchKernelGGL((conv3d_wgrad_k<2>), grid, dim3(256), 0, s, p, q, g, workspace);
+    if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1, 4>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
+    else hipLaunchKernelGGL((conv3d_wgrad_k<2, 4>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
     return gens_launch_status("gens_conv3d_wgrad");
 }

@@ -889,6 +889,14 @@ def _conv_wgrad(p, q, stride):
     return ws.sum(0)[:cp, :cq]
 
 
+def _plane_sums(x2):
+    """Per-row sums of a (c, n) float32 tensor through K16's statistics pass (float64 accumulation, the whole chip per row)."""
+    c, n = x2.shape
+    part = torch.empty(c, L.load().gens_instnorm_blocks(c, n), 2, device=x2.device, dtype=torch.float64)
+    L.call("gens_instnorm_stats", L.ptr(x2), c, n, L.ptr(part, torch.float64), L.stream(), nbytes=4 * c * n)
+    return part[:, :, 0].sum(1).to(_f32)
+
+
 class _Conv3d(torch.autograd.Function):
     """torch.nn.functional.conv3d(x, w, b, stride, padding=1) for a 3 x 3 x 3 kernel and batch 1."""
 
@@ -911,7 +919,7 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _conv_wgrad(g3, x3, ctx.stride).reshape(w.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g3.sum((1, 2, 3))
+            gb = _plane_sums(g3.reshape(g3.shape[0], -1))                # (aten::sum over a (4, 256^3) tensor takes 3.6 ms: 4 outputs, no parallelism)
         return gx, gw, gb, None
 
 
