@@ -159,10 +159,11 @@ __global__ __launch_bounds__(TV_BLOCK) void tv_fwd_k(const float* __restrict__ v
 }
 
 __global__ __launch_bounds__(TV_BLOCK) void tv_bwd_k(const float* __restrict__ vol, const float* __restrict__ mask, int X, int Y, int Z,
-                                                     float coef, float* __restrict__ g_vol) {
+                                                     float coef, const float* __restrict__ coef_dev, float* __restrict__ g_vol) {
     int64_t n = (int64_t)X * Y * Z;
     int64_t i = (int64_t)blockIdx.x * TV_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (coef_dev != nullptr) coef *= coef_dev[0];
     int kz = (int)(i % Z), jy = (int)((i / Z) % Y), ix = (int)(i / ((int64_t)Z * Y));
     int64_t sx = (int64_t)Y * Z, sy = Z;
     float m = mask[i];
@@ -192,8 +193,16 @@ extern "C" int gens_tv_fwd(const float* vol, const float* mask, int x, int y, in
 extern "C" int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float coef, float* g_vol, void* stream) {
     GENS_CHECK_ARG(vol && mask && g_vol && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_bwd: bad argument");
     int64_t n = (int64_t)x * y * z;
-    tv_bwd_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, g_vol);
+    tv_bwd_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, nullptr, g_vol);
     return gens_launch_status("gens_tv_bwd");
+}
+
+extern "C" int gens_tv_bwd_scaled(const float* vol, const float* mask, int x, int y, int z, float coef, const float* coef_dev, float* g_vol,
+                                  void* stream) {
+    GENS_CHECK_ARG(vol && mask && coef_dev && g_vol && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_bwd_scaled: bad argument");
+    int64_t n = (int64_t)x * y * z;
+    tv_bwd_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, coef_dev, g_vol);
+    return gens_launch_status("gens_tv_bwd_scaled");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

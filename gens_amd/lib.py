@@ -77,6 +77,7 @@ SIGNATURES = {
     "gens_upsample2d_into": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
+    "gens_tv_bwd_scaled": [_p, _p, _i, _i, _i, _f, _p, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
     "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p, _p],
     "gens_compact_valid": [_p, _l, _p, _p, _p, _p],

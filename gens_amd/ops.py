@@ -577,9 +577,9 @@ class _TVLevel(torch.autograd.Function):
     def backward(ctx, g):
         vol, mask, tv, den = ctx.saved_tensors
         _, _, x, y, z = vol.shape
-        coef = float(g / (2.0 * tv * den))
+        coef = _c((g / (2.0 * tv * den)).to(_f32).reshape(1))                  # stays on the device (float(...) here stalled the host once per level)
         g_vol = torch.empty_like(vol)
-        L.call("gens_tv_bwd", L.ptr(vol), L.ptr(mask), x, y, z, coef, L.ptr(g_vol), L.stream())
+        L.call("gens_tv_bwd_scaled", L.ptr(vol), L.ptr(mask), x, y, z, 1.0, L.ptr(coef), L.ptr(g_vol), L.stream())
         return g_vol, None
 
 

@@ -292,6 +292,9 @@ int gens_mc_emit(const float* u, int x, int y, int z, float iso, const int8_t* t
 int gens_tv_blocks(int64_t n_voxels);
 int gens_tv_fwd(const float* vol, const float* mask, int x, int y, int z, float* partial, void* stream);
 int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float coef, float* g_vol, void* stream);
+/* the same with the coefficient = coef * coef_dev[0], coef_dev a device scalar (the upstream gradient stays on the device: no host sync) */
+int gens_tv_bwd_scaled(const float* vol, const float* mask, int x, int y, int z, float coef, const float* coef_dev, float* g_vol,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K11  the lattice of extract_geometry                            (implicit_surface.py:407-418)
