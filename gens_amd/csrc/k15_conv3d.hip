@@ -61,19 +61,29 @@ __global__ __launch_bounds__(256) void conv3d_gather_k(const float* __restrict__
     float acc[OB];
 #pragma unroll
     for (int o = 0; o < OB; ++o) acc[o] = (bias != nullptr && cb + o < g.cp) ? bias[cb + o] : 0.0f;
+    // Two register buffers: the 27 loads of input channel b + 1 are in flight while the 27 OB multiply-adds of channel b run (a single
+    // buffer left every channel's load latency exposed: the loop body was "27 loads, wait, 108 packed FMAs").
     const float* wc = w + cb;
     uint32_t soff = 0;
-    for (int b = 0; b < g.cq; ++b) {
-        float xv[27];
-#pragma unroll
-        for (int t = 0; t < 27; ++t) xv[t] = conv_load(qr, off[t], soff);
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-            for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[t * g.cpp + o], xv[t], acc[o]);
-        wc += 27 * g.cpp;
-        soff += qn_bytes;
+    float xa[27], xb[27];
+#define GATHER_LOAD(buf)                                                  \
+    _Pragma("unroll") for (int t = 0; t < 27; ++t) buf[t] = conv_load(qr, off[t], soff); \
+    soff += qn_bytes
+#define GATHER_FMA(buf)                                                   \
+    _Pragma("unroll") for (int t = 0; t < 27; ++t)                        \
+        _Pragma("unroll") for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[t * g.cpp + o], buf[t], acc[o]); \
+    wc += 27 * g.cpp
+    GATHER_LOAD(xa);
+    for (int b = 0; b < g.cq; b += 2) {
+        if (b + 1 < g.cq) { GATHER_LOAD(xb); }
+        GATHER_FMA(xa);
+        if (b + 1 < g.cq) {
+            if (b + 2 < g.cq) { GATHER_LOAD(xa); }
+            GATHER_FMA(xb);
+        }
     }
+#undef GATHER_LOAD
+#undef GATHER_FMA
 #pragma unroll
     for (int o = 0; o < OB; ++o)
         if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
@@ -166,8 +176,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[a][b][t] = 0.0f;
     const int v_end = min(pn, (range + 1) * chunks_per_range * 256);
-    for (int v = range * chunks_per_range * 256 + threadIdx.x; v < v_end; v += 256) {
-        const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+    const int v0 = range * chunks_per_range * 256 + threadIdx.x;
+    int oz = v0 % g.z, oy = (v0 / g.z) % g.y, ox = v0 / g.z / g.y;                // decoded once, then advanced by 256 voxels per trip
+    for (int v = v0; v < v_end; v += 256) {                                       // (four divisions per trip were 40 % of the instructions)
         const int ix = ox * S + dx - 1, iy = oy * S + dy - 1, iz = oz * S - 1;
         const bool okr = (unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy;
         const uint32_t base = (uint32_t)((ix * qy + iy) * qz + iz) * 4u;
@@ -188,6 +199,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
             for (int a = 0; a < PB; ++a)
 #pragma unroll
                 for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
+        }
+        oz += 256;
+        while (oz >= g.z) {
+            oz -= g.z;
+            if (++oy == g.y) { oy = 0; ++ox; }
         }
     }
     const int lane = threadIdx.x & 63, part = range * 4 + (threadIdx.x >> 6);
