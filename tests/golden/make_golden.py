@@ -605,8 +605,59 @@ def g16_backbones():
     npz("g16_backbones", **out)
 
 
+def g17_gens_forward():
+    """The reference's WHOLE model, models/gens.py:12-157 `GenS.forward("train", ...)`: its FeatureNetwork (trunk: see g16), Volume,
+    RegNetwork and ImplicitSurface on the CPU, one step with a scalar loss and its backward.  Backbone weights are the seeded
+    initialisation (checksums stored); the implicit-surface weights are stored in full."""
+    import torch.nn as nn
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.feature_network import _mnasnet_trunk
+    sys.modules["torchvision.models"].mnasnet1_0 = lambda pretrained=True: types.SimpleNamespace(
+        layers=nn.Sequential(*_mnasnet_trunk(), nn.Identity(), nn.Identity(), nn.Identity()))
+    from models.gens import GenS
+    dims = (16, 8, 4)
+    torch.manual_seed(170)
+    model = GenS(Conf(dict(gens_model_conf(volume_dims=dims)))).train()
+    h, w, nv, n_rays = 64, 96, 3, 16
+    sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=1, seed=171)
+    g = torch.Generator().manual_seed(172)
+    pix = torch.stack([torch.randint(8, w - 8, (n_rays,), generator=g), torch.randint(8, h - 8, (n_rays,), generator=g)], -1)
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w, pixels=pix)
+    ipts = {"imgs": sc["imgs"], "intrs": sc["intrs"], "c2ws": sc["c2ws"], "rays_o": rays_o, "rays_d": rays_d, "near": sc["near"], "far": sc["far"],
+            "pseudo_pts": torch.rand(64, 3, generator=g) - 0.5}
+    d = {"in." + k: v for k, v in ipts.items()}
+    d["pix"] = pix
+    for k, v in model.implicit_surface.state_dict().items():
+        d["sd." + k] = v
+    sd = model.state_dict()
+    names = [k for k in sd if not k.startswith("implicit_surface.")]
+    d["backbone.keys"] = np.array(names)
+    d["backbone.sums"] = np.array([float(sd[k].double().sum()) for k in names])
+    d["backbone.abs_sums"] = np.array([float(sd[k].double().abs().sum()) for k in names])
+    torch.manual_seed(173)
+    out = model("train", ipts, cos_anneal_ratio=0.7, step=3)
+    hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+    loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
+            + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
+            + 0.1 * out["render_depth"].sum() + out["pseudo_sdf"].abs().mean())
+    loss.backward()
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            d["out." + k] = v
+    d["loss"] = loss
+    params = dict(model.named_parameters())
+    for k in ("feature_network.layer1.0.weight", "feature_network.out_layer1.weight", "feature_network.out_layer5.weight",
+              "reg_network.conv0.conv.weight", "reg_network.out_layers.0.bias", "reg_network.decoder_layers.2.conv.weight",
+              "implicit_surface.sdf_network.lin0.weight_v", "implicit_surface.sdf_network.lin6.bias", "implicit_surface.deviation_network.variance"):
+        d["grad." + k] = params[k].grad
+    npz("g17_gens_forward", **d)
+
+
 def main():
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "g17":
+        g17_gens_forward()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g16":
         g16_backbones()
         return

@@ -327,3 +327,56 @@ def test_bmvs_datasets_drive_val_finetune_and_the_writers(tmp_path):
     loss = _loss(out)
     loss.backward()
     assert torch.isfinite(loss) and all(vol.grad is not None for vol in model.volumes)
+
+
+def test_gens_forward_matches_the_reference_model_end_to_end():
+    """The whole model against the reference's own `GenS.forward("train", ...)` run on the CPU (golden g17: its FeatureNetwork, Volume,
+    RegNetwork and ImplicitSurface classes, make_golden.py g17): same seeded backbone weights, same implicit-surface weights, same
+    host RNG stream -> the 19 outputs, the loss and parameter gradients in every part of the model.  Floating point through two CNNs
+    (MIOpen / K15 / K16 against ATen's CPU convolutions), the volume build, ~250 MLP evaluations per ray and their derivatives:
+    outputs within 2e-4 of each tensor's largest magnitude, gradients within 2 %."""
+    import numpy as np
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models import gens
+    from .conftest import GOLDEN
+    raw = np.load(os.path.join(GOLDEN, "g17_gens_forward.npz"))
+    g = {k: raw[k] for k in raw.files}
+    saved = dict(gens._BACKBONES)
+    gens._BACKBONES.clear()
+    try:
+        torch.manual_seed(170)
+        model = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4))).train()
+    finally:
+        gens._BACKBONES.update(saved)
+    sd = model.state_dict()
+    names = [k for k in sd if not k.startswith("implicit_surface.")]
+    assert names == list(g["backbone.keys"])
+    np.testing.assert_allclose([float(sd[k].double().sum()) for k in names], g["backbone.sums"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose([float(sd[k].double().abs().sum()) for k in names], g["backbone.abs_sums"], rtol=1e-9, atol=1e-9)
+    model.implicit_surface.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    model = model.cuda()
+    ipts = {k[3:]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith("in.")}
+    torch.manual_seed(173)
+    out = model("train", ipts, cos_anneal_ratio=0.7, step=3)
+    hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+    loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
+            + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
+            + 0.1 * out["render_depth"].sum() + out["pseudo_sdf"].abs().mean())
+    loss.backward()
+    worst = {}
+    for k, v in g.items():
+        if not k.startswith("out."):
+            continue
+        a, b = out[k[4:]].detach().cpu().double().reshape(-1), torch.from_numpy(v).double().reshape(-1)
+        assert a.shape == b.shape, k
+        worst[k] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+    bad = {k: e for k, e in worst.items() if e > 2e-4}
+    assert not bad, bad
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    params = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad."):
+            a, b = params[k[5:]].grad.cpu().double(), torch.from_numpy(v).double()
+            # (the bias of the finest output head has an analytically zero gradient here: 1e-11 of round-off on both sides)
+            err = ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item()
+            assert err < 2e-2, (k, err, a.reshape(-1)[:4].tolist(), b.reshape(-1)[:4].tolist())
