@@ -18,7 +18,10 @@ from collections import defaultdict
 ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_mlp_h_k": "gens_sdf_mlp_f16", "blend_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
          "upsample_k": "gens_upsample", "merge_k": "gens_merge_samples", "volume_build_fwd_k": "gens_volume_build_fwd", "volume_build_fwd_lean_k": "gens_volume_build_fwd", "volume_build_fwd_levels_k": "gens_volume_build_levels", "volume_build_fwd_pow2_k": "gens_volume_build_fwd",
          "ray_points_k": "gens_ray_points", "compact_count_k": "gens_compact_valid", "compact_write_k": "gens_compact_valid",
-         "compact_scan_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit"}
+         "compact_scan_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit",
+         "conv3d_gather_k": "gens_conv3d_gather", "conv3d_scatter2_k": "gens_conv3d_scatter2", "conv3d_wgrad_k": "gens_conv3d_wgrad",
+         "instnorm_stats_k": "gens_instnorm_stats", "instnorm_relu_fwd_k": "gens_instnorm_relu_fwd",
+         "instnorm_relu_bwd_stats_k": "gens_instnorm_relu_bwd_stats", "instnorm_relu_bwd_k": "gens_instnorm_relu_bwd"}
 
 
 def collect(root, counter):
@@ -36,6 +39,7 @@ def collect(root, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing, ray chunk 32768"
     ft, fd = collect(fetch_dir, "FETCH_SIZE")
     wt, wd = collect(write_dir, "WRITE_SIZE")
     kernels = {}
@@ -54,8 +58,8 @@ def main():
         f, w = d["fetch_bytes"] / nf, d["write_bytes"] / nw
         res[e] = {"fetch_bytes_per_launch_raw": int(f), "write_bytes_per_launch_raw": int(w),
                   "traffic_bytes_per_launch_corrected": int(2 * f + w), "launches": nf, "device_kernels": d["device_kernels"]}
-    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing`, "
-            "ray chunk 32768; KB x 1024; launch-weighted mean over the kernel's template instances; corrected = 2 x FETCH + WRITE "
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of " + workload + "; "
+            "KB x 1024; launch-weighted mean over the kernel's template instances; corrected = 2 x FETCH + WRITE "
             "(MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reports half of wide coalesced reads; 16-B gathers uncalibrated, so the "
             "corrected figure is an upper estimate there); Infinity-Cache hits are counted")
     json.dump({"_note": note, "kernels": res}, open(out, "w"), indent=1)
