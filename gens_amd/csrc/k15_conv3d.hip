@@ -18,6 +18,8 @@
 // with the weights as scalar operands (wave-uniform indices: s_load through the constant cache).  Arithmetic intensity is
 // 27 cp cq MACs per voxel against 4 (cp + cq) bytes: 54 FLOP / B at 8 -> 8 channels, i.e. bound by the vector ALUs (78 TFLOP/s
 // float32 FMA), not HBM: 58 GFLOP per 256^3 layer = 0.74 ms at that peak.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CONV_OOB 0x7fffffffu     // beyond num_records of every buffer this file makes (< 2 GiB): the load returns 0
@@ -149,7 +151,16 @@ __global__ __launch_bounds__(256) void conv3d_scatter2_k(const float* __restrict
 
 // wgrad: one (dx, dy) tap row (three taps along z), PB = 8 (or 4) channels of P and eight of Q per workgroup column; every wave leaves its
 // 3 PB QB partial sums in ws (parts, cpp, cqp, 27); the host adds the parts (a fixed order: no atomics).
-template <int S, int PB>
+// ROWLDS (stride 1, z a multiple of 64: a wave's 64 voxels are consecutive in ONE z-row): a lane loads only the centre tap of its row and
+// gets the z - 1 / z + 1 taps from its neighbours through a wave-private LDS strip (plus one load for the two halo values of all eight
+// channels): 13 loads per trip instead of 28 -- the kernel was bound by the texture addresser (TA busy 92 %, PMC).
+__device__ __forceinline__ void wave_lds_sync() {                 // orders the LDS accesses of ONE wave (wave-synchronous exchange: no s_barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int S, int PB, bool ROWLDS>
 __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int n_ranges, int chunks_per_range,
                                                       float* __restrict__ ws) {
     constexpr int QB = 8;
@@ -188,17 +199,46 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
         float pv[PB];
 #pragma unroll
         for (int a = 0; a < PB; ++a) pv[a] = pb + a < g.cp ? conv_load(pr, (uint32_t)v * 4u, (uint32_t)(pb + a) * (uint32_t)pn * 4u) : 0.0f;
+        if constexpr (ROWLDS) {
+            __shared__ float strip[4][QB][66];                                   // [wave][channel][halo + 64 + halo]
+            const int lane = threadIdx.x & 63;
+            float (*my)[66] = strip[threadIdx.x >> 6];
+            float c[QB];
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            if (qb + b >= g.cq) break;                                           // (uniform) padding channels of the last block
-            const uint32_t soff = (uint32_t)(qb + b) * qn_bytes;
-            float qv[3];
+            for (int b = 0; b < QB; ++b) c[b] = qb + b < g.cq ? conv_load(qr, off[1], (uint32_t)(qb + b) * qn_bytes) : 0.0f;
+            // lanes 0..7: the value left of the wave's segment for channel `lane`; lanes 8..15: the value right of it
+            uint32_t hoff = CONV_OOB;
+            if (lane < 2 * QB) {
+                const int j = lane & (QB - 1), hz = lane < QB ? oz - lane - 1 : oz - lane + 64;
+                if (okr && qb + j < g.cq && (unsigned)hz < (unsigned)qz) hoff = (uint32_t)((ix * qy + iy) * qz + hz) * 4u + (uint32_t)(qb + j) * qn_bytes;
+            }
+            const float h = conv_load(qr, hoff, 0u);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) qv[t] = conv_load(qr, off[t], soff);
+            for (int b = 0; b < QB; ++b) my[b][1 + lane] = c[b];
+            if (lane < 2 * QB) my[lane & (QB - 1)][lane < QB ? 0 : 65] = h;
+            wave_lds_sync();
 #pragma unroll
-            for (int a = 0; a < PB; ++a)
+            for (int b = 0; b < QB; ++b) {
+                const float qv[3] = {my[b][lane], c[b], my[b][lane + 2]};
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
+                for (int a = 0; a < PB; ++a)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
+            }
+            wave_lds_sync();
+        } else {
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                if (qb + b >= g.cq) break;                                       // (uniform) padding channels of the last block
+                const uint32_t soff = (uint32_t)(qb + b) * qn_bytes;
+                float qv[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) qv[t] = conv_load(qr, off[t], soff);
+#pragma unroll
+                for (int a = 0; a < PB; ++a)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[a][b][t] = __builtin_fmaf(pv[a], qv[t], acc[a][b][t]);
+            }
         }
         oz += 256;
         while (oz >= g.z) {
@@ -294,7 +334,9 @@ extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq,
     wgrad_shape(cp, cq, (int64_t)g.x * g.y * g.z, g.cpp, g.cqp, ny, n_ranges, cpr);
     const dim3 grid(8u * (unsigned)ny * (unsigned)((n_ranges + 7) / 8));
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1, 4>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
-    else hipLaunchKernelGGL((conv3d_wgrad_k<2, 4>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
+    if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr)
+        hipLaunchKernelGGL((conv3d_wgrad_k<1, 4, true>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
+    else if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1, 4, false>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
+    else hipLaunchKernelGGL((conv3d_wgrad_k<2, 4, false>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
     return gens_launch_status("gens_conv3d_wgrad");
 }

@@ -18,7 +18,8 @@ def _close(name, got, want, tol=2e-5):
 @pytest.mark.parametrize("cin,cout,dims,stride,bias", [
     (8, 8, (16, 16, 16), 1, False), (8, 4, (12, 8, 20), 1, True), (8, 8, (16, 16, 16), 2, False), (24, 32, (8, 8, 8), 2, False),
     (3, 5, (6, 10, 12), 1, True), (16, 16, (4, 4, 4), 1, False), (7, 13, (4, 6, 2), 2, True), (32, 32, (8, 4, 68), 1, False),
-    (1, 1, (2, 2, 2), 1, False), (9, 3, (2, 2, 2), 2, False)])
+    (1, 1, (2, 2, 2), 1, False), (9, 3, (2, 2, 2), 2, False),
+    (8, 8, (4, 6, 64), 1, True), (12, 5, (3, 3, 128), 1, False), (4, 4, (2, 5, 192), 1, False)])      # z % 64 == 0: wgrad's LDS neighbour exchange
 def test_conv3d_matches_torch(cin, cout, dims, stride, bias):
     from gens_amd import ops
     g = torch.Generator().manual_seed(cin * 100 + cout)
