@@ -91,6 +91,81 @@ __global__ __launch_bounds__(256) void conv3d_gather_k(const float* __restrict__
         if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
 }
 
+__device__ __forceinline__ void wave_lds_sync() {                 // orders the LDS accesses of ONE wave (wave-synchronous exchange: no s_barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// gather, stride 1, z a multiple of 64 (a wave's 64 voxels are consecutive in one z-row): per input channel a lane loads the CENTRE tap of
+// its nine (dx, dy) rows and takes the z - 1 / z + 1 taps from its neighbours through a wave-private LDS strip; one more load brings the
+// 18 halo values (lanes 0..8 left, 16..24 right).  10 loads per channel instead of 27: the direct kernel keeps the texture addresser
+// busy 95 % of the time (PMC), this one is bound by the packed FMAs.
+template <int OB>
+__global__ __launch_bounds__(256) void conv3d_gather_rows_k(const float* __restrict__ q, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            ConvGeom g, float* __restrict__ p) {
+    __shared__ float strip[4][9][66];                                             // [wave][row][halo + 64 + halo]
+    const int pn = g.x * g.y * g.z;
+    const int v = blockIdx.x * 256 + threadIdx.x;                                 // pn is a multiple of 64: whole waves are in or out
+    if (v >= pn) return;
+    const int lane = threadIdx.x & 63;
+    float (*my)[66] = strip[threadIdx.x >> 6];
+    const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+    const uint32_t qn_bytes = (uint32_t)pn * 4u;
+    uint32_t off[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int ix = ox + r / 3 - 1, iy = oy + r % 3 - 1;
+        off[r] = ((unsigned)ix < (unsigned)g.x && (unsigned)iy < (unsigned)g.y) ? (uint32_t)((ix * g.y + iy) * g.z + oz) * 4u : CONV_OOB;
+    }
+    uint32_t hoff = CONV_OOB;                                                     // lane r: left halo of row r; lane 16 + r: right halo
+    {
+        const int r = lane & 15, hz = lane < 16 ? oz - lane - 1 : oz - lane + 64;
+        const int ix = ox + r / 3 - 1, iy = oy + r % 3 - 1;
+        if (lane < 32 && r < 9 && (unsigned)ix < (unsigned)g.x && (unsigned)iy < (unsigned)g.y && (unsigned)hz < (unsigned)g.z)
+            hoff = (uint32_t)((ix * g.y + iy) * g.z + hz) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * pn);
+    const int cb = blockIdx.y * OB;
+    float acc[OB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) acc[o] = (bias != nullptr && cb + o < g.cp) ? bias[cb + o] : 0.0f;
+    const float* wc = w + cb;
+    uint32_t soff = 0;
+    float ca[9], cn[9], ha, hn;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) ca[r] = conv_load(qr, off[r], soff);
+    ha = conv_load(qr, hoff, soff);
+    for (int b = 0; b < g.cq; ++b) {
+        soff += qn_bytes;
+        if (b + 1 < g.cq) {                                                       // next channel's loads fly during this channel's arithmetic
+#pragma unroll
+            for (int r = 0; r < 9; ++r) cn[r] = conv_load(qr, off[r], soff);
+            hn = conv_load(qr, hoff, soff);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) my[r][1 + lane] = ca[r];
+        if (lane < 32 && (lane & 15) < 9) my[lane & 15][lane < 16 ? 0 : 65] = ha;
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const float xv[3] = {my[r][lane], ca[r], my[r][lane + 2]};
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[(r * 3 + dz) * g.cpp + o], xv[dz], acc[o]);
+        }
+        wave_lds_sync();
+        wc += 27 * g.cpp;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) ca[r] = cn[r];
+        ha = hn;
+    }
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+        if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
+}
+
 // scatter, stride 2: w laid out (cp, 27, cqp).  The thread of coarse voxel o produces the 2 x 2 x 2 fine voxels 2 o + e; along each axis
 // an even fine index takes tap 1 from P[o], an odd one tap 2 from P[o] and tap 0 from P[o + 1].
 template <int OB>
@@ -154,11 +229,6 @@ __global__ __launch_bounds__(256) void conv3d_scatter2_k(const float* __restrict
 // ROWLDS (stride 1, z a multiple of 64: a wave's 64 voxels are consecutive in ONE z-row): a lane loads only the centre tap of its row and
 // gets the z - 1 / z + 1 taps from its neighbours through a wave-private LDS strip (plus one load for the two halo values of all eight
 // channels): 13 loads per trip instead of 28 -- the kernel was bound by the texture addresser (TA busy 92 %, PMC).
-__device__ __forceinline__ void wave_lds_sync() {                 // orders the LDS accesses of ONE wave (wave-synchronous exchange: no s_barrier)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <int S, int PB, bool ROWLDS>
 __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int n_ranges, int chunks_per_range,
@@ -280,6 +350,11 @@ extern "C" int gens_conv3d_gather(const float* q, const float* w, const float* b
     g.cqp = cq;
     const dim3 grid(gens_blocks((int64_t)g.x * g.y * g.z, 256), g.cpp / ob);
     hipStream_t s = (hipStream_t)stream;
+    if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr) {
+        if (ob == 8) hipLaunchKernelGGL((conv3d_gather_rows_k<8>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        else hipLaunchKernelGGL((conv3d_gather_rows_k<4>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        return gens_launch_status("gens_conv3d_gather");
+    }
     if (ob == 8) {
         if (stride == 1) hipLaunchKernelGGL((conv3d_gather_k<8, 1>), grid, dim3(256), 0, s, q, w, bias, g, p);
         else hipLaunchKernelGGL((conv3d_gather_k<8, 2>), grid, dim3(256), 0, s, q, w, bias, g, p);
