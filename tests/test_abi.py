@@ -82,3 +82,27 @@ def test_new_entry_points_validate_their_arguments(libpath):
     assert lib.gens_mc_classify(None, 1, 8, 8, 0.0, None, None, None, None, None, None) == -1      # lattice must be >= 2 per axis
     assert lib.gens_mc_emit(None, 8, 8, 8, 0.0, None, 3, None, None, None, None, None, None, None, None) == -1
     assert lib.gens_pack_mask_bits(None, 0, None, None) == -1
+
+
+def test_conv_and_norm_entry_points_validate_their_arguments(libpath):
+    """K15 / K16: shape, stride, pointer and size checks happen before any launch."""
+    import ctypes as C
+    from gens_amd import lib as L
+    lib = L.load()
+    dims = (C.c_int * 3)(8, 8, 8)
+    assert lib.gens_conv3d_gather(None, None, None, 8, 8, dims, 1, None, None) == -1 and b"null" in lib.gens_last_error()
+    assert lib.gens_conv3d_gather(None, None, None, 8, 8, dims, 3, None, None) == -1 and b"stride" in lib.gens_last_error()
+    assert lib.gens_conv3d_gather(None, None, None, 0, 8, dims, 1, None, None) == -1
+    huge = (C.c_int * 3)(1024, 1024, 1024)                                            # 4 GiB per channel: beyond the 32-bit buffer offsets
+    assert lib.gens_conv3d_scatter2(None, None, 8, 8, huge, None, None) == -1 and b"2 GiB" in lib.gens_last_error()
+    assert lib.gens_conv3d_wgrad(None, None, 8, 8, dims, 1, None, None) == -1
+    assert lib.gens_conv3d_wgrad_parts(8, 8, dims) >= 4 and lib.gens_conv3d_wgrad_parts(0, 8, dims) == 0
+    big = (C.c_int * 3)(256, 256, 256)
+    parts = lib.gens_conv3d_wgrad_parts(8, 8, big)
+    assert parts % 4 == 0 and 64 <= parts <= 4096                                     # one partial per wave of every voxel range
+    assert lib.gens_instnorm_blocks(8, 256 ** 3) * 8 <= 8192 + 8 and lib.gens_instnorm_blocks(3, 10) == 1 and lib.gens_instnorm_blocks(0, 10) == 0
+    assert lib.gens_instnorm_stats(None, 8, 64, None, None) == -1
+    assert lib.gens_instnorm_relu_fwd(None, None, 8, 0, None, None) == -1
+    assert lib.gens_instnorm_relu_bwd_stats(None, None, None, 8, 64, None, None) == -1
+    assert lib.gens_instnorm_relu_bwd(None, None, None, None, 70000, 64, None, None) == -1
+    assert lib.gens_tv_bwd_scaled(None, None, 4, 4, 4, 1.0, None, None, None) == -1
