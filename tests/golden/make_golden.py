@@ -653,8 +653,59 @@ def g17_gens_forward():
     npz("g17_gens_forward", **d)
 
 
+def g18_gens_finetune():
+    """The reference's per-scene fine-tune path, models/gens.py:63-85,141-155: `init_volumes` (CNN outputs frozen into parameters) on four
+    views, then `forward("finetune", ...)` on a re-ordered subset of them (view_ids), loss and backward into the volume parameters."""
+    import torch.nn as nn
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.feature_network import _mnasnet_trunk
+    sys.modules["torchvision.models"].mnasnet1_0 = lambda pretrained=True: types.SimpleNamespace(
+        layers=nn.Sequential(*_mnasnet_trunk(), nn.Identity(), nn.Identity(), nn.Identity()))
+    from models.gens import GenS
+    dims = (16, 8, 4)
+    torch.manual_seed(180)
+    model = GenS(Conf(dict(gens_model_conf(volume_dims=dims)))).train()
+    h, w, nv, n_rays = 64, 96, 4, 16
+    sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=1, seed=181)
+    d = {"all.imgs": sc["imgs"], "all.intrs": sc["intrs"], "all.c2ws": sc["c2ws"]}
+    for k, v in model.implicit_surface.state_dict().items():
+        d["sd." + k] = v
+    model.init_volumes({"imgs": sc["imgs"], "intrs": sc["intrs"], "c2ws": sc["c2ws"]})
+    for i in range(3):
+        d[f"init.volume{i}"], d[f"init.mask{i}"] = model.volumes[i].detach().clone(), model.mask_volmes[i].detach().clone()
+    for i in range(5):
+        d[f"init.feature{i}"] = model.features[i].detach().clone()
+    view_ids = [2, 0, 3]
+    g = torch.Generator().manual_seed(182)
+    pix = torch.stack([torch.randint(8, w - 8, (n_rays,), generator=g), torch.randint(8, h - 8, (n_rays,), generator=g)], -1)
+    intrs, c2ws = sc["intrs"][view_ids], sc["c2ws"][view_ids]
+    rays_o, rays_d = synthetic.make_rays(intrs, c2ws, h, w, pixels=pix)
+    ipts = {"imgs": sc["imgs"][view_ids], "intrs": intrs, "c2ws": c2ws, "rays_o": rays_o, "rays_d": rays_d, "near": sc["near"], "far": sc["far"],
+            "pseudo_pts": torch.rand(64, 3, generator=g) - 0.5, "view_ids": view_ids}
+    for k, v in ipts.items():
+        d["in." + k] = np.array(v) if k == "view_ids" else v
+    torch.manual_seed(183)
+    out = model("finetune", ipts, cos_anneal_ratio=1.0, step=11)
+    hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+    loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
+            + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
+            + 0.1 * out["render_depth"].sum() + out["pseudo_sdf"].abs().mean())
+    loss.backward()
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            d["out." + k] = v
+    d["loss"] = loss
+    for i in range(3):
+        d[f"grad.volume{i}"] = model.volumes[i].grad
+    d["grad.lin0"] = model.implicit_surface.sdf_network.lin0.weight_v.grad
+    npz("g18_gens_finetune", **d)
+
+
 def main():
     _install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "g18":
+        g18_gens_finetune()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g17":
         g17_gens_forward()
         return

@@ -380,3 +380,52 @@ def test_gens_forward_matches_the_reference_model_end_to_end():
             # (the bias of the finest output head has an analytically zero gradient here: 1e-11 of round-off on both sides)
             err = ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item()
             assert err < 2e-2, (k, err, a.reshape(-1)[:4].tolist(), b.reshape(-1)[:4].tolist())
+
+
+def test_gens_finetune_path_matches_the_reference_model():
+    """`init_volumes` + `forward("finetune", ...)` against the reference's own run (golden g18, models/gens.py:63-85,141-155): the CNN
+    outputs frozen into parameters (volumes, masks, feature maps), a step on a re-ordered subset of the views, gradients of the volume
+    parameters."""
+    import numpy as np
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models import gens
+    from .conftest import GOLDEN
+    raw = np.load(os.path.join(GOLDEN, "g18_gens_finetune.npz"))
+    g = {k: raw[k] for k in raw.files}
+    saved = dict(gens._BACKBONES)
+    gens._BACKBONES.clear()
+    try:
+        torch.manual_seed(180)
+        model = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4))).train()
+    finally:
+        gens._BACKBONES.update(saved)
+    model.implicit_surface.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    model = model.cuda()
+    t = lambda k: torch.from_numpy(g[k]).cuda()  # noqa: E731
+
+    def rel(a, b):
+        a, b = a.detach().cpu().double().reshape(-1), torch.from_numpy(b).double().reshape(-1)
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item()
+
+    model.init_volumes({"imgs": t("all.imgs"), "intrs": t("all.intrs"), "c2ws": t("all.c2ws")})
+    assert model.has_vol and len(model.volumes) == 3 and len(model.features) == 5
+    for i in range(3):
+        assert rel(model.volumes[i], g[f"init.volume{i}"]) < 2e-4, i
+        assert torch.equal(model.mask_volmes[i].cpu(), torch.from_numpy(g[f"init.mask{i}"])), i
+        assert model.volumes[i].requires_grad and not model.mask_volmes[i].requires_grad
+    for i in range(5):
+        assert rel(model.features[i], g[f"init.feature{i}"]) < 2e-4, i
+    ipts = {k[3:]: (g[k].tolist() if k == "in.view_ids" else t(k)) for k in g if k.startswith("in.")}
+    torch.manual_seed(183)
+    out = model("finetune", ipts, cos_anneal_ratio=1.0, step=11)
+    hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
+    loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
+            + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
+            + 0.1 * out["render_depth"].sum() + out["pseudo_sdf"].abs().mean())
+    loss.backward()
+    bad = {k: e for k, e in ((k, rel(out[k[4:]], v)) for k, v in g.items() if k.startswith("out.")) if e > 3e-4}
+    assert not bad, bad
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for i in range(3):
+        assert rel(model.volumes[i].grad, g[f"grad.volume{i}"]) < 2e-2, i
+    assert rel(model.implicit_surface.sdf_network.lin0.weight_v.grad, g["grad.lin0"]) < 2e-2
