@@ -72,8 +72,13 @@ __global__ __launch_bounds__(256) void conv3d_gather_k(const float* __restrict__
     _Pragma("unroll") for (int t = 0; t < 27; ++t) buf[t] = conv_load(qr, off[t], soff); \
     soff += qn_bytes
 #define GATHER_FMA(buf)                                                   \
-    _Pragma("unroll") for (int t = 0; t < 27; ++t)                        \
-        _Pragma("unroll") for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[t * g.cpp + o], buf[t], acc[o]); \
+    {                                                                     \
+        float part[OB]; /* the 27 taps of one input channel in their own accumulator, then one add: round-off grows with 27 + cq, not 27 cq */ \
+        _Pragma("unroll") for (int o = 0; o < OB; ++o) part[o] = 0.0f;    \
+        _Pragma("unroll") for (int t = 0; t < 27; ++t)                    \
+            _Pragma("unroll") for (int o = 0; o < OB; ++o) part[o] = __builtin_fmaf(wc[t * g.cpp + o], buf[t], part[o]); \
+        _Pragma("unroll") for (int o = 0; o < OB; ++o) acc[o] += part[o]; \
+    }                                                                     \
     wc += 27 * g.cpp
     GATHER_LOAD(xa);
     for (int b = 0; b < g.cq; b += 2) {
@@ -147,14 +152,19 @@ __global__ __launch_bounds__(256) void conv3d_gather_rows_k(const float* __restr
         for (int r = 0; r < 9; ++r) my[r][1 + lane] = ca[r];
         if (lane < 32 && (lane & 15) < 9) my[lane & 15][lane < 16 ? 0 : 65] = ha;
         wave_lds_sync();
+        float part[OB];                                                           // one input channel's 27 taps, then one add (see conv3d_gather_k)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) part[o] = 0.0f;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const float xv[3] = {my[r][lane], ca[r], my[r][lane + 2]};
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-                for (int o = 0; o < OB; ++o) acc[o] = __builtin_fmaf(wc[(r * 3 + dz) * g.cpp + o], xv[dz], acc[o]);
+                for (int o = 0; o < OB; ++o) part[o] = __builtin_fmaf(wc[(r * 3 + dz) * g.cpp + o], xv[dz], part[o]);
         }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[o] += part[o];
         wave_lds_sync();
         wc += 27 * g.cpp;
 #pragma unroll

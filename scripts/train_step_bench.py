@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda:0")
     if os.environ.get("GENS_BLAS"):                                     # "hipblaslt" / "cublas" (rocBLAS): which GEMM library torch uses
         torch.backends.cuda.preferred_blas_library(os.environ["GENS_BLAS"])
-    dims = [256, 128, 64]
+    dims = [256, 128, 64, 32, 16] if "--levels5" in sys.argv else [256, 128, 64]       # --levels5: the shipped confs/gens.conf pyramid
     sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
     imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
     feats = [f.to(dev).requires_grad_(True) for f in sc["features"]]

@@ -19,7 +19,8 @@ def _close(name, got, want, tol=2e-5):
     (8, 8, (16, 16, 16), 1, False), (8, 4, (12, 8, 20), 1, True), (8, 8, (16, 16, 16), 2, False), (24, 32, (8, 8, 8), 2, False),
     (3, 5, (6, 10, 12), 1, True), (16, 16, (4, 4, 4), 1, False), (7, 13, (4, 6, 2), 2, True), (32, 32, (8, 4, 68), 1, False),
     (1, 1, (2, 2, 2), 1, False), (9, 3, (2, 2, 2), 2, False),
-    (8, 8, (4, 6, 64), 1, True), (12, 5, (3, 3, 128), 1, False), (4, 4, (2, 5, 192), 1, False)])      # z % 64 == 0: wgrad's LDS neighbour exchange
+    (8, 8, (4, 6, 64), 1, True), (12, 5, (3, 3, 128), 1, False), (4, 4, (2, 5, 192), 1, False),       # z % 64 == 0: the LDS neighbour exchange
+    (72, 128, (2, 2, 2), 2, False), (128, 128, (2, 2, 2), 1, False), (64, 64, (4, 4, 4), 1, True), (40, 64, (4, 4, 4), 2, False)])   # the deep levels of the 5-stage U-Net
 def test_conv3d_matches_torch(cin, cout, dims, stride, bias):
     from gens_amd import ops
     g = torch.Generator().manual_seed(cin * 100 + cout)
@@ -38,7 +39,8 @@ def test_conv3d_matches_torch(cin, cout, dims, stride, bias):
         _close(name, a, r)
 
 
-@pytest.mark.parametrize("cin,cout,dims", [(8, 8, (8, 8, 8)), (32, 16, (4, 4, 4)), (16, 8, (6, 10, 34)), (5, 3, (3, 2, 7)), (1, 9, (1, 1, 1))])
+@pytest.mark.parametrize("cin,cout,dims", [(8, 8, (8, 8, 8)), (32, 16, (4, 4, 4)), (16, 8, (6, 10, 34)), (5, 3, (3, 2, 7)), (1, 9, (1, 1, 1)),
+                                           (128, 64, (2, 2, 2)), (64, 32, (4, 4, 4))])
 def test_conv_transpose3d_matches_torch(cin, cout, dims):
     from gens_amd import ops
     g = torch.Generator().manual_seed(cin * 100 + cout + 7)
@@ -73,53 +75,36 @@ def test_conv3d_linearity_and_adjointness_at_full_size():
         assert torch.equal(z, 2.0 * y.detach())                                            # scaling by 2 is exact in float32
 
 
-def test_reg_network_on_the_device_matches_the_cpu_module():
+def _unet_run(net, vols, cots):
+    outs = net(vols)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    return [o.detach() for o in outs], [v.grad for v in vols], [p.grad for p in net.parameters()]
+
+
+def _err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize("dims", [(32, 16, 8), (128, 64, 32, 16, 8)])       # three stages; the five of confs/gens.conf (up to 72 -> 128 channels)
+def test_reg_network_on_the_device_matches_the_cpu_module(dims):
+    """The U-Net on K15 / K16 against the same module run by torch on the CPU.  Its deep levels normalise over a handful of voxels
+    (instance-norm over 4^3 at the bottom of five stages), which amplifies float32 round-off in the gradients: the yardstick is the
+    module in float64, and the device result may be off by no more than a few times what torch's own float32 CPU run is off by."""
+    import copy
     from gens_amd.config import Conf
     from gens_amd.models.modules.reg_network import RegNetwork
     torch.manual_seed(11)
-    net = RegNetwork(Conf({"d_voluem": [8, 8, 8], "d_out": [4, 4, 4], "d_base": 8}))
+    n = len(dims)
+    net = RegNetwork(Conf({"d_voluem": [8] * n, "d_out": [4] * n, "d_base": 8}))
     g = torch.Generator().manual_seed(12)
-    vols = [torch.randn(1, 8, d, d, d, generator=g).requires_grad_(True) for d in (32, 16, 8)]
-    cots = [torch.randn(1, 4, d, d, d, generator=g) for d in (32, 16, 8)]
-    outs = net(vols)
-    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
-    import copy
-    dnet = copy.deepcopy(net).cuda()
-    dnet.zero_grad()
-    dvols = [v.detach().cuda().requires_grad_(True) for v in vols]
-    douts = dnet(dvols)
-    sum((o * c.cuda()).sum() for o, c in zip(douts, cots)).backward()
-    for i in range(3):
-        _close(f"out{i}", douts[i], outs[i], 1e-4)
-        _close(f"gin{i}", dvols[i].grad, vols[i].grad, 2e-4)
-    for (name, p), q in zip(net.named_parameters(), dnet.parameters()):
-        _close(name, q.grad, p.grad, 5e-4)
-
-
-@pytest.mark.parametrize("shape", [(1, 8, 16, 16, 16), (1, 3, 5, 7, 9), (1, 32, 4, 4, 4), (1, 1, 1, 1, 3), (1, 8, 64, 64, 64)])
-def test_instnorm_relu_matches_torch(shape):
-    """K16 against torch's float64 instance_norm + relu on the CPU: value and gradient."""
-    from gens_amd import ops
-    g = torch.Generator().manual_seed(sum(shape))
-    x = (torch.randn(shape, generator=g) * 1.7 + 0.4).requires_grad_(True)
-    cot = torch.randn(shape, generator=g)
-    y = torch.relu(F.instance_norm(x.double(), eps=1e-5))
-    (gx,) = torch.autograd.grad(y, x, cot.double())
-    xd = x.detach().cuda().requires_grad_(True)
-    yd = ops.instnorm_relu(xd, 1e-5)
-    _close("value", yd, y, 1e-5)
-    # an element whose xhat is within rounding of 0 may take the other ReLU branch: compare away from the kink
-    (gd,) = torch.autograd.grad(yd, xd, cot.cuda())
-    xh = F.instance_norm(x.detach().double(), eps=1e-5)
-    keep = xh.abs() > 1e-5
-    err = ((gd.cpu().double() - gx) * keep).abs().max().item() / gx.abs().max().item()
-    assert err < 2e-5, err
-
-
-def test_instnorm_relu_statistics_survive_a_large_offset():
-    """Sums are accumulated in float64: mean 1000, standard deviation 1 (E[x^2] - E[x]^2 in float32 would keep no digit)."""
-    from gens_amd import ops
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(1, 2, 32, 32, 32, generator=g) + 1000.0
-    y = torch.relu(F.instance_norm(x.double()))
-    _close("value", ops.instnorm_relu(x.cuda()), y, 2e-4)                            # x itself carries 6e-5 of rounding at 1000
+    vols = [torch.randn(1, 8, d, d, d, generator=g) for d in dims]
+    cots = [torch.randn(1, 4, d, d, d, generator=g) for d in dims]
+    ref = _unet_run(copy.deepcopy(net).double(), [v.double().requires_grad_(True) for v in vols], [c.double() for c in cots])
+    cpu = _unet_run(copy.deepcopy(net), [v.clone().requires_grad_(True) for v in vols], cots)
+    dev = _unet_run(copy.deepcopy(net).cuda(), [v.cuda().requires_grad_(True) for v in vols], [c.cuda() for c in cots])
+    names = [f"out{i}" for i in range(n)], [f"gin{i}" for i in range(n)], [k for k, _ in net.named_parameters()]
+    for group, r_group, c_group, d_group, floor in zip(names, ref, cpu, dev, (1e-5, 2e-5, 1e-4)):
+        for name, r, c, d in zip(group, r_group, c_group, d_group):
+            e_cpu, e_dev = _err(c, r), _err(d, r)
+            assert e_dev <= max(4.0 * e_cpu, floor), f"{name}: device {e_dev:.2e}, torch float32 on the CPU {e_cpu:.2e} (both against float64)"
