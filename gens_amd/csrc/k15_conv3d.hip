@@ -176,6 +176,74 @@ __global__ __launch_bounds__(256) void conv3d_gather_rows_k(const float* __restr
         if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
 }
 
+// gather, stride 2, z a multiple of 64: the taps of coarse voxel oz are Q[2 oz - 1], Q[2 oz], Q[2 oz + 1]: one aligned 8-byte load per
+// (dx, dy) row brings the last two, the first is the neighbouring lane's second value (LDS strip; one load for the nine left halos) --
+// 10 loads per input channel instead of 27 loads at an 8-byte lane stride.
+template <int OB>
+__global__ __launch_bounds__(256) void conv3d_gather_rows2_k(const float* __restrict__ q, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             ConvGeom g, float* __restrict__ p) {
+    __shared__ float strip[4][9][65];                                             // [wave][row][left halo + 64]
+    const int pn = g.x * g.y * g.z;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= pn) return;
+    const int lane = threadIdx.x & 63;
+    float (*my)[65] = strip[threadIdx.x >> 6];
+    const int oz = v % g.z, t1 = v / g.z, oy = t1 % g.y, ox = t1 / g.y;
+    const int qx = 2 * g.x, qy = 2 * g.y, qz = 2 * g.z;
+    const uint32_t qn_bytes = (uint32_t)pn * 32u;
+    // (plain 8-byte global loads for the pairs: this compiler lowers __builtin_amdgcn_raw_buffer_load_b64 to a ONE-dword load; a row is
+    // valid or not for the whole wave, and inside a valid row the pair is always in range)
+    int off[9];                                                                   // element offset of Q[row r][2 oz] in a channel plane, -1: padding row
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int ix = 2 * ox + r / 3 - 1, iy = 2 * oy + r % 3 - 1;
+        off[r] = ((unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy) ? (ix * qy + iy) * qz + 2 * oz : -1;
+    }
+    uint32_t hoff = CONV_OOB;                                                     // lane r < 9: Q[row r][2 oz0 - 1], oz0 = the wave's first voxel
+    if (lane < 9) {
+        const int ix = 2 * ox + lane / 3 - 1, iy = 2 * oy + lane % 3 - 1, hz = 2 * (oz - lane) - 1;
+        if ((unsigned)ix < (unsigned)qx && (unsigned)iy < (unsigned)qy && hz >= 0) hoff = (uint32_t)((ix * qy + iy) * qz + hz) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * pn * 8);
+    const int cb = blockIdx.y * OB;
+    float acc[OB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) acc[o] = (bias != nullptr && cb + o < g.cp) ? bias[cb + o] : 0.0f;
+    const float* wc = w + cb;
+    uint32_t soff = 0;
+    const float* qc = q;
+    for (int b = 0; b < g.cq; ++b) {
+        float2 c[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) c[r] = off[r] >= 0 ? *(const float2*)(qc + off[r]) : make_float2(0.0f, 0.0f);
+        const float h = conv_load(qr, hoff, soff);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) my[r][1 + lane] = c[r].y;
+        if (lane < 9) my[lane][0] = h;
+        wave_lds_sync();
+        float part[OB];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) part[o] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const float xv[3] = {my[r][lane], c[r].x, c[r].y};
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int o = 0; o < OB; ++o) part[o] = __builtin_fmaf(wc[(r * 3 + dz) * g.cpp + o], xv[dz], part[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[o] += part[o];
+        wave_lds_sync();
+        wc += 27 * g.cpp;
+        soff += qn_bytes;
+        qc += (int64_t)pn * 8;
+    }
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+        if (cb + o < g.cp) p[(int64_t)(cb + o) * pn + v] = acc[o];
+}
+
 // scatter, stride 2: w laid out (cp, 27, cqp).  The thread of coarse voxel o produces the 2 x 2 x 2 fine voxels 2 o + e; along each axis
 // an even fine index takes tap 1 from P[o], an odd one tap 2 from P[o] and tap 0 from P[o + 1].
 template <int OB>
@@ -360,9 +428,14 @@ extern "C" int gens_conv3d_gather(const float* q, const float* w, const float* b
     g.cqp = cq;
     const dim3 grid(gens_blocks((int64_t)g.x * g.y * g.z, 256), g.cpp / ob);
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr) {
-        if (ob == 8) hipLaunchKernelGGL((conv3d_gather_rows_k<8>), grid, dim3(256), 0, s, q, w, bias, g, p);
-        else hipLaunchKernelGGL((conv3d_gather_rows_k<4>), grid, dim3(256), 0, s, q, w, bias, g, p);
+    if ((g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr) {
+        if (stride == 1) {
+            if (ob == 8) hipLaunchKernelGGL((conv3d_gather_rows_k<8>), grid, dim3(256), 0, s, q, w, bias, g, p);
+            else hipLaunchKernelGGL((conv3d_gather_rows_k<4>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        } else {
+            if (ob == 8) hipLaunchKernelGGL((conv3d_gather_rows2_k<8>), grid, dim3(256), 0, s, q, w, bias, g, p);
+            else hipLaunchKernelGGL((conv3d_gather_rows2_k<4>), grid, dim3(256), 0, s, q, w, bias, g, p);
+        }
         return gens_launch_status("gens_conv3d_gather");
     }
     if (ob == 8) {
