@@ -17,6 +17,8 @@ from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E4
 
 def main():
     dev = torch.device("cuda:0")
+    if "--miopen-find" in sys.argv:                                     # the reference's own setting (runner.py:26): MIOpen searches per conv shape
+        torch.backends.cudnn.benchmark = True
     if os.environ.get("GENS_BLAS"):                                     # "hipblaslt" / "cublas" (rocBLAS): which GEMM library torch uses
         torch.backends.cuda.preferred_blas_library(os.environ["GENS_BLAS"])
     dims = [256, 128, 64, 32, 16] if "--levels5" in sys.argv else [256, 128, 64]       # --levels5: the shipped confs/gens.conf pyramid
