@@ -470,7 +470,7 @@ static void wgrad_shape(int cp, int cq, int64_t pn, int& cpp, int& cqp, int& ny,
     cqp = (cq + 7) / 8 * 8;
     ny = 9 * (cpp / pb) * (cqp / 8);
     const int64_t chunks = (pn + 255) / 256;
-    int64_t want = (8192 + ny - 1) / ny;                         // ~8 000 work items per launch, each with >= 4 chunks of voxels if there are that many
+    int64_t want = 456;                                          // voxel ranges per launch (x 12 ... 18 columns at 8 -> 8 channels), each with >= 4 chunks if there are that many
     if (want > (chunks + 3) / 4) want = (chunks + 3) / 4;
     if (want < 1) want = 1;
     chunks_per_range = (int)((chunks + want - 1) / want);
