@@ -56,19 +56,27 @@ __global__ __launch_bounds__(256) void instnorm_stats_k(const float* __restrict_
 
 __device__ __forceinline__ float norm_relu(float x, float m, float r) { return fmaxf((x - m) * r, 0.0f); }
 
+// y = max((x - mean) * rstd, 0) [+ skip]: the decoder blocks of the U-Net add the encoder's tensor right after the block (reg_network.py:158)
 template <bool VEC>
-__global__ __launch_bounds__(256) void instnorm_relu_fwd_k(const float* __restrict__ x, const float* __restrict__ mr, int64_t n, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void instnorm_relu_fwd_k(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ skip,
+                                                           int64_t n, float* __restrict__ y) {
     const float m = mr[2 * blockIdx.y], r = mr[2 * blockIdx.y + 1];
     const float* xc = x + (int64_t)blockIdx.y * n;
+    const float* sc = skip ? skip + (int64_t)blockIdx.y * n : nullptr;
     float* yc = y + (int64_t)blockIdx.y * n;
     if (VEC) {
         const int64_t n4 = n >> 2;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
             const float4 v = ((const float4*)xc)[i];
-            ((float4*)yc)[i] = make_float4(norm_relu(v.x, m, r), norm_relu(v.y, m, r), norm_relu(v.z, m, r), norm_relu(v.w, m, r));
+            float4 o = make_float4(norm_relu(v.x, m, r), norm_relu(v.y, m, r), norm_relu(v.z, m, r), norm_relu(v.w, m, r));
+            if (sc) {
+                const float4 k = ((const float4*)sc)[i];
+                o = make_float4(o.x + k.x, o.y + k.y, o.z + k.z, o.w + k.w);
+            }
+            ((float4*)yc)[i] = o;
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yc[i] = norm_relu(xc[i], m, r);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yc[i] = norm_relu(xc[i], m, r) + (sc ? sc[i] : 0.0f);
     }
 }
 
@@ -151,8 +159,14 @@ extern "C" int gens_instnorm_stats(const float* x, int c, int64_t n, double* par
 
 extern "C" int gens_instnorm_relu_fwd(const float* x, const float* mean_rstd, int c, int64_t n, float* y, void* stream) {
     GENS_CHECK_ARG(x && mean_rstd && y && c > 0 && n > 0 && c <= 65535, GENS_EINVAL, "gens_instnorm_relu_fwd: bad argument");
-    INSTNORM_LAUNCH(instnorm_relu_fwd_k, x, mean_rstd, n, y);
+    INSTNORM_LAUNCH(instnorm_relu_fwd_k, x, mean_rstd, (const float*)nullptr, n, y);
     return gens_launch_status("gens_instnorm_relu_fwd");
+}
+
+extern "C" int gens_instnorm_relu_add_fwd(const float* x, const float* mean_rstd, const float* skip, int c, int64_t n, float* y, void* stream) {
+    GENS_CHECK_ARG(x && mean_rstd && skip && y && c > 0 && n > 0 && c <= 65535, GENS_EINVAL, "gens_instnorm_relu_add_fwd: bad argument");
+    INSTNORM_LAUNCH(instnorm_relu_fwd_k, x, mean_rstd, skip, n, y);
+    return gens_launch_status("gens_instnorm_relu_add_fwd");
 }
 
 extern "C" int gens_instnorm_relu_bwd_stats(const float* x, const float* gy, const float* mean_rstd, int c, int64_t n, double* partials, void* stream) {

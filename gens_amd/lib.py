@@ -58,6 +58,7 @@ SIGNATURES = {
     "gens_instnorm_blocks": [_i, _l],
     "gens_instnorm_stats": [_p, _i, _l, _p, _p],
     "gens_instnorm_relu_fwd": [_p, _p, _i, _l, _p, _p],
+    "gens_instnorm_relu_add_fwd": [_p, _p, _p, _i, _l, _p, _p],
     "gens_instnorm_relu_bwd_stats": [_p, _p, _p, _i, _l, _p, _p],
     "gens_instnorm_relu_bwd": [_p, _p, _p, _p, _i, _l, _p, _p],
     "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],

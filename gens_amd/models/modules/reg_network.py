@@ -23,11 +23,13 @@ class _Block3d(nn.Module):
         self.bn = nn.InstanceNorm3d(conv.out_channels)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, skip=None):
+        """relu(norm(conv(x))) [+ skip]"""
         x = self.conv(x)
         if x.is_cuda and x.dtype == torch.float32 and x.shape[0] == 1 and not self.bn.affine and not self.bn.track_running_stats:
-            return ops.instnorm_relu(x, self.bn.eps)                       # K16: statistics + normalise + ReLU in two streaming passes
-        return self.relu(self.bn(x))
+            return ops.instnorm_relu(x, self.bn.eps, skip)                 # K16: statistics + normalise + ReLU (+ the skip addition) in two streaming passes
+        x = self.relu(self.bn(x))
+        return x if skip is None else x + skip
 
 
 def _conv(cin, cout, stride):
@@ -69,7 +71,7 @@ class RegNetwork(nn.Module):
                 x = torch.cat([x, volumes[i + 1]], dim=1)
         ups = []
         for i in range(self.num_stage - 1, -1, -1):
-            x = self.decoder_layers[i](x) + skips[i]
+            x = self.decoder_layers[i](x, skips[i])
             ups.append(x)
         ups.reverse()                                  # finest first
         return [head(u) for head, u in zip(self.out_layers, ups)]

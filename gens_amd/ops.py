@@ -963,7 +963,7 @@ _f64 = torch.float64
 
 class _InstNormRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps):
+    def forward(ctx, x, eps, skip=None):
         x2 = _c(x.detach().to(_f32)).reshape(x.shape[1], -1)
         c, n = x2.shape
         blocks = L.load().gens_instnorm_blocks(c, n)
@@ -973,7 +973,11 @@ class _InstNormRelu(torch.autograd.Function):
         mean = s[:, 0]
         mr = torch.stack([mean, torch.rsqrt((s[:, 1] - mean * mean).clamp_min(0.0) + eps)], 1).to(_f32)
         y = torch.empty_like(x2)
-        L.call("gens_instnorm_relu_fwd", L.ptr(x2), L.ptr(mr), c, n, L.ptr(y), L.stream(), nbytes=8 * c * n)
+        if skip is None:
+            L.call("gens_instnorm_relu_fwd", L.ptr(x2), L.ptr(mr), c, n, L.ptr(y), L.stream(), nbytes=8 * c * n)
+        else:
+            assert skip.shape == x.shape
+            L.call("gens_instnorm_relu_add_fwd", L.ptr(x2), L.ptr(mr), L.ptr(_c(skip.detach().to(_f32))), c, n, L.ptr(y), L.stream(), nbytes=12 * c * n)
         ctx.save_for_backward(x2, mr)
         ctx.blocks = blocks
         return y.reshape(x.shape)
@@ -989,13 +993,13 @@ class _InstNormRelu(torch.autograd.Function):
         m12 = (part.sum(1) / n).to(_f32)
         gx = torch.empty_like(x2)
         L.call("gens_instnorm_relu_bwd", L.ptr(x2), L.ptr(g2), L.ptr(mr), L.ptr(m12), c, n, L.ptr(gx), L.stream(), nbytes=12 * c * n)
-        return gx.reshape(gy.shape), None
+        return gx.reshape(gy.shape), None, (gy if ctx.needs_input_grad[2] else None)
 
 
-def instnorm_relu(x, eps=1e-5):
-    """relu(instance_norm(x)) for x (1, c, ...): per-channel statistics over the plane, biased variance, no affine parameters."""
+def instnorm_relu(x, eps=1e-5, skip=None):
+    """relu(instance_norm(x)) [+ skip] for x (1, c, ...): per-channel statistics over the plane, biased variance, no affine parameters."""
     assert x.shape[0] == 1 and x.dim() >= 3
-    return _InstNormRelu.apply(x, float(eps))
+    return _InstNormRelu.apply(x, float(eps), skip)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -344,6 +344,8 @@ int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int*
 int gens_instnorm_blocks(int c, int64_t n);
 int gens_instnorm_stats(const float* x, int c, int64_t n, double* partials, void* stream);
 int gens_instnorm_relu_fwd(const float* x, const float* mean_rstd, int c, int64_t n, float* y, void* stream);
+/* the same + skip (c, n): the decoder blocks add the encoder's tensor right after norm + ReLU (reg_network.py:158) */
+int gens_instnorm_relu_add_fwd(const float* x, const float* mean_rstd, const float* skip, int c, int64_t n, float* y, void* stream);
 int gens_instnorm_relu_bwd_stats(const float* x, const float* gy, const float* mean_rstd, int c, int64_t n, double* partials, void* stream);
 int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rstd, const float* g_means, int c, int64_t n, float* gx,
                            void* stream);

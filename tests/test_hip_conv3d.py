@@ -109,3 +109,20 @@ def test_reg_network_on_the_device_matches_the_cpu_module(dims):
         for name, r, c, d in zip(group, r_group, c_group, d_group):
             e_cpu, e_dev = _err(c, r), _err(d, r)
             assert e_dev <= max(4.0 * e_cpu, floor), f"{name}: device {e_dev:.2e}, torch float32 on the CPU {e_cpu:.2e} (both against float64)"
+
+
+def test_instnorm_relu_with_the_fused_skip_addition():
+    from gens_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 8, 8, 8, 64, generator=g).requires_grad_(True)
+    skip = torch.randn(1, 8, 8, 8, 64, generator=g).requires_grad_(True)
+    cot = torch.randn(1, 8, 8, 8, 64, generator=g)
+    y = torch.relu(F.instance_norm(x.double(), eps=1e-5)) + skip.double()
+    gx, gs = torch.autograd.grad(y, [x, skip], cot.double())
+    xd, sd = x.detach().cuda().requires_grad_(True), skip.detach().cuda().requires_grad_(True)
+    yd = ops.instnorm_relu(xd, 1e-5, sd)
+    _close("value", yd, y, 1e-5)
+    gxd, gsd = torch.autograd.grad(yd, [xd, sd], cot.cuda())
+    assert torch.equal(gsd.cpu(), cot)                                               # the skip branch passes the gradient through
+    keep = F.instance_norm(x.detach().double(), eps=1e-5).abs() > 1e-5
+    assert ((gxd.cpu().double() - gx) * keep).abs().max().item() / gx.abs().max().item() < 2e-5
