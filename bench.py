@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--views", type=int, default=5)
     p.add_argument("--cpu-rays", type=int, default=640, help="rays of the CPU-oracle baseline sample (0 = skip); ~15 s on a 128-core host")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step figure (N = 1)")
     p.add_argument("--sdf-precision", default="f32", choices=["f32", "f16x2"],
                    help="f32: exact float32 MFMA (headline); f16x2: split-half operands on the f16 matrix cores (~1e-6 relative)")
     return p.parse_args()
@@ -210,6 +211,21 @@ def main():
         split = {"sdf_precision": "f16x2", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": dt * 1e3, "steps": 2,
                  "note": "opt-in arithmetic of the SDF network only; not the headline"}
 
+    # secondary figure (N = 1): one TRAINING step of BASELINE config[2] as runner.py runs it -- GenS.forward with the 2-D feature CNN, the
+    # volume build, the 3-D U-Net, 512 rays + 2048 pseudo points, a reference-like loss, backward through every kernel and Adam
+    # (scripts/train_step_bench.py --full).  Reported beside the headline, never as `value`.
+    train = None
+    if world == 1 and not args.no_train_step and not args.no_kernel_timing:
+        try:
+            from scripts.train_step_bench import measure
+            torch.cuda.empty_cache()
+            ms, _ = measure(["--full", "--steps", "10", "--warm", "3"], quiet=True)
+            train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
+                                 "points, 2-D CNN + volume build + 3-D U-Net + render + loss + backward + Adam", "ms_per_step": round(ms, 2), "steps": 10,
+                     "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "note": "secondary figure; not the headline"}
+        except Exception as e:                                             # never let the secondary figure take the headline down
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if world == 1 and args.cpu_rays > 0:
         cpu = cpu_baseline(args, surf, sc, vols, state["masks"], n_final)
@@ -225,7 +241,7 @@ def main():
                    "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
                    "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": "scenes sharded across ranks, all_gather of rendered buffers" if world > 1 else "single GPU"},
-        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "hip_kernels": table,
+        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "train_step": train, "hip_kernels": table,
     }
     print(json.dumps(line))
     if dist is not None:

@@ -15,7 +15,21 @@ from gens_amd.losses import compute_LNCC  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E402
 
 
+def measure(argv=(), quiet=False):
+    """One measurement; argv: the command-line flags below.  -> (milliseconds per step, label)"""
+    saved = sys.argv
+    sys.argv = [saved[0], *argv]
+    try:
+        return _measure(quiet)
+    finally:
+        sys.argv = saved
+
+
 def main():
+    _measure(False)
+
+
+def _measure(quiet):
     dev = torch.device("cuda:0")
     if "--miopen-find" in sys.argv:                                     # the reference's own setting (runner.py:26): MIOpen searches per conv shape
         torch.backends.cudnn.benchmark = True
@@ -53,7 +67,7 @@ def main():
         ft_opt.zero_grad(set_to_none=True)
         loss.backward()
         ft_opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     def step():
         if finetune:
@@ -71,7 +85,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen
     if full:                                     # matching copy too) and the 3-D U-Net inside the step
@@ -90,9 +104,9 @@ def main():
             full_opt.zero_grad(set_to_none=True)
             loss.backward()
             full_opt.step()
-            return float(loss)
+            return float(loss.detach())
 
-    for _ in range(2):
+    for _ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -101,7 +115,10 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"{'full (CNNs + hot path)' if full else 'fine-tune' if finetune else 'train'} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
+    if not quiet:
+        print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    return dt * 1e3, label
 
 
 if __name__ == "__main__":
