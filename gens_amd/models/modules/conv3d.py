@@ -21,8 +21,8 @@ class Conv3d(nn.Conv3d):
 
 
 class ConvTranspose3d(nn.ConvTranspose3d):
-    def forward(self, x):
-        if _hip(x) and self.kernel_size == (3, 3, 3) and self.padding == (1, 1, 1) and self.stride == (2, 2, 2) and self.bias is None \
+    def forward(self, x, output_size=None):
+        if output_size is None and _hip(x) and self.kernel_size == (3, 3, 3) and self.padding == (1, 1, 1) and self.stride == (2, 2, 2) and self.bias is None \
                 and self.output_padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1:
             return ops.conv_transpose3d(x, self.weight)
-        return super().forward(x)
+        return super().forward(x, output_size)
