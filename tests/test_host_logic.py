@@ -37,3 +37,24 @@ def test_config_stand_in_behaves_like_a_config_tree():
     assert c.get_bool("has_vol", default=False) is False
     assert c["implicit_surface"]["sdf_network"]["feat_channels"] == 12
     assert dict(**c["implicit_surface"]["color_network"]) == {"d_feature": 20}
+
+
+def test_bench_command_line_contract():
+    """bench.py's flags as the driver uses them (`--gpus N --steps K --warmup W`), its defaults, and that the opt-in extras stay off."""
+    import importlib
+    import sys
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    saved = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert (a.gpus, a.steps, a.warmup, a.rays, a.dims, a.views) == (1, 10, 3, 480 * 640, [256, 128, 64], 5)
+        assert a.sdf_precision == "f32" and not a.train_step and not a.no_kernel_timing
+        sys.argv = ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"]
+        a = bench.parse()
+        assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
+    finally:
+        sys.argv = saved
