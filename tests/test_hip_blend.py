@@ -41,3 +41,23 @@ def test_fused_blend_indexed_scatter():
     keep[idx] = True
     assert torch.allclose(rgb[keep], dense_rgb[keep], atol=1e-6) and torch.equal(vis[keep], dense_vis[keep])
     assert (rgb[~keep] == 0).all() and (vis[~keep] == 0).all()
+
+
+@pytest.mark.parametrize("nv,n", [(5, 600), (3, 200)])
+def test_fused_blend_matches_the_cpu_oracle(nv, n):
+    """gens_blend_views against the CPU oracle directly (oracle.gens_oracle.lookup_feature + oracle.render_oracle.blend_mlp, themselves
+    pinned to the reference's lookup_feature / BlendingNetwork by goldens g4 and g9a-c): S = 4 source views is the shipped count
+    (confs/gens.conf:13), S = 2 the validation one.  Not a self-comparison: nothing of the device path is on the reference side."""
+    from oracle import gens_oracle as K
+    from oracle import render_oracle as R
+    from gens_amd import synthetic
+    ops, net, views, pts = _setup(nv, 5, seed=77 + nv, n=n)
+    sc = synthetic.make_scene(nv=nv, h=48, w=64, n_levels=5, seed=77 + nv)
+    sd = {"color_network." + k: v.detach().cpu() for k, v in net.state_dict().items()}
+    fv, rd, mk = K.lookup_feature(pts.cpu(), sc["imgs"], sc["intrs"], sc["c2ws"], sc["features"])
+    live = mk.any(1)                                        # a point no source view sees: softmax over -1e9 only, colour is arbitrary
+    ref = R.blend_mlp(sd, torch.nan_to_num(fv), torch.nan_to_num(rd), mk)
+    rgb, vis = ops.blend_views(ops.BlendPlan(net), views, pts)
+    assert torch.equal(vis.bool().cpu(), mk)
+    err = (rgb.cpu() - ref)[live].abs().max()
+    assert err < 2e-5, err

@@ -401,3 +401,71 @@ def test_device_compaction_matches_nonzero_and_rescue(ops, n, frac):
         ref = torch.arange(min(10, n), device="cuda")          # implicit_surface.py:123-124
     assert int(count) == ref.numel()
     assert torch.equal(idx[:ref.numel()], ref)
+
+
+def test_k2_second_order_outside_the_cube_vs_fd64_of_aten(ops):
+    """K2'' at and beyond the border of the volume (rays without a crossing are sampled at the camera centre, outside the cube:
+    implicit_surface.py:301-305).  The reference's CUDA kernel cannot run here and its pure-torch sampler clamps instead of zero-padding,
+    so golden g2 pins second order only inside the cube.  Ground truth for the rest: central differences, in float64, of ATen's OWN
+    first-order backward (aten::grid_sampler_3d_backward, the op cuda_gridsample.py:97 calls) -- gG'(p) . e_k = d/dp_k <gG(p), ggG>,
+    ggO = d/d gO <gG, ggG>, gI' = d/dV <gG, ggG> -- compared with the HIP kernel's outputs.  Points are kept 1e-3 away from the
+    kinks of the piecewise-trilinear interpolant (integer voxel positions), where no second derivative exists."""
+    vols, pts, go, ggp, gp2, ggo_ref, gv_ref = second_order_fd64_case()
+    dv = [v.float().cuda().requires_grad_(True) for v in vols]
+    dp = pts.float().cuda().requires_grad_(True)
+    dgo = go.float().cuda().requires_grad_(True)
+    grads = torch.autograd.grad(ops.lookup_volume(dp, dv), [dp], dgo, create_graph=True)
+    outs = torch.autograd.grad((grads[0] * ggp.float().cuda()).sum(), [dgo, dp] + dv)
+    close(outs[1], gp2, atol=2e-3, rtol=2e-4, what="gP2 (fd64 of aten backward)")
+    close(outs[0], ggo_ref, atol=1e-4, rtol=1e-4, what="ggO")
+    for i in range(2):
+        close(outs[2 + i], gv_ref[i], atol=1e-4, rtol=1e-4, what=f"gV2_{i}")
+    assert ((pts.abs() > 1).any(-1)).float().mean() > 0.5
+
+
+def second_order_fd64_case():
+    """-> (vols, pts, gO, ggG, gP2_fd, ggO_fd, gV2_fd), all float64 (see test_k2_second_order_outside_the_cube_vs_fd64_of_aten)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17)
+    dims = [7, 5]
+    vols = [torch.randn(1, 4, d, d, d, generator=g, dtype=torch.float64) for d in dims]
+    n = 600
+    pts = torch.rand(n, 3, generator=g, dtype=torch.float64) * 3.0 - 1.5               # a third of the points lie outside [-1, 1]^3
+    pts[:40] = torch.sign(pts[:40]) * (1.0 + 0.02 * torch.rand(40, 3, generator=g, dtype=torch.float64))   # just over the border
+    for d in dims:                                                                         # off the kinks of every level
+        pos = (pts + 1) * 0.5 * (d - 1)
+        near = (pos - pos.round()).abs() < 2e-3
+        pts = torch.where(near, pts + 8e-3 / (d - 1), pts)
+    go = torch.randn(n, 8, generator=g, dtype=torch.float64)
+    ggp = torch.randn(n, 3, generator=g, dtype=torch.float64)
+
+    def first_order(p, vs, o):
+        """<gG(p), ggG> summed per point, with gG from ATen's backward (float64)."""
+        p = p.clone().requires_grad_(True)
+        x = p.flip(-1)[None, None, None]
+        y = torch.cat([F.grid_sample(v, x, padding_mode="zeros", align_corners=True).reshape(4, -1).t() for v in vs], -1)
+        gp = torch.autograd.grad(y, p, o)[0]
+        return (gp * ggp).sum(-1)
+
+    eps = 1e-6
+    gp2 = torch.stack([(first_order(pts + eps * e, vols, go) - first_order(pts - eps * e, vols, go)) / (2 * eps)
+                       for e in torch.eye(3, dtype=torch.float64)], -1)
+    ggo_ref, gv_ref = _second_order_linear_parts_fd(vols, pts, go, ggp)
+    return vols, pts, go, ggp, gp2, ggo_ref, gv_ref
+
+
+def _second_order_linear_parts_fd(vols, pts, go, ggp):
+    """ggO[n, c] = d/d gO[n, c] <gG, ggG> and gI' = d/dV <gG, ggG>: <gG, ggG> is LINEAR in gO and in V, so one evaluation of ATen's
+    backward per basis direction would do; cheaper: directional derivative of the forward, y(p + t ggG) in t, again through ATen in
+    float64 (central difference, exact up to the O(eps^2) term, which vanishes for a trilinear polynomial away from the kinks)."""
+    import torch.nn.functional as F
+    eps = 1e-5
+
+    def fwd(p, vs):
+        x = p.flip(-1)[None, None, None]
+        return torch.cat([F.grid_sample(v, x, padding_mode="zeros", align_corners=True).reshape(4, -1).t() for v in vs], -1)
+
+    ggo = (fwd(pts + eps * ggp, vols) - fwd(pts - eps * ggp, vols)) / (2 * eps)            # J ggG
+    vs = [v.clone().requires_grad_(True) for v in vols]
+    phi = (((fwd(pts + eps * ggp, vs) - fwd(pts - eps * ggp, vs)) / (2 * eps)) * go).sum()
+    return ggo, torch.autograd.grad(phi, vs)

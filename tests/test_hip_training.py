@@ -329,7 +329,18 @@ def test_bmvs_datasets_drive_val_finetune_and_the_writers(tmp_path):
     assert torch.isfinite(loss) and all(vol.grad is not None for vol in model.volumes)
 
 
-def test_gens_forward_matches_the_reference_model_end_to_end():
+GRAD_RTOL = 2e-2     # of each gradient tensor's largest magnitude; the table printed by the tests shows what float32 delivers
+
+
+def _grad_table(rows):
+    """rows: (name, error relative to the tensor's largest magnitude, largest magnitude) -> printed worst first (pytest -s / on failure)."""
+    rows = sorted(rows, key=lambda r: -r[1])
+    print("\n".join(f"  {e:9.2e}  |max| {m:9.2e}  {k}" for k, e, m in rows))
+    return rows
+
+
+@pytest.mark.parametrize("tag,dims,seed", [("g17_gens_forward", (16, 8, 4), 170), ("g17b_gens_forward_l5", (64, 32, 16, 8, 4), 270)])
+def test_gens_forward_matches_the_reference_model_end_to_end(tag, dims, seed):
     """The whole model against the reference's own `GenS.forward("train", ...)` run on the CPU (golden g17: its FeatureNetwork, Volume,
     RegNetwork and ImplicitSurface classes, make_golden.py g17): same seeded backbone weights, same implicit-surface weights, same
     host RNG stream -> the 19 outputs, the loss and parameter gradients in every part of the model.  Floating point through two CNNs
@@ -339,13 +350,13 @@ def test_gens_forward_matches_the_reference_model_end_to_end():
     from gens_amd.config import gens_model_conf
     from gens_amd.models import gens
     from .conftest import GOLDEN
-    raw = np.load(os.path.join(GOLDEN, "g17_gens_forward.npz"))
+    raw = np.load(os.path.join(GOLDEN, tag + ".npz"))
     g = {k: raw[k] for k in raw.files}
     saved = dict(gens._BACKBONES)
     gens._BACKBONES.clear()
     try:
-        torch.manual_seed(170)
-        model = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4))).train()
+        torch.manual_seed(seed)
+        model = gens.GenS(gens_model_conf(volume_dims=dims)).train()
     finally:
         gens._BACKBONES.update(saved)
     sd = model.state_dict()
@@ -356,7 +367,7 @@ def test_gens_forward_matches_the_reference_model_end_to_end():
     model.implicit_surface.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
     model = model.cuda()
     ipts = {k[3:]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith("in.")}
-    torch.manual_seed(173)
+    torch.manual_seed(seed + 3)
     out = model("train", ipts, cos_anneal_ratio=0.7, step=3)
     hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
     loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
@@ -374,15 +385,18 @@ def test_gens_forward_matches_the_reference_model_end_to_end():
     assert not bad, bad
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     params = dict(model.named_parameters())
+    rows = []
     for k, v in g.items():
         if k.startswith("grad."):
             a, b = params[k[5:]].grad.cpu().double(), torch.from_numpy(v).double()
             # (the bias of the finest output head has an analytically zero gradient here: 1e-11 of round-off on both sides)
-            err = ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item()
-            assert err < 2e-2, (k, err, a.reshape(-1)[:4].tolist(), b.reshape(-1)[:4].tolist())
+            rows.append((k, ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item(), b.abs().max().item()))
+    rows = _grad_table(rows)
+    assert rows[0][1] < GRAD_RTOL, rows[:5]
 
 
-def test_gens_finetune_path_matches_the_reference_model():
+@pytest.mark.parametrize("tag,dims,seed", [("g18_gens_finetune", (16, 8, 4), 180), ("g18b_gens_finetune_l5", (64, 32, 16, 8, 4), 280)])
+def test_gens_finetune_path_matches_the_reference_model(tag, dims, seed):
     """`init_volumes` + `forward("finetune", ...)` against the reference's own run (golden g18, models/gens.py:63-85,141-155): the CNN
     outputs frozen into parameters (volumes, masks, feature maps), a step on a re-ordered subset of the views, gradients of the volume
     parameters."""
@@ -390,13 +404,14 @@ def test_gens_finetune_path_matches_the_reference_model():
     from gens_amd.config import gens_model_conf
     from gens_amd.models import gens
     from .conftest import GOLDEN
-    raw = np.load(os.path.join(GOLDEN, "g18_gens_finetune.npz"))
+    raw = np.load(os.path.join(GOLDEN, tag + ".npz"))
     g = {k: raw[k] for k in raw.files}
+    nl = len(dims)
     saved = dict(gens._BACKBONES)
     gens._BACKBONES.clear()
     try:
-        torch.manual_seed(180)
-        model = gens.GenS(gens_model_conf(volume_dims=(16, 8, 4))).train()
+        torch.manual_seed(seed)
+        model = gens.GenS(gens_model_conf(volume_dims=dims)).train()
     finally:
         gens._BACKBONES.update(saved)
     model.implicit_surface.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
@@ -408,15 +423,23 @@ def test_gens_finetune_path_matches_the_reference_model():
         return ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item()
 
     model.init_volumes({"imgs": t("all.imgs"), "intrs": t("all.intrs"), "c2ws": t("all.c2ws")})
-    assert model.has_vol and len(model.volumes) == 3 and len(model.features) == 5
-    for i in range(3):
-        assert rel(model.volumes[i], g[f"init.volume{i}"]) < 2e-4, i
-        assert torch.equal(model.mask_volmes[i].cpu(), torch.from_numpy(g[f"init.mask{i}"])), i
+    assert model.has_vol and len(model.volumes) == nl and len(model.features) == 5
+
+    def thin(t, i):          # the fixture keeps every second voxel per axis of levels above 32^3
+        return t[..., ::2, ::2, ::2] if dims[i] > 32 else t
+
+    for i in range(nl):
+        assert rel(thin(model.volumes[i], i), g[f"init.volume{i}"]) < 2e-4, i
+        if dims[i] > 32:
+            bits = np.packbits(model.mask_volmes[i].cpu().numpy().astype(np.uint8).reshape(-1))
+            assert np.array_equal(bits, g[f"init.mask{i}"]), i
+        else:
+            assert torch.equal(model.mask_volmes[i].cpu(), torch.from_numpy(g[f"init.mask{i}"])), i
         assert model.volumes[i].requires_grad and not model.mask_volmes[i].requires_grad
     for i in range(5):
         assert rel(model.features[i], g[f"init.feature{i}"]) < 2e-4, i
     ipts = {k[3:]: (g[k].tolist() if k == "in.view_ids" else t(k)) for k in g if k.startswith("in.")}
-    torch.manual_seed(183)
+    torch.manual_seed(seed + 3)
     out = model("finetune", ipts, cos_anneal_ratio=1.0, step=11)
     hit = out["mid_inside_sphere"].reshape(1, -1, 1, 1)
     loss = (out["color_fine"].abs().sum() + 0.1 * out["gradient_error"] + 0.01 * out["smooth_error"] + 0.01 * out["tv_reg"]
@@ -426,6 +449,9 @@ def test_gens_finetune_path_matches_the_reference_model():
     bad = {k: e for k, e in ((k, rel(out[k[4:]], v)) for k, v in g.items() if k.startswith("out.")) if e > 3e-4}
     assert not bad, bad
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
-    for i in range(3):
-        assert rel(model.volumes[i].grad, g[f"grad.volume{i}"]) < 2e-2, i
-    assert rel(model.implicit_surface.sdf_network.lin0.weight_v.grad, g["grad.lin0"]) < 2e-2
+    rows = [(f"volume{i}", rel(thin(model.volumes[i].grad, i), g[f"grad.volume{i}"]), float(np.abs(g[f"grad.volume{i}"]).max())) for i in range(nl)]
+    rows.append(("lin0.weight_v", rel(model.implicit_surface.sdf_network.lin0.weight_v.grad, g["grad.lin0"]), float(np.abs(g["grad.lin0"]).max())))
+    params = dict(model.named_parameters())
+    rows += [(k[5:], rel(params[k[5:]].grad, v), float(np.abs(v).max())) for k, v in g.items() if k.startswith("grad.implicit_surface.")]
+    rows = _grad_table(rows)
+    assert rows[0][1] < GRAD_RTOL, rows[:5]

@@ -129,13 +129,15 @@ def test_k10_tv(golden):
 def _render_inputs(g):
     sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
     feats = [g[f"feat{i}"] for i in range(5)]
-    vols = [g[f"vol{i}"] for i in range(3)]
-    masks = [g[f"mask{i}"] for i in range(3)]
+    nl = sum(1 for k in g if k.startswith("vol"))
+    vols = [g[f"vol{i}"] for i in range(nl)]
+    masks = [g[f"mask{i}"] for i in range(nl)]
     step = None if float(g["step"]) < 0 else float(g["step"])
     return sd, feats, vols, masks, step
 
 
-@pytest.mark.parametrize("tag", ["g9a_render", "g9b_render"])
+# g9c: the shipped level count (five volume levels, confs/gens.conf:63-67,86) with four source views
+@pytest.mark.parametrize("tag", ["g9a_render", "g9b_render", "g9c_render_l5"])
 def test_render_end_to_end(golden, tag):
     g = golden(tag)
     sd, feats, vols, masks, step = _render_inputs(g)
@@ -178,3 +180,33 @@ def test_k11_sdf_grid(golden):
     sd, _, vols, _, _ = _render_inputs(r)
     u = R.sdf_grid(sd, vols, [-1, -1, -1], [1, 1, 1], int(g["resolution"]))
     close(u, g["u"], atol=2e-5, rtol=1e-4, what="-sdf lattice")
+
+
+def config0_scene(g):
+    """BASELINE config[0]: the synthetic 3-view 480 x 640 scene of golden g9d regenerated from its seed (checksums stored)."""
+    from gens_amd import synthetic
+    sc = synthetic.make_scene(nv=3, h=480, w=640, n_levels=5, seed=int(g["scene_seed"]))
+    sums = [float(f.double().sum()) for f in sc["features"]] + [float(sc["imgs"].double().sum())]
+    assert torch.allclose(torch.tensor(sums, dtype=torch.float64), g["feat_sums"].double(), rtol=1e-9, atol=1e-6), "synthetic scene drifted"
+    return sc
+
+
+def test_render_config0_coarsest_volume_only(golden):
+    """BASELINE config[0] as written (3 views 480 x 640, ONE 16^3 volume from the level-4 map with intrinsics * 2^-4 (Q2), 512 rays):
+    K1 mask bit-exact, then the reference's render on that single-level pyramid (golden g9d), 64 of the 512 rays on the CPU."""
+    g = golden("g9d_config0")
+    sc = config0_scene(g)
+    intr4 = sc["intrs"].clone()
+    intr4[:, :2] *= 0.5 ** 4
+    _, masks = K.volume_build([sc["features"][4]], intr4, sc["c2ws"], [16])
+    assert torch.equal(masks[0], g["mask0"])
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    n = 64
+    out = R.render(sd, g["rays_o"][:n], g["rays_d"][:n], sc["near"], sc["far"], [g["vol0"]], masks, sc["imgs"], sc["features"], sc["features"],
+                   sc["intrs"], sc["c2ws"], 1.0, None, g["draw_trand"][:n], g["draw_ptsrand"] * 2 - 1, z=g["z_final"][:n])
+    for k in ("color_fine", "render_depth", "sdf_depth"):
+        assert (out[k] - g["out." + k][:n]).abs().mean() < 1e-4, k
+    assert torch.equal(out["valid_mask"], g["out.valid_mask"][:n])
+    assert torch.equal(out["mid_inside_sphere"], g["out.mid_inside_sphere"][:n])
+    close(out["gradients"], g["out.gradients"][:n], atol=5e-4, rtol=1e-3, what="gradients")
+    close(out["weights"], g["out.weights"][:n], atol=1e-4, rtol=1e-3, what="weights")

@@ -72,3 +72,15 @@ def test_volume_build_mean_is_linear_in_the_features():
     v1, _ = K.volume_build([feats[0].detach() - 0.5 * d], sc["intrs"], sc["c2ws"], [6])
     fd, an = float(((v2[0][:, :4] - v1[0][:, :4]) * cot).sum()), float((g * d).sum())
     assert abs(fd - an) < 1e-3 * max(1.0, abs(an))
+
+
+def test_second_order_lookup_outside_the_cube_vs_fd64_of_aten():
+    """The oracle's K2'' restatement at and beyond the volume border against float64 central differences of ATen's own
+    grid_sampler_3d backward (the op the reference calls, cuda_gridsample.py:97): the same case the HIP kernel is held to in
+    tests/test_hip_kernels.py::test_k2_second_order_outside_the_cube_vs_fd64_of_aten."""
+    from .test_hip_kernels import second_order_fd64_case
+    vols, pts, go, ggp, gp2, ggo_ref, gv_ref = second_order_fd64_case()
+    ggo, gv2, gp2_o = K.lookup_volume_bwd2(None, ggp.float(), go.float(), [v.float() for v in vols], pts.float())
+    assert (gp2_o - gp2).abs().max() < 2e-3 and (ggo - ggo_ref).abs().max() < 1e-4
+    for a, b in zip(gv2, gv_ref):
+        assert (a - b).abs().max() < 1e-4
