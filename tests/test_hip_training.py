@@ -329,14 +329,30 @@ def test_bmvs_datasets_drive_val_finetune_and_the_writers(tmp_path):
     assert torch.isfinite(loss) and all(vol.grad is not None for vol in model.volumes)
 
 
-GRAD_RTOL = 2e-2     # of each gradient tensor's largest magnitude; the table printed by the tests shows what float32 delivers
+# Gradient tolerances, as a fraction of each gradient tensor's largest magnitude.  Measured against the reference's own backward
+# (goldens g17 / g17b / g18 / g18b, whose sampler drops third order like the reference's CUDA Function pair): implicit-surface
+# parameters and fine-tune volumes 1e-5 ... 8e-4 (the reference's own 1-thread / 8-thread runs differ by 6e-6), the two CNNs up to
+# 1.6e-2 (first MnasNet convolution: batch-norm statistics over three 64 x 96 views amplify float32 round-off of MIOpen against ATen).
+GRAD_RTOL = 2e-3
+GRAD_RTOL_CNN = 3e-2
+GRAD_ZERO = 1e-5     # a tensor whose largest golden entry is below GRAD_ZERO x the largest gradient in the table is analytically zero
+                     # (the bias in front of a softmax, a head whose output is unused): pure round-off on both sides, compared absolutely
 
 
 def _grad_table(rows):
-    """rows: (name, error relative to the tensor's largest magnitude, largest magnitude) -> printed worst first (pytest -s / on failure)."""
-    rows = sorted(rows, key=lambda r: -r[1])
+    """rows: (name, error relative to the tensor's largest magnitude, largest magnitude) -> the rows that matter, worst first; printed in
+    full (pytest -s / on failure).  Analytically-zero tensors are re-scaled to the table's largest gradient."""
+    top = max(m for _, _, m in rows)
+    rows = [(k, e * m / (GRAD_ZERO * top) if m < GRAD_ZERO * top else e, m) for k, e, m in rows]
+    rows = sorted(rows, key=lambda r: -r[1] / (GRAD_RTOL_CNN if "_network." in r[0] and "implicit_surface" not in r[0] else GRAD_RTOL))
     print("\n".join(f"  {e:9.2e}  |max| {m:9.2e}  {k}" for k, e, m in rows))
     return rows
+
+
+def _check_grad_table(rows):
+    rows = _grad_table(rows)
+    bad = [r for r in rows if r[1] >= (GRAD_RTOL_CNN if "_network." in r[0] and "implicit_surface" not in r[0] else GRAD_RTOL)]
+    assert not bad, bad[:6]
 
 
 @pytest.mark.parametrize("tag,dims,seed", [("g17_gens_forward", (16, 8, 4), 170), ("g17b_gens_forward_l5", (64, 32, 16, 8, 4), 270)])
@@ -391,8 +407,7 @@ def test_gens_forward_matches_the_reference_model_end_to_end(tag, dims, seed):
             a, b = params[k[5:]].grad.cpu().double(), torch.from_numpy(v).double()
             # (the bias of the finest output head has an analytically zero gradient here: 1e-11 of round-off on both sides)
             rows.append((k, ((a - b).abs().max() / b.abs().max().clamp_min(1e-8)).item(), b.abs().max().item()))
-    rows = _grad_table(rows)
-    assert rows[0][1] < GRAD_RTOL, rows[:5]
+    _check_grad_table(rows)
 
 
 @pytest.mark.parametrize("tag,dims,seed", [("g18_gens_finetune", (16, 8, 4), 180), ("g18b_gens_finetune_l5", (64, 32, 16, 8, 4), 280)])
@@ -453,5 +468,4 @@ def test_gens_finetune_path_matches_the_reference_model(tag, dims, seed):
     rows.append(("lin0.weight_v", rel(model.implicit_surface.sdf_network.lin0.weight_v.grad, g["grad.lin0"]), float(np.abs(g["grad.lin0"]).max())))
     params = dict(model.named_parameters())
     rows += [(k[5:], rel(params[k[5:]].grad, v), float(np.abs(v).max())) for k, v in g.items() if k.startswith("grad.implicit_surface.")]
-    rows = _grad_table(rows)
-    assert rows[0][1] < GRAD_RTOL, rows[:5]
+    _check_grad_table(rows)
