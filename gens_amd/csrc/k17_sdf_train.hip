@@ -1,0 +1,941 @@
+// K17: the SDF network of a TRAINING step in four launches -- value, gradient and `smooth` vector forward; the loss backward
+// into every layer's matrix / bias and into the volume pyramid -- instead of the ~2 400 launches of the PyTorch autograd graph.
+//
+// Replaces, in train / fine-tune mode, SDFNetwork.sdf + SDFNetwork.gradient (create_graph twice) and the backward of both
+// (/root/reference/models/modules/sdf_network.py:98-154, driven from implicit_surface.py:179-191,257,305,490 and loss.backward()),
+// including the multi-level trilinear look-up with the reference's truncation: what grad2_3d returns is constant in the loss
+// backward (cuda_gridsample.py:110-123), so no third derivative of the sampler appears.
+//
+// Mathematics (oracle/sdf_train_oracle.py `by_sweeps` is the same text in torch; tests/test_sdf_train_oracle.py proves it equal to
+// autograd).  Per point, with a_l = W_l z_l + b_l, h_l = softplus(a_l), v = (1,1,1):
+//   forward launch (sdf_train_fwd_k):   value sweep a, tangent sweep a' (along v)           -> y
+//                                        reverse sweep lambda (adjoint of y), its tangent mu -> g = dy/dx, s = d(sum g)/dx
+//   backward launch (sdf_train_bwd_k):  a, a' again, tangent nu (along s_bar), second tangent kappa (along (v, s_bar) and g_bar)
+//                                        reverse sweeps lambda, mu, rho (tangent of lambda along s_bar), omega (adjoint of the loss)
+//     dL/dW_l = sum_points  omega_a z^T + rho_a z'^T + lambda_a kappa_z^T + mu_a nu_z^T      (gens_gemm_tn over operand rows written here)
+//     dL/dvolumes: three trilinear scatters (sdf_train_scatter_k)
+//
+// MI355X mapping (K6's, widened).  A workgroup = 4 waves = 32 points; wave w owns output columns [32w, 32w+32) of every layer.  The
+// sweeps that share a weight matrix run TOGETHER: 2 (forward launch) or 4 (backward launch) activation tiles in LDS are multiplied by
+// ONE stream of B fragments, so a 16-byte weight load feeds 8 / 16 v_mfma_f32_32x32x2_f32 instead of 4 and the independent accumulator
+// chains keep the matrix pipe busy with a single wave per SIMD (the four 32 x 236 tiles of the L = 5 backward fill 139 KB of the CU's
+// 160 KB LDS).  Per-element layer state the reverse sweeps need (a, a', nu_a, kappa_a) is parked in an HBM scratch in accumulator
+// layout (1-KB coalesced stores, read back by the same lane), not in registers: 6 layers x 4 values x 16 would be 384 VGPRs.
+// Exact fp32 arithmetic throughout (fp32 MFMA is an fmaf chain); activations use the hardware exp / log / rcp like K6.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TR_M 32
+#define TR_H 128
+#define TR_PE 27
+#define TR_PE_K 32
+#define TR_PE_STRIDE 36
+#define TR_SKIP_H 101
+#define TR_NLAYER 6
+#define TR_SQ2 0.70710678118654752440f
+#define TR_DEAD (-1.0e30f)   // pre-activation stored for the 27 pass-through columns of layer 2: softplus' = '' = ''' = 0
+
+struct SdfTrainWeights {
+    const float4* wf[TR_NLAYER];   // forward B groups [4][G_l][64] float4, bias in reduction row K_l (layout of gens_sdf_mlp)
+    const float4* wb[TR_NLAYER];   // transposed B groups [n_tile][16][64] float4
+    const float* w_last;           // row 0 of layer 6 (128 + FE)
+    const float* b_last;           // DEVICE scalar: bias 0 of layer 6 (weights change every step; no host read-back)
+};
+
+// softplus(beta = 100, threshold 20) with its first three derivatives, branch-free (hardware exp2 / log2 / rcp).  Above the
+// threshold torch's softplus is the identity: derivatives 1, 0, 0 (v_cndmask discards the inf / NaN of the other branch).
+__device__ __forceinline__ void softplus_d3(float a, float& h, float& d1, float& d2, float& d3) {
+    const float e = __builtin_amdgcn_exp2f(a * 144.269504088896340736f);   // e^{100 a}
+    const float u = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(u);                              // 1 - sigmoid(100 a)
+    const float t = e * r;                                                 // sigmoid(100 a)
+    const float q = t * r;
+    const bool lin = a > 0.2f;
+    h = lin ? a : __builtin_amdgcn_logf(u) * 0.0069314718055994530942f;
+    d1 = lin ? 1.0f : t;
+    d2 = lin ? 0.0f : 100.0f * q;
+    d3 = lin ? 0.0f : 1.0e4f * q * (r - t);
+}
+
+// acc[t] += A_t (32 x 8G, rows of stride given by the caller's pointer arithmetic; tile t starts `tstride` floats after tile 0)
+// * B (G packed groups).  `a` points at this lane's row + 4 * half of tile 0, `b` at this lane's float4 of group 0.
+template <int G, int T>
+__device__ __forceinline__ void mfma_tiles(const float* __restrict__ a, const int tstride, const float4* __restrict__ b, f32x16 (&acc)[T]) {
+    constexpr int PF = 4;
+    float4 pre[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < G) pre[j] = b[64 * j];
+    float4 av[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) av[t] = *(const float4*)(a + t * tstride);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const float4 bv = pre[j % PF];
+        float4 ac[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) ac[t] = av[t];
+        if (j + 1 < G) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) av[t] = *(const float4*)(a + t * tstride + 8 * (j + 1));
+        }
+        if (j + PF < G) pre[j % PF] = b[64 * (j + PF)];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].x, bv.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].y, bv.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].z, bv.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t].w, bv.w, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ int tr_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int T>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+}
+
+// The 8 corners of one level around x: value and the derivatives of the interpolant along up to three directions.
+// dir[k] (k < ND) are direction vectors in point space; out[0] = f, out[1 + k] = J dir[k]; when MIXED, mix[a] = sum_b d2f/dx_a dx_b
+// (direction v = 1) and jac[a] = df/dx_a.
+template <int ND, bool MIXED>
+__device__ __forceinline__ void corner_sums(const LevelSet& vols, int l, const float x[3], bool live, const float (*dir)[3], float4 (&out)[1 + ND],
+                                            float4 (&jac)[3], float4 (&mix)[3]) {
+    const int Xd = vols.dx[l], Yd = vols.dy[l], Zd = vols.dz[l];
+    const float4* v = (const float4*)vols.data[l];
+    const int sz[3] = {Xd, Yd, Zd};
+    float w0[3], w1[3], k[3];
+    int i0[3];
+    bool in0[3], in1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pos = (x[a] + 1.0f) / 2.0f * (float)(sz[a] - 1);
+        const float f = fminf(fmaxf(floorf(pos), -2.0f), (float)sz[a] + 1.0f);
+        i0[a] = (int)f;
+        w0[a] = (f + 1.0f) - pos;
+        w1[a] = pos - f;
+        in0[a] = i0[a] >= 0 && i0[a] < sz[a];
+        in1[a] = i0[a] + 1 >= 0 && i0[a] + 1 < sz[a];
+        k[a] = (float)(sz[a] - 1) / 2.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 1 + ND; ++q) out[q] = f4_zero();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { jac[a] = f4_zero(); mix[a] = f4_zero(); }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
+        const bool ok = live && (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+        const int cx = min(max(i0[0] + a, 0), Xd - 1), cy = min(max(i0[1] + b, 0), Yd - 1), cz = min(max(i0[2] + d, 0), Zd - 1);
+        float4 t = v[((int64_t)cx * Yd + cy) * Zd + cz];
+        if (!ok) t = f4_zero();
+        const float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
+        const float sx = (a ? k[0] : -k[0]), sy = (b ? k[1] : -k[1]), sz_ = (d ? k[2] : -k[2]);
+        const float dwx = sx * wy * wz, dwy = wx * sy * wz, dwz = wx * wy * sz_;
+        out[0] = f4_madd(out[0], t, wx * wy * wz);
+#pragma unroll
+        for (int q = 0; q < ND; ++q) out[1 + q] = f4_madd(out[1 + q], t, dwx * dir[q][0] + dwy * dir[q][1] + dwz * dir[q][2]);
+        if constexpr (MIXED) {
+            jac[0] = f4_madd(jac[0], t, dwx);
+            jac[1] = f4_madd(jac[1], t, dwy);
+            jac[2] = f4_madd(jac[2], t, dwz);
+            const float mxy = sx * sy * wz, mxz = sx * wy * sz_, myz = wx * sy * sz_;
+            mix[0] = f4_madd(mix[0], t, mxy + mxz);
+            mix[1] = f4_madd(mix[1], t, mxy + myz);
+            mix[2] = f4_madd(mix[2], t, mxz + myz);
+        }
+    }
+}
+
+__device__ __forceinline__ float f4_at(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// ====================================================================================================================
+// forward launch: y, g = dy/dx, s = d(sum_k g_k)/dx
+// ====================================================================================================================
+template <int FE>
+__global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts, int64_t n,
+                                                       float2* __restrict__ stash, float* __restrict__ y_out, float* __restrict__ g_out,
+                                                       float* __restrict__ s_out) {
+    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4;
+    static_assert(KP > KIN, "a pad column carries the bias");
+    constexpr int NT_B = (KIN + 31) / 32;
+    constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                       // [2][XT]: value tile [h | e | 1 | 0], tangent tile [h' | e' | 0]; h part reused by the reverse sweeps
+    float* PE = X + 2 * XT;                // [2][PT]: point encoding and its tangent
+    float* GPE = PE + 2 * PT;              // [2][PT]: lambda / mu with respect to the point encoding
+    float* JAC = GPE + 2 * PT;             // [32][CF][3] df/dx ; then [32][CF][3] sum_b d2f/dx dx_b
+    float* LF = JAC + 2 * TR_M * CF * 3;   // [2][32][CF]: lambda_f, mu_f
+    float* RED = LF + 2 * TR_M * CF;       // [32][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
+    const int col = 32 * wave + (lane & 31);
+
+    // ------------------------------------------------------------------ prologue
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        const int64_t row = m0 + p;
+        const bool live = row < n;
+        float x[3] = {0.f, 0.f, 0.f};
+        if (live) { x[0] = pts[3 * row]; x[1] = pts[3 * row + 1]; x[2] = pts[3 * row + 2]; }
+        if (sub < 3) {
+            const int a = sub;
+            float* pe = PE + p * TR_PE_STRIDE;
+            float* pd = pe + PT;
+            pe[a] = x[a];
+            pd[a] = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = (float)(1 << k);
+                float s, c;
+                hw_sincos(x[a] * f, s, c);
+                pe[3 + 6 * k + a] = s;
+                pe[6 + 6 * k + a] = c;
+                pd[3 + 6 * k + a] = f * c;
+                pd[6 + 6 * k + a] = -f * s;
+            }
+            if (a == 0) {
+                pe[TR_PE] = 1.0f;
+                pd[TR_PE] = 0.0f;
+#pragma unroll
+                for (int k = TR_PE + 1; k < TR_PE_K; ++k) { pe[k] = 0.0f; pd[k] = 0.0f; }
+            }
+        }
+        if (sub == 7) {
+            X[p * RS + KIN] = 1.0f;
+            X[XT + p * RS + KIN] = 0.0f;
+#pragma unroll
+            for (int k = KIN + 1; k < KP; ++k) { X[p * RS + k] = 0.0f; X[XT + p * RS + k] = 0.0f; }
+        }
+        if (sub < vols.n) {
+            const int l = sub;
+            const float dir[1][3] = {{1.0f, 1.0f, 1.0f}};
+            float4 o[2], jac[3], mix[3];
+            corner_sums<1, true>(vols, l, x, live, dir, o, jac, mix);
+            float* xr = X + p * RS + TR_H;
+            float* xd = xr + XT;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * l + c;
+                const float f = f4_at(o[0], c), fd = f4_at(o[1], c);
+                float s1, c1, s2, c2;
+                hw_sincos(f, s1, c1);
+                hw_sincos(2.0f * f, s2, c2);
+                xr[ch] = f; xr[CF + ch] = s1; xr[2 * CF + ch] = c1; xr[3 * CF + ch] = s2; xr[4 * CF + ch] = c2;
+                xd[ch] = fd; xd[CF + ch] = c1 * fd; xd[2 * CF + ch] = -s1 * fd; xd[3 * CF + ch] = 2.0f * c2 * fd; xd[4 * CF + ch] = -2.0f * s2 * fd;
+                float* j = JAC + (p * CF + ch) * 3;
+                float* jd = j + TR_M * CF * 3;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { j[a] = f4_at(jac[a], c); jd[a] = f4_at(mix[a], c); }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ forward sweeps: value + tangent
+    const int64_t sbase = (int64_t)blockIdx.x * TR_NLAYER;
+    for (int l = 0; l < TR_NLAYER; ++l) {
+        f32x16 acc[2];
+        zero_acc(acc);
+        if (l == 0)
+            mfma_tiles<TR_PE_K / 8, 2>(PE + a_lane * TR_PE_STRIDE + a_half, PT, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
+        else
+            mfma_tiles<GIN, 2>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
+        __syncthreads();
+        float2* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tr_acc_row(r, lane);
+            float h, d1, d2, d3;
+            softplus_d3(acc[0][r], h, d1, d2, d3);
+            (void)d3;
+            float hd = d1 * acc[1][r];
+            float2 keep = make_float2(d1, d2 * acc[1][r]);
+            if (l == 2) {   // z_3 = [h_2 | pe] / sqrt(2)   (sdf_network.py:111-112)
+                if (col < TR_SKIP_H) {
+                    h *= TR_SQ2;
+                    hd *= TR_SQ2;
+                } else {
+                    h = PE[row * TR_PE_STRIDE + (col - TR_SKIP_H)] * TR_SQ2;
+                    hd = PE[PT + row * TR_PE_STRIDE + (col - TR_SKIP_H)] * TR_SQ2;
+                    keep = make_float2(0.0f, 0.0f);
+                }
+            }
+            X[row * RS + col] = h;
+            X[XT + row * RS + col] = hd;
+            st[r * 64] = keep;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ layer 6, sdf row only
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        const float* xr = X + p * RS;
+        float s = 0.0f;
+        for (int k = sub; k < KIN; k += 8) s += xr[k] * W.w_last[k];
+        RED[p * 8 + sub] = s;
+    }
+    __syncthreads();
+    if (tid < TR_M) {
+        const int64_t row = m0 + tid;
+        if (row < n) {
+            float s = W.b_last[0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += RED[tid * 8 + k];
+            y_out[row] = s;
+        }
+    }
+
+    // ------------------------------------------------------------------ reverse sweeps: lambda + mu
+    constexpr bool SPLIT_K = (NT_B - 4) == 2;
+    const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
+    const int fe_g0 = SPLIT_K ? 8 * (wave >> 1) : 0;
+    constexpr int FE_G = SPLIT_K ? 8 : 16;
+    f32x16 gfe[2];
+    zero_acc(gfe);
+    __syncthreads();
+    {
+        const float wl = W.w_last[col];
+        const float2* st = stash + (((sbase + 5) * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tr_acc_row(r, lane);
+            const float2 k = st[r * 64];
+            X[row * RS + col] = k.x * wl;            // lambda_a5 = softplus' w6
+            X[XT + row * RS + col] = k.y * wl;       // mu_a5 = softplus'' a' w6
+        }
+    }
+    __syncthreads();
+    for (int l = 5; l >= 1; --l) {
+        f32x16 gh[2];
+        zero_acc(gh);
+        mfma_tiles<16, 2>(X + a_lane * RS + a_half, XT, W.wb[l] + (size_t)wave * 16 * 64 + lane, gh);
+        mfma_tiles<FE_G, 2>(X + a_lane * RS + a_half + 8 * fe_g0, XT, W.wb[l] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
+        __syncthreads();
+        const float2* st = stash + (((sbase + (l - 1)) * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tr_acc_row(r, lane);
+            float lh = gh[0][r], mh = gh[1][r];
+            if (l == 3) {
+                lh *= TR_SQ2;
+                mh *= TR_SQ2;
+                if (col >= TR_SKIP_H) {
+                    GPE[row * TR_PE_STRIDE + (col - TR_SKIP_H)] = lh;
+                    GPE[PT + row * TR_PE_STRIDE + (col - TR_SKIP_H)] = mh;
+                }
+            }
+            const float2 k = st[r * 64];
+            X[row * RS + col] = k.x * lh;
+            X[XT + row * RS + col] = k.y * lh + k.x * mh;
+        }
+        __syncthreads();
+    }
+    // layer 0: (32 x 128) x (128 x 27); the four waves split the reduction, partial tiles summed in a fixed order
+    {
+        f32x16 gp[2];
+        zero_acc(gp);
+        mfma_tiles<4, 2>(X + a_lane * RS + a_half + 32 * wave, XT, W.wb[0] + (size_t)(4 * wave) * 64 + lane, gp);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            X[tr_acc_row(r, lane) * RS + col] = gp[0][r];
+            X[XT + tr_acc_row(r, lane) * RS + col] = gp[1][r];
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * TR_M * 32; i += 256) {
+            const int t = i >> 10, row = (i >> 5) & 31, c = i & 31;
+            if (c < TR_PE) {
+                const float* xr = X + t * XT + row * RS + c;
+                GPE[t * PT + row * TR_PE_STRIDE + c] += ((xr[0] + xr[32]) + xr[64]) + xr[96];
+            }
+        }
+    }
+    __syncthreads();
+    // conditioning adjoints -> the (dead) h part of the two tiles
+    {
+        const int c = 32 * (fe_tile - 4) + (lane & 31);
+        if (c < FE && (!SPLIT_K || wave < 2)) {
+            const float wl = W.w_last[TR_H + c];      // layer 6 adds the same vector for every point; its tangent is zero
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                X[tr_acc_row(r, lane) * RS + c] = gfe[0][r] + wl;
+                X[XT + tr_acc_row(r, lane) * RS + c] = gfe[1][r];
+            }
+        }
+        if (SPLIT_K) {
+            __syncthreads();
+            if (c < FE && wave >= 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    X[tr_acc_row(r, lane) * RS + c] += gfe[0][r];
+                    X[XT + tr_acc_row(r, lane) * RS + c] += gfe[1][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // lambda_f = E'^T lambda_e ; mu_f = E'^T mu_e + E''[f'] lambda_e
+        const int p = tid >> 3, sub = tid & 7;
+        if (sub < vols.n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * sub + c;
+                const float* e = X + p * RS + TR_H;           // [f, sin f, cos f, sin 2f, cos 2f]
+                const float fd = X[XT + p * RS + TR_H + ch];
+                const float s1 = e[CF + ch], c1 = e[2 * CF + ch], s2 = e[3 * CF + ch], c2 = e[4 * CF + ch];
+                const float* le = X + p * RS;
+                const float* me = le + XT;
+                const float l0 = le[ch], l1 = le[CF + ch], l2 = le[2 * CF + ch], l3 = le[3 * CF + ch], l4 = le[4 * CF + ch];
+                const float lam_f = l0 + c1 * l1 - s1 * l2 + 2.0f * (c2 * l3 - s2 * l4);
+                const float mu_f = me[ch] + c1 * me[CF + ch] - s1 * me[2 * CF + ch] + 2.0f * (c2 * me[3 * CF + ch] - s2 * me[4 * CF + ch]) -
+                                   fd * (s1 * l1 + c1 * l2 + 4.0f * (s2 * l3 + c2 * l4));
+                LF[p * CF + ch] = lam_f;
+                LF[TR_M * CF + p * CF + ch] = mu_f;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < TR_M * 3) {
+        const int p = tid / 3, a = tid % 3;
+        const int64_t row = m0 + p;
+        if (row < n) {
+            const float* pe = PE + p * TR_PE_STRIDE;
+            const float* lp = GPE + p * TR_PE_STRIDE;
+            const float* mp = lp + PT;
+            float g = lp[a], s = mp[a];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = (float)(1 << k);
+                const float S = pe[3 + 6 * k + a], C = pe[6 + 6 * k + a];
+                const float ls = lp[3 + 6 * k + a], lc = lp[6 + 6 * k + a];
+                g += f * (ls * C - lc * S);
+                s += f * (mp[3 + 6 * k + a] * C - mp[6 + 6 * k + a] * S) - f * f * (ls * S + lc * C);
+            }
+            const float* j = JAC + p * CF * 3;
+            const float* jd = j + TR_M * CF * 3;
+            const float* lf = LF + p * CF;
+            const float* mf = lf + TR_M * CF;
+            for (int c = 0; c < CF; ++c) {
+                g += j[c * 3 + a] * lf[c];
+                s += jd[c * 3 + a] * lf[c] + j[c * 3 + a] * mf[c];
+            }
+            g_out[3 * row + a] = g;
+            s_out[3 * row + a] = s;
+        }
+    }
+}
+
+// ====================================================================================================================
+// backward launch: operand rows of the weight-gradient products, and the three per-point vectors of the volume scatter
+// tiles (LDS) / operand pairs:  0: z  with omega_a   1: z' with rho_a   2: kappa_z with lambda_a   3: nu_z with mu_a
+// ====================================================================================================================
+struct SdfTrainBwdOut {
+    float* lop;     // [4][npad][6][128]   omega_a, rho_a, lambda_a, mu_a of layers 0..5
+    float* rh;      // [6][4][npad][128]   h parts of the inputs of layers 1..6: z, z', kappa_z, nu_z
+    float* re;      // [4][npad][KP-128]   conditioning parts (+ the bias column) of the same four
+    float* r0;      // [4][npad][32]       inputs of layer 0
+    float* f_hat;   // [npad][CF]          cotangent of the looked-up features
+    float* mu_f;    // [npad][CF]
+    float* lam_f;   // [npad][CF]
+    int64_t npad;
+};
+
+template <int FE>
+__global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts, int64_t n,
+                                                       const float* __restrict__ y_bar, const float* __restrict__ g_bar,
+                                                       const float* __restrict__ s_bar, float4* __restrict__ stash, SdfTrainBwdOut O) {
+    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4, FEP = KP - TR_H;
+    constexpr int NT_B = (KIN + 31) / 32;
+    constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;              // [4][XT]
+    float* PE = X + 4 * XT;       // [4][PT]
+    float* YB = PE + 4 * PT;      // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
+    const int col = 32 * wave + (lane & 31);
+    const int64_t npad = O.npad;
+
+    // ------------------------------------------------------------------ prologue
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        const int64_t row = m0 + p;
+        const bool live = row < n;
+        float x[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                x[a] = pts[3 * row + a];
+                sb[a] = s_bar ? s_bar[3 * row + a] : 0.0f;
+                gb[a] = g_bar ? g_bar[3 * row + a] : 0.0f;
+            }
+        }
+        if (sub == 6) YB[p] = (live && y_bar) ? y_bar[row] : 0.0f;
+        if (sub < 3) {
+            const int a = sub;
+            float* p0 = PE + p * TR_PE_STRIDE;
+            float *p1 = p0 + PT, *p2 = p0 + 2 * PT, *p3 = p0 + 3 * PT;
+            p0[a] = x[a];
+            p1[a] = 1.0f;
+            p2[a] = gb[a];
+            p3[a] = sb[a];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = (float)(1 << k);
+                float s, c;
+                hw_sincos(x[a] * f, s, c);
+                const int is = 3 + 6 * k + a, ic = 6 + 6 * k + a;
+                p0[is] = s;
+                p0[ic] = c;
+                p1[is] = f * c;
+                p1[ic] = -f * s;
+                p3[is] = f * c * sb[a];
+                p3[ic] = -f * s * sb[a];
+                p2[is] = -f * f * s * sb[a] + f * c * gb[a];
+                p2[ic] = -f * f * c * sb[a] - f * s * gb[a];
+            }
+            if (a == 0) {
+                p0[TR_PE] = 1.0f;
+                p1[TR_PE] = p2[TR_PE] = p3[TR_PE] = 0.0f;
+#pragma unroll
+                for (int k = TR_PE + 1; k < TR_PE_K; ++k) p0[k] = p1[k] = p2[k] = p3[k] = 0.0f;
+            }
+        }
+        if (sub == 7) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                X[t * XT + p * RS + KIN] = t == 0 ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = KIN + 1; k < KP; ++k) X[t * XT + p * RS + k] = 0.0f;
+            }
+        }
+        if (sub < vols.n) {
+            const int l = sub;
+            const float dir[3][3] = {{1.0f, 1.0f, 1.0f}, {gb[0], gb[1], gb[2]}, {sb[0], sb[1], sb[2]}};
+            float4 o[4], jac[3], mix[3];
+            corner_sums<3, false>(vols, l, x, live, dir, o, jac, mix);
+            float* x0 = X + p * RS + TR_H;
+            float *x1 = x0 + XT, *x2 = x0 + 2 * XT, *x3 = x0 + 3 * XT;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * l + c;
+                const float f = f4_at(o[0], c), fd = f4_at(o[1], c), kf = f4_at(o[2], c), nf = f4_at(o[3], c);
+                float s1, c1, s2, c2;
+                hw_sincos(f, s1, c1);
+                hw_sincos(2.0f * f, s2, c2);
+                const float fn = fd * nf;
+                x0[ch] = f; x0[CF + ch] = s1; x0[2 * CF + ch] = c1; x0[3 * CF + ch] = s2; x0[4 * CF + ch] = c2;
+                x1[ch] = fd; x1[CF + ch] = c1 * fd; x1[2 * CF + ch] = -s1 * fd; x1[3 * CF + ch] = 2.0f * c2 * fd; x1[4 * CF + ch] = -2.0f * s2 * fd;
+                x3[ch] = nf; x3[CF + ch] = c1 * nf; x3[2 * CF + ch] = -s1 * nf; x3[3 * CF + ch] = 2.0f * c2 * nf; x3[4 * CF + ch] = -2.0f * s2 * nf;
+                x2[ch] = kf;
+                x2[CF + ch] = c1 * kf - s1 * fn;
+                x2[2 * CF + ch] = -s1 * kf - c1 * fn;
+                x2[3 * CF + ch] = 2.0f * c2 * kf - 4.0f * s2 * fn;
+                x2[4 * CF + ch] = -2.0f * s2 * kf - 4.0f * c2 * fn;
+            }
+        }
+    }
+    __syncthreads();
+    // operand rows that are already complete: the conditioning parts and the inputs of layer 0
+    for (int i = tid; i < 4 * TR_M * FEP; i += 256) {
+        const int t = i / (TR_M * FEP), rem = i % (TR_M * FEP), row = rem / FEP, c = rem % FEP;
+        O.re[((int64_t)t * npad + m0 + row) * FEP + c] = X[t * XT + row * RS + TR_H + c];
+    }
+    for (int i = tid; i < 4 * TR_M * 32; i += 256) {
+        const int t = i >> 10, row = (i >> 5) & 31, c = i & 31;
+        O.r0[((int64_t)t * npad + m0 + row) * 32 + c] = PE[t * PT + row * TR_PE_STRIDE + c];
+    }
+
+    // ------------------------------------------------------------------ forward sweeps: a, a', kappa_a, nu_a
+    const int64_t sbase = (int64_t)blockIdx.x * TR_NLAYER;
+    for (int l = 0; l < TR_NLAYER; ++l) {
+        f32x16 acc[4];
+        zero_acc(acc);
+        if (l == 0)
+            mfma_tiles<TR_PE_K / 8, 4>(PE + a_lane * TR_PE_STRIDE + a_half, PT, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
+        else
+            mfma_tiles<GIN, 4>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
+        __syncthreads();
+        float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+        float* rh = O.rh + (((int64_t)l * 4) * npad + m0) * TR_H + col;       // inputs of layer l + 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tr_acc_row(r, lane);
+            const float a = acc[0][r], ad = acc[1][r], ak = acc[2][r], an = acc[3][r];
+            float h, d1, d2, d3;
+            softplus_d3(a, h, d1, d2, d3);
+            (void)d3;
+            float hd = d1 * ad, hn = d1 * an, hk = d1 * ak + d2 * ad * an;
+            float4 keep = make_float4(a, ad, an, ak);
+            if (l == 2) {
+                if (col < TR_SKIP_H) {
+                    h *= TR_SQ2; hd *= TR_SQ2; hk *= TR_SQ2; hn *= TR_SQ2;
+                } else {
+                    const float* pe = PE + row * TR_PE_STRIDE + (col - TR_SKIP_H);
+                    h = pe[0] * TR_SQ2; hd = pe[PT] * TR_SQ2; hk = pe[2 * PT] * TR_SQ2; hn = pe[3 * PT] * TR_SQ2;
+                    keep = make_float4(TR_DEAD, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            float* xr = X + row * RS + col;
+            xr[0] = h; xr[XT] = hd; xr[2 * XT] = hk; xr[3 * XT] = hn;
+            float* gr = rh + (int64_t)row * TR_H;
+            gr[0] = h; gr[npad * TR_H] = hd; gr[2 * npad * TR_H] = hk; gr[3 * npad * TR_H] = hn;
+            st[r * 64] = keep;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ reverse sweeps: omega, rho, lambda, mu
+    constexpr bool SPLIT_K = (NT_B - 4) == 2;
+    const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
+    const int fe_g0 = SPLIT_K ? 8 * (wave >> 1) : 0;
+    constexpr int FE_G = SPLIT_K ? 8 : 16;
+    f32x16 gfe[4];
+    zero_acc(gfe);
+    const float wl_col = W.w_last[col];
+    for (int l = 5; l >= 0; --l) {
+        // cotangents of h_l: from the output row (l = 5) or from the reverse products of layer l + 1
+        f32x16 gh[4];
+        zero_acc(gh);
+        if (l < 5) {
+            mfma_tiles<16, 4>(X + a_lane * RS + a_half, XT, W.wb[l + 1] + (size_t)wave * 16 * 64 + lane, gh);
+            mfma_tiles<FE_G, 4>(X + a_lane * RS + a_half + 8 * fe_g0, XT, W.wb[l + 1] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
+        }
+        __syncthreads();
+        const float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+        float* lop = O.lop + ((int64_t)m0 * TR_NLAYER + l) * TR_H + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tr_acc_row(r, lane);
+            float oh, rho_h, lh, mh;
+            if (l == 5) {
+                oh = YB[row] * wl_col; rho_h = 0.0f; lh = wl_col; mh = 0.0f;
+            } else {
+                oh = gh[0][r]; rho_h = gh[1][r]; lh = gh[2][r]; mh = gh[3][r];
+                if (l == 2) { oh *= TR_SQ2; rho_h *= TR_SQ2; lh *= TR_SQ2; mh *= TR_SQ2; }
+            }
+            const float4 k = st[r * 64];                       // a, a', nu_a, kappa_a
+            float h, d1, d2, d3;
+            softplus_d3(k.x, h, d1, d2, d3);
+            (void)h;
+            const float lam_a = d1 * lh;
+            const float mu_a = d2 * k.y * lh + d1 * mh;
+            const float rho_a = d2 * k.z * lh + d1 * rho_h;
+            const float om_a = d1 * oh + d3 * k.y * k.z * lh + d2 * (mh * k.z + k.y * rho_h + lh * k.w);
+            float* xr = X + row * RS + col;
+            xr[0] = om_a; xr[XT] = rho_a; xr[2 * XT] = lam_a; xr[3 * XT] = mu_a;
+            float* gr = lop + (int64_t)row * TR_NLAYER * TR_H;
+            const int64_t qs = npad * TR_NLAYER * TR_H;
+            gr[0] = om_a; gr[qs] = rho_a; gr[2 * qs] = lam_a; gr[3 * qs] = mu_a;
+        }
+        __syncthreads();
+    }
+    // conditioning cotangents -> the (dead) h part of the four tiles
+    {
+        const int c = 32 * (fe_tile - 4) + (lane & 31);
+        if (c < FE && (!SPLIT_K || wave < 2)) {
+            const float wl = W.w_last[TR_H + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tr_acc_row(r, lane);
+                float* xr = X + row * RS + c;
+                xr[0] = gfe[0][r] + YB[row] * wl;
+                xr[XT] = gfe[1][r];
+                xr[2 * XT] = gfe[2][r] + wl;
+                xr[3 * XT] = gfe[3][r];
+            }
+        }
+        if (SPLIT_K) {
+            __syncthreads();
+            if (c < FE && wave >= 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* xr = X + tr_acc_row(r, lane) * RS + c;
+                    xr[0] += gfe[0][r]; xr[XT] += gfe[1][r]; xr[2 * XT] += gfe[2][r]; xr[3 * XT] += gfe[3][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int p = tid >> 3, sub = tid & 7;
+        if (sub < vols.n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * sub + c;
+                const float* x0 = X + p * RS;
+                const float *x1 = x0 + XT, *x2 = x0 + 2 * XT, *x3 = x0 + 3 * XT;
+                const float s1 = x0[TR_H + CF + ch], c1 = x0[TR_H + 2 * CF + ch], s2 = x0[TR_H + 3 * CF + ch], c2 = x0[TR_H + 4 * CF + ch];
+                const float fd = x1[TR_H + ch], kf = x2[TR_H + ch], nf = x3[TR_H + ch];
+                // E' = [1, c1, -s1, 2 c2, -2 s2], E'' = [0, -s1, -c1, -4 s2, -4 c2], E''' = [0, -c1, s1, -8 c2, 8 s2]
+#define TR_E1(v) ((v)[ch] + c1 * (v)[CF + ch] - s1 * (v)[2 * CF + ch] + 2.0f * (c2 * (v)[3 * CF + ch] - s2 * (v)[4 * CF + ch]))
+#define TR_E2(v) (-(s1 * (v)[CF + ch] + c1 * (v)[2 * CF + ch] + 4.0f * (s2 * (v)[3 * CF + ch] + c2 * (v)[4 * CF + ch])))
+#define TR_E3(v) (-c1 * (v)[CF + ch] + s1 * (v)[2 * CF + ch] + 8.0f * (s2 * (v)[4 * CF + ch] - c2 * (v)[3 * CF + ch]))
+                const float lam_f = TR_E1(x2);
+                const float e2l = TR_E2(x2);
+                const float mu_f = TR_E1(x3) + fd * e2l;
+                const float f_hat = TR_E1(x0) + fd * TR_E2(x1) + nf * TR_E2(x3) + nf * fd * TR_E3(x2) + kf * e2l;
+#undef TR_E1
+#undef TR_E2
+#undef TR_E3
+                const int64_t o = (m0 + p) * CF + ch;
+                O.f_hat[o] = f_hat;
+                O.mu_f[o] = mu_f;
+                O.lam_f[o] = lam_f;
+            }
+        }
+    }
+}
+
+// ====================================================================================================================
+// volume scatter: dV += w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lambda_f     (planar (4, X, Y, Z) gradients)
+// ====================================================================================================================
+__global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const float* __restrict__ pts, const float* __restrict__ g_bar,
+                                                           const float* __restrict__ s_bar, const float4* __restrict__ f_hat,
+                                                           const float4* __restrict__ mu_f, const float4* __restrict__ lam_f, int64_t n) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int L = vs.n;
+    if (gid >= n * L) return;
+    const int l = (int)(gid % L);
+    const int64_t i = gid / L;
+    float* gv = vs.grad[l];
+    if (!gv) return;
+    const int sz[3] = {vs.dx[l], vs.dy[l], vs.dz[l]};
+    const int64_t nvox = (int64_t)sz[0] * sz[1] * sz[2];
+    float w0[3], w1[3], k[3], sb[3], gb[3];
+    int i0[3];
+    bool in0[3], in1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = pts[3 * i + a];
+        const float pos = (x + 1.0f) / 2.0f * (float)(sz[a] - 1);
+        const float f = fminf(fmaxf(floorf(pos), -2.0f), (float)sz[a] + 1.0f);
+        i0[a] = (int)f;
+        w0[a] = (f + 1.0f) - pos;
+        w1[a] = pos - f;
+        in0[a] = i0[a] >= 0 && i0[a] < sz[a];
+        in1[a] = i0[a] + 1 >= 0 && i0[a] + 1 < sz[a];
+        if (!(pos == pos)) in0[a] = in1[a] = false;
+        k[a] = (float)(sz[a] - 1) / 2.0f;
+        sb[a] = s_bar ? s_bar[3 * i + a] : 0.0f;
+        gb[a] = g_bar ? g_bar[3 * i + a] : 0.0f;
+    }
+    const float4 fh = f_hat[i * L + l], mf = mu_f[i * L + l], lf = lam_f[i * L + l];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
+        const bool ok = (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+        if (!ok) continue;
+        const float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
+        const float dwx = (a ? k[0] : -k[0]) * wy * wz, dwy = wx * (b ? k[1] : -k[1]) * wz, dwz = wx * wy * (d ? k[2] : -k[2]);
+        const float w = wx * wy * wz;
+        const float ts = dwx * sb[0] + dwy * sb[1] + dwz * sb[2];
+        const float tg = dwx * gb[0] + dwy * gb[1] + dwz * gb[2];
+        const int64_t lin = ((int64_t)(i0[0] + a) * sz[1] + (i0[1] + b)) * sz[2] + (i0[2] + d);
+        atomicAdd(gv + lin, w * fh.x + ts * mf.x + tg * lf.x);
+        atomicAdd(gv + nvox + lin, w * fh.y + ts * mf.y + tg * lf.y);
+        atomicAdd(gv + 2 * nvox + lin, w * fh.z + ts * mf.z + tg * lf.z);
+        atomicAdd(gv + 3 * nvox + lin, w * fh.w + ts * mf.w + tg * lf.w);
+    }
+}
+
+// ====================================================================================================================
+// weight packing: effective matrices (row major, weight norm already applied) -> the two B streams of every layer
+// ====================================================================================================================
+struct SdfPackArgs {
+    const float* w[TR_NLAYER];
+    const float* b[TR_NLAYER];
+    float4* wf[TR_NLAYER];
+    float4* wb[TR_NLAYER];
+    int rows[TR_NLAYER], cols[TR_NLAYER];   // J_l (128 / 101), K_l (27 / 128 + FE)
+    int gf[TR_NLAYER];                      // forward groups per n-tile: ceil((K_l + 1) / 8)
+    int ntb[TR_NLAYER];                     // backward n-tiles: ceil(K_l / 32)
+};
+
+__global__ __launch_bounds__(256) void sdf_train_pack_k(SdfPackArgs A) {
+    const int l = blockIdx.y;
+    const int J = A.rows[l], K = A.cols[l], G = A.gf[l];
+    const int nf = 4 * G * 64, nb = A.ntb[l] * 16 * 64;
+    const float* w = A.w[l];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += gridDim.x * 256) {
+        float v[4];
+        if (i < nf) {
+            const int lane = i & 63, g = (i >> 6) % G, nt = (i >> 6) / G;
+            const int j = 32 * nt + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 8 * g + 4 * (lane >> 5) + q;
+                v[q] = (j < J && k < K) ? w[(size_t)j * K + k] : (j < J && k == K) ? A.b[l][j] : 0.0f;
+            }
+            A.wf[l][i] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            const int ii = i - nf;
+            const int lane = ii & 63, g = (ii >> 6) & 15, nt = ii >> 10;
+            const int jj = 32 * nt + (lane & 31);              // input column of W
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kk = 8 * g + 4 * (lane >> 5) + q;    // output row of W
+                v[q] = (jj < K && kk < J) ? w[(size_t)kk * K + jj] : 0.0f;
+            }
+            A.wb[l][ii] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ====================================================================================================================
+// C ABI
+// ====================================================================================================================
+int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
+
+template <int FE>
+static constexpr size_t fwd_lds_bytes() {
+    constexpr int CF = FE / 5, KP = (TR_H + FE + 7) / 8 * 8, RS = KP + 4;
+    return sizeof(float) * (2 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + 2 * TR_M * CF * 3 + 2 * TR_M * CF + TR_M * 8);
+}
+template <int FE>
+static constexpr size_t bwd_lds_bytes() {
+    constexpr int KP = (TR_H + FE + 7) / 8 * 8, RS = KP + 4;
+    return sizeof(float) * (4 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + TR_M);
+}
+
+static int fill_train_weights(const char* who, SdfTrainWeights* W, const float* const* wf, const float* const* wb, const float* w_last,
+                              const float* b_last) {
+    GENS_CHECK_ARG(wf && wb && w_last, GENS_EINVAL, "%s: null weight table", who);
+    for (int l = 0; l < TR_NLAYER; ++l) {
+        GENS_CHECK_ARG(wf[l] && wb[l], GENS_EINVAL, "%s: layer %d weights are null", who, l);
+        W->wf[l] = (const float4*)wf[l];
+        W->wb[l] = (const float4*)wb[l];
+    }
+    W->w_last = w_last;
+    W->b_last = b_last;
+    return 0;
+}
+
+extern "C" int64_t gens_sdf_train_stash_bytes(int64_t n, int backward) {
+    return gens_blocks(n, TR_M) * (int64_t)TR_NLAYER * 4 * 16 * 64 * (backward ? 16 : 8);
+}
+
+extern "C" int gens_sdf_train_pack(const float* const* w, const float* const* b, int n_levels, float* const* wf, float* const* wb,
+                                   void* stream) {
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_pack: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(w && b && wf && wb, GENS_EINVAL, "gens_sdf_train_pack: null table");
+    SdfPackArgs A;
+    const int kin = TR_H + 20 * n_levels;
+    int most = 0;
+    for (int l = 0; l < TR_NLAYER; ++l) {
+        GENS_CHECK_ARG(w[l] && b[l] && wf[l] && wb[l], GENS_EINVAL, "gens_sdf_train_pack: layer %d is null", l);
+        A.w[l] = w[l];
+        A.b[l] = b[l];
+        A.wf[l] = (float4*)wf[l];
+        A.wb[l] = (float4*)wb[l];
+        A.rows[l] = l == 2 ? TR_SKIP_H : TR_H;
+        A.cols[l] = l == 0 ? TR_PE : kin;
+        A.gf[l] = (A.cols[l] + 1 + 7) / 8;
+        A.ntb[l] = (A.cols[l] + 31) / 32;
+        most = max(most, 4 * A.gf[l] * 64 + A.ntb[l] * 16 * 64);
+    }
+    sdf_train_pack_k<<<dim3(gens_blocks(most, 256), TR_NLAYER), 256, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_sdf_train_pack");
+}
+
+extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                                  const float* const* wb, const float* w_last, const float* b_last, const float* pts, int64_t n,
+                                  void* stash, float* y_out, float* g_out, float* s_out, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_sdf_train_fwd", &vs, vols_packed, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_fwd: built for 3 or 5 volume levels, got %d", n_levels);
+    SdfTrainWeights W;
+    if (int e = fill_train_weights("gens_sdf_train_fwd", &W, wf, wb, w_last, b_last)) return e;
+    GENS_CHECK_ARG(b_last, GENS_EINVAL, "gens_sdf_train_fwd: null b_last");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && y_out && g_out && s_out)), GENS_EINVAL, "gens_sdf_train_fwd: null pts / stash / output");
+    if (n == 0) return 0;
+    const unsigned grid = gens_blocks(n, TR_M);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_levels == 3) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<60>());
+            once = true;
+        }
+        sdf_train_fwd_k<60><<<grid, 256, fwd_lds_bytes<60>(), s>>>(W, vs, pts, n, (float2*)stash, y_out, g_out, s_out);
+    } else {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<100>());
+            once = true;
+        }
+        sdf_train_fwd_k<100><<<grid, 256, fwd_lds_bytes<100>(), s>>>(W, vs, pts, n, (float2*)stash, y_out, g_out, s_out);
+    }
+    return gens_launch_status("gens_sdf_train_fwd");
+}
+
+extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                                  const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
+                                  const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
+                                  float* f_hat, float* mu_f, float* lam_f, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_sdf_train_bwd", &vs, vols_packed, dims, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_bwd: built for 3 or 5 volume levels, got %d", n_levels);
+    SdfTrainWeights W;
+    if (int e = fill_train_weights("gens_sdf_train_bwd", &W, wf, wb, w_last, nullptr)) return e;
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && lop && rh && re && r0 && f_hat && mu_f && lam_f)), GENS_EINVAL,
+                   "gens_sdf_train_bwd: null pts / stash / output");
+    if (n == 0) return 0;
+    const unsigned grid = gens_blocks(n, TR_M);
+    SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, (int64_t)grid * TR_M};
+    hipStream_t s = (hipStream_t)stream;
+    if (n_levels == 3) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<60>());
+            once = true;
+        }
+        sdf_train_bwd_k<60><<<grid, 256, bwd_lds_bytes<60>(), s>>>(W, vs, pts, n, y_bar, g_bar, s_bar, (float4*)stash, O);
+    } else {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<100>());
+            once = true;
+        }
+        sdf_train_bwd_k<100><<<grid, 256, bwd_lds_bytes<100>(), s>>>(W, vs, pts, n, y_bar, g_bar, s_bar, (float4*)stash, O);
+    }
+    return gens_launch_status("gens_sdf_train_bwd");
+}
+
+extern "C" int gens_sdf_train_scatter(const int* dims, int n_levels, const float* pts, const float* g_bar, const float* s_bar,
+                                      const float* f_hat, const float* mu_f, const float* lam_f, int64_t n, float* const* g_vols,
+                                      void* stream) {
+    GENS_CHECK_ARG(dims && g_vols, GENS_EINVAL, "gens_sdf_train_scatter: null table");
+    GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_sdf_train_scatter: n_levels=%d not in 1..%d", n_levels,
+                   GENS_MAX_LEVELS);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && f_hat && mu_f && lam_f)), GENS_EINVAL, "gens_sdf_train_scatter: null pointer");
+    if (n == 0) return 0;
+    LevelSet vs;
+    vs.n = n_levels;
+    vs.bits = 0;
+    for (int l = 0; l < GENS_MAX_LEVELS; ++l) {
+        vs.data[l] = nullptr;
+        vs.aux[l] = nullptr;
+        vs.grad[l] = l < n_levels ? g_vols[l] : nullptr;
+        vs.dx[l] = l < n_levels ? dims[3 * l] : 1;
+        vs.dy[l] = l < n_levels ? dims[3 * l + 1] : 1;
+        vs.dz[l] = l < n_levels ? dims[3 * l + 2] : 1;
+    }
+    sdf_train_scatter_k<<<gens_blocks(n * n_levels, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, g_bar, s_bar, (const float4*)f_hat,
+                                                                                         (const float4*)mu_f, (const float4*)lam_f, n);
+    return gens_launch_status("gens_sdf_train_scatter");
+}

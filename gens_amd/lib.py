@@ -88,6 +88,10 @@ SIGNATURES = {
     "gens_mc_classify": [_p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p],
     "gens_mc_emit": [_p, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_sdf_train_pack": [_pp, _pp, _i, _pp, _pp, _p],
+    "gens_sdf_train_fwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _l, _p, _p, _p, _p, _p],
+    "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _l, _pp, _p],
 }
 
 _lib = None
@@ -108,6 +112,8 @@ def load():
     lib.gens_abi_version.argtypes = []
     lib.gens_tv_blocks.restype = _i
     lib.gens_tv_blocks.argtypes = [_l]
+    lib.gens_sdf_train_stash_bytes.restype = _l
+    lib.gens_sdf_train_stash_bytes.argtypes = [_l, _i]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i

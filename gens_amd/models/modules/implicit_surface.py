@@ -134,6 +134,7 @@ class ImplicitSurface(nn.Module):
         self._sdf_plan = None
         self.fused_blend = True        # inference: source-view look-up + colour network in one kernel (gens_blend_views)
         self._blend_plan = None
+        self.fused_train = True        # training: SDF value / gradient / smooth and their backward in the K17 kernels (gens_sdf_train_*)
 
     # ----------------------------------------------------------------------------------------------------------
     # masked SDF evaluation (Q7, Q8)
@@ -229,9 +230,11 @@ class ImplicitSurface(nn.Module):
     # render_core
     # ----------------------------------------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None):
+                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None, extra_pts=None):
         """Everything after sampling (:152-349).  `lean` (validate only) skips the quantities validate discards:
-        second derivatives, random-point SDF, TV, the surface-point gradient and the patch warp."""
+        second derivatives, random-point SDF, TV, the surface-point gradient and the patch warp.
+        extra_pts: more points whose SDF the caller wants from the same network pass (forward()'s pseudo points, :484-497):
+        returned under the private key "_extra_sdf"."""
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
         b, n = z_vals.shape
@@ -242,6 +245,10 @@ class ImplicitSurface(nn.Module):
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
         plan = self._fused_plan(vols) if lean else None
         bplan = self._fused_blend_plan(scene.views) if lean else None
+        net = None                                     # training: one fused evaluator for every SDF query of this step
+        if not lean and self.fused_train and torch.is_grad_enabled():
+            net = self.sdf_network.train_step(scene.volumes, scene.volumes_nograd())
+        sdf_random = extra_sdf = None
         if plan is not None and bplan is not None:     # fully fused inference: nothing in this branch synchronises with the host
             idx, count = ops.compact_valid(valid)
             sdf = torch.full((b * n, 1), 100.0, device=dev)
@@ -264,6 +271,15 @@ class ImplicitSurface(nn.Module):
                         sdf_v = self.sdf_network.sdf(x, vols)
                         grad_v = torch.autograd.grad(sdf_v, x, torch.ones_like(sdf_v))[0]
                     sdf_v, smooth_v = sdf_v.detach(), None
+                elif net is not None:                      # K17: the ray samples, the 1024 random points (:256-257) and the caller's extra
+                    if pts_random is None:                 # points share ONE forward / backward pair of launches
+                        pts_random = torch.rand([N_RANDOM_PTS, 3]).to(dev) * 2 - 1             # CPU generator, :256
+                    batch = [pts_v, pts_random] + ([extra_pts] if extra_pts is not None else [])
+                    y_all, g_all, s_all = net(torch.cat(batch))
+                    n_v, n_r = pts_v.shape[0], pts_random.shape[0]
+                    sdf_v, grad_v, smooth_v = y_all[:n_v], g_all[:n_v], s_all[:n_v]
+                    sdf_random = y_all[n_v:n_v + n_r]
+                    extra_sdf = y_all[n_v + n_r:] if extra_pts is not None else None
                 else:                                      # one forward pass for :179 (sdf) and :188 (gradient, smooth)
                     sdf_v, grad_v, smooth_v = self.sdf_network.sdf_gradient_smooth(pts_v.clone(), vols)
                 sdf = torch.full((b * n, 1), 100.0, device=dev).index_put((idx,), sdf_v)
@@ -302,13 +318,20 @@ class ImplicitSurface(nn.Module):
 
         if pts_random is None:
             pts_random = torch.rand([N_RANDOM_PTS, 3]).to(dev) * 2 - 1                     # CPU generator, :256
-        out["sparse_sdf"] = torch.cat([self.sdf_network.sdf(pts_random, vols), sdf])
+        if sdf_random is None:
+            sdf_random = self.sdf_network.sdf(pts_random, vols)
+        out["sparse_sdf"] = torch.cat([sdf_random, sdf])
+        if extra_pts is not None:
+            out["_extra_sdf"] = extra_sdf if extra_sdf is not None else self.sdf_network.sdf(extra_pts, vols)
         out["tv_reg"] = self.tv_regularization(scene.volumes, scene.mask_volumes)
 
         # surface point of the first sign change and the plane-induced patch warp (:288-328)
         pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
         # the reference builds the second-order graph here too and throws it away: the normal is used detached (:306-310)
-        g0, _ = self.sdf_network.gradient(pts_sdf0.detach().reshape(-1, 3).clone(), vols, second_order=False)
+        if net is not None:
+            g0 = net.first_order(pts_sdf0)
+        else:
+            g0, _ = self.sdf_network.gradient(pts_sdf0.detach().reshape(-1, 3).clone(), vols, second_order=False)
         g0 = g0.reshape(b, 1, 3)
         g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
         g0 = g0 / torch.where(g0_norm <= 0, torch.full_like(g0_norm, 1e-8), g0_norm)
@@ -331,7 +354,7 @@ class ImplicitSurface(nn.Module):
         return cached[1]
 
     def render(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, cos_anneal_ratio, step,
-               scene=None, lean=False, t_rand=None, pts_random=None):
+               scene=None, lean=False, t_rand=None, pts_random=None, extra_pts=None):
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
         b = len(rays_o)
@@ -349,7 +372,7 @@ class ImplicitSurface(nn.Module):
         if self.n_importance > 0:
             z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene)
         return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random)
+                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts)
 
     # ----------------------------------------------------------------------------------------------------------
     # geometry + validation
@@ -445,19 +468,24 @@ class ImplicitSurface(nn.Module):
         imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
         rays_o, rays_d, near, far = ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"]
         scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
-        if mode == "val":
-            outputs = self.validate(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
-                                    ipts["bound_min"], ipts["bound_max"], ipts["hw"], cos_anneal_ratio, step, scene=scene)
-        else:
-            outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
-                                  cos_anneal_ratio, step, scene=scene)
-        if "pseudo_pts" in ipts:
+        pseudo_pts = idx = None
+        if "pseudo_pts" in ipts:                       # (:484-497) the mask look-up draws nothing from the generator, so it can come first
             pseudo_pts = ipts["pseudo_pts"].float()
             valid = ops.lookup_mask(pseudo_pts, scene.masks)
             if int(valid.sum()) < 1:
                 raise RuntimeError("No valid pseudo pts!")                                  # the reference raises a str (:494-495)
             idx = torch.nonzero(valid)[:, 0]
-            vols = scene.volumes if any(v.requires_grad for v in scene.volumes) else scene.volumes_nograd()
-            pseudo_sdf = torch.zeros_like(pseudo_pts[:, :1]).index_put((idx,), self.sdf_network.sdf(pseudo_pts[idx], vols))
-            outputs["pseudo_sdf"] = pseudo_sdf
+        if mode == "val":
+            outputs = self.validate(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                    ipts["bound_min"], ipts["bound_max"], ipts["hw"], cos_anneal_ratio, step, scene=scene)
+            extra = None
+        else:                                          # the pseudo points ride on the render's network pass
+            outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                  cos_anneal_ratio, step, scene=scene, extra_pts=None if idx is None else pseudo_pts[idx])
+            extra = outputs.pop("_extra_sdf", None)
+        if pseudo_pts is not None:
+            if extra is None:
+                vols = scene.volumes if any(v.requires_grad for v in scene.volumes) else scene.volumes_nograd()
+                extra = self.sdf_network.sdf(pseudo_pts[idx], vols)
+            outputs["pseudo_sdf"] = torch.zeros_like(pseudo_pts[:, :1]).index_put((idx,), extra)
         return outputs

@@ -112,6 +112,25 @@ class SDFNetwork(nn.Module):
     def sdf_hidden_appearance(self, x, volumes):
         return self.forward(x, volumes)
 
+    def effective_weights(self):
+        """-> ([W_0 .. W_6], [b_0 .. b_6]): the matrices the layers multiply by (weight norm applied: g v / |v| per row, the same
+        `torch._weight_norm` the hook of nn.utils.weight_norm calls), with autograd history back to weight_g / weight_v / bias."""
+        ws, bs = [], []
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, f"lin{l}")
+            ws.append(torch._weight_norm(lin.weight_v, lin.weight_g, 0) if hasattr(lin, "weight_g") else lin.weight)
+            bs.append(lin.bias)
+        return ws, bs
+
+    def train_step(self, volumes, packed):
+        """The fused training-mode evaluator (ops.SdfTrainStep: value, gradient, `smooth` and their backward in four launches) for this
+        step's weights, or None when the kernels do not cover the architecture / pyramid (then the PyTorch layers run on K2 / K2'')."""
+        from ... import ops
+        if not (isinstance(packed, ops.VolumeSet) and ops.SdfTrainStep.supported(self, packed.n)):
+            return None
+        ws, bs = self.effective_weights()
+        return ops.SdfTrainStep(ws, bs, volumes, packed)
+
     @torch.enable_grad()
     def sdf_gradient_smooth(self, x, volumes):
         """-> (sdf (N,1), d sdf/dx (N,3), d(sum_k d sdf/dx_k)/dx (N,3)) from ONE forward pass.  The reference evaluates the network twice

@@ -777,6 +777,120 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# K17  the SDF network of a training step: value, gradient, `smooth`, and the loss backward   (sdf_network.py:98-154)
+# ------------------------------------------------------------------------------------------------------------------
+class SdfTrainStep:
+    """One training / fine-tune step's view of the SDF network (gens_sdf_train_*): the effective (weight-normed) matrices are packed
+    into MFMA B streams ONCE, then any number of point batches are evaluated against them.
+
+        step = SdfTrainStep(weights, biases, volumes, packed)      # weights[l] (out_l, in_l) with autograd history, l = 0..6
+        y, g, s = step(pts)                                         # (N,1), (N,3), (N,3); differentiable once more (loss.backward())
+        g0 = step.first_order(pts0)                                 # d sdf / dx only, no graph (implicit_surface.py:305-310)
+
+    `volumes`: the planar (1,4,X,Y,Z) tensors the gradient goes to; `packed`: their (X,Y,Z,4) texel copy the kernels read."""
+
+    @staticmethod
+    def supported(net, n_levels):
+        return SdfMlpPlan.supported(net) and float(net.scale) == 1.0 and n_levels in (3, 5) and net.init_feat_channels == 4 * n_levels
+
+    def __init__(self, weights, biases, volumes, packed):
+        assert len(weights) == 7 and len(biases) == 7
+        assert isinstance(packed, VolumeSet) and packed.layout == L.LAYOUT_PACKED and packed.n in (3, 5)
+        self.weights, self.biases, self.volumes, self.packed = list(weights), list(biases), list(volumes), packed
+        self.n_levels = packed.n
+        dev = weights[0].device
+        kin = 128 + 20 * self.n_levels
+        self.kp = (kin + 1 + 7) // 8 * 8
+        gf = [(27 + 1 + 7) // 8] + [self.kp // 8] * 5
+        ntb = [1] + [(kin + 31) // 32] * 5
+        with torch.no_grad():
+            w = [_c(t.detach().to(_f32)) for t in weights[:6]]
+            b = [_c(t.detach().to(_f32)) for t in biases[:6]]
+            assert tuple(w[0].shape) == (128, 27) and tuple(w[2].shape) == (101, kin) and tuple(w[5].shape) == (128, kin)
+            self.wf = [torch.empty(4 * g * 64 * 4, device=dev, dtype=_f32) for g in gf]
+            self.wb = [torch.empty(nt * 16 * 64 * 4, device=dev, dtype=_f32) for nt in ntb]
+            self.wf_table, self.wb_table = L.ptr_table(self.wf), L.ptr_table(self.wb)
+            L.call("gens_sdf_train_pack", L.ptr_table(w), L.ptr_table(b), self.n_levels, self.wf_table, self.wb_table, L.stream())
+            self.w_last = _c(weights[6].detach().to(_f32)[0].clone())
+            self.b_last = _c(biases[6].detach().to(_f32)[:1].clone())
+
+    def _forward(self, pts):
+        n = pts.shape[0]
+        dev = pts.device
+        stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 0), device=dev, dtype=torch.uint8)
+        y, g, s = (torch.empty(n, k, device=dev, dtype=_f32) for k in (1, 3, 3))
+        fe = 20 * self.n_levels
+        flops = 4 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))
+        L.call("gens_sdf_train_fwd", self.packed.table, self.packed.dim_table, self.n_levels, self.wf_table, self.wb_table, L.ptr(self.w_last),
+               L.ptr(self.b_last), L.ptr(pts), n, L.ptr(stash, torch.uint8), L.ptr(y), L.ptr(g), L.ptr(s), L.stream(), nbytes=n * 40,
+               flops=n * flops)
+        return y, g, s
+
+    def __call__(self, pts):
+        return _SdfTrain.apply(_c(pts.detach().reshape(-1, 3).to(_f32)), self, *self.weights, *self.biases, *self.volumes)
+
+    @torch.no_grad()
+    def first_order(self, pts):
+        return self._forward(_c(pts.detach().reshape(-1, 3).to(_f32)))[1]
+
+
+class _SdfTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, step, *tensors):
+        ctx.step = step
+        ctx.save_for_backward(pts)
+        ctx.shapes = [t.shape for t in tensors]
+        return step._forward(pts)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, y_bar, g_bar, s_bar):
+        step = ctx.step
+        pts, = ctx.saved_tensors
+        n, dev = pts.shape[0], pts.device
+        nl = step.n_levels
+        cf, fe, kin = 4 * nl, 20 * nl, 128 + 20 * nl
+        fep = step.kp - 128
+        npad = (n + 31) // 32 * 32
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
+        lop, rh, re, r0 = f(4, npad, 6, 128), f(6, 4, npad, 128), f(4, npad, fep), f(4, npad, 32)
+        f_hat, mu_f, lam_f = f(npad, cf), f(npad, cf), f(npad, cf)
+        stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 1), device=dev, dtype=torch.uint8)
+        cot = [None if t is None else _c(t.to(_f32)) for t in (y_bar, g_bar, s_bar)]
+        flops = 8 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))
+        L.call("gens_sdf_train_bwd", step.packed.table, step.packed.dim_table, nl, step.wf_table, step.wb_table, L.ptr(step.w_last), L.ptr(pts), n,
+               L.ptr(cot[0]), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(stash, torch.uint8), L.ptr(lop), L.ptr(rh), L.ptr(re), L.ptr(r0), L.ptr(f_hat),
+               L.ptr(mu_f), L.ptr(lam_f), L.stream(), nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)), flops=n * flops)
+        # weight gradients: sums over the 4 * npad operand rows (rows of padding points are zero on one side of every product)
+        l4 = lop.view(4 * npad, 768)
+        e_all = matmul_tn(l4, re.view(4 * npad, fep))                       # (768, fep): conditioning columns + bias of every layer
+        w0 = matmul_tn(_c(l4[:, :128]), r0.view(4 * npad, 32))              # (128, 32)
+        g_w, g_b = [w0[:, :27]], [e_all[:128, fe]]
+        for l in range(1, 6):
+            h = matmul_tn(_c(l4[:, 128 * l:128 * (l + 1)]), rh[l - 1].view(4 * npad, 128))
+            rows = 101 if l == 2 else 128
+            g_w.append(torch.cat([h, e_all[128 * l:128 * (l + 1), :fe]], 1)[:rows])
+            g_b.append(e_all[128 * l:128 * l + rows, fe])
+        yb = torch.zeros(1, npad, device=dev, dtype=_f32)
+        if cot[0] is not None:
+            yb[0, :n] = cot[0].reshape(-1)
+        w6 = torch.zeros(ctx.shapes[6], device=dev, dtype=_f32)
+        w6[0, :128] = (yb @ rh[5, 0])[0] + rh[5, 2].sum(0)
+        w6[0, 128:] = ((yb @ re[0])[0] + re[2].sum(0))[:fe]
+        b6 = torch.zeros(ctx.shapes[13], device=dev, dtype=_f32)
+        b6[0] = yb.sum()
+        g_w.append(w6)
+        g_b.append(b6)
+        # volume gradients
+        g_vols = [None] * nl
+        if any(ctx.needs_input_grad[2 + 14:]):
+            g_vols = [torch.zeros(s, device=dev, dtype=_f32) for s in ctx.shapes[14:]]
+            L.call("gens_sdf_train_scatter", step.packed.dim_table, nl, L.ptr(pts), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(f_hat), L.ptr(mu_f),
+                   L.ptr(lam_f), n, L.ptr_table(g_vols), L.stream(), nbytes=n * (36 + 3 * 4 * cf))
+        return (None, None, *g_w, *g_b, *g_vols)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # K14  a^T b for tall operands: the weight-gradient product of the training step
 # ------------------------------------------------------------------------------------------------------------------
 MATMUL_TN_MIN_ROWS = 8192      # below this the library GEMM is as good

@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 3 */
+int gens_abi_version(void);   /* 4 */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -220,6 +220,42 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
                      const void* const* wf_lo, const float* const* bias, const void* const* wb_hi, const void* const* wb_lo,
                      const float* w_last, float b_last, float scale, const float* pts, const int64_t* index, int64_t n,
                      const int32_t* n_device, float* sdf_out, float* grad_out, int* overflow_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K17  the SDF network of a training / fine-tune step: value, gradient, `smooth` vector and the loss backward
+ *      (sdf_network.py:98-154: SDFNetwork.sdf, SDFNetwork.gradient with create_graph twice; their autograd backward under
+ *      loss.backward(); call sites implicit_surface.py:179-191,257,305,490; sampler Function pair cuda_gridsample.py:71-123,
+ *      whose second-backward outputs are constants in the loss backward: third order through the sampler is dropped)
+ *   Architecture and n_levels as gens_sdf_mlp, scale = 1 (confs/gens.conf:78).  All buffers are caller-allocated device memory.
+ *   gens_sdf_train_pack: w[0..5] / b[0..5]: HOST arrays of device pointers to the EFFECTIVE (weight norm applied) row-major
+ *     matrices (128 x 27, 128 x K, 101 x K, 128 x K x 3; K = 128 + 20 n_levels) and biases of lin0..lin5; writes the forward /
+ *     transposed B streams wf[l] ([4][ceil((K_l + 1) / 8)][64] float4, bias in reduction row K_l) and wb[l] ([ceil(K_l / 32)][16][64]
+ *     float4) that the other entry points (and gens_sdf_mlp) read.
+ *   gens_sdf_train_fwd: pts (n, 3) -> y (n), g (n, 3) = dy/dx, s (n, 3) = d(sum_k g_k)/dx.  w_last: row 0 of lin6 (K floats),
+ *     b_last: DEVICE pointer to its bias.  stash: scratch of gens_sdf_train_stash_bytes(n, 0) bytes.
+ *   gens_sdf_train_bwd: cotangents y_bar (n), g_bar (n, 3), s_bar (n, 3) (NULL = zero) -> operand rows of the weight-gradient
+ *     products, npad = 32 ceil(n / 32) rows each (rows >= n contribute zero):
+ *       lop (4, npad, 6, 128), rh (6, 4, npad, 128), re (4, npad, KP - 128), r0 (4, npad, 32), KP = 8 ceil((K + 1) / 8):
+ *       dL/dW_l[:, :128]  = sum_q lop[q, :, l, :]^T rh[l - 1, q]        (l = 1..5; layer 3's columns are [h_2 | pe] / sqrt 2)
+ *       dL/dW_l[:, 128:K] , dL/db_l = sum_q lop[q, :, l, :]^T re[q]      (column K - 128 of re is the bias input)
+ *       dL/dW_0, dL/db_0  = sum_q lop[q, :, 0, :]^T r0[q]               (column 27 = bias input)
+ *       dL/dw_last = y_bar^T [rh[5, 0] | re[0]] + column sums of [rh[5, 2] | re[2]]
+ *     and f_hat, mu_f, lam_f (npad, 4 n_levels) for gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
+ *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
+ *       w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lam_f per corner  (float atomics).
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t gens_sdf_train_stash_bytes(int64_t n, int backward);
+int gens_sdf_train_pack(const float* const* w, const float* const* b, int n_levels, float* const* wf, float* const* wb, void* stream);
+int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                       const float* const* wb, const float* w_last, const float* b_last, const float* pts, int64_t n,
+                       void* stash, float* y_out, float* g_out, float* s_out, void* stream);
+int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                       const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
+                       const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
+                       float* f_hat, float* mu_f, float* lam_f, void* stream);
+int gens_sdf_train_scatter(const int* dims, int n_levels, const float* pts, const float* g_bar, const float* s_bar,
+                           const float* f_hat, const float* mu_f, const float* lam_f, int64_t n, float* const* g_vols,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K7  lookup_feature + BlendingNetwork.forward fused, inference only

@@ -108,6 +108,7 @@ def test_lean_validation_path_equals_full_render(golden):
     feats, vols, masks, match, step = scene_inputs(g)
     c = lambda t: t.cuda()  # noqa: E731
     args = (c(g["rays_o"]), c(g["rays_d"]), c(g["z_final"]), 2.0 / 64, vols, masks, feats, match, c(g["imgs"]), c(g["intrs"]), c(g["c2ws"]), 1.0, step)
+    surf.fused_train = False                      # `full` on the PyTorch layers, so that the last comparison below is like for like
     full = surf.render_core(*args)
     with torch.no_grad():
         lean = surf.render_core(*args, lean=True)
