@@ -104,3 +104,142 @@ extern "C" int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, in
     }
     return gens_launch_status("gens_gemm_tn");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched, strided form: up to GEMM_TN_MAX_BATCH products C_p (m_p x n_p) = A_p^T B_p over the SAME K rows in ONE launch, operands
+// given with leading dimensions (column blocks of wider row-major buffers: no copies).  The weight-gradient products of the fused
+// training-mode SDF network (K17: seven products over 4 x points rows).  A unit = (slab, tile of one product); consecutive units
+// are the tiles of one slab, so the rows a slab's tiles share are served by L2.  Results: the C_p concatenated in one vector.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define GEMM_TN_MAX_BATCH 8
+struct GemmTnBatch {
+    const float* a[GEMM_TN_MAX_BATCH];
+    const float* b[GEMM_TN_MAX_BATCH];
+    int lda[GEMM_TN_MAX_BATCH], ldb[GEMM_TN_MAX_BATCH], m[GEMM_TN_MAX_BATCH], n[GEMM_TN_MAX_BATCH];
+    int tile0[GEMM_TN_MAX_BATCH + 1];      // first tile of product p in the per-slab tile list
+    int64_t off[GEMM_TN_MAX_BATCH];        // offset of C_p in the concatenated result
+    int count;
+    int64_t csz;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int tiles = B.tile0[B.count];
+    const int64_t s = unit / tiles;
+    int t = (int)(unit % tiles);
+    int p = 0;
+    while (p + 1 < B.count && t >= B.tile0[p + 1]) ++p;
+    t -= B.tile0[p];
+    const int m = B.m[p], n = B.n[p], lda = B.lda[p], ldb = B.ldb[p];
+    const int nt = (n + 31) >> 5;
+    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int m0 = (t / nt) << 5, n0 = (t % nt) << 5;
+    const bool am = m0 + i < m, bn = n0 + i < n;
+    const float* ap = B.a[p] + (k_begin + h) * lda + (am ? m0 + i : 0);
+    const float* bp = B.b[p] + (k_begin + h) * ldb + (bn ? n0 + i : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    int64_t k = k_begin;
+    for (; k + 16 <= k_end; k += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            av[q] = ap[(int64_t)(2 * q) * lda];
+            bv[q] = bp[(int64_t)(2 * q) * ldb];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(am ? av[q] : 0.0f, bn ? bv[q] : 0.0f, acc, 0, 0, 0);
+        ap += 16 * (int64_t)lda;
+        bp += 16 * (int64_t)ldb;
+    }
+    for (; k < k_end; k += 2) {
+        const bool row = k + h < k_end;
+        const float av = (am && row) ? ap[0] : 0.0f, bv = (bn && row) ? bp[0] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        ap += 2 * (int64_t)lda;
+        bp += 2 * (int64_t)ldb;
+    }
+    if (bn) {
+        float* w = ws + s * B.csz + B.off[p];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < m) w[(int64_t)row * n + n0 + i] = acc[r];
+        }
+    }
+}
+
+static int64_t gemm_tn_batch_slab(int64_t k, int64_t tiles) {
+    int64_t slab = (k * tiles + 8191) / 8192;
+    slab = (slab + 15) / 16 * 16;
+    return slab < 64 ? 64 : slab;
+}
+
+static int gemm_tn_batch_layout(int count, const int* m, const int* n, int64_t* tiles, int64_t* csz) {
+    *tiles = 0;
+    *csz = 0;
+    if (count <= 0 || count > GEMM_TN_MAX_BATCH || !m || !n) return -1;
+    for (int p = 0; p < count; ++p) {
+        if (m[p] <= 0 || n[p] <= 0 || m[p] > 1024 || n[p] > 1024) return -1;
+        *tiles += (int64_t)((m[p] + 31) / 32) * ((n[p] + 31) / 32);
+        *csz += (int64_t)m[p] * n[p];
+    }
+    return 0;
+}
+
+// floats of workspace a gens_gemm_tn_batch call needs
+extern "C" int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const int* n, int64_t k) {
+    int64_t tiles, csz;
+    if (k <= 0 || gemm_tn_batch_layout(count, m, n, &tiles, &csz)) return 0;
+    const int64_t slab = gemm_tn_batch_slab(k, tiles);
+    return ((k + slab - 1) / slab + GEMM_TN_GROUPS) * csz;
+}
+
+extern "C" int gens_gemm_tn_batch(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                                  const int* n, int64_t k, float* workspace, float* c, void* stream) {
+    int64_t tiles, csz;
+    GENS_CHECK_ARG(a && lda && b && ldb && workspace && c, GENS_EINVAL, "gens_gemm_tn_batch: null pointer");
+    GENS_CHECK_ARG(k > 0 && gemm_tn_batch_layout(count, m, n, &tiles, &csz) == 0, GENS_ELIMIT,
+                   "gens_gemm_tn_batch: 1 <= count <= %d products with 1 <= m, n <= 1024 and k > 0", GEMM_TN_MAX_BATCH);
+    GemmTnBatch B;
+    B.count = count;
+    B.csz = csz;
+    int t0 = 0;
+    int64_t off = 0;
+    for (int p = 0; p < GEMM_TN_MAX_BATCH; ++p) {
+        const bool live = p < count;
+        GENS_CHECK_ARG(!live || (a[p] && b[p] && lda[p] >= m[p] && ldb[p] >= n[p]), GENS_EINVAL, "gens_gemm_tn_batch: product %d: null operand or leading dimension too small", p);
+        B.a[p] = live ? a[p] : nullptr;
+        B.b[p] = live ? b[p] : nullptr;
+        B.lda[p] = live ? lda[p] : 0;
+        B.ldb[p] = live ? ldb[p] : 0;
+        B.m[p] = live ? m[p] : 0;
+        B.n[p] = live ? n[p] : 0;
+        B.tile0[p] = t0;
+        B.off[p] = off;
+        if (live) {
+            t0 += ((m[p] + 31) / 32) * ((n[p] + 31) / 32);
+            off += (int64_t)m[p] * n[p];
+        }
+    }
+    B.tile0[GEMM_TN_MAX_BATCH] = t0;
+    for (int p = count; p <= GEMM_TN_MAX_BATCH; ++p) B.tile0[p] = t0;
+    const int64_t slab = gemm_tn_batch_slab(k, tiles);
+    const int n_slabs = (int)((k + slab - 1) / slab);
+    const int64_t units = (int64_t)n_slabs * tiles;
+    hipStream_t s = (hipStream_t)stream;
+    gemm_tn_batch_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+    if (n_slabs <= GEMM_TN_GROUPS) {
+        gemm_tn_reduce_k<<<dim3(gens_blocks(csz, 256), 1), 256, 0, s>>>(workspace, n_slabs, n_slabs, csz, c);
+    } else {
+        const int per = (n_slabs + GEMM_TN_GROUPS - 1) / GEMM_TN_GROUPS, groups = (n_slabs + per - 1) / per;
+        float* stage = workspace + (int64_t)n_slabs * csz;
+        gemm_tn_reduce_k<<<dim3(gens_blocks(csz, 256), groups), 256, 0, s>>>(workspace, n_slabs, per, csz, stage);
+        gemm_tn_reduce_k<<<dim3(gens_blocks(csz, 256), 1), 256, 0, s>>>(stage, groups, groups, csz, c);
+    }
+    return gens_launch_status("gens_gemm_tn_batch");
+}

@@ -449,6 +449,7 @@ struct SdfTrainBwdOut {
     float* f_hat;   // [npad][CF]          cotangent of the looked-up features
     float* mu_f;    // [npad][CF]
     float* lam_f;   // [npad][CF]
+    float* w6_part; // [blocks][KP]        this workgroup's share of d loss / d w_last (column K = its bias)
     int64_t npad;
 };
 
@@ -592,11 +593,20 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
             }
             float* xr = X + row * RS + col;
             xr[0] = h; xr[XT] = hd; xr[2 * XT] = hk; xr[3 * XT] = hn;
-            float* gr = rh + (int64_t)row * TR_H;
-            gr[0] = h; gr[npad * TR_H] = hd; gr[2 * npad * TR_H] = hk; gr[3 * npad * TR_H] = hn;
+            if (l < 5) {   // (the inputs of the output row stay in LDS: its weight gradient is summed below)
+                float* gr = rh + (int64_t)row * TR_H;
+                gr[0] = h; gr[npad * TR_H] = hd; gr[2 * npad * TR_H] = hk; gr[3 * npad * TR_H] = hn;
+            }
             st[r * 64] = keep;
         }
         __syncthreads();
+    }
+
+    // d loss / d w_last = sum_points y_bar z_6 + kappa_z6 (the constant-1 column gives the bias): this workgroup's 32 points in row order
+    if (tid < KP) {
+        float s = 0.0f;
+        for (int row = 0; row < TR_M; ++row) s += YB[row] * X[row * RS + tid] + X[2 * XT + row * RS + tid];
+        O.w6_part[(int64_t)blockIdx.x * KP + tid] = s;
     }
 
     // ------------------------------------------------------------------ reverse sweeps: omega, rho, lambda, mu
@@ -886,17 +896,17 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
 extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
                                   const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
                                   const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
-                                  float* f_hat, float* mu_f, float* lam_f, void* stream) {
+                                  float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_train_bwd", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_bwd: built for 3 or 5 volume levels, got %d", n_levels);
     SdfTrainWeights W;
     if (int e = fill_train_weights("gens_sdf_train_bwd", &W, wf, wb, w_last, nullptr)) return e;
-    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && lop && rh && re && r0 && f_hat && mu_f && lam_f)), GENS_EINVAL,
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && lop && rh && re && r0 && f_hat && mu_f && lam_f && w6_part)), GENS_EINVAL,
                    "gens_sdf_train_bwd: null pts / stash / output");
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, TR_M);
-    SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, (int64_t)grid * TR_M};
+    SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, w6_part, (int64_t)grid * TR_M};
     hipStream_t s = (hipStream_t)stream;
     if (n_levels == 3) {
         static bool once = false;

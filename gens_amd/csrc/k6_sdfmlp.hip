@@ -37,6 +37,7 @@ struct SdfMlpWeights {
     const float4* wb[MLP_NLAYER];  // backward B groups [n_tile][16][64]; wb[0]: 1 tile (27 -> 32 columns)
     const float* w_last;           // (128 + FE) row 0 of layer 6
     float b_last;
+    const float* b_last_dev;       // when non-null: the bias is read from the device (training: weights change every step, no host read-back)
     float inv_scale;               // 1 / scale  (sdf_network.py:123)
     float scale;
 };
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
     if (tid < MLP_M) {
         const int64_t row = m0 + tid;
         if (row < n) {
-            float s = W.b_last;
+            float s = W.b_last_dev ? W.b_last_dev[0] : W.b_last;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += RED[tid * 8 + k];
             sdf_out[index ? index[row] : row] = s * W.inv_scale;
@@ -373,10 +374,30 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
+static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                          const float* const* wb, const float* w_last, float b_last, const float* b_last_dev, float scale,
+                          const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                          void* stream);
+
 extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
                             const float* const* wb, const float* w_last, float b_last, float scale,
                             const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                             void* stream) {
+    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, b_last, nullptr, scale, pts, index, n, n_device, sdf_out, grad_out, stream);
+}
+
+extern "C" int gens_sdf_mlp_dev(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                                const float* const* wb, const float* w_last, const float* b_last_dev, float scale,
+                                const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                                void* stream) {
+    GENS_CHECK_ARG(b_last_dev, GENS_EINVAL, "gens_sdf_mlp_dev: null bias pointer");
+    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, 0.0f, b_last_dev, scale, pts, index, n, n_device, sdf_out, grad_out, stream);
+}
+
+static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                          const float* const* wb, const float* w_last, float b_last, const float* b_last_dev, float scale,
+                          const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                          void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_mlp", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp: built for 3 or 5 volume levels, got %d", n_levels);
@@ -392,6 +413,7 @@ extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, in
     }
     W.w_last = w_last;
     W.b_last = b_last;
+    W.b_last_dev = b_last_dev;
     W.scale = scale;
     W.inv_scale = 1.0f / scale;
     unsigned grid = gens_blocks(n, MLP_M);

@@ -51,7 +51,7 @@ class Scene:
         """Row-major inverse of the reference camera's rotation (implicit_surface.py:242,245) as 9 host floats, read back once
         per scene (the compositing kernel takes it by value)."""
         if self._rot is None:
-            self._rot = torch.linalg.inv(self.c2ws[0][:3, :3].to(torch.float32)).reshape(-1).tolist()
+            self._rot = ops.inv(self.c2ws[0][:3, :3].to(torch.float32)).reshape(-1).tolist()
         return self._rot
 
     def volumes_nograd(self):
@@ -172,15 +172,24 @@ class ImplicitSurface(nn.Module):
         return self._blend_plan if self._blend_plan.n_feat == 3 + 4 * len(views.feat_tex) else None
 
     def _precision(self, plan):
-        return "f16x2" if (self.sdf_precision == "f16x2" and plan.f16_ok) else "f32"
+        return "f16x2" if (self.sdf_precision == "f16x2" and getattr(plan, "f16_ok", False)) else "f32"
+
+    def _train_net(self, scene, lean=False):
+        """This step's fused SDF evaluator (ops.SdfTrainStep: the effective weights packed once for the sampling passes, render_core
+        and the backward), or None outside training / for architectures the K17 kernels do not cover."""
+        if lean or not self.fused_train or not torch.is_grad_enabled():
+            return None
+        if not any(p.requires_grad for p in self.sdf_network.parameters()) and not any(v.requires_grad for v in scene.volumes):
+            return None
+        return self.sdf_network.train_step(scene.volumes, scene.volumes_nograd())
 
     def _split_half_overflowed(self):
         """True if a split-half launch met a value outside the half range since the last check (one device sync)."""
         return self.sdf_precision == "f16x2" and self._sdf_plan is not None and self._sdf_plan.overflowed()
 
-    def _masked_sdf(self, pts, valid, volumes):
+    def _masked_sdf(self, pts, valid, volumes, net=None):
         sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
-        plan = self._fused_plan(volumes)
+        plan = net if net is not None else self._fused_plan(volumes)
         if plan is not None:              # compaction + count stay on the device: no host synchronisation
             idx, count = ops.compact_valid(valid)
             ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf, precision=self._precision(plan), count=count)
@@ -210,11 +219,11 @@ class ImplicitSurface(nn.Module):
         return ops.tv_regularization(list(volume_feat_cas), list(volume_mask_cas))
 
     @torch.no_grad()
-    def _sample_rays(self, rays_o, rays_d, z_vals, scene):
+    def _sample_rays(self, rays_o, rays_d, z_vals, scene, net=None):
         masks, vols = scene.masks, scene.volumes_nograd()
         b = rays_o.shape[0]
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, masks)
-        sdf = self._masked_sdf(pts, valid, vols).reshape(b, -1)
+        sdf = self._masked_sdf(pts, valid, vols, net).reshape(b, -1)
         n_new = self.n_importance // self.up_sample_steps
         valid = valid.reshape(b, -1)                       # mask decisions travel with the samples through the merges
         for i in range(self.up_sample_steps):
@@ -222,7 +231,7 @@ class ImplicitSurface(nn.Module):
             if i + 1 == self.up_sample_steps:
                 z_vals, _ = ops.merge_samples(z_vals, z_new)
             else:
-                sdf_new = self._masked_sdf(pts_new, valid_new, vols).reshape(b, n_new)
+                sdf_new = self._masked_sdf(pts_new, valid_new, vols, net).reshape(b, n_new)
                 z_vals, sdf, valid = ops.merge_samples(z_vals, z_new, sdf, sdf_new, valid, valid_new)
         return z_vals
 
@@ -230,7 +239,7 @@ class ImplicitSurface(nn.Module):
     # render_core
     # ----------------------------------------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None, extra_pts=None):
+                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None, extra_pts=None, net=None):
         """Everything after sampling (:152-349).  `lean` (validate only) skips the quantities validate discards:
         second derivatives, random-point SDF, TV, the surface-point gradient and the patch warp.
         extra_pts: more points whose SDF the caller wants from the same network pass (forward()'s pseudo points, :484-497):
@@ -245,9 +254,8 @@ class ImplicitSurface(nn.Module):
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
         plan = self._fused_plan(vols) if lean else None
         bplan = self._fused_blend_plan(scene.views) if lean else None
-        net = None                                     # training: one fused evaluator for every SDF query of this step
-        if not lean and self.fused_train and torch.is_grad_enabled():
-            net = self.sdf_network.train_step(scene.volumes, scene.volumes_nograd())
+        if net is None:                                # training: one fused evaluator for every SDF query of this step
+            net = self._train_net(scene, lean)
         sdf_random = extra_sdf = None
         if plan is not None and bplan is not None:     # fully fused inference: nothing in this branch synchronises with the host
             idx, count = ops.compact_valid(valid)
@@ -369,10 +377,11 @@ class ImplicitSurface(nn.Module):
                 t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
             z_vals = z_vals + (t_rand.to(dev, non_blocking=True) - 0.5) * 2.0 / self.n_samples
         z_vals = z_vals.contiguous()
+        net = self._train_net(scene, lean)
         if self.n_importance > 0:
-            z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene)
+            z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene, net)
         return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts)
+                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts, net=net)
 
     # ----------------------------------------------------------------------------------------------------------
     # geometry + validation

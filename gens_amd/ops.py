@@ -21,6 +21,12 @@ def _dev_f32(t, device):
     return _c(t.to(device=device, dtype=_f32))
 
 
+def inv(a):
+    """torch.linalg.inv without its error check: the same LU solve, but the `info` read-back of linalg.inv is a device-to-host copy
+    that drains the stream (three of them per training step: camera poses, intrinsics, the reference rotation)."""
+    return torch.linalg.inv_ex(a).inverse
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # texel layout (NHWC, channels padded to a multiple of 4)
 # ------------------------------------------------------------------------------------------------------------------
@@ -176,7 +182,7 @@ class _VolumeBuildLevels(torch.autograd.Function):
 def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
     """features: list of (nv,4,H_i,W_i) NCHW -> (volumes [(1,8,D,D,D)], masks [(1,1,D,D,D)]).  One launch for all levels."""
     dev = features[0].device
-    w2c = _dev_f32(torch.linalg.inv(c2ws.to(_f32)), dev)
+    w2c = _dev_f32(inv(c2ws.to(_f32)), dev)
     intr = _dev_f32(intrs, dev)
     ks = []
     for lvl in range(len(dims)):
@@ -363,7 +369,7 @@ class SceneViews:
         dev = imgs.device
         self.nv = imgs.shape[0]
         self.c2w = _dev_f32(c2ws, dev)
-        self.w2c = _c(torch.linalg.inv(self.c2w))
+        self.w2c = _c(inv(self.c2w))
         self.intr = _dev_f32(intrs, dev)
         self.imgs_tex = pack_nchw(imgs.to(_f32))
         self.feat_tex = [pack_nchw(f.to(_f32)) for f in features]
@@ -500,7 +506,7 @@ def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, vox
     b, n = z.shape
     # R_ref^-1 (implicit_surface.py:242,245) travels by value in the launch block; a list from Scene.ref_rotation() avoids the
     # device->host read (a synchronisation) on every ray chunk
-    rot = c2w_ref if isinstance(c2w_ref, (list, tuple)) else torch.linalg.inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()
+    rot = c2w_ref if isinstance(c2w_ref, (list, tuple)) else inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()
     z = _c(z.detach().to(_f32))
     z_max = z.max().reshape(1)                                                  # implicit_surface.py:301
     vm = _c(voxel_mask.reshape(b * n).to(torch.uint8))
@@ -763,6 +769,11 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     fe = 20 * plan.n_levels
     flops = 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1)) * (2 if want_grad else 1)
     nbytes = n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0))
+    if isinstance(plan, SdfTrainStep):           # this training step's streams (gens_sdf_train_pack): same layout, bias on the device
+        L.call("gens_sdf_mlp_dev", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
+               L.ptr(plan.b_last), 1.0, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
+               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n))
+        return (sdf_out, grad_out) if want_grad else sdf_out
     if precision == "f16x2":
         assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
         L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
@@ -853,32 +864,41 @@ class _SdfTrain(torch.autograd.Function):
         fep = step.kp - 128
         npad = (n + 31) // 32 * 32
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
-        lop, rh, re, r0 = f(4, npad, 6, 128), f(6, 4, npad, 128), f(4, npad, fep), f(4, npad, 32)
-        f_hat, mu_f, lam_f = f(npad, cf), f(npad, cf), f(npad, cf)
+        lop, rh, re, r0 = f(4, npad, 6, 128), f(5, 4, npad, 128), f(4, npad, fep), f(4, npad, 32)
+        f_hat, mu_f, lam_f, w6p = f(npad, cf), f(npad, cf), f(npad, cf), f(npad // 32, step.kp)
         stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 1), device=dev, dtype=torch.uint8)
         cot = [None if t is None else _c(t.to(_f32)) for t in (y_bar, g_bar, s_bar)]
         flops = 8 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))
         L.call("gens_sdf_train_bwd", step.packed.table, step.packed.dim_table, nl, step.wf_table, step.wb_table, L.ptr(step.w_last), L.ptr(pts), n,
                L.ptr(cot[0]), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(stash, torch.uint8), L.ptr(lop), L.ptr(rh), L.ptr(re), L.ptr(r0), L.ptr(f_hat),
-               L.ptr(mu_f), L.ptr(lam_f), L.stream(), nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)), flops=n * flops)
-        # weight gradients: sums over the 4 * npad operand rows (rows of padding points are zero on one side of every product)
-        l4 = lop.view(4 * npad, 768)
-        e_all = matmul_tn(l4, re.view(4 * npad, fep))                       # (768, fep): conditioning columns + bias of every layer
-        w0 = matmul_tn(_c(l4[:, :128]), r0.view(4 * npad, 32))              # (128, 32)
+               L.ptr(mu_f), L.ptr(lam_f), L.ptr(w6p), L.stream(), nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)),
+               flops=n * flops)
+        # weight gradients: seven products over the 4 * npad operand rows in one launch (rows of padding points are zero on one side of
+        # every product): layer 0, the hidden parts of layers 1..5, and the conditioning columns + bias of every layer at once
+        k = 4 * npad
+        fl = 4                                                            # bytes per float
+        a_ptr = [lop.data_ptr() + fl * 128 * l for l in range(6)] + [lop.data_ptr()]
+        b_ptr = [r0.data_ptr()] + [rh.data_ptr() + fl * l * k * 128 for l in range(5)] + [re.data_ptr()]
+        ms, ns = [128] * 6 + [768], [32] + [128] * 5 + [fep]
+        mi, ni = L.int_table(ms), L.int_table(ns)
+        ws = f(L.load().gens_gemm_tn_batch_workspace(7, mi, ni, k))
+        cc = f(sum(m * n_ for m, n_ in zip(ms, ns)))
+        tab = lambda v: C.cast((C.c_void_p * len(v))(*v), C.POINTER(C.c_void_p))  # noqa: E731
+        L.call("gens_gemm_tn_batch", 7, tab(a_ptr), L.int_table([768] * 7), tab(b_ptr), L.int_table([32] + [128] * 5 + [fep]), mi, ni, k,
+               L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 * 2 + 32 + 5 * 128 + fep), flops=2 * k * sum(m * n_ for m, n_ in zip(ms, ns)))
+        w0 = cc[:128 * 32].view(128, 32)
+        hs = cc[128 * 32:128 * 32 + 5 * 128 * 128].view(5, 128, 128)
+        e_all = cc[128 * 32 + 5 * 128 * 128:].view(768, fep)
         g_w, g_b = [w0[:, :27]], [e_all[:128, fe]]
         for l in range(1, 6):
-            h = matmul_tn(_c(l4[:, 128 * l:128 * (l + 1)]), rh[l - 1].view(4 * npad, 128))
             rows = 101 if l == 2 else 128
-            g_w.append(torch.cat([h, e_all[128 * l:128 * (l + 1), :fe]], 1)[:rows])
+            g_w.append(torch.cat([hs[l - 1], e_all[128 * l:128 * (l + 1), :fe]], 1)[:rows])
             g_b.append(e_all[128 * l:128 * l + rows, fe])
-        yb = torch.zeros(1, npad, device=dev, dtype=_f32)
-        if cot[0] is not None:
-            yb[0, :n] = cot[0].reshape(-1)
+        w6s = w6p.sum(0)
         w6 = torch.zeros(ctx.shapes[6], device=dev, dtype=_f32)
-        w6[0, :128] = (yb @ rh[5, 0])[0] + rh[5, 2].sum(0)
-        w6[0, 128:] = ((yb @ re[0])[0] + re[2].sum(0))[:fe]
+        w6[0] = w6s[:kin]
         b6 = torch.zeros(ctx.shapes[13], device=dev, dtype=_f32)
-        b6[0] = yb.sum()
+        b6[0] = w6s[kin]
         g_w.append(w6)
         g_b.append(b6)
         # volume gradients

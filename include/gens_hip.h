@@ -211,6 +211,13 @@ int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels,
                  const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                  void* stream);
 
+/* gens_sdf_mlp with the output bias read from DEVICE memory (training: the weights change every step and the streams come from
+ * gens_sdf_train_pack; a by-value bias would cost a device-to-host read per step). */
+int gens_sdf_mlp_dev(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
+                     const float* const* wb, const float* w_last, const float* b_last_dev, float scale,
+                     const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
+                     void* stream);
+
 /* Same computation as gens_sdf_mlp on the f16 matrix cores with split operands: every float32 operand is an (hi, lo)
  * pair of halfs and every product is hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error, 5.3x
  * fewer matrix-pipe cycles).  wf_hi / wf_lo / wb_hi / wb_lo: HOST arrays of 6 device pointers to half fragments
@@ -235,12 +242,13 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
  *     b_last: DEVICE pointer to its bias.  stash: scratch of gens_sdf_train_stash_bytes(n, 0) bytes.
  *   gens_sdf_train_bwd: cotangents y_bar (n), g_bar (n, 3), s_bar (n, 3) (NULL = zero) -> operand rows of the weight-gradient
  *     products, npad = 32 ceil(n / 32) rows each (rows >= n contribute zero):
- *       lop (4, npad, 6, 128), rh (6, 4, npad, 128), re (4, npad, KP - 128), r0 (4, npad, 32), KP = 8 ceil((K + 1) / 8):
+ *       lop (4, npad, 6, 128), rh (5, 4, npad, 128), re (4, npad, KP - 128), r0 (4, npad, 32), KP = 8 ceil((K + 1) / 8):
  *       dL/dW_l[:, :128]  = sum_q lop[q, :, l, :]^T rh[l - 1, q]        (l = 1..5; layer 3's columns are [h_2 | pe] / sqrt 2)
  *       dL/dW_l[:, 128:K] , dL/db_l = sum_q lop[q, :, l, :]^T re[q]      (column K - 128 of re is the bias input)
  *       dL/dW_0, dL/db_0  = sum_q lop[q, :, 0, :]^T r0[q]               (column 27 = bias input)
- *       dL/dw_last = y_bar^T [rh[5, 0] | re[0]] + column sums of [rh[5, 2] | re[2]]
- *     and f_hat, mu_f, lam_f (npad, 4 n_levels) for gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
+ *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 32, KP): columns [0, K) and column K
+ *     (gens_gemm_tn_batch runs the seven products in one launch) and f_hat, mu_f, lam_f (npad, 4 n_levels) for
+ *     gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
  *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
  *       w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lam_f per corner  (float atomics).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -252,7 +260,7 @@ int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_l
 int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
                        const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
                        const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
-                       float* f_hat, float* mu_f, float* lam_f, void* stream);
+                       float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream);
 int gens_sdf_train_scatter(const int* dims, int n_levels, const float* pts, const float* g_bar, const float* s_bar,
                            const float* f_hat, const float* mu_f, const float* lam_f, int64_t n, float* const* g_vols,
                            void* stream);
@@ -348,6 +356,12 @@ int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int re
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_gemm_tn_slabs(int64_t k, int m, int n);
 int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float* workspace, float* c, void* stream);
+/* Up to 8 products C_p (m_p x n_p) = A_p^T B_p over the same k rows in one launch; A_p / B_p are column blocks of row-major buffers
+ * with leading dimensions lda[p] / ldb[p] (HOST arrays of device pointers / ints).  c: the C_p concatenated (row major each).
+ * workspace: gens_gemm_tn_batch_workspace(count, m, n, k) floats.  Partial sums are added in a fixed order (deterministic). */
+int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const int* n, int64_t k);
+int gens_gemm_tn_batch(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                       const int* n, int64_t k, float* workspace, float* c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K15  the 3 x 3 x 3 convolutions of the cost-volume U-Net (reg_network.py:7-50: nn.Conv3d(k=3, padding=1, stride 1 | 2) and
