@@ -31,7 +31,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak (same guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide)
-DOMINANT = "gens_sdf_mlp"      # the kernel the roofline object is about (asserted against the measured table)
+DOMINANT = "gens_sdf_mlp:grad"  # the kernel the roofline object is about: the fwd + d/dx launches of the fused SDF network, device kernel
+                                # sdf_mlp_k<FE, true> (asserted against the measured table).  Its value-only sibling (sdf_mlp_k<FE, false>,
+                                # profile key "gens_sdf_mlp:value") is listed beside it; the secondary workloads below never launch the
+                                # GRAD kernel at other shapes, so rocprof's per-process average of that symbol is the timed region's
 
 
 def parse():
@@ -45,8 +48,9 @@ def parse():
     p.add_argument("--views", type=int, default=5)
     p.add_argument("--cpu-rays", type=int, default=640, help="rays of the CPU-oracle baseline sample (0 = skip); ~15 s on a 128-core host")
     p.add_argument("--no-kernel-timing", action="store_true")
-    p.add_argument("--train-step", action="store_true", help="add the secondary training-step figure (N = 1; off by default so that the process's "
-                                                             "kernel statistics are those of the headline workload alone)")
+    p.add_argument("--headline-only", action="store_true", help="skip the secondary figures (training steps, validation item, five-level and "
+                                                                "split-half variants) that follow the timed region at N = 1")
+    p.add_argument("--train-step", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: the training figures are on by default now
     p.add_argument("--sdf-precision", default="f32", choices=["f32", "f16x2"],
                    help="f32: exact float32 MFMA (headline); f16x2: split-half operands on the f16 matrix cores (~1e-6 relative)")
     return p.parse_args()
@@ -66,7 +70,7 @@ def build_model(dims, device):
 def main():
     global DOMINANT
     args = parse()
-    DOMINANT = "gens_sdf_mlp" if args.sdf_precision == "f32" else "gens_sdf_mlp_f16"
+    DOMINANT = "gens_sdf_mlp:grad" if args.sdf_precision == "f32" else "gens_sdf_mlp_f16:grad"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -179,13 +183,17 @@ def main():
                 table[name]["TFLOPs"] = round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1)
         dom_name, dom = max(((n, k) for n, k in kernels.items() if k["bytes"]), key=lambda kv: kv[1]["ms"] / timed_steps[kv[0]])
         assert dom_name == DOMINANT, f"dominant kernel is {dom_name}, not {DOMINANT}: update bench.DOMINANT"
-        traffic = None      # HBM bytes per launch from the committed PMC passes (same command, ray chunk 32768): scripts/pmc_traffic.py
-        tpath = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
-        if os.path.exists(tpath) and args.chunk == 32768:
-            t = json.load(open(tpath))["kernels"].get(dom_name)
-            if t:
+        # HBM bytes per launch of the dominant entry point: from the newest committed PMC passes of THIS command (two separate rocprofv3
+        # --pmc runs, scripts/pmc_traffic.py); the file it came from is named beside the number
+        traffic = traffic_source = None
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            t = json.load(open(tpath))["kernels"].get(dom_name.split(":")[0])
+            if t and args.chunk == 32768:
                 traffic = t["traffic_bytes_per_launch_corrected"]      # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)
-        common = {"kernel": dom_name, "traffic": traffic, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                traffic_source = "profiles/" + os.path.basename(tpath) + " (mean over the entry point's launches, both device kernels)"
+                break
+        common = {"kernel": dom_name, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                   "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
         if dom.get("flops"):      # the fused MLP is matrix-core bound: price it against the dense MFMA peak of the operand type
             split = args.sdf_precision != "f32"     # split-half: every fp32 product costs three f16 products on the f16 pipe
@@ -208,7 +216,7 @@ def main():
     # f16 hi + lo pair, three f16 MFMAs per product, fp32 accumulate; ~1e-6 relative to the fp32 kernel).
     # Reported beside the headline, never as `value`.
     split = None
-    if world == 1 and args.sdf_precision == "f32" and not args.no_kernel_timing:
+    if world == 1 and args.sdf_precision == "f32" and not args.no_kernel_timing and not args.headline_only:
         surf.sdf_precision = "f16x2"
         step()
         sync()
@@ -221,24 +229,48 @@ def main():
         split = {"sdf_precision": "f16x2", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": dt * 1e3, "steps": 2,
                  "note": "opt-in arithmetic of the SDF network only; not the headline"}
 
-    # secondary figure (N = 1): one TRAINING step of BASELINE config[2] as runner.py runs it -- GenS.forward with the 2-D feature CNN, the
-    # volume build, the 3-D U-Net, 512 rays + 2048 pseudo points, a reference-like loss, backward through every kernel and Adam
-    # (scripts/train_step_bench.py --full).  Opt-in (--train-step); reported beside the headline, never as `value`.
-    train = None
-    if world == 1 and args.train_step:
-        try:
-            from scripts.train_step_bench import measure
-            torch.cuda.empty_cache()
-            ms, _ = measure(["--full", "--steps", "10", "--warm", "3"], quiet=True)
-            train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
-                                 "points, 2-D CNN + volume build + 3-D U-Net + render + loss + backward + Adam", "ms_per_step": round(ms, 2), "steps": 10,
-                     "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "note": "secondary figure; not the headline"}
-        except Exception as e:                                             # never let the secondary figure take the headline down
-            train = {"error": f"{type(e).__name__}: {e}"}
-
     cpu = None
     if world == 1 and args.cpu_rays > 0:
         cpu = cpu_baseline(args, surf, sc, vols, state["masks"], n_final)
+
+    secondary = world == 1 and not args.headline_only
+    # secondary figure (N = 1): the headline step at the SHIPPED level count (confs/gens.conf:63-67: five volume levels, sdf_mlp_k<100>)
+    levels5 = None
+    if secondary and args.sdf_precision == "f32" and len(args.dims) == 3:
+        try:
+            levels5 = five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final)
+        except Exception as e:
+            levels5 = {"error": f"{type(e).__name__}: {e}"}
+
+    # secondary figures (N = 1): TRAINING steps of BASELINE config[2] / config[4] shape -- 5 views 480x640, volume_dims [256, 128, 64], 512 rays
+    # + 2048 pseudo points, a reference-like loss, backward through every kernel, Adam (scripts/train_step_bench.py):
+    #   "full"      GenS.forward as runner.py runs it: 2-D feature CNN (twice), volume build, 3-D U-Net, render
+    #   "hot_path"  the same step without the two CNNs (features / regularised volumes are leaves): volume build + render + backward
+    #   "finetune"  per-scene fine-tune: the volumes are the parameters (no CNN, no volume build)
+    # Run after the headline's timed region and kernel table; reported beside the headline, never as `value`.
+    train = val_item = None
+    if secondary:
+        state.clear()
+        torch.cuda.empty_cache()
+        try:
+            from scripts.train_step_bench import measure
+            train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
+                                 "points, loss + backward + Adam; 10 timed steps after 3 warm-up each", "note": "secondary figures; not the headline"}
+            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("full", ["--full"])):
+                ms, _, kt = measure(flags + ["--steps", "10", "--warm", "3"], quiet=True, kernels=True)
+                train[key] = {"ms_per_step": round(ms, 2), "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "hip_kernels": kernel_rows(kt, 8)}
+                train[key]["roofline"] = kernel_roofline(kt)
+                torch.cuda.empty_cache()
+            train["ms_per_step"] = train["full"]["ms_per_step"]
+        except Exception as e:                                             # never let a secondary figure take the headline down
+            train = {"error": f"{type(e).__name__}: {e}"}
+        # secondary figure: one whole `--mode val` item (volume build, 512^3 SDF lattice, marching cubes on the device, 480x640 render)
+        try:
+            from scripts.val_full_bench import measure as val_measure
+            val_item = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in val_measure(repeats=2).items()}
+            val_item["workload"] = "BASELINE config[1] as runner.py --mode val runs it: K1 + 512^3 lattice + iso-surface + 307 200-ray render"
+        except Exception as e:
+            val_item = {"error": f"{type(e).__name__}: {e}"}
 
     line = {
         "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
@@ -251,11 +283,66 @@ def main():
                    "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
                    "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": "scenes sharded across ranks, all_gather of rendered buffers" if world > 1 else "single GPU"},
-        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "train_step": train, "hip_kernels": table,
+        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "train_step": train, "val_item": val_item,
+        "hip_kernels": table,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def kernel_rows(table, top):
+    """{entry: {launches, ms, bytes, flops}} of one step -> the `top` slowest as rows with their algorithmic rates."""
+    rows = {}
+    for name, k in sorted(table.items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        rows[name] = {"launches": k["launches"], "ms_per_step": round(k["ms"], 3)}
+        if k["ms"] > 0 and k["bytes"]:
+            rows[name]["algo_GBs"] = round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1)
+        if k["ms"] > 0 and k.get("flops"):
+            rows[name]["TFLOPs"] = round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1)
+    return rows
+
+
+def kernel_roofline(table):
+    """Roofline object of the slowest C-ABI kernel of a step that carries an algorithmic count (HIP events on the launch stream)."""
+    cand = [(n, k) for n, k in table.items() if k["ms"] > 0 and (k["bytes"] or k.get("flops"))]
+    if not cand:
+        return None
+    name, k = max(cand, key=lambda kv: kv[1]["ms"])
+    if k.get("flops"):
+        a = k["flops"] / 1e12 / (k["ms"] / 1e3)
+        return {"kernel": name, "bound": "mfma", "achieved": round(a, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(a / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 1)}
+    a = k["bytes"] / 1e9 / (k["ms"] / 1e3)
+    return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+            "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 1)}
+
+
+def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final):
+    """The headline step with the shipped five-level pyramid (volume_dims 256 / 128 / 64 / 32 / 16: sdf_mlp_k<100>): 3 timed steps."""
+    from gens_amd import synthetic
+    from gens_amd.models.modules.implicit_surface import Scene
+    dims = [256, 128, 64, 32, 16]
+    surf, volume = build_model(dims, dev)
+    surf.val_chunk = args.chunk
+    vols = [v.to(dev) for v in synthetic.make_volumes(dims, seed=100)]
+    n_rays = rays_o.shape[0]
+
+    def step():
+        with torch.no_grad():
+            _, masks = volume.agg_mean_var(feats, intrs, c2ws)
+            scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
+            surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, (1, n_rays), extract_geometry=False,
+                          scene=scene)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    return {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
+            "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
 
 
 def cpu_baseline(args, surf, sc, vols, masks, n_final):

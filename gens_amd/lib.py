@@ -161,15 +161,17 @@ def profile_end(raw=False):
     return out
 
 
-def call(name, *args, nbytes=0, flops=0, live=None):
-    """Invoke one C-ABI entry point; `nbytes` / `flops` = algorithmic HBM bytes / FLOPs of this launch."""
+def call(name, *args, nbytes=0, flops=0, live=None, label=None):
+    """Invoke one C-ABI entry point; `nbytes` / `flops` = algorithmic HBM bytes / FLOPs of this launch.
+    label: key of this launch in the profile table when one entry point stands for several device kernels (default: name)."""
     lib = load()
-    if _profile is not None and (_profile_only is None or name in _profile_only):
+    key = label or name
+    if _profile is not None and (_profile_only is None or key in _profile_only):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()
-        _profile.append((name, s, e, int(nbytes), int(flops), (live[0].clone(), live[1]) if live is not None else None))
+        _profile.append((key, s, e, int(nbytes), int(flops), (live[0].clone(), live[1]) if live is not None else None))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -136,7 +136,7 @@ class _VolumeBuild(torch.autograd.Function):
         nv, h, w, _ = feat_tex.shape
         g = torch.zeros_like(feat_tex)
         L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
-               L.stream())
+               L.stream(), nbytes=2 * nv * h * w * 16 + 32 * d ** 3)
         return g, None, None, None, None, None
 
 
@@ -174,7 +174,8 @@ class _VolumeBuildLevels(torch.autograd.Function):
                 continue
             nv, h, w, _ = texs[l].shape
             g = torch.zeros_like(texs[l])
-            L.call("gens_volume_build_bwd", L.ptr(_c(texs[l])), L.ptr(w2c), L.ptr(intrs[l]), 1.0, nv, h, w, d, L.ptr(_c(grads[l])), L.ptr(g), L.stream())
+            L.call("gens_volume_build_bwd", L.ptr(_c(texs[l])), L.ptr(w2c), L.ptr(intrs[l]), 1.0, nv, h, w, d, L.ptr(_c(grads[l])), L.ptr(g), L.stream(),
+                   nbytes=2 * nv * h * w * 16 + 32 * d ** 3)      # texels read + their gradient written, 8 cotangent planes read
             out.append(g)
         return (None, None, None, *out, *([None] * n))
 
@@ -769,21 +770,24 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     fe = 20 * plan.n_levels
     flops = 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1)) * (2 if want_grad else 1)
     nbytes = n * (12 + (16 if want_grad else 4) + (8 if idx is not None else 0))
+    tag = ":grad" if want_grad else ":value"     # profile key: the two device kernels (sdf_mlp_k<FE, true / false>) are priced separately
     if isinstance(plan, SdfTrainStep):           # this training step's streams (gens_sdf_train_pack): same layout, bias on the device
         L.call("gens_sdf_mlp_dev", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
                L.ptr(plan.b_last), 1.0, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
-               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n))
+               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
+               label="gens_sdf_mlp" + tag)
         return (sdf_out, grad_out) if want_grad else sdf_out
     if precision == "f16x2":
         assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
         L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
                plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
                L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
-               flops=n * flops, live=None if count is None else (count, n))
+               flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
     else:
         L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
                plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
-               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n))
+               L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
+               label="gens_sdf_mlp" + tag)
     return (sdf_out, grad_out) if want_grad else sdf_out
 
 

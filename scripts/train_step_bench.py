@@ -15,12 +15,13 @@ from gens_amd.losses import compute_LNCC  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E402
 
 
-def measure(argv=(), quiet=False):
-    """One measurement; argv: the command-line flags below.  -> (milliseconds per step, label)"""
+def measure(argv=(), quiet=False, kernels=False):
+    """One measurement; argv: the command-line flags below.  -> (milliseconds per step, label), or with kernels=True
+    (milliseconds per step, label, {C-ABI entry: {"launches", "ms", "bytes", "flops"}} of ONE extra, untimed step)."""
     saved = sys.argv
     sys.argv = [saved[0], *argv]
     try:
-        return _measure(quiet)
+        return _measure(quiet, kernels)
     finally:
         sys.argv = saved
 
@@ -29,7 +30,7 @@ def main():
     _measure(False)
 
 
-def _measure(quiet):
+def _measure(quiet, kernels=False):
     dev = torch.device("cuda:0")
     if "--miopen-find" in sys.argv:                                     # the reference's own setting (runner.py:26): MIOpen searches per conv shape
         torch.backends.cudnn.benchmark = True
@@ -118,6 +119,11 @@ def _measure(quiet):
     label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
     if not quiet:
         print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    if kernels:
+        from gens_amd import lib as L
+        L.profile_begin()
+        step()
+        return dt * 1e3, label, L.profile_end()
     return dt * 1e3, label
 
 

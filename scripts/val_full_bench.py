@@ -12,39 +12,50 @@ from gens_amd import ops, synthetic  # noqa: E402
 from gens_amd.config import gens_model_conf  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene  # noqa: E402
 
-dev = torch.device("cuda:0")
-dims = [256, 128, 64]
-sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
-imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
-feats = [f.to(dev) for f in sc["features"]]
-vols = [v.to(dev) for v in synthetic.make_volumes(dims, seed=100)]
-ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
-ro, rd = ro.to(dev), rd.to(dev)
-near, far = sc["near"].to(dev), sc["far"].to(dev)
-torch.manual_seed(0)
-surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
-surf.val_chunk = 32768
-bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
+
+def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True):
+    """-> dict of milliseconds (last of `repeats` items): volume_build, lattice, marching_cubes, render, total; mesh sizes."""
+    dev = torch.device("cuda:0")
+    dims = list(dims)
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
+    imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
+    feats = [f.to(dev) for f in sc["features"]]
+    vols = [v.to(dev) for v in synthetic.make_volumes(dims, seed=100)]
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
+    ro, rd = ro.to(dev), rd.to(dev)
+    near, far = sc["near"].to(dev), sc["far"].to(dev)
+    torch.manual_seed(0)
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
+    surf.val_chunk = 32768
+    bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
+
+    def T():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    res = None
+    for it in range(repeats):
+        with torch.no_grad():
+            t0 = T()
+            _, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)
+            scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
+            t1 = T()
+            u = surf.sdf_grid(scene.volumes_nograd(), bmin, bmax, resolution)
+            t2 = T()
+            v, t = ops.marching_cubes(u, 0.0)
+            v, t = v.cpu(), t.cpu()
+            t3 = T()
+            surf.validate(ro, rd, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, bmin, bmax, (480, 640), extract_geometry=False, scene=scene)
+            t4 = T()
+        res = {"volume_build_ms": 1e3 * (t1 - t0), "lattice_ms": 1e3 * (t2 - t1), "lattice_Mpoints_per_s": resolution ** 3 / (t2 - t1) / 1e6,
+               "marching_cubes_ms": 1e3 * (t3 - t2), "render_ms": 1e3 * (t4 - t3), "total_ms": 1e3 * (t4 - t0), "vertices": int(v.shape[0]),
+               "triangles": int(t.shape[0])}
+        if not quiet:
+            print(f"volume build + scene {res['volume_build_ms']:.1f} ms | {resolution}^3 SDF lattice {res['lattice_ms']:.1f} ms "
+                  f"({res['lattice_Mpoints_per_s']:.0f} M points/s) | marching cubes + mesh read-back {res['marching_cubes_ms']:.1f} ms "
+                  f"({res['vertices']} vertices, {res['triangles']} triangles) | render {res['render_ms']:.1f} ms | total {res['total_ms']:.1f} ms")
+    return res
 
 
-def T():
-    torch.cuda.synchronize()
-    return time.perf_counter()
-
-
-for it in range(3):
-    with torch.no_grad():
-        t0 = T()
-        _, masks = ops.volume_build(feats[:3], intrs, c2ws, dims)
-        scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
-        t1 = T()
-        u = surf.sdf_grid(scene.volumes_nograd(), bmin, bmax, 512)
-        t2 = T()
-        v, t = ops.marching_cubes(u, 0.0)
-        v, t = v.cpu(), t.cpu()
-        t3 = T()
-        out = surf.validate(ro, rd, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, bmin, bmax, (480, 640), extract_geometry=False, scene=scene)
-        t4 = T()
-    print(f"volume build + scene {1e3 * (t1 - t0):.1f} ms | 512^3 SDF lattice {1e3 * (t2 - t1):.1f} ms ({512 ** 3 / (t2 - t1) / 1e6:.0f} M points/s) | "
-          f"marching cubes + mesh read-back {1e3 * (t3 - t2):.1f} ms ({v.shape[0]} vertices, {t.shape[0]} triangles) | render {1e3 * (t4 - t3):.1f} ms | "
-          f"total {1e3 * (t4 - t0):.1f} ms")
+if __name__ == "__main__":
+    measure(quiet=False)
