@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--views", type=int, default=5)
     p.add_argument("--cpu-rays", type=int, default=640, help="rays of the CPU-oracle baseline sample (0 = skip); ~15 s on a 128-core host")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--shard", default="scenes", choices=["scenes", "rays"],
+                   help="N > 1: 'scenes' = one scene per rank (weak scaling, the headline the driver runs); 'rays' = ONE scene whose rays are "
+                        "split across the ranks (BASELINE config 4: strong scaling), rendered buffers gathered over RCCL inside the timed region")
     p.add_argument("--headline-only", action="store_true", help="skip the secondary figures (training steps, validation item, five-level and "
                                                                 "split-half variants) that follow the timed region at N = 1")
     p.add_argument("--train-step", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: the training figures are on by default now
@@ -89,11 +92,13 @@ def main():
     L.load()
 
     h, w = 480, 640
-    sc = synthetic.make_scene(nv=args.views, h=h, w=w, n_levels=5, seed=rank)    # one scene per rank
+    by_rays = args.shard == "rays" and dist is not None
+    seed = 0 if by_rays else rank                                                  # 'rays': every rank holds the SAME scene
+    sc = synthetic.make_scene(nv=args.views, h=h, w=w, n_levels=5, seed=seed)      # 'scenes': one scene per rank
     imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
     feats = [f.to(dev) for f in sc["features"]]
     near, far = sc["near"].to(dev), sc["far"].to(dev)
-    vols = [v.to(dev) for v in synthetic.make_volumes(args.dims, seed=100 + rank)]
+    vols = [v.to(dev) for v in synthetic.make_volumes(args.dims, seed=100 + seed)]
     rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w)
     rays_o, rays_d = rays_o[:args.rays].to(dev), rays_d[:args.rays].to(dev)
     n_rays = rays_o.shape[0]
@@ -104,6 +109,10 @@ def main():
     hw = (1, n_rays)
 
     state = {}
+    shard = None
+    if by_rays:
+        from gens_amd.distributed import Shard
+        shard = Shard()
 
     def step():
         # the previous step's 690 MB of cost volumes and masks go back to the allocator BEFORE this step's are built (no second set of segments)
@@ -113,8 +122,8 @@ def main():
             cost_volumes, masks = volume.agg_mean_var(feats, intrs, c2ws)                # K1 (cost volumes feed the U-Net upstream)
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             out = surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, hw,
-                                extract_geometry=False, scene=scene)
-        if dist is not None:                                                             # config 4: gather of rendered buffers
+                                extract_geometry=False, scene=scene, shard=shard)       # shard: this rank's ray range + RCCL gather inside
+        if dist is not None and not by_rays:                                             # config 4: gather of rendered buffers
             buf = surf.last_device_image                                                 # (P, 8) rgb | normal | sdf depth | rendered depth, on the device
             gathered = torch.empty(world * buf.shape[0], buf.shape[1], device=dev, dtype=buf.dtype)
             dist.all_gather_into_tensor(gathered, buf)                                   # RCCL over xGMI, device to device
@@ -159,12 +168,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
+    # secondary figure (N > 1, headline = one scene per rank): the SAME run's strong-scaling number -- ONE scene whose rays are split
+    # across the ranks (BASELINE config 4), gather inside the timed region.  Every rank takes part (collectives), rank 0 reports.
+    ray_sharded = None
+    if dist is not None and world > 1 and not by_rays and not args.headline_only:
+        try:
+            ray_sharded = ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync)
+        except Exception as e:
+            ray_sharded = {"error": f"{type(e).__name__}: {e}"}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_ray_samples = world * n_rays * n_final * args.steps
+    total_ray_samples = (1 if by_rays else world) * n_rays * n_final * args.steps
     value = total_ray_samples / elapsed
     # sanity of the rendered buffers (a bench that renders garbage is not a bench)
     col = state["out"]["color_fine"]
@@ -275,15 +293,17 @@ def main():
     line = {
         "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if by_rays else "weak", "vs_baseline": None,
         "dtype": "f32" if args.sdf_precision == "f32" else "f32 (SDF-MLP operands as split f16 hi+lo pairs, f32 accumulate)", "data": "synthetic",
         "config": {"workload": "BASELINE config[1]: 5-view 480x640, volume_dims=%s, inference of %d rays x %d samples per scene "
                                "(K1 volume build + hierarchical sampling + SDF/blend MLPs + compositing); one scene per GPU"
                                % (args.dims, n_rays, n_final),
                    "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
                    "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
-                   "parallelism": "scenes sharded across ranks, all_gather of rendered buffers" if world > 1 else "single GPU"},
+                   "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
+                                   if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
         "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "train_step": train, "val_item": val_item,
+        "ray_sharded": ray_sharded,
         "hip_kernels": table,
     }
     print(json.dumps(line))
@@ -316,6 +336,44 @@ def kernel_roofline(table):
     a = k["bytes"] / 1e9 / (k["ms"] / 1e3)
     return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 1)}
+
+
+def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
+    """ONE scene (seed 0 on every rank), its 307 200 rays split into contiguous ranges across the ranks, K1 replicated, the rendered (P, 8)
+    buffers all-gathered over RCCL inside the timed region: whole-job ray-samples/s with the work FIXED as N grows (strong scaling)."""
+    from gens_amd import synthetic
+    from gens_amd.distributed import Shard
+    from gens_amd.models.modules.implicit_surface import Scene
+    sc = synthetic.make_scene(nv=args.views, h=480, w=640, n_levels=5, seed=0)
+    imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
+    feats = [f.to(dev) for f in sc["features"]]
+    near, far = sc["near"].to(dev), sc["far"].to(dev)
+    vols = [v.to(dev) for v in synthetic.make_volumes(args.dims, seed=100)]
+    rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
+    rays_o, rays_d = rays_o[:args.rays].to(dev), rays_d[:args.rays].to(dev)
+    n_rays = rays_o.shape[0]
+    shard = Shard()
+
+    def step():
+        with torch.no_grad():
+            _, masks = volume.agg_mean_var(feats, intrs, c2ws)
+            scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
+            surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, (1, n_rays), extract_geometry=False,
+                          scene=scene, shard=shard)
+    torch.manual_seed(4321)                    # the same CPU generator state on every rank: identical jitter for every ray
+    step()
+    sync()
+    t0 = time.perf_counter()
+    steps = 5
+    for _ in range(steps):
+        step()
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t) / steps
+    return {"scaling": "strong", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+            "n_gpus": dist.get_world_size(), "workload": "one scene, %d rays split across the ranks, all_gather of the (P, 8) buffers in the timed region" % n_rays,
+            "note": "secondary figure of the same run; `python bench.py --gpus N --shard rays` reports it as the headline"}
 
 
 def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final):

@@ -19,6 +19,19 @@ def scene_shard(n_scenes, rank, world):
     return list(range(rank, n_scenes, world))
 
 
+def _all_gather_equal(pad, group):
+    """all_gather of equally shaped buffers -> list of per-rank tensors.  On RCCL ('nccl') one all_gather_into_tensor, device to device;
+    gloo (CPU tests) has no flat form for every dtype, so it takes the list form."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        flat = torch.empty(world * pad.shape[0], *pad.shape[1:], dtype=pad.dtype, device=pad.device)
+        dist.all_gather_into_tensor(flat, pad, group=group)
+        return list(flat.reshape(world, *pad.shape).unbind(0))
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return parts
+
+
 def gather_rows(local, n_total, group=None):
     """all_gather of row-sharded (n_local, C) buffers whose shards follow `ray_shard` -> (n_total, C) on every rank."""
     world = dist.get_world_size(group)
@@ -26,8 +39,7 @@ def gather_rows(local, n_total, group=None):
     longest = -(-n_total // world)
     pad = torch.zeros(longest, *local.shape[1:], dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    parts = _all_gather_equal(pad, group)
     out = []
     for r, p in enumerate(parts):
         s, e = ray_shard(n_total, r, world)
@@ -51,17 +63,125 @@ def render_sharded(render_fn, rays_o, rays_d, jitter=None, group=None):
     return {k: gather_rows(v.reshape(v.shape[0], -1), n, group).reshape(n, *v.shape[1:]) for k, v in local.items()}
 
 
+class Shard:
+    """This process' place in a ray- / lattice-sharded evaluation of ONE scene (BASELINE config 4: "ray batches sharded across 8 x MI355X,
+    RCCL gather of rendered buffers"; the loops it splits: implicit_surface.py:407-427, 437-453).
+    `Shard.single(rank, world, sink)` is the collective-free stand-in the one-GPU tests use: shards are rendered one after the other in
+    one process and `sink` collects them."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._sink = None
+
+    @classmethod
+    def single(cls, rank, world, sink):
+        self = cls.__new__(cls)
+        self.group, self.rank, self.world, self._sink = None, rank, world, sink
+        return self
+
+    def rays(self, n_rays):
+        return ray_shard(n_rays, self.rank, self.world)
+
+    def gather_rows(self, local, n_total, key="rows"):
+        """(n_local, C) row shard -> the (n_total, C) buffer of all ranks."""
+        if self._sink is not None:
+            self._sink.setdefault(key, {})[self.rank] = local.clone()
+            if len(self._sink[key]) < self.world:
+                return None
+            return torch.cat([self._sink[key][r] for r in range(self.world)], 0)
+        return gather_rows(local, n_total, self.group)
+
+    def chunks(self, n_chunks):
+        """Lattice chunks of this rank: chunk index mod world."""
+        return list(range(self.rank, n_chunks, self.world))
+
+    def gather_chunks(self, local, n_chunks, key="chunks"):
+        """local (n_own, chunk_len): this rank's chunks in increasing index order -> (n_chunks, chunk_len) on every rank."""
+        per = -(-n_chunks // self.world)
+        pad = torch.zeros(per, local.shape[1], dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        if self._sink is not None:
+            self._sink.setdefault(key, {})[self.rank] = pad
+            if len(self._sink[key]) < self.world:
+                return None
+            parts = [self._sink[key][r] for r in range(self.world)]
+        else:
+            parts = _all_gather_equal(pad, self.group)
+        # chunk c lives at parts[c % world][c // world]
+        return torch.stack(parts, 1).reshape(per * self.world, -1)[:n_chunks]
+
+
 def allreduce_gradients(params, group=None, average=True):
     """Bucket-free gradient all-reduce for a short parameter list (fine-tune: MLPs + the volume pyramid).
-    Gradients are flattened into ONE buffer so a single large collective crosses xGMI (few, large messages)."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    Gradients are flattened into ONE buffer so a single large collective crosses xGMI (few, large messages).  Every parameter that
+    requires grad takes part -- a missing gradient (an unused head, a rank without pseudo points) counts as zeros -- so the flat layout
+    is the same on every rank whatever each rank's step touched."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, group=group)
     if average:
         flat /= dist.get_world_size(group)
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].reshape(g.shape))
-        off += g.numel()
+    for p in params:
+        g = flat[off:off + p.numel()].reshape(p.shape)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+
+
+class FlatGradients:
+    """Fine-tune data parallelism (BASELINE config 5; the reference would wrap the model in DDP, runner.py:102-105): the gradients of the
+    volume pyramid (307 MB at five levels) and the MLPs live in ONE persistent flat buffer -- `p.grad` of every parameter is a view of
+    it, so autograd accumulates straight into the communication buffer (no cat, no copy back) -- and a step's exchange is
+    reduce_scatter + all_gather on that buffer: each rank reduces 1/world of it and every byte crosses each xGMI link once, where the
+    ring all-reduce of a dense `torch.cat` copy made three more passes over the 307 MB and paid the concatenation.
+
+        flat = FlatGradients(model.get_optim_params(...)' tensors)      # once
+        loss.backward(); flat.sync(); optimizer.step(); flat.zero()      # per step (do NOT zero_grad(set_to_none=True))"""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = sum(p.numel() for p in self.params)
+        self.numel = n
+        self.padded = -(-n // world) * world
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.padded, dtype=p0.dtype, device=p0.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def attached(self):
+        """True while every parameter's .grad still is its view of the flat buffer (zero_grad(set_to_none=True) detaches them)."""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                return False
+            off += p.numel()
+        return True
+
+    def sync(self, average=True):
+        assert self.attached(), "a parameter's .grad no longer aliases the flat buffer (use FlatGradients.zero(), not zero_grad(set_to_none=True))"
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        world = dist.get_world_size(self.group)
+        shard = torch.empty(self.padded // world, dtype=self.flat.dtype, device=self.flat.device)
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(shard, self.flat, group=self.group)
+            if average:
+                shard /= world
+            dist.all_gather_into_tensor(self.flat, shard, group=self.group)
+        else:                                   # gloo (CPU tests): no reduce_scatter; same result through all_reduce
+            dist.all_reduce(self.flat, group=self.group)
+            if average:
+                self.flat /= world

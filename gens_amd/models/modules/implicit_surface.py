@@ -387,24 +387,44 @@ class ImplicitSurface(nn.Module):
     # geometry + validation
     # ----------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def sdf_grid(self, volumes, bound_min, bound_max, resolution, chunk=1 << 21):
-        """u = -sdf on the resolution^3 lattice (:407-421), kept on the device."""
+    def sdf_grid(self, volumes, bound_min, bound_max, resolution, chunk=1 << 21, shard=None):
+        """u = -sdf on the resolution^3 lattice (:407-421), kept on the device.  shard (gens_amd.distributed.Shard): this rank evaluates
+        the chunks `index mod world` and the slabs are gathered on every rank (None under Shard.single until the last shard arrives)."""
         vols = volumes if isinstance(volumes, ops.VolumeSet) else ops.VolumeSet.packed(volumes)
         dev = vols.tensors[0].device
         total = resolution ** 3
-        u = torch.empty(total, device=dev)
-        for first in range(0, total, chunk):
-            count = min(chunk, total - first)
-            pts = ops.lattice_points(bound_min.tolist(), bound_max.tolist(), resolution, first, count, dev)
-            plan = self._fused_plan(vols)
-            sdf = ops.sdf_mlp(plan, vols, pts, precision=self._precision(plan)) if plan is not None else self.sdf_network.sdf(pts, vols)
-            u[first:first + count] = -sdf[:, 0]
+        n_chunks = -(-total // chunk)
+        own = range(n_chunks) if shard is None else shard.chunks(n_chunks)
+        u = torch.zeros(len(own), chunk, device=dev) if shard is not None else torch.empty(total, device=dev)
+        split_half = None                              # a value outside the half range: the lattice again in float32, like the image
+        for attempt in range(2):
+            for k, c in enumerate(own):
+                first = c * chunk
+                count = min(chunk, total - first)
+                pts = ops.lattice_points(bound_min.tolist(), bound_max.tolist(), resolution, first, count, dev)
+                plan = self._fused_plan(vols)
+                prec = "f32" if split_half is False else self._precision(plan) if plan is not None else "f32"
+                sdf = ops.sdf_mlp(plan, vols, pts, precision=prec) if plan is not None else self.sdf_network.sdf(pts, vols)
+                if shard is not None:
+                    u[k, :count] = -sdf[:, 0]
+                else:
+                    u[first:first + count] = -sdf[:, 0]
+            if split_half is False or not self._split_half_overflowed():
+                break
+            split_half = False
+        if shard is not None:
+            u = shard.gather_chunks(u, n_chunks)
+            if u is None:
+                return None
+            u = u.reshape(-1)[:total]
         return u.reshape(resolution, resolution, resolution)
 
-    def extract_geometry(self, volumes, bound_min, bound_max, resolution, threshold):
+    def extract_geometry(self, volumes, bound_min, bound_max, resolution, threshold, shard=None):
         """-> vertices (V,3) float64, triangles (T,3) int32 as numpy arrays (implicit_surface.py:407-427).  The SDF lattice and
         the marching cubes both run on the device (the reference: 512 D2H copies + PyMCubes on the host); only the mesh is copied."""
-        u = self.sdf_grid(volumes, bound_min, bound_max, resolution)
+        u = self.sdf_grid(volumes, bound_min, bound_max, resolution, shard=shard)
+        if u is None:
+            return None, None
         vertices, triangles = ops.marching_cubes(u, threshold)
         vertices, triangles = vertices.cpu().numpy(), triangles.cpu().numpy()
         b_max, b_min = bound_max.detach().cpu().numpy(), bound_min.detach().cpu().numpy()
@@ -413,31 +433,36 @@ class ImplicitSurface(nn.Module):
 
     @torch.no_grad()
     def validate(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, bound_min, bound_max,
-                 hw, cos_anneal_ratio=1.0, step=None, extract_geometry=True, mesh_resolution=512, threshold=0.0, scene=None):
+                 hw, cos_anneal_ratio=1.0, step=None, extract_geometry=True, mesh_resolution=512, threshold=0.0, scene=None, shard=None):
+        """shard (gens_amd.distributed.Shard, optional): render only this rank's contiguous ray range and evaluate only its lattice
+        chunks; the (P, 8) image buffer / the lattice slabs are gathered over RCCL, so every rank returns the whole image.  The jitter
+        of EVERY ray is drawn on every rank from the identically seeded CPU generator (the reference's draw order) and sliced with
+        the rays: the image does not depend on the partition."""
         outputs = {}
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
         height, width = int(hw[0]), int(hw[1])
         n_rays = rays_o.shape[0]
+        r0, r1 = (0, n_rays) if shard is None else shard.rays(n_rays)
         # the jitter thread starts first: its ~1.5 ms per 32 768 rays (the reference's draw order costs 13 draws per ray) then hide behind
         # the mesh extraction, which draws nothing from the generator
         jitter = JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter")) if self.perturb > 0 else None
         if extract_geometry:
             outputs["vertices"], outputs["triangles"] = self.extract_geometry(scene.volumes_nograd(), bound_min, bound_max, mesh_resolution,
-                                                                              threshold)
+                                                                              threshold, shard=shard)
         # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
         # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
-        image = torch.empty(n_rays, 8, device=rays_o.device, dtype=torch.float32)
+        image = torch.empty(r1 - r0, 8, device=rays_o.device, dtype=torch.float32)
 
         def render_image():
-            for s in range(0, n_rays, self.val_chunk):
-                e = min(s + self.val_chunk, n_rays)
+            for s in range(r0, r1, self.val_chunk):
+                e = min(s + self.val_chunk, r1)
                 r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                                 cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
-                image[s:e, 0:3] = r["color_fine"]
-                image[s:e, 3:6] = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1)
-                image[s:e, 6] = r["sdf_depth"].reshape(-1)
-                image[s:e, 7] = r["render_depth"].reshape(-1)
+                image[s - r0:e - r0, 0:3] = r["color_fine"]
+                image[s - r0:e - r0, 3:6] = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(dim=1)
+                image[s - r0:e - r0, 6] = r["sdf_depth"].reshape(-1)
+                image[s - r0:e - r0, 7] = r["render_depth"].reshape(-1)
 
         render_image()
         if jitter is not None:
@@ -448,6 +473,10 @@ class ImplicitSurface(nn.Module):
                 render_image()
             finally:
                 self.sdf_precision = saved
+        if shard is not None:               # RCCL all_gather of the rendered buffers (config 4), device to device
+            image = shard.gather_rows(image, n_rays, key="image")
+            if image is None:               # Shard.single: the other shards have not been rendered yet
+                return None
         self.last_device_image = image      # (P, 8) [rgb | normal | sdf_depth | render_depth] on the device: what a multi-GPU driver gathers
         host = self._pinned(n_rays)
         host.copy_(image, non_blocking=True)

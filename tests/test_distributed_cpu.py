@@ -79,3 +79,71 @@ def test_sharded_render_equals_single_process_gloo():
     assert (color - ref_color).abs().max() < 1e-5
     assert (depth - ref_depth).abs().max() < 1e-5
     assert torch.allclose(g1, torch.full((5,), 1.5)) and torch.allclose(g2, torch.full((2, 3), 15.0))
+
+
+def _worker_flat(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        vols = [torch.nn.Parameter(torch.zeros(1, 4, d, d, d)) for d in (6, 3)]
+        w = torch.nn.Parameter(torch.zeros(5, 3))
+        unused = torch.nn.Parameter(torch.zeros(7))                          # a parameter this step never touches on rank 1
+        flat = D.FlatGradients(vols + [w, unused])
+        assert flat.attached() and flat.padded % world == 0
+        x = torch.full((1, 4, 6, 6, 6), float(rank + 1))
+        loss = (vols[0] * x).sum() + (vols[1] * 2.0).sum() * (rank + 1) + (w * (rank + 1)).sum()
+        if rank == 0:
+            loss = loss + unused.sum()
+        loss.backward()                                                       # accumulates INTO the flat buffer (the .grad views)
+        assert flat.attached()
+        flat.sync()
+        shards = D.Shard()
+        # lattice chunks: 5 chunks of 4 values, chunk c holds c everywhere; rank r owns c % world == r
+        own = shards.chunks(5)
+        local = torch.stack([torch.full((4,), float(c)) for c in own])
+        lattice = shards.gather_chunks(local, 5)
+        rows = shards.gather_rows(torch.full((D.ray_shard(7, rank, world)[1] - D.ray_shard(7, rank, world)[0], 2), float(rank)), 7)
+        # the legacy helper with a missing gradient on one rank
+        a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+        a.grad = torch.full((3,), float(rank + 1))
+        if rank == 0:
+            b.grad = torch.full((2,), 4.0)
+        D.allreduce_gradients([a, b])
+        if rank == 0:
+            q.put(tuple(t.detach().numpy().copy() for t in (vols[0].grad, vols[1].grad, w.grad, unused.grad, lattice, rows, a.grad, b.grad)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_exchange_lattice_chunks_and_missing_gradients_gloo():
+    """Fine-tune exchange on the persistent flat buffer (reduce_scatter + all_gather on RCCL; all_reduce on gloo), K11's chunk-mod-world
+    lattice sharding, the ray-shard gather, and the all-reduce helper when one rank has no gradient for a parameter (world size 2)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    v0, v1, w, unused, lattice, rows, a, b = (torch.from_numpy(x) for x in q.get(timeout=200))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.allclose(v0, torch.full_like(v0, 1.5)) and torch.allclose(v1, torch.full_like(v1, 3.0)) and torch.allclose(w, torch.full_like(w, 1.5))
+    assert torch.allclose(unused, torch.full_like(unused, 0.5))                     # mean of (1, nothing)
+    assert torch.equal(lattice, torch.arange(5.0)[:, None].expand(5, 4))
+    assert torch.equal(rows[:, 0], torch.tensor([0.0, 0, 0, 0, 1, 1, 1]))
+    assert torch.allclose(a, torch.full_like(a, 1.5)) and torch.allclose(b, torch.full_like(b, 2.0))
+
+
+def test_single_process_shard_stand_in_collects_in_rank_order():
+    sink = {}
+    outs = [D.Shard.single(r, 3, sink).gather_rows(torch.full((D.ray_shard(8, r, 3)[1] - D.ray_shard(8, r, 3)[0], 1), float(r)), 8) for r in range(3)]
+    assert outs[0] is None and outs[1] is None and torch.equal(outs[2][:, 0], torch.tensor([0.0, 0, 0, 1, 1, 1, 2, 2]))
+    sink = {}
+    got = None
+    for r in range(3):
+        sh = D.Shard.single(r, 3, sink)
+        got = sh.gather_chunks(torch.stack([torch.full((2,), float(c)) for c in sh.chunks(7)]), 7)
+    assert torch.equal(got, torch.arange(7.0)[:, None].expand(7, 2))

@@ -262,3 +262,65 @@ def test_render_config0_coarsest_volume_only(golden):
     close(out["sparse_sdf"], g["out.sparse_sdf"], atol=1e-4, rtol=1e-4, what="sparse_sdf")
     for k in ["gradient_error", "smooth_error", "tv_reg"]:
         close(out[k], g["out." + k], atol=1e-4, rtol=2e-3, what=k)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_and_lattice_shards_reproduce_the_single_gpu_result_bit_for_bit(golden, world):
+    """BASELINE config 4 on the HIP kernels: validate() with the rays split into `world` contiguous ranges and the lattice into chunks
+    `index mod world` -- each shard rendered by the device kernels, gathered by the collective-free stand-in of the RCCL all_gather
+    (gens_amd.distributed.Shard.single; the collectives themselves are covered on gloo, tests/test_distributed_cpu.py) -- must give
+    the image and the lattice of the unsharded call EXACTLY: every ray's jitter is drawn on every rank from the same generator state and
+    the fused kernels evaluate each point independently of its neighbours in the batch."""
+    from gens_amd.distributed import Shard
+    g = golden("g15_validate")
+    gg = dict(g)
+    gg["step"] = torch.tensor(-1.0)
+    surf = build_surface(gg)
+    feats, vols, masks, match, _ = scene_inputs(gg)
+    c = lambda t: t.cuda()  # noqa: E731
+    surf.val_chunk = 200                                     # not a divisor of any shard: chunk boundaries differ from the unsharded run
+    h, w = (int(x) for x in g["hw"])
+    bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
+    args = (c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]), c(g["c2ws"]), bmin, bmax,
+            torch.tensor([h, w]).int())
+    torch.manual_seed(77)
+    ref = surf.validate(*args, extract_geometry=True, mesh_resolution=33)
+    ref_u = surf.sdf_grid(vols, bmin, bmax, 33, chunk=5000)
+    sink, out = {}, None
+    for r in range(world):
+        torch.manual_seed(77)                                # every rank starts from the same CPU generator state
+        out = surf.validate(*args, extract_geometry=True, mesh_resolution=33, shard=Shard.single(r, world, sink))
+        assert (out is None) == (r + 1 < world)
+    for k in ("color_fine", "img_fine", "normal_img", "sdf_depth", "render_depth", "vertices", "triangles"):
+        assert torch.equal(torch.as_tensor(out[k]), torch.as_tensor(ref[k])), k
+    sink, u = {}, None
+    for r in range(world):
+        u = surf.sdf_grid(vols, bmin, bmax, 33, chunk=5000, shard=Shard.single(r, world, sink))
+    assert torch.equal(u, ref_u)
+
+
+def test_split_half_overflow_recomputes_the_lattice_in_float32(golden):
+    """An out-of-range volume feature raises the split-half kernel's overflow flag during the SDF LATTICE too: extract_geometry must then
+    hand marching cubes float32 values (the flag used to be consumed by the image check only, leaving a mesh from out-of-range halves)."""
+    g = golden("g9a_render")
+    surf = build_surface(g)
+    feats, vols, masks, match, step = scene_inputs(g)
+    vols = [v.clone() for v in vols]
+    vols[1][0, 2, 3:9, 3:9, 3:9] = 4.0e4
+    bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
+    surf.sdf_precision = "f32"
+    ref = surf.sdf_grid(vols, bmin, bmax, 24)
+    surf.sdf_precision = "f16x2"
+    got = surf.sdf_grid(vols, bmin, bmax, 24)
+    assert torch.equal(got, ref)
+    assert not surf._split_half_overflowed()                  # the lattice consumed its own flag: nothing left for the image check
+    c = lambda t: t.cuda()  # noqa: E731
+    torch.manual_seed(3)
+    out = surf.validate(c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]), c(g["c2ws"]),
+                        bmin, bmax, (4, 6), extract_geometry=True, mesh_resolution=24)
+    surf.sdf_precision = "f32"
+    torch.manual_seed(3)
+    ref_out = surf.validate(c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]),
+                            c(g["c2ws"]), bmin, bmax, (4, 6), extract_geometry=True, mesh_resolution=24)
+    assert torch.equal(torch.as_tensor(out["vertices"]), torch.as_tensor(ref_out["vertices"]))
+    close(torch.as_tensor(out["color_fine"]), torch.as_tensor(ref_out["color_fine"]), atol=1e-6, rtol=1e-6, what="colour")
