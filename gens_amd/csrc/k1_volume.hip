@@ -12,6 +12,8 @@
 
 #include "common.h"
 
+#define K1_FAST_VIEWS 8   // the frustum-culled kernels map (z-row, view) pairs onto 32 x 8 threads; more views run the generic kernel
+
 // ---------------------------------------------------------------------------------------------------------------
 // layout helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -273,7 +275,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // arithmetic (64 % of all (wave, view) pairs at the benchmark geometry, where that arithmetic was 55 % of the kernel's instructions).
     // The exact per-voxel test below still decides visibility; the intervals only have to be supersets, and the bit-for-bit
     // comparisons with the unculled kernels check that they are.
-    __shared__ int2 row_span[32][GENS_MAX_VIEWS];
+    __shared__ int2 row_span[32][K1_FAST_VIEWS];
     {
         const int rows = tiled ? 4 : 256 >> lc.log2d;                             // z-rows the workgroup touches (d <= 256)
         const int r = threadIdx.x >> 3, v = threadIdx.x & 7;
@@ -605,7 +607,7 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
     const bool pow2 = d >= 2 && d <= 256 && (d & (d - 1)) == 0;
     if (pow2 && !getenv("GENS_K1_GENERIC")) {                 // (the environment switch keeps the generic kernel reachable for A/B tests)
         const LevelConst lc = level_const(h, w, d);
-        if (d >= 8 && nv <= GENS_MAX_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
+        if (d >= 8 && nv <= K1_FAST_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
             volume_build_fwd_lean_k<<<(unsigned)(n / 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
                                                                                      min_vis_view, volume, mask);
             return gens_launch_status("gens_volume_build_fwd");
@@ -630,7 +632,7 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
                                         void* stream) {
     GENS_CHECK_ARG(feat && hw && dims && w2c && intr && volumes && masks, GENS_EINVAL, "gens_volume_build_levels: null table");
     GENS_CHECK_ARG(n_levels >= 1 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_volume_build_levels: %d levels (1..%d)", n_levels, GENS_MAX_LEVELS);
-    bool one_launch = nv <= GENS_MAX_VIEWS && !getenv("GENS_K1_GENERIC") && !getenv("GENS_K1_SINGLE") && !getenv("GENS_K1_PER_LEVEL");
+    bool one_launch = nv <= K1_FAST_VIEWS && !getenv("GENS_K1_GENERIC") && !getenv("GENS_K1_SINGLE") && !getenv("GENS_K1_PER_LEVEL");
     for (int l = 0; l < n_levels; ++l) {
         if (int e = check_volume_args("gens_volume_build_levels", feat[l], w2c, intr[l], nv, hw[2 * l], hw[2 * l + 1], dims[l])) return e;
         GENS_CHECK_ARG(volumes[l] && masks[l], GENS_EINVAL, "gens_volume_build_levels: null output (level %d)", l);

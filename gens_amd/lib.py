@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GENS_HIP_LIB", os.path.join(_HERE, "csrc", "libgens_hip.so"))   # env override: development builds
 
 MAX_LEVELS = 8
-MAX_VIEWS = 8
+MAX_VIEWS = 16
 LAYOUT_PLANAR = 0
 LAYOUT_PACKED = 1
 
@@ -182,8 +182,8 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def ptr(t, dtype=torch.float32):
-    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+def ptr(t, dtype=torch.float32, align=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL).  align=16 for buffers a kernel reads / writes as float4."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -192,16 +192,20 @@ def ptr(t, dtype=torch.float32):
         raise RuntimeError(f"expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError("tensor must be contiguous")
+    if align and t.data_ptr() % align != 0 and t.numel() > 0:
+        # texels, packed volumes and the K15 / K16 tensors are accessed as float4 / float2: a view that starts in the middle of an allocation
+        # (flat[1:].view(...)) would fault or tear; torch's own allocations are 256-byte aligned.  ops.aligned16() clones such a view.
+        raise RuntimeError(f"tensor storage is not {align}-byte aligned (offset view, data_ptr % {align} = {t.data_ptr() % align}): pass a .clone()")
     return C.c_void_p(t.data_ptr())
 
 
-def ptr_table(tensors, dtype=torch.float32):
+def ptr_table(tensors, dtype=torch.float32, align=None):
     """HOST array of device pointers (None -> NULL table)."""
     if tensors is None:
         return None
     arr = (C.c_void_p * len(tensors))()
     for k, t in enumerate(tensors):
-        arr[k] = None if t is None else ptr(t, dtype).value
+        arr[k] = None if t is None else ptr(t, dtype, align).value
     return C.cast(arr, _pp)
 
 

@@ -1,14 +1,16 @@
 """Drop-in for the reference's models/gens.py: same class name, constructor, methods, state-dict names and output
 keys (gens.py:12-157), with the volume build and the renderer running on libgens_hip.so.
 
-The 2-D feature CNN (MnasNet) and the 3-D regularisation U-Net are outside the accelerated path (SURVEY.md
-section 2 rows 4h, 4i: dense convolutions, MIOpen through PyTorch).  In order of preference: classes
-registered with `register_backbones`; the reference tree this package is dropped into
-(`models.modules.feature_network_mnasnet.FeatureNetwork`, `models.modules.reg_network.RegNetwork`); this package's own
-restatements with the same parameter names (`modules/feature_network.py`, `modules/reg_network.py`), so that `GenS(confs)`
-also runs stand-alone.
+The 2-D feature CNN (MnasNet) and the 3-D regularisation U-Net.  In order of preference: classes
+registered with `register_backbones`; then
+  * U-Net: THIS package's `modules/reg_network.RegNetwork` (same constructor, same state-dict keys -- checkpoints load with strict=True --
+    on the K15 / K16 kernels: 13.8 ms forward + backward against 6.2 s through MIOpen).  The reference tree's own
+    class is used only when registered explicitly: picking it silently cost three orders of magnitude in the drop-in scenario;
+  * feature CNN: the reference tree this package is dropped into (`models.modules.feature_network_mnasnet.FeatureNetwork`, i.e. the real
+    torchvision trunk with its pretrained weights) when importable, else this package's restatement of the same architecture.
 """
 import importlib
+import warnings
 
 import torch
 import torch.nn as nn
@@ -29,19 +31,47 @@ def register_backbones(feature_network_cls=None, reg_network_cls=None):
 
 def _backbone(kind):
     if kind in _BACKBONES:
-        return _BACKBONES[kind]
-    module, name = {"feature": ("models.modules.feature_network_mnasnet", "FeatureNetwork"),
-                    "reg": ("models.modules.reg_network", "RegNetwork")}[kind]
+        cls = _BACKBONES[kind]
+        if kind == "reg" and cls.__module__.split(".")[0] != __name__.split(".")[0]:
+            warnings.warn(f"gens_amd: RegNetwork registered from {cls.__module__}: its nn.Conv3d / nn.InstanceNorm3d layers run through MIOpen "
+                          "(seconds per training step at 256^3, DESIGN.md section 4c); gens_amd's own RegNetwork has the same state-dict keys",
+                          RuntimeWarning, stacklevel=3)
+        return cls
+    from .modules import feature_network, reg_network
+    if kind == "reg":
+        return reg_network.RegNetwork
     try:
-        return getattr(importlib.import_module(module), name)
+        return getattr(importlib.import_module("models.modules.feature_network_mnasnet"), "FeatureNetwork")
     except ImportError:                    # stand-alone: this package's own restatement (same parameter names, MIOpen convolutions)
-        from .modules import feature_network, reg_network
-        return {"feature": feature_network.FeatureNetwork, "reg": reg_network.RegNetwork}[kind]
+        return feature_network.FeatureNetwork
+
+
+def _check_limits(confs):
+    """The kernels' hard limits, checked where the model is built (a wrong configuration used to fail deep inside a kernel call, or to drop
+    silently to the unfused path)."""
+    from .. import lib as L
+    surf = confs["implicit_surface"]
+    feat_ch = surf["sdf_network"]["feat_channels"]
+    if feat_ch % 4 != 0 or not 1 <= feat_ch // 4 <= L.MAX_LEVELS:
+        raise ValueError(f"implicit_surface.sdf_network.feat_channels = {feat_ch}: the look-up kernels read 4-channel volume levels, 1 to "
+                         f"{L.MAX_LEVELS} of them (include/gens_hip.h: GENS_MAX_LEVELS); confs/gens.conf uses 4 channels x 5 levels")
+    if not confs.get_bool("has_vol", default=False):
+        d_out = confs["reg_network"]["d_out"]
+        dims = confs["volume"]["volume_dims"]
+        if any(c != 4 for c in d_out) or len(d_out) != len(dims) or 4 * len(dims) != feat_ch:
+            raise ValueError(f"reg_network.d_out = {list(d_out)}, volume.volume_dims = {list(dims)}, feat_channels = {feat_ch}: every volume level "
+                             "must have 4 channels and feat_channels must equal 4 x the number of levels (the kernels' texel layout)")
+        if any(c != 4 for c in confs["feature_network"]["d_out"]) or len(confs["feature_network"]["d_out"]) > 5:
+            raise ValueError("feature_network.d_out: at most 5 feature levels of 4 channels each (K1 / K4 / K7 read 4-channel texels)")
+    if feat_ch // 4 not in (3, 5):
+        warnings.warn(f"gens_amd: {feat_ch // 4} volume levels: the fused SDF kernels (gens_sdf_mlp, gens_sdf_train_*) are built for 3 or 5 levels; "
+                      "this configuration runs the PyTorch layers on the K2 look-up kernels (correct, several times slower)", RuntimeWarning, stacklevel=3)
 
 
 class GenS(nn.Module):
     def __init__(self, confs):
         super().__init__()
+        _check_limits(confs)
         self.has_vol = confs.get_bool("has_vol", default=False)
         if not self.has_vol:
             self.feature_network = _backbone("feature")(confs["feature_network"])

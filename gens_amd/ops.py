@@ -17,6 +17,13 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def aligned16(t):
+    """Contiguous and 16-byte aligned (what the float4 / float2 accesses of the texel, packed-volume, K15 and K16 kernels need): a
+    contiguous VIEW that starts mid-allocation (flat[1:].view(c, n)) is copied; everything torch allocates itself already qualifies."""
+    t = _c(t)
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _dev_f32(t, device):
     return _c(t.to(device=device, dtype=_f32))
 
@@ -69,7 +76,7 @@ class VolumeSet:
 
     def __init__(self, tensors, layout):
         self.layout = layout
-        self.tensors = [_c(t) for t in tensors]
+        self.tensors = [aligned16(t) if layout == L.LAYOUT_PACKED else _c(t) for t in tensors]
         if layout == L.LAYOUT_PACKED:
             dims = [tuple(t.shape[:3]) for t in self.tensors]
         else:
@@ -122,7 +129,7 @@ class _VolumeBuild(torch.autograd.Function):
         assert cp == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
         vol = torch.empty(1, 8, d, d, d, device=feat_tex.device, dtype=_f32)
         mask = torch.empty(1, 1, d, d, d, device=feat_tex.device, dtype=_f32)
-        L.call("gens_volume_build_fwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
+        L.call("gens_volume_build_fwd", L.ptr(aligned16(feat_tex), align=16), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
                L.ptr(mask), L.stream(), nbytes=nv * h * w * 16 + 36 * d ** 3)
         ctx.save_for_backward(feat_tex, w2c, intr)
         ctx.meta = (scale, d)
@@ -154,7 +161,7 @@ class _VolumeBuildLevels(torch.autograd.Function):
         hw = [x for t in texs for x in (t.shape[1], t.shape[2])]
         for t in texs:
             assert t.shape[0] == nv and t.shape[3] == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
-        texs_c = [_c(t) for t in texs]
+        texs_c = [aligned16(t) for t in texs]
         L.call("gens_volume_build_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv, min_vis,
                L.ptr_table(vols), L.ptr_table(masks), L.stream(), nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)))
         ctx.save_for_backward(w2c, *texs, *intrs)
@@ -339,8 +346,8 @@ class _LookupFeature(torch.autograd.Function):
         out = torch.empty(n, s, 3 + 4 * nl, device=pts.device, dtype=_f32)
         ray_diff = torch.empty(n, s, 4, device=pts.device, dtype=_f32)
         vis = torch.empty(n, s, device=pts.device, dtype=torch.uint8)
-        feats = [_c(f.detach()) for f in feat_tex]
-        L.call("gens_lookup_feature_fwd", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(imgs_tex.detach())), L.ptr(w2c), L.ptr(intr),
+        feats = [aligned16(f.detach()) for f in feat_tex]
+        L.call("gens_lookup_feature_fwd", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(imgs_tex.detach()), align=16), L.ptr(w2c), L.ptr(intr),
                L.ptr(c2w), nv, L.ptr(pts), n, L.ptr(out), L.ptr(ray_diff), L.ptr(vis, torch.uint8), L.stream(),
                nbytes=n * 12 + n * s * (4 * (3 + 4 * nl) + 17))
         ctx.save_for_backward(pts, w2c, intr)
@@ -998,7 +1005,7 @@ def _conv_gather(q, w_abt, bias, stride, reverse=False):
     wt = _conv_pad_last(wt, 8 if cp > 4 else 4)
     p = torch.empty(cp, *dims, device=q.device, dtype=_f32)
     n = p[0].numel()
-    L.call("gens_conv3d_gather", L.ptr(q), L.ptr(wt), L.ptr(None if bias is None else _c(bias.detach().to(_f32))), cp, cq, L.int_table(dims), stride,
+    L.call("gens_conv3d_gather", L.ptr(q, align=16), L.ptr(wt), L.ptr(None if bias is None else _c(bias.detach().to(_f32))), cp, cq, L.int_table(dims), stride,
            L.ptr(p), L.stream(), nbytes=4 * (q.numel() + p.numel()), flops=2 * 27 * cp * cq * n)
     return p
 
@@ -1010,7 +1017,7 @@ def _conv_scatter2(p, w_abt):
     dims = list(p.shape[1:])
     wt = _conv_pad_last(w_abt.permute(0, 2, 1), 8 if cq > 4 else 4)                      # (cp, 27, cq padded)
     q = torch.empty(cq, *[2 * d for d in dims], device=p.device, dtype=_f32)
-    L.call("gens_conv3d_scatter2", L.ptr(p), L.ptr(wt), cp, cq, L.int_table(dims), L.ptr(q), L.stream(),
+    L.call("gens_conv3d_scatter2", L.ptr(p, align=16), L.ptr(wt), cp, cq, L.int_table(dims), L.ptr(q), L.stream(),
            nbytes=4 * (q.numel() + p.numel()), flops=2 * 27 * cp * cq * p[0].numel())
     return q
 
@@ -1031,7 +1038,7 @@ def _plane_sums(x2):
     """Per-row sums of a (c, n) float32 tensor through K16's statistics pass (float64 accumulation, the whole chip per row)."""
     c, n = x2.shape
     part = torch.empty(c, L.load().gens_instnorm_blocks(c, n), 2, device=x2.device, dtype=torch.float64)
-    L.call("gens_instnorm_stats", L.ptr(x2), c, n, L.ptr(part, torch.float64), L.stream(), nbytes=4 * c * n)
+    L.call("gens_instnorm_stats", L.ptr(x2, align=16), c, n, L.ptr(part, torch.float64), L.stream(), nbytes=4 * c * n)
     return part[:, :, 0].sum(1).to(_f32)
 
 
@@ -1040,7 +1047,7 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride):
-        x3 = _c(x.detach()[0].to(_f32))
+        x3 = aligned16(x.detach()[0].to(_f32))
         ctx.save_for_backward(x3, w)
         ctx.stride, ctx.has_bias = stride, b is not None
         return _conv_gather(x3, w.detach().to(_f32).reshape(w.shape[0], w.shape[1], 27), b, stride)[None]
@@ -1066,7 +1073,7 @@ class _ConvTranspose3d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
-        x3 = _c(x.detach()[0].to(_f32))
+        x3 = aligned16(x.detach()[0].to(_f32))
         ctx.save_for_backward(x3, w)
         return _conv_scatter2(x3, w.detach().to(_f32).reshape(w.shape[0], w.shape[1], 27))[None]
 
@@ -1102,11 +1109,11 @@ _f64 = torch.float64
 class _InstNormRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps, skip=None):
-        x2 = _c(x.detach().to(_f32)).reshape(x.shape[1], -1)
+        x2 = aligned16(x.detach().to(_f32)).reshape(x.shape[1], -1)
         c, n = x2.shape
         blocks = L.load().gens_instnorm_blocks(c, n)
         part = torch.empty(c, blocks, 2, device=x.device, dtype=_f64)
-        L.call("gens_instnorm_stats", L.ptr(x2), c, n, L.ptr(part, _f64), L.stream(), nbytes=4 * c * n)
+        L.call("gens_instnorm_stats", L.ptr(x2, align=16), c, n, L.ptr(part, _f64), L.stream(), nbytes=4 * c * n)
         s = part.sum(1) / n                                                        # float64: mean, mean of squares
         mean = s[:, 0]
         mr = torch.stack([mean, torch.rsqrt((s[:, 1] - mean * mean).clamp_min(0.0) + eps)], 1).to(_f32)
@@ -1194,10 +1201,10 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
         vis_out = torch.zeros(pts.shape[0], s, device=pts.device, dtype=torch.uint8)
     idx = None if index is None else _c(index.to(torch.int64))
     hw = [d for f in views.feat_tex for d in f.shape[1:3]]
-    feats = [_c(f.detach()) for f in views.feat_tex]
+    feats = [aligned16(f.detach()) for f in views.feat_tex]
     f = plan.n_feat
     flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
-    L.call("gens_blend_views", L.ptr_table(feats), L.int_table(hw), nl, L.ptr(_c(views.imgs_tex.detach())), L.ptr(views.w2c), L.ptr(views.intr),
+    L.call("gens_blend_views", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16), L.ptr(views.w2c), L.ptr(views.intr),
            L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
            L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
     return rgb_out, vis_out

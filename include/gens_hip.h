@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define GENS_MAX_LEVELS 8
-#define GENS_MAX_VIEWS 8
+#define GENS_MAX_VIEWS 16  /* the reference's fine-tune sets hold up to 11 views (dtu_finetune.py: ref + 10 sources); K1's culled fast path serves <= 8, more views take its generic kernel */
 
 #define GENS_EINVAL (-1)   /* bad argument (null pointer, size out of range)          */
 #define GENS_ELIMIT (-2)   /* more levels / views / channels than the build supports */

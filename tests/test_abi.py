@@ -106,3 +106,29 @@ def test_conv_and_norm_entry_points_validate_their_arguments(libpath):
     assert lib.gens_instnorm_relu_bwd_stats(None, None, None, 8, 64, None, None) == -1
     assert lib.gens_instnorm_relu_bwd(None, None, None, None, 70000, 64, None, None) == -1
     assert lib.gens_tv_bwd_scaled(None, None, 4, 4, 4, 1.0, None, None, None) == -1
+
+
+def test_limits_are_checked_where_the_model_is_built():
+    """Channel / level limits of the kernels surface in GenS.__init__ with a message that names the limit, not deep inside a kernel call."""
+    import pytest
+    from gens_amd.config import Conf, gens_model_conf
+    from gens_amd.models.gens import _check_limits
+    _check_limits(gens_model_conf())                                                     # the shipped configuration passes
+    bad = gens_model_conf()
+    bad = Conf({**bad, "reg_network": {"d_voluem": [8] * 5, "d_out": [8] * 5, "d_base": 8}})
+    with pytest.raises(ValueError, match="4 channels"):
+        _check_limits(bad)
+    nine = gens_model_conf(volume_dims=tuple([8] * 9))
+    with pytest.raises(ValueError, match="GENS_MAX_LEVELS"):
+        _check_limits(nine)
+    with pytest.warns(RuntimeWarning, match="3 or 5 levels"):
+        _check_limits(gens_model_conf(volume_dims=(16, 8)))
+
+
+def test_offset_views_are_refused_by_float4_consumers():
+    import torch
+    from gens_amd import lib as L, ops
+    t = torch.zeros(9)[1:]
+    assert ops.aligned16(t).data_ptr() % 16 == 0 and torch.equal(ops.aligned16(t), t)
+    assert ops.aligned16(torch.zeros(8)).data_ptr() % 16 == 0
+    assert L.ptr(None, align=16) is None
