@@ -75,65 +75,33 @@ class BMVSDataset(Dataset):
     def __getitem__(self, idx):
         scan, ref_view, src_views = self.metas[idx]
         view_ids = [ref_view] + src_views[:self.num_src_view]
-        h, w = self.img_hw
-        imgs, intrs, w2cs, near_fars, depths, masks = [], [], [], [], [], []
-        for vid in view_ids:
-            imgs.append(self.read_img(os.path.join(self.data_dir, scan, "blended_images", "%08d_masked.jpg" % vid)) / 256.0)
-            intr, w2c, near_far = self.read_cam(os.path.join(self.data_dir, scan, "cams", "%08d_cam.txt" % vid))
-            intrs.append(intr)
-            w2cs.append(w2c)
-            near_fars.append(near_far)
-            depth, mask = self.read_depth_and_mask(os.path.join(self.data_dir, scan, "rendered_depth_maps", "%08d.pfm" % vid), near_far[0])
-            depths.append(depth)
-            masks.append(mask)
-        w2c_ref_inv = np.linalg.inv(w2cs[0])
-        w2cs = [w2c @ w2c_ref_inv for w2c in w2cs]                       # every pose relative to the reference camera
-        scale_mat, scale_factor = self.get_scale_mat(self.img_hw, intrs, w2cs, near_fars, factor=self.factor)
-        c2ws, new_near_fars, new_intrs, new_depths = [], [], [], []
-        for intr, w2c, depth in zip(intrs, w2cs, depths):                # cameras of the unit-sphere-normalised scene
-            new_intr, c2w = C.load_K_Rt_from_P(None, (intr @ w2c @ scale_mat)[:3, :4])
-            c2ws.append(c2w)
-            new_intrs.append(new_intr)
-            dist = np.sqrt(np.sum(c2w[:3, 3] ** 2)).astype(np.float32)
-            new_near_fars.append([0.95 * (dist - 1), 1.05 * (dist + 1)])
-            new_depths.append(depth * scale_factor)
-        depths = torch.from_numpy(np.stack(new_depths).astype(np.float32))
-        masks = torch.from_numpy(np.stack(masks).astype(np.float32))
-        imgs = torch.from_numpy(np.stack(imgs).astype(np.float32))
-        intrs = torch.from_numpy(np.stack(new_intrs).astype(np.float32))
-        c2ws = torch.from_numpy(np.stack(c2ws).astype(np.float32))
-        near_fars = torch.from_numpy(np.stack(new_near_fars).astype(np.float32))
-        outputs = {"imgs": imgs.permute(0, 3, 1, 2).contiguous(), "intrs": intrs, "c2ws": c2ws,
-                   "scale_mat": torch.from_numpy(w2c_ref_inv @ scale_mat), "view_ids": torch.from_numpy(np.array(view_ids)).long()}
+        scene_dir = os.path.join(self.data_dir, scan)
+        cams = [self.read_cam(os.path.join(scene_dir, "cams", "%08d_cam.txt" % v)) for v in view_ids]               # (intr, w2c, near_far)
+        imgs = torch.from_numpy(np.stack([self.read_img(os.path.join(scene_dir, "blended_images", "%08d_masked.jpg" % v)) / 256.0
+                                          for v in view_ids]).astype(np.float32))
+        depth_mask = [self.read_depth_and_mask(os.path.join(scene_dir, "rendered_depth_maps", "%08d.pfm" % v), cam[2][0])
+                      for v, cam in zip(view_ids, cams)]
+        views = C.NormalisedViews([c[0] for c in cams], [c[1] for c in cams], [c[2] for c in cams], self.img_hw, self.factor)
+        depths = views.scaled([d for d, _ in depth_mask])
+        masks = torch.from_numpy(np.stack([m for _, m in depth_mask]).astype(np.float32))
 
-        ys, xs = torch.meshgrid(torch.linspace(0, h - 1, h), torch.linspace(0, w - 1, w), indexing="ij")
-        pixel_all = torch.stack([xs, ys], dim=-1)
+        h, w = self.img_hw
+        item = {"imgs": imgs.permute(0, 3, 1, 2).contiguous(), "intrs": views.intrs, "c2ws": views.c2ws, "scale_mat": views.scale_mat,
+                "view_ids": torch.from_numpy(np.array(view_ids)).long()}
         if self.mode == "train":
             assert self.n_rays > 0, "No sampling rays!"
-            n = self.n_rays
-            p_valid = pixel_all[masks[0] > 0.5]                          # three quarters of the rays inside the object mask
-            pixels_x_i = torch.randint(low=0, high=w, size=[n // 4])
-            pixels_y_i = torch.randint(low=0, high=h, size=[n // 4])
-            p_select = p_valid[torch.randint(low=0, high=p_valid.shape[0], size=[n - n // 4])]
-            pixels_x = torch.cat([p_select[:, 0], pixels_x_i], dim=0)
-            pixels_y = torch.cat([p_select[:, 1], pixels_y_i], dim=0)
+            px, py = C.sample_train_pixels(masks[0], self.n_rays)
         else:
             lvl = self.val_res_level
-            outputs.update({"bound_min": torch.tensor([-1, -1, -1], dtype=torch.float32), "bound_max": torch.tensor([1, 1, 1], dtype=torch.float32),
-                            "scene": scan, "file_name": scan + "_view" + str(ref_view), "hw": torch.Tensor([h // lvl, w // lvl]).int(), "masks": masks})
-            pixels_y, pixels_x = torch.meshgrid(torch.linspace(0, h - 1, h // lvl), torch.linspace(0, w - 1, w // lvl), indexing="ij")
-            pixels_x, pixels_y = pixels_x.reshape(-1), pixels_y.reshape(-1)
-
-        at = (pixels_y.long(), pixels_x.long())
-        p = torch.stack([pixels_x, pixels_y, torch.ones_like(pixels_y)], dim=-1).float()
-        p = torch.matmul(intrs.inverse()[0, None, :3, :3], p[:, :, None]).squeeze()
-        rays_d = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
-        rays_d = torch.matmul(c2ws[0, None, :3, :3], rays_d[:, :, None]).squeeze()
-        rays_o = c2ws[0, None, :3, 3].expand(rays_d.shape)
-        near, far = near_fars[0].reshape(1, 2).split(split_size=1, dim=1)
-        outputs.update({"pixels_x": pixels_x, "pixels_y": pixels_y, "near_fars": near_fars, "rays_o": rays_o, "rays_d": rays_d, "near": near, "far": far,
-                        "color": imgs[0][at], "depth": depths[0][at], "mask": masks[0][at], "masks": masks, "depth_ref": depths[0], "src_idx": 1})
-        return outputs
+            px, py = C.lattice_pixels(h, w, lvl)
+            item.update(bound_min=torch.tensor([-1, -1, -1], dtype=torch.float32), bound_max=torch.tensor([1, 1, 1], dtype=torch.float32),
+                        scene=scan, file_name=scan + "_view" + str(ref_view), hw=torch.Tensor([h // lvl, w // lvl]).int())
+        rays_o, rays_d = C.rays_from_pixels(views.intrs[0], views.c2ws[0], px, py)
+        near, far = views.near_fars[0].reshape(1, 2).split(split_size=1, dim=1)
+        at = (py.long(), px.long())
+        item.update(pixels_x=px, pixels_y=py, near_fars=views.near_fars, rays_o=rays_o, rays_d=rays_d, near=near, far=far, color=imgs[0][at],
+                    depth=depths[0][at], mask=masks[0][at], masks=masks, depth_ref=depths[0], src_idx=1)
+        return item
 
     def __len__(self):
         return len(self.metas)

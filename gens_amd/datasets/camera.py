@@ -159,3 +159,80 @@ def near_far_from_sphere(rays_o, rays_d):
     b = torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
     mid = (-b) / a
     return mid - 1.0, mid + 1.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the item a multi-view dataset hands to GenS.forward, assembled from parts (shared by the DTU / BlendedMVS train, val and fine-tune sets)
+# ----------------------------------------------------------------------------------------------------------------------
+class NormalisedViews:
+    """Cameras of one item re-expressed in the frame the renderer assumes: reference camera at the origin of the world frame BEFORE the
+    unit-sphere normalisation, then everything scaled so that the frusta's bounding box fits the unit sphere (datasets/dtu.py:330-356,
+    bmvs.py:229-252).  Fields are float32 torch tensors stacked over the views; `scale_mat` maps normalised coordinates back to the
+    dataset's world frame (what runner.py:231 multiplies the mesh by); `depth_scale` turns metric depths into normalised ones."""
+
+    def __init__(self, intrs, w2cs, near_fars, img_hw, factor):
+        ref_c2w = np.linalg.inv(w2cs[0])
+        rel = [w2c @ ref_c2w for w2c in w2cs]                               # poses relative to the reference camera
+        sphere, self.depth_scale = get_scale_mat(img_hw, intrs, rel, near_fars, factor=factor)
+        k_new, poses, ranges = [], [], []
+        for intr, w2c in zip(intrs, rel):
+            k, c2w = load_K_Rt_from_P(None, (intr @ w2c @ sphere)[:3, :4])  # the projection of the normalised scene, split again
+            centre_dist = np.sqrt(np.sum(c2w[:3, 3] ** 2)).astype(np.float32)
+            k_new.append(k)
+            poses.append(c2w)
+            ranges.append([0.95 * (centre_dist - 1), 1.05 * (centre_dist + 1)])     # the unit sphere seen from this camera
+        as_t = lambda seq: torch.from_numpy(np.stack(seq).astype(np.float32))  # noqa: E731
+        self.intrs, self.c2ws, self.near_fars = as_t(k_new), as_t(poses), as_t(ranges)
+        self.scale_mat = torch.from_numpy(ref_c2w @ sphere)
+
+    def scaled(self, maps):
+        """Depth-like maps (list of (H, W) arrays in dataset units) -> one float32 tensor in normalised units."""
+        return torch.from_numpy(np.stack([m * self.depth_scale for m in maps]).astype(np.float32))
+
+
+def lattice_pixels(h, w, level=1):
+    """Every `level`-th pixel of an h x w image as flat float (x, y) vectors -- torch.linspace end points included, which is what the
+    reference's validation rays use (dtu.py:389-393)."""
+    ys, xs = torch.meshgrid(torch.linspace(0, h - 1, h // level), torch.linspace(0, w - 1, w // level), indexing="ij")
+    return xs.reshape(-1), ys.reshape(-1)
+
+
+def sample_train_pixels(mask, n_rays):
+    """n_rays training pixels of an (h, w) object mask: the last quarter uniform over the image, the rest uniform over the pixels inside
+    the mask -- drawn from torch's global generator in the reference's order: x of the uniform part, y of the uniform part, indices into
+    the mask pixels (dtu.py:370-381).  -> float (x, y) vectors, mask part first."""
+    h, w = mask.shape
+    n_uniform = n_rays // 4
+    ux = torch.randint(low=0, high=w, size=[n_uniform])
+    uy = torch.randint(low=0, high=h, size=[n_uniform])
+    gx, gy = lattice_pixels(h, w)
+    inside = (mask > 0.5).reshape(-1)
+    gx, gy = gx[inside], gy[inside]
+    pick = torch.randint(low=0, high=gx.shape[0], size=[n_rays - n_uniform])
+    return torch.cat([gx[pick], ux], dim=0), torch.cat([gy[pick], uy], dim=0)
+
+
+def rays_from_pixels(intr, c2w, px, py):
+    """Unit-length world-space rays of the camera (intr (4,4), c2w (4,4)) through pixel centres (px, py): -> rays_o (N,3) (the camera
+    centre, expanded), rays_d (N,3)   (dtu.py:395-401)."""
+    homog = torch.stack([px, py, torch.ones_like(py)], dim=-1).float()
+    cam = torch.matmul(intr.inverse()[None, :3, :3], homog[:, :, None]).squeeze()
+    cam = cam / torch.linalg.norm(cam, ord=2, dim=-1, keepdim=True)
+    rays_d = torch.matmul(c2w[None, :3, :3], cam[:, :, None]).squeeze()
+    return c2w[None, :3, 3].expand(rays_d.shape), rays_d
+
+
+def unproject_pseudo_points(depth, mask, intr, c2w, count=2048, at_least=100):
+    """`count` world points un-projected from a (pseudo) depth map at random pixels where both depth and mask are positive; None when
+    fewer than `at_least` such pixels exist.  One draw from torch's global generator (dtu.py:406-419)."""
+    usable = (depth > 0) & (mask > 0)
+    if usable.sum() <= at_least:
+        return None
+    h, w = depth.shape
+    rows, cols = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
+    cols, rows, z = cols[usable].type_as(intr), rows[usable].type_as(intr), depth[usable]
+    pick = torch.randint(low=0, high=cols.shape[0], size=[count])
+    cols, rows, z = cols[pick], rows[pick], z[pick]
+    cam = torch.matmul(intr.inverse()[:3, :3], torch.stack((cols, rows, torch.ones_like(cols)), dim=0) * z.unsqueeze(0))
+    world = torch.matmul(c2w, torch.cat((cam, torch.ones_like(cols).unsqueeze(0)), dim=0))[:3]
+    return world.permute(1, 0)

@@ -88,102 +88,58 @@ class DTUDataset(Dataset):
         return C.resize_nearest(np.array(C.read_pfm(filename)[0], dtype=np.float32), self.img_hw)
 
     # ------------------------------------------------------------------------------------------------ one item (dtu.py:273-436)
+    def _files(self, scan, vid, light_idx):
+        tag = "r7000" if vid > 48 else "r5000"
+        return (os.path.join(self.data_dir, "Rectified_raw/{}/rect_{:0>3}_{}_{}.png".format(scan, vid + 1, light_idx, tag)),
+                os.path.join(self.data_dir, "Depths_raw/{}/depth_visual_{:0>4}.png".format(scan, vid)),
+                os.path.join(self.data_dir, "Depths_raw/{}/depth_map_{:0>4}.pfm".format(scan, vid)))
+
+    def _object_mask(self, filename):
+        m = (self.read_img(filename) > 10).astype(np.float32)
+        return m if m.ndim == 2 else (np.mean(m, axis=-1) > 0).astype(np.float32)
+
     def __getitem__(self, idx):
         scan, light_idx, ref_view = self.metas[idx]
-        pairs = list(self.pairs[ref_view])
-        if self.mode == "train":
-            src_views = random.sample(pairs[:6], min(self.num_src_view, len(pairs)))
-        else:
-            src_views = pairs[:min(self.num_src_view, len(pairs))]
-        view_ids = [ref_view] + src_views
+        train = self.mode == "train"
+        # host RNG draws, in the reference's order: source views (python `random`), src_idx (numpy), then torch's generator below
+        candidates = list(self.pairs[ref_view])
+        keep = min(self.num_src_view, len(candidates))
+        view_ids = [ref_view] + (random.sample(candidates[:6], keep) if train else candidates[:keep])
         src_idx = np.random.randint(1, len(view_ids))
+
+        files = [self._files(scan, v, light_idx) for v in view_ids]
+        imgs = torch.from_numpy(np.stack([self.read_img(f[0]) / 256.0 for f in files]).astype(np.float32))
+        masks = torch.from_numpy(np.stack([self._object_mask(f[1]) for f in files]).astype(np.float32))
+        views = C.NormalisedViews([self.intrs[v] for v in view_ids], [self.w2cs[v] for v in view_ids], [self.near_fars[v] for v in view_ids],
+                                  self.img_hw, self.factor)
+        depths = views.scaled([self.read_depth(f[2]) for f in files])
+        if train:                                                          # pseudo depth of the reference view (else: its mask stands in)
+            pseudo = self.read_numpy(os.path.join(self.data_dir, "pseudo_depths/{}/{}_epoch0.npy".format(scan, ref_view))) / self.pseudo_scale
+        else:
+            pseudo = masks[0].numpy()
+        pseudo = views.scaled([pseudo])[0]
+
         h, w = self.img_hw
-        w2c_ref_inv = np.linalg.inv(self.w2cs[ref_view])
-
-        imgs, intrs, w2cs, near_fars, masks, depths = [], [], [], [], [], []
-        for i, vid in enumerate(view_ids):
-            tag = "r7000" if vid > 48 else "r5000"
-            img_file = os.path.join(self.data_dir, "Rectified_raw/{}/rect_{:0>3}_{}_{}.png".format(scan, vid + 1, light_idx, tag))
-            mask_file = os.path.join(self.data_dir, "Depths_raw/{}/depth_visual_{:0>4}.png".format(scan, vid))
-            depth_file = os.path.join(self.data_dir, "Depths_raw/{}/depth_map_{:0>4}.pfm".format(scan, vid))
-            mask = (self.read_img(mask_file) > 10).astype(np.float32)
-            if mask.ndim > 2:
-                mask = (np.mean(mask, axis=-1) > 0).astype(np.float32)
-            imgs.append(self.read_img(img_file) / 256.0)
-            intrs.append(self.intrs[vid])
-            w2cs.append(self.w2cs[vid] @ w2c_ref_inv)                     # every pose relative to the reference camera
-            near_fars.append(self.near_fars[vid])
-            masks.append(mask)
-            depths.append(self.read_depth(depth_file))
-            if i == 0:
-                if self.mode == "train":
-                    pseudo_file = os.path.join(self.data_dir, "pseudo_depths/{}/{}_epoch0.npy".format(scan, vid))
-                    ref_pseudo_depth = self.read_numpy(pseudo_file) / self.pseudo_scale
-                else:
-                    ref_pseudo_depth = masks[0]
-
-        scale_mat, scale_factor = self.get_scale_mat(self.img_hw, intrs, w2cs, near_fars, factor=self.factor)
-        c2ws, new_near_fars, new_intrs, new_depths = [], [], [], []
-        for intr, w2c, depth in zip(intrs, w2cs, depths):                # cameras of the unit-sphere-normalised scene
-            new_intr, c2w = C.load_K_Rt_from_P(None, (intr @ w2c @ scale_mat)[:3, :4])
-            c2ws.append(c2w)
-            new_intrs.append(new_intr)
-            dist = np.sqrt(np.sum(c2w[:3, 3] ** 2)).astype(np.float32)
-            new_near_fars.append([0.95 * (dist - 1), 1.05 * (dist + 1)])
-            new_depths.append(scale_factor * depth)
-        ref_pseudo_depth = torch.from_numpy((ref_pseudo_depth * scale_factor).astype(np.float32))
-
-        imgs = torch.from_numpy(np.stack(imgs).astype(np.float32))
-        intrs = torch.from_numpy(np.stack(new_intrs).astype(np.float32))
-        c2ws = torch.from_numpy(np.stack(c2ws).astype(np.float32))
-        near_fars = torch.from_numpy(np.stack(new_near_fars).astype(np.float32))
-        masks = torch.from_numpy(np.stack(masks).astype(np.float32))
-        depths = torch.from_numpy(np.stack(new_depths).astype(np.float32))
-        outputs = {"imgs": imgs.permute(0, 3, 1, 2).contiguous(), "intrs": intrs, "c2ws": c2ws, "masks": masks,
-                   "scale_mat": torch.from_numpy(w2c_ref_inv @ scale_mat), "view_ids": torch.from_numpy(np.array(view_ids)).long()}
-
-        ys, xs = torch.meshgrid(torch.linspace(0, h - 1, h), torch.linspace(0, w - 1, w), indexing="ij")
-        pixel_all = torch.stack([xs, ys], dim=-1)
-        if self.mode == "train":
+        item = {"imgs": imgs.permute(0, 3, 1, 2).contiguous(), "intrs": views.intrs, "c2ws": views.c2ws, "masks": masks,
+                "scale_mat": views.scale_mat, "view_ids": torch.from_numpy(np.array(view_ids)).long()}
+        if train:
             assert self.n_rays > 0, "No sampling rays!"
-            n = self.n_rays
-            p_valid = pixel_all[masks[0] > 0.5]                          # three quarters of the rays inside the object mask
-            pixels_x_i = torch.randint(low=0, high=w, size=[n // 4])
-            pixels_y_i = torch.randint(low=0, high=h, size=[n // 4])
-            p_select = p_valid[torch.randint(low=0, high=p_valid.shape[0], size=[n - n // 4])]
-            pixels_x = torch.cat([p_select[:, 0], pixels_x_i], dim=0)
-            pixels_y = torch.cat([p_select[:, 1], pixels_y_i], dim=0)
+            px, py = C.sample_train_pixels(masks[0], self.n_rays)
         else:
             lvl = self.val_res_level
-            outputs.update({"bound_min": torch.tensor([-1, -1, -1], dtype=torch.float32), "bound_max": torch.tensor([1, 1, 1], dtype=torch.float32),
-                            "scene": scan, "file_name": scan + "_view" + str(ref_view) + "_light" + str(light_idx),
-                            "hw": torch.Tensor([h // lvl, w // lvl]).int()})
-            pixels_y, pixels_x = torch.meshgrid(torch.linspace(0, h - 1, h // lvl), torch.linspace(0, w - 1, w // lvl), indexing="ij")
-            pixels_x, pixels_y = pixels_x.reshape(-1), pixels_y.reshape(-1)
-
-        at = (pixels_y.long(), pixels_x.long())
-        p = torch.stack([pixels_x, pixels_y, torch.ones_like(pixels_y)], dim=-1).float()
-        p = torch.matmul(intrs.inverse()[0, None, :3, :3], p[:, :, None]).squeeze()
-        rays_d = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
-        rays_d = torch.matmul(c2ws[0, None, :3, :3], rays_d[:, :, None]).squeeze()
-        rays_o = c2ws[0, None, :3, 3].expand(rays_d.shape)
-        near, far = near_fars[0].reshape(1, 2).split(split_size=1, dim=1)
-
-        p_mask = (ref_pseudo_depth > 0) & (masks[0] > 0)
-        if self.mode == "train" and p_mask.sum() > 100:                   # 2048 points un-projected from the pseudo depth (dtu.py:406-419)
-            y, x = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
-            x, y = x[p_mask].type_as(intrs), y[p_mask].type_as(intrs)
-            p_depth = ref_pseudo_depth[p_mask]
-            pick = torch.randint(low=0, high=x.shape[0], size=[2048])
-            x, y, p_depth = x[pick], y[pick], p_depth[pick]
-            xyz_ref = torch.matmul(intrs.inverse()[0, :3, :3], torch.stack((x, y, torch.ones_like(x)), dim=0) * p_depth.unsqueeze(0))
-            xyz_world = torch.matmul(c2ws[0], torch.cat((xyz_ref, torch.ones_like(x).unsqueeze(0)), dim=0))[:3]
-            outputs["pseudo_pts"] = xyz_world.permute(1, 0)
-
-        outputs.update({"rays_o": rays_o, "rays_d": rays_d, "near": near, "far": far, "color": imgs[0][at], "depth": depths[0][at],
-                        "pseudo_depth": ref_pseudo_depth[at], "depth_ref": depths[0], "mask": masks[0][at], "mask_ref": masks[0],
-                        "pseudo_depth_ref": ref_pseudo_depth, "src_idx": src_idx})
-        return outputs
+            px, py = C.lattice_pixels(h, w, lvl)
+            item.update(bound_min=torch.tensor([-1, -1, -1], dtype=torch.float32), bound_max=torch.tensor([1, 1, 1], dtype=torch.float32),
+                        scene=scan, file_name=scan + "_view" + str(ref_view) + "_light" + str(light_idx), hw=torch.Tensor([h // lvl, w // lvl]).int())
+        rays_o, rays_d = C.rays_from_pixels(views.intrs[0], views.c2ws[0], px, py)
+        near, far = views.near_fars[0].reshape(1, 2).split(split_size=1, dim=1)
+        if train:
+            pts = C.unproject_pseudo_points(pseudo, masks[0], views.intrs[0], views.c2ws[0])
+            if pts is not None:
+                item["pseudo_pts"] = pts
+        at = (py.long(), px.long())
+        item.update(rays_o=rays_o, rays_d=rays_d, near=near, far=far, color=imgs[0][at], depth=depths[0][at], pseudo_depth=pseudo[at],
+                    depth_ref=depths[0], mask=masks[0][at], mask_ref=masks[0], pseudo_depth_ref=pseudo, src_idx=src_idx)
+        return item
 
     def __len__(self):
         return len(self.metas)
