@@ -161,9 +161,16 @@ class ImplicitSurface(nn.Module):
             self._sdf_plan = ops.SdfMlpPlan(net)
         return self._sdf_plan
 
-    def _fused_blend_plan(self, views):
-        if not self.fused_blend or torch.is_grad_enabled():
+    def _fused_blend_plan(self, views, features=None, imgs=None):
+        """The packed-weight plan of gens_blend_views, or None when the fused kernel does not apply.  It has no backward: under autograd it
+        runs only if NOTHING on the colour path asks for a gradient (a frozen colour network over frozen feature maps / images)."""
+        if not self.fused_blend:
             return None
+        if torch.is_grad_enabled():
+            wants = any(p.requires_grad for p in self.color_network.parameters())
+            wants = wants or any(t.requires_grad for t in (features or [])) or (imgs is not None and imgs.requires_grad)
+            if wants or features is None:
+                return None
         net = self.color_network
         if not ops.BlendPlan.supported(net) or len(views.feat_tex) > 5 or net.rgb_fc[0].weight.shape[1] != 37:
             return None
@@ -253,7 +260,7 @@ class ImplicitSurface(nn.Module):
 
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
         plan = self._fused_plan(vols) if lean else None
-        bplan = self._fused_blend_plan(scene.views) if lean else None
+        bplan = self._fused_blend_plan(scene.views) if lean else self._fused_blend_plan(scene.views, features, imgs)
         if net is None:                                # training: one fused evaluator for every SDF query of this step
             net = self._train_net(scene, lean)
         sdf_random = extra_sdf = None

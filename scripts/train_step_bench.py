@@ -49,14 +49,16 @@ def _measure(quiet, kernels=False):
     ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": sc["near"].to(dev),
             "far": sc["far"].to(dev), "pseudo_pts": (torch.rand(2048, 3, generator=g) - 0.5).to(dev)}
     target = torch.rand(512, 3, device=dev)
-    opt = torch.optim.Adam(surf.parameters(), lr=5e-4)
+    if "--freeze-color" in sys.argv:             # probe: what the colour network's PyTorch-layer training costs (fine-tune: the feature maps are frozen too)
+        surf.color_network.requires_grad_(False)
+    opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4)
 
     finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
     if finetune:
         with torch.no_grad():
             _, ft_masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
         ft_feats = [f.detach() for f in feats]
-        ft_opt = torch.optim.Adam(list(surf.parameters()) + vols, lr=5e-4)
+        ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4)
 
     def ft_step():
         out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
