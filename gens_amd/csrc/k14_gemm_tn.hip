@@ -106,12 +106,12 @@ extern "C" int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Batched, strided form: up to GEMM_TN_MAX_BATCH products C_p (m_p x n_p) = A_p^T B_p over the SAME K rows in ONE launch, operands
+// Batched, strided form: up to GEMM_TN_MAX_BATCH (12) products C_p (m_p x n_p) = A_p^T B_p over the SAME K rows in ONE launch, operands
 // given with leading dimensions (column blocks of wider row-major buffers: no copies).  The weight-gradient products of the fused
 // training-mode SDF network (K17: seven products over 4 x points rows).  A unit = (slab, tile of one product); consecutive units
 // are the tiles of one slab, so the rows a slab's tiles share are served by L2.  Results: the C_p concatenated in one vector.
 // ---------------------------------------------------------------------------------------------------------------------------
-#define GEMM_TN_MAX_BATCH 8
+#define GEMM_TN_MAX_BATCH 12
 struct GemmTnBatch {
     const float* a[GEMM_TN_MAX_BATCH];
     const float* b[GEMM_TN_MAX_BATCH];

@@ -1,0 +1,584 @@
+// K18: the colour branch of a TRAINING step -- source-view feature look-up (K4) + the IBRNet-style BlendingNetwork -- forward in one
+// launch, backward in one launch (+ one batched K14 launch for the eleven weight gradients), instead of ~250 PyTorch launches.
+//
+// Replaces, in train / fine-tune mode, lookup_feature + compute_angle (/root/reference/models/modules/projector.py:278-349) followed by
+// BlendingNetwork.forward (models/modules/blending_network.py:69-118) as called from implicit_surface.py:196-199, and their autograd
+// backward under loss.backward().  First order only (the colour branch is never differentiated twice).
+//
+// A training step has ~62 000 valid samples x 4 source views: the arithmetic is 10 GFLOP, nothing; what the PyTorch path pays is
+// launches and host time (4.4 ms of a 15 ms fine-tune step).  So this kernel is written for clarity, not for the last TFLOP/s: one
+// wavefront = 32 (point, view) rows, EVERY activation of the rows kept in LDS (61 KB per wave, two waves per CU), every layer on the fp32
+// matrix cores straight from the RAW row-major weights (no packed streams: the weights change every step, and 43 KB of them live in L1 / L2).
+// The backward launch recomputes the forward for its rows (cheaper than a stash), walks the layers in reverse, and leaves for each
+// layer the operand rows of its weight-gradient product: L = cotangent of the pre-activation, R = [input | 1] (the 1 yields the bias
+// gradient), which gens_gemm_tn_batch multiplies over all rows.  The cotangent of the looked-up features goes to K4's own backward
+// (gens_lookup_feature_bwd) when the feature maps / images ask for a gradient.
+#include "k4_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BT_NLAYER 11
+// LDS row strides (odd: conflict-free column walks) of the per-row arrays
+#define BT_S_RD 9
+#define BT_S_D1 17
+#define BT_S_DFE 25
+#define BT_S_H0 73
+#define BT_S_TB 65
+#define BT_S_H 33
+#define BT_S_TV 33
+#define BT_S_HV 37
+#define BT_S_HH 41
+#define BT_S_TU 33
+#define BT_S_T1 17
+#define BT_S_T2 9
+#define BT_S_A 73
+#define BT_S_SC 12
+
+struct BlendRaw {   // raw nn.Linear parameters, row major (out, in)
+    const float *rd1, *rd1b, *rd2, *rd2b;     // ray_dir_fc: 4 -> 16 -> F
+    const float *b1, *b1b, *b2, *b2b;         // base_fc:    3F -> 64 -> 32
+    const float *v1, *v1b, *v2, *v2b;         // vis_fc:     32 -> 32 -> 33
+    const float *u1, *u1b, *u2, *u2b;         // vis_fc2:    32 -> 32 -> 1
+    const float *r1, *r1b, *r2, *r2b, *r3, *r3b;   // rgb_fc: 37 -> 16 -> 8 -> 1
+    const float* s;                           // anti-alias temperature (1)
+};
+
+struct BlendTrainIO {
+    const float4* imgs;
+    const float *w2c, *intr, *c2w;
+    int nv;
+    const float* pts;
+    int64_t n;
+    float* rgb_out;        // forward: (n, 3)
+    uint8_t* vis_out;      // forward: (n, S) or NULL
+    // backward
+    const float* g_rgb;    // (n, 3) cotangent of rgb_out
+    float* R[BT_NLAYER];   // (rows_pad, in_l + 1)
+    float* L[BT_NLAYER];   // (rows_pad, out_l)
+    float* g_feat;         // (n, S, F) cotangent of the looked-up [rgb | features] rows, or NULL
+    float* s_part;         // (waves) partial sums of d loss / d |s|
+};
+
+__device__ __forceinline__ float bt_elu(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
+__device__ __forceinline__ float bt_elu_d(float out) { return out > 0.0f ? 1.0f : out + 1.0f; }    // d elu / d a from the OUTPUT
+__device__ __forceinline__ int bt_crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// One 32 x 32 tile on the matrix cores from an LDS A tile (rows of stride rs, reduction length K) and a RAW weight matrix W (w_out, w_in):
+//   TRANS = false: y[row][n0 + j] = sum_k A[row][k] W[n0 + j][k]      (forward, K = w_in)
+//   TRANS = true : x[row][n0 + j] = sum_k A[row][k] W[k][n0 + j]      (reverse, K = w_out)
+template <bool TRANS>
+__device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, int K, const float* __restrict__ W, int w_out, int w_in, int n0,
+                                          int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int i = lane & 31, half = lane >> 5, n = n0 + i;
+    const int N = TRANS ? w_in : w_out;
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const int k = k0 + half;
+        const bool kin = k < K;
+        const float a = kin ? A[i * rs + k] : 0.0f;
+        float b = 0.0f;
+        if (kin && n < N) b = TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <int NLEV, bool BWD>
+__global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {
+    constexpr int F = 3 + 4 * NLEV, F3 = 3 * F;
+    static_assert(F3 + 1 <= BT_S_A && F3 <= BT_S_H0, "tile too narrow");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* RD = smem;                      // [32][9]   ray difference (4)
+    float* D1 = RD + 32 * BT_S_RD;         // [32][17]  ray_dir_fc hidden (16)
+    float* DFE = D1 + 32 * BT_S_D1;        // [32][25]  direction feature (F)
+    float* H0 = DFE + 32 * BT_S_DFE;       // [32][73]  [mean | var | x]
+    float* TB = H0 + 32 * BT_S_H0;         // [32][65]  base_fc hidden (64)
+    float* H = TB + 32 * BT_S_TB;          // [32][33]  base_fc output (32)
+    float* TV = H + 32 * BT_S_H;           // [32][33]  vis_fc hidden
+    float* HV = TV + 32 * BT_S_TV;         // [32][37]  vis_fc output (33)
+    float* HH = HV + 32 * BT_S_HV;         // [32][41]  [h + res | vis2 | ray difference] (37)
+    float* TU = HH + 32 * BT_S_HH;         // [32][33]  vis_fc2 hidden
+    float* T1 = TU + 32 * BT_S_TU;         // [32][17]  rgb_fc hidden 1
+    float* T2 = T1 + 32 * BT_S_T1;         // [32][9]   rgb_fc hidden 2
+    float* A0 = T2 + 32 * BT_S_T2;         // [32][73]  scratch operand / cotangent tiles
+    float* A1 = A0 + 32 * BT_S_A;          // [32][73]
+    float* SC = A1 + 32 * BT_S_A;          // [32][12]  per row: 0 mask, 1 e, 2 w, 3 vis, 4 vis2, 5 score, 6 p, 7 w_bar, 8 vis_bar, 9 e_bar, 10 dot
+    float* C = SC + 32 * BT_S_SC;          // [32][3]   rgb_in
+    float* GX = C + 32 * 3;                // [32][25]  cotangent of the looked-up [rgb | features] row
+    float* GH = GX + 32 * BT_S_DFE;        // [32][33]  cotangent of h / h + res
+    float* PP = GH + 32 * BT_S_H;          // [32][4]   per point: 0 sum of raw weights, 1 arg-min view, 2 spare, 3 spare
+
+    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5, col = lane & 31;
+    const int S = io.nv - 1, PPW = 32 / S;
+    const int64_t first = (int64_t)blockIdx.x * PPW;
+    const int64_t n = io.n;
+    const int pl = row / S, sv = row % S + 1;
+    const bool live = pl < PPW && first + pl < n;
+    const int64_t src = live ? first + pl : 0;
+    const int64_t grow0 = (int64_t)blockIdx.x * 32;                  // first operand row of this wave
+
+    // ---------------------------------------------------------------- look-up (K4): [rgb | features] of the row into H0[:, 2F..3F)
+    {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (live) { x = io.pts[3 * src]; y = io.pts[3 * src + 1]; z = io.pts[3 * src + 2]; }
+        bool inside = true;
+        const int l_begin = half ? 2 : 0, l_end = half ? NLEV : min(2, NLEV);
+        float* xr = H0 + row * BT_S_H0 + 2 * F;
+        for (int l = l_begin; l < l_end; ++l) {
+            const int h = fs.h[l], w = fs.w[l];
+            SrcProj p = project_src(io.w2c + 16 * sv, io.intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
+            inside = inside && p.inside;
+            float4 f = f4_zero(), c = f4_zero();
+            if (live) {
+                Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+                f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+                if (l == 0) c = sample_texel(io.imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+            }
+            xr[3 + 4 * l] = f.x; xr[4 + 4 * l] = f.y; xr[5 + 4 * l] = f.z; xr[6 + 4 * l] = f.w;
+            if (l == 0) {
+                xr[0] = c.x; xr[1] = c.y; xr[2] = c.z;
+                C[row * 3] = c.x; C[row * 3 + 1] = c.y; C[row * 3 + 2] = c.z;
+            }
+        }
+        const bool other = __shfl_xor((int)inside, 32, 64) != 0;
+        inside = inside && other;
+        if (half == 0) {
+            SC[row * BT_S_SC] = (live && inside) ? 1.0f : 0.0f;
+            if (live && io.vis_out && !BWD) io.vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
+            // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them
+            float rx = io.c2w[3] - x, ry = io.c2w[7] - y, rz = io.c2w[11] - z;
+            const float rn = sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f;
+            rx /= rn; ry /= rn; rz /= rn;
+            const float* cs = io.c2w + 16 * sv;
+            float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
+            const float sn = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
+            sx /= sn; sy /= sn; sz /= sn;
+            const float dx = rx - sx, dy = ry - sy, dz = rz - sz;
+            const float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+            float* rd = RD + row * BT_S_RD;
+            rd[0] = live ? dx / dn : 0.0f;
+            rd[1] = live ? dy / dn : 0.0f;
+            rd[2] = live ? dz / dn : 0.0f;
+            rd[3] = live ? rx * sx + ry * sy + rz * sz : 0.0f;
+        }
+    }
+    __syncthreads();
+
+#define BT_FOR(i, count) for (int i = lane; i < (count); i += 64)
+    // write the operand rows [input | 1] of layer l (width `in`) from an LDS array
+#define BT_STORE_R(l, SRC, stride, in)                                                                       \
+    if (BWD) {                                                                                               \
+        BT_FOR(i_, 32 * ((in) + 1)) {                                                                        \
+            const int r_ = i_ / ((in) + 1), c_ = i_ % ((in) + 1);                                            \
+            io.R[l][(grow0 + r_) * ((in) + 1) + c_] = c_ < (in) ? (SRC)[r_ * (stride) + c_] : 1.0f;          \
+        }                                                                                                    \
+    }
+    // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out
+#define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT)                                             \
+    for (int n0_ = 0; n0_ < (n_out); n0_ += 32) {                                                            \
+        f32x16 acc_ = bt_gemm<false>(IN, s_in, k_in, Wm, n_out, k_in, n0_, lane);                            \
+        const int c_ = n0_ + col;                                                                            \
+        if (c_ < (n_out)) {                                                                                  \
+            const float bias_ = (Bv)[c_];                                                                    \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \
+                const float v_ = acc_[r_] + bias_;                                                           \
+                (OUT)[bt_crow(r_, lane) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;                             \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    // ---------------------------------------------------------------- ray_dir_fc, x = rgb_feat + direction feature (:87-89)
+    BT_STORE_R(0, RD, BT_S_RD, 4)
+    BT_LAYER(RD, BT_S_RD, 4, W.rd1, W.rd1b, 16, D1, BT_S_D1, true)
+    __syncthreads();
+    BT_STORE_R(1, D1, BT_S_D1, 16)
+    BT_LAYER(D1, BT_S_D1, 16, W.rd2, W.rd2b, F, DFE, BT_S_DFE, true)
+    __syncthreads();
+    BT_FOR(i, 32 * F) {
+        const int r = i / F, c = i % F;
+        H0[r * BT_S_H0 + 2 * F + c] += DFE[r * BT_S_DFE + c];
+    }
+    const float s_abs = fabsf(W.s[0]);
+    if (lane < 32) SC[row * BT_S_SC + 1] = expf(s_abs * (RD[row * BT_S_RD + 3] - 1.0f));           // exp(|s| (dot - 1))  (:93)
+    __syncthreads();
+    // ---------------------------------------------------------------- view weights, weighted mean / variance (:94-101)
+    if (lane < 32 && pl < PPW && sv == 1) {                       // one lane per point
+        const int base = pl * S;
+        float mn = 3.4e38f;
+        int arg = 0;
+        for (int v = 0; v < S; ++v) {
+            const float e = SC[(base + v) * BT_S_SC + 1];
+            if (e < mn) { mn = e; arg = v; }
+        }
+        float sum = 0.0f;
+        for (int v = 0; v < S; ++v) sum += (SC[(base + v) * BT_S_SC + 1] - mn) * SC[(base + v) * BT_S_SC];
+        for (int v = 0; v < S; ++v) SC[(base + v) * BT_S_SC + 2] = (SC[(base + v) * BT_S_SC + 1] - mn) * SC[(base + v) * BT_S_SC] / (sum + 1e-8f);
+        PP[pl * 4] = sum;
+        PP[pl * 4 + 1] = (float)arg;
+    }
+    if (lane < 32 && pl >= PPW) SC[row * BT_S_SC + 2] = 0.0f;
+    __syncthreads();
+    BT_FOR(it, PPW * F) {
+        const int p = it / F, c = it % F, base = p * S;
+        float mean = 0.0f, var = 0.0f;
+        for (int v = 0; v < S; ++v) mean += H0[(base + v) * BT_S_H0 + 2 * F + c] * SC[(base + v) * BT_S_SC + 2];
+        for (int v = 0; v < S; ++v) {
+            const float d = H0[(base + v) * BT_S_H0 + 2 * F + c] - mean;
+            var += SC[(base + v) * BT_S_SC + 2] * (d * d);
+        }
+        for (int v = 0; v < S; ++v) {
+            H0[(base + v) * BT_S_H0 + c] = mean;
+            H0[(base + v) * BT_S_H0 + F + c] = var;
+        }
+    }
+    BT_FOR(it, (32 - PPW * S) * 2 * F) {                          // unused rows (32 % S != 0): keep them finite
+        const int rr = PPW * S + it / (2 * F);
+        H0[rr * BT_S_H0 + it % (2 * F)] = 0.0f;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- base_fc (:103-104)
+    BT_STORE_R(2, H0, BT_S_H0, F3)
+    BT_LAYER(H0, BT_S_H0, F3, W.b1, W.b1b, 64, TB, BT_S_TB, true)
+    __syncthreads();
+    BT_STORE_R(3, TB, BT_S_TB, 64)
+    BT_LAYER(TB, BT_S_TB, 64, W.b2, W.b2b, 32, H, BT_S_H, true)
+    __syncthreads();
+    // ---------------------------------------------------------------- vis_fc on h * w (:106-109)
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        A0[r * BT_S_A + c] = H[r * BT_S_H + c] * SC[r * BT_S_SC + 2];
+    }
+    __syncthreads();
+    BT_STORE_R(4, A0, BT_S_A, 32)
+    BT_LAYER(A0, BT_S_A, 32, W.v1, W.v1b, 32, TV, BT_S_TV, true)
+    __syncthreads();
+    BT_STORE_R(5, TV, BT_S_TV, 32)
+    BT_LAYER(TV, BT_S_TV, 32, W.v2, W.v2b, 33, HV, BT_S_HV, true)
+    __syncthreads();
+    if (lane < 32) SC[row * BT_S_SC + 3] = (1.0f / (1.0f + expf(-HV[row * BT_S_HV + 32]))) * SC[row * BT_S_SC];      // vis
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        HH[r * BT_S_HH + c] = H[r * BT_S_H + c] + HV[r * BT_S_HV + c];                                              // x = x + x_res
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- vis_fc2 on x * vis (:110)
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        A0[r * BT_S_A + c] = HH[r * BT_S_HH + c] * SC[r * BT_S_SC + 3];
+    }
+    __syncthreads();
+    BT_STORE_R(6, A0, BT_S_A, 32)
+    BT_LAYER(A0, BT_S_A, 32, W.u1, W.u1b, 32, TU, BT_S_TU, true)
+    __syncthreads();
+    BT_STORE_R(7, TU, BT_S_TU, 32)
+    if (lane < 32) {
+        float q = W.u2b[0];
+        for (int k = 0; k < 32; ++k) q += TU[row * BT_S_TU + k] * W.u2[k];
+        const float v2 = (1.0f / (1.0f + expf(-q))) * SC[row * BT_S_SC];
+        SC[row * BT_S_SC + 4] = v2;
+        float* hh = HH + row * BT_S_HH;
+        hh[32] = v2;
+        hh[33] = RD[row * BT_S_RD]; hh[34] = RD[row * BT_S_RD + 1]; hh[35] = RD[row * BT_S_RD + 2]; hh[36] = RD[row * BT_S_RD + 3];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
+    BT_STORE_R(8, HH, BT_S_HH, 37)
+    BT_LAYER(HH, BT_S_HH, 37, W.r1, W.r1b, 16, T1, BT_S_T1, true)
+    __syncthreads();
+    BT_STORE_R(9, T1, BT_S_T1, 16)
+    BT_LAYER(T1, BT_S_T1, 16, W.r2, W.r2b, 8, T2, BT_S_T2, true)
+    __syncthreads();
+    BT_STORE_R(10, T2, BT_S_T2, 8)
+    if (lane < 32) {
+        float sc = W.r3b[0];
+        for (int k = 0; k < 8; ++k) sc += T2[row * BT_S_T2 + k] * W.r3[k];
+        SC[row * BT_S_SC + 5] = (SC[row * BT_S_SC] == 0.0f) ? -1e9f : sc;                  // masked_fill(mask == 0, -1e9)  (:115)
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- softmax over views, colour (:116-117)
+    if (lane < PPW && first + lane < n) {
+        const int base = lane * S;
+        float mx = -3.4e38f;
+        for (int v = 0; v < S; ++v) mx = fmaxf(mx, SC[(base + v) * BT_S_SC + 5]);
+        float den = 0.0f;
+        for (int v = 0; v < S; ++v) den += expf(SC[(base + v) * BT_S_SC + 5] - mx);
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        for (int v = 0; v < S; ++v) {
+            const float p = expf(SC[(base + v) * BT_S_SC + 5] - mx) / den;
+            SC[(base + v) * BT_S_SC + 6] = p;
+            cr += C[(base + v) * 3] * p;
+            cg += C[(base + v) * 3 + 1] * p;
+            cb += C[(base + v) * 3 + 2] * p;
+        }
+        if (!BWD) {
+            io.rgb_out[3 * (first + lane)] = cr;
+            io.rgb_out[3 * (first + lane) + 1] = cg;
+            io.rgb_out[3 * (first + lane) + 2] = cb;
+        }
+    }
+    if constexpr (!BWD) return;
+    __syncthreads();
+
+    // ================================================================ reverse
+    // store the cotangent rows of layer l's pre-activation (width out) from an LDS tile
+#define BT_STORE_L(l, SRC, stride, out)                                                                      \
+    BT_FOR(i_, 32 * (out)) {                                                                                 \
+        const int r_ = i_ / (out), c_ = i_ % (out);                                                          \
+        io.L[l][(grow0 + r_) * (out) + c_] = (SRC)[r_ * (stride) + c_];                                      \
+    }
+    // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
+#define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY)                                              \
+    for (int n0_ = 0; n0_ < (n_in); n0_ += 32) {                                                             \
+        f32x16 acc_ = bt_gemm<true>(IN, s_in, k_out, Wm, k_out, n_in, n0_, lane);                            \
+        const int c_ = n0_ + col;                                                                            \
+        if (c_ < (n_in)) {                                                                                   \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \
+                const int rr_ = bt_crow(r_, lane);                                                           \
+                const float xb_ = acc_[r_];                                                                  \
+                BODY                                                                                         \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    // colour = sum_v rgb_in p_v: score_bar = p (p_bar - sum_u p_u p_bar_u), rgb_in_bar = g p
+    if (lane < 32) {
+        float sb = 0.0f;
+        float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;
+        if (live) {
+            const float g0 = io.g_rgb[3 * src], g1 = io.g_rgb[3 * src + 1], g2 = io.g_rgb[3 * src + 2];
+            const int base = pl * S;
+            float dot = 0.0f;
+            for (int v = 0; v < S; ++v)
+                dot += SC[(base + v) * BT_S_SC + 6] * (g0 * C[(base + v) * 3] + g1 * C[(base + v) * 3 + 1] + g2 * C[(base + v) * 3 + 2]);
+            const float p = SC[row * BT_S_SC + 6];
+            sb = p * ((g0 * C[row * 3] + g1 * C[row * 3 + 1] + g2 * C[row * 3 + 2]) - dot);
+            gx0 = g0 * p; gx1 = g1 * p; gx2 = g2 * p;
+        }
+        A1[row * BT_S_A] = sb;                                   // cotangent of the score = L of rgb_fc.4
+        GX[row * BT_S_DFE] = gx0; GX[row * BT_S_DFE + 1] = gx1; GX[row * BT_S_DFE + 2] = gx2;
+        for (int c = 3; c < F; ++c) GX[row * BT_S_DFE + c] = 0.0f;
+        SC[row * BT_S_SC + 7] = 0.0f;                            // w_bar
+    }
+    __syncthreads();
+    BT_STORE_L(10, A1, BT_S_A, 1)
+    // rgb_fc.4 -> rgb_fc.2 pre-activation
+    BT_FOR(i, 32 * 8) {
+        const int r = i >> 3, c = i & 7;
+        A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.r3[c] * bt_elu_d(T2[r * BT_S_T2 + c]);
+    }
+    __syncthreads();
+    BT_STORE_L(9, A0, BT_S_A, 8)
+    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);)
+    __syncthreads();
+    BT_STORE_L(8, A1, BT_S_A, 16)
+    // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]: cotangent of h2 -> GH, of vis2 -> SC[8]
+    BT_REVERSE(A1, BT_S_A, 16, W.r1, 37, GH, BT_S_H,
+               if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;)
+    __syncthreads();
+    // vis2 = sigmoid(q) mask ; q = u2 . tu + b
+    if (lane < 32) {
+        const float v2 = SC[row * BT_S_SC + 4];
+        A1[row * BT_S_A] = SC[row * BT_S_SC + 8] * SC[row * BT_S_SC] * v2 * (1.0f - v2);       // q_bar (mask is 0 or 1: vis2 = sigmoid there)
+    }
+    __syncthreads();
+    BT_STORE_L(7, A1, BT_S_A, 1)
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.u2[c] * bt_elu_d(TU[r * BT_S_TU + c]);
+    }
+    __syncthreads();
+    BT_STORE_L(6, A0, BT_S_A, 32)
+    // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
+    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;)
+    __syncthreads();
+    if (lane < 32) {
+        float vb = 0.0f;
+        for (int k = 0; k < 32; ++k) vb += A1[row * BT_S_A + k] * HH[row * BT_S_HH + k];
+        const float vis = SC[row * BT_S_SC + 3];
+        SC[row * BT_S_SC + 8] = vb * SC[row * BT_S_SC] * vis * (1.0f - vis);                    // cotangent of hv[32] before its ELU
+    }
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        GH[r * BT_S_H + c] += A1[r * BT_S_A + c] * SC[r * BT_S_SC + 3];
+    }
+    __syncthreads();
+    // h2 = h + hv[:32]: hv_bar[:32] = h_bar = GH ; vis = sigmoid(hv[32]) mask
+    BT_FOR(i, 32 * 33) {
+        const int r = i / 33, c = i % 33;
+        const float g = c < 32 ? GH[r * BT_S_H + c] : SC[r * BT_S_SC + 8];
+        A0[r * BT_S_A + c] = g * bt_elu_d(HV[r * BT_S_HV + c]);
+    }
+    __syncthreads();
+    BT_STORE_L(5, A0, BT_S_A, 33)
+    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);)
+    __syncthreads();
+    BT_STORE_L(4, A1, BT_S_A, 32)
+    // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
+    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;)
+    __syncthreads();
+    if (lane < 32) {
+        float wb = 0.0f;
+        for (int k = 0; k < 32; ++k) wb += A0[row * BT_S_A + k] * H[row * BT_S_H + k];
+        SC[row * BT_S_SC + 7] += wb;
+    }
+    BT_FOR(i, 32 * 32) {
+        const int r = i >> 5, c = i & 31;
+        const float hb = GH[r * BT_S_H + c] + A0[r * BT_S_A + c] * SC[r * BT_S_SC + 2];
+        A1[r * BT_S_A + c] = hb * bt_elu_d(H[r * BT_S_H + c]);                                   // base_fc.2 pre-activation
+    }
+    __syncthreads();
+    BT_STORE_L(3, A1, BT_S_A, 32)
+    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);)
+    __syncthreads();
+    BT_STORE_L(2, A0, BT_S_A, 64)
+    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;)                // cotangent of [mean | var | x]
+    __syncthreads();
+    // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
+    BT_FOR(it, PPW * F) {
+        const int p = it / F, c = it % F, base = p * S;
+        float mb = 0.0f, vb = 0.0f, cross = 0.0f;
+        const float mean = H0[base * BT_S_H0 + c];
+        for (int v = 0; v < S; ++v) {
+            mb += A1[(base + v) * BT_S_A + c];
+            vb += A1[(base + v) * BT_S_A + F + c];
+            cross += SC[(base + v) * BT_S_SC + 2] * (H0[(base + v) * BT_S_H0 + 2 * F + c] - mean);
+        }
+        mb -= 2.0f * vb * cross;                                                                 // var depends on mean too
+        for (int v = 0; v < S; ++v) {
+            const float xv = H0[(base + v) * BT_S_H0 + 2 * F + c], w = SC[(base + v) * BT_S_SC + 2], d = xv - mean;
+            const float xb = A1[(base + v) * BT_S_A + 2 * F + c] + w * mb + 2.0f * w * d * vb;
+            GX[(base + v) * BT_S_DFE + c] += xb;
+            A0[(base + v) * BT_S_A + c] = xb * bt_elu_d(DFE[(base + v) * BT_S_DFE + c]);         // ray_dir_fc.2 pre-activation
+            atomicAdd(&SC[(base + v) * BT_S_SC + 7], mb * xv + vb * d * d);                      // w_bar (LDS)
+        }
+    }
+    BT_FOR(it, (32 - PPW * S) * F) {
+        const int rr = PPW * S + it / F;
+        A0[rr * BT_S_A + it % F] = 0.0f;
+    }
+    __syncthreads();
+    // w = wr / (sum wr + 1e-8), wr = (e - min e) mask, e = exp(|s| (dot - 1))
+    float s_bar = 0.0f;
+    if (lane < 32 && pl < PPW && sv == 1 && first + pl < n) {
+        const int base = pl * S;
+        const float sum = PP[pl * 4] + 1e-8f;
+        const int arg = (int)PP[pl * 4 + 1];
+        float ww = 0.0f;
+        for (int v = 0; v < S; ++v) ww += SC[(base + v) * BT_S_SC + 7] * SC[(base + v) * BT_S_SC + 2];
+        float tot = 0.0f;
+        for (int v = 0; v < S; ++v) {
+            const float wrb = (SC[(base + v) * BT_S_SC + 7] - ww) / sum * SC[(base + v) * BT_S_SC];     // wr_bar mask
+            SC[(base + v) * BT_S_SC + 9] = wrb;
+            tot += wrb;
+        }
+        SC[(base + arg) * BT_S_SC + 9] -= tot;                                                   // the minimum's share
+        for (int v = 0; v < S; ++v)
+            s_bar += SC[(base + v) * BT_S_SC + 9] * SC[(base + v) * BT_S_SC + 1] * (RD[(base + v) * BT_S_RD + 3] - 1.0f);
+    }
+    s_bar = wave_sum(s_bar);
+    if (lane == 0) io.s_part[blockIdx.x] = s_bar;
+    BT_STORE_L(1, A0, BT_S_A, F)
+    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);)
+    __syncthreads();
+    BT_STORE_L(0, A1, BT_S_A, 16)
+    if (io.g_feat) {
+        BT_FOR(i, PPW * S * F) {
+            const int r = i / F, c = i % F;
+            const int64_t pt = first + r / S;
+            if (pt < n) io.g_feat[(pt * S + r % S) * F + c] = GX[r * BT_S_DFE + c];
+        }
+    }
+#undef BT_FOR
+#undef BT_STORE_R
+#undef BT_STORE_L
+#undef BT_LAYER
+#undef BT_REVERSE
+}
+
+// ====================================================================================================================
+int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels);
+
+static constexpr size_t bt_lds_bytes() {
+    return sizeof(float) * 32 * (BT_S_RD + BT_S_D1 + BT_S_DFE + BT_S_H0 + BT_S_TB + BT_S_H + BT_S_TV + BT_S_HV + BT_S_HH + BT_S_TU + BT_S_T1 + BT_S_T2 +
+                                 2 * BT_S_A + BT_S_SC + 3 + BT_S_DFE + BT_S_H + 4);
+}
+
+static int bt_fill(const char* who, BlendRaw* W, const float* const* w) {
+    GENS_CHECK_ARG(w, GENS_EINVAL, "%s: null weight table", who);
+    for (int k = 0; k < 23; ++k) GENS_CHECK_ARG(w[k], GENS_EINVAL, "%s: weight %d is null", who, k);
+    W->rd1 = w[0]; W->rd1b = w[1]; W->rd2 = w[2]; W->rd2b = w[3];
+    W->b1 = w[4]; W->b1b = w[5]; W->b2 = w[6]; W->b2b = w[7];
+    W->v1 = w[8]; W->v1b = w[9]; W->v2 = w[10]; W->v2b = w[11];
+    W->u1 = w[12]; W->u1b = w[13]; W->u2 = w[14]; W->u2b = w[15];
+    W->r1 = w[16]; W->r1b = w[17]; W->r2 = w[18]; W->r2b = w[19]; W->r3 = w[20]; W->r3b = w[21];
+    W->s = w[22];
+    return 0;
+}
+
+template <bool BWD>
+static int bt_launch(const char* who, const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                     const float* c2w, int nv, const float* const* weights, BlendTrainIO io, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats, GENS_EINVAL, "%s: null table", who);
+    if (int e = gens_fill_maps(who, &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "%s: 1..5 feature levels (d_feature <= 20), got %d", who, n_levels);
+    GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "%s: nv=%d not in 2..%d", who, nv, GENS_MAX_VIEWS);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "%s: null camera / image pointer", who);
+    BlendRaw W;
+    if (int e = bt_fill(who, &W, weights)) return e;
+    io.imgs = (const float4*)imgs;
+    io.w2c = w2c; io.intr = intr; io.c2w = c2w; io.nv = nv;
+    const int ppw = 32 / (nv - 1);
+    const unsigned grid = gens_blocks(io.n, ppw);
+    hipStream_t st = (hipStream_t)stream;
+    static bool once[6][2] = {};
+#define BT_LAUNCH(NL)                                                                                                              \
+    {                                                                                                                              \
+        if (!once[NL][BWD]) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)blend_train_k<NL, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_lds_bytes()); \
+            once[NL][BWD] = true;                                                                                                  \
+        }                                                                                                                          \
+        blend_train_k<NL, BWD><<<grid, 64, bt_lds_bytes(), st>>>(W, fs, io);                                                       \
+    }
+    switch (n_levels) {
+        case 1: BT_LAUNCH(1) break;
+        case 2: BT_LAUNCH(2) break;
+        case 3: BT_LAUNCH(3) break;
+        case 4: BT_LAUNCH(4) break;
+        default: BT_LAUNCH(5) break;
+    }
+#undef BT_LAUNCH
+    return gens_launch_status(who);
+}
+
+extern "C" int64_t gens_blend_train_rows(int64_t n, int nv) {
+    if (n <= 0 || nv < 2) return 0;
+    return (int64_t)gens_blocks(n, 32 / (nv - 1)) * 32;
+}
+
+extern "C" int gens_blend_train_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                    const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, float* rgb_out,
+                                    uint8_t* vis_out, void* stream) {
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_train_fwd: null pts / output");
+    if (n == 0) return 0;
+    BlendTrainIO io = {};
+    io.pts = pts; io.n = n; io.rgb_out = rgb_out; io.vis_out = vis_out;
+    return bt_launch<false>("gens_blend_train_fwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
+}
+
+extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                    const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, const float* g_rgb,
+                                    float* const* r_ops, float* const* l_ops, float* g_feat, float* s_part, void* stream) {
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_rgb && r_ops && l_ops && s_part)), GENS_EINVAL, "gens_blend_train_bwd: null pointer");
+    if (n == 0) return 0;
+    BlendTrainIO io = {};
+    io.pts = pts; io.n = n; io.g_rgb = g_rgb; io.g_feat = g_feat; io.s_part = s_part;
+    for (int l = 0; l < BT_NLAYER; ++l) {
+        GENS_CHECK_ARG(r_ops[l] && l_ops[l], GENS_EINVAL, "gens_blend_train_bwd: operand buffer %d is null", l);
+        io.R[l] = r_ops[l];
+        io.L[l] = l_ops[l];
+    }
+    return bt_launch<true>("gens_blend_train_bwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
+}

@@ -89,6 +89,8 @@ SIGNATURES = {
     "gens_mc_emit": [_p, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp_dev": [_pp, _ip, _i, _pp, _pp, _p, _p, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_blend_train_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _p, _p],
+    "gens_blend_train_bwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _pp, _pp, _p, _p, _p],
     "gens_sdf_train_pack": [_pp, _pp, _i, _pp, _pp, _p],
     "gens_sdf_train_fwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -116,6 +118,8 @@ def load():
     lib.gens_tv_blocks.argtypes = [_l]
     lib.gens_sdf_train_stash_bytes.restype = _l
     lib.gens_sdf_train_stash_bytes.argtypes = [_l, _i]
+    lib.gens_blend_train_rows.restype = _l
+    lib.gens_blend_train_rows.argtypes = [_l, _i]
     lib.gens_gemm_tn_batch_workspace.restype = _l
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
     for name, args in SIGNATURES.items():

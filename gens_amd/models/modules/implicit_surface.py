@@ -302,6 +302,11 @@ class ImplicitSurface(nn.Module):
                 smooth = None if smooth_v is None else torch.zeros(b * n, 3, device=dev).index_put((idx,), smooth_v)
             if bplan is not None:                      # K4 + colour network fused, scattered into the dense arrays
                 sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx)
+            elif (self.fused_train and torch.is_grad_enabled() and ops.BlendPlan.supported(self.color_network) and len(scene.views.feat_tex) <= 5
+                  and self.color_network.ray_dir_fc[2].weight.shape[0] == 3 + 4 * len(scene.views.feat_tex)):
+                color_v, vis_v = ops.blend_train(self.color_network, scene.views, pts_v)      # K18: forward / backward in one launch each
+                sampled_color = torch.zeros(b * n, 3, device=dev).index_put((idx,), color_v)
+                src_vis = torch.zeros(b * n, vis_v.shape[1], dtype=torch.bool, device=dev).index_put((idx,), vis_v)
             else:
                 feat_views, ray_diff, vis_v = lookup_feature(pts_v, imgs, intrs, c2ws, features, views=scene.views)
                 color_v = self.color_network(feat_views, ray_diff, vis_v)

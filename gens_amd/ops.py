@@ -1208,3 +1208,93 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
            L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
            L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
     return rgb_out, vis_out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K18  lookup_feature + BlendingNetwork of a training step, forward and backward   (projector.py:278-349, blending_network.py:69-118)
+# ------------------------------------------------------------------------------------------------------------------
+def blend_params(net):
+    """The 23 raw parameters of a BlendingNetwork in the order gens_blend_train_* read them."""
+    mods = [net.ray_dir_fc[0], net.ray_dir_fc[2], net.base_fc[0], net.base_fc[2], net.vis_fc[0], net.vis_fc[2], net.vis_fc2[0], net.vis_fc2[2],
+            net.rgb_fc[0], net.rgb_fc[2], net.rgb_fc[4]]
+    out = []
+    for m in mods:
+        out += [m.weight, m.bias]
+    return out + [net.s]
+
+
+class _BlendTrain(torch.autograd.Function):
+    """(pts, views, *23 parameters, imgs_tex, *feat_tex) -> (rgb (N,3), vis (N,S) uint8).  Backward: one launch that recomputes the forward
+    of its rows and walks the layers in reverse, one batched K14 launch for the eleven [dW | db], K4's backward for the maps."""
+
+    @staticmethod
+    def forward(ctx, pts, views, *tensors):
+        params, imgs_tex, feat_tex = tensors[:23], tensors[23], tensors[24:]
+        n, s, nl = pts.shape[0], views.nv - 1, len(feat_tex)
+        dev = pts.device
+        w = [_c(p.detach().to(_f32)).reshape(-1) if p.dim() == 0 else _c(p.detach().to(_f32)) for p in params]
+        feats = [aligned16(f.detach()) for f in feat_tex]
+        imgs = aligned16(imgs_tex.detach())
+        hw = [d for f in feats for d in f.shape[1:3]]
+        rgb = torch.empty(n, 3, device=dev, dtype=_f32)
+        vis = torch.empty(n, s, device=dev, dtype=torch.uint8)
+        f = 3 + 4 * nl
+        flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
+        ctx.args = (L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(imgs, align=16), L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w),
+                    views.nv, L.ptr_table(w), L.ptr(pts), n)
+        ctx.keep = (feats, imgs, w, views, pts, hw)
+        ctx.meta = (n, s, nl, f, flops, [p.shape for p in params], [t.shape for t in feat_tex], imgs_tex.shape)
+        L.call("gens_blend_train_fwd", *ctx.args, L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(), nbytes=n * (24 + s), flops=n * flops)
+        ctx.mark_non_differentiable(vis)
+        return rgb, vis
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb, _g_vis):
+        n, s, nl, f, flops, pshapes, fshapes, ishape = ctx.meta
+        feats, imgs, w, views, pts, hw = ctx.keep
+        dev = pts.device
+        rows = L.load().gens_blend_train_rows(n, views.nv)
+        ins = [4, 16, 3 * f, 64, 32, 32, 32, 32, 37, 16, 8]
+        outs = [16, f, 64, 32, 32, 33, 32, 1, 16, 8, 1]
+        e = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
+        r_ops = [e(rows, k + 1) for k in ins]
+        l_ops = [e(rows, m) for m in outs]
+        want_maps = any(ctx.needs_input_grad[2 + 23:])
+        g_feat = e(n, s, f) if want_maps else None
+        s_part = e(rows // 32)
+        L.call("gens_blend_train_bwd", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr_table(r_ops), L.ptr_table(l_ops), L.ptr(g_feat), L.ptr(s_part),
+               L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops)
+        # [dW_l | db_l] = l_ops[l]^T r_ops[l]: eleven products over the same rows in one launch
+        ms, ns = outs, [k + 1 for k in ins]
+        mi, ni = L.int_table(ms), L.int_table(ns)
+        ws = e(L.load().gens_gemm_tn_batch_workspace(11, mi, ni, rows))
+        cc = e(sum(m * k for m, k in zip(ms, ns)))
+        L.call("gens_gemm_tn_batch", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(ws), L.ptr(cc), L.stream(),
+               nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)))
+        grads, off = [], 0
+        for l, (m, k) in enumerate(zip(ms, ns)):
+            c = cc[off:off + m * k].view(m, k)
+            off += m * k
+            grads += [c[:, :k - 1].reshape(pshapes[2 * l]), c[:, k - 1].reshape(pshapes[2 * l + 1])]
+        s_sign = torch.sign(w[22]).reshape(pshapes[22])
+        grads.append(s_sign * s_part.sum())
+        g_imgs, g_feats = None, [None] * nl
+        if want_maps:
+            want_img = ctx.needs_input_grad[2 + 23]
+            want_feat = any(ctx.needs_input_grad[2 + 24:])
+            g_feats_t = [torch.zeros(sh, device=dev, dtype=_f32) for sh in fshapes] if want_feat else None
+            g_imgs = torch.zeros(ishape, device=dev, dtype=_f32) if want_img else None
+            L.call("gens_lookup_feature_bwd", L.int_table(hw), nl, L.ptr(views.w2c), L.ptr(views.intr), views.nv, L.ptr(pts), L.ptr(g_feat), n,
+                   L.ptr_table(g_feats_t), L.ptr(g_imgs), L.stream())
+            if want_feat:
+                g_feats = g_feats_t
+        return (None, None, *grads, g_imgs, *g_feats)
+
+
+def blend_train(net, views, pts):
+    """Colour of every point blended from the source views, differentiable with respect to the network and the maps:
+    -> (rgb (N,3), vis (N,S) bool).  pts (N,3) device float32 (no gradient flows to the points, as in the reference's call)."""
+    pts = _c(pts.detach().reshape(-1, 3).to(_f32))
+    rgb, vis = _BlendTrain.apply(pts, views, *blend_params(net), views.imgs_tex, *views.feat_tex)
+    return rgb, vis.bool()

@@ -283,6 +283,28 @@ int gens_blend_views(const float* const* feats, const int* hw, int n_levels, con
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K18  lookup_feature + BlendingNetwork.forward of a training / fine-tune step, and their backward
+ *      (projector.py:278-349, blending_network.py:69-118 as called from implicit_surface.py:196-199; first order only)
+ *   feats / hw / imgs / w2c / intr / c2w / nv as in gens_lookup_feature_fwd (n_levels <= 5).
+ *   weights: HOST array of 23 device pointers to the RAW nn.Linear parameters (row major (out, in)) in the order
+ *     ray_dir_fc.0 W,b  ray_dir_fc.2 W,b  base_fc.0 W,b  base_fc.2 W,b  vis_fc.0 W,b  vis_fc.2 W,b  vis_fc2.0 W,b  vis_fc2.2 W,b
+ *     rgb_fc.0 W,b  rgb_fc.2 W,b  rgb_fc.4 W,b  s
+ *   fwd: pts (n, 3) -> rgb_out (n, 3), vis_out (n, S) uint8 (NULL to skip).
+ *   bwd: g_rgb (n, 3) cotangent of rgb_out -> for each of the 11 layers the operand rows of its weight-gradient product over
+ *     rows = gens_blend_train_rows(n, nv) = 32 ceil(n / floor(32 / S)):  r_ops[l] (rows, in_l + 1) = [layer input | 1],
+ *     l_ops[l] (rows, out_l) = cotangent of the pre-activation:  [dW_l | db_l] = l_ops[l]^T r_ops[l]   (gens_gemm_tn_batch);
+ *     g_feat (n, S, 3 + 4 n_levels): cotangent of the looked-up rows for gens_lookup_feature_bwd (NULL to skip);
+ *     s_part (rows / 32): partial sums of d loss / d |s|.
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t gens_blend_train_rows(int64_t n, int nv);
+int gens_blend_train_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                         const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, float* rgb_out,
+                         uint8_t* vis_out, void* stream);
+int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                         const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, const float* g_rgb,
+                         float* const* r_ops, float* const* l_ops, float* g_feat, float* s_part, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)
  *   image (H, W, C_pad) texels of one view; xy (P, 2) PIXEL coordinates (the normalise/un-normalise pair of
  *   :404-405 and align_corners=True cancel); out (P, C).  bwd: g_out (P, C) -> g_xy (P, 2), overwritten.
@@ -356,7 +378,7 @@ int gens_lattice_points(const float* bmin3_host, const float* bmax3_host, int re
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_gemm_tn_slabs(int64_t k, int m, int n);
 int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float* workspace, float* c, void* stream);
-/* Up to 8 products C_p (m_p x n_p) = A_p^T B_p over the same k rows in one launch; A_p / B_p are column blocks of row-major buffers
+/* Up to 12 products C_p (m_p x n_p) = A_p^T B_p over the same k rows in one launch; A_p / B_p are column blocks of row-major buffers
  * with leading dimensions lda[p] / ldb[p] (HOST arrays of device pointers / ints).  c: the C_p concatenated (row major each).
  * workspace: gens_gemm_tn_batch_workspace(count, m, n, k) floats.  Partial sums are added in a fixed order (deterministic). */
 int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const int* n, int64_t k);

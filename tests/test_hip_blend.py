@@ -61,3 +61,48 @@ def test_fused_blend_matches_the_cpu_oracle(nv, n):
     assert torch.equal(vis.bool().cpu(), mk)
     err = (rgb.cpu() - ref)[live].abs().max()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("nv,n_levels,n", [(5, 5, 203), (3, 5, 50), (4, 3, 64), (5, 5, 5)])
+def test_training_kernels_match_the_cpu_oracle(nv, n_levels, n):
+    """K18 (gens_blend_train_fwd / _bwd + the batched weight-gradient products + K4's backward for the maps) against autograd over the
+    CPU oracle (oracle.gens_oracle.lookup_feature + oracle.render_oracle.blend_mlp): colours, and the gradient of a random linear
+    functional of them with respect to every parameter of the network, the feature pyramid and the images."""
+    from oracle import gens_oracle as K
+    from oracle import render_oracle as R
+    from gens_amd import synthetic
+    ops, net, views, pts = _setup(nv, n_levels, seed=50 + nv, n=n)
+    sc = synthetic.make_scene(nv=nv, h=48, w=64, n_levels=n_levels, seed=50 + nv)
+    g = torch.Generator().manual_seed(3)
+    cot = torch.randn(n, 3, generator=g)
+    # oracle
+    sd = {"color_network." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    feats_c = [f.clone().requires_grad_(True) for f in sc["features"]]
+    imgs_c = sc["imgs"].clone().requires_grad_(True)
+    fv, rd, mk = K.lookup_feature(pts.cpu(), imgs_c, sc["intrs"], sc["c2ws"], feats_c)
+    ref = R.blend_mlp(sd, torch.nan_to_num(fv), torch.nan_to_num(rd), mk)
+    live = mk.any(1)
+    (ref[live] * cot[live]).sum().backward()
+    # device: maps with gradients
+    feats_d = [f.cuda().requires_grad_(True) for f in sc["features"]]
+    imgs_d = sc["imgs"].cuda().requires_grad_(True)
+    views = ops.SceneViews(imgs_d, sc["intrs"].cuda(), sc["c2ws"].cuda(), feats_d)
+    rgb, vis = ops.blend_train(net, views, pts)
+    assert torch.equal(vis.cpu(), mk)
+    assert (rgb.cpu() - ref.detach())[live].abs().max() < 3e-5
+    (rgb[live.cuda()] * cot.cuda()[live.cuda()]).sum().backward()
+    worst = {}
+    top = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        r = sd["color_network." + k].grad
+        worst[k] = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-4 * top)
+    for i in range(n_levels):
+        worst[f"feat{i}"] = float((feats_d[i].grad.cpu() - feats_c[i].grad).abs().max()) / max(float(feats_c[i].grad.abs().max()), 1e-6)
+    worst["imgs"] = float((imgs_d.grad.cpu() - imgs_c.grad).abs().max()) / max(float(imgs_c.grad.abs().max()), 1e-6)
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    print("s:", float(net.s.grad), float(sd["color_network.s"].grad), "largest parameter gradient", top)
+    # the anti-alias temperature's gradient is a sum of cancelling per-sample terms, three to five orders of magnitude below the other
+    # gradients: its float32 round-off is judged against THEIR scale
+    worst.pop("s")
+    assert abs(float(net.s.grad) - float(sd["color_network.s"].grad)) < 3e-5 * top
+    assert max(worst.values()) < 2e-3, worst
