@@ -173,19 +173,91 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, in
     }
 }
 
+// Register-blocked form of the batched kernel for EVEN m, n, lda, ldb (8-byte aligned operands): a unit is a 64 x 64 block of C = 2 x 2
+// MFMA tiles whose rows / columns INTERLEAVE (tile a holds rows m0 + 2 i + a), so one 8-byte load per operand and lane feeds four
+// v_mfma_f32_32x32x2_f32 -- 0.5 load instructions per MFMA instead of 2 (the 32 x 32 kernel is bound by load issue: 1.7 TB/s).
+__global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int tiles = B.tile0[B.count];
+    const int64_t s = unit / tiles;
+    int t = (int)(unit % tiles);
+    int p = 0;
+    while (p + 1 < B.count && t >= B.tile0[p + 1]) ++p;
+    t -= B.tile0[p];
+    const int m = B.m[p], n = B.n[p], lda = B.lda[p], ldb = B.ldb[p];
+    const int nt = (n + 63) >> 6;
+    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int m0 = (t / nt) << 6, n0 = (t % nt) << 6;
+    const bool am = m0 + 2 * i < m, bn = n0 + 2 * i < n;               // (m, n even: a pair is inside or outside as a whole)
+    const float2* ap = (const float2*)(B.a[p] + (k_begin + h) * lda + (am ? m0 + 2 * i : 0));
+    const float2* bp = (const float2*)(B.b[p] + (k_begin + h) * ldb + (bn ? n0 + 2 * i : 0));
+    const int64_t sa = lda, sb = ldb;                                   // row strides in floats = 2 x (stride in float2) per 2 rows
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    int64_t k = k_begin;
+    for (; k + 8 <= k_end; k += 8) {                                    // four row pairs per trip, their eight loads issued together
+        float2 av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            av[q] = ap[(int64_t)q * sa];                                // rows k + 2 q + h  (a float2 pointer advances 2 floats per unit)
+            bv[q] = bp[(int64_t)q * sb];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a0 = am ? av[q].x : 0.0f, a1 = am ? av[q].y : 0.0f, b0 = bn ? bv[q].x : 0.0f, b1 = bn ? bv[q].y : 0.0f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        ap += 4 * sa;
+        bp += 4 * sb;
+    }
+    for (; k < k_end; k += 2) {
+        const bool row = k + h < k_end;
+        float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
+        if (am && row) av = ap[0];
+        if (bn && row) bv = bp[0];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+        ap += sa;
+        bp += sb;
+    }
+    if (bn) {
+        float* w = ws + s * B.csz + B.off[p];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+                if (row < m) *(float2*)(w + (int64_t)row * n + n0 + 2 * i) = make_float2(acc[a][0][r], acc[a][1][r]);
+            }
+    }
+}
+
 static int64_t gemm_tn_batch_slab(int64_t k, int64_t tiles) {
     int64_t slab = (k * tiles + 8191) / 8192;
     slab = (slab + 15) / 16 * 16;
     return slab < 64 ? 64 : slab;
 }
 
-static int gemm_tn_batch_layout(int count, const int* m, const int* n, int64_t* tiles, int64_t* csz) {
+static int gemm_tn_batch_layout(int count, const int* m, const int* n, int64_t* tiles, int64_t* csz, int tile = 32) {
     *tiles = 0;
     *csz = 0;
     if (count <= 0 || count > GEMM_TN_MAX_BATCH || !m || !n) return -1;
     for (int p = 0; p < count; ++p) {
         if (m[p] <= 0 || n[p] <= 0 || m[p] > 1024 || n[p] > 1024) return -1;
-        *tiles += (int64_t)((m[p] + 31) / 32) * ((n[p] + 31) / 32);
+        *tiles += (int64_t)((m[p] + tile - 1) / tile) * ((n[p] + tile - 1) / tile);
         *csz += (int64_t)m[p] * n[p];
     }
     return 0;
@@ -193,10 +265,11 @@ static int gemm_tn_batch_layout(int count, const int* m, const int* n, int64_t* 
 
 // floats of workspace a gens_gemm_tn_batch call needs
 extern "C" int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const int* n, int64_t k) {
-    int64_t tiles, csz;
-    if (k <= 0 || gemm_tn_batch_layout(count, m, n, &tiles, &csz)) return 0;
-    const int64_t slab = gemm_tn_batch_slab(k, tiles);
-    return ((k + slab - 1) / slab + GEMM_TN_GROUPS) * csz;
+    int64_t tiles, tiles64, csz;
+    if (k <= 0 || gemm_tn_batch_layout(count, m, n, &tiles, &csz) || gemm_tn_batch_layout(count, m, n, &tiles64, &csz, 64)) return 0;
+    const int64_t slab = gemm_tn_batch_slab(k, tiles), slab64 = gemm_tn_batch_slab(k, tiles64);      // either kernel may run: room for both
+    const int64_t slabs = (k + slab - 1) / slab, slabs64 = (k + slab64 - 1) / slab64;
+    return ((slabs > slabs64 ? slabs : slabs64) + GEMM_TN_GROUPS) * csz;
 }
 
 extern "C" int gens_gemm_tn_batch(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
@@ -228,11 +301,32 @@ extern "C" int gens_gemm_tn_batch(int count, const float* const* a, const int* l
     }
     B.tile0[GEMM_TN_MAX_BATCH] = t0;
     for (int p = count; p <= GEMM_TN_MAX_BATCH; ++p) B.tile0[p] = t0;
-    const int64_t slab = gemm_tn_batch_slab(k, tiles);
-    const int n_slabs = (int)((k + slab - 1) / slab);
-    const int64_t units = (int64_t)n_slabs * tiles;
+    // even sizes and 8-byte aligned operands: the register-blocked kernel (64 x 64 blocks)
+    bool even = !getenv("GENS_GEMM_TN_32");
+    for (int p = 0; p < count; ++p)
+        even = even && !((m[p] | n[p] | lda[p] | ldb[p]) & 1) && !(((uintptr_t)a[p] | (uintptr_t)b[p]) & 7);
+    even = even && !((uintptr_t)workspace & 7);
+    for (int p = 0; p < count && even; ++p) even = !(B.off[p] & 1);
     hipStream_t s = (hipStream_t)stream;
-    gemm_tn_batch_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+    int n_slabs;
+    if (even) {
+        int64_t tiles64, csz64;
+        gemm_tn_batch_layout(count, m, n, &tiles64, &csz64, 64);
+        int t64 = 0;
+        for (int p = 0; p <= GEMM_TN_MAX_BATCH; ++p) {
+            B.tile0[p] = t64;
+            if (p < count) t64 += ((m[p] + 63) / 64) * ((n[p] + 63) / 64);
+        }
+        const int64_t slab = gemm_tn_batch_slab(k, tiles64);
+        n_slabs = (int)((k + slab - 1) / slab);
+        const int64_t units = (int64_t)n_slabs * tiles64;
+        gemm_tn_batch2_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+    } else {
+        const int64_t slab = gemm_tn_batch_slab(k, tiles);
+        n_slabs = (int)((k + slab - 1) / slab);
+        const int64_t units = (int64_t)n_slabs * tiles;
+        gemm_tn_batch_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+    }
     if (n_slabs <= GEMM_TN_GROUPS) {
         gemm_tn_reduce_k<<<dim3(gens_blocks(csz, 256), 1), 256, 0, s>>>(workspace, n_slabs, n_slabs, csz, c);
     } else {

@@ -53,8 +53,8 @@ struct BlendTrainIO {
     uint8_t* vis_out;      // forward: (n, S) or NULL
     // backward
     const float* g_rgb;    // (n, 3) cotangent of rgb_out
-    float* R[BT_NLAYER];   // (rows_pad, in_l + 1)
-    float* L[BT_NLAYER];   // (rows_pad, out_l)
+    float* R[BT_NLAYER];   // (rows_pad, in_l + 1 rounded up to even): [input | 1 | 0]
+    float* L[BT_NLAYER];   // (rows_pad, out_l rounded up to even)
     float* g_feat;         // (n, S, F) cotangent of the looked-up [rgb | features] rows, or NULL
     float* s_part;         // (waves) partial sums of d loss / d |s|
 };
@@ -66,21 +66,27 @@ __device__ __forceinline__ int bt_crow(int r, int lane) { return (r & 3) + 8 * (
 // One 32 x 32 tile on the matrix cores from an LDS A tile (rows of stride rs, reduction length K) and a RAW weight matrix W (w_out, w_in):
 //   TRANS = false: y[row][n0 + j] = sum_k A[row][k] W[n0 + j][k]      (forward, K = w_in)
 //   TRANS = true : x[row][n0 + j] = sum_k A[row][k] W[k][n0 + j]      (reverse, K = w_out)
-template <bool TRANS>
-__device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, int K, const float* __restrict__ W, int w_out, int w_in, int n0,
-                                          int lane) {
+template <bool TRANS, int K>
+__device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, const float* __restrict__ W, int w_out, int w_in, int n0, int lane) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int i = lane & 31, half = lane >> 5, n = n0 + i;
     const int N = TRANS ? w_in : w_out;
-    for (int k0 = 0; k0 < K; k0 += 2) {
-        const int k = k0 + half;
-        const bool kin = k < K;
-        const float a = kin ? A[i * rs + k] : 0.0f;
-        float b = 0.0f;
-        if (kin && n < N) b = TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    constexpr int KP = (K + 1) / 2;
+    // every weight of the tile first (the loads overlap each other's L2 latency: two waves per CU cannot hide a load -> MFMA chain), then
+    // the matrix instructions
+    float bv[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = 2 * j + half;
+        bv[j] = (k < K && n < N) ? (TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = 2 * j + half;
+        const float a = k < K ? A[i * rs + k] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -170,15 +176,16 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     // write the operand rows [input | 1] of layer l (width `in`) from an LDS array
 #define BT_STORE_R(l, SRC, stride, in)                                                                       \
     if (BWD) {                                                                                               \
-        BT_FOR(i_, 32 * ((in) + 1)) {                                                                        \
-            const int r_ = i_ / ((in) + 1), c_ = i_ % ((in) + 1);                                            \
-            io.R[l][(grow0 + r_) * ((in) + 1) + c_] = c_ < (in) ? (SRC)[r_ * (stride) + c_] : 1.0f;          \
+        constexpr int rw_ = ((in) + 2) & ~1;          /* [input | 1 | 0]: even width (8-byte loads of the batched product) */ \
+        BT_FOR(i_, 32 * rw_) {                                                                               \
+            const int r_ = i_ / rw_, c_ = i_ % rw_;                                                          \
+            io.R[l][(grow0 + r_) * rw_ + c_] = c_ < (in) ? (SRC)[r_ * (stride) + c_] : (c_ == (in) ? 1.0f : 0.0f); \
         }                                                                                                    \
     }
     // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out
 #define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT)                                             \
     for (int n0_ = 0; n0_ < (n_out); n0_ += 32) {                                                            \
-        f32x16 acc_ = bt_gemm<false>(IN, s_in, k_in, Wm, n_out, k_in, n0_, lane);                            \
+        f32x16 acc_ = bt_gemm<false, k_in>(IN, s_in, Wm, n_out, k_in, n0_, lane);                            \
         const int c_ = n0_ + col;                                                                            \
         if (c_ < (n_out)) {                                                                                  \
             const float bias_ = (Bv)[c_];                                                                    \
@@ -324,14 +331,17 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     // ================================================================ reverse
     // store the cotangent rows of layer l's pre-activation (width out) from an LDS tile
 #define BT_STORE_L(l, SRC, stride, out)                                                                      \
-    BT_FOR(i_, 32 * (out)) {                                                                                 \
-        const int r_ = i_ / (out), c_ = i_ % (out);                                                          \
-        io.L[l][(grow0 + r_) * (out) + c_] = (SRC)[r_ * (stride) + c_];                                      \
+    {                                                                                                        \
+        constexpr int lw_ = ((out) + 1) & ~1;                                                                \
+        BT_FOR(i_, 32 * lw_) {                                                                               \
+            const int r_ = i_ / lw_, c_ = i_ % lw_;                                                          \
+            io.L[l][(grow0 + r_) * lw_ + c_] = c_ < (out) ? (SRC)[r_ * (stride) + c_] : 0.0f;                \
+        }                                                                                                    \
     }
     // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
 #define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY)                                              \
     for (int n0_ = 0; n0_ < (n_in); n0_ += 32) {                                                             \
-        f32x16 acc_ = bt_gemm<true>(IN, s_in, k_out, Wm, k_out, n_in, n0_, lane);                            \
+        f32x16 acc_ = bt_gemm<true, k_out>(IN, s_in, Wm, k_out, n_in, n0_, lane);                            \
         const int c_ = n0_ + col;                                                                            \
         if (c_ < (n_in)) {                                                                                   \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \

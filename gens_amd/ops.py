@@ -1258,15 +1258,16 @@ class _BlendTrain(torch.autograd.Function):
         ins = [4, 16, 3 * f, 64, 32, 32, 32, 32, 37, 16, 8]
         outs = [16, f, 64, 32, 32, 33, 32, 1, 16, 8, 1]
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
-        r_ops = [e(rows, k + 1) for k in ins]
-        l_ops = [e(rows, m) for m in outs]
+        ev = lambda x: (x + 1) // 2 * 2  # noqa: E731      (even widths: the batched product then reads 8 bytes per lane)
+        r_ops = [e(rows, ev(k + 1)) for k in ins]
+        l_ops = [e(rows, ev(m)) for m in outs]
         want_maps = any(ctx.needs_input_grad[2 + 23:])
         g_feat = e(n, s, f) if want_maps else None
         s_part = e(rows // 32)
         L.call("gens_blend_train_bwd", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr_table(r_ops), L.ptr_table(l_ops), L.ptr(g_feat), L.ptr(s_part),
                L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops)
         # [dW_l | db_l] = l_ops[l]^T r_ops[l]: eleven products over the same rows in one launch
-        ms, ns = outs, [k + 1 for k in ins]
+        ms, ns = [ev(m) for m in outs], [ev(k + 1) for k in ins]
         mi, ni = L.int_table(ms), L.int_table(ns)
         ws = e(L.load().gens_gemm_tn_batch_workspace(11, mi, ni, rows))
         cc = e(sum(m * k for m, k in zip(ms, ns)))
@@ -1276,7 +1277,7 @@ class _BlendTrain(torch.autograd.Function):
         for l, (m, k) in enumerate(zip(ms, ns)):
             c = cc[off:off + m * k].view(m, k)
             off += m * k
-            grads += [c[:, :k - 1].reshape(pshapes[2 * l]), c[:, k - 1].reshape(pshapes[2 * l + 1])]
+            grads += [c[:outs[l], :ins[l]].reshape(pshapes[2 * l]), c[:outs[l], ins[l]].reshape(pshapes[2 * l + 1])]
         s_sign = torch.sign(w[22]).reshape(pshapes[22])
         grads.append(s_sign * s_part.sum())
         g_imgs, g_feats = None, [None] * nl

@@ -291,8 +291,9 @@ int gens_blend_views(const float* const* feats, const int* hw, int n_levels, con
  *     rgb_fc.0 W,b  rgb_fc.2 W,b  rgb_fc.4 W,b  s
  *   fwd: pts (n, 3) -> rgb_out (n, 3), vis_out (n, S) uint8 (NULL to skip).
  *   bwd: g_rgb (n, 3) cotangent of rgb_out -> for each of the 11 layers the operand rows of its weight-gradient product over
- *     rows = gens_blend_train_rows(n, nv) = 32 ceil(n / floor(32 / S)):  r_ops[l] (rows, in_l + 1) = [layer input | 1],
- *     l_ops[l] (rows, out_l) = cotangent of the pre-activation:  [dW_l | db_l] = l_ops[l]^T r_ops[l]   (gens_gemm_tn_batch);
+ *     rows = gens_blend_train_rows(n, nv) = 32 ceil(n / floor(32 / S)):  r_ops[l] (rows, even(in_l + 1)) = [layer input | 1 | 0],
+ *     l_ops[l] (rows, even(out_l)) = cotangent of the pre-activation (zero padded; even(x) = x rounded up to a multiple of 2):
+ *     [dW_l | db_l] = the leading out_l x (in_l + 1) block of l_ops[l]^T r_ops[l]   (gens_gemm_tn_batch);
  *     g_feat (n, S, 3 + 4 n_levels): cotangent of the looked-up rows for gens_lookup_feature_bwd (NULL to skip);
  *     s_part (rows / 32): partial sums of d loss / d |s|.
  * ---------------------------------------------------------------------------------------------------------- */

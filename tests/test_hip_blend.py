@@ -95,7 +95,8 @@ def test_training_kernels_match_the_cpu_oracle(nv, n_levels, n):
     top = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
     for k, p in net.named_parameters():
         r = sd["color_network." + k].grad
-        worst[k] = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-4 * top)
+        # (the bias in front of the softmax has an analytically zero gradient -- 1e-8 of round-off on both sides: the floor keeps it out)
+        worst[k] = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-3 * top)
     for i in range(n_levels):
         worst[f"feat{i}"] = float((feats_d[i].grad.cpu() - feats_c[i].grad).abs().max()) / max(float(feats_c[i].grad.abs().max()), 1e-6)
     worst["imgs"] = float((imgs_d.grad.cpu() - imgs_c.grad).abs().max()) / max(float(imgs_c.grad.abs().max()), 1e-6)
@@ -105,4 +106,5 @@ def test_training_kernels_match_the_cpu_oracle(nv, n_levels, n):
     # gradients: its float32 round-off is judged against THEIR scale
     worst.pop("s")
     assert abs(float(net.s.grad) - float(sd["color_network.s"].grad)) < 3e-5 * top
-    assert max(worst.values()) < 2e-3, worst
+    bad = {k: v for k, v in worst.items() if v >= 2e-3}
+    assert not bad, (bad, {k: float(sd["color_network." + k].grad.abs().max()) for k in bad if "color_network." + k in sd}, top)
