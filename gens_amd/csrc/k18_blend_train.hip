@@ -7,7 +7,8 @@
 //
 // A training step has ~62 000 valid samples x 4 source views: the arithmetic is 10 GFLOP, nothing; what the PyTorch path pays is
 // launches and host time (4.4 ms of a 15 ms fine-tune step).  So this kernel is written for clarity, not for the last TFLOP/s: one
-// wavefront = 32 (point, view) rows, EVERY activation of the rows kept in LDS (61 KB per wave, two waves per CU), every layer on the fp32
+// workgroup of four waves = 32 (point, view) rows, EVERY activation of the rows kept in LDS (79 KB, two workgroups per CU; the waves split
+// the element-wise passes, the operand stores and the output tiles of a layer), every layer on the fp32
 // matrix cores straight from the RAW row-major weights (no packed streams: the weights change every step, and 43 KB of them live in L1 / L2).
 // The backward launch recomputes the forward for its rows (cheaper than a stash), walks the layers in reverse, and leaves for each
 // layer the operand rows of its weight-gradient product: L = cotangent of the pre-activation, R = [input | 1] (the 1 yields the bias
@@ -18,6 +19,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BT_NLAYER 11
+#define BT_WAVES 4
+#define BT_THREADS (64 * BT_WAVES)
 // LDS row strides (odd: conflict-free column walks) of the per-row arrays
 #define BT_S_RD 9
 #define BT_S_D1 17
@@ -92,7 +95,7 @@ __device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, c
 }
 
 template <int NLEV, bool BWD>
-__global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {
+__global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {
     constexpr int F = 3 + 4 * NLEV, F3 = 3 * F;
     static_assert(F3 + 1 <= BT_S_A && F3 <= BT_S_H0, "tile too narrow");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -116,26 +119,27 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     float* GH = GX + 32 * BT_S_DFE;        // [32][33]  cotangent of h / h + res
     float* PP = GH + 32 * BT_S_H;          // [32][4]   per point: 0 sum of raw weights, 1 arg-min view, 2 spare, 3 spare
 
-    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid & 31, col = lane & 31;
     const int S = io.nv - 1, PPW = 32 / S;
     const int64_t first = (int64_t)blockIdx.x * PPW;
     const int64_t n = io.n;
     const int pl = row / S, sv = row % S + 1;
     const bool live = pl < PPW && first + pl < n;
     const int64_t src = live ? first + pl : 0;
-    const int64_t grow0 = (int64_t)blockIdx.x * 32;                  // first operand row of this wave
+    const int64_t grow0 = (int64_t)blockIdx.x * 32;                  // first operand row of this workgroup
+    const bool owner = tid < 32;                                     // one thread per row for the per-row scalars
 
     // ---------------------------------------------------------------- look-up (K4): [rgb | features] of the row into H0[:, 2F..3F)
-    {
+    {   // thread (row, part): part l < NLEV reads feature level l (level 0 also the image); the in-frustum flags meet in GH (free here)
+        const int part = tid >> 5;
         float x = 0.f, y = 0.f, z = 0.f;
         if (live) { x = io.pts[3 * src]; y = io.pts[3 * src + 1]; z = io.pts[3 * src + 2]; }
-        bool inside = true;
-        const int l_begin = half ? 2 : 0, l_end = half ? NLEV : min(2, NLEV);
         float* xr = H0 + row * BT_S_H0 + 2 * F;
-        for (int l = l_begin; l < l_end; ++l) {
+        if (part < NLEV) {
+            const int l = part;
             const int h = fs.h[l], w = fs.w[l];
             SrcProj p = project_src(io.w2c + 16 * sv, io.intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
-            inside = inside && p.inside;
+            GH[row * BT_S_H + l] = p.inside ? 1.0f : 0.0f;
             float4 f = f4_zero(), c = f4_zero();
             if (live) {
                 Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
@@ -148,9 +152,10 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
                 C[row * 3] = c.x; C[row * 3 + 1] = c.y; C[row * 3 + 2] = c.z;
             }
         }
-        const bool other = __shfl_xor((int)inside, 32, 64) != 0;
-        inside = inside && other;
-        if (half == 0) {
+        __syncthreads();
+        if (owner) {
+            bool inside = true;
+            for (int l = 0; l < NLEV; ++l) inside = inside && GH[row * BT_S_H + l] != 0.0f;
             SC[row * BT_S_SC] = (live && inside) ? 1.0f : 0.0f;
             if (live && io.vis_out && !BWD) io.vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
             // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     }
     __syncthreads();
 
-#define BT_FOR(i, count) for (int i = lane; i < (count); i += 64)
+#define BT_FOR(i, count) for (int i = tid; i < (count); i += BT_THREADS)
     // write the operand rows [input | 1] of layer l (width `in`) from an LDS array
 #define BT_STORE_R(l, SRC, stride, in)                                                                       \
     if (BWD) {                                                                                               \
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     }
     // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out
 #define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT)                                             \
-    for (int n0_ = 0; n0_ < (n_out); n0_ += 32) {                                                            \
+    for (int n0_ = 32 * wave; n0_ < (n_out); n0_ += 32 * BT_WAVES) {                                         \
         f32x16 acc_ = bt_gemm<false, k_in>(IN, s_in, Wm, n_out, k_in, n0_, lane);                            \
         const int c_ = n0_ + col;                                                                            \
         if (c_ < (n_out)) {                                                                                  \
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
         H0[r * BT_S_H0 + 2 * F + c] += DFE[r * BT_S_DFE + c];
     }
     const float s_abs = fabsf(W.s[0]);
-    if (lane < 32) SC[row * BT_S_SC + 1] = expf(s_abs * (RD[row * BT_S_RD + 3] - 1.0f));           // exp(|s| (dot - 1))  (:93)
+    if (owner) SC[row * BT_S_SC + 1] = expf(s_abs * (RD[row * BT_S_RD + 3] - 1.0f));           // exp(|s| (dot - 1))  (:93)
     __syncthreads();
     // ---------------------------------------------------------------- view weights, weighted mean / variance (:94-101)
-    if (lane < 32 && pl < PPW && sv == 1) {                       // one lane per point
+    if (owner && pl < PPW && sv == 1) {                       // one lane per point
         const int base = pl * S;
         float mn = 3.4e38f;
         int arg = 0;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
         PP[pl * 4] = sum;
         PP[pl * 4 + 1] = (float)arg;
     }
-    if (lane < 32 && pl >= PPW) SC[row * BT_S_SC + 2] = 0.0f;
+    if (owner && pl >= PPW) SC[row * BT_S_SC + 2] = 0.0f;
     __syncthreads();
     BT_FOR(it, PPW * F) {
         const int p = it / F, c = it % F, base = p * S;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     BT_STORE_R(5, TV, BT_S_TV, 32)
     BT_LAYER(TV, BT_S_TV, 32, W.v2, W.v2b, 33, HV, BT_S_HV, true)
     __syncthreads();
-    if (lane < 32) SC[row * BT_S_SC + 3] = (1.0f / (1.0f + expf(-HV[row * BT_S_HV + 32]))) * SC[row * BT_S_SC];      // vis
+    if (owner) SC[row * BT_S_SC + 3] = (1.0f / (1.0f + expf(-HV[row * BT_S_HV + 32]))) * SC[row * BT_S_SC];      // vis
     BT_FOR(i, 32 * 32) {
         const int r = i >> 5, c = i & 31;
         HH[r * BT_S_HH + c] = H[r * BT_S_H + c] + HV[r * BT_S_HV + c];                                              // x = x + x_res
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     BT_LAYER(A0, BT_S_A, 32, W.u1, W.u1b, 32, TU, BT_S_TU, true)
     __syncthreads();
     BT_STORE_R(7, TU, BT_S_TU, 32)
-    if (lane < 32) {
+    if (owner) {
         float q = W.u2b[0];
         for (int k = 0; k < 32; ++k) q += TU[row * BT_S_TU + k] * W.u2[k];
         const float v2 = (1.0f / (1.0f + expf(-q))) * SC[row * BT_S_SC];
@@ -298,15 +303,15 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     BT_LAYER(T1, BT_S_T1, 16, W.r2, W.r2b, 8, T2, BT_S_T2, true)
     __syncthreads();
     BT_STORE_R(10, T2, BT_S_T2, 8)
-    if (lane < 32) {
+    if (owner) {
         float sc = W.r3b[0];
         for (int k = 0; k < 8; ++k) sc += T2[row * BT_S_T2 + k] * W.r3[k];
         SC[row * BT_S_SC + 5] = (SC[row * BT_S_SC] == 0.0f) ? -1e9f : sc;                  // masked_fill(mask == 0, -1e9)  (:115)
     }
     __syncthreads();
     // ---------------------------------------------------------------- softmax over views, colour (:116-117)
-    if (lane < PPW && first + lane < n) {
-        const int base = lane * S;
+    if (tid < PPW && first + tid < n) {
+        const int base = tid * S;
         float mx = -3.4e38f;
         for (int v = 0; v < S; ++v) mx = fmaxf(mx, SC[(base + v) * BT_S_SC + 5]);
         float den = 0.0f;
@@ -320,9 +325,9 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
             cb += C[(base + v) * 3 + 2] * p;
         }
         if (!BWD) {
-            io.rgb_out[3 * (first + lane)] = cr;
-            io.rgb_out[3 * (first + lane) + 1] = cg;
-            io.rgb_out[3 * (first + lane) + 2] = cb;
+            io.rgb_out[3 * (first + tid)] = cr;
+            io.rgb_out[3 * (first + tid) + 1] = cg;
+            io.rgb_out[3 * (first + tid) + 2] = cb;
         }
     }
     if constexpr (!BWD) return;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     }
     // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
 #define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY)                                              \
-    for (int n0_ = 0; n0_ < (n_in); n0_ += 32) {                                                             \
+    for (int n0_ = 32 * wave; n0_ < (n_in); n0_ += 32 * BT_WAVES) {                                          \
         f32x16 acc_ = bt_gemm<true, k_out>(IN, s_in, Wm, k_out, n_in, n0_, lane);                            \
         const int c_ = n0_ + col;                                                                            \
         if (c_ < (n_in)) {                                                                                   \
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     }
 
     // colour = sum_v rgb_in p_v: score_bar = p (p_bar - sum_u p_u p_bar_u), rgb_in_bar = g p
-    if (lane < 32) {
+    if (owner) {
         float sb = 0.0f;
         float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;
         if (live) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
                if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;)
     __syncthreads();
     // vis2 = sigmoid(q) mask ; q = u2 . tu + b
-    if (lane < 32) {
+    if (owner) {
         const float v2 = SC[row * BT_S_SC + 4];
         A1[row * BT_S_A] = SC[row * BT_S_SC + 8] * SC[row * BT_S_SC] * v2 * (1.0f - v2);       // q_bar (mask is 0 or 1: vis2 = sigmoid there)
     }
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
     BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;)
     __syncthreads();
-    if (lane < 32) {
+    if (owner) {
         float vb = 0.0f;
         for (int k = 0; k < 32; ++k) vb += A1[row * BT_S_A + k] * HH[row * BT_S_HH + k];
         const float vis = SC[row * BT_S_SC + 3];
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
     BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;)
     __syncthreads();
-    if (lane < 32) {
+    if (owner) {
         float wb = 0.0f;
         for (int k = 0; k < 32; ++k) wb += A0[row * BT_S_A + k] * H[row * BT_S_H + k];
         SC[row * BT_S_SC + 7] += wb;
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
     __syncthreads();
     // w = wr / (sum wr + 1e-8), wr = (e - min e) mask, e = exp(|s| (dot - 1))
     float s_bar = 0.0f;
-    if (lane < 32 && pl < PPW && sv == 1 && first + pl < n) {
+    if (owner && pl < PPW && sv == 1 && first + pl < n) {
         const int base = pl * S;
         const float sum = PP[pl * 4] + 1e-8f;
         const int arg = (int)PP[pl * 4 + 1];
@@ -487,8 +492,10 @@ __global__ __launch_bounds__(64) void blend_train_k(BlendRaw W, MapSet fs, Blend
         for (int v = 0; v < S; ++v)
             s_bar += SC[(base + v) * BT_S_SC + 9] * SC[(base + v) * BT_S_SC + 1] * (RD[(base + v) * BT_S_RD + 3] - 1.0f);
     }
-    s_bar = wave_sum(s_bar);
-    if (lane == 0) io.s_part[blockIdx.x] = s_bar;
+    if (wave == 0) {                                               // (the owners all sit in wave 0)
+        s_bar = wave_sum(s_bar);
+        if (lane == 0) io.s_part[blockIdx.x] = s_bar;
+    }
     BT_STORE_L(1, A0, BT_S_A, F)
     BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);)
     __syncthreads();
@@ -550,7 +557,7 @@ static int bt_launch(const char* who, const float* const* feats, const int* hw, 
             (void)hipFuncSetAttribute((const void*)blend_train_k<NL, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_lds_bytes()); \
             once[NL][BWD] = true;                                                                                                  \
         }                                                                                                                          \
-        blend_train_k<NL, BWD><<<grid, 64, bt_lds_bytes(), st>>>(W, fs, io);                                                       \
+        blend_train_k<NL, BWD><<<grid, BT_THREADS, bt_lds_bytes(), st>>>(W, fs, io);                                                       \
     }
     switch (n_levels) {
         case 1: BT_LAUNCH(1) break;
