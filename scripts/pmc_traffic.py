@@ -21,7 +21,11 @@ ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_mlp_h_k": "gens_sdf_mlp_f16", "blend_
          "compact_scan_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit",
          "conv3d_gather_k": "gens_conv3d_gather", "conv3d_scatter2_k": "gens_conv3d_scatter2", "conv3d_wgrad_k": "gens_conv3d_wgrad",
          "instnorm_stats_k": "gens_instnorm_stats", "instnorm_relu_fwd_k": "gens_instnorm_relu_fwd",
-         "instnorm_relu_bwd_stats_k": "gens_instnorm_relu_bwd_stats", "instnorm_relu_bwd_k": "gens_instnorm_relu_bwd"}
+         "instnorm_relu_bwd_stats_k": "gens_instnorm_relu_bwd_stats", "instnorm_relu_bwd_k": "gens_instnorm_relu_bwd",
+         "sdf_train_fwd_k": "gens_sdf_train_fwd", "sdf_train_bwd_k": "gens_sdf_train_bwd", "sdf_train_scatter_k": "gens_sdf_train_scatter",
+         "sdf_train_pack_k": "gens_sdf_train_pack", "blend_train_k": "gens_blend_train", "gemm_tn_batch2_partial_k": "gens_gemm_tn_batch",
+         "gemm_tn_batch_partial_k": "gens_gemm_tn_batch", "volume_build_bwd_k": "gens_volume_build_bwd", "tv_fwd4_k": "gens_tv_fwd",
+         "tv_bwd4_k": "gens_tv_bwd", "lookup_feature_bwd_k": "gens_lookup_feature_bwd", "mc_classify4_k": "gens_mc_classify"}
 
 
 def collect(root, counter):
