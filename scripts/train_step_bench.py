@@ -56,7 +56,7 @@ def _measure(quiet, kernels=False):
     finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
     if finetune:
         with torch.no_grad():
-            _, ft_masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
+            _, ft_masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], intrs, c2ws, dims)
         ft_feats = [f.detach() for f in feats]
         ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4)
 
@@ -76,8 +76,8 @@ def _measure(quiet, kernels=False):
         if finetune:
             return ft_step()
         with torch.no_grad():
-            _, masks = ops.volume_build([f.detach() for f in feats[:3]], intrs, c2ws, dims)
-        cost, _ = ops.volume_build(feats[:3], intrs, c2ws, dims)            # K1 with autograd to the features
+            _, masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], intrs, c2ws, dims)
+        cost, _ = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)            # K1 with autograd to the features
         out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
         ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]                     # loss.py:36-38
         loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \

@@ -246,3 +246,82 @@ def test_k1_backward_window_scatter_equals_direct_atomics(scene):
         scale = float(outs[1].abs().max())
         assert scale > 1.0
         assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * scale + 1e-6, (d, float((outs[0] - outs[1]).abs().max()), scale)
+
+
+# --------------------------------------------------------------------------------------------------- K17 / K18 at training-step size
+def _train_case(n_levels, n, seed):
+    from gens_amd import ops
+    from oracle import sdf_train_oracle as T
+    g = torch.Generator().manual_seed(seed)
+    dims = [64, 32, 16, 8, 4][:n_levels]
+    vols = [(0.3 * torch.randn(1, 4, d, d, d, generator=g)).cuda() for d in dims]
+    W, b = T.shipped_weights(n_levels, seed=seed + 1, scale=1.0)
+    pts = (torch.rand(n, 3, generator=g) * 2.2 - 1.1).cuda()
+    cot = [torch.randn(n, k, generator=g).cuda() for k in (1, 3, 3)]
+    return ops, [w.cuda() for w in W], [v.cuda() for v in b], vols, pts, cot
+
+
+def _sdf_train_grads(ops, W, b, vols, pts, cot):
+    Wd = [w.clone().requires_grad_(True) for w in W]
+    bd = [v.clone().requires_grad_(True) for v in b]
+    vd = [v.clone().requires_grad_(True) for v in vols]
+    y, g, s = ops.SdfTrainStep(Wd, bd, vd, ops.VolumeSet.packed(vd))(pts)
+    ((y * cot[0]).sum() + (g * cot[1]).sum() + (s * cot[2]).sum()).backward()
+    return (y.detach(), g.detach(), s.detach()), [t.grad for t in Wd + bd + vd]
+
+
+@pytest.mark.parametrize("n_levels", [3, 5])
+def test_sdf_train_kernels_at_step_size_partition_and_order(n_levels):
+    """K17 at the size of a training step (BASELINE config[2]: 512 rays x 128 samples + 1 024 random + 2 048 pseudo points = 68 608), where
+    the oracle is too slow, through properties that do not depend on the size: (i) every point is evaluated independently of its
+    neighbours in the batch -- a permutation of the points permutes y, g, s bit for bit; (ii) the parameter and volume gradients are
+    sums over points -- the two halves of the batch add up to the whole (float32 summation order aside); (iii) the backward is linear in
+    the cotangents."""
+    n = 68608
+    ops, W, b, vols, pts, cot = _train_case(n_levels, n, seed=70 + n_levels)
+    (y, g, s), full = _sdf_train_grads(ops, W, b, vols, pts, cot)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).cuda()
+    (yp, gp, sp), _ = _sdf_train_grads(ops, W, b, vols, pts[perm], [c[perm] for c in cot])
+    assert torch.equal(yp, y[perm]) and torch.equal(gp, g[perm]) and torch.equal(sp, s[perm])
+    h = n // 2 + 7                                                     # not a multiple of the 32-point tile
+    _, first = _sdf_train_grads(ops, W, b, vols, pts[:h], [c[:h] for c in cot])
+    _, second = _sdf_train_grads(ops, W, b, vols, pts[h:], [c[h:] for c in cot])
+    for a, p, q in zip(full, first, second):
+        scale = a.abs().max().clamp_min(1e-20)
+        assert ((p + q - a).abs().max() / scale) < 2e-4
+    _, doubled = _sdf_train_grads(ops, W, b, vols, pts, [2.0 * c for c in cot])
+    for a, d2 in zip(full, doubled):
+        assert ((d2 - 2.0 * a).abs().max() / a.abs().max().clamp_min(1e-20)) < 1e-5
+    assert all(torch.isfinite(t).all() for t in full)
+
+
+def test_blend_train_kernels_at_step_size_partition():
+    """K18 at training-step size (61 000 points x 4 source views of a 480 x 640 five-view scene): outputs are per point (a permutation
+    permutes them bit for bit) and the parameter gradients of the two halves add up to the whole."""
+    from gens_amd import ops, synthetic
+    from gens_amd.models.modules.blending_network import BlendingNetwork
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=9)
+    torch.manual_seed(2)
+    net = BlendingNetwork(d_feature=20).cuda()
+    views = ops.SceneViews(sc["imgs"].cuda(), sc["intrs"].cuda(), sc["c2ws"].cuda(), [f.cuda() for f in sc["features"]])
+    g = torch.Generator().manual_seed(3)
+    n = 61003
+    pts = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+    cot = torch.randn(n, 3, generator=g).cuda()
+
+    def run(p, c):
+        net.zero_grad(set_to_none=True)
+        rgb, vis = ops.blend_train(net, views, p)
+        (rgb * c).sum().backward()
+        return rgb.detach(), vis, [q.grad.clone() for q in net.parameters()]
+    rgb, vis, full = run(pts, cot)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(4)).cuda()
+    rgb_p, vis_p, _ = run(pts[perm], cot[perm])
+    assert torch.equal(rgb_p, rgb[perm]) and torch.equal(vis_p, vis[perm])
+    h = n // 2 + 3
+    _, _, a = run(pts[:h], cot[:h])
+    _, _, b = run(pts[h:], cot[h:])
+    top = max(float(t.abs().max()) for t in full)
+    for f, p, q in zip(full, a, b):
+        assert float((p + q - f).abs().max()) < 2e-4 * max(float(f.abs().max()), 1e-3 * top)
+    assert torch.isfinite(rgb).all() and vis.any()
