@@ -884,27 +884,42 @@ class _SdfTrain(torch.autograd.Function):
                L.ptr(cot[0]), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(stash, torch.uint8), L.ptr(lop), L.ptr(rh), L.ptr(re), L.ptr(r0), L.ptr(f_hat),
                L.ptr(mu_f), L.ptr(lam_f), L.ptr(w6p), L.stream(), nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)),
                flops=n * flops)
-        # weight gradients: seven products over the 4 * npad operand rows in one launch (rows of padding points are zero on one side of
-        # every product): layer 0, the hidden parts of layers 1..5, and the conditioning columns + bias of every layer at once
+        # weight gradients: eleven products over the 4 * npad operand rows in ONE launch (rows of padding points are zero on one side of
+        # every product).  Per layer l = 1..5 the hidden columns (lop_l^T rh_l) and the conditioning columns + bias (lop_l^T re) are
+        # neighbours in the unit list, so the second product finds lop_l's slab in L2 instead of reading it from HBM again; layer 0 last.
         k = 4 * npad
         fl = 4                                                            # bytes per float
-        a_ptr = [lop.data_ptr() + fl * 128 * l for l in range(6)] + [lop.data_ptr()]
-        b_ptr = [r0.data_ptr()] + [rh.data_ptr() + fl * l * k * 128 for l in range(5)] + [re.data_ptr()]
-        ms, ns = [128] * 6 + [768], [32] + [128] * 5 + [fep]
+        a_ptr, b_ptr, ldb, ms, ns = [], [], [], [], []
+        for l in range(1, 6):
+            a_ptr += [lop.data_ptr() + fl * 128 * l] * 2
+            b_ptr += [rh.data_ptr() + fl * (l - 1) * k * 128, re.data_ptr()]
+            ldb += [128, fep]
+            ms += [128, 128]
+            ns += [128, fep]
+        a_ptr.append(lop.data_ptr())
+        b_ptr.append(r0.data_ptr())
+        ldb.append(32)
+        ms.append(128)
+        ns.append(32)
+        cnt = len(ms)
         mi, ni = L.int_table(ms), L.int_table(ns)
-        ws = f(L.load().gens_gemm_tn_batch_workspace(7, mi, ni, k))
-        cc = f(sum(m * n_ for m, n_ in zip(ms, ns)))
+        ws = f(L.load().gens_gemm_tn_batch_workspace(cnt, mi, ni, k))
+        sizes = [m * n_ for m, n_ in zip(ms, ns)]
+        cc = f(sum(sizes))
         tab = lambda v: C.cast((C.c_void_p * len(v))(*v), C.POINTER(C.c_void_p))  # noqa: E731
-        L.call("gens_gemm_tn_batch", 7, tab(a_ptr), L.int_table([768] * 7), tab(b_ptr), L.int_table([32] + [128] * 5 + [fep]), mi, ni, k,
-               L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 * 2 + 32 + 5 * 128 + fep), flops=2 * k * sum(m * n_ for m, n_ in zip(ms, ns)))
-        w0 = cc[:128 * 32].view(128, 32)
-        hs = cc[128 * 32:128 * 32 + 5 * 128 * 128].view(5, 128, 128)
-        e_all = cc[128 * 32 + 5 * 128 * 128:].view(768, fep)
-        g_w, g_b = [w0[:, :27]], [e_all[:128, fe]]
+        L.call("gens_gemm_tn_batch", cnt, tab(a_ptr), L.int_table([768] * cnt), tab(b_ptr), L.int_table(ldb), mi, ni, k,
+               L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 + 32 + 5 * 128 + fep), flops=2 * k * sum(sizes))
+        parts, off = [], 0
+        for m, n_ in zip(ms, ns):
+            parts.append(cc[off:off + m * n_].view(m, n_))
+            off += m * n_
+        w0 = parts[10]
+        g_w, g_b = [w0[:, :27]], [w0[:, 27]]
         for l in range(1, 6):
             rows = 101 if l == 2 else 128
-            g_w.append(torch.cat([hs[l - 1], e_all[128 * l:128 * (l + 1), :fe]], 1)[:rows])
-            g_b.append(e_all[128 * l:128 * l + rows, fe])
+            h, e_l = parts[2 * (l - 1)], parts[2 * (l - 1) + 1]
+            g_w.append(torch.cat([h, e_l[:, :fe]], 1)[:rows])
+            g_b.append(e_l[:rows, fe])
         w6s = w6p.sum(0)
         w6 = torch.zeros(ctx.shapes[6], device=dev, dtype=_f32)
         w6[0] = w6s[:kin]

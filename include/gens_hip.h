@@ -247,7 +247,7 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
  *       dL/dW_l[:, 128:K] , dL/db_l = sum_q lop[q, :, l, :]^T re[q]      (column K - 128 of re is the bias input)
  *       dL/dW_0, dL/db_0  = sum_q lop[q, :, 0, :]^T r0[q]               (column 27 = bias input)
  *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 32, KP): columns [0, K) and column K
- *     (gens_gemm_tn_batch runs the seven products in one launch) and f_hat, mu_f, lam_f (npad, 4 n_levels) for
+ *     (gens_gemm_tn_batch runs the products in one launch) and f_hat, mu_f, lam_f (npad, 4 n_levels) for
  *     gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
  *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
  *       w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lam_f per corner  (float atomics).
