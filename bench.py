@@ -123,6 +123,8 @@ def main():
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             out = surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, hw,
                                 extract_geometry=False, scene=scene, shard=shard)       # shard: this rank's ray range + RCCL gather inside
+            if by_rays:                                                                  # a late rank needs the generator state behind all
+                surf.prefetch_jitter(n_rays)                                             # earlier rays: start the next image's draws now
         if dist is not None and not by_rays:                                             # config 4: gather of rendered buffers
             buf = surf.last_device_image                                                 # (P, 8) rgb | normal | sdf depth | rendered depth, on the device
             gathered = torch.empty(world * buf.shape[0], buf.shape[1], device=dev, dtype=buf.dtype)
@@ -171,7 +173,7 @@ def main():
     # secondary figure (N > 1, headline = one scene per rank): the SAME run's strong-scaling number -- ONE scene whose rays are split
     # across the ranks (BASELINE config 4), gather inside the timed region.  Every rank takes part (collectives), rank 0 reports.
     ray_sharded = None
-    if dist is not None and world > 1 and not by_rays and not args.headline_only:
+    if dist is not None and (world > 1 or os.environ.get("GENS_BENCH_FORCE_DIST") == "2") and not by_rays and not args.headline_only:
         try:
             ray_sharded = ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync)
         except Exception as e:
@@ -360,6 +362,7 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, (1, n_rays), extract_geometry=False,
                           scene=scene, shard=shard)
+            surf.prefetch_jitter(n_rays)       # (see ImplicitSurface.prefetch_jitter: the last rank would otherwise wait ~12 ms for its draws)
     torch.manual_seed(4321)                    # the same CPU generator state on every rank: identical jitter for every ray
     step()
     sync()

@@ -324,3 +324,26 @@ def test_split_half_overflow_recomputes_the_lattice_in_float32(golden):
                             c(g["c2ws"]), bmin, bmax, (4, 6), extract_geometry=True, mesh_resolution=24)
     assert torch.equal(torch.as_tensor(out["vertices"]), torch.as_tensor(ref_out["vertices"]))
     close(torch.as_tensor(out["color_fine"]), torch.as_tensor(ref_out["color_fine"]), atol=1e-6, rtol=1e-6, what="colour")
+
+
+def test_prefetched_jitter_renders_the_same_images(golden):
+    """prefetch_jitter() only moves the generator draws of the NEXT image earlier in time, not in order: two images rendered with the head
+    start equal the two rendered without it, and the generator ends in the same state."""
+    g = golden("g9a_render")
+    surf = build_surface(g)
+    feats, vols, masks, match, step = scene_inputs(g)
+    c = lambda t: t.cuda()  # noqa: E731
+    args = (c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]), c(g["c2ws"]), None, None, (4, 6))
+    torch.manual_seed(11)
+    a1 = surf.validate(*args, extract_geometry=False)
+    a2 = surf.validate(*args, extract_geometry=False)
+    end_a = torch.rand(1)
+    torch.manual_seed(11)
+    b1 = surf.validate(*args, extract_geometry=False)
+    surf.prefetch_jitter(24)
+    b2 = surf.validate(*args, extract_geometry=False)
+    end_b = torch.rand(1)
+    for k in ("color_fine", "sdf_depth", "render_depth"):
+        assert torch.equal(torch.as_tensor(a1[k]), torch.as_tensor(b1[k])) and torch.equal(torch.as_tensor(a2[k]), torch.as_tensor(b2[k])), k
+    assert not torch.equal(torch.as_tensor(a1["color_fine"]), torch.as_tensor(a2["color_fine"]))      # the second image has its own jitter
+    assert torch.equal(end_a, end_b)
