@@ -30,7 +30,10 @@ struct BlendWeights {
     float v2_last_b, u2_b, r3_b, s_abs;
 };
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
+// ELU as ONE median: exp(x) - 1 >= x for every x, with exp(x) - 1 >= 0 exactly when x >= 0, so elu(x) = med3(x, exp(x) - 1, 0) -- x on
+// the positive side (x lies between 0 and exp(x) - 1, also when that is inf), exp(x) - 1 on the negative one (it lies between x and 0):
+// v_med3_f32 instead of a compare + select (136 of them per 32-row tile; the kernel's time is its MFMA cycles PLUS its VALU issue cycles).
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, hw_exp(x) - 1.0f, 0.0f); }
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // One 32 x 32 output tile: acc = bias + A(32 x 8G, LDS rows of stride rs) * B.  The reduction index runs in groups of 8:
@@ -126,9 +129,10 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         bool inside = true;
         const int l_begin = half ? 2 : 0, l_end = half ? NLEV : min(2, NLEV);
         float* xr = T + row * BL_TS + 2 * F;
+        const SrcBase pb = project_src_base(w2c + 16 * sv, intr + 16 * sv, x, y, z);     // once per (point, view): see k4_common.h
         for (int l = l_begin; l < l_end; ++l) {
             const int h = fs.h[l], w = fs.w[l];
-            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
+            SrcProj p = project_src_level(pb, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l]);
             inside = inside && p.inside;
             float4 f = f4_zero(), c = f4_zero();
             if (live) {
@@ -297,10 +301,11 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         f32x16 a = tile_mfma(V + 32, BL_VS, w, W.v2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[r] += elu1(a[r]);                          // x = x + x_res
-        if (half == 0) {                                                         // 33rd output -> vis
-            float s = W.v2_last_b;
-            for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.v2_last[k];
-            R[row * 8 + 4] = hw_sigmoid(elu1(s)) * R[row * 8];
+        {                                                                        // 33rd output -> vis: the two lane halves of a row take
+            float s = 0.0f;                                                      // 16 terms each (a half-masked 32-term loop issues the same
+            for (int k = 0; k < 16; ++k) s += V[row * BL_VS + 32 + 16 * half + k] * W.v2_last[16 * half + k];   // instructions for half the work)
+            s += __shfl_xor(s, 32, 64);
+            if (half == 0) R[row * 8 + 4] = hw_sigmoid(elu1(s + W.v2_last_b)) * R[row * 8];
         }
     }
     __syncthreads();
@@ -319,10 +324,11 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         for (int r = 0; r < 16; ++r) V[crow(r, lane) * BL_VS + 32 + col] = elu1(a[r]);
     }
     __syncthreads();
-    if (half == 0) {
-        float s = W.u2_b;
-        for (int k = 0; k < 32; ++k) s += V[row * BL_VS + 32 + k] * W.u2[k];
-        R[row * 8 + 5] = hw_sigmoid(s) * R[row * 8];
+    {
+        float s = 0.0f;
+        for (int k = 0; k < 16; ++k) s += V[row * BL_VS + 32 + 16 * half + k] * W.u2[16 * half + k];
+        s += __shfl_xor(s, 32, 64);
+        if (half == 0) R[row * 8 + 5] = hw_sigmoid(s + W.u2_b) * R[row * 8];
     }
     __syncthreads();
     // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
