@@ -36,6 +36,7 @@ struct SdfMlpWeights {
     const float4* wf[MLP_NLAYER];  // forward B groups  [n_tile(4)][group][64]   (float4 per lane)
     const float4* wb[MLP_NLAYER];  // backward B groups [n_tile][16][64]; wb[0]: 1 tile (27 -> 32 columns)
     const float* w_last;           // (128 + FE) row 0 of layer 6
+    const float* w_fwd;            // the row the forward dot product reads: w_last, or its pre-scaled form (see softplus_t)
     float b_last;
     const float* b_last_dev;       // when non-null: the bias is read from the device (training: weights change every step, no host read-back)
     float inv_scale;               // 1 / scale  (sdf_network.py:123)
@@ -53,6 +54,22 @@ __device__ __forceinline__ float softplus100(float x, float& dsig) {
     const bool lin = x > 0.2f;
     if constexpr (DERIV) dsig = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
     return lin ? x : __builtin_amdgcn_logf(u) * 0.0069314718055994530942f;   // log2(u) * ln2 / 100
+}
+
+// The same activation on a PRE-SCALED pre-activation t = (100 / ln 2) a, returning the scaled hidden value h~ = (100 / ln 2) softplus(a)
+// = log2(1 + 2^t) (or t itself above the threshold): the two multiplications of softplus100 disappear from the epilogue (5 issue slots
+// instead of 7, 8 instead of 10 with the derivative -- and every VALU cycle of the epilogue is a matrix cycle lost).  The host folds the
+// factor into the weight streams instead (gens_amd.ops.SdfMlpPlan): a GEMM whose hidden inputs are h~ yields t directly when the columns
+// fed by h~ keep the plain weights and the columns fed by unscaled inputs (point encoding, volume features, the bias column) carry
+// 100 / ln 2 times theirs; the output row divides its hidden part by the same factor.  The derivative sigmoid(100 a) = 2^t / (1 + 2^t)
+// is unchanged, so the reverse pass runs on the plain transposed streams.
+template <bool DERIV>
+__device__ __forceinline__ float softplus_t(float t, float& dsig) {
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float u = 1.0f + e;
+    const bool lin = t > 28.853900817779268f;                      // 0.2 * 100 / ln 2: torch's threshold (100 a > 20)
+    if constexpr (DERIV) dsig = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
+    return lin ? t : __builtin_amdgcn_logf(u);
 }
 
 // acc += A(32 x 8G, LDS rows of stride rs; `a` already points at this lane's row + 4 * half) * B(packed groups; `b`
@@ -96,7 +113,7 @@ __device__ __forceinline__ void prefetch_groups(float4 (&pre)[MLP_PF], const flo
 // row of accumulator register r for this lane (C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-template <int FE, bool GRAD>
+template <int FE, bool GRAD, bool PRE>
 __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, LevelSet vols, const float* __restrict__ pts,
                                                      const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                      float* __restrict__ sdf_out, float* __restrict__ grad_out) {
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, lane);
             float ds = 0.0f;
-            float h = softplus100<GRAD>(acc[r], ds);
+            float h = PRE ? softplus_t<GRAD>(acc[r], ds) : softplus100<GRAD>(acc[r], ds);
             if (l == 2) {   // skip connection feeding layer 3: x = cat([h, pe]) / sqrt(2)   (sdf_network.py:111-112)
                 if (col < MLP_SKIP_H) {
                     h *= 0.70710678118654752440f;
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
         const int p = tid >> 3, sub = tid & 7;
         const float* xr = X + p * RS;
         float s = 0.0f;
-        for (int k = sub; k < KIN; k += 8) s += xr[k] * W.w_last[k];
+        for (int k = sub; k < KIN; k += 8) s += xr[k] * W.w_fwd[k];
         RED[p * 8 + sub] = s;
     }
     __syncthreads();
@@ -375,15 +392,16 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
 static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                          const float* const* wb, const float* w_last, float b_last, const float* b_last_dev, float scale,
+                          const float* const* wb, const float* w_last, const float* w_last_scaled, float b_last, const float* b_last_dev, float scale,
                           const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                           void* stream);
 
 extern "C" int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                            const float* const* wb, const float* w_last, float b_last, float scale,
+                            const float* const* wb, const float* w_last, const float* w_last_scaled, float b_last, float scale,
                             const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                             void* stream) {
-    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, b_last, nullptr, scale, pts, index, n, n_device, sdf_out, grad_out, stream);
+    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, w_last_scaled, b_last, nullptr, scale, pts, index, n, n_device, sdf_out, grad_out,
+                          stream);
 }
 
 extern "C" int gens_sdf_mlp_dev(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
@@ -391,11 +409,11 @@ extern "C" int gens_sdf_mlp_dev(const float* const* vols_packed, const int* dims
                                 const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                                 void* stream) {
     GENS_CHECK_ARG(b_last_dev, GENS_EINVAL, "gens_sdf_mlp_dev: null bias pointer");
-    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, 0.0f, b_last_dev, scale, pts, index, n, n_device, sdf_out, grad_out, stream);
+    return sdf_mlp_launch(vols_packed, dims, n_levels, wf, wb, w_last, nullptr, 0.0f, b_last_dev, scale, pts, index, n, n_device, sdf_out, grad_out, stream);
 }
 
 static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                          const float* const* wb, const float* w_last, float b_last, const float* b_last_dev, float scale,
+                          const float* const* wb, const float* w_last, const float* w_last_scaled, float b_last, const float* b_last_dev, float scale,
                           const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                           void* stream) {
     LevelSet vs;
@@ -412,18 +430,23 @@ static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int 
         W.wb[l] = grad_out ? (const float4*)wb[l] : nullptr;
     }
     W.w_last = w_last;
+    W.w_fwd = w_last_scaled ? w_last_scaled : w_last;
     W.b_last = b_last;
     W.b_last_dev = b_last_dev;
     W.scale = scale;
     W.inv_scale = 1.0f / scale;
     unsigned grid = gens_blocks(n, MLP_M);
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels == 3) {
-        if (grad_out) sdf_mlp_k<60, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
-        else sdf_mlp_k<60, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
-    } else {
-        if (grad_out) sdf_mlp_k<100, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
-        else sdf_mlp_k<100, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);
+#define SDF_LAUNCH(FE_, GRAD_)                                                                                              \
+    {                                                                                                                       \
+        if (w_last_scaled) sdf_mlp_k<FE_, GRAD_, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out); \
+        else sdf_mlp_k<FE_, GRAD_, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);          \
     }
+    if (n_levels == 3) {
+        if (grad_out) SDF_LAUNCH(60, true) else SDF_LAUNCH(60, false)
+    } else {
+        if (grad_out) SDF_LAUNCH(100, true) else SDF_LAUNCH(100, false)
+    }
+#undef SDF_LAUNCH
     return gens_launch_status("gens_sdf_mlp");
 }

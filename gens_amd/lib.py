@@ -87,7 +87,7 @@ SIGNATURES = {
     "gens_lncc_bwd": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "gens_mc_classify": [_p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p],
     "gens_mc_emit": [_p, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
-    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp_dev": [_pp, _ip, _i, _pp, _pp, _p, _p, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_blend_train_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _p, _p],
     "gens_blend_train_bwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _pp, _pp, _p, _p, _p],

@@ -5,6 +5,7 @@ derivatives the way the reference's Function pair does (models/modules/grid_samp
 twice differentiable, outputs of the second backward are constants.  Citations are relative to /root/reference.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -731,18 +732,24 @@ class SdfMlpPlan:
             dev = ws[0].device
             self.n_levels = net.init_feat_channels // 4
             self.wf, self.wb, self.bias, self.hf, self.hb = [], [], [], [], []
+            c = 100.0 / math.log(2.0)      # pre-scaled forward streams (k6_sdfmlp.hip::softplus_t): hidden units travel as c * softplus
             for l in range(6):
                 w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
                 w[:ws[l].shape[0]] = ws[l]
                 b = torch.zeros(128, device=dev, dtype=_f32)
                 b[:bs[l].shape[0]] = bs[l]
-                self.wf.append(_pack_b_groups(torch.cat([w, b[:, None]], 1)))      # bias = extra reduction row K_l (constant-1 input column)
+                wbias = torch.cat([w, b[:, None]], 1)                              # bias = extra reduction row K_l (constant-1 input column)
+                hidden = 0 if l == 0 else (101 if l == 3 else 128)                  # leading columns fed by (scaled) hidden units
+                wbias[:, hidden:] *= c                                              # point encoding / skip columns / volume features / bias
+                self.wf.append(_pack_b_groups(wbias))
                 self.wb.append(_pack_b_groups(w.t().contiguous()))
                 self.bias.append(b)
                 pf, pb = _pack_b_fragments_f16(w), _pack_b_fragments_f16(w.t().contiguous())
                 self.hf.append(pf)
                 self.hb.append(pb)
             self.w_last = _c(ws[6][0].clone())
+            self.w_last_scaled = self.w_last.clone()
+            self.w_last_scaled[:128] /= c
             self.b_last = float(bs[6][0])
             self.scale = float(net.scale)
             self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
@@ -792,7 +799,7 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
     else:
         L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
-               plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
+               L.ptr(plan.w_last_scaled), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
     return (sdf_out, grad_out) if want_grad else sdf_out

@@ -205,9 +205,13 @@ int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g
  *   grad_out[3*index[i]..] (the masked evaluation of implicit_surface.py:125,179-191); NULL = identity.
  *   n_device: optional DEVICE int32: the number of points actually evaluated is min(n, *n_device) (written by
  *   gens_compact_valid), so the masked evaluation needs no host synchronisation; NULL = n.
+ *   w_last_scaled: NULL, or the PRE-SCALED convention of the forward streams (saves the two multiplications of every softplus):
+ *   with c = 100 / ln 2, wf[l] then holds W_l with the columns fed by unscaled inputs (point encoding incl. layer 3's 27 skip columns,
+ *   volume-feature columns) and the bias row multiplied by c, the columns fed by hidden units as they are; w_last_scaled = w_last with
+ *   its first 128 entries divided by c.  wb / w_last (reverse pass) are always the plain weights.  gens_amd.ops.SdfMlpPlan builds both.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_sdf_mlp(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                 const float* const* wb, const float* w_last, float b_last, float scale,
+                 const float* const* wb, const float* w_last, const float* w_last_scaled, float b_last, float scale,
                  const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                  void* stream);
 
