@@ -706,6 +706,88 @@ def _pack_b_fragments_f16(w):
     return hi, lo
 
 
+def _value_slots(n_levels):
+    """Which input column every B-operand slot of k6v_sdf_value_f16.hip carries: three tables of shape (blocks, half, 8) holding a column
+    number, -1 for the constant-one slot and -2 for a zero slot.  Hidden blocks: the accumulator layout of the previous layer (lane half h,
+    register r of tile t = feature 32 t + 8 (r >> 2) + 4 h + (r & 3) = slot r & 7 of block 2 t + (r >> 3)).  Point encoding: half 0 holds
+    pe[0:15] and the one, half 1 pe[15:27].  Volume features: half 0 the channels of the levels below the middle one and its first two, half
+    1 the levels above and its last two; five encodings per channel (column e * CF + channel, sdf_network.py:104-107), then the one."""
+    cf = 4 * n_levels
+    nch, mid = cf // 2, n_levels // 2
+    nc = (5 * nch + 1 + 7) // 8
+    hid = torch.tensor([[[32 * (b >> 1) + 16 * (b & 1) + 8 * (s >> 2) + 4 * h + (s & 3) for s in range(8)] for h in range(2)] for b in range(8)])
+    pe = torch.full((2, 2, 8), -2, dtype=torch.long)
+    for q in range(16):
+        pe[q >> 3, 0, q & 7] = q if q < 15 else -1
+        if q < 12:
+            pe[q >> 3, 1, q & 7] = 15 + q
+    cond = torch.full((nc, 2, 8), -2, dtype=torch.long)
+    for h in range(2):
+        nfull = 4 * mid if h == 0 else 4 * (n_levels - 1 - mid)
+        for lc in range(nch):
+            ch = (lc if h == 0 else 4 * (mid + 1) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
+            for e in range(5):
+                q = 5 * lc + e
+                cond[q >> 3, h, q & 7] = e * cf + ch
+    cond[(5 * nch) >> 3, 0, (5 * nch) & 7] = -1
+    return hid, pe, cond
+
+
+def _pack_value_units(ws, bs, n_levels):
+    """The weight stream and the output row of gens_sdf_value_f16 (layout and scaling: k6v_sdf_value_f16.hip's header).  ws[l] (out_l, in_l)
+    and bs[l] are the effective float32 weights of lin0..lin6.  Returns (units (U, 4, 2, 64, 8) float16, w_out (2, 64 + 8 NC) float32,
+    largest magnitude handed to half precision)."""
+    dev = ws[0].device
+    c = 100.0 / math.log(2.0)
+    r2 = 1.0 / math.sqrt(2.0)
+    hid, pe, cond = (t.to(dev) for t in _value_slots(n_levels))
+    fe = 20 * n_levels
+
+    def block_units(aug, table, offset):
+        """aug: (128, K + 2) with the bias in column K and zeros in column K + 1; table entries index aug[:, offset + entry]."""
+        k = aug.shape[1] - 2
+        cols = torch.where(table >= 0, table + offset, torch.where(table == -1, torch.full_like(table, k), torch.full_like(table, k + 1)))
+        g = aug[:, cols.reshape(-1)].reshape(4, 32, *table.shape)               # [tile][m][block][half][slot]
+        return g.permute(2, 0, 3, 1, 4).reshape(table.shape[0], 4, 64, 8)        # [block][tile][lane = 32 half + m][slot]
+
+    units = []
+    zero = torch.zeros(128, 1, device=dev, dtype=_f32)
+    for l in range(6):
+        w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+        w[:ws[l].shape[0]] = ws[l]
+        b = torch.zeros(128, 1, device=dev, dtype=_f32)
+        b[:bs[l].shape[0], 0] = bs[l]
+        if l == 0:
+            units.append(block_units(torch.cat([c * w, c * b, zero], 1), pe, 0))
+            continue
+        h = w[:, :128].clone()
+        if l == 3:                                                               # x = cat([h[:101], pe]) / sqrt(2)   (sdf_network.py:111-112)
+            skip = torch.cat([c * r2 * w[:, 101:128], zero, zero], 1)            # the one slot of the point encoding carries nothing here
+            h = r2 * h
+            h[:, 101:] = 0.0
+        aug = torch.cat([h, c * w[:, 128:], c * b, zero], 1)
+        units.append(block_units(aug, hid, 0))
+        if l == 3:
+            units.append(block_units(skip, torch.where(pe == -1, torch.full_like(pe, -2), pe), 0))
+        units.append(block_units(aug, cond, 128))
+    units = torch.cat(units, 0)
+    pad = (-units.shape[0]) % 4                                                  # whole chunks of four units
+    if pad:
+        units = torch.cat([units, torch.zeros(pad, *units.shape[1:], device=dev, dtype=_f32)], 0)
+    hi = units.half()
+    lo = (units - hi.float()).half()
+    stream = torch.stack([hi, lo], 2).contiguous()                               # [unit][tile][hi, lo][lane][slot]
+    w_last = ws[6][0]
+    nc = cond.shape[0]
+    w_out = torch.zeros(2, 64 + 8 * nc, device=dev, dtype=_f32)
+    for hh in range(2):
+        feat = torch.tensor([32 * t + 8 * (r >> 2) + 4 * hh + (r & 3) for t in range(4) for r in range(16)], device=dev)
+        w_out[hh, :64] = w_last[feat] / c
+        tb = cond[:, hh].reshape(-1)
+        w_out[hh, 64:] = torch.where(tb >= 0, w_last[(128 + tb).clamp(0, 127 + fe)], torch.zeros_like(tb, dtype=_f32))
+    return stream, w_out, float(units.abs().max())
+
+
 class SdfMlpPlan:
     """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
     (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
@@ -753,6 +835,8 @@ class SdfMlpPlan:
             self.b_last = float(bs[6][0])
             self.scale = float(net.scale)
             self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
+            self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
+            self.value_ok = vmax < 6.0e4
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
         self.wf_table, self.wb_table, self.bias_table = L.ptr_table(self.wf), L.ptr_table(self.wb), L.ptr_table(self.bias)
         h16 = torch.float16
@@ -791,7 +875,13 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
         return (sdf_out, grad_out) if want_grad else sdf_out
-    if precision == "f16x2":
+    if precision == "f16x2" and not want_grad:
+        assert plan.value_ok, "weights exceed the half range: use precision='f32'"
+        L.call("gens_sdf_value_f16", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_units, torch.float16), L.ptr(plan.value_w_out),
+               plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
+               L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
+               label="gens_sdf_value_f16")
+    elif precision == "f16x2":
         assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
         L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
                plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),

@@ -232,6 +232,20 @@ int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_lev
                      const float* w_last, float b_last, float scale, const float* pts, const int64_t* index, int64_t n,
                      const int32_t* n_device, float* sdf_out, float* grad_out, int* overflow_flag, void* stream);
 
+/* The VALUE of the same network (no gradient) with the same split-half arithmetic and overflow contract, laid out for throughput
+ * (k6v_sdf_value_f16.hip): the 512^3 lattice of extract_geometry (implicit_surface.py:407-427) and the value-only passes of the opt-in
+ * "f16x2" arithmetic.  A wavefront owns 32 points and all 128 hidden units; activations stay in registers between the layers because
+ * the weights are packed in the order the accumulators come out in; one weight stream per 128 points goes through LDS.
+ *   units: DEVICE, 16-byte aligned, gens_sdf_value_f16_units(n_levels) x 8192 bytes: per 16-deep K block of the six layers
+ *   [4 feature tiles][hi, lo][64 lanes][8 halfs] in the slot order of gens_amd.ops._value_slots, pre-scaled by 100 / ln 2 on the
+ *   columns fed by unscaled inputs, zero padded to whole chunks of four blocks.
+ *   w_out: DEVICE (2, 64 + 8 * NC) float32: row 0 of lin6 in the accumulator / slot order of each lane half. */
+int gens_sdf_value_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* units, const float* w_out,
+                       float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
+                       float* sdf_out, int* overflow_flag, void* stream);
+/* number of 8 KB K blocks in the weight stream of gens_sdf_value_f16 (64 for 3 levels, 80 for 5; 0 = unsupported level count) */
+int gens_sdf_value_f16_units(int n_levels);
+
 /* ------------------------------------------------------------------------------------------------------------
  * K17  the SDF network of a training / fine-tune step: value, gradient, `smooth` vector and the loss backward
  *      (sdf_network.py:98-154: SDFNetwork.sdf, SDFNetwork.gradient with create_graph twice; their autograd backward under

@@ -1,0 +1,90 @@
+"""Host logic of gens_sdf_value_f16 (no GPU): the weight stream and slot tables of gens_amd.ops._pack_value_units, executed by a
+plain-torch model of the kernel's dataflow (k6v_sdf_value_f16.hip: transposed products, accumulator layout = next layer's B slots,
+pre-scaled hidden units), must reproduce the network of /root/reference/models/modules/sdf_network.py:98-129."""
+import math
+
+import pytest
+import torch
+
+from gens_amd.ops import _pack_value_units, _value_slots
+
+
+def network(ws, bs, pe, cond):
+    sp = torch.nn.Softplus(beta=100)
+    h = sp(pe @ ws[0].T + bs[0])
+    for l in range(1, 6):
+        if l == 3:
+            h = torch.cat([h, pe], 1) / math.sqrt(2.0)
+        h = sp(torch.cat([h, cond], 1) @ ws[l].T + bs[l])
+    return torch.cat([h, cond], 1) @ ws[6][:1].T + bs[6][:1]
+
+
+def kernel_model(stream, w_out, b_last, n_levels, pe, cond):
+    """What the wave computes, in float64 on the de-quantised stream."""
+    hid, pet, condt = _value_slots(n_levels)
+    a = stream.double().sum(2)                                     # hi + lo: (U, 4, 64, 8)
+    a = a.reshape(a.shape[0], 4, 2, 32, 8)                         # [unit][tile][half][m][slot]
+    n = pe.shape[0]
+    one, zero = torch.ones(n, 1, dtype=torch.float64), torch.zeros(n, 1, dtype=torch.float64)
+
+    def operand(table, values):                                    # (blocks, 2, 8) slots of every point: (N, blocks, 2, 8)
+        src = torch.cat([values, one, zero], 1)
+        k = values.shape[1]
+        cols = torch.where(table >= 0, table, torch.where(table == -1, torch.full_like(table, k), torch.full_like(table, k + 1)))
+        return src[:, cols.reshape(-1)].reshape(n, *table.shape)
+
+    def product(u0, b):                                            # -> (N, 128) pre-activations, feature 32 t + m
+        blocks = b.shape[1]
+        return torch.einsum("bthms,nbhs->ntm", a[u0:u0 + blocks], b).reshape(n, 128)
+
+    def act(t):                                                    # c * softplus(t / c)
+        return torch.where(t > 0.2 * 100 / math.log(2.0), t, torch.log2(1 + torch.exp2(t)))
+
+    bp, bc = operand(pet, pe.double()), operand(condt, cond.double())
+    nc = condt.shape[0]
+    h = act(product(0, bp))
+    u = 2
+    for l in range(1, 6):
+        t = product(u, operand(hid, h))
+        u += 8
+        if l == 3:
+            t = t + product(u, bp)
+            u += 2
+        t = t + product(u, bc)
+        u += nc
+        h = act(t)
+    assert u <= stream.shape[0] and stream.shape[0] % 4 == 0
+    out = torch.zeros(n, dtype=torch.float64)
+    for hh in range(2):
+        feat = torch.tensor([32 * t + 8 * (r >> 2) + 4 * hh + (r & 3) for t in range(4) for r in range(16)])
+        out += h[:, feat] @ w_out[hh, :64].double()
+        tb = condt[:, hh].reshape(-1)
+        out += (torch.where(tb >= 0, 1.0, 0.0) * cond.double()[:, tb.clamp(min=0)]) @ w_out[hh, 64:].double()
+    return out + b_last
+
+
+@pytest.mark.parametrize("n_levels", [3, 5])
+def test_value_stream_reproduces_the_network(n_levels):
+    g = torch.Generator().manual_seed(7 + n_levels)
+    fe = 20 * n_levels
+    dims = [(128, 27), (128, 128 + fe), (101, 128 + fe), (128, 128 + fe), (128, 128 + fe), (128, 128 + fe), (1 + 12, 128 + fe)]
+    ws = [torch.randn(o, i, generator=g) / math.sqrt(i) for o, i in dims]
+    bs = [0.1 * torch.randn(o, generator=g) for o, _ in dims]
+    n = 37
+    pe = torch.randn(n, 27, generator=g)
+    cond = torch.randn(n, fe, generator=g)
+    stream, w_out, vmax = _pack_value_units(ws, bs, n_levels)
+    assert stream.dtype == torch.float16 and stream.shape[1:] == (4, 2, 64, 8) and vmax < 6e4
+    want = network([w.double() for w in ws], [b.double() for b in bs], pe.double(), cond.double())[:, 0]
+    got = kernel_model(stream, w_out, float(bs[6][0]), n_levels, pe, cond)
+    # the stream is the weights rounded to (hi, lo) half pairs: ~2^-22 relative per weight
+    assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1.0)
+
+
+def test_slot_tables_cover_every_column_once():
+    for n_levels in (3, 5):
+        hid, pe, cond = _value_slots(n_levels)
+        assert sorted(hid.reshape(-1).tolist()) == list(range(128))
+        assert sorted(v for v in pe.reshape(-1).tolist() if v >= 0) == list(range(27))
+        assert sorted(v for v in cond.reshape(-1).tolist() if v >= 0) == list(range(20 * n_levels))
+        assert (pe == -1).sum() == 1 and (cond == -1).sum() == 1
