@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROAR
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak (same guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide)
 DOMINANT = "gens_sdf_mlp:grad"  # the kernel the roofline object is about: the fwd + d/dx launches of the fused SDF network, device kernel
-                                # sdf_mlp_k<FE, true> (asserted against the measured table).  Its value-only sibling (sdf_mlp_k<FE, false>,
-                                # profile key "gens_sdf_mlp:value") is listed beside it; the secondary workloads below never launch the
+                                # sdf_mlp_k<FE, true> (asserted against the measured table).  The value-only passes run the transposed
+                                # kernel sdf_value_t_k (profile key "gens_sdf_value"), listed beside it; the secondary workloads never launch the
                                 # GRAD kernel at other shapes, so rocprof's per-process average of that symbol is the timed region's
 
 

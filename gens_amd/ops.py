@@ -5,6 +5,7 @@ derivatives the way the reference's Function pair does (models/modules/grid_samp
 twice differentiable, outputs of the second backward are constants.  Citations are relative to /root/reference.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -788,6 +789,80 @@ def _pack_value_units(ws, bs, n_levels):
     return stream, w_out, float(units.abs().max())
 
 
+def _value_pairs(n_levels):
+    """Slot tables of k6t_sdf_value.hip, (groups, half, 4) each (column number, -1 = the constant one, -2 = zero): an MFMA of group g,
+    position i multiplies the weights of the two columns [g, 0, i] and [g, 1, i] with what the two lane halves hold.  Hidden groups
+    (t, g'): columns 32 t + 8 g' + 4 half + i (the accumulator layout).  Point encoding: half 0 pe[0:15], half 1 pe[15:27] and the one.
+    Volume features: as gens_amd.ops._value_slots, 5 encodings per channel of the half, then the one (half 0)."""
+    cf = 4 * n_levels
+    nch, mid = cf // 2, n_levels // 2
+    gc = (5 * nch + 1 + 3) // 4
+    hid = torch.tensor([[[32 * t + 8 * g + 4 * h + i for i in range(4)] for h in range(2)] for t in range(4) for g in range(4)])
+    pe = torch.full((4, 2, 4), -2, dtype=torch.long)
+    for q in range(15):
+        pe[q >> 2, 0, q & 3] = q
+        pe[q >> 2, 1, q & 3] = 15 + q if q < 12 else (-1 if q == 12 else -2)
+    cond = torch.full((gc, 2, 4), -2, dtype=torch.long)
+    for h in range(2):
+        nfull = 4 * mid if h == 0 else 4 * (n_levels - 1 - mid)
+        for lc in range(nch):
+            ch = (lc if h == 0 else 4 * (mid + 1) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
+            for e in range(5):
+                q = 5 * lc + e
+                cond[q >> 2, h, q & 3] = e * cf + ch
+    cond[(5 * nch) >> 2, 0, (5 * nch) & 3] = -1
+    return hid, pe, cond
+
+
+def _pack_value_stream(ws, bs, n_levels):
+    """The float32 weight stream and output row of gens_sdf_value (k6t_sdf_value.hip): per group of four feature pairs and output tile
+    T one float4 per lane (m, half) = the weights of row 32 T + m for the group's four columns of that half; columns fed by unscaled
+    inputs carry 100 / ln 2 (pre-scaled hidden units), layer 3's hidden columns 1 / sqrt(2), its skip columns both; one zero group is
+    appended because the kernel requests the next group before it knows there is none.  -> (stream (NG + 1, 4, 64, 4), w_out)."""
+    dev = ws[0].device
+    c = 100.0 / math.log(2.0)
+    r2 = 1.0 / math.sqrt(2.0)
+    hid, pe, cond = (t.to(dev) for t in _value_pairs(n_levels))
+    fe = 20 * n_levels
+
+    def groups(aug, table, offset):
+        k = aug.shape[1] - 2
+        cols = torch.where(table >= 0, table + offset, torch.where(table == -1, torch.full_like(table, k), torch.full_like(table, k + 1)))
+        g = aug[:, cols.reshape(-1)].reshape(4, 32, *table.shape)               # [tile][m][group][half][i]
+        return g.permute(2, 0, 3, 1, 4).reshape(table.shape[0], 4, 64, 4)        # [group][tile][lane = 32 half + m][i]
+
+    out = []
+    zero = torch.zeros(128, 1, device=dev, dtype=_f32)
+    for l in range(6):
+        w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+        w[:ws[l].shape[0]] = ws[l]
+        b = torch.zeros(128, 1, device=dev, dtype=_f32)
+        b[:bs[l].shape[0], 0] = bs[l]
+        if l == 0:
+            out.append(groups(torch.cat([c * w, c * b, zero], 1), pe, 0))
+            continue
+        h = w[:, :128].clone()
+        if l == 3:                                                               # x = cat([h[:101], pe]) / sqrt(2)   (sdf_network.py:111-112)
+            skip = torch.cat([c * r2 * w[:, 101:128], zero, zero], 1)
+            h = r2 * h
+            h[:, 101:] = 0.0
+        aug = torch.cat([h, c * w[:, 128:], c * b, zero], 1)
+        out.append(groups(aug, hid if l != 3 else hid[:13], 0))                  # layer 3 reads features 0..103 only
+        if l == 3:
+            out.append(groups(skip, torch.where(pe == -1, torch.full_like(pe, -2), pe), 0))
+        out.append(groups(aug, cond, 128))
+    out.append(torch.zeros(1, 4, 64, 4, device=dev, dtype=_f32))
+    stream = torch.cat(out, 0).contiguous()
+    w_last = ws[6][0]
+    w_out = torch.zeros(2, 64 + 4 * cond.shape[0], device=dev, dtype=_f32)
+    for hh in range(2):
+        feat = torch.tensor([32 * t + 8 * (r >> 2) + 4 * hh + (r & 3) for t in range(4) for r in range(16)], device=dev)
+        w_out[hh, :64] = w_last[feat] / c
+        tb = cond[:, hh].reshape(-1)
+        w_out[hh, 64:] = torch.where(tb >= 0, w_last[(128 + tb).clamp(0, 127 + fe)], torch.zeros_like(tb, dtype=_f32))
+    return stream, w_out
+
+
 class SdfMlpPlan:
     """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
     (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
@@ -835,6 +910,7 @@ class SdfMlpPlan:
             self.b_last = float(bs[6][0])
             self.scale = float(net.scale)
             self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
+            self.value_stream, self.value_row = _pack_value_stream(ws, bs, self.n_levels)
             self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
             self.value_ok = vmax < 6.0e4
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -887,6 +963,10 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
                L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
                flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
+    elif not want_grad and os.environ.get("GENS_SDF_VALUE_ROWMAJOR") is None:
+        L.call("gens_sdf_value", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_stream), L.ptr(plan.value_row), plan.b_last,
+               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.stream(), nbytes=nbytes,
+               flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_value")
     else:
         L.call("gens_sdf_mlp", volumes.table, volumes.dim_table, volumes.n, plan.wf_table, plan.wb_table, L.ptr(plan.w_last),
                L.ptr(plan.w_last_scaled), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),

@@ -222,6 +222,20 @@ int gens_sdf_mlp_dev(const float* const* vols_packed, const int* dims, int n_lev
                      const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* sdf_out, float* grad_out,
                      void* stream);
 
+/* The VALUE of the same network (grad_out == NULL of gens_sdf_mlp), same exact float32 MFMA arithmetic, laid out for the value-only
+ * passes (k6t_sdf_value.hip): the hierarchical sampling of implicit_surface.py:125,329-352 and the lattice of :407-427.  A wavefront owns
+ * 32 points and all 128 hidden units; the activated accumulators are the next layer's matrix operands (the weights are packed in the
+ * order the accumulators come out in), so nothing goes through LDS and there are no barriers.
+ *   wstream: DEVICE, 16-byte aligned, (gens_sdf_value_groups(n_levels) + 1) x 4 KB: per group of four feature pairs
+ *   [4 output tiles][64 lanes][4 floats] in the pair order of gens_amd.ops._value_pairs, pre-scaled as gens_sdf_mlp's w_last_scaled
+ *   convention; the trailing group is zero (read ahead, never used).
+ *   w_out: DEVICE (2, 64 + 4 * GC) float32: row 0 of lin6 in the accumulator / slot order of each lane half (hidden part / (100/ln 2)). */
+int gens_sdf_value(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
+                   float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
+                   float* sdf_out, void* stream);
+/* number of 4 KB groups in the weight stream of gens_sdf_value, without the trailing zero group (125 for 3 levels, 0 = unsupported) */
+int gens_sdf_value_groups(int n_levels);
+
 /* Same computation as gens_sdf_mlp on the f16 matrix cores with split operands: every float32 operand is an (hi, lo)
  * pair of halfs and every product is hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error, 5.3x
  * fewer matrix-pipe cycles).  wf_hi / wf_lo / wb_hi / wb_lo: HOST arrays of 6 device pointers to half fragments

@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from gens_amd.ops import _pack_value_units, _value_slots
+from gens_amd.ops import _pack_value_stream, _pack_value_units, _value_pairs, _value_slots
 
 
 def network(ws, bs, pe, cond):
@@ -88,3 +88,85 @@ def test_slot_tables_cover_every_column_once():
         assert sorted(v for v in pe.reshape(-1).tolist() if v >= 0) == list(range(27))
         assert sorted(v for v in cond.reshape(-1).tolist() if v >= 0) == list(range(20 * n_levels))
         assert (pe == -1).sum() == 1 and (cond == -1).sum() == 1
+
+
+def pair_model(stream, w_out, b_last, n_levels, pe, cond):
+    """k6t_sdf_value.hip's dataflow in float64: group g, tile T, lane (m, half), position i multiplies what lane half holds for pair i."""
+    hid, pet, condt = _value_pairs(n_levels)
+    a = stream.double().reshape(stream.shape[0], 4, 2, 32, 4)      # [group][tile][half][m][i]
+    n = pe.shape[0]
+    one, zero = torch.ones(n, 1, dtype=torch.float64), torch.zeros(n, 1, dtype=torch.float64)
+
+    def operand(table, values):
+        src = torch.cat([values, one, zero], 1)
+        k = values.shape[1]
+        cols = torch.where(table >= 0, table, torch.where(table == -1, torch.full_like(table, k), torch.full_like(table, k + 1)))
+        return src[:, cols.reshape(-1)].reshape(n, *table.shape)
+
+    def product(g0, b, issued=None):
+        """issued[g] MFMAs of group g are executed (the kernel drops a block's trailing pair)."""
+        groups = b.shape[1]
+        w = a[g0:g0 + groups].clone()
+        if issued is not None:
+            for g, cnt in enumerate(issued):
+                w[g, :, :, :, cnt:] = 0.0
+        return torch.einsum("gthmi,nghi->ntm", w, b).reshape(n, 128)
+
+    def act(t):
+        return torch.where(t > 0.2 * 100 / math.log(2.0), t, torch.log2(1 + torch.exp2(t)))
+
+    gc = condt.shape[0]
+    ncs = 5 * 2 * n_levels + 1
+    cond_issued = [4 if 4 * g + 4 <= ncs else 3 for g in range(gc)]
+    bp, bc = operand(pet, pe.double()), operand(condt, cond.double())
+    h = act(product(0, bp, [4, 4, 4, 3]))
+    g = 4
+    for l in range(1, 6):
+        bh = operand(hid, h)
+        if l == 3:
+            t = product(g, bh[:, :13])
+            g += 13
+            t = t + product(g, bp, [4, 4, 4, 3])
+            g += 4
+        else:
+            t = product(g, bh)
+            g += 16
+        t = t + product(g, bc, cond_issued)
+        g += gc
+        h = act(t)
+    assert g + 1 == stream.shape[0] and float(stream[-1].abs().max()) == 0.0
+    out = torch.zeros(n, dtype=torch.float64)
+    for hh in range(2):
+        feat = torch.tensor([32 * t + 8 * (r >> 2) + 4 * hh + (r & 3) for t in range(4) for r in range(16)])
+        out += h[:, feat] @ w_out[hh, :64].double()
+        tb = condt[:, hh].reshape(-1)
+        out += (torch.where(tb >= 0, 1.0, 0.0) * cond.double()[:, tb.clamp(min=0)]) @ w_out[hh, 64:].double()
+    return out + b_last
+
+
+@pytest.mark.parametrize("n_levels", [3, 5])
+def test_float32_pair_stream_reproduces_the_network(n_levels):
+    g = torch.Generator().manual_seed(70 + n_levels)
+    fe = 20 * n_levels
+    dims = [(128, 27), (128, 128 + fe), (101, 128 + fe), (128, 128 + fe), (128, 128 + fe), (128, 128 + fe), (13, 128 + fe)]
+    ws = [torch.randn(o, i, generator=g) / math.sqrt(i) for o, i in dims]
+    bs = [0.1 * torch.randn(o, generator=g) for o, _ in dims]
+    n = 29
+    pe = torch.randn(n, 27, generator=g)
+    cond = torch.randn(n, fe, generator=g)
+    stream, w_out = _pack_value_stream(ws, bs, n_levels)
+    assert stream.dtype == torch.float32 and stream.shape[1:] == (4, 64, 4)
+    want = network([w.double() for w in ws], [b.double() for b in bs], pe.double(), cond.double())[:, 0]
+    got = pair_model(stream, w_out, float(bs[6][0]), n_levels, pe, cond)
+    assert (got - want).abs().max() < 2e-6 * want.abs().max().clamp(min=1.0)      # float32 rounding of the scaled weights only
+
+
+def test_pair_tables_cover_every_column_once():
+    for n_levels in (3, 5):
+        hid, pe, cond = _value_pairs(n_levels)
+        assert sorted(hid.reshape(-1).tolist()) == list(range(128))
+        assert sorted(v for v in pe.reshape(-1).tolist() if v >= 0) == list(range(27))
+        assert sorted(v for v in cond.reshape(-1).tolist() if v >= 0) == list(range(20 * n_levels))
+        assert (pe == -1).sum() == 1 and (cond == -1).sum() == 1
+        # the pair a kernel does not issue (trailing position of a block) carries nothing
+        assert (pe[3, :, 3] == -2).all() and (cond[-1, :, 3] == -2).all()
