@@ -73,7 +73,12 @@ def build_model(dims, device):
 def main():
     global DOMINANT
     args = parse()
-    DOMINANT = "gens_sdf_mlp:grad" if args.sdf_precision == "f32" else "gens_sdf_mlp_f16:grad"
+    if args.sdf_precision != "f32":
+        DOMINANT = "gens_sdf_mlp_f16:grad"
+    elif len(args.dims) == 3 and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None:
+        DOMINANT = "gens_sdf_grad"          # three levels: the transposed value + gradient kernel sdf_grad_t_k (k6g_sdf_grad.hip)
+    else:
+        DOMINANT = "gens_sdf_mlp:grad"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -85,6 +85,8 @@ SIGNATURES = {
     "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_value": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p],
     "gens_sdf_value_groups": [_i],
+    "gens_sdf_grad": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_sdf_grad_groups": [_i],
     "gens_sdf_value_f16": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_value_f16_units": [_i],
     "gens_lncc_fwd": [_p, _p, _l, _i, _i, _i, _p, _p, _p],

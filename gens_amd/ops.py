@@ -863,6 +863,80 @@ def _pack_value_stream(ws, bs, n_levels):
     return stream, w_out
 
 
+def _pack_grad_stream(ws, bs, n_levels):
+    """The weight stream and output row of gens_sdf_grad (k6g_sdf_grad.hip): the forward groups of _pack_value_stream, then the reverse
+    pass on the TRUE (unscaled) transposed matrices, layer 5 down to 1: 16 groups (layer 2: 13) of W_l[:, :128]^T for the hidden-unit
+    gradients, then per pair of conditioning tiles 8 groups (layer 2: 7) of 2 tiles x 8 pairs whose ROWS are ordered so that lane half h,
+    register r of tile c receives the gradient of that half's slot 16 c + r, at layer 3 four groups of 1 tile x 16 pairs for the
+    point-encoding slots, and after layer 1 the same four groups of W_0^T; two trailing zero groups (the kernel reads two groups ahead)."""
+    dev = ws[0].device
+    r2 = 1.0 / math.sqrt(2.0)
+    c = 100.0 / math.log(2.0)
+    hid, pe, cond = (t.to(dev) for t in _value_pairs(n_levels))
+    nch = 2 * n_levels
+    tc = (5 * nch + 15) // 16
+    fwd, _ = _pack_value_stream(ws, bs, n_levels)
+    out = [fwd[:-1]]
+
+    def groups(mat, table):
+        """mat (32 NT, 128): rows = output rows of NT tiles, columns = hidden units of the layer -> (G, NT, 64, 4)."""
+        nt = mat.shape[0] // 32
+        g = mat[:, table.reshape(-1)].reshape(nt, 32, *table.shape)
+        return g.permute(2, 0, 3, 1, 4).reshape(table.shape[0], nt, 64, 4)
+
+    # accumulator row m of a tile <-> (lane half, register): m = 8 (r >> 2) + 4 half + (r & 3)
+    m = torch.arange(32, device=dev)
+    row_half, row_reg = (m >> 2) & 1, ((m >> 3) << 2) | (m & 3)
+    cond_flat = cond.permute(1, 0, 2).reshape(2, -1)                     # [half][slot] -> feature column, -1 one, -2 nothing
+    pe_flat = pe.permute(1, 0, 2).reshape(2, -1)
+    for l in range(5, 0, -1):
+        w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+        w[:ws[l].shape[0]] = ws[l]
+        wt = w[:, :128].t().clone()                                       # rows: hidden inputs, columns: units of layer l
+        if l == 3:
+            wt = r2 * wt
+            wt[101:] = 0.0
+        out.append(groups(wt, hid if l != 2 else hid[:13]).reshape(-1, 4, 64, 4))
+        mc = torch.zeros(32 * tc, 128, device=dev, dtype=_f32)
+        for cc in range(tc):
+            slot = 16 * cc + row_reg
+            col = torch.where(slot < cond_flat.shape[1], cond_flat[row_half, slot.clamp(max=cond_flat.shape[1] - 1)], torch.full_like(slot, -2))
+            live = col >= 0
+            mc[32 * cc + m[live]] = w[:, 128 + col[live]].t()
+        full = groups(mc, hid)                                            # (16 = (t, g), tc, 64, 4)
+        for cc in range(0, tc, 2):
+            for t in range(4 if l != 2 else 3):
+                for gg in range(2):
+                    a, b = full[4 * t + 2 * gg], full[4 * t + 2 * gg + 1]
+                    out.append(torch.stack([a[cc], b[cc], a[cc + 1], b[cc + 1]])[None])
+            if l == 2:
+                a, b = full[12], full[13]
+                out.append(torch.stack([a[cc], b[cc], a[cc + 1], b[cc + 1]])[None])
+        if l == 3 or l == 1:
+            src = r2 * w[:, 101:128] if l == 3 else None
+            if l == 1:
+                w0 = torch.zeros(128, 27, device=dev, dtype=_f32)
+                w0[:ws[0].shape[0]] = ws[0]
+                src = w0
+            mp = torch.zeros(32, 128, device=dev, dtype=_f32)
+            col = torch.where(row_reg < pe_flat.shape[1], pe_flat[row_half, row_reg.clamp(max=pe_flat.shape[1] - 1)], torch.full_like(row_reg, -2))
+            live = col >= 0
+            mp[m[live]] = src[:, col[live]].t()
+            fp = groups(mp, hid)                                          # (16, 1, 64, 4)
+            out.append(fp[:, 0].reshape(4, 4, 64, 4))                     # group t: the four float4 g = 0..3
+    out.append(torch.zeros(2, 4, 64, 4, device=dev, dtype=_f32))
+    stream = torch.cat(out, 0).contiguous()
+    w_last = ws[6][0]
+    fe = 20 * n_levels
+    w_out = torch.zeros(2, 64 + 16 * tc, device=dev, dtype=_f32)
+    for hh in range(2):
+        feat = torch.tensor([32 * t + 8 * (r >> 2) + 4 * hh + (r & 3) for t in range(4) for r in range(16)], device=dev)
+        w_out[hh, :64] = w_last[feat] / c
+        tb = cond_flat[hh][:16 * tc]
+        w_out[hh, 64:64 + tb.shape[0]] = torch.where(tb >= 0, w_last[(128 + tb).clamp(0, 127 + fe)], torch.zeros_like(tb, dtype=_f32))
+    return stream, w_out
+
+
 class SdfMlpPlan:
     """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
     (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
@@ -911,6 +985,10 @@ class SdfMlpPlan:
             self.scale = float(net.scale)
             self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
             self.value_stream, self.value_row = _pack_value_stream(ws, bs, self.n_levels)
+            self.grad_stream = None
+            if self.n_levels == 3:
+                self.grad_stream, self.grad_row = _pack_grad_stream(ws, bs, self.n_levels)
+                assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(3) + 2
             self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
             self.value_ok = vmax < 6.0e4
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -963,6 +1041,10 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
                L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
                flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
+    elif want_grad and plan.grad_stream is not None and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None:
+        L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
+               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out), L.stream(),
+               nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad")
     elif not want_grad and os.environ.get("GENS_SDF_VALUE_ROWMAJOR") is None:
         L.call("gens_sdf_value", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_stream), L.ptr(plan.value_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.stream(), nbytes=nbytes,

@@ -236,6 +236,20 @@ int gens_sdf_value(const float* const* vols_packed, const int* dims, int n_level
 /* number of 4 KB groups in the weight stream of gens_sdf_value, without the trailing zero group (125 for 3 levels, 0 = unsupported) */
 int gens_sdf_value_groups(int n_levels);
 
+/* Value and gradient (gens_sdf_mlp with grad_out) in the transposed dataflow of gens_sdf_value (k6g_sdf_grad.hip): one wavefront per 32
+ * points runs the forward chain and the reverse chain G_{l-1} = (W_l^T G_l) * softplus' entirely in registers (softplus' of layers 0 and 1
+ * waits in LDS); the gradients of the volume features and of the point encoding accumulate in tiles whose rows are ordered per lane, so
+ * the chain rule to x is lane-local.  Three volume levels only (GENS_ELIMIT otherwise: use gens_sdf_mlp).
+ *   wstream: DEVICE, 16-byte aligned, (gens_sdf_grad_groups(n_levels) + 2) x 4 KB in the order of gens_amd.ops._pack_grad_stream: the
+ *   forward groups of gens_sdf_value, then the reverse pass on the plain transposed matrices; the two trailing groups are zero
+ *   (the kernel requests weights two groups ahead).
+ *   w_out: DEVICE (2, 64 + 16 * TC) float32: row 0 of lin6 per lane half (hidden part / (100 / ln 2), then the conditioning slots). */
+int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
+                  float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
+                  float* sdf_out, float* grad_out, void* stream);
+/* number of 4 KB groups in the weight stream of gens_sdf_grad, without the trailing zero groups (0 = unsupported level count) */
+int gens_sdf_grad_groups(int n_levels);
+
 /* Same computation as gens_sdf_mlp on the f16 matrix cores with split operands: every float32 operand is an (hi, lo)
  * pair of halfs and every product is hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error, 5.3x
  * fewer matrix-pipe cycles).  wf_hi / wf_lo / wb_hi / wb_lo: HOST arrays of 6 device pointers to half fragments

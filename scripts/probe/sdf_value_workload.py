@@ -15,6 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4 * 1024 * 1024
 levels = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = sys.argv[3] if len(sys.argv) > 3 else "lattice"
 precision = sys.argv[4] if len(sys.argv) > 4 else "f16x2"
+want_grad = len(sys.argv) > 5 and sys.argv[5] == "grad"
 dims = [256, 128, 64, 32, 16][:levels]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -35,13 +36,15 @@ else:                                   # 64^3 chunks of a 512^3 lattice, as ext
     pts = torch.cat(chunks)[:n].contiguous()
 plan = ops.SdfMlpPlan(surf.sdf_network)
 sdf = torch.empty(n, 1, device=dev)
+grad = torch.empty(n, 3, device=dev) if want_grad else None
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-ops.sdf_mlp(plan, vols, pts, sdf_out=sdf, precision=precision)
+ops.sdf_mlp(plan, vols, pts, sdf_out=sdf, grad_out=grad, want_grad=want_grad, precision=precision)
 torch.cuda.synchronize()
 s.record()
 for _ in range(5):
-    ops.sdf_mlp(plan, vols, pts, sdf_out=sdf, precision=precision)
+    ops.sdf_mlp(plan, vols, pts, sdf_out=sdf, grad_out=grad, want_grad=want_grad, precision=precision)
 e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 5
-print(f"{precision} L={levels} {mode}: {ms:.3f} ms per {n} points = {n / ms / 1e3:.1f} Mpts/s")
+tag = precision + (" grad" if want_grad else "")
+print(f"{tag} L={levels} {mode}: {ms:.3f} ms per {n} points = {n / ms / 1e3:.1f} Mpts/s")
