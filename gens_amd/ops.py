@@ -1029,7 +1029,13 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
         return (sdf_out, grad_out) if want_grad else sdf_out
-    if precision == "f16x2" and not want_grad:
+    if want_grad and plan.grad_stream is not None and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None and (
+            precision == "f32" or os.environ.get("GENS_SDF_GRAD_F16") is None):
+        # (also under "f16x2": the float32 transposed kernel is faster than the split-half gradient kernel, and exact)
+        L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
+               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out), L.stream(),
+               nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad")
+    elif precision == "f16x2" and not want_grad:
         assert plan.value_ok, "weights exceed the half range: use precision='f32'"
         L.call("gens_sdf_value_f16", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_units, torch.float16), L.ptr(plan.value_w_out),
                plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
@@ -1041,10 +1047,6 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
                L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
                flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
-    elif want_grad and plan.grad_stream is not None and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None:
-        L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
-               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out), L.stream(),
-               nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad")
     elif not want_grad and os.environ.get("GENS_SDF_VALUE_ROWMAJOR") is None:
         L.call("gens_sdf_value", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_stream), L.ptr(plan.value_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.stream(), nbytes=nbytes,

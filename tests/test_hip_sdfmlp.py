@@ -75,9 +75,10 @@ def test_fused_matches_cpu_oracle(golden):
 
 
 @pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 33)])
-def test_split_half_kernel_matches_float32_kernel(n_levels, n):
-    """gens_sdf_mlp_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation."""
+def test_split_half_kernel_matches_float32_kernel(n_levels, n, monkeypatch):
+    """gens_sdf_mlp_f16 / gens_sdf_value_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation."""
     from gens_amd import ops, synthetic
+    monkeypatch.setenv("GENS_SDF_GRAD_F16", "1")      # (three levels otherwise take the float32 transposed kernel for the gradient)
     net, dims = _net(n_levels, seed=10 + n_levels)
     vols = ops.VolumeSet.packed([v.cuda() * 3 for v in synthetic.make_volumes(dims, seed=9)])
     pts = (torch.rand(n, 3, generator=torch.Generator().manual_seed(n)) * 2.2 - 1.1).cuda()
@@ -97,3 +98,59 @@ def test_split_half_overflow_is_flagged():
     plan = ops.SdfMlpPlan(net)
     ops.sdf_mlp(plan, ops.VolumeSet.packed(big), torch.zeros(64, 3, device="cuda"), precision="f16x2")
     assert plan.overflowed() and not plan.overflowed()                      # reading the flag clears it
+
+
+@pytest.mark.parametrize("n_levels,n", [(3, 1), (3, 33), (3, 129), (3, 4097), (5, 257)])
+def test_transposed_kernels_equal_row_major_kernel(n_levels, n, monkeypatch):
+    """gens_sdf_value / gens_sdf_grad (one wave per 32 points, activations chained in registers) against gens_sdf_mlp (four waves per
+    32 points, activations through LDS): the same float32 MFMA products in another summation order, with an index map and a device-side
+    count as the masked evaluation of implicit_surface.py:125,179-191 passes them; untouched outputs keep their fill values."""
+    from gens_amd import ops, synthetic
+    net, dims = _net(n_levels, seed=20 + n_levels)
+    packed = ops.VolumeSet.packed([v.cuda() * 2 for v in synthetic.make_volumes(dims, seed=4)])
+    g = torch.Generator().manual_seed(n)
+    pts = (torch.rand(n, 3, generator=g) * 2.4 - 1.2).cuda()
+    idx = torch.randperm(n, generator=g).cuda()
+    count = torch.tensor([max(1, (2 * n) // 3)], dtype=torch.int32, device="cuda")
+    plan = ops.SdfMlpPlan(net)
+
+    def run():
+        sdf, grad, val = torch.full((n, 1), 100.0, device="cuda"), torch.zeros(n, 3, device="cuda"), torch.full((n, 1), 100.0, device="cuda")
+        ops.sdf_mlp(plan, packed, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=grad, count=count)
+        ops.sdf_mlp(plan, packed, pts, index=idx, sdf_out=val, count=count)
+        return sdf, grad, val
+
+    new = run()
+    monkeypatch.setenv("GENS_SDF_VALUE_ROWMAJOR", "1")
+    monkeypatch.setenv("GENS_SDF_GRAD_ROWMAJOR", "1")
+    old = run()
+    live = idx[:int(count)]
+    dead = idx[int(count):]
+    for a, b, tol in zip(new, old, (2e-6, 2e-5, 2e-6)):
+        assert (a[live] - b[live]).abs().max() <= tol * max(1.0, b[live].abs().max().item())
+        assert torch.equal(a[dead], b[dead])                      # fill values
+    assert (new[0][live] - new[2][live]).abs().max() <= 2e-6      # the value of the gradient kernel and of the value kernel
+
+
+def test_new_sdf_kernels_reject_bad_arguments():
+    from gens_amd import lib as L, ops, synthetic
+    net, dims = _net(3, seed=1)
+    packed = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims, seed=4)])
+    plan = ops.SdfMlpPlan(net)
+    pts = torch.zeros(8, 3, device="cuda")
+    out = torch.zeros(8, 1, device="cuda")
+    with pytest.raises(RuntimeError, match="null weight stream"):
+        L.call("gens_sdf_value", packed.table, packed.dim_table, 3, None, L.ptr(plan.value_row), 0.0, 1.0, L.ptr(pts), None, 8, None, L.ptr(out),
+               L.stream())
+    with pytest.raises(RuntimeError, match="scale must be non-zero"):
+        L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 0.0, L.ptr(pts), None, 8,
+               None, L.ptr(out), L.ptr(pts), L.stream())
+    net5, dims5 = _net(5, seed=1)
+    packed5 = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims5, seed=4)])
+    with pytest.raises(RuntimeError, match="3 volume levels"):
+        L.call("gens_sdf_grad", packed5.table, packed5.dim_table, 5, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
+               None, L.ptr(out), L.ptr(pts), L.stream())
+    # empty launches are no-ops
+    ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), want_grad=True)
+    ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"))
+    ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), precision="f16x2")
