@@ -94,10 +94,11 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     // the weight stream: a wave-uniform (scalar) base that advances by one group + 16 lane + an immediate per tile; three register
     // sets rotate: this group's weights and the next TWO groups' (in flight): with one wave per SIMD nothing else hides an L2 miss
     const float4* wp = wstream;
-    float4 wbuf[3][4];
+    constexpr int NB = NLEV == 3 ? 3 : 2;      // (five levels: the conditioning operands take the third set's registers; one group ahead)
+    float4 wbuf[NB][4];
     int par = 0;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB - 1; ++b) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) wbuf[b][t] = wp[lane + 64 * t];
         wp += 256;
@@ -180,13 +181,13 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
     f32x16 gc[TC], gp;            // d sdf / d (this lane's conditioning slots), d sdf / d (its point-encoding slots)
 
-    // one group = 4 float4 of weights per lane (requested two groups ahead, into the register set just freed) and up to 16 MFMAs
+    // one group = 4 float4 of weights per lane (requested NB - 1 groups ahead, into the register set just freed) and up to 16 MFMAs
 #define TG_FETCH()                                                                                    \
     float4(&a_)[4] = wbuf[par];                                                                       \
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                  \
-        wbuf[(par + 2) % 3][t_] = wp[lane + 64 * t_];                                                 \
+        wbuf[(par + NB - 1) % NB][t_] = wp[lane + 64 * t_];                                           \
     wp += 256;                                                                                        \
-    par = (par + 1) % 3;                                                                              \
+    par = (par + 1) % NB;                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 #define TG_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), ACC, 0, 0, 0)
     // 4 tiles x 4 pairs (CNT: 3): acc[T] += A_T(pair i) * b_i
@@ -421,21 +422,27 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
-extern "C" int gens_sdf_grad_groups(int n_levels) { return n_levels == 3 ? GradShapeT<3>::NG_FWD + GradShapeT<3>::NG_BWD : 0; }
+extern "C" int gens_sdf_grad_groups(int n_levels) {
+    return n_levels == 3 ? GradShapeT<3>::NG_FWD + GradShapeT<3>::NG_BWD : n_levels == 5 ? GradShapeT<5>::NG_FWD + GradShapeT<5>::NG_BWD : 0;
+}
 
 extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
                              float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
                              float* sdf_out, float* grad_out, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_grad", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3, GENS_ELIMIT, "gens_sdf_grad: built for 3 volume levels, got %d (use gens_sdf_mlp)", n_levels);
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_grad: built for 3 or 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(wstream && w_out, GENS_EINVAL, "gens_sdf_grad: null weight stream");
     GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_sdf_grad: the weight stream must be 16-byte aligned");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out && grad_out)), GENS_EINVAL, "gens_sdf_grad: null pts / output");
     GENS_CHECK_ARG(scale != 0.0f, GENS_EINVAL, "gens_sdf_grad: scale must be non-zero");
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, 32);
-    sdf_grad_t_k<3><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
-                                                         sdf_out, grad_out);
+    if (n_levels == 3)
+        sdf_grad_t_k<3><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
+                                                             sdf_out, grad_out);
+    else
+        sdf_grad_t_k<5><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
+                                                             sdf_out, grad_out);
     return gens_launch_status("gens_sdf_grad");
 }

@@ -985,10 +985,8 @@ class SdfMlpPlan:
             self.scale = float(net.scale)
             self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
             self.value_stream, self.value_row = _pack_value_stream(ws, bs, self.n_levels)
-            self.grad_stream = None
-            if self.n_levels == 3:
-                self.grad_stream, self.grad_row = _pack_grad_stream(ws, bs, self.n_levels)
-                assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(3) + 2
+            self.grad_stream, self.grad_row = _pack_grad_stream(ws, bs, self.n_levels)
+            assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(self.n_levels) + 2
             self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
             self.value_ok = vmax < 6.0e4
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)

@@ -239,7 +239,7 @@ int gens_sdf_value_groups(int n_levels);
 /* Value and gradient (gens_sdf_mlp with grad_out) in the transposed dataflow of gens_sdf_value (k6g_sdf_grad.hip): one wavefront per 32
  * points runs the forward chain and the reverse chain G_{l-1} = (W_l^T G_l) * softplus' entirely in registers (softplus' of layers 0 and 1
  * waits in LDS); the gradients of the volume features and of the point encoding accumulate in tiles whose rows are ordered per lane, so
- * the chain rule to x is lane-local.  Three volume levels only (GENS_ELIMIT otherwise: use gens_sdf_mlp).
+ * the chain rule to x is lane-local.  Three or five volume levels.
  *   wstream: DEVICE, 16-byte aligned, (gens_sdf_grad_groups(n_levels) + 2) x 4 KB in the order of gens_amd.ops._pack_grad_stream: the
  *   forward groups of gens_sdf_value, then the reverse pass on the plain transposed matrices; the two trailing groups are zero
  *   (the kernel requests weights two groups ahead).
