@@ -105,13 +105,17 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     // V (64-wide tile, stride BL_VS) ALIASES T: a wave finishes every MFMA read of a tile before its epilogue writes, and
     // the two layouts are never live together (T: until base_fc.0 has been read; again from rgb_fc.0's output on).
     float* V = T_[wave];
-    // D (ray_dir_fc hidden layer, 16 columns) lives in T's columns 0..15, which are free until the mean / variance are written
+    // D (ray_dir_fc hidden layer, 16 columns) lives in T's columns D_OFF.., which are free until the mean / variance are written
     float* RD = RD_[wave];
     float* R = R_[wave];
     float* C = C_[wave];
     constexpr int F = 3 + 4 * NLEV;
     constexpr int G_B1 = (3 * F + 7) / 8;      // reduction groups of base_fc.0
     static_assert(8 * G_B1 <= BL_TS, "wide tile too narrow");
+    // columns of the 16-wide ray_dir_fc hidden layer D inside T: 0..15 while x (columns 2F..3F) starts behind them; with one feature level
+    // (F = 7: x at 14..20) behind base_fc.0's padded reduction instead
+    constexpr int D_OFF = (2 * F >= 16) ? 0 : 8 * G_B1;
+    static_assert(D_OFF + 16 <= BL_TS, "no room for the ray_dir_fc hidden layer");
     const int S = nv - 1, PPW = 32 / S;
     const int64_t first = ((int64_t)blockIdx.x * BL_WAVES + wave) * PPW;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
@@ -183,15 +187,15 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         narrow_group<2>(RD, BL_RS, 0, W.rd1, lane, c0, c1);                              // K = 4 (+4 zero columns)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            T[nrow(0, r, lane) * BL_TS + j] = elu1(c0[r]);
-            T[nrow(1, r, lane) * BL_TS + j] = elu1(c1[r]);
+            T[nrow(0, r, lane) * BL_TS + D_OFF + j] = elu1(c0[r]);
+            T[nrow(1, r, lane) * BL_TS + D_OFF + j] = elu1(c1[r]);
         }
     }
     __syncthreads();
     {
         BGroups<2> w;
         load_b(w, W.rd2, lane);
-        f32x16 a = tile_mfma(T, BL_TS, w, W.rd2_b[col], lane);
+        f32x16 a = tile_mfma(T + D_OFF, BL_TS, w, W.rd2_b[col], lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (col < F) T[crow(r, lane) * BL_TS + 2 * F + col] += elu1(a[r]);        // x = rgb_feat + direction_feat (:89)

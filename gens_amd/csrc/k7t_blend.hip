@@ -1,0 +1,422 @@
+// K7t: source-view feature look-up + the whole IBRNet-style BlendingNetwork for FOUR source views, TRANSPOSED (the dataflow of
+// k6t_sdf_value.hip applied to k7_blend.hip's eleven small layers; replaces for validation rendering lookup_feature + compute_angle,
+// /root/reference/models/modules/projector.py:278-349, and BlendingNetwork.forward, models/modules/blending_network.py:69-118, as
+// called from implicit_surface.py:196-199).
+//
+//   * weights are the A operand of v_mfma_f32_16x16x4_f32 (16 output features x 4 K, exact float32), the (point, view) rows the B
+//     operand: one wavefront owns 64 rows = 16 points x 4 views as four N tiles of 16 columns; column n' = 4 * point + view of a tile
+//     lives in the four lanes (n', q), q = 0..3.  Every activation vector is kept in "quad layout": feature f = 4 kq + q is register
+//     kq of lane group q -- which is both what an accumulator tile T delivers (register i of lane group q = output row 4 q + i, and
+//     the host orders the rows of every matrix so that row 4 q + i of tile T is feature 4 (4 T + i) + q) and what the B operand of
+//     the K quad kq wants.  The activations of all eleven layers stay in registers: k7_blend.hip moved them through an LDS tile
+//     (362 LDS instructions and their address arithmetic per 32 rows) and loaded every weight once per 32 rows; here a weight float4
+//     is loaded once per 64 rows and feeds 16 MFMAs.
+//   * the four views of a point are four ADJACENT lanes: min / sum / max over views are two quad_perm DPP butterflies.
+//   * base_fc.0 reads cat([mean, var, x]): mean and var are the same for the four views of a point, so their 2 F columns are
+//     multiplied ONCE per point -- an N tile of the wave's 16 points (operands gathered with ds_bpermute) -- and the result, broadcast
+//     back to the rows, is the initial value of the x-part's accumulators: 48 instead of 192 MFMAs per 64 rows.
+//   * biases ride in spare K slots where the K padding is free (base_fc.0, rgb_fc.0), else in the accumulators' initial value; the
+//     single-output layers (vis_fc's 33rd row, vis_fc2.2, rgb_fc.4) are per-lane dot products reduced over the four lane groups.
+#include "k4_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define KT_NT 4                 // N tiles per wave (16 columns each): 16 points x 4 views
+#define KT_XS 29                // row stride of the gathered-feature tile (floats): odd, so the per-column reads spread over the banks
+
+struct BlendTWeights {
+    const float4* stream;       // A fragments in consumption order: per (M tile, group of 4 K quads) 64 lanes x float4
+    const float* tab;           // per lane group q: [entry][q][8] floats (accumulator-layout biases, dot-product rows)
+    float v2_last_b, u2_b, r3_b, s_abs;
+};
+enum { KT_RD1_B = 0, KT_RD2_B, KT_B2_B, KT_V1_B, KT_V2_B, KT_U1_B, KT_R2_B, KT_V2_LAST, KT_U2, KT_R3, KT_TAB_ENTRIES };
+
+__device__ __forceinline__ float elu1t(float x) { return __builtin_amdgcn_fmed3f(x, hw_exp(x) - 1.0f, 0.0f); }   // see k7_blend.hip::elu1
+__device__ __forceinline__ float quad_sum(float v) {      // sum over the 4 lanes of a quad (= the 4 views of a point), in every lane
+    v += dpp_move<0xB1, 0xF>(v, v);                       // quad_perm:[1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(v, v);                       // quad_perm:[2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float lanes_q_sum(float v) {   // sum over the four lane groups q of a column
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, const float4* __restrict__ imgs, const float* __restrict__ w2c,
+                                                   const float* __restrict__ intr, const float* __restrict__ c2w, const float* __restrict__ pts,
+                                                   const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                   float* __restrict__ rgb_out, uint8_t* __restrict__ vis_out) {
+    constexpr int F = 3 + 4 * NLEV;
+    constexpr int XQ = NLEV + 1;             // K quads of a feature vector: F + 1 = 4 (NLEV + 1) slots, the last one carries the constant one
+    constexpr int XT = (XQ + 3) / 4;         // accumulator tiles of a feature vector
+    static_assert(4 * XQ <= KT_XS, "feature tile too narrow");
+    __shared__ float X[64 * KT_XS];          // gathered rows: rgb (3), features (4 NLEV), one
+    __shared__ float RD[64 * 5];             // ray difference (4)
+    __shared__ float R[64];                  // mask
+    const int lane = threadIdx.x;
+    const int np = lane & 15, q = lane >> 4;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
+    const int64_t first = (int64_t)blockIdx.x * 16;
+    if (first >= n) return;
+
+    // weights: scalar base, three float4 registers rotate (this group's, the next two in flight)
+    const float4* wp = W.stream;
+    float4 wb[3];
+    int par = 0;
+    wb[0] = wp[lane];
+    wb[1] = wp[lane + 64];
+    wp += 128;
+
+    // ---------------------------------------------------------------- phase 0: one lane per (point, view) row gathers it
+    {
+        const int pl = lane >> 2, sv = (lane & 3) + 1;
+        const bool live = first + pl < n;
+        const int64_t src = live ? (index ? index[first + pl] : first + pl) : 0;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (live) { x = pts[3 * src]; y = pts[3 * src + 1]; z = pts[3 * src + 2]; }
+        bool inside = true;
+        float* xr = X + lane * KT_XS;
+        const SrcBase pb = project_src_base(w2c + 16 * sv, intr + 16 * sv, x, y, z);
+#pragma unroll
+        for (int l = 0; l < NLEV; ++l) {
+            const int h = fs.h[l], w = fs.w[l];
+            const SrcProj p = project_src_level(pb, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l]);
+            inside = inside && p.inside;
+            float4 f = f4_zero(), c = f4_zero();
+            if (live) {
+                const Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+                f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+                if (l == 0) c = sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+            }
+            xr[3 + 4 * l] = f.x; xr[4 + 4 * l] = f.y; xr[5 + 4 * l] = f.z; xr[6 + 4 * l] = f.w;
+            if (l == 0) { xr[0] = c.x; xr[1] = c.y; xr[2] = c.z; }
+        }
+        xr[F] = 1.0f;
+        R[lane] = (live && inside) ? 1.0f : 0.0f;
+        if (live && vis_out) vis_out[src * 4 + (sv - 1)] = inside ? 1 : 0;
+        // compute_angle (projector.py:278-291), hardware sqrt / rcp as in k7_blend.hip
+        float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
+        const float rn = hw_rcp(__builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f);
+        rx *= rn; ry *= rn; rz *= rn;
+        const float* cs = c2w + 16 * sv;
+        float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
+        const float sn = hw_rcp(__builtin_amdgcn_sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
+        sx *= sn; sy *= sn; sz *= sn;
+        const float dx = rx - sx, dy = ry - sy, dz = rz - sz;
+        const float dn = hw_rcp(fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f));
+        float* rd = RD + lane * 5;
+        rd[0] = live ? dx * dn : 0.0f;
+        rd[1] = live ? dy * dn : 0.0f;
+        rd[2] = live ? dz * dn : 0.0f;
+        rd[3] = live ? rx * sx + ry * sy + rz * sz : 0.0f;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- this lane's operand slots of the four N tiles
+    float xq[KT_NT][XQ];        // x in quad layout (slot F = the one)
+    float rgbc[KT_NT];          // colour channel q of the column (q < 3)
+    float rdq[KT_NT], dotv[KT_NT], mask[KT_NT], rd3one[KT_NT], rdsh[KT_NT];
+#pragma unroll
+    for (int j = 0; j < KT_NT; ++j) {
+        const int row = 16 * j + np;
+#pragma unroll
+        for (int kq = 0; kq < XQ; ++kq) xq[j][kq] = X[row * KT_XS + 4 * kq + q];
+        rgbc[j] = xq[j][0];
+        rdq[j] = RD[row * 5 + q];
+        dotv[j] = RD[row * 5 + 3];
+        mask[j] = R[row];
+        rdsh[j] = q ? RD[row * 5 + q - 1] : 0.0f;                      // rgb_fc.0's quad [vis, rd0, rd1, rd2] (vis filled in later)
+        rd3one[j] = q == 0 ? dotv[j] : (q == 1 ? 1.0f : 0.0f);        // ... and [rd3, one, 0, 0]
+    }
+    const float* tab = W.tab + q * 8;
+#define KT_TAB(E, K) tab[(E) * 32 + (K)]
+
+    // one group of the weight stream: NQ_ (<= 4) K quads of one M tile for the NT_ N tiles whose accumulators are ACC_(j) and whose
+    // operands are B_(j, quad); requested two groups ahead
+#define KT_GROUP(NT_, NQ_, ACC_, B_, Q0_)                                                                \
+    {                                                                                                    \
+        const float4 a_ = wb[par];                                                                       \
+        wb[(par + 2) % 3] = wp[lane];                                                                    \
+        wp += 64;                                                                                        \
+        par = (par + 1) % 3;                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, B_(j_, (Q0_)), ACC_(j_), 0, 0, 0); \
+        if ((NQ_) > 1) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.y, B_(j_, (Q0_) + 1), ACC_(j_), 0, 0, 0); } \
+        if ((NQ_) > 2) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.z, B_(j_, (Q0_) + 2), ACC_(j_), 0, 0, 0); } \
+        if ((NQ_) > 3) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.w, B_(j_, (Q0_) + 3), ACC_(j_), 0, 0, 0); } \
+    }
+    // a whole product: M tiles MT_, K quads NQ_ (groups of 4), accumulators ACC2_(T, j)
+#define KT_PRODUCT(NT_, MT_, NQ_, ACC2_, B_)                                                             \
+    _Pragma("unroll") for (int T_ = 0; T_ < (MT_); ++T_)                                                 \
+        _Pragma("unroll") for (int g_ = 0; g_ < ((NQ_) + 3) / 4; ++g_) {                                 \
+            KT_GROUP(NT_, ((NQ_) - 4 * g_ < 4 ? (NQ_) - 4 * g_ : 4), ACC_T_, B_, 4 * g_)                 \
+        }
+
+    // ---------------------------------------------------------------- ray_dir_fc (blending_network.py:36-39, 87)
+    f32x4 D[KT_NT];
+    {
+        const f32x4 b = {KT_TAB(KT_RD1_B, 0), KT_TAB(KT_RD1_B, 1), KT_TAB(KT_RD1_B, 2), KT_TAB(KT_RD1_B, 3)};
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j) D[j] = b;
+#define ACC_T_(j) D[j]
+#define B_RD(j, k) rdq[j]
+        KT_GROUP(KT_NT, 1, ACC_T_, B_RD, 0)
+#undef ACC_T_
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) D[j][i] = elu1t(D[j][i]);
+    }
+    {
+        f32x4 E[XT][KT_NT];
+#pragma unroll
+        for (int T = 0; T < XT; ++T) {
+            const f32x4 b = {KT_TAB(KT_RD2_B, 4 * T), KT_TAB(KT_RD2_B, 4 * T + 1), KT_TAB(KT_RD2_B, 4 * T + 2), KT_TAB(KT_RD2_B, 4 * T + 3)};
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j) E[T][j] = b;
+        }
+#define ACC_T_(j) E[T_][j]
+#define B_D(j, k) D[j][k]
+        KT_PRODUCT(KT_NT, XT, 4, E, B_D)
+#undef ACC_T_
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+            for (int kq = 0; kq < XQ; ++kq) xq[j][kq] += elu1t(E[kq >> 2][j][kq & 3]);      // x = rgb_feat + direction_feat (:89); the one's row is zero
+    }
+
+    // ---------------------------------------------------------------- view weights, weighted mean / variance (:93-101)
+    float wn[KT_NT];
+    float pm[XQ], pv[XQ];          // mean / variance of the wave's 16 points as the operand of an N tile of points
+    {
+        const int src = (4 * (np & 3) + 16 * q) * 4;          // byte address for ds_bpermute: lane 4 (point in tile) of the same lane group
+        const int jsel = np >> 2;
+#pragma unroll
+        for (int kq = 0; kq < XQ; ++kq) { pm[kq] = 0.0f; pv[kq] = 0.0f; }
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j) {
+            const float e = hw_exp(W.s_abs * (dotv[j] - 1.0f));
+            float mn = fminf(e, dpp_move<0xB1, 0xF>(e, e));
+            mn = fminf(mn, dpp_move<0x4E, 0xF>(mn, mn));
+            const float wr = (e - mn) * mask[j];
+            wn[j] = wr / (quad_sum(wr) + 1e-8f);
+#pragma unroll
+            for (int kq = 0; kq < XQ; ++kq) {
+                const float mean = quad_sum(wn[j] * xq[j][kq]);
+                const float d = xq[j][kq] - mean;
+                const float var = quad_sum(wn[j] * (d * d));
+                const float tm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, mean)));
+                const float tv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, var)));
+                pm[kq] = jsel == j ? tm : pm[kq];
+                pv[kq] = jsel == j ? tv : pv[kq];
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- base_fc (:103-104)
+    f32x4 H1[4][KT_NT];           // base_fc.0's 64 outputs per N tile
+    {
+        f32x4 P[4];                // the mean / variance columns, once per POINT (N tile = the 16 points)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) P[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define ACC_T_(j) P[T_]
+#define B_PM(j, k) ((k) < XQ ? pm[(k) < XQ ? (k) : 0] : pv[(k) < XQ ? 0 : (k) - XQ])
+        KT_PRODUCT(1, 4, 2 * XQ, P, B_PM)
+#undef ACC_T_
+        // back to the rows: column n' of N tile j is point 4 j + n' / 4
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j) {
+            const int src = (4 * j + (np >> 2) + 16 * q) * 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = P[T][i];
+                    asm volatile("" : "+v"(v));      // (hipcc 7.2 otherwise replaces the four moves of a tile by ONE and splats its result)
+                    H1[T][j][i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
+                }
+        }
+#define ACC_T_(j) H1[T_][j]
+#define B_X(j, k) xq[j][k]
+        KT_PRODUCT(KT_NT, 4, XQ, H1, B_X)          // + x's columns and the bias (slot F)
+#undef ACC_T_
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) H1[T][j][i] = elu1t(H1[T][j][i]);
+    }
+    f32x4 XH[2][KT_NT];           // the 32-wide hidden state x
+    {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const f32x4 b = {KT_TAB(KT_B2_B, 4 * T), KT_TAB(KT_B2_B, 4 * T + 1), KT_TAB(KT_B2_B, 4 * T + 2), KT_TAB(KT_B2_B, 4 * T + 3)};
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j) XH[T][j] = b;
+        }
+#define ACC_T_(j) XH[T_][j]
+#define B_H1(j, k) H1[(k) >> 2][j][(k) & 3]
+        KT_PRODUCT(KT_NT, 2, 16, XH, B_H1)
+#undef ACC_T_
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) XH[T][j][i] = elu1t(XH[T][j][i]);
+    }
+
+    // a 32 -> 32 layer on SCALE(j) * x: G1 = elu(W (s x) + b)
+    f32x4 G1[2][KT_NT];
+#define B_XS(j, k) xs[j][k]
+#define KT_LAYER32(ENTRY, SCALE)                                                                                      \
+    {                                                                                                                 \
+        float xs[KT_NT][8];                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < KT_NT; ++j)                                                             \
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) xs[j][k] = XH[k >> 2][j][k & 3] * SCALE[j];                 \
+        _Pragma("unroll") for (int T = 0; T < 2; ++T) {                                                               \
+            const f32x4 b = {KT_TAB(ENTRY, 4 * T), KT_TAB(ENTRY, 4 * T + 1), KT_TAB(ENTRY, 4 * T + 2), KT_TAB(ENTRY, 4 * T + 3)}; \
+            _Pragma("unroll") for (int j = 0; j < KT_NT; ++j) G1[T][j] = b;                                           \
+        }                                                                                                             \
+        KT_PRODUCT(KT_NT, 2, 8, G1, B_XS)                                                                             \
+        _Pragma("unroll") for (int T = 0; T < 2; ++T)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < KT_NT; ++j)                                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) G1[T][j][i] = elu1t(G1[T][j][i]);                       \
+    }
+    // dot product of G1 with a 32-float row given in quad layout, summed over the lane groups: every lane of the column gets it
+#define KT_DOT32(ENTRY, OUT)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < KT_NT; ++j) {                                                               \
+        float s_ = 0.0f;                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) s_ = __builtin_fmaf(G1[k >> 2][j][k & 3], KT_TAB(ENTRY, k), s_); \
+        OUT[j] = lanes_q_sum(s_);                                                                                     \
+    }
+
+    // ---------------------------------------------------------------- vis_fc on x * weight (:106-109)
+    float vis[KT_NT];
+#define ACC_T_(j) G1[T_][j]
+    KT_LAYER32(KT_V1_B, wn)
+    KT_DOT32(KT_V2_LAST, vis)                                      // the 33rd output of vis_fc.2 reads the same hidden layer
+#undef ACC_T_
+    {
+        f32x4 V2[2][KT_NT];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const f32x4 b = {KT_TAB(KT_V2_B, 4 * T), KT_TAB(KT_V2_B, 4 * T + 1), KT_TAB(KT_V2_B, 4 * T + 2), KT_TAB(KT_V2_B, 4 * T + 3)};
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j) V2[T][j] = b;
+        }
+#define ACC_T_(j) V2[T_][j]
+#define B_G1(j, k) G1[(k) >> 2][j][(k) & 3]
+        KT_PRODUCT(KT_NT, 2, 8, V2, B_G1)
+#undef ACC_T_
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) XH[T][j][i] += elu1t(V2[T][j][i]);              // x = x + x_res
+    }
+#pragma unroll
+    for (int j = 0; j < KT_NT; ++j) vis[j] = hw_sigmoid(elu1t(vis[j] + W.v2_last_b)) * mask[j];
+
+    // ---------------------------------------------------------------- vis_fc2 on x * vis (:110)
+    float vis2[KT_NT];
+#define ACC_T_(j) G1[T_][j]
+    KT_LAYER32(KT_U1_B, vis)
+    KT_DOT32(KT_U2, vis2)
+#undef ACC_T_
+#pragma unroll
+    for (int j = 0; j < KT_NT; ++j) vis2[j] = hw_sigmoid(vis2[j] + W.u2_b) * mask[j];
+
+    // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-115)
+    float score[KT_NT];
+    {
+        f32x4 C1[KT_NT];
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j) C1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                 // (bias: the one of quad 9)
+#define ACC_T_(j) C1[j]
+#define B_R1(j, k) ((k) < 8 ? XH[((k) < 8 ? (k) : 0) >> 2][j][(k) & 3] : (k) == 8 ? (q == 0 ? vis2[j] : rdsh[j]) : rd3one[j])
+        KT_PRODUCT(KT_NT, 1, 10, C1, B_R1)
+#undef ACC_T_
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) C1[j][i] = elu1t(C1[j][i]);
+        f32x4 C2[KT_NT];
+        {
+            const f32x4 b = {KT_TAB(KT_R2_B, 0), KT_TAB(KT_R2_B, 1), KT_TAB(KT_R2_B, 2), KT_TAB(KT_R2_B, 3)};
+#pragma unroll
+            for (int j = 0; j < KT_NT; ++j) C2[j] = b;
+        }
+#define ACC_T_(j) C2[j]
+#define B_C1(j, k) C1[j][k]
+        KT_PRODUCT(KT_NT, 1, 4, C2, B_C1)
+#undef ACC_T_
+#pragma unroll
+        for (int j = 0; j < KT_NT; ++j) {
+            const float s = elu1t(C2[j][0]) * KT_TAB(KT_R3, 0) + elu1t(C2[j][1]) * KT_TAB(KT_R3, 1);      // features 0..7 = registers 0, 1 of the four groups
+            score[j] = mask[j] == 0.0f ? -1e9f : lanes_q_sum(s) + W.r3_b;                                  // masked_fill(mask == 0, -1e9)  (:115)
+        }
+    }
+
+    // ---------------------------------------------------------------- softmax over views, colour (:116-117)
+#pragma unroll
+    for (int j = 0; j < KT_NT; ++j) {
+        float mx = fmaxf(score[j], dpp_move<0xB1, 0xF>(score[j], score[j]));
+        mx = fmaxf(mx, dpp_move<0x4E, 0xF>(mx, mx));
+        const float e = hw_exp(score[j] - mx);
+        const float den = quad_sum(e);
+        const float col = quad_sum(rgbc[j] * e) / den;
+        const int64_t pt = first + 4 * j + (np >> 2);
+        if ((np & 3) == 0 && q < 3 && pt < n) {
+            const int64_t dst = index ? index[pt] : pt;
+            rgb_out[3 * dst + q] = col;
+        }
+    }
+#undef KT_TAB
+#undef KT_GROUP
+#undef KT_PRODUCT
+#undef KT_LAYER32
+#undef KT_DOT32
+}
+
+int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels);
+
+// number of float4-per-lane groups of the weight stream (without the two zero groups the kernel reads ahead)
+extern "C" int gens_blend_views4_groups(int n_levels) {
+    if (n_levels < 1 || n_levels > 5) return 0;
+    const int xq = n_levels + 1, xt = (xq + 3) / 4;
+    return 1 + xt + 4 * ((2 * xq + 3) / 4) + 4 * ((xq + 3) / 4) + 2 * 4 + 2 * 2 + 2 * 2 + 2 * 2 + 3 + 1;
+}
+
+extern "C" int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                 const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
+                                 const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats && wstream && tab && scalars, GENS_EINVAL, "gens_blend_views4: null table");
+    if (int e = gens_fill_maps("gens_blend_views4", &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels <= 5, GENS_ELIMIT, "gens_blend_views4: at most 5 feature levels (d_feature <= 20), got %d", n_levels);
+    GENS_CHECK_ARG(nv == 5, GENS_ELIMIT, "gens_blend_views4: built for four source views (nv = 5), got nv=%d (use gens_blend_views)", nv);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_blend_views4: null camera / image pointer");
+    GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_blend_views4: the weight stream must be 16-byte aligned");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_views4: null pts / output");
+    if (n == 0) return 0;
+    BlendTWeights W;
+    W.stream = (const float4*)wstream;
+    W.tab = tab;
+    W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
+    const unsigned grid = gens_blocks(n, 16);
+    hipStream_t st = (hipStream_t)stream;
+#define BLEND_LAUNCH(NL) blend_t_k<NL><<<grid, 64, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out)
+    switch (n_levels) {
+        case 1: BLEND_LAUNCH(1); break;
+        case 2: BLEND_LAUNCH(2); break;
+        case 3: BLEND_LAUNCH(3); break;
+        case 4: BLEND_LAUNCH(4); break;
+        default: BLEND_LAUNCH(5); break;
+    }
+#undef BLEND_LAUNCH
+    return gens_launch_status("gens_blend_views4");
+}

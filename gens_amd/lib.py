@@ -81,6 +81,8 @@ SIGNATURES = {
     "gens_tv_bwd_scaled": [_p, _p, _i, _i, _i, _f, _p, _p, _p],
     "gens_lattice_points": [_fp, _fp, _i, _l, _l, _p, _p],
     "gens_blend_views": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _fp, _p, _p, _l, _p, _p, _p, _p],
+    "gens_blend_views4": [_pp, _ip, _i, _p, _p, _p, _p, _i, _p, _p, _fp, _p, _p, _l, _p, _p, _p, _p],
+    "gens_blend_views4_groups": [_i],
     "gens_compact_valid": [_p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_value": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p],

@@ -1430,6 +1430,74 @@ def _pad32(b):
     return out
 
 
+def _pack_blend_t(layers, n_feat):
+    """Weight stream and tables of gens_blend_views4 (k7t_blend.hip).  Activations live in "quad layout" (feature f = 4 kq + q: register
+    kq of lane group q); an A fragment of (M tile T, group g of four K quads) holds for lane (m, qk) and j = 0..3 the weight
+    W[16 T + 4 (m & 3) + (m >> 2)][slot 16 g + 4 j + qk], so that accumulator register i of lane group q is output feature 4 (4 T + i) + q.
+    `layers`: dict name -> (weight, bias).  Returns (stream (G + 2, 64, 4), tab (entries, 4, 8)); the two trailing groups are zero."""
+    f = n_feat
+    xq = (f + 1) // 4
+    dev = layers["rd1"][0].device
+    lane = torch.arange(64, device=dev)
+    m, qk = lane & 15, lane >> 4
+    row_in_tile = 4 * (m & 3) + (m >> 2)
+
+    def product(w, slots, m_tiles, bias=None):
+        """w (O, I); slots: list of source columns per input slot (-1: the bias, -2: nothing), padded to whole quads."""
+        o = w.shape[0]
+        aug = torch.cat([w, (bias if bias is not None else torch.zeros(o, device=dev))[:, None], torch.zeros(o, 1, device=dev)], 1)
+        aug = torch.cat([aug, torch.zeros(16 * m_tiles - o, aug.shape[1], device=dev)], 0) if 16 * m_tiles > o else aug
+        cols = torch.tensor([c if c >= 0 else (w.shape[1] if c == -1 else w.shape[1] + 1) for c in slots], device=dev)
+        nq = (len(slots) + 3) // 4
+        cols = torch.cat([cols, torch.full((4 * nq - len(slots),), w.shape[1] + 1, device=dev)])
+        groups = []
+        for t in range(m_tiles):
+            rows = 16 * t + row_in_tile
+            for g in range((nq + 3) // 4):
+                frag = torch.zeros(64, 4, device=dev, dtype=_f32)
+                for j in range(4):
+                    kq = 4 * g + j
+                    if kq < nq:
+                        frag[:, j] = aug[rows, cols[4 * kq + qk]]
+                groups.append(frag)
+        return groups
+
+    rd1, rd2, b1, b2, v1, v2, u1, u2, r1, r2, r3 = (layers[k] for k in ("rd1", "rd2", "b1", "b2", "v1", "v2", "u1", "u2", "r1", "r2", "r3"))
+    xt = (xq + 3) // 4
+    g = []
+    g += product(rd1[0], [0, 1, 2, 3], 1)
+    g += product(rd2[0], list(range(16)), xt)
+    pad = [-2] * (4 * xq - f)
+    g += product(b1[0], list(range(f)) + pad + list(range(f, 2 * f)) + pad, 4)                         # mean | var, once per point
+    g += product(b1[0], list(range(2 * f, 3 * f)) + [-1], 4, b1[1])                                    # x and the bias (slot F)
+    g += product(b2[0], list(range(64)), 2)
+    g += product(v1[0], list(range(32)), 2)
+    g += product(v2[0][:32], list(range(32)), 2)
+    g += product(u1[0], list(range(32)), 2)
+    g += product(r1[0], list(range(36)) + [36, -1, -2, -2], 1, r1[1])
+    g += product(r2[0], list(range(16)), 1)
+    stream = torch.stack(g + [torch.zeros(64, 4, device=dev, dtype=_f32)] * 2).contiguous()
+
+    def acc_bias(b, m_tiles):            # [q][4 T + i] = b[16 T + 4 i + q]
+        full = torch.zeros(32, device=dev, dtype=_f32)
+        full[:min(b.shape[0], 16 * m_tiles)] = b[:16 * m_tiles]
+        out = torch.zeros(4, 8, device=dev, dtype=_f32)
+        for q in range(4):
+            for t in range(m_tiles):
+                for i in range(4):
+                    out[q, 4 * t + i] = full[16 * t + 4 * i + q]
+        return out
+
+    def dot_row(w):                      # [q][kq] = w[4 kq + q]
+        full = torch.zeros(32, device=dev, dtype=_f32)
+        full[:w.shape[0]] = w
+        return full.reshape(8, 4).t().contiguous()
+
+    tab = torch.stack([acc_bias(rd1[1], 1), acc_bias(rd2[1], xt), acc_bias(b2[1], 2), acc_bias(v1[1], 2), acc_bias(v2[1][:32], 2),
+                       acc_bias(u1[1], 2), acc_bias(r2[1], 1), dot_row(v2[0][32]), dot_row(u2[0][0]), dot_row(r3[0][0])]).contiguous()
+    return stream, tab
+
+
 class BlendPlan:
     """Weights of a BlendingNetwork re-packed for gens_blend_views (anti_alias_pooling=True, d_feature <= 20)."""
 
@@ -1458,6 +1526,9 @@ class BlendPlan:
                             P(u1[0]), _pad32(u1[1]), _c(u2[0][0].clone()),
                             N(r1[0], [(0, 4), (16, 4), (32, 2)]), _pad32(r1[1]), N(r2[0], [(0, 4)]), _pad32(r2[1]), _c(r3[0][0].clone())]
             self.scalars = (C.c_float * 4)(float(v2[1][32]), float(u2[1][0]), float(r3[1][0]), float(net.s.detach().abs()))
+            self.t_stream, self.t_tab = _pack_blend_t(dict(rd1=rd1, rd2=rd2, b1=b1, b2=b2, v1=v1, v2=v2, u1=u1, u2=u2, r1=r1, r2=r2, r3=r3),
+                                                      self.n_feat)
+            assert self.t_stream.shape[0] == L.load().gens_blend_views4_groups((self.n_feat - 3) // 4) + 2
         self.table = L.ptr_table(self.tensors)
         self.key = BlendPlan.version(net)
 
@@ -1478,9 +1549,16 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
     feats = [aligned16(f.detach()) for f in views.feat_tex]
     f = plan.n_feat
     flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
+    nbytes = n * (12 + 12 + s + (8 if idx is not None else 0))
+    if s == 4 and os.environ.get("GENS_BLEND_ROWMAJOR") is None:       # four source views: the transposed kernel (k7t_blend.hip)
+        L.call("gens_blend_views4", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16),
+               L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), views.nv, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts),
+               L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(),
+               live=None if count is None else (count, n), nbytes=nbytes, flops=n * flops, label="gens_blend_views")
+        return rgb_out, vis_out
     L.call("gens_blend_views", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16), L.ptr(views.w2c), L.ptr(views.intr),
            L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
-           L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=n * (12 + 12 + s + (8 if idx is not None else 0)), flops=n * flops)
+           L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=nbytes, flops=n * flops)
     return rgb_out, vis_out
 
 

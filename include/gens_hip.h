@@ -328,6 +328,18 @@ int gens_blend_views(const float* const* feats, const int* hw, int n_levels, con
                      const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out,
                      void* stream);
 
+/* gens_blend_views for FOUR source views (nv = 5, the shipped configuration) in the transposed dataflow of gens_sdf_value
+ * (k7t_blend.hip): one wavefront owns 64 (point, view) rows, the weights are the A operand of v_mfma_f32_16x16x4_f32, the activations of
+ * the eleven layers stay in registers in "quad layout", the mean / variance columns of base_fc.0 are multiplied once per point.
+ * Same inputs and outputs as gens_blend_views except the weights:
+ *   wstream: DEVICE, 16-byte aligned, (gens_blend_views4_groups(n_levels) + 2) x 1 KB: A fragments in consumption order
+ *   (gens_amd.ops._pack_blend_t), the two trailing groups zero;  tab: DEVICE (10, 4, 8) float32: accumulator-layout biases and the
+ *   three single-output rows per lane group;  scalars: HOST float[4] as gens_blend_views. */
+int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                      const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
+                      const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
+int gens_blend_views4_groups(int n_levels);
+
 /* ------------------------------------------------------------------------------------------------------------
  * K18  lookup_feature + BlendingNetwork.forward of a training / fine-tune step, and their backward
  *      (projector.py:278-349, blending_network.py:69-118 as called from implicit_surface.py:196-199; first order only)

@@ -21,7 +21,7 @@ def _setup(nv, n_levels, seed, n):
     return ops, net, views, pts.cuda()
 
 
-@pytest.mark.parametrize("nv,n_levels,n", [(5, 5, 1000), (3, 5, 333), (4, 5, 250), (5, 3, 64), (5, 5, 1)])
+@pytest.mark.parametrize("nv,n_levels,n", [(5, 5, 1000), (3, 5, 333), (4, 5, 250), (5, 3, 64), (5, 5, 1), (5, 1, 130), (5, 2, 77), (3, 1, 130)])
 def test_fused_blend_matches_k4_plus_torch_network(nv, n_levels, n):
     ops, net, views, pts = _setup(nv, n_levels, seed=nv * 10 + n_levels, n=n)
     fv, rd, mk = ops.lookup_feature(pts, views)
@@ -108,3 +108,42 @@ def test_training_kernels_match_the_cpu_oracle(nv, n_levels, n):
     assert abs(float(net.s.grad) - float(sd["color_network.s"].grad)) < 3e-5 * top
     bad = {k: v for k, v in worst.items() if v >= 2e-3}
     assert not bad, (bad, {k: float(sd["color_network." + k].grad.abs().max()) for k in bad if "color_network." + k in sd}, top)
+
+
+@pytest.mark.parametrize("n_levels,n", [(5, 1), (5, 15), (5, 17), (3, 1000), (1, 130), (2, 64), (4, 333)])
+def test_transposed_blend_kernel_equals_row_major_kernel(n_levels, n, monkeypatch):
+    """gens_blend_views4 (four source views: 64 rows per wave, activations in registers in quad layout, mean / variance columns once per
+    point) against gens_blend_views (32 rows per wave through an LDS tile): the same float32 MFMA products in another order; with an index
+    map and a device-side count as implicit_surface.py:196-199 passes them, untouched outputs keep their fill values."""
+    ops, net, views, pts = _setup(5, n_levels, seed=70 + n_levels, n=n)
+    g = torch.Generator().manual_seed(n)
+    idx = torch.randperm(n, generator=g).cuda()
+    count = torch.tensor([max(1, (3 * n) // 4)], dtype=torch.int32, device="cuda")
+    plan = ops.BlendPlan(net)
+
+    def run():
+        rgb = torch.full((n, 3), -7.0, device="cuda")
+        vis = torch.full((n, 4), 9, dtype=torch.uint8, device="cuda")
+        ops.blend_views(plan, views, pts, index=idx, rgb_out=rgb, vis_out=vis, count=count)
+        return rgb, vis
+
+    new = run()
+    monkeypatch.setenv("GENS_BLEND_ROWMAJOR", "1")
+    old = run()
+    live, dead = idx[:int(count)], idx[int(count):]
+    assert torch.equal(new[1], old[1])
+    assert (new[0][live] - old[0][live]).abs().max() < 5e-6
+    assert (new[0][dead] == -7).all() and (new[1][dead] == 9).all()
+
+
+def test_transposed_blend_kernel_rejects_other_view_counts():
+    from gens_amd import lib as L
+    ops, net, views, pts = _setup(5, 5, seed=3, n=8)
+    plan = ops.BlendPlan(net)
+    feats = [ops.aligned16(f.detach()) for f in views.feat_tex]
+    hw = [d for f in views.feat_tex for d in f.shape[1:3]]
+    out = torch.zeros(8, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="four source views"):
+        L.call("gens_blend_views4", L.ptr_table(feats, align=16), L.int_table(hw), 5, L.ptr(ops.aligned16(views.imgs_tex.detach()), align=16),
+               L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), 4, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts), None, 8,
+               None, L.ptr(out), None, L.stream())
