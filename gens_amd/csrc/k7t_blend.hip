@@ -135,51 +135,52 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 
     // one group of the weight stream: NQ_ (<= 4) K quads of one M tile for the NT_ N tiles whose accumulators are ACC_(j) and whose
     // operands are B_(j, quad); requested two groups ahead
-#define KT_GROUP(NT_, NQ_, ACC_, B_, Q0_)                                                                \
+#define KT_GROUP(NT_, NQ_, ACC_, C0_, B_, Q0_)                                                           \
     {                                                                                                    \
         const float4 a_ = wb[par];                                                                       \
         wb[(par + 2) % 3] = wp[lane];                                                                    \
         wp += 64;                                                                                        \
         par = (par + 1) % 3;                                                                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, B_(j_, (Q0_)), ACC_(j_), 0, 0, 0); \
+        _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, B_(j_, (Q0_)), C0_(j_), 0, 0, 0); \
         if ((NQ_) > 1) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.y, B_(j_, (Q0_) + 1), ACC_(j_), 0, 0, 0); } \
         if ((NQ_) > 2) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.z, B_(j_, (Q0_) + 2), ACC_(j_), 0, 0, 0); } \
         if ((NQ_) > 3) { _Pragma("unroll") for (int j_ = 0; j_ < (NT_); ++j_) ACC_(j_) = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.w, B_(j_, (Q0_) + 3), ACC_(j_), 0, 0, 0); } \
     }
-    // a whole product: M tiles MT_, K quads NQ_ (groups of 4), accumulators ACC2_(T, j)
+    // a whole product: M tiles MT_, K quads NQ_ (groups of 4), accumulators ACC_T_(j); the FIRST MFMA of a chain reads its C operand
+    // from INIT_T_(j) -- the bias vector of the tile, shared by the four N tiles -- instead of from a copy of it in the accumulator
 #define KT_PRODUCT(NT_, MT_, NQ_, ACC2_, B_)                                                             \
     _Pragma("unroll") for (int T_ = 0; T_ < (MT_); ++T_)                                                 \
         _Pragma("unroll") for (int g_ = 0; g_ < ((NQ_) + 3) / 4; ++g_) {                                 \
-            KT_GROUP(NT_, ((NQ_) - 4 * g_ < 4 ? (NQ_) - 4 * g_ : 4), ACC_T_, B_, 4 * g_)                 \
+            if (g_ == 0) KT_GROUP(NT_, ((NQ_) < 4 ? (NQ_) : 4), ACC_T_, INIT_T_, B_, 0)                  \
+            else KT_GROUP(NT_, ((NQ_) - 4 * g_ < 4 ? (NQ_) - 4 * g_ : 4), ACC_T_, ACC_T_, B_, 4 * g_)   \
         }
 
     // ---------------------------------------------------------------- ray_dir_fc (blending_network.py:36-39, 87)
     f32x4 D[KT_NT];
     {
         const f32x4 b = {KT_TAB(KT_RD1_B, 0), KT_TAB(KT_RD1_B, 1), KT_TAB(KT_RD1_B, 2), KT_TAB(KT_RD1_B, 3)};
-#pragma unroll
-        for (int j = 0; j < KT_NT; ++j) D[j] = b;
 #define ACC_T_(j) D[j]
+#define INIT_T_(j) b
 #define B_RD(j, k) rdq[j]
-        KT_GROUP(KT_NT, 1, ACC_T_, B_RD, 0)
+        KT_GROUP(KT_NT, 1, ACC_T_, INIT_T_, B_RD, 0)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) D[j][i] = elu1t(D[j][i]);
     }
     {
-        f32x4 E[XT][KT_NT];
+        f32x4 E[XT][KT_NT], bias[XT];
 #pragma unroll
-        for (int T = 0; T < XT; ++T) {
-            const f32x4 b = {KT_TAB(KT_RD2_B, 4 * T), KT_TAB(KT_RD2_B, 4 * T + 1), KT_TAB(KT_RD2_B, 4 * T + 2), KT_TAB(KT_RD2_B, 4 * T + 3)};
-#pragma unroll
-            for (int j = 0; j < KT_NT; ++j) E[T][j] = b;
-        }
+        for (int T = 0; T < XT; ++T)
+            bias[T] = (f32x4){KT_TAB(KT_RD2_B, 4 * T), KT_TAB(KT_RD2_B, 4 * T + 1), KT_TAB(KT_RD2_B, 4 * T + 2), KT_TAB(KT_RD2_B, 4 * T + 3)};
 #define ACC_T_(j) E[T_][j]
+#define INIT_T_(j) bias[T_]
 #define B_D(j, k) D[j][k]
         KT_PRODUCT(KT_NT, XT, 4, E, B_D)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j)
 #pragma unroll
@@ -218,12 +219,13 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     f32x4 H1[4][KT_NT];           // base_fc.0's 64 outputs per N tile
     {
         f32x4 P[4];                // the mean / variance columns, once per POINT (N tile = the 16 points)
-#pragma unroll
-        for (int T = 0; T < 4; ++T) P[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define INIT_T_(j) zero4
 #define ACC_T_(j) P[T_]
 #define B_PM(j, k) ((k) < XQ ? pm[(k) < XQ ? (k) : 0] : pv[(k) < XQ ? 0 : (k) - XQ])
         KT_PRODUCT(1, 4, 2 * XQ, P, B_PM)
 #undef ACC_T_
+#undef INIT_T_
         // back to the rows: column n' of N tile j is point 4 j + n' / 4
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j) {
@@ -238,9 +240,11 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
                 }
         }
 #define ACC_T_(j) H1[T_][j]
+#define INIT_T_(j) H1[T_][j]
 #define B_X(j, k) xq[j][k]
         KT_PRODUCT(KT_NT, 4, XQ, H1, B_X)          // + x's columns and the bias (slot F)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -250,16 +254,16 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     }
     f32x4 XH[2][KT_NT];           // the 32-wide hidden state x
     {
+        f32x4 bias[2];
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const f32x4 b = {KT_TAB(KT_B2_B, 4 * T), KT_TAB(KT_B2_B, 4 * T + 1), KT_TAB(KT_B2_B, 4 * T + 2), KT_TAB(KT_B2_B, 4 * T + 3)};
-#pragma unroll
-            for (int j = 0; j < KT_NT; ++j) XH[T][j] = b;
-        }
+        for (int T = 0; T < 2; ++T)
+            bias[T] = (f32x4){KT_TAB(KT_B2_B, 4 * T), KT_TAB(KT_B2_B, 4 * T + 1), KT_TAB(KT_B2_B, 4 * T + 2), KT_TAB(KT_B2_B, 4 * T + 3)};
 #define ACC_T_(j) XH[T_][j]
+#define INIT_T_(j) bias[T_]
 #define B_H1(j, k) H1[(k) >> 2][j][(k) & 3]
         KT_PRODUCT(KT_NT, 2, 16, XH, B_H1)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -276,10 +280,9 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
         float xs[KT_NT][8];                                                                                           \
         _Pragma("unroll") for (int j = 0; j < KT_NT; ++j)                                                             \
             _Pragma("unroll") for (int k = 0; k < 8; ++k) xs[j][k] = XH[k >> 2][j][k & 3] * SCALE[j];                 \
-        _Pragma("unroll") for (int T = 0; T < 2; ++T) {                                                               \
-            const f32x4 b = {KT_TAB(ENTRY, 4 * T), KT_TAB(ENTRY, 4 * T + 1), KT_TAB(ENTRY, 4 * T + 2), KT_TAB(ENTRY, 4 * T + 3)}; \
-            _Pragma("unroll") for (int j = 0; j < KT_NT; ++j) G1[T][j] = b;                                           \
-        }                                                                                                             \
+        f32x4 bias[2];                                                                                                \
+        _Pragma("unroll") for (int T = 0; T < 2; ++T)                                                                 \
+            bias[T] = (f32x4){KT_TAB(ENTRY, 4 * T), KT_TAB(ENTRY, 4 * T + 1), KT_TAB(ENTRY, 4 * T + 2), KT_TAB(ENTRY, 4 * T + 3)}; \
         KT_PRODUCT(KT_NT, 2, 8, G1, B_XS)                                                                             \
         _Pragma("unroll") for (int T = 0; T < 2; ++T)                                                                 \
             _Pragma("unroll") for (int j = 0; j < KT_NT; ++j)                                                         \
@@ -296,21 +299,22 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     // ---------------------------------------------------------------- vis_fc on x * weight (:106-109)
     float vis[KT_NT];
 #define ACC_T_(j) G1[T_][j]
+#define INIT_T_(j) bias[T_]
     KT_LAYER32(KT_V1_B, wn)
     KT_DOT32(KT_V2_LAST, vis)                                      // the 33rd output of vis_fc.2 reads the same hidden layer
 #undef ACC_T_
+#undef INIT_T_
     {
-        f32x4 V2[2][KT_NT];
+        f32x4 V2[2][KT_NT], bias[2];
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const f32x4 b = {KT_TAB(KT_V2_B, 4 * T), KT_TAB(KT_V2_B, 4 * T + 1), KT_TAB(KT_V2_B, 4 * T + 2), KT_TAB(KT_V2_B, 4 * T + 3)};
-#pragma unroll
-            for (int j = 0; j < KT_NT; ++j) V2[T][j] = b;
-        }
+        for (int T = 0; T < 2; ++T)
+            bias[T] = (f32x4){KT_TAB(KT_V2_B, 4 * T), KT_TAB(KT_V2_B, 4 * T + 1), KT_TAB(KT_V2_B, 4 * T + 2), KT_TAB(KT_V2_B, 4 * T + 3)};
 #define ACC_T_(j) V2[T_][j]
+#define INIT_T_(j) bias[T_]
 #define B_G1(j, k) G1[(k) >> 2][j][(k) & 3]
         KT_PRODUCT(KT_NT, 2, 8, V2, B_G1)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -324,9 +328,11 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     // ---------------------------------------------------------------- vis_fc2 on x * vis (:110)
     float vis2[KT_NT];
 #define ACC_T_(j) G1[T_][j]
+#define INIT_T_(j) bias[T_]
     KT_LAYER32(KT_U1_B, vis)
     KT_DOT32(KT_U2, vis2)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
     for (int j = 0; j < KT_NT; ++j) vis2[j] = hw_sigmoid(vis2[j] + W.u2_b) * mask[j];
 
@@ -334,26 +340,25 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     float score[KT_NT];
     {
         f32x4 C1[KT_NT];
-#pragma unroll
-        for (int j = 0; j < KT_NT; ++j) C1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                 // (bias: the one of quad 9)
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};                                            // (bias: the one of quad 9)
+#define INIT_T_(j) zero4
 #define ACC_T_(j) C1[j]
 #define B_R1(j, k) ((k) < 8 ? XH[((k) < 8 ? (k) : 0) >> 2][j][(k) & 3] : (k) == 8 ? (q == 0 ? vis2[j] : rdsh[j]) : rd3one[j])
         KT_PRODUCT(KT_NT, 1, 10, C1, B_R1)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) C1[j][i] = elu1t(C1[j][i]);
         f32x4 C2[KT_NT];
-        {
-            const f32x4 b = {KT_TAB(KT_R2_B, 0), KT_TAB(KT_R2_B, 1), KT_TAB(KT_R2_B, 2), KT_TAB(KT_R2_B, 3)};
-#pragma unroll
-            for (int j = 0; j < KT_NT; ++j) C2[j] = b;
-        }
+        const f32x4 b2 = {KT_TAB(KT_R2_B, 0), KT_TAB(KT_R2_B, 1), KT_TAB(KT_R2_B, 2), KT_TAB(KT_R2_B, 3)};
 #define ACC_T_(j) C2[j]
+#define INIT_T_(j) b2
 #define B_C1(j, k) C1[j][k]
         KT_PRODUCT(KT_NT, 1, 4, C2, B_C1)
 #undef ACC_T_
+#undef INIT_T_
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j) {
             const float s = elu1t(C2[j][0]) * KT_TAB(KT_R3, 0) + elu1t(C2[j][1]) * KT_TAB(KT_R3, 1);      // features 0..7 = registers 0, 1 of the four groups
