@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rays", type=int, default=32768)
+    ap.add_argument("--no-smi", action="store_true", help="skip the rocm-smi snapshot (a child exec is refused under rocprofv3 --pmc)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L.load()
@@ -196,6 +197,8 @@ def main():
 
     smi = ""
     try:
+        if args.no_smi:
+            raise RuntimeError("skipped (--no-smi)")
         smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30).stdout
     except Exception as e:  # noqa: BLE001
         smi = f"rocm-smi unavailable: {e}"
