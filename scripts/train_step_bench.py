@@ -121,6 +121,16 @@ def _measure(quiet, kernels=False):
     label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
     if not quiet:
         print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+    if os.environ.get("GENS_TRAIN_OPS"):         # which torch operators make up the step's launches (torch.profiler over one step)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.count > 0 and getattr(e, "device_time_total", 0) > 0]
+        rows.sort(key=lambda e: -e.device_time_total)
+        print(f"{'op':38s} {'count':>6s} {'gpu ms':>8s}  shapes")
+        for e in rows[:int(os.environ["GENS_TRAIN_OPS"])]:
+            print(f"{e.key[:38]:38s} {e.count:6d} {e.device_time_total / 1e3:8.3f}  {str(e.input_shapes)[:110]}")
     if kernels:
         from gens_amd import lib as L
         L.profile_begin()
