@@ -185,9 +185,15 @@ def main():
         except Exception as e:
             ray_sharded = {"error": f"{type(e).__name__}: {e}"}
 
-    if rank != 0:
+    def finish():
+        pending = getattr(surf, "_jitter_ahead", None)  # the draws for an image that will not be rendered: let the helper thread finish before the
+        if pending is not None:                         # interpreter tears down (a daemon thread killed inside torch's generator aborts the process)
+            pending[1].join()
         if dist is not None:
             dist.destroy_process_group()
+
+    if rank != 0:
+        finish()
         return
 
     total_ray_samples = (1 if by_rays else world) * n_rays * n_final * args.steps
@@ -326,9 +332,8 @@ def main():
         "ray_sharded": ray_sharded,
         "hip_kernels": table,
     }
-    print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    print(json.dumps(line), flush=True)
+    finish()
 
 
 def kernel_rows(table, top):

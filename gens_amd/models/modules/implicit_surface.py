@@ -99,7 +99,7 @@ class JitterStream:
         self.bounds = [(s, min(s + group, n_rays)) for s in range(0, n_rays, group)]
         self.buf = buf if buf is not None else torch.empty(n_rays, 1)
         self.ready = [threading.Event() for _ in self.bounds]
-        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread = threading.Thread(target=self._run, daemon=False)    # (joined at interpreter exit: a daemon thread killed inside torch's generator aborts the process)
         self.thread.start()
 
     def _run(self):
