@@ -16,9 +16,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The same mask-free formulation as k6g_sdf_grad.hip's epilogue, so that the value this kernel returns and the value the gradient kernel returns
+// are the SAME float32 number for the same point (tests/test_hip_properties.py): log2(1 + 2^t) >= t always, and where torch switches to the
+// linear branch (100 a > 20, t > 28.85) it already equals t to the last bit or two, so max(t, .) is the threshold; the clamp keeps 2^t finite.
 __device__ __forceinline__ float softplus_ct(float t) {   // c * softplus_100(a) for t = c a, c = 100 / ln 2  (k6_sdfmlp.hip::softplus_t)
-    const float u = 1.0f + __builtin_amdgcn_exp2f(t);
-    return t > 28.853900817779268f ? t : __builtin_amdgcn_logf(u);
+    const float u = 1.0f + __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(t, 126.0f, -3.0e38f));
+    return __builtin_amdgcn_fmed3f(t, __builtin_amdgcn_logf(u), 3.0e38f);
 }
 
 // value of one packed (X, Y, Z, 4) volume at x (zero padding, align_corners=True): the taps of k6_sdfmlp.hip's prologue

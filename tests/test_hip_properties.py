@@ -325,3 +325,33 @@ def test_blend_train_kernels_at_step_size_partition():
     for f, p, q in zip(full, a, b):
         assert float((p + q - f).abs().max()) < 2e-4 * max(float(f.abs().max()), 1e-3 * top)
     assert torch.isfinite(rgb).all() and vis.any()
+
+
+def test_value_and_gradient_kernels_return_the_same_value_at_full_chunk_size():
+    """K6t (gens_sdf_value) and K6g (gens_sdf_grad) share the forward chain instruction for instruction: at the size of one bench.py ray chunk
+    (32 768 rays x 128 samples) the two values are the same float32 numbers, so the sampling passes and the render pass see ONE function; the
+    gradient is orthogonal-free sanity-checked by a directional finite difference on the points where the SDF is smooth enough for float32."""
+    from gens_amd import ops, synthetic
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface
+    dims = [256, 128, 64]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
+    vols = ops.VolumeSet.packed([v.to(dev) for v in synthetic.make_volumes(dims, seed=3)])
+    n = 32768 * 128
+    pts = torch.rand(n, 3, device=dev) * 2.2 - 1.1
+    plan = ops.SdfMlpPlan(surf.sdf_network)
+    value = ops.sdf_mlp(plan, vols, pts)
+    sdf, grad = ops.sdf_mlp(plan, vols, pts, want_grad=True)
+    assert torch.equal(value, sdf)
+    assert torch.isfinite(grad).all()
+    # directional derivative along a fixed direction on a subsample, central difference with h = 2e-3 (float32: ~1e-3 absolute noise)
+    sub = pts[::4099].contiguous()
+    d = torch.tensor([0.3, -0.5, 0.8], device=dev)
+    d = d / d.norm()
+    h = 2e-3
+    fd = (ops.sdf_mlp(plan, vols, sub + h * d) - ops.sdf_mlp(plan, vols, sub - h * d))[:, 0] / (2 * h)
+    an = (grad[::4099] * d).sum(-1)
+    err = (fd - an).abs()
+    assert err.median() < 5e-3 and (err < 0.05 * (1 + an.abs())).float().mean() > 0.97     # (kinks of the trilinear volumes and of softplus-100 excepted)
