@@ -223,9 +223,13 @@ def main():
             t = json.load(open(tpath))["kernels"].get(dom_name.split(":")[0])
             if t and args.chunk == 32768:
                 traffic = t["traffic_bytes_per_launch_corrected"]      # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)
-                traffic_source = "profiles/" + os.path.basename(tpath) + " (mean over the entry point's launches, both device kernels)"
+                traffic_source = "profiles/" + os.path.basename(tpath) + " (mean over the entry point's launches)"
                 break
-        common = {"kernel": dom_name, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+        common = {"kernel": dom_name, "traffic": traffic, "traffic_source": traffic_source,
+                  "traffic_note": ("gens_sdf_grad keeps softplus' of one layer in private memory: 16 KB per 32 points written once and read once "
+                                   "(2 x 2.1 GB per launch, evicted from the write-back L2 in between) on top of ~0.15 GB of algorithmic bytes; "
+                                   "0.36 TB/s of HBM on a matrix-pipe-bound kernel (DESIGN.md section 4b')") if dom_name == "gens_sdf_grad" else None,
+                  "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                   "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
         if dom.get("flops"):      # the fused MLP is matrix-core bound: price it against the dense MFMA peak of the operand type
             split = args.sdf_precision != "f32"     # split-half: every fp32 product costs three f16 products on the f16 pipe
