@@ -34,7 +34,9 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True):
         return time.perf_counter()
 
     res = None
+    import gc
     for it in range(repeats):
+        gc.collect()          # (a full pass of Python's cyclic collector costs ~30 ms here: keep it out of the timed item, as bench.py does for the headline)
         with torch.no_grad():
             t0 = T()
             _, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)
