@@ -125,6 +125,14 @@ __global__ __launch_bounds__(64 * TV_WAVES, 2) void sdf_value_t_k(LevelSet vols,
             f[4 * MID] = half ? t.z : t.x;
             f[4 * MID + 1] = half ? t.w : t.y;
         }
+        // not-a-number inputs must come out as not-a-number (the reference's layers propagate them; the max / median forms of the
+        // activation below would drop them): a poison term 0 * (sum of the inputs), NaN iff one of them is NaN or infinite
+        {
+            float acc_in = x[0] + x[1] + x[2];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) acc_in += f[j];
+            s_cond = 0.0f * acc_in;
+        }
 #pragma unroll
         for (int k = NCS - 1; k < 4 * GC; ++k) cnd[k] = (k == NCS - 1 && half == 0) ? 1.0f : 0.0f;
 #pragma unroll

@@ -152,8 +152,13 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
         }
         const bool other = __shfl_xor((int)inside, 32, 64) != 0;
         inside = inside && other;
+        // (not-a-number inputs must come out as not-a-number: the median form of the ELU would drop them, so the row's mask carries a poison
+        // term 0 * (sum of its inputs) -- the mask multiplies the view weights, the visibilities and is added to the score)
+        float acc_in = x + y + z;
+        for (int l = l_begin; l < l_end; ++l) acc_in += xr[3 + 4 * l] + xr[4 + 4 * l] + xr[5 + 4 * l] + xr[6 + 4 * l] + (l == 0 ? xr[0] + xr[1] + xr[2] : 0.0f);
+        acc_in += __shfl_xor(acc_in, 32, 64);
         if (half == 0) {
-            R[row * 8] = (live && inside) ? 1.0f : 0.0f;
+            R[row * 8] = ((live && inside) ? 1.0f : 0.0f) + 0.0f * acc_in;
             if (live && vis_out) vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
             // compute_angle (projector.py:278-291)
             float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(64 * BL_WAVES) void blend_k(BlendWeights W, MapSet 
     if (half == 0) {
         float s = W.r3_b;
         for (int k = 0; k < 8; ++k) s += T[row * BL_TS + 32 + k] * W.r3[k];
-        R[row * 8 + 6] = (R[row * 8] == 0.0f) ? -1e9f : s;                          // masked_fill(mask == 0, -1e9)  (:115)
+        R[row * 8 + 6] = ((R[row * 8] == 0.0f) ? -1e9f : s) + 0.0f * R[row * 8];    // masked_fill(mask == 0, -1e9)  (:115); NaN mask = poisoned row
     }
     __syncthreads();
     // ---------------------------------------------------------------- softmax over views, colour (:116-117)

@@ -94,7 +94,12 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
             if (l == 0) { xr[0] = c.x; xr[1] = c.y; xr[2] = c.z; }
         }
         xr[F] = 1.0f;
-        R[lane] = (live && inside) ? 1.0f : 0.0f;
+        // (not-a-number inputs must come out as not-a-number: the median form of the ELU would drop them, so the row's mask carries a
+        // poison term 0 * (sum of its inputs) -- the mask multiplies the view weights, the visibilities and gates the score)
+        float acc_in = x + y + z;
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc_in += xr[k];
+        R[lane] = ((live && inside) ? 1.0f : 0.0f) + 0.0f * acc_in;
         if (live && vis_out) vis_out[src * 4 + (sv - 1)] = inside ? 1 : 0;
         // compute_angle (projector.py:278-291), hardware sqrt / rcp as in k7_blend.hip
         float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j) {
             const float s = elu1t(C2[j][0]) * KT_TAB(KT_R3, 0) + elu1t(C2[j][1]) * KT_TAB(KT_R3, 1);      // features 0..7 = registers 0, 1 of the four groups
-            score[j] = mask[j] == 0.0f ? -1e9f : lanes_q_sum(s) + W.r3_b;                                  // masked_fill(mask == 0, -1e9)  (:115)
+            score[j] = (mask[j] == 0.0f ? -1e9f : lanes_q_sum(s) + W.r3_b) + 0.0f * mask[j];              // masked_fill(mask == 0, -1e9)  (:115); NaN mask = poisoned row
         }
     }
 

@@ -147,3 +147,21 @@ def test_transposed_blend_kernel_rejects_other_view_counts():
         L.call("gens_blend_views4", L.ptr_table(feats, align=16), L.int_table(hw), 5, L.ptr(ops.aligned16(views.imgs_tex.detach()), align=16),
                L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), 4, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts), None, 8,
                None, L.ptr(out), None, L.stream())
+
+
+@pytest.mark.parametrize("rowmajor", [False, True])
+def test_blend_kernels_propagate_not_a_number_inputs(rowmajor, monkeypatch):
+    """A NaN feature texel must give a NaN colour exactly for the points whose rows read it, as through the PyTorch layers (the median form
+    of the ELU would drop it: the kernels carry a poison term in the row mask)."""
+    ops, net, views, pts = _setup(5, 5, seed=9, n=3000)
+    views.feat_tex[1][2, 6:18, 8:24, 1] = float("nan")             # view 2, level 1, channel 1
+    fv, rd, mk = ops.lookup_feature(pts, views)
+    with torch.no_grad():
+        ref = net(fv, rd, mk)
+    bad = torch.isnan(ref).any(1)
+    assert 0 < int(bad.sum()) < 2500
+    if rowmajor:
+        monkeypatch.setenv("GENS_BLEND_ROWMAJOR", "1")
+    rgb, vis = ops.blend_views(ops.BlendPlan(net), views, pts)
+    assert torch.equal(torch.isnan(rgb).any(1), bad)
+    assert (rgb[~bad] - ref[~bad]).abs().max() < 2e-5

@@ -152,3 +152,30 @@ def test_new_sdf_kernels_reject_bad_arguments():
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), want_grad=True)
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"))
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), precision="f16x2")
+
+
+def test_transposed_kernels_propagate_not_a_number_inputs():
+    """A NaN in a volume texel (or in a point) must come out as NaN, as through the reference's layers: the max / median forms of the
+    activation in gens_sdf_value / gens_sdf_grad would otherwise drop it (they carry a poison term for this)."""
+    from gens_amd import ops, synthetic
+    net, dims = _net(3, seed=4)
+    vols = [v.cuda() for v in synthetic.make_volumes(dims, seed=6)]
+    vols[1][0, 2, 3:6, 3:6, 3:6] = float("nan")                    # one channel of a block of level-1 texels
+    packed = ops.VolumeSet.packed(vols)
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(4000, 3, generator=g) * 2 - 1).cuda()
+    pts[7, 1] = float("nan")
+    plan = ops.SdfMlpPlan(net)
+    val = ops.sdf_mlp(plan, packed, pts)
+    sdf, grad = ops.sdf_mlp(plan, packed, pts, want_grad=True)
+    os_env = __import__("os").environ
+    os_env["GENS_SDF_VALUE_ROWMAJOR"] = os_env["GENS_SDF_GRAD_ROWMAJOR"] = "1"
+    try:
+        ref_s, ref_g = ops.sdf_mlp(plan, packed, pts, want_grad=True)
+    finally:
+        del os_env["GENS_SDF_VALUE_ROWMAJOR"], os_env["GENS_SDF_GRAD_ROWMAJOR"]
+    bad = torch.isnan(ref_s[:, 0])
+    assert bad[7] and 5 < int(bad.sum()) < 2000
+    assert torch.equal(torch.isnan(val[:, 0]), bad) and torch.equal(torch.isnan(sdf[:, 0]), bad)
+    assert torch.equal(torch.isnan(grad).any(1), torch.isnan(ref_g).any(1))
+    assert (sdf[~bad] - ref_s[~bad]).abs().max() < 2e-6
