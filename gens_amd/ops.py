@@ -978,6 +978,8 @@ class SdfMlpPlan:
                 pf, pb = _pack_b_fragments_f16(w), _pack_b_fragments_f16(w.t().contiguous())
                 self.hf.append(pf)
                 self.hb.append(pb)
+            # (the kernels' max / median activations drop NaNs: non-finite WEIGHTS are answered with NaN outputs, as the reference's layers would)
+            self.finite = bool(torch.stack([torch.isfinite(w).all() for w in ws] + [torch.isfinite(b).all() for b in bs]).all())
             self.w_last = _c(ws[6][0].clone())
             self.w_last_scaled = self.w_last.clone()
             self.w_last_scaled[:128] /= c
@@ -1054,7 +1056,21 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(plan.w_last_scaled), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
+    if not getattr(plan, "finite", True):
+        _poison(idx, count, sdf_out, grad_out if want_grad else None)
     return (sdf_out, grad_out) if want_grad else sdf_out
+
+
+def _poison(idx, count, *outs):
+    """NaN into the evaluated rows of `outs` (index map / device-side count as the kernels take them): a network with non-finite weights."""
+    for out in outs:
+        if out is None:
+            continue
+        if idx is None:
+            out.fill_(float("nan"))
+        else:
+            live = idx if count is None else idx[torch.arange(idx.shape[0], device=idx.device) < count.to(idx.device)[0]]
+            out[live] = float("nan")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1526,6 +1542,7 @@ class BlendPlan:
                             P(u1[0]), _pad32(u1[1]), _c(u2[0][0].clone()),
                             N(r1[0], [(0, 4), (16, 4), (32, 2)]), _pad32(r1[1]), N(r2[0], [(0, 4)]), _pad32(r2[1]), _c(r3[0][0].clone())]
             self.scalars = (C.c_float * 4)(float(v2[1][32]), float(u2[1][0]), float(r3[1][0]), float(net.s.detach().abs()))
+            self.finite = bool(torch.stack([torch.isfinite(p.detach()).all() for p in net.parameters()]).all())
             self.t_stream, self.t_tab = _pack_blend_t(dict(rd1=rd1, rd2=rd2, b1=b1, b2=b2, v1=v1, v2=v2, u1=u1, u2=u2, r1=r1, r2=r2, r3=r3),
                                                       self.n_feat)
             assert self.t_stream.shape[0] == L.load().gens_blend_views4_groups((self.n_feat - 3) // 4) + 2
@@ -1555,10 +1572,14 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
                L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), views.nv, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts),
                L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(),
                live=None if count is None else (count, n), nbytes=nbytes, flops=n * flops, label="gens_blend_views")
+        if not plan.finite:
+            _poison(idx, count, rgb_out)
         return rgb_out, vis_out
     L.call("gens_blend_views", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16), L.ptr(views.w2c), L.ptr(views.intr),
            L.ptr(views.c2w), views.nv, plan.table, plan.scalars, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
            L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(), live=None if count is None else (count, n), nbytes=nbytes, flops=n * flops)
+    if not plan.finite:
+        _poison(idx, count, rgb_out)
     return rgb_out, vis_out
 
 

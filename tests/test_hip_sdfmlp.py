@@ -179,3 +179,21 @@ def test_transposed_kernels_propagate_not_a_number_inputs():
     assert torch.equal(torch.isnan(val[:, 0]), bad) and torch.equal(torch.isnan(sdf[:, 0]), bad)
     assert torch.equal(torch.isnan(grad).any(1), torch.isnan(ref_g).any(1))
     assert (sdf[~bad] - ref_s[~bad]).abs().max() < 2e-6
+
+
+def test_non_finite_weights_give_not_a_number_outputs():
+    from gens_amd import ops, synthetic
+    net, dims = _net(3, seed=8)
+    with torch.no_grad():
+        net.lin4.bias[5] = float("nan")
+    packed = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims, seed=6)])
+    pts = (torch.rand(100, 3) * 2 - 1).cuda()
+    idx = torch.arange(0, 100, 2).cuda()
+    count = torch.tensor([30], dtype=torch.int32, device="cuda")
+    plan = ops.SdfMlpPlan(net)
+    sdf = torch.full((100, 1), 100.0, device="cuda")
+    grad = torch.zeros(100, 3, device="cuda")
+    ops.sdf_mlp(plan, packed, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=grad, count=count)
+    assert torch.isnan(sdf[idx[:30]]).all() and torch.isnan(grad[idx[:30]]).all()
+    assert (sdf[idx[30:]] == 100).all() and (sdf[1::2] == 100).all()
+    assert torch.isnan(ops.sdf_mlp(plan, packed, pts)).all()
