@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 
     float cnd[4 * GC];     // volume features: 5 encodings of this half's NCH channels, then ONE (half 0), then zeros
     const float* wo = w_out + half * (64 + 16 * TC);
-    float s_cond = 0.0f, poison = 0.0f;
+    float s_cond = 0.0f;
     float f[NCH];          // the raw features: the chain rule at the end re-derives the encodings from them (46 registers less to carry)
     {
 #pragma unroll
@@ -153,15 +153,6 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
                 JL[3 * (4 * MID + 1)][lane] = half ? jx.w : jx.y; JL[3 * (4 * MID + 1) + 1][lane] = half ? jy.w : jy.y;
                 JL[3 * (4 * MID + 1) + 2][lane] = half ? jz.w : jz.y;
             }
-        }
-        // not-a-number inputs must come out as not-a-number (the reference's layers propagate them; the max / median forms of the
-        // activation would drop them): a poison term 0 * (sum of the inputs), NaN iff one of them is NaN or infinite
-        {
-            float acc_in = x[0] + x[1] + x[2];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) acc_in += f[j];
-            poison = 0.0f * acc_in;
-            s_cond = poison;
         }
 #pragma unroll
         for (int k = NCS - 1; k < 4 * GC; ++k) cnd[k] = (k == NCS - 1 && half == 0) ? 1.0f : 0.0f;
@@ -324,6 +315,15 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
             }
             asm volatile("" ::: "memory");                           // one tile's 16 weights at a time
         }
+        // not-a-number inputs must come out as not-a-number (the reference's layers propagate them; the max / median forms of the
+        // activation drop them): a poison term 0 * (sum of the inputs), NaN iff one of them is NaN or infinite -- computed from values that
+        // are live here anyway, here and again before the gradient is written
+        {
+            float acc_in = x[0] + x[1] + x[2];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) acc_in += f[j];
+            s += 0.0f * acc_in;
+        }
         s += __shfl_xor(s, 32, 64);
         if (half == 0 && live) sdf_out[src] = (s + b_last) * inv_scale;
     }
@@ -406,7 +406,14 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
             // half 0 slots: x, sin / cos of octaves 0 and 1; half 1: sin / cos of octaves 2 and 3
             g[a] = half ? 4.0f * (gp[a] * c0 - gp[3 + a] * s0) + 8.0f * (gp[6 + a] * c1 - gp[9 + a] * s1)
                         : gp[a] + (gp[3 + a] * c0 - gp[6 + a] * s0) + 2.0f * (gp[9 + a] * c1 - gp[12 + a] * s1);
-            g[a] = g[a] * scale + poison;
+            g[a] *= scale;
+        }
+        {
+            float acc_in = x[0] + x[1] + x[2];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) acc_in += f[j];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) g[a] += 0.0f * acc_in;
         }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
