@@ -93,15 +93,33 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 
     // the weight stream: a wave-uniform (scalar) base that advances by one group + 16 lane + an immediate per tile; three register
     // sets rotate: this group's weights and the next TWO groups' (in flight): with one wave per SIMD nothing else hides an L2 miss
+    // Three levels: buffer loads -- descriptor + 16 lane in a VGPR + the group's byte offset in an SGPR + an immediate per tile: no vector
+    // address arithmetic (with flat global loads hipcc spent ~540 VALU instructions and 300 wait states per tile on 64-bit addresses).
+    // Five levels keep the scalar pointer + 16 lane form: with buffer loads the allocator spills the weight registers there.
+    constexpr bool WBUF = NLEV == 3;
+    typedef float f32x4b __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, (int)((S::NG_FWD + S::NG_BWD + 2) * 4096), 0x00020000);
+    const uint32_t wlane = (uint32_t)lane * 16u;
+    uint32_t woff = 0;
     const float4* wp = wstream;
+#define TG_WLOAD(DST, T_)                                                                                                     \
+    if constexpr (WBUF) {                                                                                                     \
+        const f32x4b v_ = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + 1024u * (T_), woff, 0)); \
+        DST = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                                        \
+    } else {                                                                                                                  \
+        DST = wp[lane + 64 * (T_)];                                                                                           \
+    }
+#define TG_WNEXT()      \
+    woff += 4096u;      \
+    wp += 256;
     constexpr int NB = NLEV == 3 ? 3 : 2;      // (five levels: the conditioning operands take the third set's registers; one group ahead)
     float4 wbuf[NB][4];
     int par = 0;
 #pragma unroll
     for (int b = 0; b < NB - 1; ++b) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wbuf[b][t] = wp[lane + 64 * t];
-        wp += 256;
+        for (int t = 0; t < 4; ++t) { TG_WLOAD(wbuf[b][t], t) }
+        TG_WNEXT()
     }
 
     // ------------------------------------------------------------------ prologue: this lane's B-operand slots
@@ -184,9 +202,8 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     // one group = 4 float4 of weights per lane (requested NB - 1 groups ahead, into the register set just freed) and up to 16 MFMAs
 #define TG_FETCH()                                                                                    \
     float4(&a_)[4] = wbuf[par];                                                                       \
-    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                  \
-        wbuf[(par + NB - 1) % NB][t_] = wp[lane + 64 * t_];                                           \
-    wp += 256;                                                                                        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { TG_WLOAD(wbuf[(par + NB - 1) % NB][t_], t_) }  \
+    TG_WNEXT()                                                                                        \
     par = (par + 1) % NB;                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 #define TG_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), ACC, 0, 0, 0)
@@ -378,6 +395,8 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 #pragma unroll
     for (int t = 0; t < 4; ++t) TG_GROUP1(gp, H[t]);        // layer 0 reads the point encoding only
 #undef TG_FETCH
+#undef TG_WLOAD
+#undef TG_WNEXT
 #undef TG_MFMA
 #undef TG_GROUP4
 #undef TG_GROUP2
