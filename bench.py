@@ -82,12 +82,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if os.environ.get("GENS_BENCH_ONE_DEVICE"):       # test aid: every rank on GPU 0 (a 2-rank dry run on a 1-GPU box, with GENS_BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or os.environ.get("GENS_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://")      # 'nccl' is RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get("GENS_BENCH_BACKEND", "nccl"), init_method="env://")      # 'nccl' is RCCL on ROCm
 
     from gens_amd import lib as L
     from gens_amd import synthetic
@@ -134,7 +136,10 @@ def main():
         if dist is not None and not by_rays:                                             # config 4: gather of rendered buffers
             buf = surf.last_device_image                                                 # (P, 8) rgb | normal | sdf depth | rendered depth, on the device
             gathered = torch.empty(world * buf.shape[0], buf.shape[1], device=dev, dtype=buf.dtype)
-            dist.all_gather_into_tensor(gathered, buf)                                   # RCCL over xGMI, device to device
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(gathered, buf)                               # RCCL over xGMI, device to device
+            else:                                                                        # (gloo dry run)
+                dist.all_gather(list(gathered.view(world, *buf.shape).unbind(0)), buf)
             state["gathered"] = gathered
         state["out"], state["masks"], state["cost"] = out, masks, cost_volumes
 
