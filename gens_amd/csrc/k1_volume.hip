@@ -10,6 +10,7 @@
 // L2 / Infinity Cache.
 #include <stdlib.h>
 
+#include <algorithm>
 #include "common.h"
 
 #define K1_FAST_VIEWS 8   // the frustum-culled kernels map (z-row, view) pairs onto 32 x 8 threads; more views run the generic kernel
@@ -580,6 +581,314 @@ __global__ __launch_bounds__(256) void volume_build_bwd_k(const float4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1 backward, second generation: the IMAGE TILE owns the sum.
+//
+// The wave windows above reduce what one 4 x 16 voxel tile sends to a view by ~4 x (a z run slides 0 .. 1.4 pixels per voxel), and what is
+// left -- ~0.3 G global float atomics at 256^3 -- is the kernel's whole time (~66 G atomics/s on this chip, whatever the tile shape:
+// scripts/probe/README.md).  But a view's gradient image has only nv x H x W x 4 = 6 M floats for 1.3 G taps: nearly all of the reduction
+// is between voxels far apart in the volume that lie along the same viewing rays.  So the sum is turned around:
+//   prep   one pass over the voxels (the same 4 x 16 wave tiles): count / mean of the visible views, the per-voxel factors of
+//          g_view = A + B * (f_view - M)   (A = g_mean / count, B = 2 g_var / count, M = mean)   to scratch, and for every view the image
+//          tiles (BT_W x BT_H texels, by the north-west tap) the wave's voxels fall into: at most 2 x 2, else that wave / view pair
+//          scatters directly as before;
+//   bins   counting sort of the (wave tile, view) pairs by image tile (count in prep, one-workgroup scan, fill), cut into work items of
+//          at most BT_SEG wave tiles;
+//   tiles  a workgroup per work item keeps the gradient of its image tile (+ one texel of halo for the south / east taps) in LDS, walks
+//          its wave tiles -- reads A, B, M, re-projects into ITS view with the same arithmetic as prep, and adds the taps of the voxels
+//          that belong to the tile with LDS atomics -- and sends each touched texel to memory once.
+// Every (voxel, view) pair is owned by exactly one image tile, so the sums are those of the direct scatter in another order.
+#define BT_W 64
+#define BT_H 30          // (65 x 31 texels x 4 channels x 8 bytes = 63 KB of LDS per workgroup; 480 / 240 / 120 rows are whole tiles)
+#define BT_SEG 1024
+#define BT_THREADS 512
+#define BT_WIN ((BT_W + 1) * (BT_H + 1))
+
+struct BwdScratch {
+    float4 *a, *b, *m;              // per voxel
+    uint32_t* range;                // per (wave tile, view): tile range code, 0 = none
+    uint32_t *count, *cursor, *offset;   // per bin = (view, tile row, tile column); offset has one more
+    uint32_t *n_items, *gmax;       // gmax: bits of an upper bound of |g_view| over all voxels, views and channels (fixed-point scale)
+    uint4* items;                   // (bin, begin, end, -)
+    uint32_t* list;                 // wave tiles, bin after bin
+    int tiles_x, tiles_y, n_bins, seg;   // seg: wave tiles per work item
+    uint32_t max_items;
+    int64_t n_waves;
+};
+
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+static int64_t bwd_scratch_layout(int nv, int h, int w, int d, char* base, BwdScratch* out) {
+    const int64_t n = (int64_t)d * d * d, nw = n / 64;
+    BwdScratch sc;
+    sc.tiles_x = (w + BT_W - 1) / BT_W;
+    sc.tiles_y = (h + BT_H - 1) / BT_H;
+    sc.n_bins = nv * sc.tiles_x * sc.tiles_y;
+    sc.n_waves = nw;
+    sc.seg = (int)std::min<int64_t>(BT_SEG, std::max<int64_t>(64, nw * nv / 512 / 64 * 64));     // (small levels: shorter items, more of them)
+    sc.max_items = (uint32_t)((nw * nv * 4 + sc.seg - 1) / sc.seg + sc.n_bins);
+    int64_t at = 0;
+    auto take = [&](int64_t bytes) { char* p = base ? base + at : nullptr; at += align256(bytes); return p; };
+    sc.a = (float4*)take(n * 16);
+    sc.b = (float4*)take(n * 16);
+    sc.m = (float4*)take(n * 16);
+    sc.range = (uint32_t*)take(nw * nv * 4);
+    sc.count = (uint32_t*)take((int64_t)sc.n_bins * 4);        // count, cursor, n_items, gmax: one block, zeroed per call
+    sc.cursor = (uint32_t*)take((int64_t)sc.n_bins * 4);
+    sc.n_items = (uint32_t*)take(4);
+    sc.gmax = (uint32_t*)take(4);
+    sc.offset = (uint32_t*)take((int64_t)(sc.n_bins + 1) * 4);
+    sc.items = (uint4*)take((int64_t)sc.max_items * 16);
+    sc.list = (uint32_t*)take(nw * nv * 4 * 4);
+    if (out) *out = sc;
+    return at;
+}
+
+// wave tile q = (ix / 4, jy, z piece), z piece fastest, as (z piece | jy << 8 | ix / 4 << 20): 16 consecutive z of 4 x-adjacent rows, lane = 16 row + z
+__device__ __forceinline__ uint32_t bwd_wave_code(uint32_t q, int d) {
+    const uint32_t zp = (uint32_t)d >> 4, r = q / zp;
+    return (q - r * zp) | ((r % (uint32_t)d) << 8) | ((r / (uint32_t)d) << 20);
+}
+struct WaveVoxel {
+    int ix, jy, kz;
+    int64_t vox;
+};
+__device__ __forceinline__ WaveVoxel bwd_wave_voxel(uint32_t code, int lane, int d) {
+    WaveVoxel o;
+    o.kz = (int)(code & 0xFFu) * 16 + (lane & 15);
+    o.jy = (int)((code >> 8) & 0xFFFu);
+    o.ix = (int)(code >> 20) * 4 + (lane >> 4);
+    o.vox = ((int64_t)o.ix * d + o.jy) * d + o.kz;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void volume_build_bwd_prep_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
+                                                               const float* __restrict__ intr, float s, int nv, int h, int w, int d,
+                                                               const float* __restrict__ gvol, float* __restrict__ gfeat, BwdScratch sc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t n = (int64_t)d * d * d;
+    const uint32_t q = blockIdx.x * 4u + (uint32_t)(tid >> 6);
+    const WaveVoxel wv = bwd_wave_voxel(bwd_wave_code(q, d), lane, d);              // (d a multiple of 16: every lane has a voxel)
+    const int64_t vox = wv.vox;
+    const float x = linspace_at(-1.0f, 1.0f, d, wv.ix), y = linspace_at(-1.0f, 1.0f, d, wv.jy), z = linspace_at(-1.0f, 1.0f, d, wv.kz);
+    float4 s1 = f4_zero();
+    float cnt = 0.0f;
+    uint32_t direct = 0;                                                            // (wave-uniform) views whose footprint spans more than 2 x 2 tiles
+    const float big = 1.0e9f;
+    float4 f_lo = make_float4(big, big, big, big), f_hi = make_float4(-big, -big, -big, -big);
+    for (int v = 0; v < nv; ++v) {
+        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
+        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+        if (p.vis) {
+            float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
+            s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
+            cnt += 1.0f;
+            f_lo = make_float4(fminf(f_lo.x, f.x), fminf(f_lo.y, f.y), fminf(f_lo.z, f.z), fminf(f_lo.w, f.w));
+            f_hi = make_float4(fmaxf(f_hi.x, f.x), fmaxf(f_hi.y, f.y), fmaxf(f_hi.z, f.z), fmaxf(f_hi.w, f.w));
+        }
+        uint32_t code = 0;
+        if (__any(p.vis)) {                                                         // visible: 0 <= x0 <= w - 1, 0 <= y0 <= h - 1
+            const int tx_lo = (int)-wave_max(p.vis ? -(float)t.x0 : -big) / BT_W, tx_hi = (int)wave_max(p.vis ? (float)t.x0 : -big) / BT_W;
+            const int ty_lo = (int)-wave_max(p.vis ? -(float)t.y0 : -big) / BT_H, ty_hi = (int)wave_max(p.vis ? (float)t.y0 : -big) / BT_H;
+            if (tx_hi - tx_lo > 1 || ty_hi - ty_lo > 1) {
+                direct |= 1u << v;
+            } else {
+                code = 0x80000000u | (uint32_t)tx_lo | ((uint32_t)ty_lo << 12) | ((uint32_t)(tx_hi - tx_lo) << 24) | ((uint32_t)(ty_hi - ty_lo) << 25);
+            }
+        }
+        if (lane == 0) sc.range[(int64_t)v * sc.n_waves + q] = code;
+    }
+    const bool live = cnt > 0.0f;
+    const float inv = live ? 1.0f / cnt : 0.0f;
+    const float4 mean = make_float4(s1.x * inv, s1.y * inv, s1.z * inv, s1.w * inv);
+    float4 ga = f4_zero(), gb = f4_zero();
+    if (live) {
+        ga = make_float4(gvol[vox] * inv, gvol[n + vox] * inv, gvol[2 * n + vox] * inv, gvol[3 * n + vox] * inv);
+        gb = make_float4(2.0f * gvol[4 * n + vox] * inv, 2.0f * gvol[5 * n + vox] * inv, 2.0f * gvol[6 * n + vox] * inv, 2.0f * gvol[7 * n + vox] * inv);
+    }
+    sc.a[vox] = ga;
+    sc.b[vox] = gb;
+    sc.m[vox] = mean;
+    // |g_view| <= |A| + |B| (max f - min f) in every channel: the scale of the tile kernel's fixed-point sums.  Compared as BITS of
+    // non-negative floats, so a NaN or an infinity (which sends that kernel to its float path) wins over every finite bound.
+    uint32_t bound = 0;
+    if (live) {
+        bound = max(max(__float_as_uint(fabsf(ga.x) + fabsf(gb.x) * (f_hi.x - f_lo.x)), __float_as_uint(fabsf(ga.y) + fabsf(gb.y) * (f_hi.y - f_lo.y))),
+                    max(__float_as_uint(fabsf(ga.z) + fabsf(gb.z) * (f_hi.z - f_lo.z)), __float_as_uint(fabsf(ga.w) + fabsf(gb.w) * (f_hi.w - f_lo.w))));
+        bound = max(bound, max(max(__float_as_uint(fabsf(mean.x)), __float_as_uint(fabsf(mean.y))), max(__float_as_uint(fabsf(mean.z)), __float_as_uint(fabsf(mean.w)))) >= 0x7f800000u ? 0x7fc00000u : 0u);
+    }
+    for (int o = 32; o; o >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, o));
+    if (lane == 0 && bound > *(volatile uint32_t*)sc.gmax) atomicMax(sc.gmax, bound);     // (a stale read only costs an atomic)
+    for (int v = 0; direct >> v; ++v) {                                             // (rare: very oblique or very wide views)
+        if (!((direct >> v) & 1u) || !live) continue;
+        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
+        if (!p.vis) continue;
+        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+        float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
+        const float4 g = make_float4(ga.x + gb.x * (f.x - mean.x), ga.y + gb.y * (f.y - mean.y), ga.z + gb.z * (f.z - mean.z), ga.w + gb.w * (f.w - mean.w));
+        float* base = gfeat + (((int64_t)v * h + t.y0) * w + t.x0) * 4;
+        if (t.ok00) atomic_add4(base, g, t.w00);
+        if (t.ok01) atomic_add4(base + 4, g, t.w01);
+        if (t.ok10) atomic_add4(base + (int64_t)w * 4, g, t.w10);
+        if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, g, t.w11);
+    }
+}
+
+// offsets of the bins in the list and the work items (one workgroup; the bins number a few hundred)
+__global__ __launch_bounds__(256) void volume_build_bwd_scan_k(BwdScratch sc) {
+    __shared__ uint32_t part_c[256], part_i[256];
+    const int tid = threadIdx.x, per = (sc.n_bins + 255) / 256;
+    const uint32_t seg = (uint32_t)sc.seg;
+    const int lo = min(tid * per, sc.n_bins), hi = min(lo + per, sc.n_bins);
+    uint32_t c = 0, it = 0;
+    for (int b = lo; b < hi; ++b) {
+        c += sc.count[b];
+        it += (sc.count[b] + seg - 1) / seg;
+    }
+    part_c[tid] = c;
+    part_i[tid] = it;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t rc = 0, ri = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t tc = part_c[i], ti = part_i[i];
+            part_c[i] = rc;
+            part_i[i] = ri;
+            rc += tc;
+            ri += ti;
+        }
+        sc.offset[sc.n_bins] = rc;
+        *sc.n_items = ri;
+    }
+    __syncthreads();
+    c = part_c[tid];
+    it = part_i[tid];
+    for (int b = lo; b < hi; ++b) {
+        const uint32_t k = sc.count[b];
+        sc.offset[b] = c;
+        for (uint32_t at = 0; at < k; at += seg) sc.items[it++] = make_uint4((uint32_t)b, c + at, c + min(at + seg, k), 0u);
+        c += k;
+    }
+}
+
+// The (wave tile, view) pairs of one view, counted per bin (FILL = false) or written to their bins' lists (FILL = true).  Neighbouring wave tiles
+// mostly share their bins: the lanes of a wave that address one bin send ONE atomic for all of them (the bins are a few hundred addresses).
+template <bool FILL>
+__global__ __launch_bounds__(256) void volume_build_bwd_bins_k(BwdScratch sc, int d) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y, lane = threadIdx.x & 63;
+    const uint32_t code = q < sc.n_waves ? sc.range[(int64_t)v * sc.n_waves + q] : 0u;
+    const uint32_t wave_code = FILL ? bwd_wave_code((uint32_t)min(q, sc.n_waves - 1), d) : 0u;
+    const int tx_lo = code & 0xFFF, ty_lo = (code >> 12) & 0xFFF, nx = (code >> 24) & 1, ny = (code >> 25) & 1;
+    for (int k = 0; k < 4; ++k) {                                                   // the up to 2 x 2 tiles of the pair
+        const int dx = k & 1, dy = k >> 1;
+        int bin = (code && dx <= nx && dy <= ny) ? (v * sc.tiles_y + ty_lo + dy) * sc.tiles_x + tx_lo + dx : -1;
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int b = __builtin_amdgcn_readlane(bin, lead);
+            const unsigned long long same = __ballot(bin == b);
+            uint32_t base = 0;
+            if (lane == lead) base = atomicAdd((FILL ? sc.cursor : sc.count) + b, (uint32_t)__popcll(same));
+            if (FILL && bin == b) {
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+                sc.list[sc.offset[b] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = wave_code;
+            }
+            todo &= ~same;
+            if (bin == b) bin = -1;
+        }
+    }
+}
+
+// One tap into the tile window.  FIXED: 64-bit fixed-point sums (ds_add_u64: ~18 cycles per wave instruction, against ~200-250 for ds_add_f32
+// on this chip -- scripts/probe/lds_atomic_probe.py -- and the window's adds are this kernel's whole time).  v * w * scale is rounded to an integer
+// by the 1.5 x 2^52 trick (|v w scale| < 2^42, one tap is exact to 2^-41 of the largest |g| of the call, a work item sums < 2^18 taps per texel:
+// no overflow, and the error of a texel is far below one float32 rounding of its sum).  Otherwise (a NaN / infinity among the gradients) float adds.
+template <bool FIXED>
+__device__ __forceinline__ void tile_add4(void* win, int at, float4 v, float w, double scale) {
+    if (FIXED) {
+        unsigned long long* q = (unsigned long long*)win + at;
+        const double ws = (double)w * scale, magic = 6755399441055744.0;
+        atomicAdd(q, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.x, ws, magic)) - 0x4338000000000000ull);
+        atomicAdd(q + BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.y, ws, magic)) - 0x4338000000000000ull);
+        atomicAdd(q + 2 * BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.z, ws, magic)) - 0x4338000000000000ull);
+        atomicAdd(q + 3 * BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.w, ws, magic)) - 0x4338000000000000ull);
+    } else {
+        float* q = (float*)win + at;
+        atomicAdd(q, v.x * w);
+        atomicAdd(q + BT_WIN, v.y * w);
+        atomicAdd(q + 2 * BT_WIN, v.z * w);
+        atomicAdd(q + 3 * BT_WIN, v.w * w);
+    }
+}
+
+template <bool FIXED>
+__device__ __forceinline__ void bwd_tile_item(unsigned long long* win, const float4* __restrict__ feat, const float* __restrict__ w2c,
+                                              const float* __restrict__ intr, float s, int h, int w, int d, float* __restrict__ gfeat,
+                                              const BwdScratch& sc, double scale, double inv_scale) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint4 item = sc.items[blockIdx.x];
+    const int bin = (int)item.x, tx = bin % sc.tiles_x, ty = (bin / sc.tiles_x) % sc.tiles_y, v = bin / (sc.tiles_x * sc.tiles_y);
+    const int x_org = tx * BT_W, y_org = ty * BT_H;
+    for (int i = tid; i < 4 * BT_WIN; i += BT_THREADS) win[i] = 0ull;              // (the float path uses the first half)
+    __syncthreads();
+    const float4* img = feat + (int64_t)v * h * w;
+    const float *m = w2c + 16 * v, *k = intr + 16 * v;
+    for (uint32_t e0 = item.y + 64u * wave; e0 < item.z; e0 += 64u * (BT_THREADS / 64)) {
+        const uint32_t mine = e0 + lane < item.z ? sc.list[e0 + lane] : 0u;       // the wave's next 64 wave tiles, one per lane
+        const int cnt = (int)min(64u, item.z - e0);
+        for (int j = 0; j < cnt; ++j) {
+            const WaveVoxel wv = bwd_wave_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, j), lane, d);
+            const float4 ga = sc.a[wv.vox], gb = sc.b[wv.vox], mean = sc.m[wv.vox];
+            const float x = linspace_at(-1.0f, 1.0f, d, wv.ix), y = linspace_at(-1.0f, 1.0f, d, wv.jy), z = linspace_at(-1.0f, 1.0f, d, wv.kz);
+            Proj p = project_voxel(m, k, s, h, w, x, y, z);
+            Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+            const int cx = t.x0 - x_org, cy = t.y0 - y_org;
+            const bool live = ga.x != 0.0f || ga.y != 0.0f || ga.z != 0.0f || ga.w != 0.0f || gb.x != 0.0f || gb.y != 0.0f || gb.z != 0.0f || gb.w != 0.0f;
+            if (p.vis && live && cx >= 0 && cx < BT_W && cy >= 0 && cy < BT_H) {
+                float4 f = sample_texel(img, h, w, 1, 0, t);
+                const float4 g = make_float4(ga.x + gb.x * (f.x - mean.x), ga.y + gb.y * (f.y - mean.y), ga.z + gb.z * (f.z - mean.z), ga.w + gb.w * (f.w - mean.w));
+                const int at = cy * (BT_W + 1) + cx;
+                if (t.ok00) tile_add4<FIXED>(win, at, g, t.w00, scale);
+                if (t.ok01) tile_add4<FIXED>(win, at + 1, g, t.w01, scale);
+                if (t.ok10) tile_add4<FIXED>(win, at + (BT_W + 1), g, t.w10, scale);
+                if (t.ok11) tile_add4<FIXED>(win, at + (BT_W + 1) + 1, g, t.w11, scale);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = gfeat + (int64_t)v * h * w * 4;
+    for (int i = tid; i < BT_WIN; i += BT_THREADS) {
+        float4 a;
+        if (FIXED) {
+            a = make_float4((float)((double)(long long)win[i] * inv_scale), (float)((double)(long long)win[BT_WIN + i] * inv_scale),
+                            (float)((double)(long long)win[2 * BT_WIN + i] * inv_scale), (float)((double)(long long)win[3 * BT_WIN + i] * inv_scale));
+        } else {
+            const float* fw = (const float*)win;
+            a = make_float4(fw[i], fw[BT_WIN + i], fw[2 * BT_WIN + i], fw[3 * BT_WIN + i]);
+        }
+        if (a.x != 0.0f || a.y != 0.0f || a.z != 0.0f || a.w != 0.0f) {
+            const int r = i / (BT_W + 1), c = i - r * (BT_W + 1);
+            atomic_add4(out + ((int64_t)(y_org + r) * w + x_org + c) * 4, a, 1.0f);    // (only in-image taps were added: the texel exists)
+        }
+    }
+}
+
+__global__ __launch_bounds__(BT_THREADS) void volume_build_bwd_tiles_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
+                                                                      const float* __restrict__ intr, float s, int h, int w, int d,
+                                                                      float* __restrict__ gfeat, BwdScratch sc) {
+    __shared__ unsigned long long win[4 * BT_WIN];      // channel planes: the lanes of one add (one channel) spread over all banks
+    if (blockIdx.x >= *sc.n_items) return;
+    const uint32_t e = (*sc.gmax >> 23) & 0xFFu;                                    // biased exponent of the bound: 2^(e - 127) <= bound < 2^(e - 126)
+    if (e != 0xFFu) {
+        const double scale = __longlong_as_double((long long)(1023 + 40 + 127 - (int)e) << 52);      // bound * scale in [2^40, 2^41)
+        const double inv_scale = __longlong_as_double((long long)(1023 - 40 - 127 + (int)e) << 52);
+        bwd_tile_item<true>(win, feat, w2c, intr, s, h, w, d, gfeat, sc, scale, inv_scale);
+    } else {
+        bwd_tile_item<false>(win, feat, w2c, intr, s, h, w, d, gfeat, sc, 1.0, 1.0);
+    }
+}
+
 static int check_volume_args(const char* who, const void* a, const void* b, const void* c, int nv, int h, int w, int d) {
     GENS_CHECK_ARG(a && b && c, GENS_EINVAL, "%s: null pointer", who);
     GENS_CHECK_ARG(nv > 0 && h > 1 && w > 1 && d > 0, GENS_EINVAL, "%s: bad size nv=%d h=%d w=%d d=%d", who, nv, h, w, d);
@@ -662,6 +971,34 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
     }
     volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view);
     return gens_launch_status("gens_volume_build_levels");
+}
+
+extern "C" int64_t gens_volume_build_bwd_scratch_bytes(int nv, int h, int w, int d) {
+    if (nv <= 0 || nv > GENS_MAX_VIEWS || h <= 1 || w <= 1 || d <= 0 || d > 4096 || (d & 15) || (w + BT_W - 1) / BT_W > 4095 || (h + BT_H - 1) / BT_H > 4095) return 0;
+    if ((int64_t)d * d * d / 64 * nv * 4 > 0xFFFFFFFFll) return 0;                  // (list offsets are 32-bit)
+    return bwd_scratch_layout(nv, h, w, d, nullptr, nullptr);
+}
+
+extern "C" int gens_volume_build_bwd_tiled(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,
+                                           int h, int w, int d, const float* g_volume, float* g_feat, void* scratch,
+                                           int64_t scratch_bytes, void* stream) {
+    if (int e = check_volume_args("gens_volume_build_bwd_tiled", feat, w2c, intr, nv, h, w, d)) return e;
+    GENS_CHECK_ARG(g_volume && g_feat && scratch, GENS_EINVAL, "gens_volume_build_bwd_tiled: null buffer");
+    const int64_t need = gens_volume_build_bwd_scratch_bytes(nv, h, w, d);
+    GENS_CHECK_ARG(need > 0, GENS_ELIMIT, "gens_volume_build_bwd_tiled: d=%d must be a multiple of 16 (image %d x %d, %d views): use gens_volume_build_bwd", d, h, w, nv);
+    GENS_CHECK_ARG(scratch_bytes >= need && ((uintptr_t)scratch & 15) == 0, GENS_EINVAL,
+                   "gens_volume_build_bwd_tiled: scratch of %lld bytes, 16-byte aligned, needed (got %lld)", (long long)need, (long long)scratch_bytes);
+    BwdScratch sc;
+    bwd_scratch_layout(nv, h, w, d, (char*)scratch, &sc);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sc.count, 0, (char*)sc.offset - (char*)sc.count, st) != hipSuccess) return gens_launch_status("gens_volume_build_bwd_tiled");
+    volume_build_bwd_prep_k<<<(unsigned)(sc.n_waves / 4), 256, 0, st>>>((const float4*)feat, w2c, intr, intr_scale, nv, h, w, d, g_volume, g_feat, sc);
+    const dim3 bins_grid(gens_blocks(sc.n_waves, 256), (unsigned)nv);
+    volume_build_bwd_bins_k<false><<<bins_grid, 256, 0, st>>>(sc, d);
+    volume_build_bwd_scan_k<<<1, 256, 0, st>>>(sc);
+    volume_build_bwd_bins_k<true><<<bins_grid, 256, 0, st>>>(sc, d);
+    volume_build_bwd_tiles_k<<<sc.max_items, BT_THREADS, 0, st>>>((const float4*)feat, w2c, intr, intr_scale, h, w, d, g_feat, sc);
+    return gens_launch_status("gens_volume_build_bwd_tiled");
 }
 
 extern "C" int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,

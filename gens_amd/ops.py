@@ -143,10 +143,26 @@ class _VolumeBuild(torch.autograd.Function):
         feat_tex, w2c, intr = ctx.saved_tensors
         scale, d = ctx.meta
         nv, h, w, _ = feat_tex.shape
-        g = torch.zeros_like(feat_tex)
+        return _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol), None, None, None, None, None
+
+
+def _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol):
+    """d(volume)/d(texels) of one level: the image-tile kernel (gens_volume_build_bwd_tiled: 1.27 against 4.31 ms at 256^3, 0.31 / 0.56 at
+    128^3) from D = 128 up, the wave-window kernel below (0.09 against 0.13 ms at 64^3: five launches do not pay there).  GENS_K1_BWD_WINDOW /
+    GENS_K1_BWD_TILED force one of them wherever it applies.  Both are labelled gens_volume_build_bwd in the kernel table."""
+    nv, h, w, _ = feat_tex.shape
+    g = torch.zeros_like(feat_tex)
+    nbytes = 2 * nv * h * w * 16 + 32 * d ** 3                # texels read + their gradient written, 8 cotangent planes read
+    tiled = not os.environ.get("GENS_K1_BWD_WINDOW") and (d >= 128 or bool(os.environ.get("GENS_K1_BWD_TILED")))
+    need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d) if tiled else 0
+    if need > 0:
+        scratch = torch.empty(need, device=g.device, dtype=torch.uint8)
+        L.call("gens_volume_build_bwd_tiled", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
+               L.ptr(scratch, torch.uint8), need, L.stream(), nbytes=nbytes, label="gens_volume_build_bwd")
+    else:
         L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
-               L.stream(), nbytes=2 * nv * h * w * 16 + 32 * d ** 3)
-        return g, None, None, None, None, None
+               L.stream(), nbytes=nbytes)
+    return g
 
 
 class _VolumeBuildLevels(torch.autograd.Function):
@@ -181,11 +197,7 @@ class _VolumeBuildLevels(torch.autograd.Function):
             if grads[l] is None or not ctx.needs_input_grad[3 + l]:
                 out.append(None)
                 continue
-            nv, h, w, _ = texs[l].shape
-            g = torch.zeros_like(texs[l])
-            L.call("gens_volume_build_bwd", L.ptr(_c(texs[l])), L.ptr(w2c), L.ptr(intrs[l]), 1.0, nv, h, w, d, L.ptr(_c(grads[l])), L.ptr(g), L.stream(),
-                   nbytes=2 * nv * h * w * 16 + 32 * d ** 3)      # texels read + their gradient written, 8 cotangent planes read
-            out.append(g)
+            out.append(_volume_build_bwd(texs[l], w2c, intrs[l], 1.0, d, grads[l]))
         return (None, None, None, *out, *([None] * n))
 
 

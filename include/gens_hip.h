@@ -66,6 +66,15 @@ int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr
                           int w, int d, int min_vis_view, float* volume, float* mask, void* stream);
 int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
                           int w, int d, const float* g_volume, float* g_feat, void* stream);
+/* The same gradient with the sum owned by the IMAGE: voxels are binned by the 64 x 32-texel tile of each view they project into, a
+ * workgroup per tile keeps that tile's gradient in LDS and writes every touched texel once (the wave-window kernel above is bound by its
+ * ~0.3 G global atomics at 256^3).  D must be a multiple of 16; scratch: gens_volume_build_bwd_scratch_bytes(nv, H, W, D) bytes of device
+ * memory (48 bytes per voxel + the bins; 0 = this size is not covered, use gens_volume_build_bwd), contents irrelevant before and after.
+ * Results equal gens_volume_build_bwd's up to the order of the float32 sums. */
+int64_t gens_volume_build_bwd_scratch_bytes(int nv, int h, int w, int d);
+int gens_volume_build_bwd_tiled(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
+                                int w, int d, const float* g_volume, float* g_feat, void* scratch, int64_t scratch_bytes,
+                                void* stream);
 /* All levels of one scene in a single launch (volume.py:21-61 is a loop over the levels): feat[l] (nv, H_l, W_l, 4) texels,
  * hw = {H_0, W_0, H_1, W_1, ...}, intr[l] (nv, 4, 4) with rows 0-1 already multiplied by 0.5^l, volumes[l] (8, D_l^3), masks[l] (D_l^3).
  * Same results as n_levels calls of gens_volume_build_fwd with intr_scale = 1 (which it falls back to for sizes the fused kernel

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K1 backward: LDS-window scatter against direct device atomics (GENS_K1_BWD_DIRECT=1): time and agreement."""
+"""K1 backward: image-tile kernel and LDS-window scatter against direct device atomics (GENS_K1_BWD_DIRECT=1): time and agreement."""
 import os
 import sys
 
@@ -17,11 +17,17 @@ for lvl, d in enumerate([256, 128, 64]):
     nv, h, w, _ = tex.shape
     gvol = torch.randn(8, d, d, d, device=dev)
     res = {}
-    for mode in ("window", "direct"):
+    need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d)
+    scratch = torch.empty(need, device=dev, dtype=torch.uint8)
+    for mode in ("tiled", "window", "direct"):
         if mode == "direct":
             os.environ["GENS_K1_BWD_DIRECT"] = "1"
         g = torch.zeros_like(tex)
-        fn = lambda: L.call("gens_volume_build_bwd", L.ptr(tex), L.ptr(w2c), L.ptr(intrs), 0.5 ** lvl, nv, h, w, d, L.ptr(gvol), L.ptr(g), L.stream())  # noqa: E731
+        if mode == "tiled":
+            fn = lambda: L.call("gens_volume_build_bwd_tiled", L.ptr(tex), L.ptr(w2c), L.ptr(intrs), 0.5 ** lvl, nv, h, w, d, L.ptr(gvol), L.ptr(g),  # noqa: E731
+                                L.ptr(scratch, torch.uint8), need, L.stream())
+        else:
+            fn = lambda: L.call("gens_volume_build_bwd", L.ptr(tex), L.ptr(w2c), L.ptr(intrs), 0.5 ** lvl, nv, h, w, d, L.ptr(gvol), L.ptr(g), L.stream())  # noqa: E731
         fn()
         torch.cuda.synchronize()
         res[mode] = g.clone()
@@ -36,5 +42,9 @@ for lvl, d in enumerate([256, 128, 64]):
         torch.cuda.synchronize()
         print(f"D={d} {mode}: {s.elapsed_time(e) / 10:8.3f} ms")
         os.environ.pop("GENS_K1_BWD_DIRECT", None)
-    diff = (res["window"] - res["direct"]).abs().max().item()
-    print(f"D={d} max |window - direct| = {diff:.3e}  (max |g| = {res['direct'].abs().max().item():.3e})")
+    for mode in ("tiled", "window"):
+        diff = (res[mode] - res["direct"]).abs().max().item()
+        print(f"D={d} max |{mode} - direct| = {diff:.3e}  (max |g| = {res['direct'].abs().max().item():.3e})")
+    if d == 256:
+        items = scratch.view(torch.int32)   # (layout: gens_amd/csrc/k1_volume.hip::bwd_scratch_layout)
+        print(f"scratch {need / 2**20:.0f} MiB")

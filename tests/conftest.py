@@ -33,3 +33,29 @@ def golden():
         d = np.load(os.path.join(GOLDEN, name + ".npz"))
         return {k: torch.from_numpy(d[k]) for k in d.files}
     return load
+
+
+@pytest.fixture(autouse=True)
+def poisoned_allocator(request):
+    """GENS_TEST_POISON=1: before every GPU test the caching allocator's free blocks are filled with NaN bit patterns, so that a kernel reading
+    memory it (or its caller) never initialised -- torch.empty scratch, stash and output buffers -- fails its test instead of passing on
+    whatever an earlier test left behind."""
+    if os.environ.get("GENS_TEST_POISON") and "gpu" in request.keywords:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            free = [torch.empty(0)]
+            try:
+                reserved = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                for size in (min(reserved, 4 << 30), 1 << 28, 1 << 24, 1 << 20):       # the cached blocks, largest first, then typical small ones
+                    for _ in range(4):
+                        if size <= 0:
+                            break
+                        try:
+                            free.append(torch.full((size // 4,), float("nan"), device="cuda"))
+                        except RuntimeError:
+                            break
+            finally:
+                del free
+                torch.cuda.synchronize()
+    yield

@@ -201,6 +201,18 @@ def g1_volume(Volume):
     npz("g1b_volume_ms", **d)
 
 
+def g1c_volume_tiles(Volume):
+    """K1 backward over several image tiles of the image-tile kernel (64 x 30 texels): 4 views 96 x 160 (3 x 4 tiles), one 32^3 volume."""
+    sc = synthetic.make_scene(nv=4, h=96, w=160, n_levels=1, seed=13)
+    feat = sc["features"][0].clone().requires_grad_(True)
+    vol = Volume(Conf({"volume_dims": [32]}))
+    v, m = vol.agg_mean_var([feat], sc["intrs"], sc["c2ws"])
+    g = torch.Generator().manual_seed(6)
+    cot = torch.randn(v[0].shape, generator=g)
+    (v[0] * cot).sum().backward()
+    npz("g1c_volume_tiles", feat=feat, intrs=sc["intrs"], c2ws=sc["c2ws"], mask=m[0], cot=cot, gfeat=feat.grad)
+
+
 def g2_lookup(projector):
     g = torch.Generator().manual_seed(21)
     dims = [12, 8, 5]
@@ -822,6 +834,10 @@ def main():
         g15_validate(surf, sc, vols, masks, tag="g15b_validate_l5")
         g9d_config0(isurf_mod, Volume)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g1c":
+        from models.modules.volume import Volume
+        g1c_volume_tiles(Volume)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g17b":
         g17_gens_forward(dims=(64, 32, 16, 8, 4), tag="g17b_gens_forward_l5", nv=4, seed=270)
         return
@@ -860,6 +876,7 @@ def main():
     from models.modules import implicit_surface as isurf_mod
 
     g1_volume(Volume)
+    g1c_volume_tiles(Volume)
     g2_lookup(projector)
     g3_nearest(projector)
     g4_feature(projector)

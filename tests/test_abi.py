@@ -44,7 +44,8 @@ def test_library_exports_every_declared_symbol(libpath):
 
 def test_ctypes_table_covers_header(libpath):
     from gens_amd import lib as L
-    declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks", "gens_sdf_train_stash_bytes", "gens_gemm_tn_batch_workspace", "gens_blend_train_rows"}
+    declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks", "gens_sdf_train_stash_bytes", "gens_gemm_tn_batch_workspace", "gens_blend_train_rows",
+                                              "gens_volume_build_bwd_scratch_bytes"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     L.load()
 
@@ -54,6 +55,9 @@ def test_argument_errors_are_reported_without_a_gpu(libpath):
     from gens_amd import lib as L
     lib = L.load()
     rc = lib.gens_volume_build_fwd(None, None, None, 1.0, 3, 30, 40, 16, 1, None, None, None)
+    assert rc == -1 and b"null" in lib.gens_last_error()
+    assert lib.gens_volume_build_bwd_scratch_bytes(5, 480, 640, 256) >= 48 * 256 ** 3 and lib.gens_volume_build_bwd_scratch_bytes(5, 480, 640, 250) == 0
+    rc = lib.gens_volume_build_bwd_tiled(None, None, None, 1.0, 3, 30, 40, 16, None, None, None, 0, None)
     assert rc == -1 and b"null" in lib.gens_last_error()
     rc = lib.gens_merge_samples(None, None, None, None, None, None, 4, 120, 16, None, None, None, None)
     assert rc == -2

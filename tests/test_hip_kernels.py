@@ -30,7 +30,9 @@ def ops():
 
 
 # --------------------------------------------------------------------------------------------------- K1
-def test_k1_volume_golden_c1(ops, golden):
+@pytest.mark.parametrize("bwd", ["window", "tiled"])
+def test_k1_volume_golden_c1(ops, golden, bwd, monkeypatch):
+    monkeypatch.setenv("GENS_K1_BWD_TILED" if bwd == "tiled" else "GENS_K1_BWD_WINDOW", "1")      # both backward kernels against the reference
     g = golden("g1a_volume_c1")
     feat = dev(g["feat"]).requires_grad_(True)
     v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [16])
@@ -38,6 +40,21 @@ def test_k1_volume_golden_c1(ops, golden):
     close(m[0], g["mask"], atol=0, rtol=0, what="mask")
     (v[0] * dev(g["cot"])).sum().backward()
     close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat")
+
+
+@pytest.mark.parametrize("bwd", ["window", "tiled"])
+def test_k1_volume_golden_backward_over_image_tiles(ops, golden, bwd, monkeypatch):
+    """4 views 96 x 160, one 32^3 volume: the image-tile backward spreads every view over 3 x 4 tiles (and the 4 x 16 voxel wave tiles over up to
+    2 x 2 of them); the reference's own gradient."""
+    monkeypatch.setenv("GENS_K1_BWD_TILED" if bwd == "tiled" else "GENS_K1_BWD_WINDOW", "1")
+    g = golden("g1c_volume_tiles")
+    feat = dev(g["feat"]).requires_grad_(True)
+    v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [32])
+    close(m[0], g["mask"], atol=0, rtol=0, what="mask")
+    (v[0] * dev(g["cot"])).sum().backward()
+    # a voxel projecting within an ulp of an image border may flip visibility in one view (count 3 <-> 4: the mask stays, its taps move by 1e-4)
+    close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat", frac=2e-3)
+    close(feat.grad, g["gfeat"], atol=2e-4, what="d/dfeat")
 
 
 def test_k1_volume_golden_multiscale(ops, golden):

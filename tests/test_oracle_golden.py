@@ -42,6 +42,15 @@ def test_k1_volume_multiscale(golden):
         close(feats[i].grad, g[f"gfeat{i}"], atol=2e-5, what=f"gfeat{i}")
 
 
+def test_k1_volume_backward_over_image_tiles(golden):
+    g = golden("g1c_volume_tiles")
+    feat = g["feat"].clone().requires_grad_(True)
+    v, m = K.volume_build([feat], g["intrs"], g["c2ws"], [32])
+    assert torch.equal(m[0], g["mask"])
+    (v[0] * g["cot"]).sum().backward()
+    close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat")
+
+
 def test_k2_lookup_all_orders(golden):
     g = golden("g2_lookup")
     vols = [g[f"vol{i}"] for i in range(3)]
