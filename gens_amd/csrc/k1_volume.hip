@@ -592,11 +592,11 @@ __global__ __launch_bounds__(256) void volume_build_bwd_k(const float4* __restri
 //          g_view = A + B * (f_view - M)   (A = g_mean / count, B = 2 g_var / count, M = mean)   to scratch, and for every view the image
 //          tiles (BT_W x BT_H texels, by the north-west tap) the wave's voxels fall into: at most 2 x 2, else that wave / view pair
 //          scatters directly as before;
-//   bins   counting sort of the (wave tile, view) pairs by image tile (count in prep, one-workgroup scan, fill), cut into work items of
-//          at most BT_SEG wave tiles;
+//   bins   counting sort of the (wave tile, view) pairs by image tile (count, one-workgroup scan, fill: the lanes of a wave that address one
+//          bin send one atomic between them), cut into work items of at most `seg` wave tiles;
 //   tiles  a workgroup per work item keeps the gradient of its image tile (+ one texel of halo for the south / east taps) in LDS, walks
 //          its wave tiles -- reads A, B, M, re-projects into ITS view with the same arithmetic as prep, and adds the taps of the voxels
-//          that belong to the tile with LDS atomics -- and sends each touched texel to memory once.
+//          that belong to the tile with LDS atomics (64-bit fixed point: tile_add4) -- and sends each touched texel to memory once.
 // Every (voxel, view) pair is owned by exactly one image tile, so the sums are those of the direct scatter in another order.
 #define BT_W 64
 #define BT_H 30          // (65 x 31 texels x 4 channels x 8 bytes = 63 KB of LDS per workgroup; 480 / 240 / 120 rows are whole tiles)

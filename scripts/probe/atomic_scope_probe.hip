@@ -9,6 +9,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 }
 
 // mode 0: device scope, one copy | 1: workgroup scope, copy per XCD (blockIdx % 8) | 2: device scope, copy per XCD | 3: workgroup scope, one copy (WRONG across XCDs: timing only)
+// | 4: device scope, one copy, uint32 adds | 5: device scope, one copy, uint64 adds (two channels per word: half the texel span)
 template <int MODE>
 __global__ __launch_bounds__(256) void atomic_k(float* __restrict__ maps, uint32_t n_texels, int per_thread, int* __restrict__ xcc_mismatch) {
     const uint32_t xcd = blockIdx.x & 7u;
@@ -23,7 +24,9 @@ __global__ __launch_bounds__(256) void atomic_k(float* __restrict__ maps, uint32
         const uint32_t t = (hash32((tid >> 4) * 977u + k) + (tid & 15u)) % n_texels;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (MODE == 1 || MODE == 3) __hip_atomic_fetch_add(dst + (size_t)t * 4 + c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 4) __hip_atomic_fetch_add((uint32_t*)dst + (size_t)t * 4 + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (MODE == 5) __hip_atomic_fetch_add((unsigned long long*)dst + (size_t)(t >> 1) * 4 + c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (MODE == 1 || MODE == 3) __hip_atomic_fetch_add(dst + (size_t)t * 4 + c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_fetch_add(dst + (size_t)t * 4 + c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -35,6 +38,8 @@ extern "C" void atomic_probe(float* maps, uint32_t n_texels, int per_thread, int
         case 0: atomic_k<0><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
         case 1: atomic_k<1><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
         case 2: atomic_k<2><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
+        case 4: atomic_k<4><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
+        case 5: atomic_k<5><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
         default: atomic_k<3><<<blocks, 256, 0, s>>>(maps, n_texels, per_thread, mismatch); break;
     }
 }

@@ -41,6 +41,8 @@ timeit(0, "device scope, one copy")
 timeit(2, "device scope, one copy per XCD")
 timeit(1, "workgroup scope, one copy per XCD")
 timeit(3, "workgroup scope, one copy (not coherent across XCDs)")
+timeit(4, "device scope, one copy, uint32 adds")
+timeit(5, "device scope, one copy, uint64 adds")
 print("workgroups whose XCC_ID differs from blockIdx % 8:", int(mismatch.item()))
 maps.zero_()
 lib.atomic_probe(maps.data_ptr(), n_texels, per_thread, blocks, 1, mismatch.data_ptr(), torch.cuda.current_stream().cuda_stream)
