@@ -51,14 +51,15 @@ def _measure(quiet, kernels=False):
     target = torch.rand(512, 3, device=dev)
     if "--freeze-color" in sys.argv:             # probe: what the colour network's PyTorch-layer training costs (fine-tune: the feature maps are frozen too)
         surf.color_network.requires_grad_(False)
-    opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4)
+    adam = {"fused": True} if "--fused-adam" in sys.argv else {}      # (runner.py:97 builds the default, multi-tensor Adam: measured as such; the flag: one fused kernel)
+    opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4, **adam)
 
     finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
     if finetune:
         with torch.no_grad():
             _, ft_masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], intrs, c2ws, dims)
         ft_feats = [f.detach() for f in feats]
-        ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4)
+        ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4, **adam)
 
     def ft_step():
         out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
@@ -95,7 +96,7 @@ def _measure(quiet, kernels=False):
         from gens_amd.models import gens
         torch.manual_seed(0)
         model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
-        full_opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+        full_opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), **adam)
 
         def step():  # noqa: F811
             out = model("train", ipts, cos_anneal_ratio=0.5, step=1)
