@@ -73,13 +73,18 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
     for (int e = threadIdx.x; e < span; e += K4_BLOCK) dst[e] = row_lds[(e / row) * stride + (e % row)];
 }
 
+// Backward of the look-up: the bilinear taps of every (point, source view, level) scattered into the maps' gradients.  Bound by the float
+// atomics at L2, which are served per REQUEST, not per lane: an instruction whose lanes hit consecutive floats runs at 190 - 280 G atomics/s,
+// one whose lanes each hit their own texel at 66 G/s (scripts/probe/atomic_scope_probe.py).  So SIXTEEN lanes share a (point, view) pair --
+// lane = (tap, channel): the two taps of a row are 32 contiguous bytes -- and one atomic instruction per level carries four pairs.
 __global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __restrict__ g_imgs, const float* __restrict__ w2c,
                                                             const float* __restrict__ intr, int nv, const float* __restrict__ pts,
                                                             const float* __restrict__ g_out, int64_t n) {
     const int S = nv - 1;
     const int row = 3 + 4 * fs.n;
-    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (gid >= n * S) return;
+    const int sub = threadIdx.x & 15, tap = sub >> 2, ch = sub & 3, dy = tap >> 1, dx = tap & 1;
     int sv = (int)(gid % S) + 1;
     int64_t i = gid / S;
     float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
@@ -88,22 +93,17 @@ __global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __
         int h = fs.h[l], w = fs.w[l];
         SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
         Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-        int64_t off = (((int64_t)sv * h + t.y0) * w + t.x0) * 4;
+        const bool ok = tap == 0 ? t.ok00 : tap == 1 ? t.ok01 : tap == 2 ? t.ok10 : t.ok11;
+        if (!ok) continue;
+        const float wt = tap == 0 ? t.w00 : tap == 1 ? t.w01 : tap == 2 ? t.w10 : t.w11;
+        const int64_t off = (((int64_t)sv * h + t.y0 + dy) * w + t.x0 + dx) * 4 + ch;
         if (fs.grad[l]) {
-            float4 gf = make_float4(g[3 + 4 * l], g[4 + 4 * l], g[5 + 4 * l], g[6 + 4 * l]);
-            float* base = fs.grad[l] + off;
-            if (t.ok00) atomic_add4(base, gf, t.w00);
-            if (t.ok01) atomic_add4(base + 4, gf, t.w01);
-            if (t.ok10) atomic_add4(base + (int64_t)w * 4, gf, t.w10);
-            if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, gf, t.w11);
+            const float v = g[3 + 4 * l + ch] * wt;
+            if (v != 0.0f) atomicAdd(fs.grad[l] + off, v);                       // (masked samples carry exact zeros: nothing to add)
         }
-        if (l == 0 && g_imgs) {
-            float4 gc = make_float4(g[0], g[1], g[2], 0.0f);
-            float* base = g_imgs + off;
-            if (t.ok00) atomic_add4(base, gc, t.w00);
-            if (t.ok01) atomic_add4(base + 4, gc, t.w01);
-            if (t.ok10) atomic_add4(base + (int64_t)w * 4, gc, t.w10);
-            if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, gc, t.w11);
+        if (l == 0 && g_imgs && ch < 3) {
+            const float v = g[ch] * wt;
+            if (v != 0.0f) atomicAdd(g_imgs + off, v);
         }
     }
 }
@@ -164,6 +164,6 @@ extern "C" int gens_lookup_feature_bwd(const int* hw, int n_levels, const float*
     if (n == 0) return 0;
     if (g_feats)
         for (int l = 0; l < n_levels; ++l) fs.grad[l] = g_feats[l];
-    lookup_feature_bwd_k<<<gens_blocks(n * (nv - 1), 256), 256, 0, (hipStream_t)stream>>>(fs, g_imgs, w2c, intr, nv, pts, g_out, n);
+    lookup_feature_bwd_k<<<gens_blocks(n * (nv - 1) * 16, 256), 256, 0, (hipStream_t)stream>>>(fs, g_imgs, w2c, intr, nv, pts, g_out, n);
     return gens_launch_status("gens_lookup_feature_bwd");
 }

@@ -43,6 +43,8 @@ timeit(1, "workgroup scope, one copy per XCD")
 timeit(3, "workgroup scope, one copy (not coherent across XCDs)")
 timeit(4, "device scope, one copy, uint32 adds")
 timeit(5, "device scope, one copy, uint64 adds")
+timeit(6, "float, 64 lanes on 64 consecutive floats")
+timeit(7, "float, 16 lanes on 16 consecutive floats")
 print("workgroups whose XCC_ID differs from blockIdx % 8:", int(mismatch.item()))
 maps.zero_()
 lib.atomic_probe(maps.data_ptr(), n_texels, per_thread, blocks, 1, mismatch.data_ptr(), torch.cuda.current_stream().cuda_stream)
