@@ -45,6 +45,4 @@ for lvl, d in enumerate([256, 128, 64]):
     for mode in ("tiled", "window"):
         diff = (res[mode] - res["direct"]).abs().max().item()
         print(f"D={d} max |{mode} - direct| = {diff:.3e}  (max |g| = {res['direct'].abs().max().item():.3e})")
-    if d == 256:
-        items = scratch.view(torch.int32)   # (layout: gens_amd/csrc/k1_volume.hip::bwd_scratch_layout)
-        print(f"scratch {need / 2**20:.0f} MiB")
+    print(f"D={d} scratch of the tiled kernel: {need / 2**20:.0f} MiB")
