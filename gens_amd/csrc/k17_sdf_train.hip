@@ -714,12 +714,16 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
 // ====================================================================================================================
 // volume scatter: dV += w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lambda_f     (planar (4, X, Y, Z) gradients)
 // ====================================================================================================================
+// THIRTY-TWO lanes share a (point, level) pair -- lane = (channel, corner), the two z-neighbours of a corner pair adjacent: L2 serves float atomics
+// per request, and the lanes of an instruction that hit consecutive floats share one (scripts/probe/atomic_scope_probe.py); the planes of a planar
+// gradient only have z-neighbours contiguous.
 __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const float* __restrict__ pts, const float* __restrict__ g_bar,
                                                            const float* __restrict__ s_bar, const float4* __restrict__ f_hat,
                                                            const float4* __restrict__ mu_f, const float4* __restrict__ lam_f, int64_t n) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     const int L = vs.n;
     if (gid >= n * L) return;
+    const int sub = threadIdx.x & 31, ch = sub >> 3, a = (sub >> 2) & 1, b = (sub >> 1) & 1, d = sub & 1;
     const int l = (int)(gid % L);
     const int64_t i = gid / L;
     float* gv = vs.grad[l];
@@ -730,37 +734,33 @@ __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const fl
     int i0[3];
     bool in0[3], in1[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float x = pts[3 * i + a];
-        const float pos = (x + 1.0f) / 2.0f * (float)(sz[a] - 1);
-        const float f = fminf(fmaxf(floorf(pos), -2.0f), (float)sz[a] + 1.0f);
-        i0[a] = (int)f;
-        w0[a] = (f + 1.0f) - pos;
-        w1[a] = pos - f;
-        in0[a] = i0[a] >= 0 && i0[a] < sz[a];
-        in1[a] = i0[a] + 1 >= 0 && i0[a] + 1 < sz[a];
-        if (!(pos == pos)) in0[a] = in1[a] = false;
-        k[a] = (float)(sz[a] - 1) / 2.0f;
-        sb[a] = s_bar ? s_bar[3 * i + a] : 0.0f;
-        gb[a] = g_bar ? g_bar[3 * i + a] : 0.0f;
+    for (int ax = 0; ax < 3; ++ax) {
+        const float x = pts[3 * i + ax];
+        const float pos = (x + 1.0f) / 2.0f * (float)(sz[ax] - 1);
+        const float f = fminf(fmaxf(floorf(pos), -2.0f), (float)sz[ax] + 1.0f);
+        i0[ax] = (int)f;
+        w0[ax] = (f + 1.0f) - pos;
+        w1[ax] = pos - f;
+        in0[ax] = i0[ax] >= 0 && i0[ax] < sz[ax];
+        in1[ax] = i0[ax] + 1 >= 0 && i0[ax] + 1 < sz[ax];
+        if (!(pos == pos)) in0[ax] = in1[ax] = false;
+        k[ax] = (float)(sz[ax] - 1) / 2.0f;
+        sb[ax] = s_bar ? s_bar[3 * i + ax] : 0.0f;
+        gb[ax] = g_bar ? g_bar[3 * i + ax] : 0.0f;
     }
-    const float4 fh = f_hat[i * L + l], mf = mu_f[i * L + l], lf = lam_f[i * L + l];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int a = c >> 2, b = (c >> 1) & 1, d = c & 1;
-        const bool ok = (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
-        if (!ok) continue;
-        const float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
-        const float dwx = (a ? k[0] : -k[0]) * wy * wz, dwy = wx * (b ? k[1] : -k[1]) * wz, dwz = wx * wy * (d ? k[2] : -k[2]);
-        const float w = wx * wy * wz;
-        const float ts = dwx * sb[0] + dwy * sb[1] + dwz * sb[2];
-        const float tg = dwx * gb[0] + dwy * gb[1] + dwz * gb[2];
-        const int64_t lin = ((int64_t)(i0[0] + a) * sz[1] + (i0[1] + b)) * sz[2] + (i0[2] + d);
-        atomicAdd(gv + lin, w * fh.x + ts * mf.x + tg * lf.x);
-        atomicAdd(gv + nvox + lin, w * fh.y + ts * mf.y + tg * lf.y);
-        atomicAdd(gv + 2 * nvox + lin, w * fh.z + ts * mf.z + tg * lf.z);
-        atomicAdd(gv + 3 * nvox + lin, w * fh.w + ts * mf.w + tg * lf.w);
-    }
+    const bool ok = (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
+    if (!ok) return;
+    const float* fp = (const float*)(f_hat + i * L + l);
+    const float* mp = (const float*)(mu_f + i * L + l);
+    const float* lp = (const float*)(lam_f + i * L + l);
+    const float fh = fp[ch], mf = mp[ch], lf = lp[ch];
+    const float wx = a ? w1[0] : w0[0], wy = b ? w1[1] : w0[1], wz = d ? w1[2] : w0[2];
+    const float dwx = (a ? k[0] : -k[0]) * wy * wz, dwy = wx * (b ? k[1] : -k[1]) * wz, dwz = wx * wy * (d ? k[2] : -k[2]);
+    const float w = wx * wy * wz;
+    const float ts = dwx * sb[0] + dwy * sb[1] + dwz * sb[2];
+    const float tg = dwx * gb[0] + dwy * gb[1] + dwz * gb[2];
+    const int64_t lin = ((int64_t)(i0[0] + a) * sz[1] + (i0[1] + b)) * sz[2] + (i0[2] + d);
+    atomicAdd(gv + ch * nvox + lin, w * fh + ts * mf + tg * lf);
 }
 
 // ====================================================================================================================
@@ -945,7 +945,7 @@ extern "C" int gens_sdf_train_scatter(const int* dims, int n_levels, const float
         vs.dy[l] = l < n_levels ? dims[3 * l + 1] : 1;
         vs.dz[l] = l < n_levels ? dims[3 * l + 2] : 1;
     }
-    sdf_train_scatter_k<<<gens_blocks(n * n_levels, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, g_bar, s_bar, (const float4*)f_hat,
+    sdf_train_scatter_k<<<gens_blocks(n * n_levels * 32, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, g_bar, s_bar, (const float4*)f_hat,
                                                                                          (const float4*)mu_f, (const float4*)lam_f, n);
     return gens_launch_status("gens_sdf_train_scatter");
 }
