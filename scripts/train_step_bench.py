@@ -71,7 +71,7 @@ def _measure(quiet, kernels=False):
         ft_opt.zero_grad(set_to_none=True)
         loss.backward()
         ft_opt.step()
-        return float(loss.detach())
+        return loss.detach()
 
     def step():
         if finetune:
@@ -89,7 +89,7 @@ def _measure(quiet, kernels=False):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        return float(loss.detach())
+        return loss.detach()
 
     full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen
     if full:                                     # matching copy too) and the 3-D U-Net inside the step
@@ -108,24 +108,28 @@ def _measure(quiet, kernels=False):
             full_opt.zero_grad(set_to_none=True)
             loss.backward()
             full_opt.step()
-            return float(loss.detach())
+            return loss.detach()
 
     for _ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
-        step()
+        float(step())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
+    host = 0.0
     for _ in range(n):
-        step()
+        t1 = time.perf_counter()
+        loss = step()
+        host += time.perf_counter() - t1                                 # the host's share: every launch of the step enqueued
+        float(loss)                                                      # (runner.py reads the loss every step: one synchronisation per step)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
     if not quiet:
-        print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays)")
+        print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step)")
     if os.environ.get("GENS_TRAIN_OPS"):         # which torch operators make up the step's launches (torch.profiler over one step)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-            step()
+            float(step())
             torch.cuda.synchronize()
         rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.count > 0 and getattr(e, "device_time_total", 0) > 0]
         rows.sort(key=lambda e: -e.device_time_total)
