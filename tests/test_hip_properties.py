@@ -316,6 +316,47 @@ def test_k1_backward_tile_kernel_rejects_what_it_does_not_cover(scene):
         L.call("gens_volume_build_bwd_tiled", *args, 64, L.ptr(gvol), L.ptr(gf), None, need, L.stream())
 
 
+def test_k4_feature_backward_at_step_size(scene):
+    """The feature / image gradients of the source-view look-up (gens_lookup_feature_bwd: sixteen lanes per (point, view) pair, one float atomic
+    per lane and level) at the size of a training step -- 61 003 points x 4 source views of the 480 x 640 five-level pyramid: against the CPU
+    oracle's autograd on the first 8 192 points, and through size-independent properties on all of them (the two halves of the batch add up
+    to the whole; doubling the cotangent doubles the result; zero cotangent rows add nothing)."""
+    from gens_amd import ops
+    from oracle import gens_oracle as K
+    feats, imgs, intrs, c2ws = scene["features"], scene["imgs"], scene["intrs"], scene["c2ws"]
+    g = torch.Generator().manual_seed(11)
+    n = 61003
+    pts = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+    cot = torch.randn(n, intrs.shape[0] - 1, 3 + 4 * len(feats), generator=g).cuda()
+
+    def grads(p, c):
+        fl = [f.detach().clone().requires_grad_(True) for f in feats]
+        im = imgs.detach().clone().requires_grad_(True)
+        fv, _, _ = ops.lookup_feature(p, ops.SceneViews(im, intrs, c2ws, fl))
+        return torch.autograd.grad((fv * c).sum(), fl + [im])
+    full = grads(pts, cot)
+    m = 8192
+    fl = [f.detach().cpu().clone().requires_grad_(True) for f in feats]
+    im = imgs.detach().cpu().clone().requires_grad_(True)
+    fv_ref, _, _ = K.lookup_feature(pts[:m].cpu(), im, intrs.cpu(), c2ws.cpu(), fl)
+    ref = torch.autograd.grad((fv_ref * cot[:m].cpu()).sum(), fl + [im])
+    for a, b in zip(grads(pts[:m].contiguous(), cot[:m].contiguous()), ref):
+        scale = float(b.abs().max())
+        # (a tap's weight moves with the projected coordinate: float32 round-off of 1e-4 pixel at x ~ 600 times a cotangent of ~4; g4 uses 1e-4 absolute)
+        assert scale > 0.1 and float((a.cpu() - b).abs().max()) <= 2e-4 * scale, (float((a.cpu() - b).abs().max()), scale)
+    h = n // 2 + 5
+    first, second = grads(pts[:h].contiguous(), cot[:h].contiguous()), grads(pts[h:].contiguous(), cot[h:].contiguous())
+    doubled = grads(pts, 2.0 * cot)
+    masked = cot.clone()
+    masked[h:] = 0.0
+    only_first = grads(pts, masked)
+    for a, p, q, d2, o in zip(full, first, second, doubled, only_first):
+        scale = float(a.abs().max())
+        assert float((p + q - a).abs().max()) <= 1e-5 * scale
+        assert float((d2 - 2.0 * a).abs().max()) <= 1e-5 * scale
+        assert float((o - p).abs().max()) <= 1e-5 * scale
+
+
 # --------------------------------------------------------------------------------------------------- K17 / K18 at training-step size
 def _train_case(n_levels, n, seed):
     from gens_amd import ops
