@@ -192,6 +192,78 @@ __global__ __launch_bounds__(256) void lookup_bwd2_k(LevelSet vs, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The volume scatter of both backward passes: g_vols[c][corner] += g_out[c] * coef(corner), coef = the corner's trilinear weight (first
+// order) or T = e . grad_pos(w) (second order).  THIRTY-TWO lanes share a (point, level) pair, lane = (corner, channel): L2 serves float
+// atomics per request, so the lanes of an instruction should hit consecutive floats (scripts/probe/atomic_scope_probe.py: 66 G atomics/s with a
+// lane per point, 190 - 280 on consecutive floats) -- in a packed volume the two z-neighbours of a corner pair are 32 contiguous bytes, in a
+// planar one two floats per channel plane (scripts/probe/k2_bwd_levels_probe.py: the one-lane-per-point scatter cost 0.85 - 1.07 ms per level and
+// 1 M points whatever the level's density).  The per-point kernels above run without gradient buffers; the products are theirs bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYOUT, bool SECOND>
+__global__ __launch_bounds__(256) void lookup_scatter_k(LevelSet vs, const float* __restrict__ pts, const float4* __restrict__ g_out,
+                                                        const float* __restrict__ gg_pts, int64_t n) {
+    // PACKED: 32 lanes per (level, point), lane = (corner, channel): the two z-neighbours of a corner pair are 32 contiguous bytes.
+    // PLANAR: 2 lanes per (level, point), lane = z-neighbour, looping over the channel planes and the four (x, y) corner pairs: only the
+    // z-neighbours are contiguous there, and consecutive points (samples along a ray) keep the neighbouring lanes on neighbouring lines.
+    constexpr int LANES = LAYOUT == GENS_LAYOUT_PACKED ? 32 : 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t item = gid / LANES;
+    if (item >= n * vs.n) return;
+    // PLANAR: level-major, so that the lanes of a wave are consecutive points of ONE volume; PACKED: level fastest (a wave = two points' levels)
+    const int l = LAYOUT == GENS_LAYOUT_PACKED ? (int)(item % vs.n) : (int)(item / n);
+    const int64_t i = LAYOUT == GENS_LAYOUT_PACKED ? item / vs.n : item - (int64_t)l * n;
+    float* gv = vs.grad[l];
+    if (!gv) return;
+    const int sub = (int)(gid % LANES);
+    const int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const Cell cx = axis_cell(pts[3 * i], X), cy = axis_cell(pts[3 * i + 1], Y), cz = axis_cell(pts[3 * i + 2], Z);
+    float ex = 0.0f, ey = 0.0f, ez = 0.0f;
+    if (SECOND) {
+        ex = gg_pts[3 * i] * ((float)(X - 1) / 2.0f);
+        ey = gg_pts[3 * i + 1] * ((float)(Y - 1) / 2.0f);
+        ez = gg_pts[3 * i + 2] * ((float)(Z - 1) / 2.0f);
+    }
+    const float* go = (const float*)(g_out + i * vs.n + l);
+    auto coef_of = [&](int a, int b, int c) {
+        const float wx = a ? cx.w1 : cx.w0, wy = b ? cy.w1 : cy.w0, wz = c ? cz.w1 : cz.w0;
+        if (!SECOND) return wx * wy * wz;
+        const float sx = a ? 1.0f : -1.0f, sy = b ? 1.0f : -1.0f, sz = c ? 1.0f : -1.0f;
+        return ex * (sx * wy * wz) + ey * (wx * sy * wz) + ez * (wx * wy * sz);
+    };
+    if (LAYOUT == GENS_LAYOUT_PACKED) {
+        const int ch = sub & 3, c = (sub >> 2) & 1, b = (sub >> 3) & 1, a = sub >> 4;
+        const bool ok = (a ? cx.in1 : cx.in0) && (b ? cy.in1 : cy.in0) && (c ? cz.in1 : cz.in0);
+        if (!ok) return;
+        const int64_t lin = ((int64_t)(cx.i0 + a) * Y + (cy.i0 + b)) * Z + (cz.i0 + c);
+        atomicAdd(gv + lin * 4 + ch, go[ch] * coef_of(a, b, c));
+    } else {
+        const int c = sub;
+        if (!(c ? cz.in1 : cz.in0)) return;
+        const float4 g = make_float4(go[0], go[1], go[2], go[3]);
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const int a = ab >> 1, b = ab & 1;
+            if (!((a ? cx.in1 : cx.in0) && (b ? cy.in1 : cy.in0))) continue;
+            const int64_t lin = ((int64_t)(cx.i0 + a) * Y + (cy.i0 + b)) * Z + (cz.i0 + c);
+            const float k = coef_of(a, b, c);
+            atomicAdd(gv + lin, g.x * k);
+            atomicAdd(gv + nvox + lin, g.y * k);
+            atomicAdd(gv + 2 * nvox + lin, g.z * k);
+            atomicAdd(gv + 3 * nvox + lin, g.w * k);
+        }
+    }
+}
+
+template <bool SECOND>
+static void launch_lookup_scatter(int layout, const LevelSet& vs, const float* pts, const float* g_out, const float* gg_pts, int64_t n, void* stream) {
+    if (layout == GENS_LAYOUT_PACKED)
+        lookup_scatter_k<GENS_LAYOUT_PACKED, SECOND><<<gens_blocks(n * vs.n * 32, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, (const float4*)g_out, gg_pts, n);
+    else
+        lookup_scatter_k<GENS_LAYOUT_PLANAR, SECOND><<<gens_blocks(n * vs.n * 2, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, (const float4*)g_out, gg_pts, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K3 nearest mask + fused ray-point generation
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_nearest_k(LevelSet ms, const float* __restrict__ pts, int64_t n,
@@ -382,9 +454,19 @@ extern "C" int gens_lookup_volume_bwd(const float* const* vols, const int* dims,
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out)), GENS_EINVAL, "gens_lookup_volume_bwd: null pts/g_out");
     GENS_CHECK_ARG(g_vols || g_pts, GENS_EINVAL, "gens_lookup_volume_bwd: no output requested");
     if (n == 0) return 0;
-    if (g_vols)
+    const bool lane_per_point = getenv("GENS_K2_SCATTER_PER_POINT") != nullptr;       // (switch: the scatter inside the per-point kernel, for A/B runs)
+    bool scatter = false;
+    if (g_vols && lane_per_point)
         for (int l = 0; l < n_levels; ++l) vs.grad[l] = g_vols[l];
-    DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts);
+    if (g_pts || (g_vols && lane_per_point))
+        DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts);
+    if (g_vols && !lane_per_point) {
+        for (int l = 0; l < n_levels; ++l) {
+            vs.grad[l] = g_vols[l];
+            scatter = scatter || g_vols[l];
+        }
+        if (scatter) launch_lookup_scatter<false>(layout, vs, pts, g_out, nullptr, n, stream);
+    }
     return gens_launch_status("gens_lookup_volume_bwd");
 }
 
@@ -397,12 +479,21 @@ extern "C" int gens_lookup_volume_bwd2(const float* const* vols, const int* dims
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out && gg_pts && gg_out && g_pts2)), GENS_EINVAL,
                    "gens_lookup_volume_bwd2: null pointer");
     if (n == 0) return 0;
+    const bool lane_per_point = getenv("GENS_K2_SCATTER_PER_POINT") != nullptr;
+    bool scatter = false;
     for (int l = 0; l < n_levels; ++l) {
-        if (g_vols2) vs.grad[l] = g_vols2[l];
+        if (g_vols2 && lane_per_point) vs.grad[l] = g_vols2[l];
         if (gg_vols) vs.aux[l] = gg_vols[l];
     }
     DISPATCH_LAYOUT(layout, lookup_bwd2_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, gg_pts, n,
                     (float4*)gg_out, g_pts2);
+    if (g_vols2 && !lane_per_point) {
+        for (int l = 0; l < n_levels; ++l) {
+            vs.grad[l] = g_vols2[l];
+            scatter = scatter || g_vols2[l];
+        }
+        if (scatter) launch_lookup_scatter<true>(layout, vs, pts, g_out, gg_pts, n, stream);
+    }
     return gens_launch_status("gens_lookup_volume_bwd2");
 }
 

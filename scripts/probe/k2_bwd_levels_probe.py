@@ -25,7 +25,10 @@ for layout_name, layout in (("planar", L.LAYOUT_PLANAR), ("packed", L.LAYOUT_PAC
     for name, pts in cases.items():
         g_out = torch.randn(n, 4 * len(dims), device=dev)
         g_pts = torch.empty(n, 3, device=dev)
-        for subset in ([], [0], [1], [2], [0, 1, 2]):
+        for subset, per_point in (([], False), ([0], False), ([1], False), ([2], False), ([0, 1, 2], False), ([0, 1, 2], True)):
+            os.environ.pop("GENS_K2_SCATTER_PER_POINT", None)
+            if per_point:
+                os.environ["GENS_K2_SCATTER_PER_POINT"] = "1"              # the round-1 form: one lane per point, the scatter inside the per-point kernel
             grads = [torch.zeros_like(t) if l in subset else None for l, t in enumerate(vs.tensors)]
             fn = lambda: L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), n, L.ptr_table(grads),  # noqa: E731
                                 L.ptr(g_pts), L.stream())
@@ -38,4 +41,5 @@ for layout_name, layout in (("planar", L.LAYOUT_PLANAR), ("packed", L.LAYOUT_PAC
                 fn()
             e.record()
             torch.cuda.synchronize()
-            print(f"{layout_name:7s} {name:12s} gradient levels {str(subset):10s} {s.elapsed_time(e) / 10 * 1e3:9.1f} us")
+            print(f"{layout_name:7s} {name:12s} gradient levels {str(subset):10s} {'lane per point' if per_point else 'lane per float':15s} {s.elapsed_time(e) / 10 * 1e3:9.1f} us")
+        os.environ.pop("GENS_K2_SCATTER_PER_POINT", None)
