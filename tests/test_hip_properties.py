@@ -316,6 +316,48 @@ def test_k1_backward_tile_kernel_rejects_what_it_does_not_cover(scene):
         L.call("gens_volume_build_bwd_tiled", *args, 64, L.ptr(gvol), L.ptr(gf), None, need, L.stream())
 
 
+@pytest.mark.parametrize("layout", ["planar", "packed"])
+def test_k2_volume_scatter_lane_per_float_equals_lane_per_point(scene, layout, monkeypatch):
+    """The volume gradients of both K2 backward passes (lookup_scatter_k: a lane per float, its own launch) against the scatter inside the
+    per-point kernels (GENS_K2_SCATTER_PER_POINT), planar and packed gradients, 262 144 ray samples + points outside the cube, three levels:
+    the same products in another order of the float atomics; d/dpts, gg_out and the second-order d/dpts are untouched (bit-identical)."""
+    from gens_amd import lib as L, ops
+    vols = scene["vols"][:3]
+    lay = L.LAYOUT_PACKED if layout == "packed" else L.LAYOUT_PLANAR
+    vs = ops.VolumeSet.packed(vols) if layout == "packed" else ops._vset(lay, vols)
+    ro, rd = scene["rays_o"][:2048], scene["rays_d"][:2048]
+    z = torch.linspace(0.2, 2.6, 128, device="cuda")
+    pts = (ro[:, None] + rd[:, None] * z[None, :, None]).reshape(-1, 3).contiguous()
+    n = pts.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    g_out = torch.randn(n, 12, device="cuda", generator=g)
+    gg_pts = torch.randn(n, 3, device="cuda", generator=g)
+
+    def run(per_point):
+        if per_point:
+            monkeypatch.setenv("GENS_K2_SCATTER_PER_POINT", "1")
+        else:
+            monkeypatch.delenv("GENS_K2_SCATTER_PER_POINT", raising=False)
+        gv = [torch.zeros_like(t) for t in vs.tensors]
+        g_pts = torch.empty(n, 3, device="cuda")
+        L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, lay, L.ptr(pts), L.ptr(g_out), n, L.ptr_table(gv), L.ptr(g_pts), L.stream())
+        gv2 = [torch.zeros_like(t) for t in vs.tensors]
+        gg_out, g_pts2 = torch.empty(n, 12, device="cuda"), torch.empty(n, 3, device="cuda")
+        L.call("gens_lookup_volume_bwd2", vs.table, vs.dim_table, vs.n, lay, L.ptr(pts), L.ptr(g_out), L.ptr(gg_pts), None, n, L.ptr(gg_out),
+               L.ptr_table(gv2), L.ptr(g_pts2), L.stream())
+        return gv, gv2, (g_pts, gg_out, g_pts2)
+    a1, a2, ar = run(False)
+    b1, b2, br = run(True)
+    for x, y in zip(ar, br):
+        assert torch.equal(x, y)
+    for x, y in zip(a1 + a2, b1 + b2):
+        scale = float(y.abs().max())
+        assert scale > 1.0 and float((x - y).abs().max()) <= 2e-6 * scale + 1e-6, (float((x - y).abs().max()), scale)
+    only = [torch.zeros_like(t) if l == 1 else None for l, t in enumerate(vs.tensors)]           # a subset of the levels
+    L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, lay, L.ptr(pts), L.ptr(g_out), n, L.ptr_table(only), None, L.stream())
+    assert float((only[1] - b1[1]).abs().max()) <= 2e-6 * float(b1[1].abs().max()) + 1e-6
+
+
 def test_k4_feature_backward_at_step_size(scene):
     """The feature / image gradients of the source-view look-up (gens_lookup_feature_bwd: sixteen lanes per (point, view) pair, one float atomic
     per lane and level) at the size of a training step -- 61 003 points x 4 source views of the 480 x 640 five-level pyramid: against the CPU
