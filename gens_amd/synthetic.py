@@ -28,7 +28,7 @@ def make_cameras(nv, h=480, w=640, dist=2.2):
     Returns intrs (nv,4,4), c2ws (nv,4,4), near (1,1), far (1,1) as float32 tensors.
     Intrinsics are those of a 480x640 image rescaled to (h, w).
     """
-    angles = [0.0, 10.0, -10.0, 20.0, -20.0, 30.0, -30.0][:nv]
+    angles = [0.0 if k == 0 else (10.0 if k % 2 else -10.0) * ((k + 1) // 2) for k in range(nv)]     # 0, 10, -10, 20, -20, ...: any view count
     sx, sy = w / 640.0, h / 480.0
     intr = np.eye(4, dtype=np.float64)
     intr[0, 0], intr[1, 1] = DTU_FX * sx, DTU_FY * sy
