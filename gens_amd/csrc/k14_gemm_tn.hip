@@ -203,24 +203,48 @@ __global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     int64_t k = k_begin;
-    for (; k + 8 <= k_end; k += 8) {                                    // four row pairs per trip, their eight loads issued together
-        float2 av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            av[q] = ap[(int64_t)q * sa];                                // rows k + 2 q + h  (a float2 pointer advances 2 floats per unit)
-            bv[q] = bp[(int64_t)q * sb];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a0 = am ? av[q].x : 0.0f, a1 = am ? av[q].y : 0.0f, b0 = bn ? bv[q].x : 0.0f, b1 = bn ? bv[q].y : 0.0f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        ap += 4 * sa;
-        bp += 4 * sb;
+    // four row pairs per trip, their eight loads issued together -- and ONE TRIP AHEAD of the products that use them (two register sets): a trip's
+    // sixteen MFMAs are 1 024 cycles of work, a load under this traffic takes longer, and the waves of a SIMD could not cover the difference
+    // (matrix pipe 57 % busy, waves waiting 76 % of their time with the loads issued at the top of their own trip).
+#define K14_LOAD(AV, BV)                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {          \
+        AV[q] = ap[(int64_t)q * sa];                         \
+        BV[q] = bp[(int64_t)q * sb];                         \
+    }                                                        \
+    ap += 4 * sa;                                            \
+    bp += 4 * sb;
+#define K14_MULT(AV, BV)                                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                      \
+        const float a0 = am ? AV[q].x : 0.0f, a1 = am ? AV[q].y : 0.0f, b0 = bn ? BV[q].x : 0.0f, b1 = bn ? BV[q].y : 0.0f;              \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);                                                    \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);                                                    \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);                                                    \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);                                                    \
     }
+    if (k + 8 <= k_end) {
+        float2 av0[4], bv0[4], av1[4], bv1[4];
+        K14_LOAD(av0, bv0)
+        for (; k + 24 <= k_end; k += 16) {                             // (this trip's set is loaded, the next two fit)
+            K14_LOAD(av1, bv1)
+            __builtin_amdgcn_sched_barrier(0);
+            K14_MULT(av0, bv0)
+            K14_LOAD(av0, bv0)
+            __builtin_amdgcn_sched_barrier(0);
+            K14_MULT(av1, bv1)
+        }
+        if (k + 16 <= k_end) {
+            K14_LOAD(av1, bv1)
+            __builtin_amdgcn_sched_barrier(0);
+            K14_MULT(av0, bv0)
+            K14_MULT(av1, bv1)
+            k += 16;
+        } else {
+            K14_MULT(av0, bv0)
+            k += 8;
+        }
+    }
+#undef K14_LOAD
+#undef K14_MULT
     for (; k < k_end; k += 2) {
         const bool row = k + h < k_end;
         float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
