@@ -1,4 +1,6 @@
-// K7t: source-view feature look-up + the whole IBRNet-style BlendingNetwork for FOUR source views, TRANSPOSED (the dataflow of
+// K7t: source-view feature look-up + the whole IBRNet-style BlendingNetwork for TWO, THREE or FOUR source views (the view counts the
+// reference ships: num_src_view = 2 in the DTU / BlendedMVS test protocol and the fine-tune configs, confs/gens.conf:24,
+// confs/gens_finetune.conf:15; 4 in training, confs/gens.conf:9), TRANSPOSED (the dataflow of
 // k6t_sdf_value.hip applied to k7_blend.hip's eleven small layers; replaces for validation rendering lookup_feature + compute_angle,
 // /root/reference/models/modules/projector.py:278-349, and BlendingNetwork.forward, models/modules/blending_network.py:69-118, as
 // called from implicit_surface.py:196-199).
@@ -11,7 +13,10 @@
 //     the K quad kq wants.  The activations of all eleven layers stay in registers: k7_blend.hip moved them through an LDS tile
 //     (362 LDS instructions and their address arithmetic per 32 rows) and loaded every weight once per 32 rows; here a weight float4
 //     is loaded once per 64 rows and feeds 16 MFMAs.
-//   * the four views of a point are four ADJACENT lanes: min / sum / max over views are two quad_perm DPP butterflies.
+//   * the S views of a point are G ADJACENT lanes (G = 4 for S = 3, 4; G = 2 for S = 2): min / sum / max over views are one or two
+//     quad_perm DPP butterflies.  S = 2: a wave owns 32 points (8 per N tile) and the per-point product below has two N tiles of
+//     points.  S = 3: the fourth lane of a quad is a DEAD row -- no camera is read for it, its mask is 0, it is +inf in the minimum of
+//     the anti-alias weights and -inf in the soft-max, so the three live views see exactly the reference's sums.
 //   * base_fc.0 reads cat([mean, var, x]): mean and var are the same for the four views of a point, so their 2 F columns are
 //     multiplied ONCE per point -- an N tile of the wave's 16 points (operands gathered with ds_bpermute) -- and the result, broadcast
 //     back to the rows, is the initial value of the x-part's accumulators: 48 instead of 192 MFMAs per 64 rows.
@@ -32,9 +37,22 @@ struct BlendTWeights {
 enum { KT_RD1_B = 0, KT_RD2_B, KT_B2_B, KT_V1_B, KT_V2_B, KT_U1_B, KT_R2_B, KT_V2_LAST, KT_U2, KT_R3, KT_TAB_ENTRIES };
 
 __device__ __forceinline__ float elu1t(float x) { return __builtin_amdgcn_fmed3f(x, hw_exp(x) - 1.0f, 0.0f); }   // see k7_blend.hip::elu1
-__device__ __forceinline__ float quad_sum(float v) {      // sum over the 4 lanes of a quad (= the 4 views of a point), in every lane
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {     // sum over the G adjacent lanes of a point (= its views), in every lane
     v += dpp_move<0xB1, 0xF>(v, v);                       // quad_perm:[1,0,3,2]
-    v += dpp_move<0x4E, 0xF>(v, v);                       // quad_perm:[2,3,0,1]
+    if (G == 4) v += dpp_move<0x4E, 0xF>(v, v);           // quad_perm:[2,3,0,1]
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_min(float v) {
+    v = fminf(v, dpp_move<0xB1, 0xF>(v, v));
+    if (G == 4) v = fminf(v, dpp_move<0x4E, 0xF>(v, v));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+    if (G == 4) v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
     return v;
 }
 __device__ __forceinline__ float lanes_q_sum(float v) {   // sum over the four lane groups q of a column
@@ -43,7 +61,7 @@ __device__ __forceinline__ float lanes_q_sum(float v) {   // sum over the four l
     return v;
 }
 
-template <int NLEV>
+template <int NLEV, int S>
 __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, const float4* __restrict__ imgs, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, const float* __restrict__ c2w, const float* __restrict__ pts,
                                                    const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
@@ -51,6 +69,11 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     constexpr int F = 3 + 4 * NLEV;
     constexpr int XQ = NLEV + 1;             // K quads of a feature vector: F + 1 = 4 (NLEV + 1) slots, the last one carries the constant one
     constexpr int XT = (XQ + 3) / 4;         // accumulator tiles of a feature vector
+    constexpr int G = S == 2 ? 2 : 4;        // lanes per point (S = 3: one dead lane)
+    constexpr int PPT = 16 / G;              // points per N tile
+    constexpr int PPW = 64 / G;              // points per wave
+    constexpr int NPT = PPW / 16;            // N tiles of POINTS of the per-point product (mean / variance columns)
+    static_assert(S >= 2 && S <= 4, "two to four source views");
     static_assert(4 * XQ <= KT_XS, "feature tile too narrow");
     __shared__ float X[64 * KT_XS];          // gathered rows: rgb (3), features (4 NLEV), one
     __shared__ float RD[64 * 5];             // ray difference (4)
@@ -58,7 +81,7 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     const int lane = threadIdx.x;
     const int np = lane & 15, q = lane >> 4;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
-    const int64_t first = (int64_t)blockIdx.x * 16;
+    const int64_t first = (int64_t)blockIdx.x * PPW;
     if (first >= n) return;
 
     // weights: scalar base, three float4 registers rotate (this group's, the next two in flight)
@@ -71,14 +94,15 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 
     // ---------------------------------------------------------------- phase 0: one lane per (point, view) row gathers it
     {
-        const int pl = lane >> 2, sv = (lane & 3) + 1;
-        const bool live = first + pl < n;
+        const int pl = lane / G, sv = (lane % G) + 1;
+        const bool live = first + pl < n && sv <= S;          // (S = 3: the fourth lane of a quad carries no view)
         const int64_t src = live ? (index ? index[first + pl] : first + pl) : 0;
         float x = 0.f, y = 0.f, z = 0.f;
         if (live) { x = pts[3 * src]; y = pts[3 * src + 1]; z = pts[3 * src + 2]; }
         bool inside = true;
         float* xr = X + lane * KT_XS;
-        const SrcBase pb = project_src_base(w2c + 16 * sv, intr + 16 * sv, x, y, z);
+        const int svc = sv <= S ? sv : S;                       // camera read by the dead lane (never used)
+        const SrcBase pb = project_src_base(w2c + 16 * svc, intr + 16 * svc, x, y, z);
 #pragma unroll
         for (int l = 0; l < NLEV; ++l) {
             const int h = fs.h[l], w = fs.w[l];
@@ -87,8 +111,8 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
             float4 f = f4_zero(), c = f4_zero();
             if (live) {
                 const Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-                f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
-                if (l == 0) c = sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+                f = sample_texel(fs.data[l] + (int64_t)svc * h * w, h, w, 1, 0, t);
+                if (l == 0) c = sample_texel(imgs + (int64_t)svc * h * w, h, w, 1, 0, t);
             }
             xr[3 + 4 * l] = f.x; xr[4 + 4 * l] = f.y; xr[5 + 4 * l] = f.z; xr[6 + 4 * l] = f.w;
             if (l == 0) { xr[0] = c.x; xr[1] = c.y; xr[2] = c.z; }
@@ -100,12 +124,12 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 #pragma unroll
         for (int k = 0; k < F; ++k) acc_in += xr[k];
         R[lane] = ((live && inside) ? 1.0f : 0.0f) + 0.0f * acc_in;
-        if (live && vis_out) vis_out[src * 4 + (sv - 1)] = inside ? 1 : 0;
+        if (live && vis_out) vis_out[src * S + (sv - 1)] = inside ? 1 : 0;
         // compute_angle (projector.py:278-291), hardware sqrt / rcp as in k7_blend.hip
         float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
         const float rn = hw_rcp(__builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f);
         rx *= rn; ry *= rn; rz *= rn;
-        const float* cs = c2w + 16 * sv;
+        const float* cs = c2w + 16 * svc;
         float sx = cs[3] - x, sy = cs[7] - y, sz = cs[11] - z;
         const float sn = hw_rcp(__builtin_amdgcn_sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
         sx *= sn; sy *= sn; sz *= sn;
@@ -194,28 +218,34 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 
     // ---------------------------------------------------------------- view weights, weighted mean / variance (:93-101)
     float wn[KT_NT];
-    float pm[XQ], pv[XQ];          // mean / variance of the wave's 16 points as the operand of an N tile of points
+    float pm[NPT][XQ], pv[NPT][XQ];          // mean / variance of the wave's points as the operands of NPT N tiles of 16 points
+    const bool dead = S == 3 && (np & 3) == 3;
     {
-        const int src = (4 * (np & 3) + 16 * q) * 4;          // byte address for ds_bpermute: lane 4 (point in tile) of the same lane group
-        const int jsel = np >> 2;
+        // point p = 16 t + np of point tile t is row tile p / PPT, column G (p % PPT) (its first view), same lane group
+        const int src = (G * (np % PPT) + 16 * q) * 4;          // byte address for ds_bpermute
 #pragma unroll
-        for (int kq = 0; kq < XQ; ++kq) { pm[kq] = 0.0f; pv[kq] = 0.0f; }
+        for (int t = 0; t < NPT; ++t)
+#pragma unroll
+            for (int kq = 0; kq < XQ; ++kq) { pm[t][kq] = 0.0f; pv[t][kq] = 0.0f; }
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j) {
             const float e = hw_exp(W.s_abs * (dotv[j] - 1.0f));
-            float mn = fminf(e, dpp_move<0xB1, 0xF>(e, e));
-            mn = fminf(mn, dpp_move<0x4E, 0xF>(mn, mn));
-            const float wr = (e - mn) * mask[j];
-            wn[j] = wr / (quad_sum(wr) + 1e-8f);
+            const float mn = group_min<G>(dead ? __builtin_inff() : e);
+            const float wr = dead ? 0.0f : (e - mn) * mask[j];
+            wn[j] = wr / (group_sum<G>(wr) + 1e-8f);
 #pragma unroll
             for (int kq = 0; kq < XQ; ++kq) {
-                const float mean = quad_sum(wn[j] * xq[j][kq]);
+                const float mean = group_sum<G>(wn[j] * xq[j][kq]);
                 const float d = xq[j][kq] - mean;
-                const float var = quad_sum(wn[j] * (d * d));
+                const float var = group_sum<G>(wn[j] * (d * d));
                 const float tm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, mean)));
                 const float tv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, var)));
-                pm[kq] = jsel == j ? tm : pm[kq];
-                pv[kq] = jsel == j ? tv : pv[kq];
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) {
+                    const bool sel = (16 * t + np) / PPT == j;
+                    pm[t][kq] = sel ? tm : pm[t][kq];
+                    pv[t][kq] = sel ? tv : pv[t][kq];
+                }
             }
         }
     }
@@ -223,23 +253,23 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     // ---------------------------------------------------------------- base_fc (:103-104)
     f32x4 H1[4][KT_NT];           // base_fc.0's 64 outputs per N tile
     {
-        f32x4 P[4];                // the mean / variance columns, once per POINT (N tile = the 16 points)
+        f32x4 P[NPT][4];           // the mean / variance columns, once per POINT (N tiles of 16 points)
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define INIT_T_(j) zero4
-#define ACC_T_(j) P[T_]
-#define B_PM(j, k) ((k) < XQ ? pm[(k) < XQ ? (k) : 0] : pv[(k) < XQ ? 0 : (k) - XQ])
-        KT_PRODUCT(1, 4, 2 * XQ, P, B_PM)
+#define ACC_T_(j) P[j][T_]
+#define B_PM(j, k) ((k) < XQ ? pm[j][(k) < XQ ? (k) : 0] : pv[j][(k) < XQ ? 0 : (k) - XQ])
+        KT_PRODUCT(NPT, 4, 2 * XQ, P, B_PM)
 #undef ACC_T_
 #undef INIT_T_
-        // back to the rows: column n' of N tile j is point 4 j + n' / 4
+        // back to the rows: column n' of row tile j is point PPT j + n' / G = column (PPT j) % 16 + n' / G of point tile (PPT j) / 16
 #pragma unroll
         for (int j = 0; j < KT_NT; ++j) {
-            const int src = (4 * j + (np >> 2) + 16 * q) * 4;
+            const int src = (((PPT * j) & 15) + np / G + 16 * q) * 4;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = P[T][i];
+                    float v = P[(PPT * j) >> 4][T][i];
                     asm volatile("" : "+v"(v));      // (hipcc 7.2 otherwise replaces the four moves of a tile by ONE and splats its result)
                     H1[T][j][i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
                 }
@@ -368,19 +398,19 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
         for (int j = 0; j < KT_NT; ++j) {
             const float s = elu1t(C2[j][0]) * KT_TAB(KT_R3, 0) + elu1t(C2[j][1]) * KT_TAB(KT_R3, 1);      // features 0..7 = registers 0, 1 of the four groups
             score[j] = (mask[j] == 0.0f ? -1e9f : lanes_q_sum(s) + W.r3_b) + 0.0f * mask[j];              // masked_fill(mask == 0, -1e9)  (:115); NaN mask = poisoned row
+            if (dead) score[j] = -__builtin_inff();                                                       // no such view: weight exactly 0 in the soft-max
         }
     }
 
     // ---------------------------------------------------------------- softmax over views, colour (:116-117)
 #pragma unroll
     for (int j = 0; j < KT_NT; ++j) {
-        float mx = fmaxf(score[j], dpp_move<0xB1, 0xF>(score[j], score[j]));
-        mx = fmaxf(mx, dpp_move<0x4E, 0xF>(mx, mx));
+        const float mx = group_max<G>(score[j]);
         const float e = hw_exp(score[j] - mx);
-        const float den = quad_sum(e);
-        const float col = quad_sum(rgbc[j] * e) / den;
-        const int64_t pt = first + 4 * j + (np >> 2);
-        if ((np & 3) == 0 && q < 3 && pt < n) {
+        const float den = group_sum<G>(e);
+        const float col = group_sum<G>(rgbc[j] * e) / den;
+        const int64_t pt = first + PPT * j + np / G;
+        if ((np % G) == 0 && q < 3 && pt < n) {
             const int64_t dst = index ? index[pt] : pt;
             rgb_out[3 * dst + q] = col;
         }
@@ -394,32 +424,19 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
 
 int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels);
 
-// number of float4-per-lane groups of the weight stream (without the two zero groups the kernel reads ahead)
-extern "C" int gens_blend_views4_groups(int n_levels) {
+// number of float4-per-lane groups of the weight stream (without the two zero groups the kernel reads ahead); the same for every view count
+extern "C" int gens_blend_views_t_groups(int n_levels) {
     if (n_levels < 1 || n_levels > 5) return 0;
     const int xq = n_levels + 1, xt = (xq + 3) / 4;
     return 1 + xt + 4 * ((2 * xq + 3) / 4) + 4 * ((xq + 3) / 4) + 2 * 4 + 2 * 2 + 2 * 2 + 2 * 2 + 3 + 1;
 }
+extern "C" int gens_blend_views4_groups(int n_levels) { return gens_blend_views_t_groups(n_levels); }
 
-extern "C" int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
-                                 const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
-                                 const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
-    MapSet fs;
-    GENS_CHECK_ARG(feats && wstream && tab && scalars, GENS_EINVAL, "gens_blend_views4: null table");
-    if (int e = gens_fill_maps("gens_blend_views4", &fs, feats, hw, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels <= 5, GENS_ELIMIT, "gens_blend_views4: at most 5 feature levels (d_feature <= 20), got %d", n_levels);
-    GENS_CHECK_ARG(nv == 5, GENS_ELIMIT, "gens_blend_views4: built for four source views (nv = 5), got nv=%d (use gens_blend_views)", nv);
-    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_blend_views4: null camera / image pointer");
-    GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_blend_views4: the weight stream must be 16-byte aligned");
-    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_views4: null pts / output");
-    if (n == 0) return 0;
-    BlendTWeights W;
-    W.stream = (const float4*)wstream;
-    W.tab = tab;
-    W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
-    const unsigned grid = gens_blocks(n, 16);
-    hipStream_t st = (hipStream_t)stream;
-#define BLEND_LAUNCH(NL) blend_t_k<NL><<<grid, 64, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out)
+template <int S>
+static void blend_t_launch(int n_levels, unsigned grid, hipStream_t st, const BlendTWeights& W, const MapSet& fs, const float* imgs, const float* w2c,
+                           const float* intr, const float* c2w, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
+                           float* rgb_out, uint8_t* vis_out) {
+#define BLEND_LAUNCH(NL) blend_t_k<NL, S><<<grid, 64, 0, st>>>(W, fs, (const float4*)imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out)
     switch (n_levels) {
         case 1: BLEND_LAUNCH(1); break;
         case 2: BLEND_LAUNCH(2); break;
@@ -428,5 +445,35 @@ extern "C" int gens_blend_views4(const float* const* feats, const int* hw, int n
         default: BLEND_LAUNCH(5); break;
     }
 #undef BLEND_LAUNCH
-    return gens_launch_status("gens_blend_views4");
+}
+
+extern "C" int gens_blend_views_t(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                  const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
+                                  const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats && wstream && tab && scalars, GENS_EINVAL, "gens_blend_views_t: null table");
+    if (int e = gens_fill_maps("gens_blend_views_t", &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels <= 5, GENS_ELIMIT, "gens_blend_views_t: at most 5 feature levels (d_feature <= 20), got %d", n_levels);
+    GENS_CHECK_ARG(nv >= 3 && nv <= 5, GENS_ELIMIT, "gens_blend_views_t: built for two to four source views (nv = 3..5), got nv=%d (use gens_blend_views)", nv);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_blend_views_t: null camera / image pointer");
+    GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_blend_views_t: the weight stream must be 16-byte aligned");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_views_t: null pts / output");
+    if (n == 0) return 0;
+    BlendTWeights W;
+    W.stream = (const float4*)wstream;
+    W.tab = tab;
+    W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
+    hipStream_t st = (hipStream_t)stream;
+    if (nv == 3) blend_t_launch<2>(n_levels, gens_blocks(n, 32), st, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out);
+    else if (nv == 4) blend_t_launch<3>(n_levels, gens_blocks(n, 16), st, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out);
+    else blend_t_launch<4>(n_levels, gens_blocks(n, 16), st, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out);
+    return gens_launch_status("gens_blend_views_t");
+}
+
+// (ABI version 4 name: four source views only)
+extern "C" int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                 const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
+                                 const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
+    GENS_CHECK_ARG(nv == 5, GENS_ELIMIT, "gens_blend_views4: built for four source views (nv = 5), got nv=%d (use gens_blend_views_t / gens_blend_views)", nv);
+    return gens_blend_views_t(feats, hw, n_levels, imgs, w2c, intr, c2w, nv, wstream, tab, scalars, pts, index, n, n_device, rgb_out, vis_out, stream);
 }

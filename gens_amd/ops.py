@@ -1459,7 +1459,7 @@ def _pad32(b):
 
 
 def _pack_blend_t(layers, n_feat):
-    """Weight stream and tables of gens_blend_views4 (k7t_blend.hip).  Activations live in "quad layout" (feature f = 4 kq + q: register
+    """Weight stream and tables of gens_blend_views_t (k7t_blend.hip).  Activations live in "quad layout" (feature f = 4 kq + q: register
     kq of lane group q); an A fragment of (M tile T, group g of four K quads) holds for lane (m, qk) and j = 0..3 the weight
     W[16 T + 4 (m & 3) + (m >> 2)][slot 16 g + 4 j + qk], so that accumulator register i of lane group q is output feature 4 (4 T + i) + q.
     `layers`: dict name -> (weight, bias).  Returns (stream (G + 2, 64, 4), tab (entries, 4, 8)); the two trailing groups are zero."""
@@ -1557,7 +1557,7 @@ class BlendPlan:
             self.finite = bool(torch.stack([torch.isfinite(p.detach()).all() for p in net.parameters()]).all())
             self.t_stream, self.t_tab = _pack_blend_t(dict(rd1=rd1, rd2=rd2, b1=b1, b2=b2, v1=v1, v2=v2, u1=u1, u2=u2, r1=r1, r2=r2, r3=r3),
                                                       self.n_feat)
-            assert self.t_stream.shape[0] == L.load().gens_blend_views4_groups((self.n_feat - 3) // 4) + 2
+            assert self.t_stream.shape[0] == L.load().gens_blend_views_t_groups((self.n_feat - 3) // 4) + 2
         self.table = L.ptr_table(self.tensors)
         self.key = BlendPlan.version(net)
 
@@ -1579,8 +1579,8 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
     f = plan.n_feat
     flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
     nbytes = n * (12 + 12 + s + (8 if idx is not None else 0))
-    if s == 4 and os.environ.get("GENS_BLEND_ROWMAJOR") is None:       # four source views: the transposed kernel (k7t_blend.hip)
-        L.call("gens_blend_views4", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16),
+    if 2 <= s <= 4 and os.environ.get("GENS_BLEND_ROWMAJOR") is None:  # two to four source views: the transposed kernel (k7t_blend.hip)
+        L.call("gens_blend_views_t", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16),
                L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), views.nv, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts),
                L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(),
                live=None if count is None else (count, n), nbytes=nbytes, flops=n * flops, label="gens_blend_views")

@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 4 */
+int gens_abi_version(void);   /* 5 */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -337,13 +337,20 @@ int gens_blend_views(const float* const* feats, const int* hw, int n_levels, con
                      const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out,
                      void* stream);
 
-/* gens_blend_views for FOUR source views (nv = 5, the shipped configuration) in the transposed dataflow of gens_sdf_value
- * (k7t_blend.hip): one wavefront owns 64 (point, view) rows, the weights are the A operand of v_mfma_f32_16x16x4_f32, the activations of
- * the eleven layers stay in registers in "quad layout", the mean / variance columns of base_fc.0 are multiplied once per point.
- * Same inputs and outputs as gens_blend_views except the weights:
- *   wstream: DEVICE, 16-byte aligned, (gens_blend_views4_groups(n_levels) + 2) x 1 KB: A fragments in consumption order
+/* gens_blend_views for TWO, THREE or FOUR source views (nv = 3, 4, 5: the view counts of the shipped configurations -- num_src_view = 2
+ * in the test protocol and the fine-tune configs, confs/gens.conf:24, confs/gens_finetune.conf:15; 4 in training, confs/gens.conf:9) in
+ * the transposed dataflow of gens_sdf_value (k7t_blend.hip): one wavefront owns 64 (point, view) rows (three views: 48 + 16 dead rows),
+ * the weights are the A operand of v_mfma_f32_16x16x4_f32, the activations of the eleven layers stay in registers in "quad layout", the
+ * mean / variance columns of base_fc.0 are multiplied once per point.
+ * Same inputs and outputs as gens_blend_views except the weights (the same stream for every view count):
+ *   wstream: DEVICE, 16-byte aligned, (gens_blend_views_t_groups(n_levels) + 2) x 1 KB: A fragments in consumption order
  *   (gens_amd.ops._pack_blend_t), the two trailing groups zero;  tab: DEVICE (10, 4, 8) float32: accumulator-layout biases and the
- *   three single-output rows per lane group;  scalars: HOST float[4] as gens_blend_views. */
+ *   three single-output rows per lane group;  scalars: HOST float[4] as gens_blend_views.
+ * gens_blend_views4 / gens_blend_views4_groups: the ABI-4 names (nv = 5 only). */
+int gens_blend_views_t(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                       const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
+                       const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
+int gens_blend_views_t_groups(int n_levels);
 int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
                       const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
                       const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
