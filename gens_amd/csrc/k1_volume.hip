@@ -978,6 +978,7 @@ extern "C" int gens_volume_build_bwd_tiled(const float* feat, const float* w2c, 
                                            int64_t scratch_bytes, void* stream) {
     if (int e = check_volume_args("gens_volume_build_bwd_tiled", feat, w2c, intr, nv, h, w, d)) return e;
     GENS_CHECK_ARG(g_volume && g_feat && scratch, GENS_EINVAL, "gens_volume_build_bwd_tiled: null buffer");
+    GENS_CHECK_ARG(((uintptr_t)feat & 15) == 0, GENS_EINVAL, "gens_volume_build_bwd_tiled: the texels are read as float4 and must be 16-byte aligned");
     const int64_t need = gens_volume_build_bwd_scratch_bytes(nv, h, w, d);
     GENS_CHECK_ARG(need > 0, GENS_ELIMIT, "gens_volume_build_bwd_tiled: d=%d must be a multiple of 16 (image %d x %d, %d views): use gens_volume_build_bwd", d, h, w, nv);
     GENS_CHECK_ARG(scratch_bytes >= need && ((uintptr_t)scratch & 15) == 0, GENS_EINVAL,

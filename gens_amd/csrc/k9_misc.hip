@@ -294,14 +294,16 @@ __global__ __launch_bounds__(TV_BLOCK) void tv_bwd4_k(const float* __restrict__ 
     }
 }
 
-static bool tv_vectorised(int x, int y, int z) {
-    return (z & 3) == 0 && (int64_t)x * y * z < ((int64_t)1 << 31) && !getenv("GENS_TV_SCALAR");     // (the switch keeps the scalar kernels reachable for A/B tests)
+// the float4 kernels need 16-byte aligned planes (a view carved out of a flat buffer at an odd offset takes the scalar kernels)
+static bool tv_vectorised(int x, int y, int z, const void* a, const void* b, const void* c = nullptr) {
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+    return aligned && (z & 3) == 0 && (int64_t)x * y * z < ((int64_t)1 << 31) && !getenv("GENS_TV_SCALAR");     // (the switch keeps the scalar kernels reachable for A/B tests)
 }
 
 extern "C" int gens_tv_fwd(const float* vol, const float* mask, int x, int y, int z, float* partial, void* stream) {
     GENS_CHECK_ARG(vol && mask && partial && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_fwd: bad argument");
     int64_t n = (int64_t)x * y * z;
-    if (tv_vectorised(x, y, z)) {   // same number of partial blocks as the scalar kernel (gens_tv_blocks): the tail blocks write zeros
+    if (tv_vectorised(x, y, z, vol, mask)) {   // same number of partial blocks as the scalar kernel (gens_tv_blocks): the tail blocks write zeros
         tv_fwd4_k<<<gens_blocks(n, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, (float4*)partial);
         return gens_launch_status("gens_tv_fwd");
     }
@@ -312,7 +314,7 @@ extern "C" int gens_tv_fwd(const float* vol, const float* mask, int x, int y, in
 extern "C" int gens_tv_bwd(const float* vol, const float* mask, int x, int y, int z, float coef, float* g_vol, void* stream) {
     GENS_CHECK_ARG(vol && mask && g_vol && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_bwd: bad argument");
     int64_t n = (int64_t)x * y * z;
-    if (tv_vectorised(x, y, z)) {
+    if (tv_vectorised(x, y, z, vol, mask, g_vol)) {
         tv_bwd4_k<<<gens_blocks(n / 4, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, nullptr, g_vol);
         return gens_launch_status("gens_tv_bwd");
     }
@@ -324,7 +326,7 @@ extern "C" int gens_tv_bwd_scaled(const float* vol, const float* mask, int x, in
                                   void* stream) {
     GENS_CHECK_ARG(vol && mask && coef_dev && g_vol && x > 0 && y > 0 && z > 0, GENS_EINVAL, "gens_tv_bwd_scaled: bad argument");
     int64_t n = (int64_t)x * y * z;
-    if (tv_vectorised(x, y, z)) {
+    if (tv_vectorised(x, y, z, vol, mask, g_vol)) {
         tv_bwd4_k<<<gens_blocks(n / 4, TV_BLOCK), TV_BLOCK, 0, (hipStream_t)stream>>>(vol, mask, x, y, z, coef, coef_dev, g_vol);
         return gens_launch_status("gens_tv_bwd_scaled");
     }

@@ -92,6 +92,15 @@ class Shard:
             return torch.cat([self._sink[key][r] for r in range(self.world)], 0)
         return gather_rows(local, n_total, self.group)
 
+    def any(self, flag):
+        """True on every rank if `flag` is true on any rank (one tiny all-reduce); the single-process stand-in has nobody to ask."""
+        if self._sink is not None or self.world == 1:
+            return bool(flag)
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0)
+
     def chunks(self, n_chunks):
         """Lattice chunks of this rank: chunk index mod world."""
         return list(range(self.rank, n_chunks, self.world))
@@ -120,18 +129,33 @@ def allreduce_gradients(params, group=None, average=True):
     params = [p for p in params if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    _check_uniform(params)
+    # one presence flag per parameter rides at the end of the same buffer: a parameter whose gradient is None on EVERY rank keeps None
+    # (Adam skips it, as it does on one GPU and under the reference's DDP); one that any rank produced becomes dense everywhere
+    present = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=params[0].dtype, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [present])
     dist.all_reduce(flat, group=group)
+    n = flat.numel() - len(params)
+    seen = (flat[n:] > 0).tolist()
     if average:
-        flat /= dist.get_world_size(group)
+        flat[:n] /= dist.get_world_size(group)
     off = 0
-    for p in params:
+    for p, any_rank in zip(params, seen):
         g = flat[off:off + p.numel()].reshape(p.shape)
+        off += p.numel()
+        if not any_rank:
+            continue
         if p.grad is None:
             p.grad = g.clone()
         else:
             p.grad.copy_(g)
-        off += p.numel()
+
+
+def _check_uniform(params):
+    p0 = params[0]
+    for p in params:
+        if p.dtype != p0.dtype or p.device != p0.device:
+            raise ValueError(f"gradient exchange needs parameters of one dtype on one device: got {p.dtype} on {p.device} next to {p0.dtype} on {p0.device}")
 
 
 class FlatGradients:
@@ -146,6 +170,9 @@ class FlatGradients:
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradients: no parameter requires a gradient")
+        _check_uniform(self.params)
         self.group = group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = sum(p.numel() for p in self.params)
@@ -185,3 +212,38 @@ class FlatGradients:
             dist.all_reduce(self.flat, group=self.group)
             if average:
                 self.flat /= world
+
+
+def optim_tensors(param_groups):
+    """The tensors of Adam-style parameter groups ({"params": tensor or list, ...}, GenS.get_optim_params) in group order."""
+    out = []
+    for g in param_groups:
+        ps = g["params"]
+        out += [ps] if isinstance(ps, torch.Tensor) else list(ps)
+    return out
+
+
+class FinetuneStepper:
+    """One data-parallel fine-tune step after another (BASELINE config 5; the loop it replaces: runner.py:294-316 with the model wrapped in
+    DDP, :102-105): every rank renders ITS rays of the same scene, the gradients of the volume pyramid and the MLPs meet in the flat
+    buffer (FlatGradients: reduce_scatter + all_gather over RCCL), every rank takes the same optimiser step.
+
+        stepper = FinetuneStepper(model, optimizer, loss_fn)          # after model.init_volumes(...) and get_optim_params(...)
+        loss = stepper.step(ipts, cos_anneal_ratio, step)             # ipts: this rank's rays of the step
+
+    Differences from DDP, both documented behaviour: gradients are dense (a parameter a step does not touch gets zeros, not None -- with
+    Adam its moments decay instead of standing still; under DDP without find_unused_parameters such a step is an error), and they must be
+    cleared with FlatGradients.zero(), which step() does."""
+
+    def __init__(self, model, optimizer, loss_fn, group=None):
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.flat = FlatGradients(optim_tensors(optimizer.param_groups), group)
+
+    def step(self, ipts, cos_anneal_ratio=1.0, step=None):
+        self.flat.zero()
+        outputs = self.model("finetune", ipts, cos_anneal_ratio=cos_anneal_ratio, step=step)
+        loss = self.loss_fn(outputs, ipts)
+        loss.backward()
+        self.flat.sync()
+        self.optimizer.step()
+        return loss.detach(), outputs

@@ -90,7 +90,13 @@ def reference_jitter(n_rays, chunk=REFERENCE_CHUNK):
 
 class JitterStream:
     """reference_jitter() produced group by group on a helper thread, so the ~4 M host RNG draws of a 480x640 image overlap
-    with GPU work instead of preceding it.  Only this thread touches the default CPU generator while it runs."""
+    with GPU work instead of preceding it.
+
+    RESTRICTION (it is what keeps the draw order equal to the reference's): while the thread runs, nothing else may draw from the default
+    CPU generator -- no torch.rand / randint on the main thread, no in-process dataset sampling (DataLoader workers are separate
+    processes and are fine).  validate() joins the thread before it returns; a driver that uses prefetch_jitter() must not interleave a
+    TRAINING render (whose pts_random / t_rand come from the same generator, implicit_surface.py:256,362) between two validations
+    without joining first -- ImplicitSurface.render() does that join itself when a prefetch is pending."""
 
     def __init__(self, n_rays, group, buf=None):
         """buf: optional (n_rays, 1) host buffer to fill -- a page-locked one makes the per-chunk upload asynchronous."""
@@ -178,8 +184,12 @@ class ImplicitSurface(nn.Module):
             self._blend_plan = ops.BlendPlan(net)
         return self._blend_plan if self._blend_plan.n_feat == 3 + 4 * len(views.feat_tex) else None
 
-    def _precision(self, plan):
-        return "f16x2" if (self.sdf_precision == "f16x2" and getattr(plan, "f16_ok", False)) else "f32"
+    def _precision(self, plan, want_grad=False):
+        """The arithmetic of one SDF launch.  The split-half VALUE kernel pre-scales its weight stream by 100 / ln 2, so it has its own range
+        condition (plan.value_ok: |w|, |b| below ~416); a network that fails it is evaluated in float32, it does not raise."""
+        if self.sdf_precision != "f16x2":
+            return "f32"
+        return "f16x2" if getattr(plan, "f16_ok" if want_grad else "value_ok", False) else "f32"
 
     def _train_net(self, scene, lean=False):
         """This step's fused SDF evaluator (ops.SdfTrainStep: the effective weights packed once for the sampling passes, render_core
@@ -268,7 +278,7 @@ class ImplicitSurface(nn.Module):
             idx, count = ops.compact_valid(valid)
             sdf = torch.full((b * n, 1), 100.0, device=dev)
             gradients = torch.zeros(b * n, 3, device=dev)
-            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan), count=count)
+            ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan, True), count=count)
             smooth = None
             sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx, count=count)
         else:
@@ -277,7 +287,7 @@ class ImplicitSurface(nn.Module):
             if plan is not None:                       # fused look-up + MLP + d/dx, scattered straight into the dense arrays
                 sdf = torch.full((b * n, 1), 100.0, device=dev)
                 gradients = torch.zeros(b * n, 3, device=dev)
-                ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan))
+                ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan, True))
                 smooth = None
             else:
                 if lean:
@@ -386,6 +396,9 @@ class ImplicitSurface(nn.Module):
         z_vals = z_vals.expand(b, self.n_samples)
         if self.perturb > 0:
             if t_rand is None:
+                pending = getattr(self, "_jitter_ahead", None)
+                if pending is not None:                                                     # a prefetch for the next validate() is drawing:
+                    pending[1].join()                                                       # one thread at a time on the generator
                 t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
             z_vals = z_vals + (t_rand.to(dev, non_blocking=True) - 0.5) * 2.0 / self.n_samples
         z_vals = z_vals.contiguous()
@@ -421,7 +434,10 @@ class ImplicitSurface(nn.Module):
                     u[k, :count] = -sdf[:, 0]
                 else:
                     u[first:first + count] = -sdf[:, 0]
-            if split_half is False or not self._split_half_overflowed():
+            overflowed = split_half is not False and self._split_half_overflowed()
+            if shard is not None and split_half is not False and self.sdf_precision == "f16x2":
+                overflowed = shard.any(overflowed)
+            if not overflowed:
                 break
             split_half = False
         if shard is not None:
@@ -483,7 +499,10 @@ class ImplicitSurface(nn.Module):
         render_image()
         if jitter is not None:
             jitter.join()
-        if self._split_half_overflowed():              # a value left the half range: the same image, same jitter, in float32
+        overflowed = self._split_half_overflowed()
+        if shard is not None and self.sdf_precision == "f16x2":
+            overflowed = shard.any(overflowed)         # every rank re-renders or none does: the gathered image never mixes precisions
+        if overflowed:                                 # a value left the half range: the same image, same jitter, in float32
             saved, self.sdf_precision = self.sdf_precision, "f32"
             try:
                 render_image()
@@ -528,7 +547,9 @@ class ImplicitSurface(nn.Module):
         pending = getattr(self, "_jitter_ahead", None)
         if pending is not None:
             pending[1].join()                          # one image ahead at most; the generator is used by one thread at a time
-        self._jitter_ahead = (n_rays, JitterStream(n_rays, self.val_chunk, torch.empty(n_rays, 1, dtype=torch.float32, pin_memory=True)))
+        # two page-locked buffers take turns: the image being rendered reads one while the next image's draws fill the other
+        self._jitter_parity = 1 - getattr(self, "_jitter_parity", 0)
+        self._jitter_ahead = (n_rays, JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter_ahead%d" % self._jitter_parity)))
 
     def _take_prefetched_jitter(self, n_rays):
         pending = getattr(self, "_jitter_ahead", None)

@@ -157,7 +157,7 @@ def _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol):
     need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d) if tiled else 0
     if need > 0:
         scratch = torch.empty(need, device=g.device, dtype=torch.uint8)
-        L.call("gens_volume_build_bwd_tiled", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
+        L.call("gens_volume_build_bwd_tiled", L.ptr(aligned16(feat_tex), align=16), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
                L.ptr(scratch, torch.uint8), need, L.stream(), nbytes=nbytes, label="gens_volume_build_bwd")
     else:
         L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),

@@ -28,6 +28,19 @@ ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_mlp_h_k": "gens_sdf_mlp_f16", "sdf_va
          "tv_bwd4_k": "gens_tv_bwd", "lookup_feature_bwd_k": "gens_lookup_feature_bwd", "mc_classify4_k": "gens_mc_classify"}
 
 
+def kernel_source_hash():
+    """sha1 over the HIP sources of the library: a traffic file is only quoted by bench.py for the tree it was measured on."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gens_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def collect(root, counter):
     tot, disp = defaultdict(float), defaultdict(set)
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
@@ -66,7 +79,7 @@ def main():
             "KB x 1024; launch-weighted mean over the kernel's template instances; corrected = 2 x FETCH + WRITE "
             "(MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reports half of wide coalesced reads; 16-B gathers uncalibrated, so the "
             "corrected figure is an upper estimate there); Infinity-Cache hits are counted")
-    json.dump({"_note": note, "kernels": res}, open(out, "w"), indent=1)
+    json.dump({"_note": note, "kernel_source_hash": kernel_source_hash(), "kernels": res}, open(out, "w"), indent=1)
     for e, r in res.items():
         print(f"{e:24s} fetch {r['fetch_bytes_per_launch_raw'] / 1e6:9.2f} MB  write {r['write_bytes_per_launch_raw'] / 1e6:9.2f} MB  corrected {r['traffic_bytes_per_launch_corrected'] / 1e6:9.2f} MB  x{r['launches']}")
 

@@ -12,11 +12,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "forks_before_gpu: forks worker processes; ordered before every test that initialises the GPU")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    if torch.cuda.is_available():
+    # tests that FORK worker processes must run before anything in this process touches the GPU (HIP does not survive a fork, and a process
+    # that has initialised the GPU must not start another program): they go first, and the check below only counts devices, which does not
+    # initialise anything
+    items.sort(key=lambda item: 0 if "forks_before_gpu" in item.keywords else 1)
+    if torch.cuda.device_count() > 0:
         return
     skip = pytest.mark.skip(reason="no GPU in this process")
     for item in items:

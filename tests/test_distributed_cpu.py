@@ -109,7 +109,9 @@ def _worker_flat(rank, world, port, q):
         a.grad = torch.full((3,), float(rank + 1))
         if rank == 0:
             b.grad = torch.full((2,), 4.0)
-        D.allreduce_gradients([a, b])
+        never = torch.nn.Parameter(torch.zeros(4))                            # no rank has a gradient for it: it must keep None (Adam skips it)
+        D.allreduce_gradients([a, never, b])
+        assert never.grad is None
         if rank == 0:
             q.put(tuple(t.detach().numpy().copy() for t in (vols[0].grad, vols[1].grad, w.grad, unused.grad, lattice, rows, a.grad, b.grad)))
     finally:
@@ -135,6 +137,15 @@ def test_flat_gradient_exchange_lattice_chunks_and_missing_gradients_gloo():
     assert torch.equal(lattice, torch.arange(5.0)[:, None].expand(5, 4))
     assert torch.equal(rows[:, 0], torch.tensor([0.0, 0, 0, 0, 1, 1, 1]))
     assert torch.allclose(a, torch.full_like(a, 1.5)) and torch.allclose(b, torch.full_like(b, 2.0))
+
+
+def test_gradient_exchange_rejects_empty_and_mixed_parameter_lists():
+    with pytest.raises(ValueError, match="no parameter"):
+        D.FlatGradients([torch.nn.Parameter(torch.zeros(3), requires_grad=False)])
+    with pytest.raises(ValueError, match="one dtype"):
+        D.FlatGradients([torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))])
+    groups = [{"params": [torch.nn.Parameter(torch.zeros(2))], "lr": 1.0}, {"params": torch.nn.Parameter(torch.zeros(3)), "lr": 2.0}]
+    assert [t.numel() for t in D.optim_tensors(groups)] == [2, 3]
 
 
 def test_single_process_shard_stand_in_collects_in_rank_order():
