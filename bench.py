@@ -327,12 +327,22 @@ def main():
 
     secondary = world == 1 and not args.headline_only
     # secondary figure (N = 1): the headline step at the SHIPPED level count (confs/gens.conf:63-67: five volume levels, sdf_mlp_k<100>)
-    levels5 = None
+    levels5 = views3 = None
     if secondary and args.sdf_precision == "f32" and len(args.dims) == 3:
         try:
             levels5 = five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final)
         except Exception as e:
             levels5 = {"error": f"{type(e).__name__}: {e}"}
+        # ... and the DTU TEST protocol as shipped (confs/gens.conf:17-30, BASELINE config[3] on one GPU): num_src_view = 2 -> three views,
+        # five levels; the blending kernel runs its S = 2 instantiation
+        try:
+            views3 = five_level_variant(args, dev, sc, [f[:3].contiguous() for f in feats], imgs[:3].contiguous(), intrs[:3].contiguous(),
+                                        c2ws[:3].contiguous(), near, far, rays_o, rays_d, n_final, kernels=True)
+            views3["views"] = 3
+            views3["note"] = ("the shipped test protocol: num_src_view = 2 (three views), five volume levels; the blending kernel's S = 2 "
+                              "instantiation (gens_blend_views_t); not the headline")
+        except Exception as e:
+            views3 = {"error": f"{type(e).__name__}: {e}"}
 
     # secondary figures (N = 1): TRAINING steps of BASELINE config[2] / config[4] shape -- 5 views 480x640, volume_dims [256, 128, 64], 512 rays
     # + 2048 pseudo points, a reference-like loss, backward through every kernel, Adam (scripts/train_step_bench.py):
@@ -348,11 +358,13 @@ def main():
             from scripts.train_step_bench import measure
             train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
                                  "points, loss + backward + Adam; 10 timed steps after 3 warm-up each", "note": "secondary figures; not the headline"}
-            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("full", ["--full"])):
+            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"])):
                 ms, _, kt = measure(flags + ["--steps", "10", "--warm", "3"], quiet=True, kernels=True)
                 train[key] = {"ms_per_step": round(ms, 2), "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "hip_kernels": kernel_rows(kt, 8)}
                 train[key]["roofline"] = kernel_roofline(kt)
                 torch.cuda.empty_cache()
+            train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "
+                                                  "volume_dims 256/128/64/32/16 as parameters, 512 rays + 2048 pseudo points")
             train["ms_per_step"] = train["full"]["ms_per_step"]
         except Exception as e:                                             # never let a secondary figure take the headline down
             train = {"error": f"{type(e).__name__}: {e}"}
@@ -378,7 +390,7 @@ def main():
                    "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
                                    if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
-        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "train_step": train, "val_item": val_item,
+        "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "views3": views3, "train_step": train, "val_item": val_item,
         "ray_sharded": ray_sharded,
         "hip_kernels": table,
     }
@@ -452,8 +464,9 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
             "note": "secondary figure of the same run; `python bench.py --gpus N --shard rays` reports it as the headline"}
 
 
-def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final):
-    """The headline step with the shipped five-level pyramid (volume_dims 256 / 128 / 64 / 32 / 16: sdf_mlp_k<100>): 3 timed steps."""
+def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final, kernels=False):
+    """The headline step with the shipped five-level pyramid (volume_dims 256 / 128 / 64 / 32 / 16: sdf_mlp_k<100>): 3 timed steps.
+    kernels: add the C-ABI kernel table of one extra, untimed step (HIP events per launch)."""
     from gens_amd import synthetic
     from gens_amd.models.modules.implicit_surface import Scene
     dims = [256, 128, 64, 32, 16]
@@ -481,8 +494,18 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
     pending = getattr(surf, "_jitter_ahead", None)
     if pending is not None:
         pending[1].join()
-    return {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
-            "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
+    res = {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
+           "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
+    if kernels:
+        from gens_amd import lib as L
+        L.profile_begin()
+        step()
+        torch.cuda.synchronize()
+        res["hip_kernels"] = kernel_rows(L.profile_end(), 4)
+        pending = getattr(surf, "_jitter_ahead", None)
+        if pending is not None:
+            pending[1].join()
+    return res
 
 
 def cpu_baseline(args, surf, sc, vols, masks, n_final):

@@ -1,0 +1,456 @@
+// K19: the step-boundary kernels of a TRAINING step.  A 512-ray step of the reference is ~2 400 PyTorch launches; after K17 / K18 took the
+// networks, ~300 of the ~530 launches left were scalar-sized torch glue around the hot-path kernels (camera inverses through a batched LU,
+// one layout pass per map, fills / index_put around the masked evaluation, the per-level total-variation epilogue, ...), each shorter than
+// its own launch.  The entry points below do that work in one launch each, on the device, without host synchronisation.
+//   gens_scene_setup     torch.inverse(c2ws), the per-level intrinsics, inverse(c2ws[0,:3,:3]), inverse(intrs)[0,:3,:3]
+//                        (volume.py:24-25,34; projector.py:322,364; implicit_surface.py:242,245)
+//   gens_pack_maps       gens_pack_nchw for all maps of a scene (images + feature pyramid);  gens_unpack_maps its adjoint
+//   gens_compact_points  the masked evaluation's index list (implicit_surface.py:121-124,174-177,484-497) for ray samples, random points and
+//                        pseudo points together, with the default values of the unselected rows written in the same launch
+//   gens_tv_levels_*     tv_regularization (implicit_surface.py:135-150) of all levels: partial sums, then one finishing workgroup
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// scene set-up
+// ---------------------------------------------------------------------------------------------------------------
+// Inverse of an N x N row-major float32 matrix: Gauss-Jordan with partial pivoting in float64, rounded once to float32 (within half an
+// ulp of the exact inverse for the well-conditioned camera matrices of the path; torch.inverse's float32 LU is a few ulp away from it on
+// either side).  Returns false for a singular matrix (an exactly zero pivot column, as LAPACK's info > 0) and writes NaN.
+template <int N>
+__device__ bool invert_f64(const float* __restrict__ a, int lda, float* __restrict__ out, int ldo) {
+    double m[N][2 * N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            m[r][c] = (double)a[r * lda + c];
+            m[r][N + c] = r == c ? 1.0 : 0.0;
+        }
+    bool ok = true;
+#pragma unroll
+    for (int col = 0; col < N; ++col) {
+        int piv = col;
+        double best = fabs(m[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < N; ++r)
+            if (fabs(m[r][col]) > best) { best = fabs(m[r][col]); piv = r; }
+        if (!(best > 0.0)) { ok = false; break; }
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (r == piv && piv != col) {
+#pragma unroll
+                for (int c = 0; c < 2 * N; ++c) { const double t = m[col][c]; m[col][c] = m[r][c]; m[r][c] = t; }
+            }
+        const double inv = 1.0 / m[col][col];
+#pragma unroll
+        for (int c = 0; c < 2 * N; ++c) m[col][c] *= inv;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            if (r == col) continue;
+            const double f = m[r][col];
+#pragma unroll
+            for (int c = 0; c < 2 * N; ++c) m[r][c] -= f * m[col][c];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) out[r * ldo + c] = ok ? (float)m[r][N + c] : __builtin_nanf("");
+    return ok;
+}
+
+// cams layout (floats): [w2c nv x 16][ks GENS_MAX_LEVELS x nv x 16][rot_inv 9 (+3 pad)][kinv_ref 9 (+3 pad)][status 1 (int32 bits)]
+extern "C" int64_t gens_scene_cams_floats(int nv) { return (int64_t)nv * 16 * (1 + GENS_MAX_LEVELS) + 12 + 12 + 4; }
+
+__global__ __launch_bounds__(64) void scene_setup_k(const float* __restrict__ c2w, const float* __restrict__ intr, int nv, float* __restrict__ cams) {
+    const int t = threadIdx.x;
+    float* w2c = cams;
+    float* ks = cams + (int64_t)nv * 16;
+    float* rot = ks + (int64_t)GENS_MAX_LEVELS * nv * 16;
+    float* kinv = rot + 12;
+    int* status = (int*)(kinv + 12);
+    if (t == 0) *status = 0;
+    __syncthreads();
+    bool ok = true;
+    if (t < nv) {
+        ok = invert_f64<4>(c2w + 16 * t, 4, w2c + 16 * t, 4);
+        float s = 1.0f;
+        for (int l = 0; l < GENS_MAX_LEVELS; ++l) {               // rows 0-1 times 0.5^l, the product the reference forms per level (Q2)
+            float* k = ks + ((int64_t)l * nv + t) * 16;
+            for (int e = 0; e < 16; ++e) k[e] = e < 8 ? intr[16 * t + e] * s : intr[16 * t + e];
+            s *= 0.5f;
+        }
+    } else if (t == nv) {
+        ok = invert_f64<3>(c2w, 4, rot, 3);                        // inverse(c2ws[0, :3, :3])   (implicit_surface.py:242,245)
+    } else if (t == nv + 1) {
+        float full[16];
+        ok = invert_f64<4>(intr, 4, full, 4);                      // inverse(intrinsics)[0, :3, :3]   (projector.py:364)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) kinv[3 * r + c] = full[4 * r + c];
+    }
+    if (!ok) atomicOr(status, 1);
+}
+
+extern "C" int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream) {
+    GENS_CHECK_ARG(c2ws && intrs && cams, GENS_EINVAL, "gens_scene_setup: null pointer");
+    GENS_CHECK_ARG(nv >= 1 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_scene_setup: nv=%d not in 1..%d", nv, GENS_MAX_VIEWS);
+    scene_setup_k<<<1, 64, 0, (hipStream_t)stream>>>(c2ws, intrs, nv, cams);
+    return gens_launch_status("gens_scene_setup");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// all maps of a scene to texels in one launch (and back)
+// ---------------------------------------------------------------------------------------------------------------
+#define GENS_MAX_MAPS 8
+struct MapPack {
+    const float* src[GENS_MAX_MAPS];
+    float* dst[GENS_MAX_MAPS];
+    int c[GENS_MAX_MAPS];
+    int64_t hw[GENS_MAX_MAPS];
+    int64_t first[GENS_MAX_MAPS + 1];      // first work item of map k (pack: texels n * hw * q4; unpack: floats n * c * hw)
+    int n_maps;
+};
+
+__global__ __launch_bounds__(256) void pack_maps_k(MapPack P) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= P.first[P.n_maps]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GENS_MAX_MAPS; ++j) k += (j < P.n_maps && gid >= P.first[j]) ? 1 : 0;
+    const int64_t i = gid - P.first[k];
+    const int c = P.c[k], q4 = (c + 3) / 4;
+    const int64_t hw = P.hw[k];
+    const int q = (int)(i % q4);
+    const int64_t pix = (i / q4) % hw, img = i / (q4 * hw);
+    const float* s = P.src[k] + (img * c + (int64_t)q * 4) * hw + pix;
+    float4 v;
+    v.x = (q * 4 + 0 < c) ? s[0] : 0.0f;
+    v.y = (q * 4 + 1 < c) ? s[hw] : 0.0f;
+    v.z = (q * 4 + 2 < c) ? s[2 * hw] : 0.0f;
+    v.w = (q * 4 + 3 < c) ? s[3 * hw] : 0.0f;
+    ((float4*)P.dst[k])[i] = v;
+}
+
+__global__ __launch_bounds__(256) void unpack_maps_k(MapPack P) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= P.first[P.n_maps]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GENS_MAX_MAPS; ++j) k += (j < P.n_maps && gid >= P.first[j]) ? 1 : 0;
+    const int64_t i = gid - P.first[k];
+    const int c = P.c[k], cpad = 4 * ((c + 3) / 4);
+    const int64_t hw = P.hw[k];
+    const int64_t pix = i % hw;
+    const int ch = (int)((i / hw) % c);
+    const int64_t img = i / (hw * c);
+    P.dst[k][i] = P.src[k][(img * hw + pix) * cpad + ch];
+}
+
+static int fill_map_pack(const char* who, MapPack* P, const float* const* src, float* const* dst, const int* nchw, int n_maps, bool unpack) {
+    GENS_CHECK_ARG(src && dst && nchw, GENS_EINVAL, "%s: null table", who);
+    GENS_CHECK_ARG(n_maps >= 1 && n_maps <= GENS_MAX_MAPS, GENS_ELIMIT, "%s: %d maps, at most %d", who, n_maps, GENS_MAX_MAPS);
+    P->n_maps = n_maps;
+    P->first[0] = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        const int n = nchw[4 * k], c = nchw[4 * k + 1], h = nchw[4 * k + 2], w = nchw[4 * k + 3];
+        GENS_CHECK_ARG(src[k] && dst[k] && n > 0 && c > 0 && h > 0 && w > 0, GENS_EINVAL, "%s: bad map %d", who, k);
+        GENS_CHECK_ARG(((uintptr_t)(unpack ? (const void*)src[k] : (const void*)dst[k]) & 15) == 0, GENS_EINVAL, "%s: texels of map %d are not 16-byte aligned", who, k);
+        P->src[k] = src[k];
+        P->dst[k] = dst[k];
+        P->c[k] = c;
+        P->hw[k] = (int64_t)h * w;
+        P->first[k + 1] = P->first[k] + (unpack ? (int64_t)n * c * h * w : (int64_t)n * h * w * ((c + 3) / 4));
+    }
+    for (int k = n_maps; k < GENS_MAX_MAPS; ++k) { P->src[k] = nullptr; P->dst[k] = nullptr; P->c[k] = 1; P->hw[k] = 1; P->first[k + 1] = P->first[n_maps]; }
+    return 0;
+}
+
+extern "C" int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream) {
+    MapPack P;
+    if (int e = fill_map_pack("gens_pack_maps", &P, src, dst, nchw, n_maps, false)) return e;
+    pack_maps_k<<<gens_blocks(P.first[n_maps], 256), 256, 0, (hipStream_t)stream>>>(P);
+    return gens_launch_status("gens_pack_maps");
+}
+
+extern "C" int gens_unpack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream) {
+    MapPack P;
+    if (int e = fill_map_pack("gens_unpack_maps", &P, src, dst, nchw, n_maps, true)) return e;
+    unpack_maps_k<<<gens_blocks(P.first[n_maps], 256), 256, 0, (hipStream_t)stream>>>(P);
+    return gens_launch_status("gens_unpack_maps");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the index list of a step's masked evaluation, in ONE launch of one workgroup
+// ---------------------------------------------------------------------------------------------------------------
+// rows [0, n0): ray samples, flags from gens_ray_points (no flag set -> the first min(10, n0) rows, Q7);
+// rows [n0, n0 + n1): always selected (the 1 024 random points, implicit_surface.py:256-257);
+// rows [n0 + n1, n): pseudo points with their own flags (:484-497; none set -> counts[2] = 0 and the caller raises).
+// idx: the selected rows in increasing order; counts = {all selected, selected ray samples, selected pseudo points}.
+#define CP_THREADS 1024
+__global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __restrict__ valid, int64_t n0, int64_t n1, int64_t n,
+                                                                int64_t* __restrict__ idx, int32_t* __restrict__ counts) {
+    __shared__ int wave_tot[CP_THREADS / 64];
+    __shared__ int seg_tot[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t per = (n + CP_THREADS - 1) / CP_THREADS;
+    const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
+    // pass 1: flags set in the ray segment / in the pseudo segment
+    int c0 = 0, c2 = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const bool v = valid[i] != 0;
+        c0 += (i < n0 && v) ? 1 : 0;
+        c2 += (i >= n0 + n1 && v) ? 1 : 0;
+    }
+    float f0 = wave_sum((float)c0), f2 = wave_sum((float)c2);      // (counts < 2^24: exact in float32)
+    if (t == 0) { seg_tot[0] = 0; seg_tot[1] = 0; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&seg_tot[0], (int)f0); atomicAdd(&seg_tot[1], (int)f2); }
+    __syncthreads();
+    const bool rescue = seg_tot[0] == 0;
+    const int64_t n_rescue = min((int64_t)10, n0);
+    // pass 2: selection with the rescue rule, exclusive scan over the threads, ordered write
+    int mine = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const bool sel = i < n0 ? (rescue ? i < n_rescue : valid[i] != 0) : (i < n0 + n1 ? true : valid[i] != 0);
+        mine += sel ? 1 : 0;
+    }
+    float inc = wave_scan_add((float)mine, lane);
+    if (lane == 63) wave_tot[wv] = (int)inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += wave_tot[k];
+    int64_t pos = base + (int)inc - mine;
+    for (int64_t i = lo; i < hi; ++i) {
+        const bool sel = i < n0 ? (rescue ? i < n_rescue : valid[i] != 0) : (i < n0 + n1 ? true : valid[i] != 0);
+        if (sel) idx[pos++] = i;
+    }
+    if (t == CP_THREADS - 1) {
+        counts[0] = base + (int)inc;
+        counts[1] = rescue ? (int)n_rescue : seg_tot[0];
+        counts[2] = seg_tot[1];
+    }
+}
+
+extern "C" int gens_compact_points(const uint8_t* valid, int64_t n_rays_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
+                                   void* stream) {
+    GENS_CHECK_ARG(valid && idx && counts, GENS_EINVAL, "gens_compact_points: null pointer");
+    GENS_CHECK_ARG(n_rays_pts >= 0 && n_always >= 0 && n_rays_pts + n_always <= n && n < ((int64_t)1 << 24), GENS_EINVAL,
+                   "gens_compact_points: bad segment sizes (%lld, %lld of %lld; fewer than 2^24 rows)", (long long)n_rays_pts, (long long)n_always, (long long)n);
+    compact_points_k<<<1, CP_THREADS, 0, (hipStream_t)stream>>>(valid, n_rays_pts, n_always, n, idx, counts);
+    return gens_launch_status("gens_compact_points");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// total-variation regulariser of all levels (implicit_surface.py:135-150; Q13)
+// ---------------------------------------------------------------------------------------------------------------
+#define TVL_BLOCK 256
+struct TvLevels {
+    const float* vol[GENS_MAX_LEVELS];
+    const float* mask[GENS_MAX_LEVELS];
+    float* g_vol[GENS_MAX_LEVELS];
+    int X[GENS_MAX_LEVELS], Y[GENS_MAX_LEVELS], Z[GENS_MAX_LEVELS];
+    int first_block[GENS_MAX_LEVELS + 1];
+    int n;
+};
+
+// one thread owns FOUR consecutive z of one (x, y) row (k9_misc.hip::tv_fwd4_k, same arithmetic and order per voxel)
+__device__ __forceinline__ float4 tv_fwd4_thread(const float* __restrict__ vol, const float* __restrict__ mask, int X, int Y, int Z, uint32_t t) {
+    const uint32_t n = (uint32_t)X * Y * Z, q = n >> 2;
+    float4 acc = f4_zero();
+    if (t >= q) return acc;
+    const uint32_t i = t << 2, zq = (uint32_t)Z >> 2;
+    const uint32_t kz = (t % zq) << 2, row = t / zq, jy = row % (uint32_t)Y, ix = row / (uint32_t)Y;
+    const uint32_t sx = (uint32_t)Y * Z, sy = (uint32_t)Z;
+    const bool hx = ix + 1 < (uint32_t)X, hy = jy + 1 < (uint32_t)Y, hz = kz + 4 < (uint32_t)Z;
+    const float4 m = *(const float4*)(mask + i);
+    const float4 mxv = hx ? *(const float4*)(mask + i + sx) : f4_zero();
+    const float4 myv = hy ? *(const float4*)(mask + i + sy) : f4_zero();
+    const float mzn = hz ? mask[i + 4] : 0.0f;
+    const float mm[4] = {m.x, m.y, m.z, m.w}, mxa[4] = {mxv.x, mxv.y, mxv.z, mxv.w}, mya[4] = {myv.x, myv.y, myv.z, myv.w};
+    const float mza[4] = {m.y, m.z, m.w, mzn};
+    bool bx[4], by[4], bz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bx[k] = hx && (mm[k] * mxa[k] > 0.0f);
+        by[k] = hy && (mm[k] * mya[k] > 0.0f);
+        bz[k] = (k < 3 || hz) && (mm[k] * mza[k] > 0.0f);
+        acc.w += bx[k] ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* v = vol + (size_t)c * n + i;
+        const float4 v0 = *(const float4*)v;
+        const float4 vx = hx ? *(const float4*)(v + sx) : f4_zero();
+        const float4 vy = hy ? *(const float4*)(v + sy) : f4_zero();
+        const float vzn = hz ? v[4] : 0.0f;
+        const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, ax[4] = {vx.x, vx.y, vx.z, vx.w}, ay[4] = {vy.x, vy.y, vy.z, vy.w};
+        const float az[4] = {v0.y, v0.z, v0.w, vzn};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (bx[k]) { const float d = ax[k] - a0[k]; acc.x += d * d; }
+            if (by[k]) { const float d = ay[k] - a0[k]; acc.y += d * d; }
+            if (bz[k]) { const float d = az[k] - a0[k]; acc.z += d * d; }
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(TVL_BLOCK) void tv_levels_fwd_k(TvLevels L, float4* __restrict__ partial) {
+    __shared__ float4 red[TVL_BLOCK / 64];
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < GENS_MAX_LEVELS; ++j) l += (j < L.n && (int)blockIdx.x >= L.first_block[j]) ? 1 : 0;
+    const uint32_t t = (blockIdx.x - L.first_block[l]) * TVL_BLOCK + threadIdx.x;
+    float4 acc = tv_fwd4_thread(L.vol[l], L.mask[l], L.X[l], L.Y[l], L.Z[l], t);
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 r = red[0];
+        for (int k = 1; k < TVL_BLOCK / 64; ++k) { r.x += red[k].x; r.y += red[k].y; r.z += red[k].z; r.w += red[k].w; }
+        partial[blockIdx.x] = r;
+    }
+}
+
+// One workgroup adds the per-block partials of every level in float64 in a fixed order (deterministic) and writes
+//   out[0]         tv_reg = sum_l 0.5^l sqrt((sx + sy + sz) / (count_x + 1e-8))            (Q13: all three axes over mx's count)
+//   out[1 + l]     the level's backward coefficient 0.5^l / (2 tv_l den_l)   (d tv_reg / d (squared-difference sum of level l))
+__global__ __launch_bounds__(256) void tv_levels_finish_k(TvLevels L, const float4* __restrict__ partial, float* __restrict__ out) {
+    __shared__ double red[4][4];
+    double total = 0.0, scale = 1.0;
+    for (int l = 0; l < L.n; ++l) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = L.first_block[l] + threadIdx.x; b < L.first_block[l + 1]; b += 256) {
+            const float4 p = partial[b];
+            s[0] += (double)p.x; s[1] += (double)p.y; s[2] += (double)p.z; s[3] += (double)p.w;
+        }
+        for (int k = 0; k < 4; ++k) {
+            double v = s[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t[4];
+            for (int k = 0; k < 4; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            const double den = t[3] + 1e-8;
+            const float tv = (float)sqrt((t[0] + t[1] + t[2]) / den);          // the reference's value is float32
+            total += scale * (double)tv;
+            out[1 + l] = (float)(scale / (2.0 * (double)tv * (double)(float)den));
+        }
+        __syncthreads();
+        scale *= 0.5;
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
+}
+
+// d tv_reg / d volume for all levels: g_vol[l] = g * coef[l] * d(sum of squared differences)/d vol   (overwrites g_vol)
+__device__ __forceinline__ void tv_bwd4_thread(const float* __restrict__ vol, const float* __restrict__ mask, int X, int Y, int Z, uint32_t t, float coef,
+                                               float* __restrict__ g_vol) {
+    const uint32_t n = (uint32_t)X * Y * Z, q = n >> 2;
+    if (t >= q) return;
+    const uint32_t i = t << 2, zq = (uint32_t)Z >> 2;
+    const uint32_t kz = (t % zq) << 2, row = t / zq, jy = row % (uint32_t)Y, ix = row / (uint32_t)Y;
+    const uint32_t sx = (uint32_t)Y * Z, sy = (uint32_t)Z;
+    const bool hxp = ix + 1 < (uint32_t)X, hxn = ix > 0, hyp = jy + 1 < (uint32_t)Y, hyn = jy > 0, hzp = kz + 4 < (uint32_t)Z, hzn = kz > 0;
+    const float4 m = *(const float4*)(mask + i);
+    const float4 mxp = hxp ? *(const float4*)(mask + i + sx) : f4_zero(), mxn = hxn ? *(const float4*)(mask + i - sx) : f4_zero();
+    const float4 myp = hyp ? *(const float4*)(mask + i + sy) : f4_zero(), myn = hyn ? *(const float4*)(mask + i - sy) : f4_zero();
+    const float mzp = hzp ? mask[i + 4] : 0.0f, mzn = hzn ? mask[i - 1] : 0.0f;
+    const float mm[4] = {m.x, m.y, m.z, m.w};
+    const float axp[4] = {mxp.x, mxp.y, mxp.z, mxp.w}, axn[4] = {mxn.x, mxn.y, mxn.z, mxn.w};
+    const float ayp[4] = {myp.x, myp.y, myp.z, myp.w}, ayn[4] = {myn.x, myn.y, myn.z, myn.w};
+    const float azp[4] = {m.y, m.z, m.w, mzp}, azn[4] = {mzn, m.x, m.y, m.z};
+    bool px[4], nx[4], py[4], ny[4], pz[4], nz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        px[k] = hxp && (mm[k] * axp[k] > 0.0f);
+        nx[k] = hxn && (mm[k] * axn[k] > 0.0f);
+        py[k] = hyp && (mm[k] * ayp[k] > 0.0f);
+        ny[k] = hyn && (mm[k] * ayn[k] > 0.0f);
+        pz[k] = (k < 3 || hzp) && (mm[k] * azp[k] > 0.0f);
+        nz[k] = (k > 0 || hzn) && (mm[k] * azn[k] > 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* v = vol + (size_t)c * n + i;
+        const float4 v0 = *(const float4*)v;
+        const float4 vxp = hxp ? *(const float4*)(v + sx) : f4_zero(), vxn = hxn ? *(const float4*)(v - sx) : f4_zero();
+        const float4 vyp = hyp ? *(const float4*)(v + sy) : f4_zero(), vyn = hyn ? *(const float4*)(v - sy) : f4_zero();
+        const float vzp = hzp ? v[4] : 0.0f, vzn = hzn ? v[-1] : 0.0f;
+        const float a0[4] = {v0.x, v0.y, v0.z, v0.w};
+        const float bxp[4] = {vxp.x, vxp.y, vxp.z, vxp.w}, bxn[4] = {vxn.x, vxn.y, vxn.z, vxn.w};
+        const float byp[4] = {vyp.x, vyp.y, vyp.z, vyp.w}, byn[4] = {vyn.x, vyn.y, vyn.z, vyn.w};
+        const float bzp[4] = {v0.y, v0.z, v0.w, vzp}, bzn[4] = {vzn, v0.x, v0.y, v0.z};
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.0f;
+            if (px[k]) s -= 2.0f * (bxp[k] - a0[k]);
+            if (nx[k]) s += 2.0f * (a0[k] - bxn[k]);
+            if (py[k]) s -= 2.0f * (byp[k] - a0[k]);
+            if (ny[k]) s += 2.0f * (a0[k] - byn[k]);
+            if (pz[k]) s -= 2.0f * (bzp[k] - a0[k]);
+            if (nz[k]) s += 2.0f * (a0[k] - bzn[k]);
+            g[k] = coef * s;
+        }
+        *(float4*)(g_vol + (size_t)c * n + i) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+__global__ __launch_bounds__(TVL_BLOCK) void tv_levels_bwd_k(TvLevels L, const float* __restrict__ coefs, const float* __restrict__ g) {
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < GENS_MAX_LEVELS; ++j) l += (j < L.n && (int)blockIdx.x >= L.first_block[j]) ? 1 : 0;
+    const uint32_t t = (blockIdx.x - L.first_block[l]) * TVL_BLOCK + threadIdx.x;
+    tv_bwd4_thread(L.vol[l], L.mask[l], L.X[l], L.Y[l], L.Z[l], t, g[0] * coefs[1 + l], L.g_vol[l]);
+}
+
+static int fill_tv_levels(const char* who, TvLevels* L, const float* const* vols, const float* const* masks, float* const* g_vols, const int* dims,
+                          int n_levels) {
+    GENS_CHECK_ARG(vols && masks && dims, GENS_EINVAL, "%s: null table", who);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "%s: n_levels=%d", who, n_levels);
+    L->n = n_levels;
+    L->first_block[0] = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int x = dims[3 * l], y = dims[3 * l + 1], z = dims[3 * l + 2];
+        GENS_CHECK_ARG(vols[l] && masks[l] && x > 0 && y > 0 && z > 0, GENS_EINVAL, "%s: bad level %d", who, l);
+        GENS_CHECK_ARG((z & 3) == 0 && (int64_t)x * y * z < ((int64_t)1 << 31), GENS_ELIMIT,
+                       "%s: level %d (%d x %d x %d): Z must be a multiple of 4 and the level smaller than 2^31 voxels (use gens_tv_fwd / gens_tv_bwd)", who, l, x, y, z);
+        GENS_CHECK_ARG((((uintptr_t)vols[l] | (uintptr_t)masks[l] | (uintptr_t)(g_vols ? g_vols[l] : nullptr)) & 15) == 0, GENS_EINVAL,
+                       "%s: level %d is not 16-byte aligned (use gens_tv_fwd / gens_tv_bwd)", who, l);
+        L->vol[l] = vols[l];
+        L->mask[l] = masks[l];
+        L->g_vol[l] = g_vols ? g_vols[l] : nullptr;
+        L->X[l] = x; L->Y[l] = y; L->Z[l] = z;
+        L->first_block[l + 1] = L->first_block[l] + (int)gens_blocks((int64_t)x * y * z / 4, TVL_BLOCK);
+    }
+    for (int l = n_levels; l < GENS_MAX_LEVELS; ++l) { L->vol[l] = L->mask[l] = nullptr; L->g_vol[l] = nullptr; L->X[l] = L->Y[l] = L->Z[l] = 0; L->first_block[l + 1] = L->first_block[n_levels]; }
+    return 0;
+}
+
+extern "C" int gens_tv_levels_blocks(const int* dims, int n_levels) {
+    int b = 0;
+    for (int l = 0; l < n_levels && l < GENS_MAX_LEVELS; ++l) b += (int)gens_blocks((int64_t)dims[3 * l] * dims[3 * l + 1] * dims[3 * l + 2] / 4, TVL_BLOCK);
+    return b;
+}
+
+extern "C" int gens_tv_levels_fwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, float* partial, float* out,
+                                  void* stream) {
+    TvLevels L;
+    if (int e = fill_tv_levels("gens_tv_levels_fwd", &L, vols, masks, nullptr, dims, n_levels)) return e;
+    GENS_CHECK_ARG(partial && out && ((uintptr_t)partial & 15) == 0, GENS_EINVAL, "gens_tv_levels_fwd: null / misaligned partial or out");
+    tv_levels_fwd_k<<<L.first_block[n_levels], TVL_BLOCK, 0, (hipStream_t)stream>>>(L, (float4*)partial);
+    tv_levels_finish_k<<<1, 256, 0, (hipStream_t)stream>>>(L, (const float4*)partial, out);
+    return gens_launch_status("gens_tv_levels_fwd");
+}
+
+extern "C" int gens_tv_levels_bwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, const float* out,
+                                  const float* g, float* const* g_vols, void* stream) {
+    TvLevels L;
+    GENS_CHECK_ARG(g_vols && out && g, GENS_EINVAL, "gens_tv_levels_bwd: null pointer");
+    if (int e = fill_tv_levels("gens_tv_levels_bwd", &L, vols, masks, g_vols, dims, n_levels)) return e;
+    for (int l = 0; l < n_levels; ++l) GENS_CHECK_ARG(g_vols[l], GENS_EINVAL, "gens_tv_levels_bwd: null gradient buffer of level %d", l);
+    tv_levels_bwd_k<<<L.first_block[n_levels], TVL_BLOCK, 0, (hipStream_t)stream>>>(L, out, g);
+    return gens_launch_status("gens_tv_levels_bwd");
+}

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_fwd_k(gens_comp
     float s0 = pick2(smp[0].sdf, smp[1].sdf, i0), s1 = pick2(smp[0].sdf, smp[1].sdf, i1);
     float z0 = pick2(smp[0].mid, smp[1].mid, i0), z1 = pick2(smp[0].mid, smp[1].mid, i1);
     if (lane == 0) {
-        const float* R = in.rot;
+        const float* R = in.rot_dev ? in.rot_dev : in.rot;
         float camz = R[6] * d[0] + R[7] * d[1] + R[8] * d[2];
         out.color[3 * r] = acc[0];
         out.color[3 * r + 1] = acc[1];
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_comp
     ray_setup(in, r, lane, true, inv_s, d, o, smp);
     float tr[2];
     excl_cumprod2(smp[0].fac, smp[1].fac, lane, tr[0], tr[1]);
-    const float* R = in.rot;
+    const float* R = in.rot_dev ? in.rot_dev : in.rot;
     float camz = R[6] * d[0] + R[7] * d[1] + R[8] * d[2];
     float gc[3] = {0, 0, 0}, gnr[3] = {0, 0, 0}, gsv[3] = {0, 0, 0};
     if (g.g_color) for (int a = 0; a < 3; ++a) gc[a] = g.g_color[3 * r + a];

@@ -27,7 +27,7 @@ _fp = C.POINTER(C.c_float)
 
 class CompositeIn(C.Structure):
     _fields_ = [(n, _p) for n in ("rays_o", "rays_d", "z", "sdf", "grad", "color", "smooth", "voxel_mask", "src_vis", "inv_s", "z_max")] + [
-        ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9)]
+        ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9), ("rot_dev", _p)]
 
 
 class CompositeOut(C.Structure):
@@ -107,6 +107,13 @@ SIGNATURES = {
     "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_gemm_tn_batch": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _p, _p],
     "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _l, _pp, _p],
+    "gens_scene_setup": [_p, _p, _i, _p, _p],
+    "gens_pack_maps": [_pp, _pp, _ip, _i, _p],
+    "gens_unpack_maps": [_pp, _pp, _ip, _i, _p],
+    "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p],
+    "gens_tv_levels_blocks": [_ip, _i],
+    "gens_tv_levels_fwd": [_pp, _pp, _ip, _i, _p, _p, _p],
+    "gens_tv_levels_bwd": [_pp, _pp, _ip, _i, _p, _p, _pp, _p],
 }
 
 _lib = None
@@ -135,6 +142,8 @@ def load():
     lib.gens_blend_train_rows.argtypes = [_l, _i]
     lib.gens_gemm_tn_batch_workspace.restype = _l
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
+    lib.gens_scene_cams_floats.restype = _l
+    lib.gens_scene_cams_floats.argtypes = [_i]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i

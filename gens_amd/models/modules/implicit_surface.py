@@ -44,15 +44,12 @@ class Scene:
         self.views = ops.SceneViews(imgs, intrs, c2ws, features)
         self._packed = None
         self._warp = {}
-        self._rot = None
-        self.ref_rotation()          # read back now, while the launch queue is short, not in the middle of the first ray chunk
 
     def ref_rotation(self):
-        """Row-major inverse of the reference camera's rotation (implicit_surface.py:242,245) as 9 host floats, read back once
-        per scene (the compositing kernel takes it by value)."""
-        if self._rot is None:
-            self._rot = ops.inv(self.c2ws[0][:3, :3].to(torch.float32)).reshape(-1).tolist()
-        return self._rot
+        """Row-major inverse of the reference camera's rotation (implicit_surface.py:242,245): nine floats ON THE DEVICE from the scene's
+        set-up launch (the compositing kernel reads them there; round 2 read them back to the host once per scene, a synchronisation per
+        training step)."""
+        return self.views.cams.rot_inv
 
     def volumes_nograd(self):
         """Packed (X,Y,Z,4) texel copy for passes that never need d/dvolume (sampling rounds, inference)."""
@@ -518,7 +515,7 @@ class ImplicitSurface(nn.Module):
         # and laid out as five CONTIGUOUS blocks [rgb (P,3) | img_fine (P,3) | normal_img (P,3) | sdf_depth (P) | render_depth (P)], so the host
         # makes one plain copy out of the reused page-locked buffer and hands out views of it (strided column copies cost 4.6 ms of idle GPU per image)
         p_ = image.shape[0]
-        rot = ops.inv(c2ws[0, :3, :3].detach().to(image.dtype))
+        rot = scene.views.cams.rot_inv.view(3, 3)
         post = torch.empty(11 * p_, device=image.device, dtype=image.dtype)
         post[0:3 * p_].view(p_, 3).copy_(image[:, 0:3])
         torch.clamp(image[:, 0:3] * 256, 0, 255, out=post[3 * p_:6 * p_].view(p_, 3))
@@ -528,7 +525,10 @@ class ImplicitSurface(nn.Module):
         post[10 * p_:11 * p_].copy_(image[:, 7])
         host = self._pinned(11 * n_rays, 1, "_pinned_post")
         host.copy_(post.view(-1, 1), non_blocking=True)
+        status = scene.views.cams.status.cpu()         # (rides behind the image copy: a singular camera matrix raises, as torch.inverse does)
         torch.cuda.current_stream().synchronize()
+        if int(status) != 0:
+            raise RuntimeError("linalg.inv: a camera pose or intrinsics matrix of the scene is singular")
         flat = host.numpy().reshape(-1).copy()
         outputs["color_fine"] = torch.from_numpy(flat[0:3 * p_].reshape(p_, 3))
         outputs["img_fine"] = flat[3 * p_:6 * p_].reshape([height, width, 3])

@@ -58,7 +58,7 @@ def surface_patch_warp(pts_sdf0, gradients_sdf0, images, intrinsics, poses, patc
     b = pts_sdf0.shape[0]
     r_ref, c_ref = poses[0, :3, :3], poses[0, :3, 3]
     k_ref = intrinsics[0, :3, :3]
-    k_ref_inv = ops.inv(intrinsics)[0, :3, :3]
+    k_ref_inv = ops.SceneCams.of(intrinsics, poses).kinv_ref
     p, nrm = pts_sdf0[:, 0], gradients_sdf0[:, 0]
     x_cam = p @ r_ref + (-(r_ref.t() @ c_ref))[None]
     proj = x_cam @ k_ref.t()

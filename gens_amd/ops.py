@@ -61,6 +61,98 @@ def pack_nchw(x):
     return _PackNCHW.apply(x)
 
 
+class _PackMaps(torch.autograd.Function):
+    """gens_pack_nchw for several maps in ONE launch (gens_pack_maps); the backward unpacks the gradients that arrived in one launch too."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_c(x) for x in xs]
+        outs = [torch.empty(x.shape[0], x.shape[2], x.shape[3], 4 * ((x.shape[1] + 3) // 4), device=x.device, dtype=_f32) for x in xs]
+        nchw = [d for x in xs for d in x.shape]
+        L.call("gens_pack_maps", L.ptr_table(xs), L.ptr_table(outs, align=16), L.int_table(nchw), len(xs), L.stream())
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.set_materialize_grads(False)          # a map nothing downstream differentiates gets no gradient pass (not a pass over zeros)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [k for k, g in enumerate(gs) if g is not None and ctx.needs_input_grad[k]]
+        res = [None] * len(gs)
+        if live:
+            srcs = [aligned16(gs[k]) for k in live]
+            dsts = [torch.empty(ctx.shapes[k], device=srcs[0].device, dtype=_f32) for k in live]
+            nchw = [d for k in live for d in ctx.shapes[k]]
+            L.call("gens_unpack_maps", L.ptr_table(srcs, align=16), L.ptr_table(dsts), L.int_table(nchw), len(live), L.stream())
+            for k, d in zip(live, dsts):
+                res[k] = d
+        return tuple(res)
+
+
+def pack_maps(maps):
+    """[(n,C,H,W), ...] -> their (n,H,W,C_pad) texel copies, in one launch for the maps that have none yet.  The texels of a map are kept ON
+    the map tensor (attribute `_gens_tex`, valid for the tensor's current version and autograd mode): the volume build and the renderer of one
+    forward pass (volume.py:21-61 and projector.py:294-349 read the same `features`) share one layout pass, and a frozen map (fine-tuning:
+    GenS.features) is packed once, not once per step."""
+    maps = [m if m.dtype == _f32 else m.to(_f32) for m in maps]
+    out, todo = [None] * len(maps), []
+    grad_mode = torch.is_grad_enabled()
+    for k, m in enumerate(maps):
+        hit = getattr(m, "_gens_tex", None)
+        if hit is not None and hit[0] == m._version and hit[1] == (grad_mode and m.requires_grad) and hit[2].device == m.device:
+            out[k] = hit[2]
+        else:
+            todo.append(k)
+    for s in range(0, len(todo), 8):
+        part = todo[s:s + 8]
+        texs = _PackMaps.apply(*[maps[k] for k in part])
+        for k, t in zip(part, texs):
+            out[k] = t
+            try:
+                maps[k]._gens_tex = (maps[k]._version, grad_mode and maps[k].requires_grad, t)
+            except (AttributeError, RuntimeError):
+                pass
+    return out
+
+
+class SceneCams:
+    """The camera constants of a scene on the device, from ONE launch (gens_scene_setup): w2c = inverse(c2ws), the per-level intrinsics,
+    inverse(c2ws[0,:3,:3]) and inverse(intrs)[0,:3,:3] (volume.py:24-25,34; projector.py:317-322,364; implicit_surface.py:242,245).  The
+    reference calls torch.inverse at each of those places: a batched LU of ~11 launches each, 45 launches per training step.
+    `SceneCams.of` returns the instance built for the same two tensor OBJECTS at their current versions (the volume build and the renderer
+    of one forward pass receive the same `intrs` / `c2ws`)."""
+    _last = None
+
+    def __init__(self, intrs, c2ws):
+        dev = c2ws.device
+        self.nv = int(c2ws.shape[0])
+        self.c2w, self.intr = _dev_f32(c2ws.detach(), dev), _dev_f32(intrs.detach(), dev)
+        self.buf = torch.empty(L.load().gens_scene_cams_floats(self.nv), device=dev, dtype=_f32)
+        L.call("gens_scene_setup", L.ptr(self.c2w), L.ptr(self.intr), self.nv, L.ptr(self.buf), L.stream())
+        nv, o = self.nv, self.nv * 16
+        self.w2c = self.buf[:o].view(nv, 4, 4)
+        self.ks = [self.buf[o + l * nv * 16:o + (l + 1) * nv * 16].view(nv, 4, 4) for l in range(L.MAX_LEVELS)]
+        o += L.MAX_LEVELS * nv * 16
+        self.rot_inv = self.buf[o:o + 9]                     # row-major inverse(c2ws[0, :3, :3])
+        self.kinv_ref = self.buf[o + 12:o + 21].view(3, 3)
+        self.status = self.buf[o + 24:o + 25].view(torch.int32)
+
+    @staticmethod
+    def of(intrs, c2ws):
+        key = (intrs, c2ws, intrs._version, c2ws._version)
+        last = SceneCams._last
+        if last is not None and last[0][0] is intrs and last[0][1] is c2ws and last[0][2:] == key[2:]:
+            return last[1]
+        cams = SceneCams(intrs, c2ws)
+        SceneCams._last = (key, cams)
+        return cams
+
+    def check(self):
+        """Raise like torch.inverse does for a singular pose / intrinsics matrix.  Reads one int back: call it where the host synchronises
+        anyway (end of validate(), end of a training forward), never between launches."""
+        if int(self.status.item()) != 0:
+            raise RuntimeError("linalg.inv: a camera pose or intrinsics matrix of the scene is singular (gens_scene_setup)")
+
+
 def pack_volume(v):
     """(1,4,X,Y,Z) or (4,X,Y,Z) -> (X,Y,Z,4) texels (inference fast path; not differentiable)."""
     v = v.detach()
@@ -203,18 +295,11 @@ class _VolumeBuildLevels(torch.autograd.Function):
 
 def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
     """features: list of (nv,4,H_i,W_i) NCHW -> (volumes [(1,8,D,D,D)], masks [(1,1,D,D,D)]).  One launch for all levels."""
-    dev = features[0].device
-    w2c = _dev_f32(inv(c2ws.to(_f32)), dev)
-    intr = _dev_f32(intrs, dev)
-    ks = []
-    for lvl in range(len(dims)):
-        # rows 0-1 of the intrinsics times 0.5^lvl (Q2), multiplied here once in float32 -- the same product the reference forms
-        # per level (volume.py:24-25)
-        k = intr.clone()
-        k[:, :2] = k[:, :2] * torch.tensor(0.5 ** lvl, device=dev, dtype=_f32)
-        ks.append(k)
-    texs = [pack_nchw(features[lvl].to(_f32)) for lvl in range(len(dims))]
-    out = _VolumeBuildLevels.apply(w2c, [int(d) for d in dims], int(min_vis_view), *texs, *ks)
+    # inverse(c2ws) and the intrinsics with rows 0-1 times 0.5^lvl (Q2; an exact power-of-two scaling, the product the reference forms per
+    # level, volume.py:24-25) come from the scene's one set-up launch; the texel copies of the maps from one layout launch
+    cams = SceneCams.of(intrs, c2ws)
+    texs = pack_maps([features[lvl] for lvl in range(len(dims))])
+    out = _VolumeBuildLevels.apply(cams.w2c, [int(d) for d in dims], int(min_vis_view), *texs, *cams.ks[:len(dims)])
     n = len(dims)
     return list(out[:n]), list(out[n:])
 
@@ -388,13 +473,10 @@ class SceneViews:
     """Per-scene camera matrices + texel copies of the images and the feature pyramid (built once per scene)."""
 
     def __init__(self, imgs, intrs, c2ws, features):
-        dev = imgs.device
         self.nv = imgs.shape[0]
-        self.c2w = _dev_f32(c2ws, dev)
-        self.w2c = _c(inv(self.c2w))
-        self.intr = _dev_f32(intrs, dev)
-        self.imgs_tex = pack_nchw(imgs.to(_f32))
-        self.feat_tex = [pack_nchw(f.to(_f32)) for f in features]
+        self.cams = SceneCams.of(intrs, c2ws)
+        self.c2w, self.w2c, self.intr = self.cams.c2w, self.cams.w2c, self.cams.intr
+        self.imgs_tex, *self.feat_tex = pack_maps([imgs, *features])
 
 
 def lookup_feature(pts, views):
@@ -454,8 +536,12 @@ def _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_v
     ci.n_rays, ci.n = z.shape
     ci.n_src = src_vis.shape[-1] if src_vis is not None else 0
     ci.sample_dist, ci.cos_anneal = float(sample_dist), float(cos_anneal)
-    for k in range(9):
-        ci.rot[k] = rot[k]
+    if torch.is_tensor(rot):                 # nine floats on the device (SceneCams.rot_inv): no host read
+        ci.rot_dev = L.ptr(rot)
+    else:
+        ci.rot_dev = None
+        for k in range(9):
+            ci.rot[k] = rot[k]
     return ci
 
 
@@ -528,7 +614,10 @@ def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, vox
     b, n = z.shape
     # R_ref^-1 (implicit_surface.py:242,245) travels by value in the launch block; a list from Scene.ref_rotation() avoids the
     # device->host read (a synchronisation) on every ray chunk
-    rot = c2w_ref if isinstance(c2w_ref, (list, tuple)) else inv(c2w_ref[:3, :3].to(_f32)).reshape(-1).tolist()
+    if isinstance(c2w_ref, (list, tuple)) or (torch.is_tensor(c2w_ref) and c2w_ref.numel() == 9):
+        rot = c2w_ref                        # host floats, or SceneCams.rot_inv on the device
+    else:
+        rot = _c(inv(c2w_ref[:3, :3].to(_f32)).reshape(-1))
     z = _c(z.detach().to(_f32))
     z_max = z.max().reshape(1)                                                  # implicit_surface.py:301
     vm = _c(voxel_mask.reshape(b * n).to(torch.uint8))
@@ -611,7 +700,43 @@ class _TVLevel(torch.autograd.Function):
         return g_vol, None
 
 
+class _TVLevels(torch.autograd.Function):
+    """tv_regularization of all levels: two launches forward (partial sums, one finishing workgroup), one backward."""
+
+    @staticmethod
+    def forward(ctx, n, *vm):
+        vols, masks = [_c(v.detach()) for v in vm[:n]], [_c(m.detach()) for m in vm[n:]]
+        dims = [d for v in vols for d in v.shape[-3:]]
+        dev = vols[0].device
+        partial = torch.empty(L.load().gens_tv_levels_blocks(L.int_table(dims), n), 4, device=dev, dtype=_f32)
+        out = torch.empty(1 + n, device=dev, dtype=_f32)
+        L.call("gens_tv_levels_fwd", L.ptr_table(vols, align=16), L.ptr_table(masks, align=16), L.int_table(dims), n, L.ptr(partial), L.ptr(out), L.stream(),
+               nbytes=sum(20 * v[0, 0].numel() for v in vols))
+        ctx.save_for_backward(out, *vols, *masks)
+        ctx.n, ctx.dims = n, dims
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        out, *vm = ctx.saved_tensors
+        n = ctx.n
+        vols, masks = vm[:n], vm[n:]
+        g_vols = [torch.empty_like(v) for v in vols]
+        L.call("gens_tv_levels_bwd", L.ptr_table(list(vols), align=16), L.ptr_table(list(masks), align=16), L.int_table(ctx.dims), n, L.ptr(out),
+               L.ptr(_c(g.detach().to(_f32).reshape(1))), L.ptr_table(g_vols, align=16), L.stream(), nbytes=sum(36 * v[0, 0].numel() for v in vols))
+        return (None, *g_vols, *([None] * n))
+
+
+def tv_levels_ok(volumes, masks):
+    """The fused all-level kernels cover 4-channel levels with Z % 4 == 0 below 2^31 voxels on 16-byte aligned storage."""
+    return all(v.dim() == 5 and v.shape[1] == 4 and v.shape[-1] % 4 == 0 and v[0, 0].numel() < 2 ** 31 and v.is_contiguous() and v.data_ptr() % 16 == 0
+               and m.is_contiguous() and m.data_ptr() % 16 == 0 for v, m in zip(volumes, masks)) and len(volumes) <= L.MAX_LEVELS
+
+
 def tv_regularization(volumes, masks):
+    volumes, masks = list(volumes), list(masks)
+    if volumes and volumes[0].is_cuda and tv_levels_ok(volumes, masks):
+        return _TVLevels.apply(len(volumes), *volumes, *masks)
     total = 0
     for lvl, (v, m) in enumerate(zip(volumes, masks)):
         total = total + _TVLevel.apply(v, m) * 0.5 ** lvl

@@ -163,7 +163,8 @@ int gens_merge_samples(const float* z, const float* sdf, const float* z_new, con
 /* ------------------------------------------------------------------------------------------------------------
  * K8  render_core compositing                                     (implicit_surface.py:160-168, 202-303)
  *   per-sample inputs (B, n[, 3]); n <= 128; voxel_mask (B*n) uint8; src_vis (B*n, S) uint8 or NULL
- *   smooth may be NULL (inference).  rot = inverse(c2ws[0,:3,:3]) (3,3) HOST floats passed by value as 9 floats
+ *   smooth may be NULL (inference).  rot = inverse(c2ws[0,:3,:3]) (3,3) HOST floats passed by value as 9 floats, or rot_dev: the same
+ *   nine floats in DEVICE memory (gens_scene_setup's rot_inv; NULL = use rot) -- no device-to-host read per scene
  *   inv_s: DEVICE pointer to one float (already clipped, :206); z_max: DEVICE pointer to max(z) (:301)
  *   per-ray outputs: color (B,3) normal (B,3) depth (B) wsum (B) wmax (B) valid (B) uint8 mid_in (B)
  *                    sdf_depth (B) z_cross (B) [clamped, :300-302] cross_idx (B) int32
@@ -181,6 +182,7 @@ typedef struct {
     int n, n_src;
     float sample_dist, cos_anneal;
     float rot[9];
+    const float* rot_dev;
 } gens_composite_in;
 
 typedef struct {
@@ -496,6 +498,41 @@ int gens_instnorm_relu_add_fwd(const float* x, const float* mean_rstd, const flo
 int gens_instnorm_relu_bwd_stats(const float* x, const float* gy, const float* mean_rstd, int c, int64_t n, double* partials, void* stream);
 int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rstd, const float* g_means, int c, int64_t n, float* gx,
                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K19  step-boundary kernels of a training step: what the reference does with dozens of scalar-sized PyTorch launches around the
+ *      hot-path kernels, each in ONE launch on the device and without host synchronisation (k19_step.hip).
+ *
+ * gens_scene_setup: the camera constants of a scene --
+ *     w2c = inverse(c2ws)                                  (volume.py:34, projector.py:322)
+ *     ks[l] = intrs with rows 0-1 times 0.5^l, l < 8       (volume.py:24-25, projector.py:317-318; Q2)
+ *     rot_inv = inverse(c2ws[0, :3, :3])                   (implicit_surface.py:242,245)
+ *     kinv_ref = inverse(intrs)[0, :3, :3]                 (projector.py:364)
+ *   written to `cams`, gens_scene_cams_floats(nv) floats laid out as
+ *     [w2c nv x 16][ks GENS_MAX_LEVELS x nv x 16][rot_inv 9 + 3 pad][kinv_ref 9 + 3 pad][status: int32, bit 0 = a singular matrix][3 pad].
+ *   Inverses: float64 Gauss-Jordan with partial pivoting, rounded once to float32; a singular matrix gives NaNs and sets the status bit
+ *   (torch.inverse raises: the host checks the bit where it synchronises anyway).
+ * gens_pack_maps / gens_unpack_maps: gens_pack_nchw / gens_unpack_nhwc for up to 8 maps in one launch; src / dst: HOST arrays of device
+ *   pointers, nchw: HOST int[4 * n_maps] = (n, C, H, W) per map.
+ * gens_compact_points: the index list of a step's masked SDF evaluation (implicit_surface.py:121-124,174-177,256-257,484-497): rows
+ *   [0, n_ray_pts) are ray samples with flags from gens_ray_points (none set: the first min(10, n) of them, Q7), the next n_always rows
+ *   are always selected (the random points), the rest are the pseudo points with their own flags.  idx (n) int64: selected rows in
+ *   increasing order; counts (3) int32 = {selected, selected ray samples, selected pseudo points}.  n < 2^24; one workgroup.
+ * gens_tv_levels_fwd / _bwd: tv_regularization (implicit_surface.py:135-150; Q13) of all levels.  vols[l] (4, X, Y, Z), masks[l]
+ *   (X, Y, Z): HOST arrays of device pointers; dims HOST int[3 * n_levels]; Z % 4 == 0, 16-byte aligned planes.
+ *   fwd: partial: scratch of gens_tv_levels_blocks(dims, n_levels) float4; out (1 + n_levels): out[0] = tv_reg, out[1 + l] = the
+ *   level's backward coefficient 0.5^l / (2 tv_l den_l).  bwd: g (1) = d loss / d tv_reg (DEVICE) -> g_vols[l] (overwritten).
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t gens_scene_cams_floats(int nv);
+int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
+int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
+int gens_unpack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
+int gens_compact_points(const uint8_t* valid, int64_t n_ray_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts, void* stream);
+int gens_tv_levels_blocks(const int* dims, int n_levels);
+int gens_tv_levels_fwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, float* partial, float* out,
+                       void* stream);
+int gens_tv_levels_bwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, const float* out,
+                       const float* g, float* const* g_vols, void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,16 +36,18 @@ def _measure(quiet, kernels=False):
         torch.backends.cudnn.benchmark = True
     if os.environ.get("GENS_BLAS"):                                     # "hipblaslt" / "cublas" (rocBLAS): which GEMM library torch uses
         torch.backends.cuda.preferred_blas_library(os.environ["GENS_BLAS"])
-    dims = [256, 128, 64, 32, 16] if "--levels5" in sys.argv else [256, 128, 64]       # --levels5: the shipped confs/gens.conf pyramid
-    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
+    conf_shape = "--conf-shape" in sys.argv     # confs/gens_finetune.conf:5-16,52-54 as shipped: img_hw [1152, 1600], num_views 3, five levels
+    dims = [256, 128, 64, 32, 16] if ("--levels5" in sys.argv or conf_shape) else [256, 128, 64]       # --levels5: the shipped confs/gens.conf pyramid
+    nv, h, w = (3, 1152, 1600) if conf_shape else (5, 480, 640)
+    sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=5, seed=0)
     imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
     feats = [f.to(dev).requires_grad_(True) for f in sc["features"]]
     vols = [v.to(dev).requires_grad_(True) for v in synthetic.make_volumes(dims, seed=1)]
     torch.manual_seed(0)
     surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).train()
     g = torch.Generator().manual_seed(3)
-    pix = torch.stack([torch.randint(0, 640, (512,), generator=g), torch.randint(0, 480, (512,), generator=g)], -1)
-    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640, pixels=pix)
+    pix = torch.stack([torch.randint(0, w, (512,), generator=g), torch.randint(0, h, (512,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], h, w, pixels=pix)
     ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": sc["near"].to(dev),
             "far": sc["far"].to(dev), "pseudo_pts": (torch.rand(2048, 3, generator=g) - 0.5).to(dev)}
     target = torch.rand(512, 3, device=dev)
@@ -76,9 +78,7 @@ def _measure(quiet, kernels=False):
     def step():
         if finetune:
             return ft_step()
-        with torch.no_grad():
-            _, masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], intrs, c2ws, dims)
-        cost, _ = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)            # K1 with autograd to the features
+        cost, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)        # K1 with autograd to the features, once per step (gens.py:139)
         out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
         ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]                     # loss.py:36-38
         loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \

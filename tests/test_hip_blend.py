@@ -184,7 +184,7 @@ def test_blend_kernels_propagate_not_a_number_inputs(rowmajor, nv, monkeypatch):
     # ulp of either exponential moves them by per cent), so such points are held to finiteness only
     e = torch.exp(net.s.detach().abs() * (rd[..., 3] - 1))
     wsum = ((e - e.min(dim=1, keepdim=True)[0]) * mk).sum(1)
-    firm = ~bad & ((wsum > 1e-3) | (wsum == 0))
-    assert int(firm.sum()) > 0.9 * int((~bad).sum())
+    firm = ~bad & ((wsum > 1e-4) | (wsum == 0))          # d w / d e = 1e-8 / (sum + 1e-8)^2 <= 1 there
+    assert int(firm.sum()) > 0.5 * int((~bad).sum())
     assert (rgb[firm] - ref[firm]).abs().max() < 2e-5
     assert torch.isfinite(rgb[~bad]).all()

@@ -1,10 +1,12 @@
 """Multi-GPU training wiring on the one GPU a test box has (runner.py:102-105):
 
-  * two FORKED ranks sharing device 0 on gloo, the model wrapped in DistributedDataParallel exactly as runner.py:104 wraps it (no
+  * two SPAWNED ranks sharing device 0 on gloo, the model wrapped in DistributedDataParallel exactly as runner.py:104 wraps it (no
     find_unused_parameters): after one train step every rank holds the MEAN of the two ranks' gradients;
   * world size 1 on 'nccl' (= RCCL): the wrapped model's step equals the unwrapped one's bit for bit;
   * FinetuneStepper (FlatGradients: reduce_scatter + all_gather on one persistent flat buffer) drives fine-tune steps the same way.
-The first test forks, so it must run before anything in the pytest process initialises the GPU (tests/conftest.py orders it first)."""
+The first test starts worker processes, which a process that has initialised the GPU must not do (HIP does not survive a fork, and the GPU
+boxes refuse an exec from such a process): tests/conftest.py orders it before every test that touches the GPU, and its own check only counts
+devices, which initialises nothing."""
 import os
 import socket
 
@@ -82,7 +84,7 @@ def _train_grads(model, seed):
 
 
 def _ddp_rank(rank, world, port, q):
-    """A forked rank: both share GPU 0, gloo carries the gradient all-reduce (RCCL wants one device per rank)."""
+    """A spawned rank: both share GPU 0, gloo carries the gradient all-reduce (RCCL wants one device per rank)."""
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel
     try:
@@ -98,7 +100,8 @@ def _ddp_rank(rank, world, port, q):
             want = {k: 0.5 * (a[k] + b[k]) for k in a}
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, None, got, want))
+        as_np = lambda d: None if d is None else {k: v.numpy() for k, v in d.items()}  # noqa: E731   (plain pickles: no shared-memory hand-over)
+        q.put((rank, None, as_np(got), as_np(want)))
     except Exception as e:                                               # a dead worker must not hang the parent
         import traceback
         q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None))
@@ -107,20 +110,27 @@ def _ddp_rank(rank, world, port, q):
 @pytest.mark.forks_before_gpu
 def test_ddp_wrapped_gens_two_ranks_on_one_gpu_average_their_gradients():
     if torch.cuda.is_initialized():
-        pytest.skip("the GPU is already initialised in this process: forking is no longer safe (run this test first or alone)")
+        pytest.skip("the GPU is already initialised in this process: starting worker processes is no longer allowed (run this test first or alone)")
     import multiprocessing as mp
-    ctx = mp.get_context("fork")                                         # no exec: the children initialise the GPU themselves
+    ctx = mp.get_context("spawn")                                        # fresh interpreters: each initialises the GPU itself
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    try:
+        for p in procs:
+            p.start()
+    except OSError as e:                                                 # a box that refuses to start programs from this process
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        pytest.skip(f"cannot start worker processes here: {e}")
     res = {}
     try:
         for _ in procs:
             rank, err, got, want = q.get(timeout=600)
             assert err is None, err
-            res[rank] = (got, want)
+            as_t = lambda d: None if d is None else {k: torch.from_numpy(v) for k, v in d.items()}  # noqa: E731
+            res[rank] = (as_t(got), as_t(want))
     finally:
         for p in procs:
             p.join(timeout=60)
@@ -162,8 +172,6 @@ def test_ddp_wrapped_gens_world_size_one_on_rccl_matches_the_unwrapped_model():
 def test_finetune_stepper_drives_flat_gradients():
     """FinetuneStepper (gens_amd/distributed.py): fine-tune steps whose gradients live in ONE flat buffer; world size 1 on RCCL, so the
     exchange is the identity and the step must equal a plain zero_grad / backward / Adam step bit for bit in its first iteration."""
-    import copy
-
     import torch.distributed as dist
     from gens_amd.distributed import FinetuneStepper, optim_tensors
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
@@ -173,7 +181,11 @@ def test_finetune_stepper_drives_flat_gradients():
         ipts = _inputs(7, nv=3)
         model.init_volumes({k: ipts[k] for k in ("imgs", "intrs", "c2ws")})
         ipts["view_ids"] = [0, 1, 2]
-        ref = copy.deepcopy(model)
+        ref = _model()                                                   # the same seed: the same weights (weight-normed modules do not deepcopy)
+        ref.load_state_dict(model.state_dict(), strict=False)
+        ref.init_volumes({k: ipts[k] for k in ("imgs", "intrs", "c2ws")})
+        for a, b in zip(model.volumes, ref.volumes):
+            assert torch.equal(a, b)
         lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
         opt = torch.optim.Adam(model.get_optim_params(lrs))
         stepper = FinetuneStepper(model, opt, _loss)

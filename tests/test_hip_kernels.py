@@ -52,8 +52,10 @@ def test_k1_volume_golden_backward_over_image_tiles(ops, golden, bwd, monkeypatc
     v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [32])
     close(m[0], g["mask"], atol=0, rtol=0, what="mask")
     (v[0] * dev(g["cot"])).sum().backward()
-    # a voxel projecting within an ulp of an image border may flip visibility in one view (count 3 <-> 4: the mask stays, its taps move by 1e-4)
-    close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat", frac=2e-3)
+    # a voxel projecting within an ulp of an image border may flip visibility in one view (count 3 <-> 4: the mask stays, its taps move by 1e-4).
+    # Which voxels do depends on the last bit of inverse(c2ws): the golden's came from LAPACK's float32 LU on the CPU, the device's is the
+    # correctly rounded inverse (gens_scene_setup; rocSOLVER's LU, used until round 2, flipped 0.2 % of the texels, this one 0.3 %)
+    close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat", frac=5e-3)
     close(feat.grad, g["gfeat"], atol=2e-4, what="d/dfeat")
 
 
