@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_k(const float* __restrict
     if (unit >= n_units) return;
     const int64_t s = unit / (mt * nt);
     const int t = (int)(unit % (mt * nt));
-    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int64_t k_begin = min(kk, s * slab), k_end = min(kk, k_begin + slab);
     const int m0 = (t / nt) << 5, n0 = (t % nt) << 5;
     const bool am = m0 + i < m, bn = n0 + i < n;
     const float* ap = a + (k_begin + h) * m + (am ? m0 + i : 0);
@@ -120,9 +120,19 @@ struct GemmTnBatch {
     int64_t off[GEMM_TN_MAX_BATCH];        // offset of C_p in the concatenated result
     int count;
     int64_t csz;
+    // rows that exist: min(k, k_rows * ceil(*k_live / k_div)) when k_live != NULL -- a DEVICE count of the producer's work items (points of a
+    // masked evaluation), k_div of which share a workgroup that wrote k_rows operand rows; slabs past them add zero tiles
+    const int32_t* k_live;
+    int k_div, k_rows;
 };
+__device__ __forceinline__ int64_t gemm_tn_live_rows(const GemmTnBatch& B, int64_t kk) {
+    if (!B.k_live) return kk;
+    const int64_t groups = ((int64_t)B.k_live[0] + B.k_div - 1) / B.k_div;
+    return min(kk, max((int64_t)0, groups) * B.k_rows);
+}
 
 __global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+    kk = gemm_tn_live_rows(B, kk);
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, in
     t -= B.tile0[p];
     const int m = B.m[p], n = B.n[p], lda = B.lda[p], ldb = B.ldb[p];
     const int nt = (n + 31) >> 5;
-    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int64_t k_begin = min(kk, s * slab), k_end = min(kk, k_begin + slab);
     const int m0 = (t / nt) << 5, n0 = (t % nt) << 5;
     const bool am = m0 + i < m, bn = n0 + i < n;
     const float* ap = B.a[p] + (k_begin + h) * lda + (am ? m0 + i : 0);
@@ -177,6 +187,7 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, in
 // MFMA tiles whose rows / columns INTERLEAVE (tile a holds rows m0 + 2 i + a), so one 8-byte load per operand and lane feeds four
 // v_mfma_f32_32x32x2_f32 -- 0.5 load instructions per MFMA instead of 2 (the 32 x 32 kernel is bound by load issue: 1.7 TB/s).
 __global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+    kk = gemm_tn_live_rows(B, kk);
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, i
     t -= B.tile0[p];
     const int m = B.m[p], n = B.n[p], lda = B.lda[p], ldb = B.ldb[p];
     const int nt = (n + 63) >> 6;
-    const int64_t k_begin = s * slab, k_end = min(kk, k_begin + slab);
+    const int64_t k_begin = min(kk, s * slab), k_end = min(kk, k_begin + slab);
     const int m0 = (t / nt) << 6, n0 = (t % nt) << 6;
     const bool am = m0 + 2 * i < m, bn = n0 + 2 * i < n;               // (m, n even: a pair is inside or outside as a whole)
     const float2* ap = (const float2*)(B.a[p] + (k_begin + h) * lda + (am ? m0 + 2 * i : 0));
@@ -296,8 +307,23 @@ extern "C" int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const i
     return ((slabs > slabs64 ? slabs : slabs64) + GEMM_TN_GROUPS) * csz;
 }
 
+static int gemm_tn_batch_run(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                             const int* n, int64_t k, const int32_t* k_live, int k_div, int k_rows, float* workspace, float* c, void* stream);
+
 extern "C" int gens_gemm_tn_batch(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
                                   const int* n, int64_t k, float* workspace, float* c, void* stream) {
+    return gemm_tn_batch_run(count, a, lda, b, ldb, m, n, k, nullptr, 1, 1, workspace, c, stream);
+}
+
+extern "C" int gens_gemm_tn_batch_live(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                                       const int* n, int64_t k, const int32_t* k_live, int k_div, int k_rows, float* workspace, float* c,
+                                       void* stream) {
+    GENS_CHECK_ARG(k_live && k_div >= 1 && k_rows >= 1, GENS_EINVAL, "gens_gemm_tn_batch_live: null count / bad group size");
+    return gemm_tn_batch_run(count, a, lda, b, ldb, m, n, k, k_live, k_div, k_rows, workspace, c, stream);
+}
+
+static int gemm_tn_batch_run(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                             const int* n, int64_t k, const int32_t* k_live, int k_div, int k_rows, float* workspace, float* c, void* stream) {
     int64_t tiles, csz;
     GENS_CHECK_ARG(a && lda && b && ldb && workspace && c, GENS_EINVAL, "gens_gemm_tn_batch: null pointer");
     GENS_CHECK_ARG(k > 0 && gemm_tn_batch_layout(count, m, n, &tiles, &csz) == 0, GENS_ELIMIT,
@@ -305,6 +331,9 @@ extern "C" int gens_gemm_tn_batch(int count, const float* const* a, const int* l
     GemmTnBatch B;
     B.count = count;
     B.csz = csz;
+    B.k_live = k_live;
+    B.k_div = k_div;
+    B.k_rows = k_rows;
     int t0 = 0;
     int64_t off = 0;
     for (int p = 0; p < GEMM_TN_MAX_BATCH; ++p) {

@@ -161,7 +161,8 @@ __device__ __forceinline__ float f4_at(const float4& v, int c) { return c == 0 ?
 // forward launch: y, g = dy/dx, s = d(sum_k g_k)/dx
 // ====================================================================================================================
 template <int FE>
-__global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts, int64_t n,
+__global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
+                                                       const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                        float2* __restrict__ stash, float* __restrict__ y_out, float* __restrict__ g_out,
                                                        float* __restrict__ s_out) {
     constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4;
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    // point i of the launch is pts[index[i]] (NULL: i) and its results go to row index[i] of the outputs; only the first min(n_max, *n_dev)
+    // points exist (the masked evaluation of implicit_surface.py:174-191 without a host-side count): later workgroups leave at once
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
+    if (m0 >= n) return;
     const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
     const int col = 32 * wave + (lane & 31);
 
@@ -187,7 +192,10 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
         const int64_t row = m0 + p;
         const bool live = row < n;
         float x[3] = {0.f, 0.f, 0.f};
-        if (live) { x[0] = pts[3 * row]; x[1] = pts[3 * row + 1]; x[2] = pts[3 * row + 2]; }
+        if (live) {
+            const int64_t src = index ? index[row] : row;
+            x[0] = pts[3 * src]; x[1] = pts[3 * src + 1]; x[2] = pts[3 * src + 2];
+        }
         if (sub < 3) {
             const int a = sub;
             float* pe = PE + p * TR_PE_STRIDE;
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
             float s = W.b_last[0];
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += RED[tid * 8 + k];
-            y_out[row] = s;
+            y_out[index ? index[row] : row] = s;
         }
     }
 
@@ -431,8 +439,9 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
                 g += j[c * 3 + a] * lf[c];
                 s += jd[c * 3 + a] * lf[c] + j[c * 3 + a] * mf[c];
             }
-            g_out[3 * row + a] = g;
-            s_out[3 * row + a] = s;
+            const int64_t dst = index ? index[row] : row;
+            g_out[3 * dst + a] = g;
+            s_out[3 * dst + a] = s;
         }
     }
 }
@@ -441,11 +450,13 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
 // backward launch: operand rows of the weight-gradient products, and the three per-point vectors of the volume scatter
 // tiles (LDS) / operand pairs:  0: z  with omega_a   1: z' with rho_a   2: kappa_z with lambda_a   3: nu_z with mu_a
 // ====================================================================================================================
+// (operand rows are POINT-major, the four sweeps of a point adjacent: the rows of the live points are then one contiguous range
+// [0, 4 * 32 ceil(n / 32)) whatever the launch's upper bound was, and the weight-gradient products stop there -- gens_gemm_tn_batch's k_live)
 struct SdfTrainBwdOut {
-    float* lop;     // [4][npad][6][128]   omega_a, rho_a, lambda_a, mu_a of layers 0..5
-    float* rh;      // [6][4][npad][128]   h parts of the inputs of layers 1..6: z, z', kappa_z, nu_z
-    float* re;      // [4][npad][KP-128]   conditioning parts (+ the bias column) of the same four
-    float* r0;      // [4][npad][32]       inputs of layer 0
+    float* lop;     // [npad][4][6][128]   omega_a, rho_a, lambda_a, mu_a of layers 0..5
+    float* rh;      // [5][npad][4][128]   h parts of the inputs of layers 1..5: z, z', kappa_z, nu_z
+    float* re;      // [npad][4][KP-128]   conditioning parts (+ the bias column) of the same four
+    float* r0;      // [npad][4][32]       inputs of layer 0
     float* f_hat;   // [npad][CF]          cotangent of the looked-up features
     float* mu_f;    // [npad][CF]
     float* lam_f;   // [npad][CF]
@@ -454,7 +465,8 @@ struct SdfTrainBwdOut {
 };
 
 template <int FE>
-__global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts, int64_t n,
+__global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
+                                                       const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                        const float* __restrict__ y_bar, const float* __restrict__ g_bar,
                                                        const float* __restrict__ s_bar, float4* __restrict__ stash, SdfTrainBwdOut O) {
     constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4, FEP = KP - TR_H;
@@ -467,6 +479,11 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;      // (as the forward launch; operand rows past the count are never read)
+    if (m0 >= n) {
+        if (threadIdx.x < (TR_H + FE + 7) / 8 * 8) O.w6_part[(int64_t)blockIdx.x * ((TR_H + FE + 7) / 8 * 8) + threadIdx.x] = 0.0f;
+        return;
+    }
     const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
     const int col = 32 * wave + (lane & 31);
     const int64_t npad = O.npad;
@@ -477,15 +494,16 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
         const int64_t row = m0 + p;
         const bool live = row < n;
         float x[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+        const int64_t src = live ? (index ? index[row] : row) : 0;
         if (live) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                x[a] = pts[3 * row + a];
-                sb[a] = s_bar ? s_bar[3 * row + a] : 0.0f;
-                gb[a] = g_bar ? g_bar[3 * row + a] : 0.0f;
+                x[a] = pts[3 * src + a];
+                sb[a] = s_bar ? s_bar[3 * src + a] : 0.0f;
+                gb[a] = g_bar ? g_bar[3 * src + a] : 0.0f;
             }
         }
-        if (sub == 6) YB[p] = (live && y_bar) ? y_bar[row] : 0.0f;
+        if (sub == 6) YB[p] = (live && y_bar) ? y_bar[src] : 0.0f;
         if (sub < 3) {
             const int a = sub;
             float* p0 = PE + p * TR_PE_STRIDE;
@@ -554,11 +572,11 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
     // operand rows that are already complete: the conditioning parts and the inputs of layer 0
     for (int i = tid; i < 4 * TR_M * FEP; i += 256) {
         const int t = i / (TR_M * FEP), rem = i % (TR_M * FEP), row = rem / FEP, c = rem % FEP;
-        O.re[((int64_t)t * npad + m0 + row) * FEP + c] = X[t * XT + row * RS + TR_H + c];
+        O.re[((m0 + row) * 4 + t) * FEP + c] = X[t * XT + row * RS + TR_H + c];
     }
     for (int i = tid; i < 4 * TR_M * 32; i += 256) {
         const int t = i >> 10, row = (i >> 5) & 31, c = i & 31;
-        O.r0[((int64_t)t * npad + m0 + row) * 32 + c] = PE[t * PT + row * TR_PE_STRIDE + c];
+        O.r0[((m0 + row) * 4 + t) * 32 + c] = PE[t * PT + row * TR_PE_STRIDE + c];
     }
 
     // ------------------------------------------------------------------ forward sweeps: a, a', kappa_a, nu_a
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
             mfma_tiles<GIN, 4>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
         __syncthreads();
         float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
-        float* rh = O.rh + (((int64_t)l * 4) * npad + m0) * TR_H + col;       // inputs of layer l + 1
+        float* rh = O.rh + (((int64_t)l * npad + m0) * 4) * TR_H + col;       // inputs of layer l + 1
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tr_acc_row(r, lane);
@@ -594,8 +612,8 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
             float* xr = X + row * RS + col;
             xr[0] = h; xr[XT] = hd; xr[2 * XT] = hk; xr[3 * XT] = hn;
             if (l < 5) {   // (the inputs of the output row stay in LDS: its weight gradient is summed below)
-                float* gr = rh + (int64_t)row * TR_H;
-                gr[0] = h; gr[npad * TR_H] = hd; gr[2 * npad * TR_H] = hk; gr[3 * npad * TR_H] = hn;
+                float* gr = rh + (int64_t)row * 4 * TR_H;
+                gr[0] = h; gr[TR_H] = hd; gr[2 * TR_H] = hk; gr[3 * TR_H] = hn;
             }
             st[r * 64] = keep;
         }
@@ -627,7 +645,7 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
         }
         __syncthreads();
         const float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
-        float* lop = O.lop + ((int64_t)m0 * TR_NLAYER + l) * TR_H + col;
+        float* lop = O.lop + ((int64_t)m0 * 4 * TR_NLAYER + l) * TR_H + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tr_acc_row(r, lane);
@@ -648,8 +666,8 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
             const float om_a = d1 * oh + d3 * k.y * k.z * lh + d2 * (mh * k.z + k.y * rho_h + lh * k.w);
             float* xr = X + row * RS + col;
             xr[0] = om_a; xr[XT] = rho_a; xr[2 * XT] = lam_a; xr[3 * XT] = mu_a;
-            float* gr = lop + (int64_t)row * TR_NLAYER * TR_H;
-            const int64_t qs = npad * TR_NLAYER * TR_H;
+            float* gr = lop + (int64_t)row * 4 * TR_NLAYER * TR_H;
+            constexpr int qs = TR_NLAYER * TR_H;
             gr[0] = om_a; gr[qs] = rho_a; gr[2 * qs] = lam_a; gr[3 * qs] = mu_a;
         }
         __syncthreads();
@@ -719,13 +737,16 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
 // gradient only have z-neighbours contiguous.
 __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const float* __restrict__ pts, const float* __restrict__ g_bar,
                                                            const float* __restrict__ s_bar, const float4* __restrict__ f_hat,
-                                                           const float4* __restrict__ mu_f, const float4* __restrict__ lam_f, int64_t n) {
+                                                           const float4* __restrict__ mu_f, const float4* __restrict__ lam_f,
+                                                           const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev) {
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     const int L = vs.n;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
     if (gid >= n * L) return;
     const int sub = threadIdx.x & 31, ch = sub >> 3, a = (sub >> 2) & 1, b = (sub >> 1) & 1, d = sub & 1;
     const int l = (int)(gid % L);
-    const int64_t i = gid / L;
+    const int64_t i = gid / L;                         // compact row: f_hat / mu_f / lam_f
+    const int64_t src = index ? index[i] : i;          // dense row: the point and its cotangents
     float* gv = vs.grad[l];
     if (!gv) return;
     const int sz[3] = {vs.dx[l], vs.dy[l], vs.dz[l]};
@@ -735,7 +756,7 @@ __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const fl
     bool in0[3], in1[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const float x = pts[3 * i + ax];
+        const float x = pts[3 * src + ax];
         const float pos = (x + 1.0f) / 2.0f * (float)(sz[ax] - 1);
         const float f = fminf(fmaxf(floorf(pos), -2.0f), (float)sz[ax] + 1.0f);
         i0[ax] = (int)f;
@@ -745,8 +766,8 @@ __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const fl
         in1[ax] = i0[ax] + 1 >= 0 && i0[ax] + 1 < sz[ax];
         if (!(pos == pos)) in0[ax] = in1[ax] = false;
         k[ax] = (float)(sz[ax] - 1) / 2.0f;
-        sb[ax] = s_bar ? s_bar[3 * i + ax] : 0.0f;
-        gb[ax] = g_bar ? g_bar[3 * i + ax] : 0.0f;
+        sb[ax] = s_bar ? s_bar[3 * src + ax] : 0.0f;
+        gb[ax] = g_bar ? g_bar[3 * src + ax] : 0.0f;
     }
     const bool ok = (a ? in1[0] : in0[0]) && (b ? in1[1] : in0[1]) && (d ? in1[2] : in0[2]);
     if (!ok) return;
@@ -863,8 +884,8 @@ extern "C" int gens_sdf_train_pack(const float* const* w, const float* const* b,
 }
 
 extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                                  const float* const* wb, const float* w_last, const float* b_last, const float* pts, int64_t n,
-                                  void* stash, float* y_out, float* g_out, float* s_out, void* stream) {
+                                  const float* const* wb, const float* w_last, const float* b_last, const float* pts, const int64_t* index,
+                                  int64_t n, const int32_t* n_device, void* stash, float* y_out, float* g_out, float* s_out, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_train_fwd", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_fwd: built for 3 or 5 volume levels, got %d", n_levels);
@@ -881,22 +902,22 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
             (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<60>());
             once = true;
         }
-        sdf_train_fwd_k<60><<<grid, 256, fwd_lds_bytes<60>(), s>>>(W, vs, pts, n, (float2*)stash, y_out, g_out, s_out);
+        sdf_train_fwd_k<60><<<grid, 256, fwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
     } else {
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<100>());
             once = true;
         }
-        sdf_train_fwd_k<100><<<grid, 256, fwd_lds_bytes<100>(), s>>>(W, vs, pts, n, (float2*)stash, y_out, g_out, s_out);
+        sdf_train_fwd_k<100><<<grid, 256, fwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
     }
     return gens_launch_status("gens_sdf_train_fwd");
 }
 
 extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                                  const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
-                                  const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
-                                  float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream) {
+                                  const float* const* wb, const float* w_last, const float* pts, const int64_t* index, int64_t n,
+                                  const int32_t* n_device, const float* y_bar, const float* g_bar, const float* s_bar, void* stash, float* lop,
+                                  float* rh, float* re, float* r0, float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_train_bwd", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_bwd: built for 3 or 5 volume levels, got %d", n_levels);
@@ -914,21 +935,21 @@ extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* di
             (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<60>());
             once = true;
         }
-        sdf_train_bwd_k<60><<<grid, 256, bwd_lds_bytes<60>(), s>>>(W, vs, pts, n, y_bar, g_bar, s_bar, (float4*)stash, O);
+        sdf_train_bwd_k<60><<<grid, 256, bwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
     } else {
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<100>());
             once = true;
         }
-        sdf_train_bwd_k<100><<<grid, 256, bwd_lds_bytes<100>(), s>>>(W, vs, pts, n, y_bar, g_bar, s_bar, (float4*)stash, O);
+        sdf_train_bwd_k<100><<<grid, 256, bwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
     }
     return gens_launch_status("gens_sdf_train_bwd");
 }
 
 extern "C" int gens_sdf_train_scatter(const int* dims, int n_levels, const float* pts, const float* g_bar, const float* s_bar,
-                                      const float* f_hat, const float* mu_f, const float* lam_f, int64_t n, float* const* g_vols,
-                                      void* stream) {
+                                      const float* f_hat, const float* mu_f, const float* lam_f, const int64_t* index, int64_t n,
+                                      const int32_t* n_device, float* const* g_vols, void* stream) {
     GENS_CHECK_ARG(dims && g_vols, GENS_EINVAL, "gens_sdf_train_scatter: null table");
     GENS_CHECK_ARG(n_levels > 0 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_sdf_train_scatter: n_levels=%d not in 1..%d", n_levels,
                    GENS_MAX_LEVELS);
@@ -946,6 +967,6 @@ extern "C" int gens_sdf_train_scatter(const int* dims, int n_levels, const float
         vs.dz[l] = l < n_levels ? dims[3 * l + 2] : 1;
     }
     sdf_train_scatter_k<<<gens_blocks(n * n_levels * 32, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, g_bar, s_bar, (const float4*)f_hat,
-                                                                                         (const float4*)mu_f, (const float4*)lam_f, n);
+                                                                                         (const float4*)mu_f, (const float4*)lam_f, index, n, n_device);
     return gens_launch_status("gens_sdf_train_scatter");
 }

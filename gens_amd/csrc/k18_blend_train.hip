@@ -51,11 +51,13 @@ struct BlendTrainIO {
     const float *w2c, *intr, *c2w;
     int nv;
     const float* pts;
+    const int64_t* index;  // point i of the launch is pts[index[i]]; rgb / vis / g_rgb live at row index[i] (NULL: i)
+    const int32_t* n_dev;  // only min(n, *n_dev) points exist (NULL: n)
     int64_t n;
-    float* rgb_out;        // forward: (n, 3)
-    uint8_t* vis_out;      // forward: (n, S) or NULL
+    float* rgb_out;        // forward: (N, 3)
+    uint8_t* vis_out;      // forward: (N, S) or NULL
     // backward
-    const float* g_rgb;    // (n, 3) cotangent of rgb_out
+    const float* g_rgb;    // (N, 3) cotangent of rgb_out
     float* R[BT_NLAYER];   // (rows_pad, in_l + 1 rounded up to even): [input | 1 | 0]
     float* L[BT_NLAYER];   // (rows_pad, out_l rounded up to even)
     float* g_feat;         // (n, S, F) cotangent of the looked-up [rgb | features] rows, or NULL
@@ -122,10 +124,14 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid & 31, col = lane & 31;
     const int S = io.nv - 1, PPW = 32 / S;
     const int64_t first = (int64_t)blockIdx.x * PPW;
-    const int64_t n = io.n;
+    const int64_t n = io.n_dev ? min(io.n, (int64_t)io.n_dev[0]) : io.n;
+    if (first >= n) {                                                // a workgroup past the device-side count: nothing to do
+        if (BWD && threadIdx.x == 0) io.s_part[blockIdx.x] = 0.0f;   // (its operand rows are never read: gens_gemm_tn_batch_live)
+        return;
+    }
     const int pl = row / S, sv = row % S + 1;
     const bool live = pl < PPW && first + pl < n;
-    const int64_t src = live ? first + pl : 0;
+    const int64_t src = live ? (io.index ? io.index[first + pl] : first + pl) : 0;      // dense row of this (point, view) row's point
     const int64_t grow0 = (int64_t)blockIdx.x * 32;                  // first operand row of this workgroup
     const bool owner = tid < 32;                                     // one thread per row for the per-row scalars
 
@@ -325,9 +331,10 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
             cb += C[(base + v) * 3 + 2] * p;
         }
         if (!BWD) {
-            io.rgb_out[3 * (first + tid)] = cr;
-            io.rgb_out[3 * (first + tid) + 1] = cg;
-            io.rgb_out[3 * (first + tid) + 2] = cb;
+            const int64_t dst = io.index ? io.index[first + tid] : first + tid;
+            io.rgb_out[3 * dst] = cr;
+            io.rgb_out[3 * dst + 1] = cg;
+            io.rgb_out[3 * dst + 2] = cb;
         }
     }
     if constexpr (!BWD) return;
@@ -576,22 +583,23 @@ extern "C" int64_t gens_blend_train_rows(int64_t n, int nv) {
 }
 
 extern "C" int gens_blend_train_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
-                                    const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, float* rgb_out,
-                                    uint8_t* vis_out, void* stream) {
+                                    const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                                    const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_train_fwd: null pts / output");
     if (n == 0) return 0;
     BlendTrainIO io = {};
-    io.pts = pts; io.n = n; io.rgb_out = rgb_out; io.vis_out = vis_out;
+    io.pts = pts; io.index = index; io.n_dev = n_device; io.n = n; io.rgb_out = rgb_out; io.vis_out = vis_out;
     return bt_launch<false>("gens_blend_train_fwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
 }
 
 extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
-                                    const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, const float* g_rgb,
-                                    float* const* r_ops, float* const* l_ops, float* g_feat, float* s_part, void* stream) {
+                                    const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                                    const int32_t* n_device, const float* g_rgb, float* const* r_ops, float* const* l_ops, float* g_feat,
+                                    float* s_part, void* stream) {
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_rgb && r_ops && l_ops && s_part)), GENS_EINVAL, "gens_blend_train_bwd: null pointer");
     if (n == 0) return 0;
     BlendTrainIO io = {};
-    io.pts = pts; io.n = n; io.g_rgb = g_rgb; io.g_feat = g_feat; io.s_part = s_part;
+    io.pts = pts; io.index = index; io.n_dev = n_device; io.n = n; io.g_rgb = g_rgb; io.g_feat = g_feat; io.s_part = s_part;
     for (int l = 0; l < BT_NLAYER; ++l) {
         GENS_CHECK_ARG(r_ops[l] && l_ops[l], GENS_EINVAL, "gens_blend_train_bwd: operand buffer %d is null", l);
         io.R[l] = r_ops[l];

@@ -186,11 +186,25 @@ extern "C" int gens_unpack_maps(const float* const* src, float* const* dst, cons
 // rows [n0, n0 + n1): always selected (the 1 024 random points, implicit_surface.py:256-257);
 // rows [n0 + n1, n): pseudo points with their own flags (:484-497; none set -> counts[2] = 0 and the caller raises).
 // idx: the selected rows in increasing order; counts = {all selected, selected ray samples, selected pseudo points}.
+// The same launch writes what the reference's dense tensors hold for the rows the networks never see (Q8: sdf 100 for ray samples -- 0 for
+// pseudo points, implicit_surface.py:497 --, gradient / smooth / colour 0, no visible source view), and the two scalars of a render_core
+// call that are reductions or functions of a parameter: max(z_vals) (:301) and inv_s = clip(exp(10 variance), 1e-6, 1e6) (:206).
+struct StepFill {
+    float *y, *g, *s;          // (n), (n, 3), (n, 3) or NULL
+    float* rgb;                // (n0, 3) or NULL
+    uint8_t* vis;              // (n0, n_src) or NULL
+    int n_src;
+    const float* z;            // (nz) ray depths or NULL
+    int64_t nz;
+    const float* variance;     // (1) or NULL
+    float* scalars;            // [z_max, inv_s, 1 / inv_s, inv_s inside the clip range ? 1 : 0]
+};
 #define CP_THREADS 1024
 __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __restrict__ valid, int64_t n0, int64_t n1, int64_t n,
-                                                                int64_t* __restrict__ idx, int32_t* __restrict__ counts) {
+                                                                int64_t* __restrict__ idx, int32_t* __restrict__ counts, StepFill F) {
     __shared__ int wave_tot[CP_THREADS / 64];
     __shared__ int seg_tot[2];
+    __shared__ float zred[CP_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t per = (n + CP_THREADS - 1) / CP_THREADS;
     const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
@@ -222,7 +236,37 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
     int64_t pos = base + (int)inc - mine;
     for (int64_t i = lo; i < hi; ++i) {
         const bool sel = i < n0 ? (rescue ? i < n_rescue : valid[i] != 0) : (i < n0 + n1 ? true : valid[i] != 0);
-        if (sel) idx[pos++] = i;
+        if (sel) {
+            idx[pos++] = i;
+            continue;
+        }
+        if (F.y) F.y[i] = i < n0 ? 100.0f : 0.0f;
+        if (F.g) { F.g[3 * i] = 0.0f; F.g[3 * i + 1] = 0.0f; F.g[3 * i + 2] = 0.0f; }
+        if (F.s) { F.s[3 * i] = 0.0f; F.s[3 * i + 1] = 0.0f; F.s[3 * i + 2] = 0.0f; }
+        if (i < n0) {
+            if (F.rgb) { F.rgb[3 * i] = 0.0f; F.rgb[3 * i + 1] = 0.0f; F.rgb[3 * i + 2] = 0.0f; }
+            if (F.vis) for (int v = 0; v < F.n_src; ++v) F.vis[i * F.n_src + v] = 0;
+        }
+    }
+    if (F.scalars) {
+        if (F.z) {
+            float m = -3.402823466e38f;
+            for (int64_t i = t; i < F.nz; i += CP_THREADS) m = fmaxf(m, F.z[i]);
+            m = wave_max(m);
+            if (lane == 0) zred[wv] = m;
+            __syncthreads();
+            if (t == 0) {
+                for (int k = 1; k < CP_THREADS / 64; ++k) m = fmaxf(m, zred[k]);
+                F.scalars[0] = m;
+            }
+        }
+        if (F.variance && t == 0) {
+            const float raw = expf(F.variance[0] * 10.0f);                 // SingleVarianceNetwork.forward (variance_network.py:11), then :206
+            const float inv_s = fminf(fmaxf(raw, 1e-6f), 1e6f);
+            F.scalars[1] = inv_s;
+            F.scalars[2] = 1.0f / inv_s;
+            F.scalars[3] = (raw >= 1e-6f && raw <= 1e6f) ? 1.0f : 0.0f;
+        }
     }
     if (t == CP_THREADS - 1) {
         counts[0] = base + (int)inc;
@@ -232,11 +276,15 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
 }
 
 extern "C" int gens_compact_points(const uint8_t* valid, int64_t n_rays_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
-                                   void* stream) {
+                                   float* y_fill, float* g_fill, float* s_fill, float* rgb_fill, uint8_t* vis_fill, int n_src, const float* z,
+                                   int64_t nz, const float* variance, float* scalars, void* stream) {
     GENS_CHECK_ARG(valid && idx && counts, GENS_EINVAL, "gens_compact_points: null pointer");
+    GENS_CHECK_ARG((!z && !variance) || scalars, GENS_EINVAL, "gens_compact_points: z / variance given without a scalars output");
+    GENS_CHECK_ARG(!vis_fill || (n_src >= 1 && n_src < GENS_MAX_VIEWS), GENS_ELIMIT, "gens_compact_points: n_src=%d", n_src);
+    StepFill F = {y_fill, g_fill, s_fill, rgb_fill, vis_fill, n_src, z, z ? nz : 0, variance, scalars};
     GENS_CHECK_ARG(n_rays_pts >= 0 && n_always >= 0 && n_rays_pts + n_always <= n && n < ((int64_t)1 << 24), GENS_EINVAL,
                    "gens_compact_points: bad segment sizes (%lld, %lld of %lld; fewer than 2^24 rows)", (long long)n_rays_pts, (long long)n_always, (long long)n);
-    compact_points_k<<<1, CP_THREADS, 0, (hipStream_t)stream>>>(valid, n_rays_pts, n_always, n, idx, counts);
+    compact_points_k<<<1, CP_THREADS, 0, (hipStream_t)stream>>>(valid, n_rays_pts, n_always, n, idx, counts, F);
     return gens_launch_status("gens_compact_points");
 }
 

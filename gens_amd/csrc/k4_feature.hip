@@ -79,15 +79,18 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
 // lane = (tap, channel): the two taps of a row are 32 contiguous bytes -- and one atomic instruction per level carries four pairs.
 __global__ __launch_bounds__(256) void lookup_feature_bwd_k(MapSet fs, float* __restrict__ g_imgs, const float* __restrict__ w2c,
                                                             const float* __restrict__ intr, int nv, const float* __restrict__ pts,
-                                                            const float* __restrict__ g_out, int64_t n) {
+                                                            const float* __restrict__ g_out, const int64_t* __restrict__ index, int64_t n_max,
+                                                            const int32_t* __restrict__ n_dev) {
     const int S = nv - 1;
     const int row = 3 + 4 * fs.n;
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
     if (gid >= n * S) return;
     const int sub = threadIdx.x & 15, tap = sub >> 2, ch = sub & 3, dy = tap >> 1, dx = tap & 1;
     int sv = (int)(gid % S) + 1;
-    int64_t i = gid / S;
-    float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    int64_t i = gid / S;                                   // compact row of g_out; the point itself is pts[index[i]]
+    const int64_t src = index ? index[i] : i;
+    float x = pts[3 * src], y = pts[3 * src + 1], z = pts[3 * src + 2];
     const float* g = g_out + gid * row;
     for (int l = 0; l < fs.n; ++l) {
         int h = fs.h[l], w = fs.w[l];
@@ -153,8 +156,23 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
     return gens_launch_status("gens_lookup_feature_fwd");
 }
 
+static int lookup_feature_bwd_run(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts, const float* g_out,
+                                  const int64_t* index, int64_t n, const int32_t* n_device, float* const* g_feats, float* g_imgs, void* stream);
+
 extern "C" int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts,
                                        const float* g_out, int64_t n, float* const* g_feats, float* g_imgs, void* stream) {
+    return lookup_feature_bwd_run(hw, n_levels, w2c, intr, nv, pts, g_out, nullptr, n, nullptr, g_feats, g_imgs, stream);
+}
+
+// g_out (n, S, 3 + 4 L) stays COMPACT (row i = the i-th selected point); the point itself is pts[index[i]], only min(n, *n_device) rows exist
+extern "C" int gens_lookup_feature_bwd_idx(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts,
+                                           const float* g_out, const int64_t* index, int64_t n, const int32_t* n_device, float* const* g_feats,
+                                           float* g_imgs, void* stream) {
+    return lookup_feature_bwd_run(hw, n_levels, w2c, intr, nv, pts, g_out, index, n, n_device, g_feats, g_imgs, stream);
+}
+
+static int lookup_feature_bwd_run(const int* hw, int n_levels, const float* w2c, const float* intr, int nv, const float* pts, const float* g_out,
+                                  const int64_t* index, int64_t n, const int32_t* n_device, float* const* g_feats, float* g_imgs, void* stream) {
     MapSet fs;
     if (int e = gens_fill_maps("gens_lookup_feature_bwd", &fs, nullptr, hw, n_levels)) return e;
     GENS_CHECK_ARG(nv >= 2 && nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "gens_lookup_feature_bwd: nv=%d not in 2..%d", nv, GENS_MAX_VIEWS);
@@ -164,6 +182,6 @@ extern "C" int gens_lookup_feature_bwd(const int* hw, int n_levels, const float*
     if (n == 0) return 0;
     if (g_feats)
         for (int l = 0; l < n_levels; ++l) fs.grad[l] = g_feats[l];
-    lookup_feature_bwd_k<<<gens_blocks(n * (nv - 1) * 16, 256), 256, 0, (hipStream_t)stream>>>(fs, g_imgs, w2c, intr, nv, pts, g_out, n);
+    lookup_feature_bwd_k<<<gens_blocks(n * (nv - 1) * 16, 256), 256, 0, (hipStream_t)stream>>>(fs, g_imgs, w2c, intr, nv, pts, g_out, index, n, n_device);
     return gens_launch_status("gens_lookup_feature_bwd");
 }

@@ -100,17 +100,19 @@ SIGNATURES = {
     "gens_mc_emit": [_p, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_sdf_mlp": [_pp, _ip, _i, _pp, _pp, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_mlp_dev": [_pp, _ip, _i, _pp, _pp, _p, _p, _f, _p, _p, _l, _p, _p, _p, _p],
-    "gens_blend_train_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _p, _p],
-    "gens_blend_train_bwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _l, _p, _pp, _pp, _p, _p, _p],
+    "gens_blend_train_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _p, _p],
+    "gens_blend_train_bwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _pp, _pp, _p, _p, _p],
+    "gens_lookup_feature_bwd_idx": [_ip, _i, _p, _p, _i, _p, _p, _p, _l, _p, _pp, _p, _p],
+    "gens_gemm_tn_batch_live": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _i, _i, _p, _p, _p],
     "gens_sdf_train_pack": [_pp, _pp, _i, _pp, _pp, _p],
-    "gens_sdf_train_fwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _l, _p, _p, _p, _p, _p],
-    "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gens_sdf_train_fwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p],
+    "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_gemm_tn_batch": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _p, _p],
-    "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _l, _pp, _p],
+    "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _pp, _p],
     "gens_scene_setup": [_p, _p, _i, _p, _p],
     "gens_pack_maps": [_pp, _pp, _ip, _i, _p],
     "gens_unpack_maps": [_pp, _pp, _ip, _i, _p],
-    "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p],
+    "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p],
     "gens_tv_levels_blocks": [_ip, _i],
     "gens_tv_levels_fwd": [_pp, _pp, _ip, _i, _p, _p, _p],
     "gens_tv_levels_bwd": [_pp, _pp, _ip, _i, _p, _p, _pp, _p],

@@ -195,7 +195,10 @@ class ImplicitSurface(nn.Module):
             return None
         if not any(p.requires_grad for p in self.sdf_network.parameters()) and not any(v.requires_grad for v in scene.volumes):
             return None
-        return self.sdf_network.train_step(scene.volumes, scene.volumes_nograd())
+        cached = getattr(scene, "_train_net_cache", None)        # one evaluator (weight norm + stream packing) per scene object = per step
+        if cached is None:
+            cached = scene._train_net_cache = (self.sdf_network.train_step(scene.volumes, scene.volumes_nograd()),)
+        return cached[0]
 
     def _split_half_overflowed(self):
         """True if a split-half launch met a value outside the half range since the last check (one device sync)."""
@@ -252,24 +255,118 @@ class ImplicitSurface(nn.Module):
     # ----------------------------------------------------------------------------------------------------------
     # render_core
     # ----------------------------------------------------------------------------------------------------------
+    def _host_draws(self, dev, b=None):
+        """The host-generator draws of a render in the reference's order -- torch.rand([B, 1]) (:362, when b is given), then
+        torch.rand([1024, 3]) (:256) -- staged through ONE page-locked buffer: a pageable host-to-device copy waits for the stream to drain
+        on ROCm (the launch queue ran empty once per step), a pinned one is just another asynchronous launch.  -> (t_rand (B,1) or None,
+        pts_random (1024,3) in [-1, 1)) on the device.  The ` * 2 - 1` of :256 happens on the host: the same two float32 operations."""
+        n_t = 0 if b is None else b
+        buf = getattr(self, "_pinned_draws", None)
+        if buf is None or buf.numel() != n_t + 3 * N_RANDOM_PTS:
+            buf = torch.empty(n_t + 3 * N_RANDOM_PTS, dtype=torch.float32, pin_memory=True)
+            self._pinned_draws = buf
+            self._pinned_draws_event = None
+        elif self._pinned_draws_event is not None:
+            self._pinned_draws_event.synchronize()           # the previous step's copy out of this buffer has long finished
+        if n_t:
+            buf[:n_t] = torch.rand([b, 1]).reshape(-1)
+        buf[n_t:] = (torch.rand([N_RANDOM_PTS, 3]) * 2 - 1).reshape(-1)
+        on_dev = buf.to(dev, non_blocking=True)
+        self._pinned_draws_event = torch.cuda.Event()
+        self._pinned_draws_event.record()
+        return (on_dev[:n_t].view(b, 1) if n_t else None), on_dev[n_t:].view(N_RANDOM_PTS, 3)
+
+    def _train_fused_ok(self, scene, net, lean):
+        """The fused TRAINING path of render_core: K17 (net) + K18 on a device-side selection (ops.StepPoints), no host synchronisation."""
+        if lean or net is None or not self.fused_train or not torch.is_grad_enabled():
+            return False
+        nf = len(scene.views.feat_tex)
+        return (ops.BlendPlan.supported(self.color_network) and nf <= 5 and self.color_network.ray_dir_fc[2].weight.shape[0] == 3 + 4 * nf
+                and scene.views.nv >= 2)
+
+    def _render_core_train(self, rays_o, rays_d, z_vals, sample_dist, scene, intrs, c2ws, cos_anneal_ratio, step, net, pts_random, extra_pts,
+                           extra_valid):
+        """render_core (:152-349) in training mode on the fused kernels, with the masked evaluation's selection left on the device:
+        [ray samples | random points | extra (pseudo) points] share ONE K17 forward / backward pair; dense outputs carry the reference's
+        defaults for unselected rows (Q8).  extra_valid: uint8 flags of extra_pts, or None (all of them are evaluated)."""
+        b, n = z_vals.shape
+        dev = z_vals.device
+        n_ray, n_r = b * n, pts_random.shape[0]
+        n_x = 0 if extra_pts is None else extra_pts.shape[0]
+        total = n_ray + n_r + n_x
+        pts_all = torch.empty(total, 3, device=dev, dtype=torch.float32)
+        valid_all = torch.empty(total, device=dev, dtype=torch.uint8)
+        ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist, out=(pts_all[:n_ray], valid_all[:n_ray]))
+        pts_all[n_ray:n_ray + n_r].copy_(pts_random)
+        if n_x:
+            pts_all[n_ray + n_r:].copy_(extra_pts)
+            if extra_valid is None:
+                valid_all[n_ray + n_r:].fill_(1)
+            else:
+                valid_all[n_ray + n_r:].copy_(extra_valid)
+        s_views = scene.views.nv - 1
+        sel = ops.StepPoints(pts_all, valid_all, n_ray, n_r, s_views, z=z_vals, variance=self.deviation_network.variance)
+        y_all, g_all, s_all = net(pts_all, sel)
+        sampled_color, src_vis = ops.blend_train(self.color_network, scene.views, pts_all, sel)
+        inv_s = ops.inv_s_from(self.deviation_network.variance, sel.scalars)
+        comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, y_all[:n_ray], g_all[:n_ray], s_all[:n_ray], sampled_color, valid_all[:n_ray],
+                             src_vis, inv_s, cos_anneal_ratio, scene.ref_rotation(), z_max=sel.scalars[0:1])
+        out = {
+            "color_fine": comp["color"],
+            "render_depth": comp["depth"],
+            "normal": comp["normal"],
+            "weights": comp["weights"],
+            "weight_sum": comp["wsum"][:, None],
+            "weight_max": comp["wmax"][:, None],
+            "inside_sphere": comp["inside"],
+            "valid_mask": comp["valid"].bool()[:, None],
+            "mid_inside_sphere": comp["mid_in"][:, None],
+            "sdf_depth": comp["sdf_depth"][:, None],
+            "gradients": g_all[:n_ray].reshape(b, n, 3),
+            "s_val": sel.scalars[2:3].detach().reshape(1, 1).expand(b * n, 1),
+            "gradient_error": comp["eik_num"].sum() / (comp["eik_den"].sum() + 1e-5),
+            "smooth_error": torch.linalg.norm(comp["smooth_vec"], ord=2, dim=-1).abs().mean(),
+            "sparse_sdf": torch.cat([y_all[n_ray:n_ray + n_r], y_all[:n_ray]]),
+            "tv_reg": self.tv_regularization(scene.volumes, scene.mask_volumes),
+        }
+        if n_x:
+            out["_extra_sdf_dense"] = y_all[n_ray + n_r:]
+        out["_step_counts"] = sel.counts
+        pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
+        g0 = net.first_order(pts_sdf0).reshape(b, 1, 3)
+        g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
+        g0 = g0 / torch.where(g0_norm <= 0, torch.full_like(g0_norm, 1e-8), g0_norm)
+        normals_ref = (g0 @ c2ws[0, :3, :3]).detach()
+        warp = scene.warp_features(use_match=not (step is None or step < 5))
+        out["ref_gray_val"], out["sampled_gray_val"] = surface_patch_warp(pts_sdf0, normals_ref, warp, intrs, c2ws)
+        return out
+
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None, extra_pts=None, net=None):
+                    cos_anneal_ratio, step, scene=None, lean=False, pts_random=None, extra_pts=None, net=None, extra_valid=None):
         """Everything after sampling (:152-349).  `lean` (validate only) skips the quantities validate discards:
         second derivatives, random-point SDF, TV, the surface-point gradient and the patch warp.
         extra_pts: more points whose SDF the caller wants from the same network pass (forward()'s pseudo points, :484-497):
-        returned under the private key "_extra_sdf"."""
+        returned under the private key "_extra_sdf" -- or, with extra_valid (their uint8 mask flags, left on the device), as the dense
+        "_extra_sdf_dense" (zeros where the flag is clear, the reference's pseudo_sdf) of the fused training path."""
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
         b, n = z_vals.shape
         dev = z_vals.device
+        if net is None:                                # training: one fused evaluator for every SDF query of this step
+            net = self._train_net(scene, lean)
+        if self._train_fused_ok(scene, net, lean) and (features is not None):
+            if pts_random is None:
+                pts_random = self._host_draws(dev)[1]                                      # CPU generator, :256
+            return self._render_core_train(rays_o, rays_d, z_vals, sample_dist, scene, intrs, c2ws, cos_anneal_ratio, step, net, pts_random,
+                                           extra_pts, extra_valid)
+        if extra_valid is not None:                    # the generic path evaluates the selected extra points only
+            extra_pts = extra_pts[torch.nonzero(extra_valid)[:, 0]]
         need_vol_grad = torch.is_grad_enabled() and any(v.requires_grad for v in scene.volumes)
         vols = scene.volumes if need_vol_grad else scene.volumes_nograd()
 
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
         plan = self._fused_plan(vols) if lean else None
         bplan = self._fused_blend_plan(scene.views) if lean else self._fused_blend_plan(scene.views, features, imgs)
-        if net is None:                                # training: one fused evaluator for every SDF query of this step
-            net = self._train_net(scene, lean)
         sdf_random = extra_sdf = None
         if plan is not None and bplan is not None:     # fully fused inference: nothing in this branch synchronises with the host
             idx, count = ops.compact_valid(valid)
@@ -381,11 +478,17 @@ class ImplicitSurface(nn.Module):
         return cached[1]
 
     def render(self, rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws, cos_anneal_ratio, step,
-               scene=None, lean=False, t_rand=None, pts_random=None, extra_pts=None):
+               scene=None, lean=False, t_rand=None, pts_random=None, extra_pts=None, extra_valid=None):
         if scene is None:
             scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
         b = len(rays_o)
         dev = rays_o.device
+        net = self._train_net(scene, lean)
+        if self.perturb > 0 and t_rand is None and pts_random is None and self._train_fused_ok(scene, net, lean):
+            pending = getattr(self, "_jitter_ahead", None)
+            if pending is not None:
+                pending[1].join()
+            t_rand, pts_random = self._host_draws(dev, b)          # both host draws of the step (:362, then :256) through one pinned copy
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         sample_dist = 2.0 / self.n_samples                                                  # unit-sphere assumption (:355)
         steps = self._coarse_steps(dev)
@@ -399,11 +502,11 @@ class ImplicitSurface(nn.Module):
                 t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
             z_vals = z_vals + (t_rand.to(dev, non_blocking=True) - 0.5) * 2.0 / self.n_samples
         z_vals = z_vals.contiguous()
-        net = self._train_net(scene, lean)
         if self.n_importance > 0:
             z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene, net)
         return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
-                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts, net=net)
+                                cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts, net=net,
+                                extra_valid=extra_valid)
 
     # ----------------------------------------------------------------------------------------------------------
     # geometry + validation
@@ -570,11 +673,53 @@ class ImplicitSurface(nn.Module):
             setattr(self, slot, buf)
         return buf
 
+    def _defer_checks(self, counts, cam_status):
+        """Host-side checks of a fused training step, taken off its critical path: the counts of gens_compact_points and the scene set-up's
+        status word travel to page-locked memory behind the step's launches."""
+        host = getattr(self, "_deferred_host", None)
+        if host is None:
+            host = self._deferred_host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        host[:3].copy_(counts, non_blocking=True)
+        host[3:4].copy_(cam_status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._deferred = ev
+
+    def check_deferred(self):
+        """Raise what the last fused training step would have raised in the reference (no valid pseudo point, implicit_surface.py:494-495; a
+        singular camera matrix, torch.inverse).  Called at the start of every forward(); call it yourself after the last step of a loop."""
+        ev = getattr(self, "_deferred", None)
+        if ev is None:
+            return
+        self._deferred = None
+        ev.synchronize()
+        host = self._deferred_host
+        if int(host[3]) != 0:
+            raise RuntimeError("linalg.inv: a camera pose or intrinsics matrix of the previous step's scene is singular")
+        if int(host[2]) < 1:
+            raise RuntimeError("No valid pseudo pts!")
+
     def forward(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):
         imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
         rays_o, rays_d, near, far = ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"]
         scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)
+        self.check_deferred()                          # what the previous fused training step left to verify (see below)
         pseudo_pts = idx = None
+        fused = mode != "val" and "pseudo_pts" in ipts and self._train_fused_ok(scene, self._train_net(scene, False), False)
+        if fused:
+            # (:484-497) on the fused training path the pseudo points ride on the render's network pass with their mask flags LEFT ON THE
+            # DEVICE: nothing is read back in the middle of the step.  The reference's `raise "No valid pseudo pts!"` (:494-495) needs the
+            # count on the host; it travels behind the step through a page-locked copy and is raised by check_deferred() -- at the next
+            # forward() at the latest (such a step's pseudo_sdf is all zeros, so its loss term and gradient are zero).
+            pseudo_pts = ipts["pseudo_pts"].float().contiguous()
+            flags = torch.empty(pseudo_pts.shape[0], device=pseudo_pts.device, dtype=torch.uint8)
+            ops.lookup_mask(pseudo_pts, scene.masks, out=flags)
+            outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
+                                  cos_anneal_ratio, step, scene=scene, extra_pts=pseudo_pts, extra_valid=flags)
+            counts = outputs.pop("_step_counts")
+            outputs["pseudo_sdf"] = outputs.pop("_extra_sdf_dense")
+            self._defer_checks(counts, scene.views.cams.status)
+            return outputs
         if "pseudo_pts" in ipts:                       # (:484-497) the mask look-up draws nothing from the generator, so it can come first
             pseudo_pts = ipts["pseudo_pts"].float()
             valid = ops.lookup_mask(pseudo_pts, scene.masks)
@@ -589,6 +734,7 @@ class ImplicitSurface(nn.Module):
             outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                                   cos_anneal_ratio, step, scene=scene, extra_pts=None if idx is None else pseudo_pts[idx])
             extra = outputs.pop("_extra_sdf", None)
+            outputs.pop("_step_counts", None)
         if pseudo_pts is not None:
             if extra is None:
                 vols = scene.volumes if any(v.requires_grad for v in scene.volumes) else scene.volumes_nograd()

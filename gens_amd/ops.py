@@ -386,12 +386,13 @@ def lookup_volume(pts, volumes):
 # ------------------------------------------------------------------------------------------------------------------
 # K3  nearest visibility look-up, ray point generation
 # ------------------------------------------------------------------------------------------------------------------
-def lookup_mask(pts, masks, return_values=False):
-    """-> valid (N,) bool [, values (N,L) float]: lookup_volume(pts, mask_volumes, 'nearest') (projector.py:231,240)."""
+def lookup_mask(pts, masks, return_values=False, out=None):
+    """-> valid (N,) bool [, values (N,L) float]: lookup_volume(pts, mask_volumes, 'nearest') (projector.py:231,240).
+    out: optional (N,) uint8 buffer (a slice of a step's flag array) the flags are written to."""
     ms = masks if isinstance(masks, VolumeSet) else VolumeSet.masks(masks)
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
     n = pts.shape[0]
-    valid = torch.empty(n, device=pts.device, dtype=torch.uint8)
+    valid = out if out is not None else torch.empty(n, device=pts.device, dtype=torch.uint8)
     vals = torch.empty(n, ms.n, device=pts.device, dtype=_f32) if return_values else None
     L.call("gens_lookup_mask_nearest", ms.table, ms.dim_table, ms.n, L.ptr(pts), n, L.ptr(valid, torch.uint8), L.ptr(vals), L.stream())
     return (valid.bool(), vals) if return_values else valid.bool()
@@ -419,12 +420,12 @@ def _mask_args(masks):
     return ms.table, ms.dim_table, ms.n, 0
 
 
-def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0):
-    """pts (B*n,3) = o + d * (z or section mid-points), valid (B*n,) bool."""
+def ray_points(rays_o, rays_d, z, masks, mid=False, sample_dist=0.0, out=None):
+    """pts (B*n,3) = o + d * (z or section mid-points), valid (B*n,) bool.  out: optional (pts, valid uint8) buffers to write (slices of a
+    step's point / flag arrays)."""
     table, dims, nl, bits = _mask_args(masks)
     b, n = z.shape
-    pts = torch.empty(b * n, 3, device=z.device, dtype=_f32)
-    valid = torch.empty(b * n, device=z.device, dtype=torch.uint8)
+    pts, valid = out if out is not None else (torch.empty(b * n, 3, device=z.device, dtype=_f32), torch.empty(b * n, device=z.device, dtype=torch.uint8))
     L.call("gens_ray_points", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), b, n, 1 if mid else 0, float(sample_dist), table,
            dims, nl, bits, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(), nbytes=b * n * 17 + b * 24)
     return pts, valid.view(torch.bool)
@@ -605,12 +606,32 @@ class _Composite(torch.autograd.Function):
         return (g_sdf, g_grad, g_col, g_smooth, g_inv_s.sum().reshape(1)) + (None,) * 9
 
 
+class _InvS(torch.autograd.Function):
+    """inv_s = clip(exp(10 variance), 1e-6, 1e6) (variance_network.py:11, implicit_surface.py:206) whose value an earlier launch of the step
+    already computed (StepPoints.scalars = [z_max, inv_s, 1 / inv_s, inside the clip range]); only the backward is left to do."""
+
+    @staticmethod
+    def forward(ctx, variance, scalars):
+        ctx.save_for_backward(scalars)
+        return scalars[1:2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        scalars, = ctx.saved_tensors
+        return (g * (scalars[1:2] * scalars[3:4] * 10.0)).reshape(()), None
+
+
+def inv_s_from(variance, scalars):
+    return _InvS.apply(variance, scalars)
+
+
 COMPOSITE_KEYS = ("color", "normal", "depth", "weights", "wsum", "eik_num", "smooth_vec", "z_cross", "sdf_depth", "wmax", "mid_in", "eik_den",
                   "inside", "valid", "cross_idx")
 
 
-def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, voxel_mask, src_vis, inv_s, cos_anneal, c2w_ref):
-    """Everything render_core computes after the networks have run; returns a dict keyed by COMPOSITE_KEYS."""
+def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, voxel_mask, src_vis, inv_s, cos_anneal, c2w_ref, z_max=None):
+    """Everything render_core computes after the networks have run; returns a dict keyed by COMPOSITE_KEYS.
+    z_max: optional (1,) device tensor holding max(z) (implicit_surface.py:301) when an earlier launch already reduced it."""
     b, n = z.shape
     # R_ref^-1 (implicit_surface.py:242,245) travels by value in the launch block; a list from Scene.ref_rotation() avoids the
     # device->host read (a synchronisation) on every ray chunk
@@ -619,9 +640,15 @@ def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, vox
     else:
         rot = _c(inv(c2w_ref[:3, :3].to(_f32)).reshape(-1))
     z = _c(z.detach().to(_f32))
-    z_max = z.max().reshape(1)                                                  # implicit_surface.py:301
-    vm = _c(voxel_mask.reshape(b * n).to(torch.uint8))
-    sv = _c(src_vis.reshape(b * n, -1).to(torch.uint8)) if src_vis is not None else None
+    if z_max is None:
+        z_max = z.max().reshape(1)                                              # implicit_surface.py:301
+    u8 = torch.uint8
+    vm = voxel_mask.reshape(b * n)
+    vm = _c(vm.view(u8) if vm.dtype == torch.bool else vm.to(u8))
+    sv = None
+    if src_vis is not None:
+        sv = src_vis.reshape(b * n, -1)
+        sv = _c(sv.view(u8) if sv.dtype == torch.bool else sv.to(u8))
     outs = _Composite.apply(sdf.reshape(b, n), gradients.reshape(b, n, 3), color.reshape(b, n, 3),
                             smooth.reshape(b, n, 3) if smooth is not None else None, inv_s.reshape(1), _c(rays_o.to(_f32)),
                             _c(rays_d.to(_f32)), z, vm, sv, z_max, float(sample_dist), float(cos_anneal), rot)
@@ -1248,20 +1275,26 @@ class SdfTrainStep:
             self.w_last = _c(weights[6].detach().to(_f32)[0].clone())
             self.b_last = _c(biases[6].detach().to(_f32)[:1].clone())
 
-    def _forward(self, pts):
+    def _forward(self, pts, sel=None):
+        """sel (StepPoints): evaluate pts[sel.idx[:count]] with the count left on the device and write rows sel.idx[i] of sel's dense
+        outputs (their other rows already hold the reference's defaults); None: every row of pts, fresh outputs."""
         n = pts.shape[0]
         dev = pts.device
         stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 0), device=dev, dtype=torch.uint8)
-        y, g, s = (torch.empty(n, k, device=dev, dtype=_f32) for k in (1, 3, 3))
+        if sel is None:
+            y, g, s = (torch.empty(n, k, device=dev, dtype=_f32) for k in (1, 3, 3))
+            idx = cnt = None
+        else:
+            y, g, s, idx, cnt = sel.y, sel.g, sel.s, sel.idx, sel.counts[0:1]
         fe = 20 * self.n_levels
         flops = 4 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))
         L.call("gens_sdf_train_fwd", self.packed.table, self.packed.dim_table, self.n_levels, self.wf_table, self.wb_table, L.ptr(self.w_last),
-               L.ptr(self.b_last), L.ptr(pts), n, L.ptr(stash, torch.uint8), L.ptr(y), L.ptr(g), L.ptr(s), L.stream(), nbytes=n * 40,
-               flops=n * flops)
+               L.ptr(self.b_last), L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr(stash, torch.uint8), L.ptr(y), L.ptr(g),
+               L.ptr(s), L.stream(), nbytes=n * 40, flops=n * flops, live=None if cnt is None else (cnt, n))
         return y, g, s
 
-    def __call__(self, pts):
-        return _SdfTrain.apply(_c(pts.detach().reshape(-1, 3).to(_f32)), self, *self.weights, *self.biases, *self.volumes)
+    def __call__(self, pts, sel=None):
+        return _SdfTrain.apply(_c(pts.detach().reshape(-1, 3).to(_f32)), self, sel, *self.weights, *self.biases, *self.volumes)
 
     @torch.no_grad()
     def first_order(self, pts):
@@ -1270,32 +1303,34 @@ class SdfTrainStep:
 
 class _SdfTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts, step, *tensors):
-        ctx.step = step
+    def forward(ctx, pts, step, sel, *tensors):
+        ctx.step, ctx.sel = step, sel
         ctx.save_for_backward(pts)
         ctx.shapes = [t.shape for t in tensors]
-        return step._forward(pts)
+        return step._forward(pts, sel)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, y_bar, g_bar, s_bar):
-        step = ctx.step
+        step, sel = ctx.step, ctx.sel
         pts, = ctx.saved_tensors
         n, dev = pts.shape[0], pts.device
+        idx, cnt = (None, None) if sel is None else (sel.idx, sel.counts[0:1])
         nl = step.n_levels
         cf, fe, kin = 4 * nl, 20 * nl, 128 + 20 * nl
         fep = step.kp - 128
         npad = (n + 31) // 32 * 32
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
-        lop, rh, re, r0 = f(4, npad, 6, 128), f(5, 4, npad, 128), f(4, npad, fep), f(4, npad, 32)
+        lop, rh, re, r0 = f(npad, 4, 6, 128), f(5, npad, 4, 128), f(npad, 4, fep), f(npad, 4, 32)      # point-major operand rows
         f_hat, mu_f, lam_f, w6p = f(npad, cf), f(npad, cf), f(npad, cf), f(npad // 32, step.kp)
         stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 1), device=dev, dtype=torch.uint8)
         cot = [None if t is None else _c(t.to(_f32)) for t in (y_bar, g_bar, s_bar)]
         flops = 8 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))
-        L.call("gens_sdf_train_bwd", step.packed.table, step.packed.dim_table, nl, step.wf_table, step.wb_table, L.ptr(step.w_last), L.ptr(pts), n,
-               L.ptr(cot[0]), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(stash, torch.uint8), L.ptr(lop), L.ptr(rh), L.ptr(re), L.ptr(r0), L.ptr(f_hat),
-               L.ptr(mu_f), L.ptr(lam_f), L.ptr(w6p), L.stream(), nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)),
-               flops=n * flops)
+        live = None if cnt is None else (cnt, n)
+        L.call("gens_sdf_train_bwd", step.packed.table, step.packed.dim_table, nl, step.wf_table, step.wb_table, L.ptr(step.w_last), L.ptr(pts),
+               L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr(cot[0]), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(stash, torch.uint8), L.ptr(lop),
+               L.ptr(rh), L.ptr(re), L.ptr(r0), L.ptr(f_hat), L.ptr(mu_f), L.ptr(lam_f), L.ptr(w6p), L.stream(),
+               nbytes=n * (40 + 4 * (4 * 6 * 128 + 6 * 4 * 128 + 4 * fep + 4 * 32 + 3 * cf)), flops=n * flops, live=live)
         # weight gradients: eleven products over the 4 * npad operand rows in ONE launch (rows of padding points are zero on one side of
         # every product).  Per layer l = 1..5 the hidden columns (lop_l^T rh_l) and the conditioning columns + bias (lop_l^T re) are
         # neighbours in the unit list, so the second product finds lop_l's slab in L2 instead of reading it from HBM again; layer 0 last.
@@ -1313,14 +1348,19 @@ class _SdfTrain(torch.autograd.Function):
         ldb.append(32)
         ms.append(128)
         ns.append(32)
-        cnt = len(ms)
+        n_prod = len(ms)
         mi, ni = L.int_table(ms), L.int_table(ns)
-        ws = f(L.load().gens_gemm_tn_batch_workspace(cnt, mi, ni, k))
+        ws = f(L.load().gens_gemm_tn_batch_workspace(n_prod, mi, ni, k))
         sizes = [m * n_ for m, n_ in zip(ms, ns)]
         cc = f(sum(sizes))
         tab = lambda v: C.cast((C.c_void_p * len(v))(*v), C.POINTER(C.c_void_p))  # noqa: E731
-        L.call("gens_gemm_tn_batch", cnt, tab(a_ptr), L.int_table([768] * cnt), tab(b_ptr), L.int_table(ldb), mi, ni, k,
-               L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 + 32 + 5 * 128 + fep), flops=2 * k * sum(sizes))
+        if idx is None:
+            L.call("gens_gemm_tn_batch", n_prod, tab(a_ptr), L.int_table([768] * n_prod), tab(b_ptr), L.int_table(ldb), mi, ni, k,
+                   L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 + 32 + 5 * 128 + fep), flops=2 * k * sum(sizes))
+        else:       # only the operand rows of the points that exist (32 points -> 128 rows per workgroup of the backward launch)
+            L.call("gens_gemm_tn_batch_live", n_prod, tab(a_ptr), L.int_table([768] * n_prod), tab(b_ptr), L.int_table(ldb), mi, ni, k,
+                   L.ptr(cnt, torch.int32), 32, 128, L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 + 32 + 5 * 128 + fep),
+                   flops=2 * k * sum(sizes), live=live, label="gens_gemm_tn_batch")
         parts, off = [], 0
         for m, n_ in zip(ms, ns):
             parts.append(cc[off:off + m * n_].view(m, n_))
@@ -1341,11 +1381,12 @@ class _SdfTrain(torch.autograd.Function):
         g_b.append(b6)
         # volume gradients
         g_vols = [None] * nl
-        if any(ctx.needs_input_grad[2 + 14:]):
+        if any(ctx.needs_input_grad[3 + 14:]):
             g_vols = [torch.zeros(s, device=dev, dtype=_f32) for s in ctx.shapes[14:]]
             L.call("gens_sdf_train_scatter", step.packed.dim_table, nl, L.ptr(pts), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(f_hat), L.ptr(mu_f),
-                   L.ptr(lam_f), n, L.ptr_table(g_vols), L.stream(), nbytes=n * (36 + 3 * 4 * cf))
-        return (None, None, *g_w, *g_b, *g_vols)
+                   L.ptr(lam_f), L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr_table(g_vols), L.stream(), nbytes=n * (36 + 3 * 4 * cf),
+                   live=live)
+        return (None, None, None, *g_w, *g_b, *g_vols)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1738,23 +1779,29 @@ class _BlendTrain(torch.autograd.Function):
     of its rows and walks the layers in reverse, one batched K14 launch for the eleven [dW | db], K4's backward for the maps."""
 
     @staticmethod
-    def forward(ctx, pts, views, *tensors):
+    def forward(ctx, pts, views, sel, *tensors):
         params, imgs_tex, feat_tex = tensors[:23], tensors[23], tensors[24:]
-        n, s, nl = pts.shape[0], views.nv - 1, len(feat_tex)
+        # sel (StepPoints): the ray samples among sel.idx[:count_ray] (the list is sorted, ray samples first), dense outputs in sel
+        n, s, nl = (pts.shape[0] if sel is None else sel.n_ray), views.nv - 1, len(feat_tex)
         dev = pts.device
+        idx, cnt = (None, None) if sel is None else (sel.idx, sel.counts[1:2])
         w = [_c(p.detach().to(_f32)).reshape(-1) if p.dim() == 0 else _c(p.detach().to(_f32)) for p in params]
         feats = [aligned16(f.detach()) for f in feat_tex]
         imgs = aligned16(imgs_tex.detach())
         hw = [d for f in feats for d in f.shape[1:3]]
-        rgb = torch.empty(n, 3, device=dev, dtype=_f32)
-        vis = torch.empty(n, s, device=dev, dtype=torch.uint8)
+        if sel is None:
+            rgb = torch.empty(n, 3, device=dev, dtype=_f32)
+            vis = torch.empty(n, s, device=dev, dtype=torch.uint8)
+        else:
+            rgb, vis = sel.rgb, sel.vis
         f = 3 + 4 * nl
         flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
         ctx.args = (L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(imgs, align=16), L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w),
-                    views.nv, L.ptr_table(w), L.ptr(pts), n)
-        ctx.keep = (feats, imgs, w, views, pts, hw)
+                    views.nv, L.ptr_table(w), L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32))
+        ctx.keep = (feats, imgs, w, views, pts, hw, idx, cnt)
         ctx.meta = (n, s, nl, f, flops, [p.shape for p in params], [t.shape for t in feat_tex], imgs_tex.shape)
-        L.call("gens_blend_train_fwd", *ctx.args, L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(), nbytes=n * (24 + s), flops=n * flops)
+        ctx.live = None if cnt is None else (cnt, n)
+        L.call("gens_blend_train_fwd", *ctx.args, L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(), nbytes=n * (24 + s), flops=n * flops, live=ctx.live)
         ctx.mark_non_differentiable(vis)
         return rgb, vis
 
@@ -1762,7 +1809,7 @@ class _BlendTrain(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb, _g_vis):
         n, s, nl, f, flops, pshapes, fshapes, ishape = ctx.meta
-        feats, imgs, w, views, pts, hw = ctx.keep
+        feats, imgs, w, views, pts, hw, idx, cnt = ctx.keep
         dev = pts.device
         rows = L.load().gens_blend_train_rows(n, views.nv)
         ins = [4, 16, 3 * f, 64, 32, 32, 32, 32, 37, 16, 8]
@@ -1771,18 +1818,23 @@ class _BlendTrain(torch.autograd.Function):
         ev = lambda x: (x + 1) // 2 * 2  # noqa: E731      (even widths: the batched product then reads 8 bytes per lane)
         r_ops = [e(rows, ev(k + 1)) for k in ins]
         l_ops = [e(rows, ev(m)) for m in outs]
-        want_maps = any(ctx.needs_input_grad[2 + 23:])
+        want_maps = any(ctx.needs_input_grad[3 + 23:])
         g_feat = e(n, s, f) if want_maps else None
         s_part = e(rows // 32)
         L.call("gens_blend_train_bwd", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr_table(r_ops), L.ptr_table(l_ops), L.ptr(g_feat), L.ptr(s_part),
-               L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops)
+               L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops, live=ctx.live)
         # [dW_l | db_l] = l_ops[l]^T r_ops[l]: eleven products over the same rows in one launch
         ms, ns = [ev(m) for m in outs], [ev(k + 1) for k in ins]
         mi, ni = L.int_table(ms), L.int_table(ns)
         ws = e(L.load().gens_gemm_tn_batch_workspace(11, mi, ni, rows))
         cc = e(sum(m * k for m, k in zip(ms, ns)))
-        L.call("gens_gemm_tn_batch", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(ws), L.ptr(cc), L.stream(),
-               nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)))
+        if cnt is None:
+            L.call("gens_gemm_tn_batch", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(ws), L.ptr(cc), L.stream(),
+                   nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)))
+        else:       # floor(32 / S) points -> 32 operand rows per workgroup of the backward launch
+            L.call("gens_gemm_tn_batch_live", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(cnt, torch.int32), 32 // s, 32,
+                   L.ptr(ws), L.ptr(cc), L.stream(), nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)),
+                   live=ctx.live, label="gens_gemm_tn_batch")
         grads, off = [], 0
         for l, (m, k) in enumerate(zip(ms, ns)):
             c = cc[off:off + m * k].view(m, k)
@@ -1792,20 +1844,46 @@ class _BlendTrain(torch.autograd.Function):
         grads.append(s_sign * s_part.sum())
         g_imgs, g_feats = None, [None] * nl
         if want_maps:
-            want_img = ctx.needs_input_grad[2 + 23]
-            want_feat = any(ctx.needs_input_grad[2 + 24:])
+            want_img = ctx.needs_input_grad[3 + 23]
+            want_feat = any(ctx.needs_input_grad[3 + 24:])
             g_feats_t = [torch.zeros(sh, device=dev, dtype=_f32) for sh in fshapes] if want_feat else None
             g_imgs = torch.zeros(ishape, device=dev, dtype=_f32) if want_img else None
-            L.call("gens_lookup_feature_bwd", L.int_table(hw), nl, L.ptr(views.w2c), L.ptr(views.intr), views.nv, L.ptr(pts), L.ptr(g_feat), n,
-                   L.ptr_table(g_feats_t), L.ptr(g_imgs), L.stream())
+            L.call("gens_lookup_feature_bwd_idx", L.int_table(hw), nl, L.ptr(views.w2c), L.ptr(views.intr), views.nv, L.ptr(pts), L.ptr(g_feat),
+                   L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr_table(g_feats_t), L.ptr(g_imgs), L.stream(), label="gens_lookup_feature_bwd")
             if want_feat:
                 g_feats = g_feats_t
-        return (None, None, *grads, g_imgs, *g_feats)
+        return (None, None, None, *grads, g_imgs, *g_feats)
 
 
-def blend_train(net, views, pts):
+def blend_train(net, views, pts, sel=None):
     """Colour of every point blended from the source views, differentiable with respect to the network and the maps:
-    -> (rgb (N,3), vis (N,S) bool).  pts (N,3) device float32 (no gradient flows to the points, as in the reference's call)."""
+    -> (rgb (N,3), vis (N,S) bool).  pts (N,3) device float32 (no gradient flows to the points, as in the reference's call).
+    sel (StepPoints): only the selected ray samples are evaluated (count on the device); rgb / vis are sel's dense arrays."""
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
-    rgb, vis = _BlendTrain.apply(pts, views, *blend_params(net), views.imgs_tex, *views.feat_tex)
+    rgb, vis = _BlendTrain.apply(pts, views, sel, *blend_params(net), views.imgs_tex, *views.feat_tex)
     return rgb, vis.bool()
+
+
+class StepPoints:
+    """The masked evaluation set of ONE training render (implicit_surface.py:174-191,256-257,484-497) with nothing read back to the host:
+    dense rows [ray samples | always-evaluated points | pseudo points] in one (N, 3) buffer, the selected rows as a device-side index list +
+    counts (gens_compact_points: the reference's nonzero + first-ten rescue), and the dense outputs of the two networks, whose unselected
+    rows the same launch fills with the reference's defaults (Q8).  The same launch computes max(z_vals) (:301) and
+    inv_s = clip(exp(10 variance), 1e-6, 1e6) (:206) into `scalars`."""
+
+    def __init__(self, pts_all, valid_all, n_ray, n_always, n_src, z=None, variance=None):
+        dev = pts_all.device
+        self.pts = pts_all
+        self.n, self.n_ray, self.n_always = int(pts_all.shape[0]), int(n_ray), int(n_always)
+        n = self.n
+        self.idx = torch.empty(n, device=dev, dtype=torch.int64)
+        self.counts = torch.empty(3, device=dev, dtype=torch.int32)
+        self.y, self.g, self.s = (torch.empty(n, k, device=dev, dtype=_f32) for k in (1, 3, 3))
+        self.rgb = torch.empty(self.n_ray, 3, device=dev, dtype=_f32)
+        self.vis = torch.empty(self.n_ray, n_src, device=dev, dtype=torch.uint8)
+        self.scalars = torch.empty(4, device=dev, dtype=_f32)
+        zc = None if z is None else _c(z.detach())
+        L.call("gens_compact_points", L.ptr(_c(valid_all), torch.uint8), self.n_ray, self.n_always, n, L.ptr(self.idx, torch.int64),
+               L.ptr(self.counts, torch.int32), L.ptr(self.y), L.ptr(self.g), L.ptr(self.s), L.ptr(self.rgb), L.ptr(self.vis, torch.uint8), n_src,
+               L.ptr(zc), 0 if zc is None else zc.numel(), L.ptr(None if variance is None else _c(variance.detach().reshape(1))), L.ptr(self.scalars),
+               L.stream(), nbytes=n * 9)

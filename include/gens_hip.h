@@ -142,6 +142,11 @@ int gens_lookup_feature_fwd(const float* const* feats, const int* hw, int n_leve
 int gens_lookup_feature_bwd(const int* hw, int n_levels, const float* w2c, const float* intr, int nv,
                             const float* pts, const float* g_out, int64_t n, float* const* g_feats, float* g_imgs,
                             void* stream);
+/* ... with g_out COMPACT (row i = the i-th selected point, as gens_blend_train_bwd writes it) while the point itself is pts[index[i]];
+ * only min(n, *n_device) rows exist. */
+int gens_lookup_feature_bwd_idx(const int* hw, int n_levels, const float* w2c, const float* intr, int nv,
+                                const float* pts, const float* g_out, const int64_t* index, int64_t n, const int32_t* n_device,
+                                float* const* g_feats, float* g_imgs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K5 + K6  ImplicitSurface.up_sample + sample_pdf(det=True)      (implicit_surface.py:14-44, 60-109)
@@ -295,15 +300,20 @@ int gens_sdf_value_f16_units(int n_levels);
  *     matrices (128 x 27, 128 x K, 101 x K, 128 x K x 3; K = 128 + 20 n_levels) and biases of lin0..lin5; writes the forward /
  *     transposed B streams wf[l] ([4][ceil((K_l + 1) / 8)][64] float4, bias in reduction row K_l) and wb[l] ([ceil(K_l / 32)][16][64]
  *     float4) that the other entry points (and gens_sdf_mlp) read.
- *   gens_sdf_train_fwd: pts (n, 3) -> y (n), g (n, 3) = dy/dx, s (n, 3) = d(sum_k g_k)/dx.  w_last: row 0 of lin6 (K floats),
- *     b_last: DEVICE pointer to its bias.  stash: scratch of gens_sdf_train_stash_bytes(n, 0) bytes.
- *   gens_sdf_train_bwd: cotangents y_bar (n), g_bar (n, 3), s_bar (n, 3) (NULL = zero) -> operand rows of the weight-gradient
- *     products, npad = 32 ceil(n / 32) rows each (rows >= n contribute zero):
- *       lop (4, npad, 6, 128), rh (5, 4, npad, 128), re (4, npad, KP - 128), r0 (4, npad, 32), KP = 8 ceil((K + 1) / 8):
- *       dL/dW_l[:, :128]  = sum_q lop[q, :, l, :]^T rh[l - 1, q]        (l = 1..5; layer 3's columns are [h_2 | pe] / sqrt 2)
- *       dL/dW_l[:, 128:K] , dL/db_l = sum_q lop[q, :, l, :]^T re[q]      (column K - 128 of re is the bias input)
- *       dL/dW_0, dL/db_0  = sum_q lop[q, :, 0, :]^T r0[q]               (column 27 = bias input)
- *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 32, KP): columns [0, K) and column K
+ *   index / n / n_device (all three entry points) as in gens_sdf_mlp: point i of the launch is pts[index[i]] and its results (cotangents)
+ *     live at row index[i] of the dense arrays; only min(n, *n_device) points exist -- the masked evaluation of
+ *     implicit_surface.py:174-191 with the count left on the device (gens_compact_points).  NULL index = identity, NULL n_device = n.
+ *   gens_sdf_train_fwd: pts -> y (N), g (N, 3) = dy/dx, s (N, 3) = d(sum_k g_k)/dx, written at index[i].  w_last: row 0 of lin6 (K
+ *     floats), b_last: DEVICE pointer to its bias.  stash: scratch of gens_sdf_train_stash_bytes(n, 0) bytes.
+ *   gens_sdf_train_bwd: cotangents y_bar (N), g_bar (N, 3), s_bar (N, 3) (NULL = zero; read at index[i]) -> operand rows of the
+ *     weight-gradient products, POINT-major: npad = 32 ceil(n / 32) points x 4 sweeps, the rows of the live points being the
+ *     contiguous range [0, 4 * 32 ceil(n_live / 32)) (rows of padding points inside it contribute zero, rows beyond it are NOT written:
+ *     pass the count to gens_gemm_tn_batch_live):
+ *       lop (npad, 4, 6, 128), rh (5, npad, 4, 128), re (npad, 4, KP - 128), r0 (npad, 4, 32), KP = 8 ceil((K + 1) / 8):
+ *       dL/dW_l[:, :128]  = lop[:, :, l, :]^T rh[l - 1]                  (l = 1..5; layer 3's columns are [h_2 | pe] / sqrt 2)
+ *       dL/dW_l[:, 128:K] , dL/db_l = lop[:, :, l, :]^T re               (column K - 128 of re is the bias input)
+ *       dL/dW_0, dL/db_0  = lop[:, :, 0, :]^T r0                         (column 27 = bias input)
+ *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 32, KP): columns [0, K) and column K (zero rows for dead workgroups)
  *     (gens_gemm_tn_batch runs the products in one launch) and f_hat, mu_f, lam_f (npad, 4 n_levels) for
  *     gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
  *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
@@ -312,15 +322,15 @@ int gens_sdf_value_f16_units(int n_levels);
 int64_t gens_sdf_train_stash_bytes(int64_t n, int backward);
 int gens_sdf_train_pack(const float* const* w, const float* const* b, int n_levels, float* const* wf, float* const* wb, void* stream);
 int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                       const float* const* wb, const float* w_last, const float* b_last, const float* pts, int64_t n,
-                       void* stash, float* y_out, float* g_out, float* s_out, void* stream);
+                       const float* const* wb, const float* w_last, const float* b_last, const float* pts, const int64_t* index,
+                       int64_t n, const int32_t* n_device, void* stash, float* y_out, float* g_out, float* s_out, void* stream);
 int gens_sdf_train_bwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
-                       const float* const* wb, const float* w_last, const float* pts, int64_t n, const float* y_bar,
-                       const float* g_bar, const float* s_bar, void* stash, float* lop, float* rh, float* re, float* r0,
-                       float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream);
+                       const float* const* wb, const float* w_last, const float* pts, const int64_t* index, int64_t n,
+                       const int32_t* n_device, const float* y_bar, const float* g_bar, const float* s_bar, void* stash, float* lop,
+                       float* rh, float* re, float* r0, float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream);
 int gens_sdf_train_scatter(const int* dims, int n_levels, const float* pts, const float* g_bar, const float* s_bar,
-                           const float* f_hat, const float* mu_f, const float* lam_f, int64_t n, float* const* g_vols,
-                           void* stream);
+                           const float* f_hat, const float* mu_f, const float* lam_f, const int64_t* index, int64_t n,
+                           const int32_t* n_device, float* const* g_vols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K7  lookup_feature + BlendingNetwork.forward fused, inference only
@@ -365,21 +375,25 @@ int gens_blend_views4_groups(int n_levels);
  *   weights: HOST array of 23 device pointers to the RAW nn.Linear parameters (row major (out, in)) in the order
  *     ray_dir_fc.0 W,b  ray_dir_fc.2 W,b  base_fc.0 W,b  base_fc.2 W,b  vis_fc.0 W,b  vis_fc.2 W,b  vis_fc2.0 W,b  vis_fc2.2 W,b
  *     rgb_fc.0 W,b  rgb_fc.2 W,b  rgb_fc.4 W,b  s
- *   fwd: pts (n, 3) -> rgb_out (n, 3), vis_out (n, S) uint8 (NULL to skip).
- *   bwd: g_rgb (n, 3) cotangent of rgb_out -> for each of the 11 layers the operand rows of its weight-gradient product over
- *     rows = gens_blend_train_rows(n, nv) = 32 ceil(n / floor(32 / S)):  r_ops[l] (rows, even(in_l + 1)) = [layer input | 1 | 0],
+ *   index / n / n_device as in gens_sdf_mlp: point i of the launch is pts[index[i]], its colour / flags / cotangent live at row index[i]
+ *     of the dense arrays, only min(n, *n_device) points exist (NULL index = identity, NULL n_device = n).
+ *   fwd: pts -> rgb_out (N, 3), vis_out (N, S) uint8 (NULL to skip), written at index[i].
+ *   bwd: g_rgb (N, 3) cotangent of rgb_out -> for each of the 11 layers the operand rows of its weight-gradient product over
+ *     rows = gens_blend_train_rows(n, nv) = 32 ceil(n / floor(32 / S)) (under a device-side count only the rows of the first
+ *     ceil(n_live / floor(32 / S)) workgroups are written: gens_gemm_tn_batch_live):  r_ops[l] (rows, even(in_l + 1)) = [layer input | 1 | 0],
  *     l_ops[l] (rows, even(out_l)) = cotangent of the pre-activation (zero padded; even(x) = x rounded up to a multiple of 2):
  *     [dW_l | db_l] = the leading out_l x (in_l + 1) block of l_ops[l]^T r_ops[l]   (gens_gemm_tn_batch);
- *     g_feat (n, S, 3 + 4 n_levels): cotangent of the looked-up rows for gens_lookup_feature_bwd (NULL to skip);
- *     s_part (rows / 32): partial sums of d loss / d |s|.
+ *     g_feat (n, S, 3 + 4 n_levels), COMPACT (row i = point i of the launch): cotangent of the looked-up rows for
+ *     gens_lookup_feature_bwd[_idx] (NULL to skip);  s_part (rows / 32): partial sums of d loss / d |s| (zero for dead workgroups).
  * ---------------------------------------------------------------------------------------------------------- */
 int64_t gens_blend_train_rows(int64_t n, int nv);
 int gens_blend_train_fwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
-                         const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, float* rgb_out,
-                         uint8_t* vis_out, void* stream);
+                         const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                         const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
 int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
-                         const float* c2w, int nv, const float* const* weights, const float* pts, int64_t n, const float* g_rgb,
-                         float* const* r_ops, float* const* l_ops, float* g_feat, float* s_part, void* stream);
+                         const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                         const int32_t* n_device, const float* g_rgb, float* const* r_ops, float* const* l_ops, float* g_feat,
+                         float* s_part, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)
@@ -461,6 +475,12 @@ int gens_gemm_tn(const float* a, const float* b, int64_t k, int m, int n, float*
 int64_t gens_gemm_tn_batch_workspace(int count, const int* m, const int* n, int64_t k);
 int gens_gemm_tn_batch(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
                        const int* n, int64_t k, float* workspace, float* c, void* stream);
+/* The same with the number of rows that EXIST left on the device: only the first min(k, k_rows ceil(*k_live / k_div)) rows of the
+ * operands are read -- *k_live work items of the producer, k_div of which share a workgroup that wrote k_rows rows (gens_sdf_train_bwd:
+ * 32 points -> 128 rows; gens_blend_train_bwd: floor(32 / S) points -> 32 rows) under a device-side point count. */
+int gens_gemm_tn_batch_live(int count, const float* const* a, const int* lda, const float* const* b, const int* ldb, const int* m,
+                            const int* n, int64_t k, const int32_t* k_live, int k_div, int k_rows, float* workspace, float* c,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K15  the 3 x 3 x 3 convolutions of the cost-volume U-Net (reg_network.py:7-50: nn.Conv3d(k=3, padding=1, stride 1 | 2) and
@@ -518,6 +538,10 @@ int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rs
  *   [0, n_ray_pts) are ray samples with flags from gens_ray_points (none set: the first min(10, n) of them, Q7), the next n_always rows
  *   are always selected (the random points), the rest are the pseudo points with their own flags.  idx (n) int64: selected rows in
  *   increasing order; counts (3) int32 = {selected, selected ray samples, selected pseudo points}.  n < 2^24; one workgroup.
+ *   Optional outputs of the same launch (NULL to skip): the values the reference's dense tensors hold for UNSELECTED rows (Q8) --
+ *   y_fill (n): 100 for ray samples, 0 for pseudo points (implicit_surface.py:125,497); g_fill / s_fill (n, 3): 0; rgb_fill
+ *   (n_ray_pts, 3): 0; vis_fill (n_ray_pts, n_src): 0 -- and scalars (4) = {max of z (nz floats; :301), inv_s = clip(exp(10 variance),
+ *   1e-6, 1e6) (variance_network.py:11, :206), 1 / inv_s, 1 if inv_s is inside the clip range else 0}.
  * gens_tv_levels_fwd / _bwd: tv_regularization (implicit_surface.py:135-150; Q13) of all levels.  vols[l] (4, X, Y, Z), masks[l]
  *   (X, Y, Z): HOST arrays of device pointers; dims HOST int[3 * n_levels]; Z % 4 == 0, 16-byte aligned planes.
  *   fwd: partial: scratch of gens_tv_levels_blocks(dims, n_levels) float4; out (1 + n_levels): out[0] = tv_reg, out[1 + l] = the
@@ -527,7 +551,9 @@ int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
 int gens_unpack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
-int gens_compact_points(const uint8_t* valid, int64_t n_ray_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts, void* stream);
+int gens_compact_points(const uint8_t* valid, int64_t n_ray_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
+                        float* y_fill, float* g_fill, float* s_fill, float* rgb_fill, uint8_t* vis_fill, int n_src, const float* z,
+                        int64_t nz, const float* variance, float* scalars, void* stream);
 int gens_tv_levels_blocks(const int* dims, int n_levels);
 int gens_tv_levels_fwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, float* partial, float* out,
                        void* stream);

@@ -72,7 +72,15 @@ def test_compact_points_against_nonzero(n0, n1, n2, p0, p2):
     valid = torch.cat([torch.rand(n0, generator=g) < p0, torch.ones(n1, dtype=torch.bool), torch.rand(n2, generator=g) < p2]).to(torch.uint8)
     idx = torch.full((max(n, 1),), -1, dtype=torch.int64, device="cuda")
     counts = torch.zeros(3, dtype=torch.int32, device="cuda")
-    L.call("gens_compact_points", L.ptr(valid.cuda(), torch.uint8), n0, n1, n, L.ptr(idx, torch.int64), L.ptr(counts, torch.int32), L.stream())
+    y = torch.full((max(n, 1),), 7.0, device="cuda")
+    g3 = torch.full((max(n, 1), 3), 7.0, device="cuda")
+    rgb = torch.full((max(n0, 1), 3), 7.0, device="cuda")
+    vis = torch.full((max(n0, 1), 4), 7, dtype=torch.uint8, device="cuda")
+    z = torch.rand(max(n0, 1), generator=g).cuda() * 3 - 1
+    var = torch.tensor([0.3], device="cuda")
+    scal = torch.zeros(4, device="cuda")
+    L.call("gens_compact_points", L.ptr(valid.cuda(), torch.uint8), n0, n1, n, L.ptr(idx, torch.int64), L.ptr(counts, torch.int32), L.ptr(y),
+           L.ptr(g3), None, L.ptr(rgb), L.ptr(vis, torch.uint8), 4, L.ptr(z), z.numel(), L.ptr(var), L.ptr(scal), L.stream())
     ray = torch.nonzero(valid[:n0])[:, 0]
     if ray.numel() < 1:
         ray = torch.arange(min(10, n0))
@@ -80,6 +88,14 @@ def test_compact_points_against_nonzero(n0, n1, n2, p0, p2):
     want = torch.cat([ray, torch.arange(n0, n0 + n1), pseudo])
     assert counts.tolist() == [want.numel(), ray.numel(), pseudo.numel()]
     assert torch.equal(idx[:want.numel()].cpu(), want)
+    sel = torch.zeros(max(n, 1), dtype=torch.bool)
+    sel[want] = True
+    y_want = torch.where(sel, torch.tensor(7.0), torch.where(torch.arange(max(n, 1)) < n0, torch.tensor(100.0), torch.tensor(0.0)))[:n]
+    assert torch.equal(y.cpu()[:n], y_want) and torch.equal(g3.cpu()[:n], torch.where(sel[:n, None], torch.tensor(7.0), torch.tensor(0.0)).expand(n, 3))
+    assert torch.equal(rgb.cpu()[:n0], torch.where(sel[:n0, None], torch.tensor(7.0), torch.tensor(0.0)).expand(n0, 3))
+    assert torch.equal(vis.cpu()[:n0], torch.where(sel[:n0, None], torch.tensor(7), torch.tensor(0)).to(torch.uint8).expand(n0, 4))
+    inv_s = float(torch.exp(var * 10.0).clip(1e-6, 1e6))
+    assert float(scal[0]) == float(z.max()) and abs(float(scal[1]) - inv_s) <= 2e-6 * inv_s and abs(float(scal[2]) * inv_s - 1) < 1e-5 and float(scal[3]) == 1.0
 
 
 @pytest.mark.parametrize("dims", [(64, 32, 16), (32, 16, 8, 8, 4), (24,)])
