@@ -331,7 +331,7 @@ class ImplicitSurface(nn.Module):
         }
         if n_x:
             out["_extra_sdf_dense"] = y_all[n_ray + n_r:]
-        out["_step_counts"] = sel.counts
+        self._last_step_counts = sel.counts            # (device; forward() hands it to the deferred checks)
         pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
         g0 = net.first_order(pts_sdf0).reshape(b, 1, 3)
         g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
@@ -716,9 +716,8 @@ class ImplicitSurface(nn.Module):
             ops.lookup_mask(pseudo_pts, scene.masks, out=flags)
             outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                                   cos_anneal_ratio, step, scene=scene, extra_pts=pseudo_pts, extra_valid=flags)
-            counts = outputs.pop("_step_counts")
             outputs["pseudo_sdf"] = outputs.pop("_extra_sdf_dense")
-            self._defer_checks(counts, scene.views.cams.status)
+            self._defer_checks(self._last_step_counts, scene.views.cams.status)
             return outputs
         if "pseudo_pts" in ipts:                       # (:484-497) the mask look-up draws nothing from the generator, so it can come first
             pseudo_pts = ipts["pseudo_pts"].float()
@@ -734,7 +733,6 @@ class ImplicitSurface(nn.Module):
             outputs = self.render(rays_o, rays_d, near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                                   cos_anneal_ratio, step, scene=scene, extra_pts=None if idx is None else pseudo_pts[idx])
             extra = outputs.pop("_extra_sdf", None)
-            outputs.pop("_step_counts", None)
         if pseudo_pts is not None:
             if extra is None:
                 vols = scene.volumes if any(v.requires_grad for v in scene.volumes) else scene.volumes_nograd()
