@@ -206,12 +206,34 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
     __shared__ int seg_tot[2];
     __shared__ float zred[CP_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t per = (n + CP_THREADS - 1) / CP_THREADS;
+    // a thread owns `per` consecutive rows, a multiple of 16 so that its flags are a few 16-byte loads (one workgroup, dependent loads: a
+    // byte at a time the kernel took longer than the 512-ray step's compositing)
+    constexpr int CP_MAX = 96;                                     // rows per thread kept in registers as packed bits (n < 1024 * 96)
+    const int64_t per = ((n + CP_THREADS - 1) / CP_THREADS + 15) / 16 * 16;
     const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
+    const bool wide = per <= CP_MAX && ((uintptr_t)valid & 15) == 0;
+    uint32_t bits[CP_MAX / 32] = {0u, 0u, 0u};
+    if (wide) {
+        for (int64_t i = lo; i < hi; i += 16) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (i + 16 <= n) {
+                const uint4 q = *(const uint4*)(valid + i);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {
+                for (int k = 0; i + k < n; ++k) w[k >> 2] |= (uint32_t)valid[i + k] << (8 * (k & 3));
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = (int)(i - lo) + k;
+                if ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) bits[r >> 5] |= 1u << (r & 31);
+            }
+        }
+    }
+#define CP_FLAG(i) (wide ? ((bits[((i) - lo) >> 5] >> (((i) - lo) & 31)) & 1u) != 0 : valid[i] != 0)
     // pass 1: flags set in the ray segment / in the pseudo segment
     int c0 = 0, c2 = 0;
     for (int64_t i = lo; i < hi; ++i) {
-        const bool v = valid[i] != 0;
+        const bool v = CP_FLAG(i);
         c0 += (i < n0 && v) ? 1 : 0;
         c2 += (i >= n0 + n1 && v) ? 1 : 0;
     }
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
     // pass 2: selection with the rescue rule, exclusive scan over the threads, ordered write
     int mine = 0;
     for (int64_t i = lo; i < hi; ++i) {
-        const bool sel = i < n0 ? (rescue ? i < n_rescue : valid[i] != 0) : (i < n0 + n1 ? true : valid[i] != 0);
+        const bool sel = i < n0 ? (rescue ? i < n_rescue : CP_FLAG(i)) : (i < n0 + n1 ? true : CP_FLAG(i));
         mine += sel ? 1 : 0;
     }
     float inc = wave_scan_add((float)mine, lane);
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
     for (int k = 0; k < wv; ++k) base += wave_tot[k];
     int64_t pos = base + (int)inc - mine;
     for (int64_t i = lo; i < hi; ++i) {
-        const bool sel = i < n0 ? (rescue ? i < n_rescue : valid[i] != 0) : (i < n0 + n1 ? true : valid[i] != 0);
+        const bool sel = i < n0 ? (rescue ? i < n_rescue : CP_FLAG(i)) : (i < n0 + n1 ? true : CP_FLAG(i));
         if (sel) {
             idx[pos++] = i;
             continue;
@@ -268,6 +290,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __
             F.scalars[3] = (raw >= 1e-6f && raw <= 1e6f) ? 1.0f : 0.0f;
         }
     }
+#undef CP_FLAG
     if (t == CP_THREADS - 1) {
         counts[0] = base + (int)inc;
         counts[1] = rescue ? (int)n_rescue : seg_tot[0];
@@ -501,4 +524,225 @@ extern "C" int gens_tv_levels_bwd(const float* const* vols, const float* const* 
     for (int l = 0; l < n_levels; ++l) GENS_CHECK_ARG(g_vols[l], GENS_EINVAL, "gens_tv_levels_bwd: null gradient buffer of level %d", l);
     tv_levels_bwd_k<<<L.first_block[n_levels], TVL_BLOCK, 0, (hipStream_t)stream>>>(L, out, g);
     return gens_launch_status("gens_tv_levels_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// surface_patch_warp fused (projector.py:353-437 as called from implicit_surface.py:301-328): the surface point of a ray, the
+// plane-induced homographies into the source views, the 11 x 11 patch grids and the bilinear reads of the warp features -- ~60 PyTorch
+// launches forward and as many backward -- in one launch each.  One wavefront per ray; lanes over the (view, pixel) samples.
+//   p = o + d z (z = z_cross, the only differentiable input: the normal is used detached, :306-310)
+//   n = normalise(g0) R_ref                         x_cam = p R_ref + t_ref            disp = n . x_cam
+//   H_v = K_v (R_v^T R_ref + (R_v^T (c_ref - c_v)) n^T / (disp + 1e-10)) K_ref^-1
+//   (u0, v0) = K_ref x_cam, dehomogenised with + 1e-8; pixel (ox, oy): q = H_v (u0 + ox, v0 + oy, 1), grid = q.xy / (q.z + 1e-8)
+//   read with align_corners=True after the reference's normalise / un-normalise round trip (kept for its rounding).
+// Backward: every quantity carries ONE tangent (d / dz); g_z[ray] = sum over views, pixels, channels of g_sampled * d sampled / dz.
+// ---------------------------------------------------------------------------------------------------------------
+#define PW_MAX_Q4 4
+struct PatchWarpArgs {
+    const float *rays_o, *rays_d, *z, *g0;     // (B,3) (B,3) (B) (B,3)
+    const float *c2w, *intr, *kinv_ref;        // (nv,4,4) (nv,4,4) (3,3)
+    const float4* tex;                         // (nv, H, W, q4) texels
+    int nv, h, w, c, q4, patch;
+    int64_t n_rays;
+    float *ref, *sampled;                      // (1, B, P, C), (S, B, P, C)
+    const float* g_sampled;                    // backward: (S, B, P, C)
+    float* g_z;                                // backward: (B)
+};
+
+struct PwRay {
+    float u0, v0, du0, dv0;       // reference pixel and its tangent
+    float nrm[3], disp, ddisp;
+    bool ok;
+};
+
+__device__ __forceinline__ PwRay pw_ray(const PatchWarpArgs& A, int64_t r) {
+    PwRay R;
+    const float* o = A.rays_o + 3 * r;
+    const float* d = A.rays_d + 3 * r;
+    const float z = A.z[r];
+    const float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};
+    const float* cr = A.c2w;                                   // reference view: rows of [R | c]
+    float g[3] = {A.g0[3 * r], A.g0[3 * r + 1], A.g0[3 * r + 2]};
+    float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    gn = gn <= 0.0f ? 1e-8f : gn;                              // (:308-309)
+    g[0] /= gn; g[1] /= gn; g[2] /= gn;
+    float xc[3], dx[3], t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        R.nrm[j] = g[0] * cr[j] + g[1] * cr[4 + j] + g[2] * cr[8 + j];                     // g R_ref (row vector)
+        t[j] = -(cr[j] * cr[3] + cr[4 + j] * cr[7] + cr[8 + j] * cr[11]);                  // -(R_ref^T c_ref)
+        xc[j] = (p[0] * cr[j] + p[1] * cr[4 + j] + p[2] * cr[8 + j]) + t[j];
+        dx[j] = d[0] * cr[j] + d[1] * cr[4 + j] + d[2] * cr[8 + j];
+    }
+    const float* k = A.intr;
+    float pr[3], dp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        pr[i] = xc[0] * k[4 * i] + xc[1] * k[4 * i + 1] + xc[2] * k[4 * i + 2];
+        dp[i] = dx[0] * k[4 * i] + dx[1] * k[4 * i + 1] + dx[2] * k[4 * i + 2];
+    }
+    R.disp = R.nrm[0] * xc[0] + R.nrm[1] * xc[1] + R.nrm[2] * xc[2];
+    R.ddisp = R.nrm[0] * dx[0] + R.nrm[1] * dx[1] + R.nrm[2] * dx[2];
+    const float den = pr[2] + 1e-8f;
+    R.u0 = pr[0] / den;
+    R.v0 = pr[1] / den;
+    R.du0 = (dp[0] * den - pr[0] * dp[2]) / (den * den);
+    R.dv0 = (dp[1] * den - pr[1] * dp[2]) / (den * den);
+    R.ok = true;
+    return R;
+}
+
+// H_v (and, if DUAL, its tangent) for source view sv >= 1
+template <bool DUAL>
+__device__ __forceinline__ void pw_homography(const PatchWarpArgs& A, const PwRay& R, int sv, float H[9], float dH[9]) {
+    const float* cr = A.c2w;
+    const float* cs = A.c2w + 16 * sv;
+    float rel[9], tv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rel[3 * i + j] = cs[i] * cr[j] + cs[4 + i] * cr[4 + j] + cs[8 + i] * cr[8 + j];      // R_v^T R_ref
+        tv[i] = cs[i] * (cr[3] - cs[3]) + cs[4 + i] * (cr[7] - cs[7]) + cs[8 + i] * (cr[11] - cs[11]);                    // R_v^T (c_ref - c_v)
+    }
+    const float den = R.disp + 1e-10f;
+    float hom[9], dhom[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float outer = tv[i] * R.nrm[j];
+            hom[3 * i + j] = rel[3 * i + j] + outer / den;
+            if (DUAL) dhom[3 * i + j] = -outer * R.ddisp / (den * den);
+        }
+    const float* ks = A.intr + 16 * sv;
+    const float* ki = A.kinv_ref;
+    float tmp[9], dtmp[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            tmp[3 * i + j] = ks[4 * i] * hom[j] + ks[4 * i + 1] * hom[3 + j] + ks[4 * i + 2] * hom[6 + j];
+            if (DUAL) dtmp[3 * i + j] = ks[4 * i] * dhom[j] + ks[4 * i + 1] * dhom[3 + j] + ks[4 * i + 2] * dhom[6 + j];
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            H[3 * i + j] = tmp[3 * i] * ki[j] + tmp[3 * i + 1] * ki[3 + j] + tmp[3 * i + 2] * ki[6 + j];
+            if (DUAL) dH[3 * i + j] = dtmp[3 * i] * ki[j] + dtmp[3 * i + 1] * ki[3 + j] + dtmp[3 * i + 2] * ki[6 + j];
+        }
+}
+
+#define PW_RAYS_PER_BLOCK 4
+__global__ __launch_bounds__(64 * PW_RAYS_PER_BLOCK) void patch_warp_fwd_k(PatchWarpArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * PW_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= A.n_rays) return;
+    const int S = A.nv - 1, P = A.patch * A.patch, half = A.patch / 2;
+    const PwRay R = pw_ray(A, r);
+    const float wm = (float)(A.w - 1), hm = (float)(A.h - 1);
+    for (int i = lane; i < (S + 1) * P; i += 64) {
+        const int v = i / P, px = i % P;                                     // v = 0: the reference view itself
+        const float u = R.u0 + (float)(px % A.patch - half), vv = R.v0 + (float)(px / A.patch - half);
+        float gx = u, gy = vv;
+        if (v > 0) {
+            float H[9], dH[9];
+            pw_homography<false>(A, R, v, H, dH);
+            const float q0 = H[0] * u + H[1] * vv + H[2], q1 = H[3] * u + H[4] * vv + H[5], q2 = H[6] * u + H[7] * vv + H[8];
+            gx = q0 / (q2 + 1e-8f);
+            gy = q1 / (q2 + 1e-8f);
+        }
+        const float ix = ((2.0f * gx / wm - 1.0f) + 1.0f) / 2.0f * wm, iy = ((2.0f * gy / hm - 1.0f) + 1.0f) / 2.0f * hm;
+        const Taps2 t = bilinear_taps(ix, iy, A.h, A.w);
+        const float4* img = A.tex + (int64_t)v * A.h * A.w * A.q4;
+        float* o = (v == 0 ? A.ref : A.sampled + ((int64_t)(v - 1) * A.n_rays) * P * A.c) + ((int64_t)r * P + px) * A.c;
+        for (int q = 0; q < A.q4; ++q) {
+            const float4 val = sample_texel(img, A.h, A.w, A.q4, q, t);
+            o[4 * q] = val.x;
+            if (4 * q + 1 < A.c) o[4 * q + 1] = val.y;
+            if (4 * q + 2 < A.c) o[4 * q + 2] = val.z;
+            if (4 * q + 3 < A.c) o[4 * q + 3] = val.w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * PW_RAYS_PER_BLOCK) void patch_warp_bwd_k(PatchWarpArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * PW_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= A.n_rays) return;
+    const int S = A.nv - 1, P = A.patch * A.patch, half = A.patch / 2;
+    const PwRay R = pw_ray(A, r);
+    const float wm = (float)(A.w - 1), hm = (float)(A.h - 1);
+    float acc = 0.0f;
+    for (int i = lane; i < S * P; i += 64) {
+        const int v = i / P + 1, px = i % P;
+        const float u = R.u0 + (float)(px % A.patch - half), vv = R.v0 + (float)(px / A.patch - half);
+        float H[9], dH[9];
+        pw_homography<true>(A, R, v, H, dH);
+        const float q0 = H[0] * u + H[1] * vv + H[2], q1 = H[3] * u + H[4] * vv + H[5], q2 = H[6] * u + H[7] * vv + H[8];
+        const float dq0 = (dH[0] * u + dH[1] * vv + dH[2]) + (H[0] * R.du0 + H[1] * R.dv0);
+        const float dq1 = (dH[3] * u + dH[4] * vv + dH[5]) + (H[3] * R.du0 + H[4] * R.dv0);
+        const float dq2 = (dH[6] * u + dH[7] * vv + dH[8]) + (H[6] * R.du0 + H[7] * R.dv0);
+        const float den = q2 + 1e-8f;
+        const float gx = q0 / den, gy = q1 / den;
+        const float dgx = (dq0 * den - q0 * dq2) / (den * den), dgy = (dq1 * den - q1 * dq2) / (den * den);
+        const float ix = ((2.0f * gx / wm - 1.0f) + 1.0f) / 2.0f * wm, iy = ((2.0f * gy / hm - 1.0f) + 1.0f) / 2.0f * hm;
+        const Taps2 t = bilinear_taps(ix, iy, A.h, A.w);
+        if (!(isfinite(ix) && isfinite(iy))) continue;
+        const float fx = (float)t.x0, fy = (float)t.y0;
+        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+        const float4* img = A.tex + (int64_t)v * A.h * A.w * A.q4;
+        const int64_t base = ((int64_t)t.y0 * A.w + t.x0) * A.q4;
+        const float* g = A.g_sampled + (((int64_t)(v - 1) * A.n_rays + r) * P + px) * A.c;
+        float sx = 0.0f, sy = 0.0f;
+        for (int q = 0; q < A.q4; ++q) {
+            float gq[4] = {g[4 * q], 0.f, 0.f, 0.f};
+            if (4 * q + 1 < A.c) gq[1] = g[4 * q + 1];
+            if (4 * q + 2 < A.c) gq[2] = g[4 * q + 2];
+            if (4 * q + 3 < A.c) gq[3] = g[4 * q + 3];
+#define PW_DOT(V) ((V).x * gq[0] + (V).y * gq[1] + (V).z * gq[2] + (V).w * gq[3])
+            const float d00 = t.ok00 ? PW_DOT(img[base + q]) : 0.0f;
+            const float d01 = t.ok01 ? PW_DOT(img[base + A.q4 + q]) : 0.0f;
+            const float d10 = t.ok10 ? PW_DOT(img[base + (int64_t)A.w * A.q4 + q]) : 0.0f;
+            const float d11 = t.ok11 ? PW_DOT(img[base + (int64_t)A.w * A.q4 + A.q4 + q]) : 0.0f;
+#undef PW_DOT
+            sx += (d01 - d00) * wy0 + (d11 - d10) * wy1;
+            sy += (d10 - d00) * wx0 + (d11 - d01) * wx1;
+        }
+        const float term = sx * dgx + sy * dgy;
+        if (term == term) acc += term;                                   // (a degenerate homography: no gradient, like a masked ray)
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) A.g_z[r] = acc;
+}
+
+static int check_patch_warp(const char* who, const PatchWarpArgs& A) {
+    GENS_CHECK_ARG(A.rays_o && A.rays_d && A.z && A.g0 && A.c2w && A.intr && A.kinv_ref && A.tex, GENS_EINVAL, "%s: null input pointer", who);
+    GENS_CHECK_ARG(A.nv >= 2 && A.nv <= GENS_MAX_VIEWS, GENS_ELIMIT, "%s: nv=%d not in 2..%d", who, A.nv, GENS_MAX_VIEWS);
+    GENS_CHECK_ARG(A.h > 1 && A.w > 1 && A.c >= 1 && A.c <= 4 * PW_MAX_Q4 && A.patch >= 1 && A.patch <= 15 && (A.patch & 1), GENS_ELIMIT,
+                   "%s: image %d x %d, %d channels (<= %d), odd patch size %d (<= 15)", who, A.h, A.w, A.c, 4 * PW_MAX_Q4, A.patch);
+    GENS_CHECK_ARG(((uintptr_t)A.tex & 15) == 0, GENS_EINVAL, "%s: texels must be 16-byte aligned", who);
+    return 0;
+}
+
+extern "C" int gens_patch_warp_fwd(const float* rays_o, const float* rays_d, const float* z, const float* g0, int64_t n_rays, const float* c2ws,
+                                   const float* intrs, const float* kinv_ref, int nv, const float* tex, int h, int w, int c, int patch, float* ref,
+                                   float* sampled, void* stream) {
+    PatchWarpArgs A = {rays_o, rays_d, z, g0, c2ws, intrs, kinv_ref, (const float4*)tex, nv, h, w, c, (c + 3) / 4, patch, n_rays, ref, sampled, nullptr, nullptr};
+    if (int e = check_patch_warp("gens_patch_warp_fwd", A)) return e;
+    GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (ref && sampled)), GENS_EINVAL, "gens_patch_warp_fwd: null output");
+    if (n_rays == 0) return 0;
+    patch_warp_fwd_k<<<gens_blocks(n_rays, PW_RAYS_PER_BLOCK), 64 * PW_RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_patch_warp_fwd");
+}
+
+extern "C" int gens_patch_warp_bwd(const float* rays_o, const float* rays_d, const float* z, const float* g0, int64_t n_rays, const float* c2ws,
+                                   const float* intrs, const float* kinv_ref, int nv, const float* tex, int h, int w, int c, int patch,
+                                   const float* g_sampled, float* g_z, void* stream) {
+    PatchWarpArgs A = {rays_o, rays_d, z, g0, c2ws, intrs, kinv_ref, (const float4*)tex, nv, h, w, c, (c + 3) / 4, patch, n_rays, nullptr, nullptr, g_sampled, g_z};
+    if (int e = check_patch_warp("gens_patch_warp_bwd", A)) return e;
+    GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (g_sampled && g_z)), GENS_EINVAL, "gens_patch_warp_bwd: null gradient pointer");
+    if (n_rays == 0) return 0;
+    patch_warp_bwd_k<<<gens_blocks(n_rays, PW_RAYS_PER_BLOCK), 64 * PW_RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_patch_warp_bwd");
 }

@@ -345,6 +345,11 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_fwd_k(gens_comp
         if (zc > in.z_max[0]) zc = 0.0f;
         out.z_cross[r] = zc;
         out.cross_idx[r] = i0;
+        if (out.pts_cross) {                                    // pts_sdf0 = o + d z (:304), for the surface-point gradient launch
+            out.pts_cross[3 * r] = o[0] + d[0] * zc;
+            out.pts_cross[3 * r + 1] = o[1] + d[1] * zc;
+            out.pts_cross[3 * r + 2] = o[2] + d[2] * zc;
+        }
     }
 }
 

@@ -32,7 +32,7 @@ class CompositeIn(C.Structure):
 
 class CompositeOut(C.Structure):
     _fields_ = [(n, _p) for n in ("color", "normal", "depth", "wsum", "wmax", "mid_in", "sdf_depth", "z_cross", "eik_num", "eik_den",
-                                  "smooth_vec", "valid", "cross_idx", "weights", "inside")]
+                                  "smooth_vec", "valid", "cross_idx", "weights", "inside", "pts_cross")]
 
 
 class CompositeGrad(C.Structure):
@@ -110,6 +110,8 @@ SIGNATURES = {
     "gens_gemm_tn_batch": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _p, _p],
     "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _pp, _p],
     "gens_scene_setup": [_p, _p, _i, _p, _p],
+    "gens_patch_warp_fwd": [_p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p],
+    "gens_patch_warp_bwd": [_p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     "gens_pack_maps": [_pp, _pp, _ip, _i, _p],
     "gens_unpack_maps": [_pp, _pp, _ip, _i, _p],
     "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p],

@@ -332,13 +332,11 @@ class ImplicitSurface(nn.Module):
         if n_x:
             out["_extra_sdf_dense"] = y_all[n_ray + n_r:]
         self._last_step_counts = sel.counts            # (device; forward() hands it to the deferred checks)
-        pts_sdf0 = rays_o[:, None, :] + rays_d[:, None, :] * comp["z_cross"][:, None, None]
-        g0 = net.first_order(pts_sdf0).reshape(b, 1, 3)
-        g0_norm = torch.linalg.norm(g0, ord=2, dim=-1, keepdim=True)
-        g0 = g0 / torch.where(g0_norm <= 0, torch.full_like(g0_norm, 1e-8), g0_norm)
-        normals_ref = (g0 @ c2ws[0, :3, :3]).detach()
+        # surface point of the first sign change (written by the compositing launch), its SDF gradient (the reference builds the second-order
+        # graph here too and throws it away: the normal is used detached, :306-310), and the plane-induced patch warp in ONE launch
+        g0 = net.first_order(comp["pts_cross"])
         warp = scene.warp_features(use_match=not (step is None or step < 5))
-        out["ref_gray_val"], out["sampled_gray_val"] = surface_patch_warp(pts_sdf0, normals_ref, warp, intrs, c2ws)
+        out["ref_gray_val"], out["sampled_gray_val"] = ops.patch_warp(comp["z_cross"], rays_o, rays_d, g0, scene.views.cams, warp)
         return out
 
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,

@@ -559,7 +559,7 @@ class _Composite(torch.autograd.Function):
         ci = _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot)
         f = lambda *s: torch.empty(*s, device=dev, dtype=_f32)  # noqa: E731
         o = dict(color=f(b, 3), normal=f(b, 3), depth=f(b), wsum=f(b), wmax=f(b), mid_in=f(b), sdf_depth=f(b), z_cross=f(b), eik_num=f(b),
-                 eik_den=f(b), smooth_vec=f(b, 3), weights=f(b, n), inside=f(b, n))
+                 eik_den=f(b), smooth_vec=f(b, 3), weights=f(b, n), inside=f(b, n), pts_cross=f(b, 3))
         valid = torch.empty(b, device=dev, dtype=torch.uint8)
         cross_idx = torch.empty(b, device=dev, dtype=torch.int32)
         co = L.CompositeOut()
@@ -573,9 +573,9 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, o["weights"], cross_idx,
                               o["smooth_vec"])
         ctx.meta = (sample_dist, cos_anneal, rot)
-        ctx.mark_non_differentiable(o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx)
+        ctx.mark_non_differentiable(o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx, o["pts_cross"])
         return (o["color"], o["normal"], o["depth"], o["weights"], o["wsum"], o["eik_num"], o["smooth_vec"], o["z_cross"], o["sdf_depth"],
-                o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx)
+                o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx, o["pts_cross"])
 
     @staticmethod
     def backward(ctx, g_color, g_normal, g_depth, g_weights, g_wsum, g_eik, g_smv, g_zc, _g_sdfdepth, *_unused):
@@ -626,7 +626,7 @@ def inv_s_from(variance, scalars):
 
 
 COMPOSITE_KEYS = ("color", "normal", "depth", "weights", "wsum", "eik_num", "smooth_vec", "z_cross", "sdf_depth", "wmax", "mid_in", "eik_den",
-                  "inside", "valid", "cross_idx")
+                  "inside", "valid", "cross_idx", "pts_cross")
 
 
 def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, voxel_mask, src_vis, inv_s, cos_anneal, c2w_ref, z_max=None):
@@ -682,6 +682,41 @@ class _PatchSample(torch.autograd.Function):
 def patch_sample(image_tex, xy, channels):
     """image_tex (H,W,C_pad) texels (constant), xy (P,2) pixel coordinates -> (P,C); differentiable in xy."""
     return _PatchSample.apply(xy, image_tex, channels)
+
+
+class _PatchWarp(torch.autograd.Function):
+    """surface_patch_warp (projector.py:353-437) fused: (z_cross (B), rays_o, rays_d, g0 (B,3), cams, texels) -> (ref (1,B,P,C), sampled
+    (S,B,P,C)); differentiable with respect to z_cross (the normal is used detached, implicit_surface.py:306-310)."""
+
+    @staticmethod
+    def forward(ctx, z, rays_o, rays_d, g0, cams, tex, c, patch):
+        nv, h, w, _ = tex.shape
+        b = z.shape[0]
+        dev = z.device
+        z_c, o_c, d_c, g_c = _c(z.detach().to(_f32)), _c(rays_o.detach().to(_f32)), _c(rays_d.detach().to(_f32)), _c(g0.detach().to(_f32).reshape(b, 3))
+        p = patch * patch
+        ref = torch.empty(1, b, p, c, device=dev, dtype=_f32)
+        sampled = torch.empty(nv - 1, b, p, c, device=dev, dtype=_f32)
+        ctx.args = (L.ptr(o_c), L.ptr(d_c), L.ptr(z_c), L.ptr(g_c), b, L.ptr(cams.c2w), L.ptr(cams.intr), L.ptr(cams.kinv_ref), nv, L.ptr(tex, align=16),
+                    h, w, c, patch)
+        ctx.keep = (o_c, d_c, z_c, g_c, cams, tex)
+        L.call("gens_patch_warp_fwd", *ctx.args, L.ptr(ref), L.ptr(sampled), L.stream(), nbytes=4 * nv * b * p * c)
+        ctx.mark_non_differentiable(ref)
+        return ref, sampled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _g_ref, g_sampled):
+        b = ctx.args[4]
+        g_z = torch.empty(b, device=g_sampled.device, dtype=_f32)
+        L.call("gens_patch_warp_bwd", *ctx.args, L.ptr(_c(g_sampled.to(_f32))), L.ptr(g_z), L.stream(), nbytes=8 * (ctx.args[8] - 1) * b * ctx.args[13] ** 2 * ctx.args[12])
+        return g_z, None, None, None, None, None, None, None
+
+
+def patch_warp(z_cross, rays_o, rays_d, g0, cams, warp, patch_size=11):
+    """warp: the (texels (nv,H,W,C_pad), C) pair of build_warp_features."""
+    tex, c = warp
+    return _PatchWarp.apply(z_cross, rays_o, rays_d, g0, cams, aligned16(tex), int(c), int(patch_size))
 
 
 def build_warp_features(levels):

@@ -195,6 +195,7 @@ typedef struct {
     uint8_t* valid;
     int32_t* cross_idx;
     float *weights, *inside;
+    float* pts_cross;          /* (B, 3) or NULL: rays_o + rays_d * z_cross, the surface point pts_sdf0 (implicit_surface.py:304) */
 } gens_composite_out;
 
 typedef struct {
@@ -547,6 +548,18 @@ int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rs
  *   fwd: partial: scratch of gens_tv_levels_blocks(dims, n_levels) float4; out (1 + n_levels): out[0] = tv_reg, out[1 + l] = the
  *   level's backward coefficient 0.5^l / (2 tv_l den_l).  bwd: g (1) = d loss / d tv_reg (DEVICE) -> g_vols[l] (overwritten).
  * ---------------------------------------------------------------------------------------------------------- */
+/* gens_patch_warp_fwd / _bwd: surface_patch_warp (projector.py:353-437 as called from implicit_surface.py:301-328) in one launch each.
+ *   rays_o, rays_d (B, 3); z (B) = the clamped crossing depth z_vals_sdf0 (:300-303), the only differentiable input; g0 (B, 3) = the SDF
+ *   gradient at the surface point, un-normalised (normalised and rotated into the reference camera in-kernel, :308-310; used detached);
+ *   c2ws, intrs (nv, 4, 4), kinv_ref (3, 3) = inverse(intrs)[0, :3, :3] (gens_scene_setup); tex (nv, H, W, C_pad) texels of the warp
+ *   features (gens_upsample2d_into), C <= 16 channels; patch: odd patch size (11).
+ *   fwd -> ref (1, B, P, C), sampled (nv - 1, B, P, C), P = patch^2 in row-major (y, x) order.  bwd: g_sampled -> g_z (B), overwritten. */
+int gens_patch_warp_fwd(const float* rays_o, const float* rays_d, const float* z, const float* g0, int64_t n_rays, const float* c2ws,
+                        const float* intrs, const float* kinv_ref, int nv, const float* tex, int h, int w, int c, int patch, float* ref,
+                        float* sampled, void* stream);
+int gens_patch_warp_bwd(const float* rays_o, const float* rays_d, const float* z, const float* g0, int64_t n_rays, const float* c2ws,
+                        const float* intrs, const float* kinv_ref, int nv, const float* tex, int h, int w, int c, int patch,
+                        const float* g_sampled, float* g_z, void* stream);
 int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
