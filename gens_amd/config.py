@@ -22,6 +22,15 @@ class Conf(dict):
     get_int = get_float = get_list = get_bool = get_string = get
 
 
+def gens_loss_conf(finetune=False):
+    """The `train.loss` block of confs/gens.conf:47-59 (finetune: confs/gens_finetune.conf:32-41)."""
+    if finetune:
+        return Conf(dict(color_weight=1.0, sparse_weight=0.0, igr_weight=0.1, sparse_scale_factor=100, mfc_weight=1.0, smooth_weight=0.0005,
+                         tv_weight=0.0001, pseudo_sdf_weight=1.0))
+    return Conf(dict(color_weight=1.0, sparse_weight=0.02, igr_weight=0.1, sparse_scale_factor=100, mfc_weight=1.0, smooth_weight=0.0001,
+                     tv_weight=0.0001, depth_weight=0.0, pseudo_sdf_weight=1.0, normal_weight=0.0, pseudo_depth_weight=0.05))
+
+
 def gens_model_conf(volume_dims=(256, 128, 64, 32, 16), n_feature_levels=5, has_vol=False):
     """The `model` block of confs/gens.conf:59-99 for `len(volume_dims)` volume scales."""
     n = len(volume_dims)

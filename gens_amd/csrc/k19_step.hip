@@ -746,3 +746,131 @@ extern "C" int gens_patch_warp_bwd(const float* rays_o, const float* rays_d, con
     patch_warp_bwd_k<<<gens_blocks(n_rays, PW_RAYS_PER_BLOCK), 64 * PW_RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(A);
     return gens_launch_status("gens_patch_warp_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Loss.forward of a training step (models/losses/loss.py:24-93) in one launch, its backward in one launch.
+//   color  = sum |color_fine - target| * valid / (sum valid + 1e-5)             (:25-27)
+//   eik    = gradient_error;  smooth = smooth_error;  tv = tv_reg               (:29, 33, 35; means of scalars)
+//   sparse = mean exp(-|sparse_sdf| * scale)                                    (:31)
+//   mfc    = 0.5 * sum ncc * m / (sum m + 1e-8),  m = valid * mid_inside_sphere (:37-39)
+//   pseudo_sdf = mean |pseudo_sdf|  (0 when absent)                             (:41-44)
+//   pseudo_depth / depth = sum |render_depth - t| [t > 0] / (sum [t > 0] + 1e-8)  (0 when the target is absent; :46-54)
+//   loss = color w_c + eik w_igr + sparse w_sp + mfc w_mfc + smooth w_sm + tv w_tv + pseudo_sdf w_ps + pseudo_depth w_pd   (:64-71)
+// out (16): [loss, color, eik, sparse, mfc, smooth, tv, depth, pseudo_sdf, pseudo_depth, den_color, den_mfc, den_pseudo_depth, den_depth, 0, 0]
+// ---------------------------------------------------------------------------------------------------------------
+typedef gens_loss_args LossArgs;      // (layout in include/gens_hip.h)
+
+#define LS_THREADS 1024
+__global__ __launch_bounds__(LS_THREADS) void loss_fwd_k(LossArgs A) {
+    __shared__ float red[10][LS_THREADS / 64];
+    float s[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int t = threadIdx.x;
+    for (int64_t r = t; r < A.b; r += LS_THREADS) {
+        const float v = A.valid[r] ? 1.0f : 0.0f;
+        s[0] += (fabsf(A.color[3 * r] - A.target[3 * r]) + fabsf(A.color[3 * r + 1] - A.target[3 * r + 1]) + fabsf(A.color[3 * r + 2] - A.target[3 * r + 2])) * v;
+        s[1] += v;
+        const float m = v * A.mid_in[r];
+        s[2] += A.ncc[r] * m;
+        s[3] += m;
+        if (A.pseudo_depth_t) {
+            const float tt = A.pseudo_depth_t[r], on = tt > 0.0f ? 1.0f : 0.0f;
+            s[4] += fabsf(A.depth[r] - tt) * on;
+            s[5] += on;
+        }
+        if (A.depth_t) {
+            const float tt = A.depth_t[r], on = tt > 0.0f ? 1.0f : 0.0f;
+            s[6] += fabsf(A.depth[r] - tt) * on;
+            s[7] += on;
+        }
+    }
+    for (int64_t i = t; i < A.n_sparse; i += LS_THREADS) s[8] += expf(-fabsf(A.sparse[i]) * A.sparse_scale);
+    if (A.pseudo)
+        for (int64_t i = t; i < A.n_pseudo; i += LS_THREADS) s[9] += fabsf(A.pseudo[i]);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float w = wave_sum(s[k]);
+        if ((t & 63) == 0) red[k][t >> 6] = w;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float tot[10];
+        for (int k = 0; k < 10; ++k) {
+            float a = 0.0f;
+            for (int w = 0; w < LS_THREADS / 64; ++w) a += red[k][w];
+            tot[k] = a;
+        }
+        const float color = tot[0] / (tot[1] + 1e-5f);
+        const float mfc = 0.5f * (tot[2] / (tot[3] + 1e-8f));
+        const float pdepth = A.pseudo_depth_t ? tot[4] / (tot[5] + 1e-8f) : 0.0f;
+        const float depth = A.depth_t ? tot[6] / (tot[7] + 1e-8f) : 0.0f;
+        const float sparse = A.n_sparse > 0 ? tot[8] / (float)A.n_sparse : 0.0f;
+        const float psdf = (A.pseudo && A.n_pseudo > 0) ? tot[9] / (float)A.n_pseudo : 0.0f;
+        const float eik = A.ge[0], smooth = A.se[0], tv = A.tv[0];
+        float loss = color * A.w_color;
+        loss += eik * A.w_igr;
+        loss += sparse * A.w_sparse;
+        loss += mfc * A.w_mfc;
+        loss += smooth * A.w_smooth;
+        loss += tv * A.w_tv;
+        loss += psdf * A.w_pseudo_sdf;
+        loss += pdepth * A.w_pseudo_depth;
+        float* o = A.out;
+        o[0] = loss; o[1] = color; o[2] = eik; o[3] = sparse; o[4] = mfc; o[5] = smooth; o[6] = tv; o[7] = depth; o[8] = psdf; o[9] = pdepth;
+        o[10] = tot[1] + 1e-5f; o[11] = tot[3] + 1e-8f; o[12] = tot[5] + 1e-8f; o[13] = tot[7] + 1e-8f; o[14] = 0.0f; o[15] = 0.0f;
+    }
+}
+
+__device__ __forceinline__ float sgn_(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(256) void loss_bwd_k(LossArgs A) {
+    const float g = A.g[0];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && A.g_scalars) { A.g_scalars[0] = g * A.w_igr; A.g_scalars[1] = g * A.w_smooth; A.g_scalars[2] = g * A.w_tv; }
+    if (i < A.b) {
+        const float v = A.valid[i] ? 1.0f : 0.0f;
+        if (A.g_color) {
+            const float k = g * A.w_color * v / A.out[10];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) A.g_color[3 * i + a] = k * sgn_(A.color[3 * i + a] - A.target[3 * i + a]);
+        }
+        if (A.g_ncc) A.g_ncc[i] = g * A.w_mfc * 0.5f * v * A.mid_in[i] / A.out[11];
+        if (A.g_depth) {
+            float gd = 0.0f;
+            if (A.pseudo_depth_t) {
+                const float tt = A.pseudo_depth_t[i];
+                if (tt > 0.0f) gd = g * A.w_pseudo_depth * sgn_(A.depth[i] - tt) / A.out[12];
+            }
+            A.g_depth[i] = gd;
+        }
+    }
+    if (i < A.n_sparse && A.g_sparse) {
+        const float x = A.sparse[i];
+        A.g_sparse[i] = g * A.w_sparse * (-A.sparse_scale * sgn_(x) * expf(-fabsf(x) * A.sparse_scale)) / (float)A.n_sparse;
+    }
+    if (A.pseudo && i < A.n_pseudo && A.g_pseudo) A.g_pseudo[i] = g * A.w_pseudo_sdf * sgn_(A.pseudo[i]) / (float)A.n_pseudo;
+}
+
+static int check_loss(const char* who, const LossArgs* A) {
+    GENS_CHECK_ARG(A, GENS_EINVAL, "%s: null argument block", who);
+    GENS_CHECK_ARG(A->color && A->target && A->valid && A->sparse && A->ncc && A->mid_in && A->ge && A->se && A->tv && A->out, GENS_EINVAL,
+                   "%s: null input pointer", who);
+    GENS_CHECK_ARG(A->b >= 0 && A->n_sparse >= 0 && A->n_pseudo >= 0, GENS_EINVAL, "%s: negative size", who);
+    GENS_CHECK_ARG(!(A->pseudo_depth_t || A->depth_t) || A->depth, GENS_EINVAL, "%s: a depth target needs render_depth", who);
+    return 0;
+}
+
+extern "C" int gens_loss_fwd(const gens_loss_args* args, void* stream) {
+    const LossArgs* A = args;
+    if (int e = check_loss("gens_loss_fwd", A)) return e;
+    loss_fwd_k<<<1, LS_THREADS, 0, (hipStream_t)stream>>>(*A);
+    return gens_launch_status("gens_loss_fwd");
+}
+
+extern "C" int gens_loss_bwd(const gens_loss_args* args, void* stream) {
+    const LossArgs* A = args;
+    if (int e = check_loss("gens_loss_bwd", A)) return e;
+    GENS_CHECK_ARG(A->g, GENS_EINVAL, "gens_loss_bwd: null cotangent");
+    const int64_t work = max(max(A->b, A->n_sparse), max(A->n_pseudo, (int64_t)1));
+    loss_bwd_k<<<gens_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(*A);
+    return gens_launch_status("gens_loss_bwd");
+}

@@ -381,6 +381,15 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_comp
     float gd = g.g_depth ? g.g_depth[r] * camz : 0.0f;
     float gws = g.g_wsum ? g.g_wsum[r] : 0.0f;
     float geik = g.g_eik_num ? g.g_eik_num[r] : 0.0f;
+    // cotangents of the two per-batch scalars gens_composite_finish_fwd formed from the per-ray outputs (implicit_surface.py:248-253):
+    //   gradient_error = sum eik_num / (sum eik_den + 1e-5);  smooth_error = mean over rays of |smooth_vec| (norm's subgradient 0 at 0)
+    if (g.g_gradient_error) geik += g.g_gradient_error[0] / (g.finish[1] + 1e-5f);
+    if (g.g_smooth_error && g.smooth_vec) {
+        const float v0 = g.smooth_vec[3 * r], v1 = g.smooth_vec[3 * r + 1], v2 = g.smooth_vec[3 * r + 2];
+        const float nv = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+        const float k = nv > 0.0f ? g.g_smooth_error[0] / (nv * (float)in.n_rays) : 0.0f;
+        gsv[0] += k * v0; gsv[1] += k * v1; gsv[2] += k * v2;
+    }
 
     float gw[2], w[2], gww[2];
 #pragma unroll
@@ -505,6 +514,73 @@ extern "C" int gens_composite_fwd(const gens_composite_in* in, const gens_compos
     if (in->n_rays == 0) return 0;
     composite_fwd_k<<<gens_blocks(in->n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(*in, *out);
     return gens_launch_status("gens_composite_fwd");
+}
+
+// gradient_error and smooth_error of a batch from the per-ray outputs (one workgroup, fixed summation order):
+//   finish = {sum eik_num, sum eik_den, gradient_error, smooth_error}
+__global__ __launch_bounds__(256) void composite_finish_fwd_k(const float* __restrict__ eik_num, const float* __restrict__ eik_den,
+                                                              const float* __restrict__ smooth_vec, int64_t b, float* __restrict__ finish) {
+    __shared__ float red[3][4];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (int64_t r = threadIdx.x; r < b; r += 256) {
+        s0 += eik_num[r];
+        s1 += eik_den[r];
+        if (smooth_vec) {
+            const float v0 = smooth_vec[3 * r], v1 = smooth_vec[3 * r + 1], v2 = smooth_vec[3 * r + 2];
+            s2 += sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; red[2][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float num = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), den = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float sm = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        finish[0] = num;
+        finish[1] = den;
+        finish[2] = num / (den + 1e-5f);
+        finish[3] = b > 0 ? sm / (float)b : 0.0f;
+    }
+}
+
+extern "C" int gens_composite_finish_fwd(const float* eik_num, const float* eik_den, const float* smooth_vec, int64_t n_rays, float* finish,
+                                         void* stream) {
+    GENS_CHECK_ARG(eik_num && eik_den && finish && n_rays >= 0, GENS_EINVAL, "gens_composite_finish_fwd: null pointer");
+    composite_finish_fwd_k<<<1, 256, 0, (hipStream_t)stream>>>(eik_num, eik_den, smooth_vec, n_rays, finish);
+    return gens_launch_status("gens_composite_finish_fwd");
+}
+
+// after gens_composite_bwd: d loss / d variance from the per-ray partials of d loss / d inv_s (inv_s = clip(exp(10 variance), 1e-6, 1e6):
+// scalars = gens_compact_points' {z_max, inv_s, 1 / inv_s, inside the clip range}), and zeros into the rows [n_ray, n_all) of the dense
+// gradient arrays that the compositing does not touch (the random / pseudo points of the step's evaluation set)
+__global__ __launch_bounds__(256) void composite_finish_bwd_k(const float* __restrict__ g_inv_s, int64_t b, const float* __restrict__ scalars,
+                                                              float* __restrict__ g_variance, float* __restrict__ g_sdf, float* __restrict__ g_grad,
+                                                              float* __restrict__ g_smooth, int64_t n_ray, int64_t n_all) {
+    __shared__ float red[4];
+    if (blockIdx.x == 0) {
+        float s = 0.0f;
+        for (int64_t r = threadIdx.x; r < b; r += 256) s += g_inv_s[r];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0 && g_variance) g_variance[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scalars[1] * scalars[3] * 10.0f;
+    }
+    const int64_t tail = n_all - n_ray;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tail; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = n_ray + i;
+        if (g_sdf) g_sdf[row] = 0.0f;
+        if (g_grad) { g_grad[3 * row] = 0.0f; g_grad[3 * row + 1] = 0.0f; g_grad[3 * row + 2] = 0.0f; }
+        if (g_smooth) { g_smooth[3 * row] = 0.0f; g_smooth[3 * row + 1] = 0.0f; g_smooth[3 * row + 2] = 0.0f; }
+    }
+}
+
+extern "C" int gens_composite_finish_bwd(const float* g_inv_s, int64_t n_rays, const float* scalars, float* g_variance, float* g_sdf, float* g_grad,
+                                         float* g_smooth, int64_t n_ray_pts, int64_t n_all, void* stream) {
+    GENS_CHECK_ARG(g_inv_s && scalars && n_rays >= 0 && n_all >= n_ray_pts, GENS_EINVAL, "gens_composite_finish_bwd: bad argument");
+    const int64_t tail = n_all - n_ray_pts;
+    const unsigned grid = tail > 0 ? (unsigned)min((int64_t)64, (tail + 255) / 256) : 1u;
+    composite_finish_bwd_k<<<grid, 256, 0, (hipStream_t)stream>>>(g_inv_s, n_rays, scalars, g_variance, g_sdf, g_grad, g_smooth, n_ray_pts, n_all);
+    return gens_launch_status("gens_composite_finish_bwd");
 }
 
 extern "C" int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g, void* stream) {

@@ -30,6 +30,13 @@ class CompositeIn(C.Structure):
         ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9), ("rot_dev", _p)]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("color", _p), ("target", _p), ("valid", _p), ("b", _l), ("sparse", _p), ("n_sparse", _l), ("sparse_scale", _f), ("pseudo", _p),
+                ("n_pseudo", _l), ("ncc", _p), ("mid_in", _p), ("depth", _p), ("pseudo_depth_t", _p), ("depth_t", _p), ("ge", _p), ("se", _p), ("tv", _p)] + [
+        (n, _f) for n in ("w_color", "w_igr", "w_sparse", "w_mfc", "w_smooth", "w_tv", "w_pseudo_sdf", "w_pseudo_depth")] + [
+        (n, _p) for n in ("out", "g", "g_color", "g_sparse", "g_pseudo", "g_ncc", "g_depth", "g_scalars")]
+
+
 class CompositeOut(C.Structure):
     _fields_ = [(n, _p) for n in ("color", "normal", "depth", "wsum", "wmax", "mid_in", "sdf_depth", "z_cross", "eik_num", "eik_den",
                                   "smooth_vec", "valid", "cross_idx", "weights", "inside", "pts_cross")]
@@ -37,7 +44,8 @@ class CompositeOut(C.Structure):
 
 class CompositeGrad(C.Structure):
     _fields_ = [(n, _p) for n in ("g_color", "g_normal", "g_depth", "g_weights", "g_wsum", "g_eik_num", "g_smooth_vec", "g_z_cross",
-                                  "weights", "cross_idx", "smooth_vec", "g_sdf", "g_grad", "g_col", "g_smooth", "g_inv_s")]
+                                  "weights", "cross_idx", "smooth_vec", "g_sdf", "g_grad", "g_col", "g_smooth", "g_inv_s", "g_gradient_error",
+                                  "g_smooth_error", "finish")]
 
 
 # name -> argtypes, mirroring include/gens_hip.h declaration by declaration
@@ -110,6 +118,10 @@ SIGNATURES = {
     "gens_gemm_tn_batch": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _p, _p],
     "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _pp, _p],
     "gens_scene_setup": [_p, _p, _i, _p, _p],
+    "gens_loss_fwd": [_p, _p],
+    "gens_loss_bwd": [_p, _p],
+    "gens_composite_finish_fwd": [_p, _p, _p, _l, _p, _p],
+    "gens_composite_finish_bwd": [_p, _l, _p, _p, _p, _p, _p, _l, _l, _p],
     "gens_patch_warp_fwd": [_p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     "gens_patch_warp_bwd": [_p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     "gens_pack_maps": [_pp, _pp, _ip, _i, _p],

@@ -308,9 +308,8 @@ class ImplicitSurface(nn.Module):
         sel = ops.StepPoints(pts_all, valid_all, n_ray, n_r, s_views, z=z_vals, variance=self.deviation_network.variance)
         y_all, g_all, s_all = net(pts_all, sel)
         sampled_color, src_vis = ops.blend_train(self.color_network, scene.views, pts_all, sel)
-        inv_s = ops.inv_s_from(self.deviation_network.variance, sel.scalars)
-        comp = ops.composite(rays_o, rays_d, z_vals, sample_dist, y_all[:n_ray], g_all[:n_ray], s_all[:n_ray], sampled_color, valid_all[:n_ray],
-                             src_vis, inv_s, cos_anneal_ratio, scene.ref_rotation(), z_max=sel.scalars[0:1])
+        comp = ops.composite_train(sel, rays_o, rays_d, z_vals, sample_dist, y_all, g_all, s_all, sampled_color, self.deviation_network.variance,
+                                   valid_all[:n_ray], sel.vis, cos_anneal_ratio, scene.ref_rotation())
         out = {
             "color_fine": comp["color"],
             "render_depth": comp["depth"],
@@ -324,8 +323,8 @@ class ImplicitSurface(nn.Module):
             "sdf_depth": comp["sdf_depth"][:, None],
             "gradients": g_all[:n_ray].reshape(b, n, 3),
             "s_val": sel.scalars[2:3].detach().reshape(1, 1).expand(b * n, 1),
-            "gradient_error": comp["eik_num"].sum() / (comp["eik_den"].sum() + 1e-5),
-            "smooth_error": torch.linalg.norm(comp["smooth_vec"], ord=2, dim=-1).abs().mean(),
+            "gradient_error": comp["gradient_error"],
+            "smooth_error": comp["smooth_error"],
             "sparse_sdf": torch.cat([y_all[n_ray:n_ray + n_r], y_all[:n_ray]]),
             "tv_reg": self.tv_regularization(scene.volumes, scene.mask_volumes),
         }

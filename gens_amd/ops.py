@@ -573,6 +573,7 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(sdf, grad, color, smooth, inv_s, rays_o, rays_d, z, voxel_mask, src_vis, z_max, o["weights"], cross_idx,
                               o["smooth_vec"])
         ctx.meta = (sample_dist, cos_anneal, rot)
+        ctx.set_materialize_grads(False)          # (an output nothing differentiates costs no zero-filled cotangent)
         ctx.mark_non_differentiable(o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx, o["pts_cross"])
         return (o["color"], o["normal"], o["depth"], o["weights"], o["wsum"], o["eik_num"], o["smooth_vec"], o["z_cross"], o["sdf_depth"],
                 o["wmax"], o["mid_in"], o["eik_den"], o["inside"], valid, cross_idx, o["pts_cross"])
@@ -623,6 +624,95 @@ class _InvS(torch.autograd.Function):
 
 def inv_s_from(variance, scalars):
     return _InvS.apply(variance, scalars)
+
+
+class _CompositeTrain(torch.autograd.Function):
+    """The compositing of a fused TRAINING step: K8 on the first n_ray rows of the step's dense arrays (StepPoints), the two per-batch
+    reductions gradient_error / smooth_error (implicit_surface.py:248-253) by one finishing workgroup, inv_s taken from the step's scalars
+    with its gradient going straight to `variance` -- two launches forward, two backward, no torch glue.  The gradients of the dense
+    arrays come back FULL size (zeros in the rows of the random / pseudo points), so no slice sits in the autograd graph.
+    inputs with gradient: y_all (N,1), g_all (N,3), s_all (N,3), color (n_ray,3), variance ()."""
+
+    @staticmethod
+    def forward(ctx, y_all, g_all, s_all, color, variance, sel, rays_o, rays_d, z, voxel_mask, src_vis, sample_dist, cos_anneal, rot):
+        b, n = z.shape
+        dev = z.device
+        y_all, g_all, s_all, color = _c(y_all.detach()), _c(g_all.detach()), _c(s_all.detach()), _c(color.detach())
+        inv_s, z_max = sel.scalars[1:2], sel.scalars[0:1]
+        ci = _composite_in(rays_o, rays_d, z, y_all, g_all, color, s_all, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=_f32)  # noqa: E731
+        o = dict(color=f(b, 3), normal=f(b, 3), depth=f(b), wsum=f(b), wmax=f(b), mid_in=f(b), sdf_depth=f(b), z_cross=f(b), eik_num=f(b),
+                 eik_den=f(b), smooth_vec=f(b, 3), weights=f(b, n), inside=f(b, n), pts_cross=f(b, 3))
+        valid = torch.empty(b, device=dev, dtype=torch.uint8)
+        cross_idx = torch.empty(b, device=dev, dtype=torch.int32)
+        co = L.CompositeOut()
+        for k, t in o.items():
+            setattr(co, k, L.ptr(t))
+        co.valid = L.ptr(valid, torch.uint8)
+        co.cross_idx = L.ptr(cross_idx, torch.int32)
+        n_src = src_vis.shape[-1] if src_vis is not None else 0
+        L.call("gens_composite_fwd", C.byref(ci), C.byref(co), L.stream(), nbytes=b * n * (4 + 4 + 12 + 12 + 1 + n_src + 12 + 8) + b * 100)
+        finish = f(4)
+        L.call("gens_composite_finish_fwd", L.ptr(o["eik_num"]), L.ptr(o["eik_den"]), L.ptr(o["smooth_vec"]), b, L.ptr(finish), L.stream())
+        ctx.save_for_backward(y_all, g_all, s_all, color, rays_o, rays_d, z, voxel_mask, src_vis, sel.scalars, o["weights"], cross_idx, o["smooth_vec"],
+                              finish)
+        ctx.meta = (sample_dist, cos_anneal, rot)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(o["wmax"], o["mid_in"], o["inside"], valid, cross_idx, o["pts_cross"])
+        return (o["color"], o["normal"], o["depth"], o["weights"], o["wsum"], o["z_cross"], o["sdf_depth"], finish[2], finish[3], o["wmax"], o["mid_in"],
+                o["inside"], valid, cross_idx, o["pts_cross"])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_color, g_normal, g_depth, g_weights, g_wsum, g_zc, _g_sdfdepth, g_ge, g_se, *_unused):
+        (y_all, g_all, s_all, color, rays_o, rays_d, z, voxel_mask, src_vis, scalars, weights, cross_idx, smooth_vec, finish) = ctx.saved_tensors
+        sample_dist, cos_anneal, rot = ctx.meta
+        b, n = z.shape
+        n_all = y_all.shape[0]
+        ci = _composite_in(rays_o, rays_d, z, y_all, g_all, color, s_all, voxel_mask, src_vis, scalars[1:2], scalars[0:1], sample_dist, cos_anneal, rot)
+        cg = L.CompositeGrad()
+        keep = []
+
+        def cot(t):
+            if t is None:
+                return None
+            t = _c(t.to(_f32))
+            keep.append(t)
+            return L.ptr(t)
+        cg.g_color, cg.g_normal, cg.g_depth, cg.g_weights = cot(g_color), cot(g_normal), cot(g_depth), cot(g_weights)
+        cg.g_wsum, cg.g_eik_num, cg.g_smooth_vec, cg.g_z_cross = cot(g_wsum), None, None, cot(g_zc)
+        cg.g_gradient_error, cg.g_smooth_error, cg.finish = cot(None if g_ge is None else g_ge.reshape(1)), cot(None if g_se is None else g_se.reshape(1)), L.ptr(finish)
+        cg.weights, cg.smooth_vec = L.ptr(weights), L.ptr(smooth_vec)
+        cg.cross_idx = L.ptr(cross_idx, torch.int32)
+        dev = z.device
+        g_sdf = torch.empty(n_all, 1, device=dev, dtype=_f32)
+        g_grad = torch.empty(n_all, 3, device=dev, dtype=_f32)
+        g_smooth = torch.empty(n_all, 3, device=dev, dtype=_f32)
+        g_col = torch.empty_like(color)
+        g_inv_s = torch.empty(b, device=dev, dtype=_f32)
+        g_var = torch.empty((), device=dev, dtype=_f32)
+        cg.g_sdf, cg.g_grad, cg.g_col, cg.g_smooth, cg.g_inv_s = L.ptr(g_sdf), L.ptr(g_grad), L.ptr(g_col), L.ptr(g_smooth), L.ptr(g_inv_s)
+        L.call("gens_composite_bwd", C.byref(ci), C.byref(cg), L.stream())
+        L.call("gens_composite_finish_bwd", L.ptr(g_inv_s), b, L.ptr(scalars), L.ptr(g_var), L.ptr(g_sdf), L.ptr(g_grad), L.ptr(g_smooth), b * n, n_all,
+               L.stream())
+        return (g_sdf, g_grad, g_smooth, g_col, g_var) + (None,) * 9
+
+
+COMPOSITE_TRAIN_KEYS = ("color", "normal", "depth", "weights", "wsum", "z_cross", "sdf_depth", "gradient_error", "smooth_error", "wmax", "mid_in",
+                        "inside", "valid", "cross_idx", "pts_cross")
+
+
+def composite_train(sel, rays_o, rays_d, z, sample_dist, y_all, g_all, s_all, color, variance, voxel_mask, src_vis, cos_anneal, rot):
+    """-> dict keyed by COMPOSITE_TRAIN_KEYS.  sel: the step's ops.StepPoints; voxel_mask (n_ray,) uint8 / bool, src_vis (n_ray, S) uint8 / bool."""
+    b, n = z.shape
+    u8 = torch.uint8
+    vm = voxel_mask.reshape(b * n)
+    vm = _c(vm.view(u8) if vm.dtype == torch.bool else vm.to(u8))
+    sv = src_vis.reshape(b * n, -1)
+    sv = _c(sv.view(u8) if sv.dtype == torch.bool else sv.to(u8))
+    outs = _CompositeTrain.apply(y_all, g_all, s_all, color, variance, sel, _c(rays_o.to(_f32)), _c(rays_d.to(_f32)), _c(z.detach().to(_f32)), vm, sv,
+                                 float(sample_dist), float(cos_anneal), rot)
+    return dict(zip(COMPOSITE_TRAIN_KEYS, outs))
 
 
 COMPOSITE_KEYS = ("color", "normal", "depth", "weights", "wsum", "eik_num", "smooth_vec", "z_cross", "sdf_depth", "wmax", "mid_in", "eik_den",
@@ -1896,7 +1986,7 @@ def blend_train(net, views, pts, sel=None):
     sel (StepPoints): only the selected ray samples are evaluated (count on the device); rgb / vis are sel's dense arrays."""
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
     rgb, vis = _BlendTrain.apply(pts, views, sel, *blend_params(net), views.imgs_tex, *views.feat_tex)
-    return rgb, vis.bool()
+    return rgb, (vis if sel is not None else vis.bool())        # (a selection's flags stay uint8: the compositing launch reads them as they are)
 
 
 class StepPoints:

@@ -204,10 +204,21 @@ typedef struct {
     const int32_t* cross_idx;  /* forward output */
     const float* smooth_vec;   /* forward output */
     float *g_sdf, *g_grad, *g_col, *g_smooth, *g_inv_s;
+    /* cotangents of the per-batch scalars of gens_composite_finish_fwd (DEVICE scalars or NULL) and its `finish` output */
+    const float *g_gradient_error, *g_smooth_error, *finish;
 } gens_composite_grad;
 
 int gens_composite_fwd(const gens_composite_in* in, const gens_composite_out* out, void* stream);
 int gens_composite_bwd(const gens_composite_in* in, const gens_composite_grad* g, void* stream);
+/* The per-batch reductions around the compositing of a training step, one workgroup each (implicit_surface.py:248-253, 206):
+ *   finish_fwd: finish (4) = {sum eik_num, sum eik_den, gradient_error = sum eik_num / (sum eik_den + 1e-5), smooth_error = mean |smooth_vec|}
+ *     (smooth_vec may be NULL).  Their cotangents go into gens_composite_grad.g_gradient_error / g_smooth_error.
+ *   finish_bwd: g_variance (1) = 10 inv_s [inside the clip range] sum_r g_inv_s[r] with scalars = gens_compact_points' {z_max, inv_s,
+ *     1 / inv_s, in range}; rows [n_ray_pts, n_all) of the dense gradient arrays g_sdf (n_all), g_grad / g_smooth (n_all, 3) are zeroed
+ *     (any of the four outputs may be NULL). */
+int gens_composite_finish_fwd(const float* eik_num, const float* eik_den, const float* smooth_vec, int64_t n_rays, float* finish, void* stream);
+int gens_composite_finish_bwd(const float* g_inv_s, int64_t n_rays, const float* scalars, float* g_variance, float* g_sdf, float* g_grad,
+                              float* g_smooth, int64_t n_ray_pts, int64_t n_all, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K6  SDFNetwork.forward(...)[:, :1] and its first derivative, inference only   (sdf_network.py:98-146)
@@ -560,6 +571,26 @@ int gens_patch_warp_fwd(const float* rays_o, const float* rays_d, const float* z
 int gens_patch_warp_bwd(const float* rays_o, const float* rays_d, const float* z, const float* g0, int64_t n_rays, const float* c2ws,
                         const float* intrs, const float* kinv_ref, int nv, const float* tex, int h, int w, int c, int patch,
                         const float* g_sampled, float* g_z, void* stream);
+/* gens_loss_fwd / _bwd: Loss.forward (models/losses/loss.py:24-93) in one launch, its backward in one launch.  The argument block: */
+typedef struct {
+    const float *color, *target;            /* color_fine, targets["color"]: (B, 3) */
+    const uint8_t* valid;                   /* valid_mask (B) */
+    int64_t b;
+    const float* sparse;                    /* sparse_sdf (n_sparse) */
+    int64_t n_sparse;
+    float sparse_scale;
+    const float* pseudo;                    /* pseudo_sdf (n_pseudo) or NULL */
+    int64_t n_pseudo;
+    const float *ncc, *mid_in;              /* compute_LNCC's result (B), mid_inside_sphere (B) */
+    const float *depth, *pseudo_depth_t, *depth_t;      /* render_depth (B); targets["pseudo_depth"], targets["depth"] (B) or NULL */
+    const float *ge, *se, *tv;              /* gradient_error, smooth_error, tv_reg: DEVICE scalars */
+    float w_color, w_igr, w_sparse, w_mfc, w_smooth, w_tv, w_pseudo_sdf, w_pseudo_depth;
+    float* out;                             /* (16): loss, color, eikonal, sparse, mfc, smooth, tv, depth, pseudo_sdf, pseudo_depth, 4 denominators, 2 spare */
+    const float* g;                         /* backward: d L / d loss, DEVICE scalar */
+    float *g_color, *g_sparse, *g_pseudo, *g_ncc, *g_depth, *g_scalars;      /* backward outputs (NULL to skip); g_scalars (3): ge, se, tv */
+} gens_loss_args;
+int gens_loss_fwd(const gens_loss_args* args, void* stream);
+int gens_loss_bwd(const gens_loss_args* args, void* stream);
 int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);

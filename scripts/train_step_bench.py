@@ -10,8 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gens_amd import ops, synthetic  # noqa: E402
-from gens_amd.config import gens_model_conf  # noqa: E402
-from gens_amd.losses import compute_LNCC  # noqa: E402
+from gens_amd.config import gens_loss_conf, gens_model_conf  # noqa: E402
+from gens_amd.losses import Loss  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E402
 
 
@@ -51,6 +51,9 @@ def _measure(quiet, kernels=False):
     ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": sc["near"].to(dev),
             "far": sc["far"].to(dev), "pseudo_pts": (torch.rand(2048, 3, generator=g) - 0.5).to(dev)}
     target = torch.rand(512, 3, device=dev)
+    targets = {"color": target}
+    # the reference's Loss module with the shipped weights (confs/gens.conf:47-59, confs/gens_finetune.conf:32-41), as runner.py:99,161 uses it
+    train_loss, ft_loss = Loss(gens_loss_conf()).to(dev), Loss(gens_loss_conf(finetune=True)).to(dev)
     if "--freeze-color" in sys.argv:             # probe: what the colour network's PyTorch-layer training costs (fine-tune: the feature maps are frozen too)
         surf.color_network.requires_grad_(False)
     adam = {"fused": True} if "--fused-adam" in sys.argv else {}      # (runner.py:97 builds the default, multi-tensor Adam: measured as such; the flag: one fused kernel)
@@ -65,11 +68,7 @@ def _measure(quiet, kernels=False):
 
     def ft_step():
         out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
-        ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]
-        loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
-            + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
-            + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
-            + out["pseudo_sdf"].abs().mean()
+        loss = ft_loss(out, targets)["loss"]                                        # runner.py:304-305 with confs/gens_finetune.conf's weights
         ft_opt.zero_grad(set_to_none=True)
         loss.backward()
         ft_opt.step()
@@ -80,12 +79,7 @@ def _measure(quiet, kernels=False):
             return ft_step()
         cost, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)        # K1 with autograd to the features, once per step (gens.py:139)
         out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
-        ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]                     # loss.py:36-38
-        loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
-            + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
-            + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
-            + out["pseudo_sdf"].abs().mean() \
-            + 1e-6 * sum(c.mean() for c in cost)
+        loss = train_loss(out, targets)["loss"] + 1e-6 * sum(c.mean() for c in cost)  # runner.py:161-162; the cost volumes stand in for the U-Net's use of them
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -100,11 +94,7 @@ def _measure(quiet, kernels=False):
 
         def step():  # noqa: F811
             out = model("train", ipts, cos_anneal_ratio=0.5, step=1)
-            ncc_mask = out["valid_mask"] * out["mid_inside_sphere"]
-            loss = ((out["color_fine"] - target).abs() * out["valid_mask"]).sum() / (out["valid_mask"].sum() + 1e-5) + 0.1 * out["gradient_error"] \
-                + 0.02 * torch.exp(-out["sparse_sdf"].abs() * 100).mean() + 1e-4 * out["smooth_error"] + 1e-4 * out["tv_reg"] \
-                + 0.5 * ((compute_LNCC(out["ref_gray_val"], out["sampled_gray_val"]) * ncc_mask).sum(0) / (ncc_mask.sum(0) + 1e-8)).squeeze(-1) \
-                + out["pseudo_sdf"].abs().mean()
+            loss = train_loss(out, targets)["loss"]
             full_opt.zero_grad(set_to_none=True)
             loss.backward()
             full_opt.step()

@@ -530,6 +530,55 @@ def g11_lncc():
     npz("g11_lncc", ref=ref, src=src, ncc=ncc, cot=cot, g_ref=g_ref, g_src=g_src)
 
 
+def g19_loss():
+    """Loss.forward (models/losses/loss.py:24-93) on random predictions / targets: every returned term and the gradient of `loss` with
+    respect to every differentiable prediction; two cases: the training configuration with all optional targets (confs/gens.conf:47-59), and
+    the fine-tune configuration without pseudo points / depth targets (confs/gens_finetune.conf:32-41)."""
+    from models.losses.loss import Loss
+    out = {}
+    for tag, conf, extras in (("a", dict(color_weight=1.0, sparse_weight=0.02, igr_weight=0.1, sparse_scale_factor=100, mfc_weight=1.0,
+                                         smooth_weight=0.0001, tv_weight=0.0001, depth_weight=0.0, pseudo_sdf_weight=1.0, normal_weight=0.0,
+                                         pseudo_depth_weight=0.05), True),
+                              ("b", dict(color_weight=1.0, sparse_weight=0.0, igr_weight=0.1, sparse_scale_factor=100, mfc_weight=1.0,
+                                         smooth_weight=0.0005, tv_weight=0.0001, pseudo_sdf_weight=1.0), False)):
+        g = torch.Generator().manual_seed(190 + len(out))
+        b, s = 40, 2 if tag == "b" else 4
+        base = torch.rand(1, b, 121, 12, generator=g)
+        preds = {
+            "color_fine": torch.rand(b, 3, generator=g), "valid_mask": torch.rand(b, 1, generator=g) > 0.25,
+            "gradient_error": torch.rand((), generator=g), "smooth_error": torch.rand((), generator=g), "tv_reg": torch.rand((), generator=g),
+            "sparse_sdf": 0.02 * torch.randn(1024 + b * 128, 1, generator=g), "mid_inside_sphere": (torch.rand(b, 1, generator=g) > 0.3).float(),
+            "ref_gray_val": base, "sampled_gray_val": base * (0.6 + 0.8 * torch.rand(s, b, 1, 12, generator=g)) + 0.25 * torch.rand(s, b, 121, 12, generator=g),
+            "render_depth": 1.0 + torch.rand(b, generator=g),
+        }
+        targets = {"color": torch.rand(b, 3, generator=g)}
+        if extras:
+            preds["pseudo_sdf"] = 0.05 * torch.randn(300, 1, generator=g)
+            pd = 1.0 + torch.rand(b, generator=g)
+            pd[::5] = 0.0
+            targets["pseudo_depth"] = pd
+            dt = 1.0 + torch.rand(b, generator=g)
+            dt[::3] = 0.0
+            targets["depth"] = dt
+        diff = [k for k in ("color_fine", "gradient_error", "smooth_error", "tv_reg", "sparse_sdf", "sampled_gray_val", "render_depth", "pseudo_sdf")
+                if k in preds]
+        for k in diff:
+            preds[k] = preds[k].clone().requires_grad_(True)
+        res = Loss(Conf(conf))(preds, targets)
+        grads = torch.autograd.grad(res["loss"], [preds[k] for k in diff], allow_unused=True)
+        for k, v in preds.items():
+            out[f"{tag}.pred.{k}"] = v.detach()
+        for k, v in targets.items():
+            out[f"{tag}.target.{k}"] = v
+        for k, v in res.items():
+            out[f"{tag}.out.{k}"] = v.detach()
+        for k, v in zip(diff, grads):
+            out[f"{tag}.grad.{k}"] = torch.zeros_like(preds[k]) if v is None else v
+        out[f"{tag}.conf"] = torch.tensor([conf.get(k, 0.0) for k in ("color_weight", "igr_weight", "sparse_weight", "mfc_weight", "smooth_weight",
+                                                                       "tv_weight", "pseudo_sdf_weight", "pseudo_depth_weight", "sparse_scale_factor")])
+    npz("g19_loss", **out)
+
+
 def _install_cv2_stub():
     """cv2 is absent here: a stub provides the two calls the datasets make -- INTER_NEAREST resize (OpenCV's documented index
     rule) and decomposeProjectionMatrix (scipy.linalg.rq + the null vector of P by SVD; the product code uses a different
@@ -871,6 +920,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g11":           # regenerate only the loss golden
         g11_lncc()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g19":           # the Loss module
+        g19_loss()
+        return
     from models.modules.volume import Volume
     from models.modules import projector
     from models.modules import implicit_surface as isurf_mod
@@ -888,6 +940,7 @@ def main():
     g10_geometry(surf, vols)
     g15_validate(surf, sc, vols, masks)
     g11_lncc()
+    g19_loss()
     g12_dtu_dataset()
     g13_bmvs_dataset()
     g14_clean_mesh()
