@@ -790,6 +790,7 @@ __global__ __launch_bounds__(256) void sdf_train_scatter_k(LevelSet vs, const fl
 struct SdfPackArgs {
     const float* w[TR_NLAYER];
     const float* b[TR_NLAYER];
+    const float* scale[TR_NLAYER];          // per output row g / |v| (weight norm: w = the raw direction matrix v), or NULL: w is effective
     float4* wf[TR_NLAYER];
     float4* wb[TR_NLAYER];
     int rows[TR_NLAYER], cols[TR_NLAYER];   // J_l (128 / 101), K_l (27 / 128 + FE)
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256) void sdf_train_pack_k(SdfPackArgs A) {
     const int J = A.rows[l], K = A.cols[l], G = A.gf[l];
     const int nf = 4 * G * 64, nb = A.ntb[l] * 16 * 64;
     const float* w = A.w[l];
+    const float* sc = A.scale[l];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += gridDim.x * 256) {
         float v[4];
         if (i < nf) {
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(256) void sdf_train_pack_k(SdfPackArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = 8 * g + 4 * (lane >> 5) + q;
-                v[q] = (j < J && k < K) ? w[(size_t)j * K + k] : (j < J && k == K) ? A.b[l][j] : 0.0f;
+                v[q] = (j < J && k < K) ? w[(size_t)j * K + k] * (sc ? sc[j] : 1.0f) : (j < J && k == K) ? A.b[l][j] : 0.0f;
             }
             A.wf[l][i] = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -820,10 +822,95 @@ __global__ __launch_bounds__(256) void sdf_train_pack_k(SdfPackArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int kk = 8 * g + 4 * (lane >> 5) + q;    // output row of W
-                v[q] = (jj < K && kk < J) ? w[(size_t)kk * K + jj] : 0.0f;
+                v[q] = (jj < K && kk < J) ? w[(size_t)kk * K + jj] * (sc ? sc[kk] : 1.0f) : 0.0f;
             }
             A.wb[l][ii] = make_float4(v[0], v[1], v[2], v[3]);
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// weight norm (nn.utils.weight_norm, sdf_network.py:90-91: W = g v / |v| per output row) around the packed streams
+// --------------------------------------------------------------------------------------------------------------------
+struct SdfNormArgs {
+    const float* v[TR_NLAYER + 1];          // weight_v of lin0..lin6, (rows_l, cols_l) row major
+    const float* g[TR_NLAYER + 1];          // weight_g (rows_l)
+    const float* b6;                        // bias of lin6 (its first entry is the SDF's)
+    int rows[TR_NLAYER + 1], cols[TR_NLAYER + 1];
+    float* scale[TR_NLAYER + 1];            // out: g / |v| per row
+    float *w_last, *b_last;                 // out: row 0 of the effective lin6 (cols_6), its bias (1)
+};
+
+// one wave per (layer, row): scale = g / |v|; row 0 of lin6 also leaves as the effective w_last
+__global__ __launch_bounds__(64) void sdf_train_norm_k(SdfNormArgs A) {
+    const int l = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    if (r >= A.rows[l]) return;
+    const int K = A.cols[l];
+    const float* v = A.v[l] + (size_t)r * K;
+    float s = 0.0f;
+    for (int k = lane; k < K; k += 64) s += v[k] * v[k];
+    s = wave_sum(s);
+    const float sc = A.g[l][r] / sqrtf(s);
+    if (lane == 0) A.scale[l][r] = sc;
+    if (l == TR_NLAYER && r == 0) {
+        for (int k = lane; k < K; k += 64) A.w_last[k] = v[k] * sc;
+        if (lane == 0) A.b_last[0] = A.b6[0];
+    }
+}
+
+// d loss / d (weight_v, weight_g, bias) of every layer from the effective-matrix gradients the batched products left in `cc`
+// (gens_sdf_train_bwd's header: per layer l = 1..5 the tiles [128 x 128 | 128 x FEP], then layer 0's [128 x 32]) and the column sums of
+// w6_part.  One wave per (layer, row):  s = dW . v,  dg = s / |v|,  dv = (g / |v|) (dW - v s / |v|^2),  db = the bias column.
+struct SdfWgradArgs {
+    const float* v[TR_NLAYER + 1];
+    const float* g[TR_NLAYER + 1];
+    int rows[TR_NLAYER + 1], cols[TR_NLAYER + 1];
+    const float* cc;                        // K14's concatenated tiles
+    const float* w6_sum;                    // (KP) column sums of w6_part
+    int fe, fep;
+    float* dv[TR_NLAYER + 1];
+    float* dg[TR_NLAYER + 1];
+    float* db[TR_NLAYER + 1];
+};
+
+__global__ __launch_bounds__(64) void sdf_train_wgrad_k(SdfWgradArgs A) {
+    const int l = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    if (r >= A.rows[l]) return;
+    const int K = A.cols[l];
+    const float* v = A.v[l] + (size_t)r * K;
+    const int64_t per_layer = (int64_t)TR_H * TR_H + (int64_t)TR_H * A.fep;
+    float dw[4], vv[4];                      // K <= 4 * 64
+    float s = 0.0f, n2 = 0.0f, bias = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        dw[q] = 0.0f;
+        vv[q] = 0.0f;
+        if (k < K) {
+            vv[q] = v[k];
+            if (l == 0) dw[q] = A.cc[5 * per_layer + (int64_t)r * 32 + k];
+            else if (l < TR_NLAYER) {
+                const float* h = A.cc + (int64_t)(l - 1) * per_layer;
+                dw[q] = k < TR_H ? h[(int64_t)r * TR_H + k] : h[(int64_t)TR_H * TR_H + (int64_t)r * A.fep + (k - TR_H)];
+            } else dw[q] = r == 0 ? A.w6_sum[k] : 0.0f;
+        }
+        s += dw[q] * vv[q];
+        n2 += vv[q] * vv[q];
+    }
+    s = wave_sum(s);
+    n2 = wave_sum(n2);
+    if (l == 0) bias = A.cc[5 * per_layer + (int64_t)r * 32 + TR_PE];
+    else if (l < TR_NLAYER) bias = A.cc[(int64_t)(l - 1) * per_layer + (int64_t)TR_H * TR_H + (int64_t)r * A.fep + A.fe];
+    else bias = r == 0 ? A.w6_sum[K] : 0.0f;
+    const float nrm = sqrtf(n2), sc = A.g[l][r] / nrm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < K) A.dv[l][(size_t)r * K + k] = sc * (dw[q] - vv[q] * (s / n2));
+    }
+    if (lane == 0) {
+        A.dg[l][r] = s / nrm;
+        A.db[l][r] = bias;
     }
 }
 
@@ -871,6 +958,7 @@ extern "C" int gens_sdf_train_pack(const float* const* w, const float* const* b,
         GENS_CHECK_ARG(w[l] && b[l] && wf[l] && wb[l], GENS_EINVAL, "gens_sdf_train_pack: layer %d is null", l);
         A.w[l] = w[l];
         A.b[l] = b[l];
+        A.scale[l] = nullptr;
         A.wf[l] = (float4*)wf[l];
         A.wb[l] = (float4*)wb[l];
         A.rows[l] = l == 2 ? TR_SKIP_H : TR_H;
@@ -969,4 +1057,72 @@ extern "C" int gens_sdf_train_scatter(const int* dims, int n_levels, const float
     sdf_train_scatter_k<<<gens_blocks(n * n_levels * 32, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, g_bar, s_bar, (const float4*)f_hat,
                                                                                          (const float4*)mu_f, (const float4*)lam_f, index, n, n_device);
     return gens_launch_status("gens_sdf_train_scatter");
+}
+
+static void sdf_layer_shapes(int n_levels, int* rows, int* cols) {
+    const int kin = TR_H + 20 * n_levels;
+    for (int l = 0; l <= TR_NLAYER; ++l) {
+        rows[l] = l == 2 ? TR_SKIP_H : (l == TR_NLAYER ? TR_H + 1 : TR_H);
+        cols[l] = l == 0 ? TR_PE : kin;
+    }
+}
+
+// gens_sdf_train_pack from the RAW weight-normed parameters (weight_v, weight_g, bias of lin0..lin6) in two launches: the row scales
+// g / |v| (+ the effective output row w_last (K floats) and its bias b_last (1)), then the streams.  scale: 7 caller-allocated DEVICE
+// arrays of rows_l floats, kept for gens_sdf_train_wgrad.
+extern "C" int gens_sdf_train_pack_wn(const float* const* v, const float* const* g, const float* const* b, int n_levels, float* const* scale,
+                                      float* const* wf, float* const* wb, float* w_last, float* b_last, void* stream) {
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_pack_wn: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(v && g && b && scale && wf && wb && w_last && b_last, GENS_EINVAL, "gens_sdf_train_pack_wn: null table");
+    SdfNormArgs N;
+    sdf_layer_shapes(n_levels, N.rows, N.cols);
+    for (int l = 0; l <= TR_NLAYER; ++l) {
+        GENS_CHECK_ARG(v[l] && g[l] && b[l] && scale[l], GENS_EINVAL, "gens_sdf_train_pack_wn: layer %d is null", l);
+        N.v[l] = v[l];
+        N.g[l] = g[l];
+        N.scale[l] = scale[l];
+    }
+    N.b6 = b[TR_NLAYER];
+    N.w_last = w_last;
+    N.b_last = b_last;
+    hipStream_t s = (hipStream_t)stream;
+    sdf_train_norm_k<<<dim3(TR_H + 1, TR_NLAYER + 1), 64, 0, s>>>(N);
+    SdfPackArgs A;
+    int most = 0;
+    for (int l = 0; l < TR_NLAYER; ++l) {
+        GENS_CHECK_ARG(wf[l] && wb[l], GENS_EINVAL, "gens_sdf_train_pack_wn: stream %d is null", l);
+        A.w[l] = v[l];
+        A.b[l] = b[l];
+        A.scale[l] = scale[l];
+        A.wf[l] = (float4*)wf[l];
+        A.wb[l] = (float4*)wb[l];
+        A.rows[l] = N.rows[l];
+        A.cols[l] = N.cols[l];
+        A.gf[l] = (A.cols[l] + 1 + 7) / 8;
+        A.ntb[l] = (A.cols[l] + 31) / 32;
+        most = max(most, 4 * A.gf[l] * 64 + A.ntb[l] * 16 * 64);
+    }
+    sdf_train_pack_k<<<dim3(gens_blocks(most, 256), TR_NLAYER), 256, 0, s>>>(A);
+    return gens_launch_status("gens_sdf_train_pack_wn");
+}
+
+// The parameter gradients of a step from the products of gens_sdf_train_bwd's operand rows: cc = gens_gemm_tn_batch's output for the
+// eleven products in the order (l = 1..5: [lop_l^T rh_l (128 x 128) | lop_l^T re (128 x FEP)], then lop_0^T r0 (128 x 32)), w6_sum (KP)
+// = the column sums of w6_part.  dv[l] (rows_l, cols_l), dg[l] (rows_l), db[l] (rows_l) for lin0..lin6: weight norm's backward included.
+extern "C" int gens_sdf_train_wgrad(const float* const* v, const float* const* g, int n_levels, const float* cc, const float* w6_sum,
+                                    float* const* dv, float* const* dg, float* const* db, void* stream) {
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_wgrad: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(v && g && cc && w6_sum && dv && dg && db, GENS_EINVAL, "gens_sdf_train_wgrad: null pointer");
+    SdfWgradArgs A;
+    sdf_layer_shapes(n_levels, A.rows, A.cols);
+    for (int l = 0; l <= TR_NLAYER; ++l) {
+        GENS_CHECK_ARG(v[l] && g[l] && dv[l] && dg[l] && db[l], GENS_EINVAL, "gens_sdf_train_wgrad: layer %d is null", l);
+        A.v[l] = v[l]; A.g[l] = g[l]; A.dv[l] = dv[l]; A.dg[l] = dg[l]; A.db[l] = db[l];
+    }
+    A.cc = cc;
+    A.w6_sum = w6_sum;
+    A.fe = 20 * n_levels;
+    A.fep = (TR_H + A.fe + 1 + 7) / 8 * 8 - TR_H;                    // KP - 128, KP = 8 ceil((K + 1) / 8)
+    sdf_train_wgrad_k<<<dim3(TR_H + 1, TR_NLAYER + 1), 64, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_sdf_train_wgrad");
 }

@@ -113,6 +113,8 @@ SIGNATURES = {
     "gens_lookup_feature_bwd_idx": [_ip, _i, _p, _p, _i, _p, _p, _p, _l, _p, _pp, _p, _p],
     "gens_gemm_tn_batch_live": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _i, _i, _p, _p, _p],
     "gens_sdf_train_pack": [_pp, _pp, _i, _pp, _pp, _p],
+    "gens_sdf_train_pack_wn": [_pp, _pp, _pp, _i, _pp, _pp, _pp, _p, _p, _p],
+    "gens_sdf_train_wgrad": [_pp, _pp, _i, _p, _p, _pp, _pp, _pp, _p],
     "gens_sdf_train_fwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p],
     "gens_sdf_train_bwd": [_pp, _ip, _i, _pp, _pp, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gens_gemm_tn_batch": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _p, _p],

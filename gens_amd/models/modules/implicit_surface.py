@@ -197,7 +197,7 @@ class ImplicitSurface(nn.Module):
             return None
         cached = getattr(scene, "_train_net_cache", None)        # one evaluator (weight norm + stream packing) per scene object = per step
         if cached is None:
-            cached = scene._train_net_cache = (self.sdf_network.train_step(scene.volumes, scene.volumes_nograd()),)
+            cached = scene._train_net_cache = (self.sdf_network.train_step(scene.volumes, scene.volumes_nograd(), tv_masks=scene.mask_volumes),)
         return cached[0]
 
     def _split_half_overflowed(self):
@@ -306,7 +306,8 @@ class ImplicitSurface(nn.Module):
                 valid_all[n_ray + n_r:].copy_(extra_valid)
         s_views = scene.views.nv - 1
         sel = ops.StepPoints(pts_all, valid_all, n_ray, n_r, s_views, z=z_vals, variance=self.deviation_network.variance)
-        y_all, g_all, s_all = net(pts_all, sel)
+        with_tv = ops.tv_levels_ok(scene.volumes, scene.mask_volumes)       # the regulariser rides on the network's Function: one gradient buffer
+        y_all, g_all, s_all, *tv_reg = net(pts_all, sel, tv=with_tv)
         sampled_color, src_vis = ops.blend_train(self.color_network, scene.views, pts_all, sel)
         comp = ops.composite_train(sel, rays_o, rays_d, z_vals, sample_dist, y_all, g_all, s_all, sampled_color, self.deviation_network.variance,
                                    valid_all[:n_ray], sel.vis, cos_anneal_ratio, scene.ref_rotation())
@@ -326,7 +327,7 @@ class ImplicitSurface(nn.Module):
             "gradient_error": comp["gradient_error"],
             "smooth_error": comp["smooth_error"],
             "sparse_sdf": torch.cat([y_all[n_ray:n_ray + n_r], y_all[:n_ray]]),
-            "tv_reg": self.tv_regularization(scene.volumes, scene.mask_volumes),
+            "tv_reg": tv_reg[0] if with_tv else self.tv_regularization(scene.volumes, scene.mask_volumes),
         }
         if n_x:
             out["_extra_sdf_dense"] = y_all[n_ray + n_r:]

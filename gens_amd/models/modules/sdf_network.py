@@ -122,14 +122,19 @@ class SDFNetwork(nn.Module):
             bs.append(lin.bias)
         return ws, bs
 
-    def train_step(self, volumes, packed):
+    def train_step(self, volumes, packed, tv_masks=None):
         """The fused training-mode evaluator (ops.SdfTrainStep: value, gradient, `smooth` and their backward in four launches) for this
         step's weights, or None when the kernels do not cover the architecture / pyramid (then the PyTorch layers run on K2 / K2'')."""
         from ... import ops
         if not (isinstance(packed, ops.VolumeSet) and ops.SdfTrainStep.supported(self, packed.n)):
             return None
+        lins = [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
+        if all(hasattr(lin, "weight_g") for lin in lins) and len(lins) == 7:
+            # the raw weight-normed parameters go in: the norm is one launch inside the pack, its backward rides on the gradient launch
+            raw = ([lin.weight_v for lin in lins], [lin.weight_g for lin in lins], [lin.bias for lin in lins])
+            return ops.SdfTrainStep(None, None, volumes, packed, raw=raw, tv_masks=tv_masks)
         ws, bs = self.effective_weights()
-        return ops.SdfTrainStep(ws, bs, volumes, packed)
+        return ops.SdfTrainStep(ws, bs, volumes, packed, tv_masks=tv_masks)
 
     @torch.enable_grad()
     def sdf_gradient_smooth(self, x, volumes):

@@ -1379,26 +1379,47 @@ class SdfTrainStep:
     def supported(net, n_levels):
         return SdfMlpPlan.supported(net) and float(net.scale) == 1.0 and n_levels in (3, 5) and net.init_feat_channels == 4 * n_levels
 
-    def __init__(self, weights, biases, volumes, packed):
-        assert len(weights) == 7 and len(biases) == 7
+    def __init__(self, weights, biases, volumes, packed, raw=None, tv_masks=None):
+        """weights / biases: the EFFECTIVE matrices with autograd history (torch._weight_norm's outputs) -- or, with raw = (weight_v list,
+        weight_g list, bias list) of lin0..lin6, None: weight norm then happens inside the pack launch and its backward inside the
+        gradient launch (gens_sdf_train_pack_wn / gens_sdf_train_wgrad), and the raw parameters are the autograd inputs.
+        tv_masks: the mask pyramid; with it `step(pts, sel, tv=True)` also returns tv_regularization(volumes, masks) (implicit_surface.py:
+        135-150) so that the dense TV gradient and the scattered look-up gradient of the volumes are formed in ONE buffer."""
         assert isinstance(packed, VolumeSet) and packed.layout == L.LAYOUT_PACKED and packed.n in (3, 5)
-        self.weights, self.biases, self.volumes, self.packed = list(weights), list(biases), list(volumes), packed
+        self.volumes, self.packed = list(volumes), packed
         self.n_levels = packed.n
-        dev = weights[0].device
+        self.raw = raw
+        self.tv_masks = None if tv_masks is None else [_c(m.detach()) for m in tv_masks]
+        dev = self.volumes[0].device if self.volumes else packed.tensors[0].device
         kin = 128 + 20 * self.n_levels
         self.kp = (kin + 1 + 7) // 8 * 8
         gf = [(27 + 1 + 7) // 8] + [self.kp // 8] * 5
         ntb = [1] + [(kin + 31) // 32] * 5
+        self.wf = [torch.empty(4 * g * 64 * 4, device=dev, dtype=_f32) for g in gf]
+        self.wb = [torch.empty(nt * 16 * 64 * 4, device=dev, dtype=_f32) for nt in ntb]
+        self.wf_table, self.wb_table = L.ptr_table(self.wf), L.ptr_table(self.wb)
         with torch.no_grad():
-            w = [_c(t.detach().to(_f32)) for t in weights[:6]]
-            b = [_c(t.detach().to(_f32)) for t in biases[:6]]
-            assert tuple(w[0].shape) == (128, 27) and tuple(w[2].shape) == (101, kin) and tuple(w[5].shape) == (128, kin)
-            self.wf = [torch.empty(4 * g * 64 * 4, device=dev, dtype=_f32) for g in gf]
-            self.wb = [torch.empty(nt * 16 * 64 * 4, device=dev, dtype=_f32) for nt in ntb]
-            self.wf_table, self.wb_table = L.ptr_table(self.wf), L.ptr_table(self.wb)
-            L.call("gens_sdf_train_pack", L.ptr_table(w), L.ptr_table(b), self.n_levels, self.wf_table, self.wb_table, L.stream())
-            self.w_last = _c(weights[6].detach().to(_f32)[0].clone())
-            self.b_last = _c(biases[6].detach().to(_f32)[:1].clone())
+            if raw is None:
+                assert len(weights) == 7 and len(biases) == 7
+                self.tensors = [*weights, *biases]
+                w = [_c(t.detach().to(_f32)) for t in weights[:6]]
+                b = [_c(t.detach().to(_f32)) for t in biases[:6]]
+                assert tuple(w[0].shape) == (128, 27) and tuple(w[2].shape) == (101, kin) and tuple(w[5].shape) == (128, kin)
+                L.call("gens_sdf_train_pack", L.ptr_table(w), L.ptr_table(b), self.n_levels, self.wf_table, self.wb_table, L.stream())
+                self.w_last = _c(weights[6].detach().to(_f32)[0].clone())
+                self.b_last = _c(biases[6].detach().to(_f32)[:1].clone())
+            else:
+                vs, gs, bs = raw
+                assert len(vs) == len(gs) == len(bs) == 7
+                self.tensors = [*vs, *gs, *bs]
+                self.v = [_c(t.detach().to(_f32)) for t in vs]
+                self.g = [_c(t.detach().to(_f32).reshape(-1)) for t in gs]
+                b = [_c(t.detach().to(_f32)) for t in bs]
+                assert tuple(self.v[0].shape) == (128, 27) and tuple(self.v[2].shape) == (101, kin) and tuple(self.v[6].shape) == (129, kin)
+                self.scale = [torch.empty(t.shape[0], device=dev, dtype=_f32) for t in self.v]
+                self.w_last, self.b_last = torch.empty(kin, device=dev, dtype=_f32), torch.empty(1, device=dev, dtype=_f32)
+                L.call("gens_sdf_train_pack_wn", L.ptr_table(self.v), L.ptr_table(self.g), L.ptr_table(b), self.n_levels, L.ptr_table(self.scale),
+                       self.wf_table, self.wb_table, L.ptr(self.w_last), L.ptr(self.b_last), L.stream(), label="gens_sdf_train_pack")
 
     def _forward(self, pts, sel=None):
         """sel (StepPoints): evaluate pts[sel.idx[:count]] with the count left on the device and write rows sel.idx[i] of sel's dense
@@ -1418,8 +1439,10 @@ class SdfTrainStep:
                L.ptr(s), L.stream(), nbytes=n * 40, flops=n * flops, live=None if cnt is None else (cnt, n))
         return y, g, s
 
-    def __call__(self, pts, sel=None):
-        return _SdfTrain.apply(_c(pts.detach().reshape(-1, 3).to(_f32)), self, sel, *self.weights, *self.biases, *self.volumes)
+    def __call__(self, pts, sel=None, tv=False):
+        """-> (y, g, s) [, tv_reg when tv=True (needs tv_masks)]."""
+        out = _SdfTrain.apply(_c(pts.detach().reshape(-1, 3).to(_f32)), self, sel, bool(tv), *self.tensors, *self.volumes)
+        return out if tv else out[:3]
 
     @torch.no_grad()
     def first_order(self, pts):
@@ -1428,17 +1451,31 @@ class SdfTrainStep:
 
 class _SdfTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts, step, sel, *tensors):
+    def forward(ctx, pts, step, sel, tv, *tensors):
         ctx.step, ctx.sel = step, sel
-        ctx.save_for_backward(pts)
         ctx.shapes = [t.shape for t in tensors]
-        return step._forward(pts, sel)
+        ctx.n_par = len(step.tensors)
+        y, g, s = step._forward(pts, sel)
+        tv_out = None
+        if tv:
+            assert step.tv_masks is not None, "SdfTrainStep(tv_masks=...) is needed for tv=True"
+            nl = step.n_levels
+            vols = [_c(v.detach()) for v in step.volumes]
+            ctx.tv_dims = [d for v in vols for d in v.shape[-3:]]
+            partial = torch.empty(L.load().gens_tv_levels_blocks(L.int_table(ctx.tv_dims), nl), 4, device=pts.device, dtype=_f32)
+            tv_out = torch.empty(1 + nl, device=pts.device, dtype=_f32)
+            L.call("gens_tv_levels_fwd", L.ptr_table(vols, align=16), L.ptr_table(step.tv_masks, align=16), L.int_table(ctx.tv_dims), nl, L.ptr(partial),
+                   L.ptr(tv_out), L.stream(), nbytes=sum(20 * v[0, 0].numel() for v in vols))
+            ctx.save_for_backward(pts, tv_out, *vols)
+            return y, g, s, tv_out[0]
+        ctx.save_for_backward(pts)
+        return y, g, s, None
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, y_bar, g_bar, s_bar):
+    def backward(ctx, y_bar, g_bar, s_bar, tv_bar):
         step, sel = ctx.step, ctx.sel
-        pts, = ctx.saved_tensors
+        pts, *tv_saved = ctx.saved_tensors
         n, dev = pts.shape[0], pts.device
         idx, cnt = (None, None) if sel is None else (sel.idx, sel.counts[0:1])
         nl = step.n_levels
@@ -1486,32 +1523,60 @@ class _SdfTrain(torch.autograd.Function):
             L.call("gens_gemm_tn_batch_live", n_prod, tab(a_ptr), L.int_table([768] * n_prod), tab(b_ptr), L.int_table(ldb), mi, ni, k,
                    L.ptr(cnt, torch.int32), 32, 128, L.ptr(ws), L.ptr(cc), L.stream(), nbytes=fl * k * (768 + 32 + 5 * 128 + fep),
                    flops=2 * k * sum(sizes), live=live, label="gens_gemm_tn_batch")
-        parts, off = [], 0
-        for m, n_ in zip(ms, ns):
-            parts.append(cc[off:off + m * n_].view(m, n_))
-            off += m * n_
-        w0 = parts[10]
-        g_w, g_b = [w0[:, :27]], [w0[:, 27]]
-        for l in range(1, 6):
-            rows = 101 if l == 2 else 128
-            h, e_l = parts[2 * (l - 1)], parts[2 * (l - 1) + 1]
-            g_w.append(torch.cat([h, e_l[:, :fe]], 1)[:rows])
-            g_b.append(e_l[:rows, fe])
         w6s = w6p.sum(0)
-        w6 = torch.zeros(ctx.shapes[6], device=dev, dtype=_f32)
-        w6[0] = w6s[:kin]
-        b6 = torch.zeros(ctx.shapes[13], device=dev, dtype=_f32)
-        b6[0] = w6s[kin]
-        g_w.append(w6)
-        g_b.append(b6)
-        # volume gradients
+        n_par = ctx.n_par
+        if step.raw is not None:
+            # d loss / d (weight_v, weight_g, bias) of lin0..lin6 in ONE launch, weight norm's backward included; the 21 gradients are views
+            # of one flat buffer (contiguous each: autograd installs them as .grad without a copy)
+            sizes_v = [v.numel() for v in step.v]
+            rows = [v.shape[0] for v in step.v]
+            flat = f(sum(sizes_v) + 2 * sum(rows))
+            dv, dg, db, off = [], [], [], 0
+            for v in step.v:
+                dv.append(flat[off:off + v.numel()].view(v.shape))
+                off += v.numel()
+            for r in rows:
+                dg.append(flat[off:off + r])
+                off += r
+            for r in rows:
+                db.append(flat[off:off + r])
+                off += r
+            L.call("gens_sdf_train_wgrad", L.ptr_table(step.v), L.ptr_table(step.g), nl, L.ptr(cc), L.ptr(w6s), L.ptr_table(dv), L.ptr_table(dg),
+                   L.ptr_table(db), L.stream())
+            g_par = [*dv, *[d.view(ctx.shapes[7 + k]) for k, d in enumerate(dg)], *db]
+        else:
+            parts, off = [], 0
+            for m, n_ in zip(ms, ns):
+                parts.append(cc[off:off + m * n_].view(m, n_))
+                off += m * n_
+            w0 = parts[10]
+            g_w, g_b = [w0[:, :27]], [w0[:, 27]]
+            for l in range(1, 6):
+                rows = 101 if l == 2 else 128
+                h, e_l = parts[2 * (l - 1)], parts[2 * (l - 1) + 1]
+                g_w.append(torch.cat([h, e_l[:, :fe]], 1)[:rows])
+                g_b.append(e_l[:rows, fe])
+            w6 = torch.zeros(ctx.shapes[6], device=dev, dtype=_f32)
+            w6[0] = w6s[:kin]
+            b6 = torch.zeros(ctx.shapes[13], device=dev, dtype=_f32)
+            b6[0] = w6s[kin]
+            g_par = [*g_w, w6, *g_b, b6]
+        # volume gradients: the dense TV gradient (when the step carries the regulariser) is WRITTEN first, the look-up's scatter adds into it
         g_vols = [None] * nl
-        if any(ctx.needs_input_grad[3 + 14:]):
-            g_vols = [torch.zeros(s, device=dev, dtype=_f32) for s in ctx.shapes[14:]]
+        if any(ctx.needs_input_grad[4 + n_par:]):
+            have_tv = bool(tv_saved) and tv_bar is not None
+            if have_tv:
+                tv_out, *vols = tv_saved
+                g_vols = [torch.empty(s, device=dev, dtype=_f32) for s in ctx.shapes[n_par:]]
+                L.call("gens_tv_levels_bwd", L.ptr_table(list(vols), align=16), L.ptr_table(step.tv_masks, align=16), L.int_table(ctx.tv_dims), nl,
+                       L.ptr(tv_out), L.ptr(_c(tv_bar.detach().to(_f32).reshape(1))), L.ptr_table(g_vols, align=16), L.stream(),
+                       nbytes=sum(36 * v[0, 0].numel() for v in vols))
+            else:
+                g_vols = [torch.zeros(s, device=dev, dtype=_f32) for s in ctx.shapes[n_par:]]
             L.call("gens_sdf_train_scatter", step.packed.dim_table, nl, L.ptr(pts), L.ptr(cot[1]), L.ptr(cot[2]), L.ptr(f_hat), L.ptr(mu_f),
                    L.ptr(lam_f), L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr_table(g_vols), L.stream(), nbytes=n * (36 + 3 * 4 * cf),
                    live=live)
-        return (None, None, None, *g_w, *g_b, *g_vols)
+        return (None, None, None, None, *g_par, *g_vols)
 
 
 # ------------------------------------------------------------------------------------------------------------------

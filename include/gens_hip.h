@@ -331,6 +331,17 @@ int gens_sdf_value_f16_units(int n_levels);
  *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
  *       w f_hat + (grad w . s_bar) mu_f + (grad w . g_bar) lam_f per corner  (float atomics).
  * ---------------------------------------------------------------------------------------------------------- */
+/*   gens_sdf_train_pack_wn: gens_sdf_train_pack from the RAW weight-normed parameters (nn.utils.weight_norm, sdf_network.py:90-91:
+ *     W = g v / |v| per output row): v / g / b = HOST arrays of the 7 device pointers weight_v (rows_l, cols_l), weight_g (rows_l), bias
+ *     (rows_l) of lin0..lin6; scale: 7 caller-allocated arrays of rows_l floats (g / |v|, kept for the backward); also writes the effective
+ *     output row w_last (K floats) and its bias b_last (1).  Two launches.
+ *   gens_sdf_train_wgrad: the parameter gradients of a step in one launch -- cc = gens_gemm_tn_batch's result for the eleven products in
+ *     the order (l = 1..5: [lop_l^T rh_l (128 x 128) | lop_l^T re (128 x KP - 128)], then lop_0^T r0 (128 x 32)), w6_sum (KP) = the column
+ *     sums of w6_part -> dv[l] (rows_l, cols_l), dg[l] (rows_l), db[l] (rows_l) for lin0..lin6, weight norm's backward included. */
+int gens_sdf_train_pack_wn(const float* const* v, const float* const* g, const float* const* b, int n_levels, float* const* scale,
+                           float* const* wf, float* const* wb, float* w_last, float* b_last, void* stream);
+int gens_sdf_train_wgrad(const float* const* v, const float* const* g, int n_levels, const float* cc, const float* w6_sum,
+                         float* const* dv, float* const* dg, float* const* db, void* stream);
 int64_t gens_sdf_train_stash_bytes(int64_t n, int backward);
 int gens_sdf_train_pack(const float* const* w, const float* const* b, int n_levels, float* const* wf, float* const* wb, void* stream);
 int gens_sdf_train_fwd(const float* const* vols_packed, const int* dims, int n_levels, const float* const* wf,
