@@ -72,6 +72,9 @@ class _PackMaps(torch.autograd.Function):
         L.call("gens_pack_maps", L.ptr_table(xs), L.ptr_table(outs, align=16), L.int_table(nchw), len(xs), L.stream())
         ctx.shapes = [tuple(x.shape) for x in xs]
         ctx.set_materialize_grads(False)          # a map nothing downstream differentiates gets no gradient pass (not a pass over zeros)
+        # the texels of a map that needs no gradient must not hang on this node: they are kept on the map (pack_maps) and outlive the step,
+        # while the node's other inputs (this step's feature maps) do not
+        ctx.mark_non_differentiable(*[o for k, o in enumerate(outs) if not ctx.needs_input_grad[k]])
         return tuple(outs)
 
     @staticmethod
@@ -97,7 +100,7 @@ def pack_maps(maps):
     out, todo = [None] * len(maps), []
     grad_mode = torch.is_grad_enabled()
     for k, m in enumerate(maps):
-        hit = getattr(m, "_gens_tex", None)
+        hit = None if os.environ.get("GENS_NO_TEX_CACHE") else getattr(m, "_gens_tex", None)
         if hit is not None and hit[0] == m._version and hit[1] == (grad_mode and m.requires_grad) and hit[2].device == m.device:
             out[k] = hit[2]
         else:
