@@ -847,10 +847,12 @@ __global__ __launch_bounds__(64) void sdf_train_norm_k(SdfNormArgs A) {
     if (r >= A.rows[l]) return;
     const int K = A.cols[l];
     const float* v = A.v[l] + (size_t)r * K;
-    float s = 0.0f;
-    for (int k = lane; k < K; k += 64) s += v[k] * v[k];
-    s = wave_sum(s);
-    const float sc = A.g[l][r] / sqrtf(s);
+    // |v| from a float64 sum, rounded once: within half an ulp of the exact norm whatever the summation order (torch's float32 tree sum
+    // is one of many orders; the hierarchical sampling downstream amplifies last-bit differences of the effective matrices)
+    double s = 0.0;
+    for (int k = lane; k < K; k += 64) s += (double)v[k] * (double)v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float sc = A.g[l][r] / (float)sqrt(s);
     if (lane == 0) A.scale[l][r] = sc;
     if (l == TR_NLAYER && r == 0) {
         for (int k = lane; k < K; k += 64) A.w_last[k] = v[k] * sc;

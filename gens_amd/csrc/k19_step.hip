@@ -199,115 +199,160 @@ struct StepFill {
     const float* variance;     // (1) or NULL
     float* scalars;            // [z_max, inv_s, 1 / inv_s, inv_s inside the clip range ? 1 : 0]
 };
-#define CP_THREADS 1024
-__global__ __launch_bounds__(CP_THREADS) void compact_points_k(const uint8_t* __restrict__ valid, int64_t n0, int64_t n1, int64_t n,
-                                                                int64_t* __restrict__ idx, int32_t* __restrict__ counts, StepFill F) {
-    __shared__ int wave_tot[CP_THREADS / 64];
-    __shared__ int seg_tot[2];
-    __shared__ float zred[CP_THREADS / 64];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // a thread owns `per` consecutive rows, a multiple of 16 so that its flags are a few 16-byte loads (one workgroup, dependent loads: a
-    // byte at a time the kernel took longer than the 512-ray step's compositing)
-    constexpr int CP_MAX = 96;                                     // rows per thread kept in registers as packed bits (n < 1024 * 96)
-    const int64_t per = ((n + CP_THREADS - 1) / CP_THREADS + 15) / 16 * 16;
-    const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
-    const bool wide = per <= CP_MAX && ((uintptr_t)valid & 15) == 0;
-    uint32_t bits[CP_MAX / 32] = {0u, 0u, 0u};
-    if (wide) {
-        for (int64_t i = lo; i < hi; i += 16) {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (i + 16 <= n) {
-                const uint4 q = *(const uint4*)(valid + i);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            } else {
-                for (int k = 0; i + k < n; ++k) w[k >> 2] |= (uint32_t)valid[i + k] << (8 * (k & 3));
-            }
+// Two launches: per-workgroup counts (+ partial maxima of z), then -- every workgroup adding up the counts before its own -- the ordered
+// write.  (One workgroup doing all of it took 127 us for a step's 68 k rows: longer than the compositing it serves.)
+#define CP_BLOCK 256
+#define CP_PER 8                       // rows per thread
+#define CP_ROWS (CP_BLOCK * CP_PER)    // rows per workgroup
+#define CP_MAX_BLOCKS 8192             // n < 2^24
+
+__device__ __forceinline__ uint32_t cp_flags(const uint8_t* __restrict__ valid, int64_t first, int64_t n) {
+    uint32_t bits = 0;
+    if (first + CP_PER <= n && (((uintptr_t)(valid + first)) & 7) == 0) {
+        const uint2 q = *(const uint2*)(valid + first);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = (int)(i - lo) + k;
-                if ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) bits[r >> 5] |= 1u << (r & 31);
-            }
+        for (int k = 0; k < 4; ++k) {
+            bits |= ((q.x >> (8 * k)) & 0xffu) ? (1u << k) : 0u;
+            bits |= ((q.y >> (8 * k)) & 0xffu) ? (1u << (4 + k)) : 0u;
         }
+    } else {
+        for (int k = 0; k < CP_PER && first + k < n; ++k) bits |= valid[first + k] ? (1u << k) : 0u;
     }
-#define CP_FLAG(i) (wide ? ((bits[((i) - lo) >> 5] >> (((i) - lo) & 31)) & 1u) != 0 : valid[i] != 0)
-    // pass 1: flags set in the ray segment / in the pseudo segment
-    int c0 = 0, c2 = 0;
-    for (int64_t i = lo; i < hi; ++i) {
-        const bool v = CP_FLAG(i);
-        c0 += (i < n0 && v) ? 1 : 0;
-        c2 += (i >= n0 + n1 && v) ? 1 : 0;
+    return bits;
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void compact_points_count_k(const uint8_t* __restrict__ valid, int64_t n0, int64_t n1, int64_t n,
+                                                                   int32_t* __restrict__ blk, const float* __restrict__ z, int64_t nz,
+                                                                   float* __restrict__ zpart) {
+    __shared__ int red[3][CP_BLOCK / 64];
+    __shared__ float zred[CP_BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t first = (int64_t)blockIdx.x * CP_ROWS + (int64_t)t * CP_PER;
+    const uint32_t bits = first < n ? cp_flags(valid, first, n) : 0u;
+    int c_ray = 0, c_other = 0, c_pseudo = 0;
+    for (int k = 0; k < CP_PER; ++k) {
+        const int64_t i = first + k;
+        const int v = (i < n && ((bits >> k) & 1u)) ? 1 : 0;
+        if (i < n0) c_ray += v;
+        else if (i < n0 + n1) c_other += i < n ? 1 : 0;
+        else { c_other += v; c_pseudo += v; }
     }
-    float f0 = wave_sum((float)c0), f2 = wave_sum((float)c2);      // (counts < 2^24: exact in float32)
-    if (t == 0) { seg_tot[0] = 0; seg_tot[1] = 0; }
+    const float f0 = wave_sum((float)c_ray), f1 = wave_sum((float)c_other), f2 = wave_sum((float)c_pseudo);
+    float zm = -3.402823466e38f;
+    if (z) {
+        for (int64_t i = (int64_t)blockIdx.x * CP_BLOCK + t; i < nz; i += (int64_t)gridDim.x * CP_BLOCK) zm = fmaxf(zm, z[i]);
+        zm = wave_max(zm);
+    }
+    if (lane == 0) { red[0][wv] = (int)f0; red[1][wv] = (int)f1; red[2][wv] = (int)f2; zred[wv] = zm; }
     __syncthreads();
-    if (lane == 0) { atomicAdd(&seg_tot[0], (int)f0); atomicAdd(&seg_tot[1], (int)f2); }
-    __syncthreads();
-    const bool rescue = seg_tot[0] == 0;
-    const int64_t n_rescue = min((int64_t)10, n0);
-    // pass 2: selection with the rescue rule, exclusive scan over the threads, ordered write
-    int mine = 0;
-    for (int64_t i = lo; i < hi; ++i) {
-        const bool sel = i < n0 ? (rescue ? i < n_rescue : CP_FLAG(i)) : (i < n0 + n1 ? true : CP_FLAG(i));
-        mine += sel ? 1 : 0;
-    }
-    float inc = wave_scan_add((float)mine, lane);
-    if (lane == 63) wave_tot[wv] = (int)inc;
-    __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wv; ++k) base += wave_tot[k];
-    int64_t pos = base + (int)inc - mine;
-    for (int64_t i = lo; i < hi; ++i) {
-        const bool sel = i < n0 ? (rescue ? i < n_rescue : CP_FLAG(i)) : (i < n0 + n1 ? true : CP_FLAG(i));
-        if (sel) {
-            idx[pos++] = i;
-            continue;
-        }
-        if (F.y) F.y[i] = i < n0 ? 100.0f : 0.0f;
-        if (F.g) { F.g[3 * i] = 0.0f; F.g[3 * i + 1] = 0.0f; F.g[3 * i + 2] = 0.0f; }
-        if (F.s) { F.s[3 * i] = 0.0f; F.s[3 * i + 1] = 0.0f; F.s[3 * i + 2] = 0.0f; }
-        if (i < n0) {
-            if (F.rgb) { F.rgb[3 * i] = 0.0f; F.rgb[3 * i + 1] = 0.0f; F.rgb[3 * i + 2] = 0.0f; }
-            if (F.vis) for (int v = 0; v < F.n_src; ++v) F.vis[i * F.n_src + v] = 0;
-        }
-    }
-    if (F.scalars) {
-        if (F.z) {
-            float m = -3.402823466e38f;
-            for (int64_t i = t; i < F.nz; i += CP_THREADS) m = fmaxf(m, F.z[i]);
-            m = wave_max(m);
-            if (lane == 0) zred[wv] = m;
-            __syncthreads();
-            if (t == 0) {
-                for (int k = 1; k < CP_THREADS / 64; ++k) m = fmaxf(m, zred[k]);
-                F.scalars[0] = m;
-            }
-        }
-        if (F.variance && t == 0) {
-            const float raw = expf(F.variance[0] * 10.0f);                 // SingleVarianceNetwork.forward (variance_network.py:11), then :206
-            const float inv_s = fminf(fmaxf(raw, 1e-6f), 1e6f);
-            F.scalars[1] = inv_s;
-            F.scalars[2] = 1.0f / inv_s;
-            F.scalars[3] = (raw >= 1e-6f && raw <= 1e6f) ? 1.0f : 0.0f;
-        }
-    }
-#undef CP_FLAG
-    if (t == CP_THREADS - 1) {
-        counts[0] = base + (int)inc;
-        counts[1] = rescue ? (int)n_rescue : seg_tot[0];
-        counts[2] = seg_tot[1];
+    if (t == 0) {
+        int a = 0, b = 0, c = 0;
+        for (int k = 0; k < CP_BLOCK / 64; ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; zm = fmaxf(zm, zred[k]); }
+        blk[3 * blockIdx.x] = a; blk[3 * blockIdx.x + 1] = b; blk[3 * blockIdx.x + 2] = c;
+        if (z) zpart[blockIdx.x] = zm;
     }
 }
 
+__global__ __launch_bounds__(CP_BLOCK) void compact_points_write_k(const uint8_t* __restrict__ valid, int64_t n0, int64_t n1, int64_t n,
+                                                                   const int32_t* __restrict__ blk, const float* __restrict__ zpart,
+                                                                   int64_t* __restrict__ idx, int32_t* __restrict__ counts, StepFill F) {
+    __shared__ int red[4][CP_BLOCK / 64];
+    __shared__ float zred[CP_BLOCK / 64];
+    __shared__ int wave_tot[CP_BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nb = gridDim.x;
+    // the counts of all workgroups: rays selected in all, selected before this one (both branches of the rescue rule), pseudo points
+    int tot_ray = 0, before_ray = 0, before_other = 0, tot_other = 0, tot_pseudo = 0;
+    float zm = -3.402823466e38f;
+    for (int b = t; b < nb; b += CP_BLOCK) {
+        const int a = blk[3 * b], o = blk[3 * b + 1];
+        tot_ray += a; tot_other += o; tot_pseudo += blk[3 * b + 2];
+        if (b < (int)blockIdx.x) { before_ray += a; before_other += o; }
+        if (F.z) zm = fmaxf(zm, zpart[b]);
+    }
+    const float s0 = wave_sum((float)tot_ray), s1 = wave_sum((float)before_ray), s2 = wave_sum((float)before_other), s3 = wave_sum((float)tot_other);
+    const float s4 = wave_sum((float)tot_pseudo);
+    zm = wave_max(zm);
+    if (lane == 0) { red[0][wv] = (int)s0; red[1][wv] = (int)s1; red[2][wv] = (int)s2; red[3][wv] = (int)s3; zred[wv] = zm; wave_tot[wv] = (int)s4; }
+    __syncthreads();
+    tot_ray = before_ray = before_other = tot_other = tot_pseudo = 0;
+    for (int k = 0; k < CP_BLOCK / 64; ++k) {
+        tot_ray += red[0][k]; before_ray += red[1][k]; before_other += red[2][k]; tot_other += red[3][k]; tot_pseudo += wave_tot[k];
+        zm = fmaxf(zm, zred[k]);
+    }
+    __syncthreads();
+    const bool rescue = tot_ray == 0;
+    const int64_t n_rescue = min((int64_t)10, n0);
+    const int64_t block_first = (int64_t)blockIdx.x * CP_ROWS;
+    const int64_t rescued_before = min(n_rescue, block_first);                      // rows < min(10, n0) that lie before this workgroup
+    const int64_t base = before_other + (rescue ? rescued_before : (int64_t)before_ray);
+    const int64_t first = block_first + (int64_t)t * CP_PER;
+    const uint32_t bits = first < n ? cp_flags(valid, first, n) : 0u;
+    uint32_t sel = 0;
+    int mine = 0;
+    for (int k = 0; k < CP_PER; ++k) {
+        const int64_t i = first + k;
+        const bool v = (bits >> k) & 1u;
+        const bool s = i < n && (i < n0 ? (rescue ? i < n_rescue : v) : (i < n0 + n1 ? true : v));
+        sel |= s ? (1u << k) : 0u;
+        mine += s ? 1 : 0;
+    }
+    const float inc = wave_scan_add((float)mine, lane);
+    if (lane == 63) wave_tot[wv] = (int)inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+    int64_t pos = base + wbase + (int)inc - mine;
+    for (int k = 0; k < CP_PER; ++k) {
+        const int64_t i = first + k;
+        if (i < n) {
+            if ((sel >> k) & 1u) {
+                idx[pos++] = i;
+            } else {
+                if (F.y) F.y[i] = i < n0 ? 100.0f : 0.0f;
+                if (F.g) { F.g[3 * i] = 0.0f; F.g[3 * i + 1] = 0.0f; F.g[3 * i + 2] = 0.0f; }
+                if (F.s) { F.s[3 * i] = 0.0f; F.s[3 * i + 1] = 0.0f; F.s[3 * i + 2] = 0.0f; }
+                if (i < n0) {
+                    if (F.rgb) { F.rgb[3 * i] = 0.0f; F.rgb[3 * i + 1] = 0.0f; F.rgb[3 * i + 2] = 0.0f; }
+                    if (F.vis) for (int v = 0; v < F.n_src; ++v) F.vis[i * F.n_src + v] = 0;
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        const int n_ray_sel = rescue ? (int)n_rescue : tot_ray;
+        counts[0] = n_ray_sel + tot_other;
+        counts[1] = n_ray_sel;
+        counts[2] = tot_pseudo;
+        if (F.scalars) {
+            if (F.z) F.scalars[0] = zm;
+            if (F.variance) {
+                const float raw = expf(F.variance[0] * 10.0f);                 // SingleVarianceNetwork.forward (variance_network.py:11), then :206
+                const float inv_s = fminf(fmaxf(raw, 1e-6f), 1e6f);
+                F.scalars[1] = inv_s;
+                F.scalars[2] = 1.0f / inv_s;
+                F.scalars[3] = (raw >= 1e-6f && raw <= 1e6f) ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
+extern "C" int64_t gens_compact_points_scratch(int64_t n) { return 4 * ((n + CP_ROWS - 1) / CP_ROWS + 1); }      // int32 / float words
+
 extern "C" int gens_compact_points(const uint8_t* valid, int64_t n_rays_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
                                    float* y_fill, float* g_fill, float* s_fill, float* rgb_fill, uint8_t* vis_fill, int n_src, const float* z,
-                                   int64_t nz, const float* variance, float* scalars, void* stream) {
-    GENS_CHECK_ARG(valid && idx && counts, GENS_EINVAL, "gens_compact_points: null pointer");
+                                   int64_t nz, const float* variance, float* scalars, int32_t* scratch, void* stream) {
+    GENS_CHECK_ARG(valid && idx && counts && scratch, GENS_EINVAL, "gens_compact_points: null pointer");
     GENS_CHECK_ARG((!z && !variance) || scalars, GENS_EINVAL, "gens_compact_points: z / variance given without a scalars output");
     GENS_CHECK_ARG(!vis_fill || (n_src >= 1 && n_src < GENS_MAX_VIEWS), GENS_ELIMIT, "gens_compact_points: n_src=%d", n_src);
     StepFill F = {y_fill, g_fill, s_fill, rgb_fill, vis_fill, n_src, z, z ? nz : 0, variance, scalars};
     GENS_CHECK_ARG(n_rays_pts >= 0 && n_always >= 0 && n_rays_pts + n_always <= n && n < ((int64_t)1 << 24), GENS_EINVAL,
                    "gens_compact_points: bad segment sizes (%lld, %lld of %lld; fewer than 2^24 rows)", (long long)n_rays_pts, (long long)n_always, (long long)n);
-    compact_points_k<<<1, CP_THREADS, 0, (hipStream_t)stream>>>(valid, n_rays_pts, n_always, n, idx, counts, F);
+    const unsigned nb = n > 0 ? gens_blocks(n, CP_ROWS) : 1u;
+    float* zpart = (float*)(scratch + 3 * (int64_t)nb);
+    hipStream_t st = (hipStream_t)stream;
+    compact_points_count_k<<<nb, CP_BLOCK, 0, st>>>(valid, n_rays_pts, n_always, n, scratch, z, F.nz, zpart);
+    compact_points_write_k<<<nb, CP_BLOCK, 0, st>>>(valid, n_rays_pts, n_always, n, scratch, zpart, idx, counts, F);
     return gens_launch_status("gens_compact_points");
 }
 

@@ -128,7 +128,7 @@ SIGNATURES = {
     "gens_patch_warp_bwd": [_p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     "gens_pack_maps": [_pp, _pp, _ip, _i, _p],
     "gens_unpack_maps": [_pp, _pp, _ip, _i, _p],
-    "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p],
+    "gens_compact_points": [_p, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p],
     "gens_tv_levels_blocks": [_ip, _i],
     "gens_tv_levels_fwd": [_pp, _pp, _ip, _i, _p, _p, _p],
     "gens_tv_levels_bwd": [_pp, _pp, _ip, _i, _p, _p, _pp, _p],
@@ -162,6 +162,8 @@ def load():
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
     lib.gens_scene_cams_floats.restype = _l
     lib.gens_scene_cams_floats.argtypes = [_i]
+    lib.gens_compact_points_scratch.restype = _l
+    lib.gens_compact_points_scratch.argtypes = [_l]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i

@@ -196,6 +196,7 @@ class VolumeSet:
         vs = VolumeSet.__new__(VolumeSet)
         vs.layout = L.LAYOUT_PLANAR
         vs.tensors = [_c(m.detach().reshape(m.shape[-3:])) for m in mask_volumes]
+        vs.sources = list(mask_volumes)
         vs.dims = [tuple(t.shape) for t in vs.tensors]
         vs.n = len(vs.tensors)
         vs.table = L.ptr_table(vs.tensors)
@@ -204,14 +205,23 @@ class VolumeSet:
         return vs
 
     def bit_table(self):
-        """Bit-packed copy of a mask pyramid (built once, on first use): HOST pointer table for mask_bits=1 calls."""
+        """Bit-packed copy of a mask pyramid (built once, on first use): HOST pointer table for mask_bits=1 calls.  The words are kept ON the
+        mask tensor (valid for its current version): a frozen pyramid (fine-tuning: GenS.mask_volmes) is packed once, not once per step."""
         if getattr(self, "_bits", None) is None:
             words = []
-            for t in self.tensors:
+            for t, src in zip(self.tensors, getattr(self, "sources", self.tensors)):
+                hit = getattr(src, "_gens_bits", None)
+                if hit is not None and hit[0] == src._version and hit[1].device == t.device:
+                    words.append(hit[1])
+                    continue
                 n = t.numel()
                 w = torch.empty((n + 31) // 32, device=t.device, dtype=torch.int32)
                 L.call("gens_pack_mask_bits", L.ptr(t), n, L.ptr(w, torch.int32), L.stream())
                 words.append(w)
+                try:
+                    src._gens_bits = (src._version, w)
+                except (AttributeError, RuntimeError):
+                    pass
             self._bits = (words, L.ptr_table(words, torch.int32))
         return self._bits[1]
 
@@ -813,7 +823,21 @@ def patch_warp(z_cross, rays_o, rays_d, g0, cams, warp, patch_size=11):
 
 
 def build_warp_features(levels):
-    """cat([f0, up(f1), up(f2)], 1) of implicit_surface.py:313-326 as (nv,H,W,12) texels; inputs (nv,4,h_i,w_i) NCHW, detached."""
+    """cat([f0, up(f1), up(f2)], 1) of implicit_surface.py:313-326 as (nv,H,W,12) texels; inputs (nv,4,h_i,w_i) NCHW, detached.
+    The result is kept on levels[0] for the current versions of the three maps (frozen maps -- fine-tuning -- are up-sampled once)."""
+    key = tuple((id(f), f._version) for f in levels)
+    hit = getattr(levels[0], "_gens_warp", None)
+    if hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[1], levels[1:])):
+        return hit[2]
+    res = _build_warp_features(levels)
+    try:
+        levels[0]._gens_warp = (key, list(levels[1:]), res)        # (the coarser maps are held so that their ids cannot be recycled)
+    except (AttributeError, RuntimeError):
+        pass
+    return res
+
+
+def _build_warp_features(levels):
     f0 = levels[0].detach()
     nv, c, h, w = f0.shape
     ctot = sum(f.shape[1] for f in levels)
@@ -2076,7 +2100,8 @@ class StepPoints:
         self.vis = torch.empty(self.n_ray, n_src, device=dev, dtype=torch.uint8)
         self.scalars = torch.empty(4, device=dev, dtype=_f32)
         zc = None if z is None else _c(z.detach())
+        scratch = torch.empty(L.load().gens_compact_points_scratch(n), device=dev, dtype=torch.int32)
         L.call("gens_compact_points", L.ptr(_c(valid_all), torch.uint8), self.n_ray, self.n_always, n, L.ptr(self.idx, torch.int64),
                L.ptr(self.counts, torch.int32), L.ptr(self.y), L.ptr(self.g), L.ptr(self.s), L.ptr(self.rgb), L.ptr(self.vis, torch.uint8), n_src,
                L.ptr(zc), 0 if zc is None else zc.numel(), L.ptr(None if variance is None else _c(variance.detach().reshape(1))), L.ptr(self.scalars),
-               L.stream(), nbytes=n * 9)
+               L.ptr(scratch, torch.int32), L.stream(), nbytes=n * 9)

@@ -560,7 +560,8 @@ int gens_instnorm_relu_bwd(const float* x, const float* gy, const float* mean_rs
  * gens_compact_points: the index list of a step's masked SDF evaluation (implicit_surface.py:121-124,174-177,256-257,484-497): rows
  *   [0, n_ray_pts) are ray samples with flags from gens_ray_points (none set: the first min(10, n) of them, Q7), the next n_always rows
  *   are always selected (the random points), the rest are the pseudo points with their own flags.  idx (n) int64: selected rows in
- *   increasing order; counts (3) int32 = {selected, selected ray samples, selected pseudo points}.  n < 2^24; one workgroup.
+ *   increasing order; counts (3) int32 = {selected, selected ray samples, selected pseudo points}.  n < 2^24; two launches (counts per
+ *   workgroup, ordered write); scratch: gens_compact_points_scratch(n) 4-byte words of device memory.
  *   Optional outputs of the same launch (NULL to skip): the values the reference's dense tensors hold for UNSELECTED rows (Q8) --
  *   y_fill (n): 100 for ray samples, 0 for pseudo points (implicit_surface.py:125,497); g_fill / s_fill (n, 3): 0; rgb_fill
  *   (n_ray_pts, 3): 0; vis_fill (n_ray_pts, n_src): 0 -- and scalars (4) = {max of z (nz floats; :301), inv_s = clip(exp(10 variance),
@@ -606,9 +607,10 @@ int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
 int gens_unpack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
+int64_t gens_compact_points_scratch(int64_t n);   /* 4-byte words of scratch for n rows */
 int gens_compact_points(const uint8_t* valid, int64_t n_ray_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
                         float* y_fill, float* g_fill, float* s_fill, float* rgb_fill, uint8_t* vis_fill, int n_src, const float* z,
-                        int64_t nz, const float* variance, float* scalars, void* stream);
+                        int64_t nz, const float* variance, float* scalars, int32_t* scratch, void* stream);
 int gens_tv_levels_blocks(const int* dims, int n_levels);
 int gens_tv_levels_fwd(const float* const* vols, const float* const* masks, const int* dims, int n_levels, float* partial, float* out,
                        void* stream);

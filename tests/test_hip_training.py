@@ -464,10 +464,11 @@ def test_gens_finetune_path_matches_the_reference_model(tag, dims, seed):
             + torch.exp(-out["sparse_sdf"].abs() * 100).mean() + (((out["sampled_gray_val"] - out["ref_gray_val"]) ** 2) * hit).mean()
             + 0.1 * out["render_depth"].sum() + out["pseudo_sdf"].abs().mean())
     loss.backward()
-    # (free-running hierarchical samples: the inverse-CDF step amplifies the float32 round-off of the weight-normed matrices -- the
-    # fused kernels take torch._weight_norm's product like the reference's hook -- on rays with a flat pdf; per-sample `weights`
-    # feel it first.  With pinned samples everything agrees to 1e-4: tests/test_hip_render.py)
-    bad = {k: e for k, e in ((k, rel(out[k[4:]], v)) for k, v in g.items() if k.startswith("out.")) if e > (1e-3 if k == "out.weights" else 3e-4)}
+    # (free-running hierarchical samples: the inverse-CDF step amplifies the float32 round-off of the weight-normed matrices on rays with a
+    # flat pdf; per-sample `weights` feel it first.  The fused step forms g v / |v| with a correctly rounded |v| (float64 sum), the
+    # reference's hook with torch._weight_norm's float32 sum: 1.1e-3 here, 0.6e-3 when the step took torch's product itself.  With pinned
+    # samples everything agrees to 1e-4: tests/test_hip_render.py)
+    bad = {k: e for k, e in ((k, rel(out[k[4:]], v)) for k, v in g.items() if k.startswith("out.")) if e > (2e-3 if k == "out.weights" else 3e-4)}
     assert not bad, bad
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     rows = [(f"volume{i}", rel(thin(model.volumes[i].grad, i), g[f"grad.volume{i}"]), float(np.abs(g[f"grad.volume{i}"]).max())) for i in range(nl)]
