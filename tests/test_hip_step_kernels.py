@@ -79,9 +79,10 @@ def test_compact_points_against_nonzero(n0, n1, n2, p0, p2):
     z = torch.rand(max(n0, 1), generator=g).cuda() * 3 - 1
     var = torch.tensor([0.3], device="cuda")
     scal = torch.zeros(4, device="cuda")
-    L.call("gens_compact_points", L.ptr(valid.cuda(), torch.uint8), n0, n1, n, L.ptr(idx, torch.int64), L.ptr(counts, torch.int32), L.ptr(y),
-           L.ptr(g3), None, L.ptr(rgb), L.ptr(vis, torch.uint8), 4, L.ptr(z), z.numel(), L.ptr(var), L.ptr(scal),
-           L.ptr(torch.empty(L.load().gens_compact_points_scratch(n), dtype=torch.int32, device="cuda"), torch.int32), L.stream())
+    valid_d = valid.cuda()                                                      # (kept alive: a temporary's memory would be handed to the scratch buffer)
+    scratch = torch.empty(L.load().gens_compact_points_scratch(n), dtype=torch.int32, device="cuda")
+    L.call("gens_compact_points", L.ptr(valid_d, torch.uint8), n0, n1, n, L.ptr(idx, torch.int64), L.ptr(counts, torch.int32), L.ptr(y),
+           L.ptr(g3), None, L.ptr(rgb), L.ptr(vis, torch.uint8), 4, L.ptr(z), z.numel(), L.ptr(var), L.ptr(scal), L.ptr(scratch, torch.int32), L.stream())
     ray = torch.nonzero(valid[:n0])[:, 0]
     if ray.numel() < 1:
         ray = torch.arange(min(10, n0))

@@ -336,25 +336,42 @@ def test_bmvs_datasets_drive_val_finetune_and_the_writers(tmp_path):
 # 1e-4 perturbation of the volumes alone moves exactly those gradients by 1.2e-3: scripts/probe/oracle_vs_reference_training.py; with the
 # reference's own volumes the CPU oracle reproduces them to 6e-6, and the K17 kernels the oracle to 5e-5), the two CNNs up to
 # 1.6e-2 (first MnasNet convolution: batch-norm statistics over three 64 x 96 views amplify float32 round-off of MIOpen against ATen).
-GRAD_RTOL = 2e-3
+# Round 3: per parameter group, three times what is measured (scripts: pytest -s prints the tables; profiles/r03_grad_tables.txt):
+#   2-D CNN / 3-D U-Net 1.6e-2 / 1.0e-3 -> 3e-2 (kept), colour network 1.7e-3 -> 5e-3, SDF network biases / weight_g 2.7e-4 -> 1e-3,
+#   SDF weight_v 8e-5 -> 3e-4 -- except the five-level fine-tune golden g18b with its free-running samples: 3.0e-3 -> 1e-2 --,
+#   fine-tune volumes 6e-5 -> 2e-4, the variance 6e-6 -> 1e-4.
 GRAD_RTOL_CNN = 3e-2
 GRAD_ZERO = 1e-5     # a tensor whose largest golden entry is below GRAD_ZERO x the largest gradient in the table is analytically zero
                      # (the bias in front of a softmax, a head whose output is unused): pure round-off on both sides, compared absolutely
 
 
-def _grad_table(rows):
+def _grad_tol(name, loose_weight_v=False):
+    if "_network." in name and "implicit_surface" not in name:
+        return GRAD_RTOL_CNN
+    if "color_network" in name:
+        return 5e-3
+    if "variance" in name:
+        return 1e-4
+    if name.startswith("volume"):
+        return 2e-4
+    if "weight_v" in name:
+        return 1e-2 if loose_weight_v else 3e-4
+    return 1e-3
+
+
+def _grad_table(rows, loose_weight_v=False):
     """rows: (name, error relative to the tensor's largest magnitude, largest magnitude) -> the rows that matter, worst first; printed in
     full (pytest -s / on failure).  Analytically-zero tensors are re-scaled to the table's largest gradient."""
     top = max(m for _, _, m in rows)
     rows = [(k, e * m / (GRAD_ZERO * top) if m < GRAD_ZERO * top else e, m) for k, e, m in rows]
-    rows = sorted(rows, key=lambda r: -r[1] / (GRAD_RTOL_CNN if "_network." in r[0] and "implicit_surface" not in r[0] else GRAD_RTOL))
+    rows = sorted(rows, key=lambda r: -r[1] / _grad_tol(r[0], loose_weight_v))
     print("\n".join(f"  {e:9.2e}  |max| {m:9.2e}  {k}" for k, e, m in rows))
     return rows
 
 
-def _check_grad_table(rows):
-    rows = _grad_table(rows)
-    bad = [r for r in rows if r[1] >= (GRAD_RTOL_CNN if "_network." in r[0] and "implicit_surface" not in r[0] else GRAD_RTOL)]
+def _check_grad_table(rows, loose_weight_v=False):
+    rows = _grad_table(rows, loose_weight_v)
+    bad = [r for r in rows if r[1] >= _grad_tol(r[0], loose_weight_v)]
     assert not bad, bad[:6]
 
 
@@ -364,7 +381,7 @@ def test_gens_forward_matches_the_reference_model_end_to_end(tag, dims, seed):
     RegNetwork and ImplicitSurface classes, make_golden.py g17): same seeded backbone weights, same implicit-surface weights, same
     host RNG stream -> the 19 outputs, the loss and parameter gradients in every part of the model.  Floating point through two CNNs
     (MIOpen / K15 / K16 against ATen's CPU convolutions), the volume build, ~250 MLP evaluations per ray and their derivatives:
-    outputs within 2e-4 of each tensor's largest magnitude, gradients within 2 %."""
+    outputs within 2e-4 of each tensor's largest magnitude, gradients within the per-group bounds of _grad_tol (three times what is measured)."""
     import numpy as np
     from gens_amd.config import gens_model_conf
     from gens_amd.models import gens
@@ -475,4 +492,7 @@ def test_gens_finetune_path_matches_the_reference_model(tag, dims, seed):
     rows.append(("lin0.weight_v", rel(model.implicit_surface.sdf_network.lin0.weight_v.grad, g["grad.lin0"]), float(np.abs(g["grad.lin0"]).max())))
     params = dict(model.named_parameters())
     rows += [(k[5:], rel(params[k[5:]].grad, v), float(np.abs(v).max())) for k, v in g.items() if k.startswith("grad.implicit_surface.")]
-    _check_grad_table(rows)
+    # g18b: the volumes come out of `init_volumes` (device CNNs, within 2e-4 of ATen's) and a 1e-4 perturbation of the volumes alone moves the
+    # weight_v gradients of lin1..6 by 1.2e-3 (scripts/probe/oracle_vs_reference_training.py); with the reference's own volumes the CPU oracle
+    # reproduces them to 6e-6
+    _check_grad_table(rows, loose_weight_v=tag.endswith("l5"))
