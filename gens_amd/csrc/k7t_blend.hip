@@ -33,6 +33,7 @@ struct BlendTWeights {
     const float4* stream;       // A fragments in consumption order: per (M tile, group of 4 K quads) 64 lanes x float4
     const float* tab;           // per lane group q: [entry][q][8] floats (accumulator-layout biases, dot-product rows)
     float v2_last_b, u2_b, r3_b, s_abs;
+    const float* sdev;          // the same four scalars in DEVICE memory (gens_blend_pack_t: weights that change every step), or NULL
 };
 enum { KT_RD1_B = 0, KT_RD2_B, KT_B2_B, KT_V1_B, KT_V2_B, KT_U1_B, KT_R2_B, KT_V2_LAST, KT_U2, KT_R3, KT_TAB_ENTRIES };
 
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64, 2) void blend_t_k(BlendTWeights W, MapSet fs, c
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
     const int64_t first = (int64_t)blockIdx.x * PPW;
     if (first >= n) return;
+    if (W.sdev) { W.v2_last_b = W.sdev[0]; W.u2_b = W.sdev[1]; W.r3_b = W.sdev[2]; W.s_abs = W.sdev[3]; }
 
     // weights: scalar base, three float4 registers rotate (this group's, the next two in flight)
     const float4* wp = W.stream;
@@ -432,6 +434,11 @@ extern "C" int gens_blend_views_t_groups(int n_levels) {
 }
 extern "C" int gens_blend_views4_groups(int n_levels) { return gens_blend_views_t_groups(n_levels); }
 
+struct BlendTWeights;
+static int blend_t_run(int n_levels, int nv, const BlendTWeights& W, const MapSet& fs, const float* imgs, const float* w2c, const float* intr,
+                       const float* c2w, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out,
+                       uint8_t* vis_out, void* stream);
+
 template <int S>
 static void blend_t_launch(int n_levels, unsigned grid, hipStream_t st, const BlendTWeights& W, const MapSet& fs, const float* imgs, const float* w2c,
                            const float* intr, const float* c2w, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
@@ -463,6 +470,13 @@ extern "C" int gens_blend_views_t(const float* const* feats, const int* hw, int 
     W.stream = (const float4*)wstream;
     W.tab = tab;
     W.v2_last_b = scalars[0]; W.u2_b = scalars[1]; W.r3_b = scalars[2]; W.s_abs = scalars[3];
+    W.sdev = nullptr;
+    return blend_t_run(n_levels, nv, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out, stream);
+}
+
+static int blend_t_run(int n_levels, int nv, const BlendTWeights& W, const MapSet& fs, const float* imgs, const float* w2c, const float* intr,
+                       const float* c2w, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out,
+                       uint8_t* vis_out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (nv == 3) blend_t_launch<2>(n_levels, gens_blocks(n, 32), st, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out);
     else if (nv == 4) blend_t_launch<3>(n_levels, gens_blocks(n, 16), st, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out);
@@ -476,4 +490,133 @@ extern "C" int gens_blend_views4(const float* const* feats, const int* hw, int n
                                  const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
     GENS_CHECK_ARG(nv == 5, GENS_ELIMIT, "gens_blend_views4: built for four source views (nv = 5), got nv=%d (use gens_blend_views_t / gens_blend_views)", nv);
     return gens_blend_views_t(feats, hw, n_levels, imgs, w2c, intr, c2w, nv, wstream, tab, scalars, pts, index, n, n_device, rgb_out, vis_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The weight stream, tables and scalars of gens_blend_views_t straight from the 23 RAW nn.Linear parameters of a BlendingNetwork
+// (order of gens_blend_train_fwd), in one launch: a training step's colour network changes every step, and gens_amd.ops._pack_blend_t
+// builds the same arrays with ~100 PyTorch launches.  Layout as documented at _pack_blend_t / in this file's header.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct BlendPackT {
+    const float* p[23];
+    int f;                       // 3 + 4 NLEV
+    float4* stream;
+    float* tab;                  // (10, 4, 8)
+    float* scalars;              // (4) DEVICE
+    int n_groups;                // without the two trailing zero groups
+};
+
+__device__ __forceinline__ float bpt_entry(const BlendPackT& A, int prod, int row, int slot, int xq) {
+    const int f = A.f;
+    int wi, O, I, col;            // parameter index of the weight, its shape, the source column (-1 bias, -2 nothing)
+    bool has_bias = false;
+    switch (prod) {
+        case 0: wi = 0; O = 16; I = 4; col = slot < 4 ? slot : -2; break;                                          // ray_dir_fc.0
+        case 1: wi = 2; O = f; I = 16; col = slot < 16 ? slot : -2; break;                                         // ray_dir_fc.2
+        case 2: wi = 4; O = 64; I = 3 * f;                                                                          // base_fc.0: mean | var
+            col = slot < 4 * xq ? (slot < f ? slot : -2) : (slot - 4 * xq < f ? f + slot - 4 * xq : -2); break;
+        case 3: wi = 4; O = 64; I = 3 * f; has_bias = true; col = slot < f ? 2 * f + slot : (slot == f ? -1 : -2); break;   // base_fc.0: x | bias
+        case 4: wi = 6; O = 32; I = 64; col = slot < 64 ? slot : -2; break;                                        // base_fc.2
+        case 5: wi = 8; O = 32; I = 32; col = slot < 32 ? slot : -2; break;                                        // vis_fc.0
+        case 6: wi = 10; O = 32; I = 32; col = slot < 32 ? slot : -2; break;                                       // vis_fc.2 rows 0..31
+        case 7: wi = 12; O = 32; I = 32; col = slot < 32 ? slot : -2; break;                                       // vis_fc2.0
+        case 8: wi = 16; O = 16; I = 37; has_bias = true; col = slot < 37 ? slot : (slot == 37 ? -1 : -2); break;  // rgb_fc.0
+        default: wi = 18; O = 8; I = 16; col = slot < 16 ? slot : -2; break;                                       // rgb_fc.2
+    }
+    if (row >= O || col == -2) return 0.0f;
+    if (col == -1) return has_bias ? A.p[wi + 1][row] : 0.0f;
+    return A.p[wi][(int64_t)row * I + col];
+}
+
+__global__ __launch_bounds__(256) void blend_pack_t_k(BlendPackT A) {
+    const int f = A.f, xq = (f + 1) / 4, xt = (xq + 3) / 4;
+    const int nq[10] = {1, 4, 2 * xq, xq, 16, 8, 8, 8, 10, 4};
+    const int mt[10] = {1, xt, 4, 4, 2, 2, 2, 2, 1, 1};
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int n_stream = (A.n_groups + 2) * 64;
+    if (gid < n_stream) {
+        const int grp = gid >> 6, lane = gid & 63;
+        float4 v = f4_zero();
+        if (grp < A.n_groups) {
+            int prod = 0, g0 = 0;
+            for (; prod < 10; ++prod) {
+                const int gp = mt[prod] * ((nq[prod] + 3) / 4);
+                if (grp < g0 + gp) break;
+                g0 += gp;
+            }
+            const int gq = (nq[prod] + 3) / 4, t = (grp - g0) / gq, g = (grp - g0) % gq;
+            const int m = lane & 15, qk = lane >> 4;
+            const int row = 16 * t + 4 * (m & 3) + (m >> 2);
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kq = 4 * g + j;
+                e[j] = kq < nq[prod] ? bpt_entry(A, prod, row, 4 * kq + qk, xq) : 0.0f;
+            }
+            v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        A.stream[gid] = v;
+        return;
+    }
+    const int k = gid - n_stream;
+    if (k < 10 * 32) {                                     // tab[entry][q][c]
+        const int entry = k >> 5, q = (k >> 3) & 3, c = k & 7;
+        float v = 0.0f;
+        if (entry < 7) {                                   // accumulator-layout bias: [q][4 T + i] = b[16 T + 4 i + q]
+            const int bi[7] = {1, 3, 7, 9, 11, 13, 19}, len[7] = {16, f, 32, 32, 32, 32, 8}, tiles[7] = {1, xt, 2, 2, 2, 2, 1};
+            const int T = c >> 2, i = c & 3, src = 16 * T + 4 * i + q;
+            if (T < tiles[entry] && src < len[entry]) v = A.p[bi[entry]][src];
+        } else {                                           // dot-product row: [q][kq] = w[4 kq + q]
+            const int src = 4 * c + q;
+            if (entry == 7) v = A.p[10][32 * 32 + src];                        // row 32 of vis_fc.2 (33 x 32)
+            else if (entry == 8) v = A.p[14][src];                             // vis_fc2.2 (1 x 32)
+            else v = src < 8 ? A.p[20][src] : 0.0f;                            // rgb_fc.4 (1 x 8)
+        }
+        A.tab[k] = v;
+    } else if (k == 10 * 32) {
+        A.scalars[0] = A.p[11][32];                        // vis_fc.2 bias[32]
+        A.scalars[1] = A.p[15][0];                         // vis_fc2.2 bias
+        A.scalars[2] = A.p[21][0];                         // rgb_fc.4 bias
+        A.scalars[3] = fabsf(A.p[22][0]);                  // |s|
+    }
+}
+
+extern "C" int gens_blend_pack_t(const float* const* weights, int n_levels, float* wstream, float* tab, float* scalars_dev, void* stream) {
+    GENS_CHECK_ARG(weights && wstream && tab && scalars_dev, GENS_EINVAL, "gens_blend_pack_t: null pointer");
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_blend_pack_t: 1..5 feature levels, got %d", n_levels);
+    GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_blend_pack_t: the weight stream must be 16-byte aligned");
+    BlendPackT A;
+    for (int k = 0; k < 23; ++k) {
+        GENS_CHECK_ARG(weights[k], GENS_EINVAL, "gens_blend_pack_t: weight %d is null", k);
+        A.p[k] = weights[k];
+    }
+    A.f = 3 + 4 * n_levels;
+    A.stream = (float4*)wstream;
+    A.tab = tab;
+    A.scalars = scalars_dev;
+    A.n_groups = gens_blend_views_t_groups(n_levels);
+    const int work = (A.n_groups + 2) * 64 + 10 * 32 + 1;
+    blend_pack_t_k<<<gens_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_blend_pack_t");
+}
+
+// gens_blend_views_t with the four scalars read from DEVICE memory (scalars_dev of gens_blend_pack_t)
+extern "C" int gens_blend_views_t_dev(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                      const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars_dev, const float* pts,
+                                      const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream) {
+    MapSet fs;
+    GENS_CHECK_ARG(feats && wstream && tab && scalars_dev, GENS_EINVAL, "gens_blend_views_t_dev: null table");
+    if (int e = gens_fill_maps("gens_blend_views_t_dev", &fs, feats, hw, n_levels)) return e;
+    GENS_CHECK_ARG(n_levels <= 5, GENS_ELIMIT, "gens_blend_views_t_dev: at most 5 feature levels (d_feature <= 20), got %d", n_levels);
+    GENS_CHECK_ARG(nv >= 3 && nv <= 5, GENS_ELIMIT, "gens_blend_views_t_dev: built for two to four source views (nv = 3..5), got nv=%d", nv);
+    GENS_CHECK_ARG(imgs && w2c && intr && c2w, GENS_EINVAL, "gens_blend_views_t_dev: null camera / image pointer");
+    GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_blend_views_t_dev: the weight stream must be 16-byte aligned");
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && rgb_out)), GENS_EINVAL, "gens_blend_views_t_dev: null pts / output");
+    if (n == 0) return 0;
+    BlendTWeights W;
+    W.stream = (const float4*)wstream;
+    W.tab = tab;
+    W.v2_last_b = W.u2_b = W.r3_b = W.s_abs = 0.0f;
+    W.sdev = scalars_dev;
+    return blend_t_run(n_levels, nv, W, fs, imgs, w2c, intr, c2w, pts, index, n, n_device, rgb_out, vis_out, stream);
 }

@@ -2018,7 +2018,18 @@ class _BlendTrain(torch.autograd.Function):
         ctx.keep = (feats, imgs, w, views, pts, hw, idx, cnt)
         ctx.meta = (n, s, nl, f, flops, [p.shape for p in params], [t.shape for t in feat_tex], imgs_tex.shape)
         ctx.live = None if cnt is None else (cnt, n)
-        L.call("gens_blend_train_fwd", *ctx.args, L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(), nbytes=n * (24 + s), flops=n * flops, live=ctx.live)
+        if 2 <= s <= 4 and os.environ.get("GENS_BLEND_TRAIN_ROWMAJOR") is None:
+            # the forward values come from the TRANSPOSED inference kernel (k7t_blend.hip: 5 - 6 x the rate of the row-major training kernel),
+            # its weight stream packed from this step's raw parameters by one launch; the backward launch recomputes what it differentiates
+            groups = L.load().gens_blend_views_t_groups(nl)
+            wstream = torch.empty((groups + 2) * 64 * 4, device=dev, dtype=_f32)
+            tab, sc = torch.empty(320, device=dev, dtype=_f32), torch.empty(4, device=dev, dtype=_f32)
+            L.call("gens_blend_pack_t", L.ptr_table(w), nl, L.ptr(wstream, align=16), L.ptr(tab), L.ptr(sc), L.stream())
+            L.call("gens_blend_views_t_dev", ctx.args[0], ctx.args[1], nl, ctx.args[3], ctx.args[4], ctx.args[5], ctx.args[6], views.nv, L.ptr(wstream),
+                   L.ptr(tab), L.ptr(sc), L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(cnt, torch.int32), L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(),
+                   nbytes=n * (24 + s), flops=n * flops, live=ctx.live, label="gens_blend_train_fwd")
+        else:
+            L.call("gens_blend_train_fwd", *ctx.args, L.ptr(rgb), L.ptr(vis, torch.uint8), L.stream(), nbytes=n * (24 + s), flops=n * flops, live=ctx.live)
         ctx.mark_non_differentiable(vis)
         return rgb, vis
 

@@ -386,6 +386,14 @@ int gens_blend_views_t(const float* const* feats, const int* hw, int n_levels, c
                        const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
                        const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
 int gens_blend_views_t_groups(int n_levels);
+/* gens_blend_pack_t: wstream / tab / the four scalars of gens_blend_views_t from the 23 RAW nn.Linear parameters of a BlendingNetwork
+ * (HOST array of device pointers in the order of gens_blend_train_fwd), in one launch; scalars_dev: DEVICE float[4].
+ * gens_blend_views_t_dev: gens_blend_views_t with those scalars read from device memory -- the forward pass of a TRAINING step, whose
+ * colour network changes every step (gens_blend_train_bwd recomputes what it needs). */
+int gens_blend_pack_t(const float* const* weights, int n_levels, float* wstream, float* tab, float* scalars_dev, void* stream);
+int gens_blend_views_t_dev(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                           const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars_dev, const float* pts,
+                           const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);
 int gens_blend_views4(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
                       const float* c2w, int nv, const float* wstream, const float* tab, const float* scalars, const float* pts,
                       const int64_t* index, int64_t n, const int32_t* n_device, float* rgb_out, uint8_t* vis_out, void* stream);

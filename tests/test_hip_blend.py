@@ -188,3 +188,28 @@ def test_blend_kernels_propagate_not_a_number_inputs(rowmajor, nv, monkeypatch):
     assert int(firm.sum()) > 0.5 * int((~bad).sum())
     assert (rgb[firm] - ref[firm]).abs().max() < 2e-5
     assert torch.isfinite(rgb[~bad]).all()
+
+
+@pytest.mark.parametrize("nv,n_levels", [(5, 5), (3, 5), (4, 3), (5, 1)])
+def test_device_side_stream_packing_equals_the_host_packing(nv, n_levels):
+    """gens_blend_pack_t (one launch from the raw parameters: the training step's forward) against gens_amd.ops._pack_blend_t, bit for bit;
+    and the training forward through the transposed kernel against the row-major training kernel."""
+    from gens_amd import lib as L
+    ops, net, views, pts = _setup(nv, n_levels, seed=33 + nv, n=257)
+    plan = ops.BlendPlan(net)
+    w = [p.detach().reshape(-1).contiguous() if p.dim() == 0 else p.detach().contiguous() for p in ops.blend_params(net)]
+    groups = L.load().gens_blend_views_t_groups(n_levels)
+    wstream = torch.empty((groups + 2) * 64 * 4, device="cuda")
+    tab, sc = torch.empty(320, device="cuda"), torch.empty(4, device="cuda")
+    L.call("gens_blend_pack_t", L.ptr_table(w), n_levels, L.ptr(wstream, align=16), L.ptr(tab), L.ptr(sc), L.stream())
+    assert torch.equal(wstream.view(-1, 64, 4), plan.t_stream)
+    assert torch.equal(tab.view(10, 4, 8), plan.t_tab)
+    assert torch.allclose(sc.cpu(), torch.tensor(list(plan.scalars)))
+    rgb, vis = ops.blend_train(net, views, pts)
+    import os
+    os.environ["GENS_BLEND_TRAIN_ROWMAJOR"] = "1"
+    try:
+        rgb_r, vis_r = ops.blend_train(net, views, pts)
+    finally:
+        del os.environ["GENS_BLEND_TRAIN_ROWMAJOR"]
+    assert torch.equal(vis, vis_r) and (rgb - rgb_r).abs().max() < 1e-5
