@@ -205,12 +205,13 @@ class ImplicitSurface(nn.Module):
         return self.sdf_precision == "f16x2" and self._sdf_plan is not None and self._sdf_plan.overflowed()
 
     def _masked_sdf(self, pts, valid, volumes, net=None):
-        sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
         plan = net if net is not None else self._fused_plan(volumes)
-        if plan is not None:              # compaction + count stay on the device: no host synchronisation
-            idx, count = ops.compact_valid(valid)
+        if plan is not None:              # compaction + count stay on the device: no host synchronisation; the unselected rows' 100 rides on it
+            sdf = torch.empty(pts.shape[0], 1, device=pts.device, dtype=torch.float32)
+            idx, count = ops.compact_fill(valid, sdf=sdf)
             ops.sdf_mlp(plan, volumes, pts, index=idx, sdf_out=sdf, precision=self._precision(plan), count=count)
         else:
+            sdf = torch.full((pts.shape[0], 1), 100.0, device=pts.device, dtype=pts.dtype)
             idx = self._select(valid)
             sdf[idx] = self.sdf_network.sdf(pts[idx], volumes)
         return sdf
@@ -367,12 +368,13 @@ class ImplicitSurface(nn.Module):
         bplan = self._fused_blend_plan(scene.views) if lean else self._fused_blend_plan(scene.views, features, imgs)
         sdf_random = extra_sdf = None
         if plan is not None and bplan is not None:     # fully fused inference: nothing in this branch synchronises with the host
-            idx, count = ops.compact_valid(valid)
-            sdf = torch.full((b * n, 1), 100.0, device=dev)
-            gradients = torch.zeros(b * n, 3, device=dev)
+            sdf, gradients = torch.empty(b * n, 1, device=dev), torch.empty(b * n, 3, device=dev)
+            sampled_color = torch.empty(b * n, 3, device=dev)
+            src_vis = torch.empty(b * n, scene.views.nv - 1, device=dev, dtype=torch.uint8)
+            idx, count = ops.compact_fill(valid, sdf=sdf, grad=gradients, rgb=sampled_color, vis=src_vis)      # (defaults of the unselected rows, Q8)
             ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=gradients, precision=self._precision(plan, True), count=count)
             smooth = None
-            sampled_color, src_vis = ops.blend_views(bplan, scene.views, pts, index=idx, count=count)
+            ops.blend_views(bplan, scene.views, pts, index=idx, rgb_out=sampled_color, vis_out=src_vis, count=count)
         else:
             idx = self._select(valid)
             pts_v = pts[idx]

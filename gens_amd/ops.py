@@ -425,6 +425,23 @@ def compact_valid(valid):
     return idx, count
 
 
+def compact_fill(valid, sdf=None, grad=None, rgb=None, vis=None):
+    """compact_valid in TWO launches (gens_compact_points) that also write the reference's values for the unselected rows into the given
+    dense outputs (Q8: sdf 100, gradient / colour 0, no visible source view) -- no torch.full / zeros before the network launches.
+    -> (idx (N,) int64, count (1,) int32)."""
+    v = _c(valid.reshape(-1))
+    v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+    n = v.shape[0]
+    dev = v.device
+    idx = torch.empty(max(n, 10), device=dev, dtype=torch.int64)
+    counts = torch.empty(3, device=dev, dtype=torch.int32)
+    scratch = torch.empty(L.load().gens_compact_points_scratch(n), device=dev, dtype=torch.int32)
+    L.call("gens_compact_points", L.ptr(v, torch.uint8), n, 0, n, L.ptr(idx, torch.int64), L.ptr(counts, torch.int32), L.ptr(sdf), L.ptr(grad), None,
+           L.ptr(rgb), L.ptr(vis, torch.uint8), 0 if vis is None else vis.shape[-1], None, 0, None, None, L.ptr(scratch, torch.int32), L.stream(),
+           nbytes=n * 9, label="gens_compact_valid")
+    return idx, counts[0:1]
+
+
 def _mask_args(masks):
     """(pointer table, dims, levels, mask_bits): a scene's VolumeSet is read through its bit-packed copy (built once)."""
     if isinstance(masks, VolumeSet):
