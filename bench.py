@@ -357,10 +357,15 @@ def main():
         try:
             from scripts.train_step_bench import measure
             train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
-                                 "points, loss + backward + Adam; 10 timed steps after 3 warm-up each", "note": "secondary figures; not the headline"}
+                                 "points, the reference's Loss (gens_amd.losses.Loss, shipped weights) + backward + Adam (torch.optim.Adam as "
+                                 "runner.py:97 builds it); 30 timed steps after 5 warm-up each, the loss read back every step as runner.py does",
+                     "note": "secondary figures; not the headline"}
             for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"])):
-                ms, _, kt = measure(flags + ["--steps", "10", "--warm", "3"], quiet=True, kernels=True)
-                train[key] = {"ms_per_step": round(ms, 2), "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "hip_kernels": kernel_rows(kt, 8)}
+                ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
+                from scripts.train_step_bench import _measure as _m
+                train[key] = {"ms_per_step": round(ms, 2), "ms_per_step_stats": dict(getattr(_m, "stats", {})),
+                              "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "launches_per_step_c_abi": sum(k["launches"] for k in kt.values()),
+                              "hip_kernels": kernel_rows(kt, 8)}
                 train[key]["roofline"] = kernel_roofline(kt)
                 torch.cuda.empty_cache()
             train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "

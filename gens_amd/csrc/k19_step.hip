@@ -919,3 +919,82 @@ extern "C" int gens_loss_bwd(const gens_loss_args* args, void* stream) {
     loss_bwd_k<<<gens_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(*A);
     return gens_launch_status("gens_loss_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// coarse depths of a render (implicit_surface.py:356-363): z = near + (far - near) * linspace(0, 1, n)[j] (+ (t_rand - 0.5) * 2 / n), the
+// reference's float32 operations in its order (this file is compiled with -ffp-contract=off), one launch instead of eight.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_z_k(const float* __restrict__ near, const float* __restrict__ far, int per_ray, const float* __restrict__ steps,
+                                                  const float* __restrict__ t_rand, int64_t b, int n, float* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= b * n) return;
+    const int64_t r = i / n;
+    const int j = (int)(i - r * n);
+    const float nr = near[per_ray ? r : 0], fr = far[per_ray ? r : 0];
+    float v = nr + (fr - nr) * steps[j];
+    if (t_rand) v = v + (t_rand[r] - 0.5f) * 2.0f / (float)n;
+    z[i] = v;
+}
+
+extern "C" int gens_coarse_z(const float* near, const float* far, int per_ray, const float* steps, const float* t_rand, int64_t n_rays, int n, float* z,
+                             void* stream) {
+    GENS_CHECK_ARG(near && far && steps && z && n_rays >= 0 && n >= 1, GENS_EINVAL, "gens_coarse_z: bad argument");
+    if (n_rays == 0) return 0;
+    coarse_z_k<<<gens_blocks(n_rays * n, 256), 256, 0, (hipStream_t)stream>>>(near, far, per_ray, steps, t_rand, n_rays, n, z);
+    return gens_launch_status("gens_coarse_z");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the 23 parameter gradients of a BlendingNetwork from the batched products of gens_blend_train_bwd's operand rows, in one launch:
+// cc = the eleven [dW_l | db_l] blocks (rows even(out_l), leading dimension even(in_l + 1)) concatenated; d loss / d s = sign(s) sum s_part.
+// ---------------------------------------------------------------------------------------------------------------
+struct BlendWgrad {
+    const float* cc;
+    const float* s_part;
+    int n_part;
+    const float* s;
+    float* out[23];
+    int outs[11], ins[11], off[11], first[12];      // off: block offset in cc; first: first output element of layer l (weights then bias)
+};
+
+__global__ __launch_bounds__(256) void blend_wgrad_k(BlendWgrad A) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid == A.first[11]) {                       // the anti-alias temperature
+        float s = 0.0f;
+        for (int k = 0; k < A.n_part; ++k) s += A.s_part[k];
+        const float v = A.s[0];
+        A.out[22][0] = (v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f)) * s;
+        return;
+    }
+    if (gid > A.first[11]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 11; ++k) l += gid >= A.first[k] ? 1 : 0;
+    const int e = gid - A.first[l], o_n = A.outs[l], i_n = A.ins[l], ld = (i_n + 2) / 2 * 2;
+    if (e < o_n * i_n) A.out[2 * l][e] = A.cc[A.off[l] + (e / i_n) * ld + (e % i_n)];
+    else A.out[2 * l + 1][e - o_n * i_n] = A.cc[A.off[l] + (e - o_n * i_n) * ld + i_n];
+}
+
+extern "C" int gens_blend_train_wgrad(const float* cc, const float* s_part, int n_part, const float* s, int n_feat, float* const* grads, void* stream) {
+    GENS_CHECK_ARG(cc && s_part && s && grads && n_part >= 0, GENS_EINVAL, "gens_blend_train_wgrad: null pointer");
+    const int f = n_feat;
+    const int ins[11] = {4, 16, 3 * f, 64, 32, 32, 32, 32, 37, 16, 8}, outs[11] = {16, f, 64, 32, 32, 33, 32, 1, 16, 8, 1};
+    BlendWgrad A;
+    A.cc = cc; A.s_part = s_part; A.n_part = n_part; A.s = s;
+    int off = 0, first = 0;
+    for (int l = 0; l < 11; ++l) {
+        GENS_CHECK_ARG(grads[2 * l] && grads[2 * l + 1], GENS_EINVAL, "gens_blend_train_wgrad: gradient buffer %d is null", l);
+        A.out[2 * l] = grads[2 * l];
+        A.out[2 * l + 1] = grads[2 * l + 1];
+        A.outs[l] = outs[l]; A.ins[l] = ins[l];
+        A.off[l] = off;
+        A.first[l] = first;
+        off += ((outs[l] + 1) / 2 * 2) * ((ins[l] + 2) / 2 * 2);
+        first += outs[l] * (ins[l] + 1);
+    }
+    GENS_CHECK_ARG(grads[22], GENS_EINVAL, "gens_blend_train_wgrad: gradient buffer of s is null");
+    A.out[22] = grads[22];
+    A.first[11] = first;
+    blend_wgrad_k<<<gens_blocks(first + 1, 256), 256, 0, (hipStream_t)stream>>>(A);
+    return gens_launch_status("gens_blend_train_wgrad");
+}

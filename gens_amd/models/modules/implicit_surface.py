@@ -492,16 +492,12 @@ class ImplicitSurface(nn.Module):
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         sample_dist = 2.0 / self.n_samples                                                  # unit-sphere assumption (:355)
         steps = self._coarse_steps(dev)
-        z_vals = near.reshape(-1, 1) + (far - near).reshape(-1, 1) * steps[None, :]
-        z_vals = z_vals.expand(b, self.n_samples)
-        if self.perturb > 0:
-            if t_rand is None:
-                pending = getattr(self, "_jitter_ahead", None)
-                if pending is not None:                                                     # a prefetch for the next validate() is drawing:
-                    pending[1].join()                                                       # one thread at a time on the generator
-                t_rand = torch.rand([b, 1])                                                 # CPU generator, :362
-            z_vals = z_vals + (t_rand.to(dev, non_blocking=True) - 0.5) * 2.0 / self.n_samples
-        z_vals = z_vals.contiguous()
+        if self.perturb > 0 and t_rand is None:
+            pending = getattr(self, "_jitter_ahead", None)
+            if pending is not None:                                                         # a prefetch for the next validate() is drawing:
+                pending[1].join()                                                           # one thread at a time on the generator
+            t_rand = torch.rand([b, 1])                                                     # CPU generator, :362
+        z_vals = ops.coarse_z(near, far, steps, t_rand.to(dev, non_blocking=True) if self.perturb > 0 else None, b)      # (:356-363, one launch)
         if self.n_importance > 0:
             z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene, net)
         return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,

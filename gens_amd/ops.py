@@ -425,6 +425,18 @@ def compact_valid(valid):
     return idx, count
 
 
+def coarse_z(near, far, steps, t_rand, b):
+    """z (B, n) = near + (far - near) * steps[None, :] (+ (t_rand - 0.5) * 2 / n): implicit_surface.py:356-363 in one launch.
+    near / far: (1, 1) for the whole batch or (B, 1) per ray; steps (n,) = linspace(0, 1, n); t_rand (B, 1) on the device or None."""
+    n = steps.shape[0]
+    nr, fr = _c(near.detach().to(_f32).reshape(-1)), _c(far.detach().to(_f32).reshape(-1))
+    assert nr.numel() == fr.numel() and nr.numel() in (1, b), "near / far: one value or one per ray"
+    z = torch.empty(b, n, device=steps.device, dtype=_f32)
+    tr = None if t_rand is None else _c(t_rand.detach().to(_f32).reshape(-1))
+    L.call("gens_coarse_z", L.ptr(nr), L.ptr(fr), 1 if nr.numel() == b and b > 1 else 0, L.ptr(_c(steps)), L.ptr(tr), b, n, L.ptr(z), L.stream())
+    return z
+
+
 def compact_fill(valid, sdf=None, grad=None, rgb=None, vis=None):
     """compact_valid in TWO launches (gens_compact_points) that also write the reference's values for the unselected rows into the given
     dense outputs (Q8: sdf 100, gradient / colour 0, no visible source view) -- no torch.full / zeros before the network launches.
@@ -2080,13 +2092,14 @@ class _BlendTrain(torch.autograd.Function):
             L.call("gens_gemm_tn_batch_live", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(cnt, torch.int32), 32 // s, 32,
                    L.ptr(ws), L.ptr(cc), L.stream(), nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)),
                    live=ctx.live, label="gens_gemm_tn_batch")
+        # the 23 parameter gradients out of the product blocks in one launch, as views of one flat buffer (contiguous each)
+        sizes = [math.prod(sh) if len(sh) else 1 for sh in pshapes]
+        flat = e(sum(sizes))
         grads, off = [], 0
-        for l, (m, k) in enumerate(zip(ms, ns)):
-            c = cc[off:off + m * k].view(m, k)
-            off += m * k
-            grads += [c[:outs[l], :ins[l]].reshape(pshapes[2 * l]), c[:outs[l], ins[l]].reshape(pshapes[2 * l + 1])]
-        s_sign = torch.sign(w[22]).reshape(pshapes[22])
-        grads.append(s_sign * s_part.sum())
+        for sh, sz in zip(pshapes, sizes):
+            grads.append(flat[off:off + sz].view(sh))
+            off += sz
+        L.call("gens_blend_train_wgrad", L.ptr(cc), L.ptr(s_part), s_part.numel(), L.ptr(w[22]), f, L.ptr_table([g_.reshape(-1) for g_ in grads]), L.stream())
         g_imgs, g_feats = None, [None] * nl
         if want_maps:
             want_img = ctx.needs_input_grad[3 + 23]

@@ -611,6 +611,15 @@ typedef struct {
 } gens_loss_args;
 int gens_loss_fwd(const gens_loss_args* args, void* stream);
 int gens_loss_bwd(const gens_loss_args* args, void* stream);
+/* gens_coarse_z: the coarse depths of a render (implicit_surface.py:356-363) in one launch: z (B, n) = near + (far - near) * steps[j]
+ *   (+ (t_rand[ray] - 0.5) * 2 / n when t_rand != NULL); near / far: one float each (per_ray = 0) or (B) (per_ray = 1); steps (n) =
+ *   torch.linspace(0, 1, n).
+ * gens_blend_train_wgrad: the 23 parameter gradients of a BlendingNetwork in one launch from cc = gens_gemm_tn_batch's result for
+ *   gens_blend_train_bwd's eleven products and s_part (n_part); n_feat = 3 + 4 n_levels; grads: HOST array of 23 device pointers (row-major
+ *   weights and biases in the order of gens_blend_train_fwd, then s). */
+int gens_coarse_z(const float* near, const float* far, int per_ray, const float* steps, const float* t_rand, int64_t n_rays, int n, float* z,
+                  void* stream);
+int gens_blend_train_wgrad(const float* cc, const float* s_part, int n_part, const float* s, int n_feat, float* const* grads, void* stream);
 int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);

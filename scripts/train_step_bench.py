@@ -106,13 +106,18 @@ def _measure(quiet, kernels=False):
     t0 = time.perf_counter()
     n = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
     host = 0.0
+    per_step = []
     for _ in range(n):
         t1 = time.perf_counter()
         loss = step()
         host += time.perf_counter() - t1                                 # the host's share: every launch of the step enqueued
         float(loss)                                                      # (runner.py reads the loss every step: one synchronisation per step)
+        per_step.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    per_step.sort()
+    _measure.stats = {"median_ms": round(per_step[len(per_step) // 2] * 1e3, 3), "p10_ms": round(per_step[len(per_step) // 10] * 1e3, 3),
+                      "p90_ms": round(per_step[(9 * len(per_step)) // 10] * 1e3, 3), "steps": n}
     label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
     if not quiet:
         print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step)")
