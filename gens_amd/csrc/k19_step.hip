@@ -958,15 +958,21 @@ struct BlendWgrad {
 };
 
 __global__ __launch_bounds__(256) void blend_wgrad_k(BlendWgrad A) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid == A.first[11]) {                       // the anti-alias temperature
+    if (blockIdx.x == gridDim.x - 1) {              // the last workgroup: the anti-alias temperature, sign(s) * sum of the partials
+        __shared__ float red[4];
         float s = 0.0f;
-        for (int k = 0; k < A.n_part; ++k) s += A.s_part[k];
-        const float v = A.s[0];
-        A.out[22][0] = (v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f)) * s;
+        for (int k = threadIdx.x; k < A.n_part; k += 256) s += A.s_part[k];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float v = A.s[0];
+            A.out[22][0] = (v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f)) * ((red[0] + red[1]) + (red[2] + red[3]));
+        }
         return;
     }
-    if (gid > A.first[11]) return;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= A.first[11]) return;
     int l = 0;
 #pragma unroll
     for (int k = 1; k < 11; ++k) l += gid >= A.first[k] ? 1 : 0;
@@ -995,6 +1001,6 @@ extern "C" int gens_blend_train_wgrad(const float* cc, const float* s_part, int 
     GENS_CHECK_ARG(grads[22], GENS_EINVAL, "gens_blend_train_wgrad: gradient buffer of s is null");
     A.out[22] = grads[22];
     A.first[11] = first;
-    blend_wgrad_k<<<gens_blocks(first + 1, 256), 256, 0, (hipStream_t)stream>>>(A);
+    blend_wgrad_k<<<gens_blocks(first, 256) + 1, 256, 0, (hipStream_t)stream>>>(A);
     return gens_launch_status("gens_blend_train_wgrad");
 }
