@@ -98,8 +98,8 @@ def main():
     args = parse()
     if len(args.dims) in (3, 5) and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None:
         DOMINANT = "gens_sdf_grad"          # the transposed value + gradient kernel sdf_grad_t_k (k6g_sdf_grad.hip), float32
-    else:                                   # under either --sdf-precision (the split-half arithmetic then covers the value-only passes)
-        DOMINANT = "gens_sdf_mlp:grad" if args.sdf_precision == "f32" else "gens_sdf_mlp_f16:grad"
+    else:                                   # under either --sdf-precision (the split-half arithmetic covers the value-only passes only)
+        DOMINANT = "gens_sdf_mlp:grad"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

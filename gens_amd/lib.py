@@ -97,7 +97,6 @@ SIGNATURES = {
     "gens_blend_pack_t": [_pp, _i, _p, _p, _p, _p],
     "gens_blend_views_t_dev": [_pp, _ip, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p],
     "gens_compact_valid": [_p, _l, _p, _p, _p, _p],
-    "gens_sdf_mlp_f16": [_pp, _ip, _i, _pp, _pp, _pp, _pp, _pp, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_value": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p],
     "gens_sdf_value_groups": [_i],
     "gens_sdf_grad": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],

@@ -184,9 +184,9 @@ class ImplicitSurface(nn.Module):
     def _precision(self, plan, want_grad=False):
         """The arithmetic of one SDF launch.  The split-half VALUE kernel pre-scales its weight stream by 100 / ln 2, so it has its own range
         condition (plan.value_ok: |w|, |b| below ~416); a network that fails it is evaluated in float32, it does not raise."""
-        if self.sdf_precision != "f16x2":
+        if self.sdf_precision != "f16x2" or want_grad:            # (the value + gradient launch is float32 under either setting)
             return "f32"
-        return "f16x2" if getattr(plan, "f16_ok" if want_grad else "value_ok", False) else "f32"
+        return "f16x2" if getattr(plan, "value_ok", False) else "f32"
 
     def _train_net(self, scene, lean=False):
         """This step's fused SDF evaluator (ops.SdfTrainStep: the effective weights packed once for the sampling passes, render_core

@@ -129,8 +129,7 @@ class SDFNetwork(nn.Module):
         if not (isinstance(packed, ops.VolumeSet) and ops.SdfTrainStep.supported(self, packed.n)):
             return None
         lins = [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
-        import os
-        if all(hasattr(lin, "weight_g") for lin in lins) and len(lins) == 7 and not os.environ.get("GENS_SDF_TRAIN_EFFECTIVE"):
+        if all(hasattr(lin, "weight_g") for lin in lins) and len(lins) == 7:
             # the raw weight-normed parameters go in: the norm is one launch inside the pack, its backward rides on the gradient launch
             raw = ([lin.weight_v for lin in lins], [lin.weight_g for lin in lins], [lin.bias for lin in lins])
             return ops.SdfTrainStep(None, None, volumes, packed, raw=raw, tv_masks=tv_masks)

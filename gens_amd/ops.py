@@ -15,6 +15,28 @@ from . import lib as L
 _f32 = torch.float32
 
 
+class KernelChoice:
+    """Which generation of a fused kernel an operator launches -- plain attributes, set once from the environment at import (the switches
+    of INTEGRATION.md) and changed by assignment afterwards (tests: monkeypatch.setattr(ops.kernels, ...)).  The operators read these
+    attributes; nothing on a launch path reads os.environ.
+        sdf_value / sdf_grad   "transposed" (k6t / k6g: register-chained, the default) | "rowmajor" (k6_sdfmlp.hip: cross-check, other shapes)
+        blend                  "transposed" (k7t, two to four source views) | "rowmajor" (k7_blend.hip)
+        blend_train_fwd        "transposed" (the training step's forward through k7t + gens_blend_pack_t) | "rowmajor" (k18's own forward)
+        k1_bwd                 "auto" (image-tile kernel from D = 128 up) | "window" | "tiled"
+        tex_cache              texel copies kept on the map tensors (pack_maps)"""
+
+    def __init__(self, env=os.environ):
+        self.sdf_value = "rowmajor" if env.get("GENS_SDF_VALUE_ROWMAJOR") else "transposed"
+        self.sdf_grad = "rowmajor" if env.get("GENS_SDF_GRAD_ROWMAJOR") else "transposed"
+        self.blend = "rowmajor" if env.get("GENS_BLEND_ROWMAJOR") else "transposed"
+        self.blend_train_fwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_ROWMAJOR") else "transposed"
+        self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else ("tiled" if env.get("GENS_K1_BWD_TILED") else "auto")
+        self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
+
+
+kernels = KernelChoice()
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -100,7 +122,7 @@ def pack_maps(maps):
     out, todo = [None] * len(maps), []
     grad_mode = torch.is_grad_enabled()
     for k, m in enumerate(maps):
-        hit = None if os.environ.get("GENS_NO_TEX_CACHE") else getattr(m, "_gens_tex", None)
+        hit = getattr(m, "_gens_tex", None) if kernels.tex_cache else None
         if hit is not None and hit[0] == m._version and hit[1] == (grad_mode and m.requires_grad) and hit[2].device == m.device:
             out[k] = hit[2]
         else:
@@ -258,7 +280,7 @@ def _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol):
     nv, h, w, _ = feat_tex.shape
     g = torch.zeros_like(feat_tex)
     nbytes = 2 * nv * h * w * 16 + 32 * d ** 3                # texels read + their gradient written, 8 cotangent planes read
-    tiled = not os.environ.get("GENS_K1_BWD_WINDOW") and (d >= 128 or bool(os.environ.get("GENS_K1_BWD_TILED")))
+    tiled = kernels.k1_bwd != "window" and (d >= 128 or kernels.k1_bwd == "tiled")
     need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d) if tiled else 0
     if need > 0:
         scratch = torch.empty(need, device=g.device, dtype=torch.uint8)
@@ -1039,19 +1061,6 @@ def _pack_b16(w, groups):
     return torch.cat(parts).contiguous()
 
 
-def _pack_b_fragments_f16(w):
-    """(J, K) matrix -> split-half MFMA 32x32x16 B fragments: two (hi, lo) tensors [ceil(J/32)][ceil(K/16)][64][8] of halfs;
-    lane l of fragment (nt, kb) holds w[32 nt + (l & 31)][16 kb + 8 (l >> 5) + 0..7]."""
-    j, k = w.shape
-    nt, kb = (j + 31) // 32, (k + 15) // 16
-    wp = torch.zeros(nt * 32, kb * 16, device=w.device, dtype=_f32)
-    wp[:j, :k] = w
-    wp = wp.view(nt, 32, kb, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
-    hi = wp.half()
-    lo = (wp - hi.float()).half()
-    return hi, lo
-
-
 def _value_slots(n_levels):
     """Which input column every B-operand slot of k6v_sdf_value_f16.hip carries: three tables of shape (blocks, half, 8) holding a column
     number, -1 for the constant-one slot and -2 for a zero slot.  Hidden blocks: the accumulator layout of the previous layer (lane half h,
@@ -1307,7 +1316,7 @@ class SdfMlpPlan:
                 bs.append(lin.bias.detach().to(_f32))
             dev = ws[0].device
             self.n_levels = net.init_feat_channels // 4
-            self.wf, self.wb, self.bias, self.hf, self.hb = [], [], [], [], []
+            self.wf, self.wb, self.bias = [], [], []
             c = 100.0 / math.log(2.0)      # pre-scaled forward streams (k6_sdfmlp.hip::softplus_t): hidden units travel as c * softplus
             for l in range(6):
                 w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
@@ -1320,9 +1329,6 @@ class SdfMlpPlan:
                 self.wf.append(_pack_b_groups(wbias))
                 self.wb.append(_pack_b_groups(w.t().contiguous()))
                 self.bias.append(b)
-                pf, pb = _pack_b_fragments_f16(w), _pack_b_fragments_f16(w.t().contiguous())
-                self.hf.append(pf)
-                self.hb.append(pb)
             # (the kernels' max / median activations drop NaNs: non-finite WEIGHTS are answered with NaN outputs, as the reference's layers would)
             self.finite = bool(torch.stack([torch.isfinite(w).all() for w in ws] + [torch.isfinite(b).all() for b in bs]).all())
             self.w_last = _c(ws[6][0].clone())
@@ -1330,7 +1336,6 @@ class SdfMlpPlan:
             self.w_last_scaled[:128] /= c
             self.b_last = float(bs[6][0])
             self.scale = float(net.scale)
-            self.f16_ok = max(float(w.abs().max()) for w in ws) < 3.0e4      # weights must fit the half range
             self.value_stream, self.value_row = _pack_value_stream(ws, bs, self.n_levels)
             self.grad_stream, self.grad_row = _pack_grad_stream(ws, bs, self.n_levels)
             assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(self.n_levels) + 2
@@ -1338,9 +1343,6 @@ class SdfMlpPlan:
             self.value_ok = vmax < 6.0e4
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
         self.wf_table, self.wb_table, self.bias_table = L.ptr_table(self.wf), L.ptr_table(self.wb), L.ptr_table(self.bias)
-        h16 = torch.float16
-        self.hf_hi, self.hf_lo = L.ptr_table([t[0] for t in self.hf], h16), L.ptr_table([t[1] for t in self.hf], h16)
-        self.hb_hi, self.hb_lo = L.ptr_table([t[0] for t in self.hb], h16), L.ptr_table([t[1] for t in self.hb], h16)
         self.key = SdfMlpPlan.version(net)
 
     def overflowed(self):
@@ -1374,25 +1376,17 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
         return (sdf_out, grad_out) if want_grad else sdf_out
-    if want_grad and plan.grad_stream is not None and os.environ.get("GENS_SDF_GRAD_ROWMAJOR") is None and (
-            precision == "f32" or os.environ.get("GENS_SDF_GRAD_F16") is None):
-        # (also under "f16x2": the float32 transposed kernel is faster than the split-half gradient kernel, and exact)
+    if want_grad and kernels.sdf_grad == "transposed":
+        # (also under "f16x2": the value + gradient pass stays float32 -- the split-half arithmetic covers the value-only passes)
         L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out), L.stream(),
                nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad")
-    elif precision == "f16x2" and not want_grad:
-        assert plan.value_ok, "weights exceed the half range: use precision='f32'"
+    elif precision == "f16x2" and not want_grad and plan.value_ok:
         L.call("gens_sdf_value_f16", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_units, torch.float16), L.ptr(plan.value_w_out),
                plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out),
                L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_value_f16")
-    elif precision == "f16x2":
-        assert plan.f16_ok, "weights exceed the half range: use precision='f32'"
-        L.call("gens_sdf_mlp_f16", volumes.table, volumes.dim_table, volumes.n, plan.hf_hi, plan.hf_lo, plan.bias_table, plan.hb_hi,
-               plan.hb_lo, L.ptr(plan.w_last), plan.b_last, plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32),
-               L.ptr(sdf_out), L.ptr(grad_out) if want_grad else None, L.ptr(plan.overflow, torch.int32), L.stream(), nbytes=nbytes,
-               flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_mlp_f16" + tag)
-    elif not want_grad and os.environ.get("GENS_SDF_VALUE_ROWMAJOR") is None:
+    elif not want_grad and kernels.sdf_value == "transposed":
         L.call("gens_sdf_value", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_stream), L.ptr(plan.value_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.stream(), nbytes=nbytes,
                flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_value")
@@ -1991,7 +1985,7 @@ def blend_views(plan, views, pts, index=None, rgb_out=None, vis_out=None, count=
     f = plan.n_feat
     flops = 2 * s * (4 * 16 + 16 * f + 3 * f * 64 + 64 * 32 + 32 * 32 + 32 * 33 + 32 * 32 + 32 + 37 * 16 + 16 * 8 + 8)
     nbytes = n * (12 + 12 + s + (8 if idx is not None else 0))
-    if 2 <= s <= 4 and os.environ.get("GENS_BLEND_ROWMAJOR") is None:  # two to four source views: the transposed kernel (k7t_blend.hip)
+    if 2 <= s <= 4 and kernels.blend == "transposed":                  # two to four source views: the transposed kernel (k7t_blend.hip)
         L.call("gens_blend_views_t", L.ptr_table(feats, align=16), L.int_table(hw), nl, L.ptr(aligned16(views.imgs_tex.detach()), align=16),
                L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), views.nv, L.ptr(plan.t_stream), L.ptr(plan.t_tab), plan.scalars, L.ptr(pts),
                L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(rgb_out), L.ptr(vis_out, torch.uint8), L.stream(),
@@ -2047,7 +2041,7 @@ class _BlendTrain(torch.autograd.Function):
         ctx.keep = (feats, imgs, w, views, pts, hw, idx, cnt)
         ctx.meta = (n, s, nl, f, flops, [p.shape for p in params], [t.shape for t in feat_tex], imgs_tex.shape)
         ctx.live = None if cnt is None else (cnt, n)
-        if 2 <= s <= 4 and os.environ.get("GENS_BLEND_TRAIN_ROWMAJOR") is None:
+        if 2 <= s <= 4 and kernels.blend_train_fwd == "transposed":
             # the forward values come from the TRANSPOSED inference kernel (k7t_blend.hip: 5 - 6 x the rate of the row-major training kernel),
             # its weight stream packed from this step's raw parameters by one launch; the backward launch recomputes what it differentiates
             groups = L.load().gens_blend_views_t_groups(nl)

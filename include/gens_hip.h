@@ -278,17 +278,9 @@ int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels
 /* number of 4 KB groups in the weight stream of gens_sdf_grad, without the trailing zero groups (0 = unsupported level count) */
 int gens_sdf_grad_groups(int n_levels);
 
-/* Same computation as gens_sdf_mlp on the f16 matrix cores with split operands: every float32 operand is an (hi, lo)
- * pair of halfs and every product is hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error, 5.3x
- * fewer matrix-pipe cycles).  wf_hi / wf_lo / wb_hi / wb_lo: HOST arrays of 6 device pointers to half fragments
- * (gens_amd.ops.SdfMlpPlan).  overflow_flag: DEVICE int, OR-ed with 1 when an activation or volume feature exceeds the
- * half range (|x| >= 3e4); the caller must then redo the batch with gens_sdf_mlp. */
-int gens_sdf_mlp_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* const* wf_hi,
-                     const void* const* wf_lo, const float* const* bias, const void* const* wb_hi, const void* const* wb_lo,
-                     const float* w_last, float b_last, float scale, const float* pts, const int64_t* index, int64_t n,
-                     const int32_t* n_device, float* sdf_out, float* grad_out, int* overflow_flag, void* stream);
-
-/* The VALUE of the same network (no gradient) with the same split-half arithmetic and overflow contract, laid out for throughput
+/* The VALUE of the same network (no gradient) on the f16 matrix cores with SPLIT operands -- every float32 operand an (hi, lo) pair of halfs,
+ * every product hi*hi + hi*lo + lo*hi with float32 accumulation (~1e-6 relative error); overflow_flag: DEVICE int, OR-ed with 1 when an
+ * activation or volume feature leaves the half range (the caller then redoes the batch with gens_sdf_value) -- laid out for throughput
  * (k6v_sdf_value_f16.hip): the 512^3 lattice of extract_geometry (implicit_surface.py:407-427) and the value-only passes of the opt-in
  * "f16x2" arithmetic.  A wavefront owns 32 points and all 128 hidden units; activations stay in registers between the layers because
  * the weights are packed in the order the accumulators come out in; one weight stream per 128 points goes through LDS.

@@ -15,10 +15,10 @@ import json
 import sys
 from collections import defaultdict
 
-ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_mlp_h_k": "gens_sdf_mlp_f16", "sdf_value_t_k": "gens_sdf_value", "sdf_grad_t_k": "gens_sdf_grad", "sdf_value_h_k": "gens_sdf_value_f16", "blend_k": "gens_blend_views", "blend_t_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
+ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_value_t_k": "gens_sdf_value", "sdf_grad_t_k": "gens_sdf_grad", "sdf_value_h_k": "gens_sdf_value_f16", "blend_k": "gens_blend_views", "blend_t_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
          "upsample_k": "gens_upsample", "merge_k": "gens_merge_samples", "volume_build_fwd_k": "gens_volume_build_fwd", "volume_build_fwd_lean_k": "gens_volume_build_fwd", "volume_build_fwd_levels_k": "gens_volume_build_levels", "volume_build_fwd_pow2_k": "gens_volume_build_fwd",
          "ray_points_k": "gens_ray_points", "compact_count_k": "gens_compact_valid", "compact_write_k": "gens_compact_valid",
-         "compact_scan_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit",
+         "compact_scan_k": "gens_compact_valid", "compact_points_count_k": "gens_compact_valid", "compact_points_write_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit",
          "conv3d_gather_k": "gens_conv3d_gather", "conv3d_scatter2_k": "gens_conv3d_scatter2", "conv3d_wgrad_k": "gens_conv3d_wgrad",
          "instnorm_stats_k": "gens_instnorm_stats", "instnorm_relu_fwd_k": "gens_instnorm_relu_fwd",
          "instnorm_relu_bwd_stats_k": "gens_instnorm_relu_bwd_stats", "instnorm_relu_bwd_k": "gens_instnorm_relu_bwd",
@@ -66,7 +66,7 @@ def main():
         d["fetch_bytes"] += ft.get(k, 0.0)
         d["write_bytes"] += wt.get(k, 0.0)
         d["device_kernels"].append(k)
-        if not k.startswith("compact_") or k == "compact_scan_k":      # one entry-point launch = 3 device kernels for the compaction
+        if not k.startswith("compact_") or k in ("compact_scan_k", "compact_points_write_k"):      # one entry-point launch = 3 (2) device kernels for the compaction
             d["launches_f"] += len(fd.get(k, ()))
             d["launches_w"] += len(wd.get(k, ()))
     res = {}

@@ -131,7 +131,7 @@ def test_transposed_blend_kernel_equals_row_major_kernel(nv, n_levels, n, monkey
         return rgb, vis
 
     new = run()
-    monkeypatch.setenv("GENS_BLEND_ROWMAJOR", "1")
+    monkeypatch.setattr(ops.kernels, "blend", "rowmajor")
     old = run()
     live, dead = idx[:int(count)], idx[int(count):]
     assert torch.equal(new[1], old[1])
@@ -176,7 +176,7 @@ def test_blend_kernels_propagate_not_a_number_inputs(rowmajor, nv, monkeypatch):
     bad = torch.isnan(ref).any(1)
     assert 0 < int(bad.sum()) < 2500
     if rowmajor:
-        monkeypatch.setenv("GENS_BLEND_ROWMAJOR", "1")
+        monkeypatch.setattr(ops.kernels, "blend", "rowmajor")
     rgb, vis = ops.blend_views(ops.BlendPlan(net), views, pts)
     assert torch.equal(torch.isnan(rgb).any(1), bad)
     # blending_network.py:93-95: weight = (e - min e) * mask / (sum + 1e-8).  With two source views the smaller e is the minimum, so the sum
@@ -206,10 +206,9 @@ def test_device_side_stream_packing_equals_the_host_packing(nv, n_levels):
     assert torch.equal(tab.view(10, 4, 8), plan.t_tab)
     assert torch.allclose(sc.cpu(), torch.tensor(list(plan.scalars)))
     rgb, vis = ops.blend_train(net, views, pts)
-    import os
-    os.environ["GENS_BLEND_TRAIN_ROWMAJOR"] = "1"
+    ops.kernels.blend_train_fwd = "rowmajor"
     try:
         rgb_r, vis_r = ops.blend_train(net, views, pts)
     finally:
-        del os.environ["GENS_BLEND_TRAIN_ROWMAJOR"]
+        ops.kernels.blend_train_fwd = "transposed"
     assert torch.equal(vis, vis_r) and (rgb - rgb_r).abs().max() < 3e-5      # (hardware exp / rcp in the transposed kernel; two views: ill-conditioned weights)

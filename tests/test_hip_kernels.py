@@ -32,7 +32,7 @@ def ops():
 # --------------------------------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("bwd", ["window", "tiled"])
 def test_k1_volume_golden_c1(ops, golden, bwd, monkeypatch):
-    monkeypatch.setenv("GENS_K1_BWD_TILED" if bwd == "tiled" else "GENS_K1_BWD_WINDOW", "1")      # both backward kernels against the reference
+    monkeypatch.setattr(ops.kernels, "k1_bwd", bwd)      # both backward kernels against the reference
     g = golden("g1a_volume_c1")
     feat = dev(g["feat"]).requires_grad_(True)
     v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [16])
@@ -46,7 +46,7 @@ def test_k1_volume_golden_c1(ops, golden, bwd, monkeypatch):
 def test_k1_volume_golden_backward_over_image_tiles(ops, golden, bwd, monkeypatch):
     """4 views 96 x 160, one 32^3 volume: the image-tile backward spreads every view over 3 x 4 tiles (and the 4 x 16 voxel wave tiles over up to
     2 x 2 of them); the reference's own gradient."""
-    monkeypatch.setenv("GENS_K1_BWD_TILED" if bwd == "tiled" else "GENS_K1_BWD_WINDOW", "1")
+    monkeypatch.setattr(ops.kernels, "k1_bwd", bwd)
     g = golden("g1c_volume_tiles")
     feat = dev(g["feat"]).requires_grad_(True)
     v, m = ops.volume_build([feat], dev(g["intrs"]), dev(g["c2ws"]), [32])

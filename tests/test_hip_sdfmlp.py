@@ -75,10 +75,10 @@ def test_fused_matches_cpu_oracle(golden):
 
 
 @pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 33)])
-def test_split_half_kernel_matches_float32_kernel(n_levels, n, monkeypatch):
-    """gens_sdf_mlp_f16 / gens_sdf_value_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation."""
+def test_split_half_kernel_matches_float32_kernel(n_levels, n):
+    """gens_sdf_value_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation; the value + gradient launch stays
+    float32 under "f16x2" (round 2's split-half gradient kernel was slower than the float32 transposed one and is retired)."""
     from gens_amd import ops, synthetic
-    monkeypatch.setenv("GENS_SDF_GRAD_F16", "1")      # (three levels otherwise take the float32 transposed kernel for the gradient)
     net, dims = _net(n_levels, seed=10 + n_levels)
     vols = ops.VolumeSet.packed([v.cuda() * 3 for v in synthetic.make_volumes(dims, seed=9)])
     pts = (torch.rand(n, 3, generator=torch.Generator().manual_seed(n)) * 2.2 - 1.1).cuda()
@@ -87,8 +87,8 @@ def test_split_half_kernel_matches_float32_kernel(n_levels, n, monkeypatch):
     s16, g16 = ops.sdf_mlp(plan, vols, pts, want_grad=True, precision="f16x2")
     only = ops.sdf_mlp(plan, vols, pts, precision="f16x2")
     assert not plan.overflowed()
-    assert (s16 - s32).abs().max() < 1e-5 and (only - s32).abs().max() < 1e-5
-    assert (g16 - g32).abs().max() < 1e-4 * max(1.0, g32.abs().max().item())
+    assert (only - s32).abs().max() < 1e-5
+    assert torch.equal(s16, s32) and torch.equal(g16, g32)
 
 
 def test_split_half_overflow_is_flagged():
@@ -121,8 +121,8 @@ def test_transposed_kernels_equal_row_major_kernel(n_levels, n, monkeypatch):
         return sdf, grad, val
 
     new = run()
-    monkeypatch.setenv("GENS_SDF_VALUE_ROWMAJOR", "1")
-    monkeypatch.setenv("GENS_SDF_GRAD_ROWMAJOR", "1")
+    monkeypatch.setattr(ops.kernels, "sdf_value", "rowmajor")
+    monkeypatch.setattr(ops.kernels, "sdf_grad", "rowmajor")
     old = run()
     live = idx[:int(count)]
     dead = idx[int(count):]
