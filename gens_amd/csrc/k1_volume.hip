@@ -91,7 +91,7 @@ __device__ __forceinline__ Proj project_voxel(const float* __restrict__ w2c, con
 __global__ __launch_bounds__(256) void volume_build_fwd_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                           const float* __restrict__ intr, float s, int nv, int h, int w,
                                                           int d, int min_vis, float* __restrict__ vol,
-                                                          float* __restrict__ mask) {
+                                                          float* __restrict__ mask, uint8_t* __restrict__ count) {
     int64_t n = (int64_t)d * d * d;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void volume_build_fwd_k(const float4* __restri
     vol[6 * n + idx] = s2.z / den - m.z * m.z;
     vol[7 * n + idx] = s2.w / den - m.w * m.w;
     mask[idx] = cnt > (float)min_vis ? 1.0f : 0.0f;                          // (Q4)
+    if (count) count[idx] = (uint8_t)cnt;                                    // the visible views, kept for the backward pass
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -150,7 +151,8 @@ struct LevelConst {
 template <bool PRESCALED>
 __global__ __launch_bounds__(256) void volume_build_fwd_pow2_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                                const float* __restrict__ intr, float s, int nv, int h, int w, int d,
-                                                               LevelConst lc, int min_vis, float* __restrict__ vol, float* __restrict__ mask) {
+                                                               LevelConst lc, int min_vis, float* __restrict__ vol, float* __restrict__ mask,
+                                                               uint8_t* __restrict__ count) {
     const int tid = threadIdx.x;
     const int kz = tid & (d - 1);
     const int row = (int)blockIdx.x * (256 >> lc.log2d) + (tid >> lc.log2d);      // = ix * d + jy
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void volume_build_fwd_pow2_k(const float4* __r
     __builtin_nontemporal_store(div_rn(s2.z, den, yn) - mm.z * mm.z, vol + 6 * n + idx);
     __builtin_nontemporal_store(div_rn(s2.w, den, yn) - mm.w * mm.w, vol + 7 * n + idx);
     __builtin_nontemporal_store(cnt > (float)min_vis ? 1.0f : 0.0f, mask + idx);   // (Q4)
+    if (count) count[idx] = (uint8_t)cnt;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -255,7 +258,7 @@ __device__ __forceinline__ void row_constraint(float g0, float g1, float scale, 
 
 __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
-                                                   float* __restrict__ vol, float* __restrict__ mask) {
+                                                   float* __restrict__ vol, float* __restrict__ mask, uint8_t* __restrict__ count) {
     // Chunk -> voxels.  d >= 64: the four waves take the SAME 64 z of four x-adjacent rows (ix = 4 g + wave), whose image footprints
     // overlap, so most of a wave's texel lines are already in the CU's L1 (the z-contiguous 256-voxel chunk sent 3-4x as many requests
     // to L2); smaller volumes: 256 consecutive voxels = 256 / d whole rows.
@@ -386,6 +389,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // texture path of a CU was busy 72 % of the kernel with 4-byte stores); streaming (non-temporal), so that the 36 B / voxel do not
     // sweep the texels out of L2; through buffer descriptors (lane offset in 32 bits; d^3 <= 2^24 voxels: 8 planes are 512 MiB).
     __shared__ float stage[9][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_count[256];
     const int tid = threadIdx.x;
     const int slot = tiled ? (int)(t_row * 64u + t_z) : tid;                        // position in the workgroup's tile: row-piece, then z
     stage[0][slot] = mm.x;
@@ -397,6 +401,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     stage[6][slot] = div_rn(s2.z, den, yn) - mm.z * mm.z;
     stage[7][slot] = div_rn(s2.w, den, yn) - mm.w * mm.w;
     stage[8][slot] = cnt > (float)min_vis ? 1.0f : 0.0f;                            // (Q4)
+    stage_count[slot] = (uint8_t)cnt;
     __syncthreads();
     const uint32_t plane = (uint32_t)d << (2 * lc.log2d + 2);                      // bytes per plane
     const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc((void*)vol, 0, (int)(8u * plane), 0x00020000);
@@ -410,6 +415,10 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[wave][4 * q], planes, off, wave * plane, NT);
     __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[wave + 4][4 * q], planes, off, (wave + 4u) * plane, NT);
     if (wave == 0) __builtin_amdgcn_raw_buffer_store_b128(*(const u4*)&stage[8][4 * q], mplane, off, 0u, NT);
+    if (count && wave == 1 && q < 16u) {      // the visible-view counts (a byte per voxel, for the backward pass): sixteen lanes, sixteen voxels each
+        const uint32_t at = tiled ? (((t_ix0 + (q >> 2)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 3u) << 4))) : chunk * 256u + q * 16u;
+        *(u4*)(count + at) = *(const u4*)&stage_count[16u * q];
+    }
 }
 
 // All levels of a scene in ONE launch: the small levels (a few hundred workgroups, latency-bound on their own: 28 + 10 us for
@@ -419,6 +428,7 @@ struct VolumeLevels {
     const float* intr[GENS_MAX_LEVELS];          // (nv, 4, 4) per level, rows 0-1 pre-scaled by 0.5^level
     float* vol[GENS_MAX_LEVELS];
     float* mask[GENS_MAX_LEVELS];
+    uint8_t* count[GENS_MAX_LEVELS];             // visible views per voxel (may be null)
     int h[GENS_MAX_LEVELS], w[GENS_MAX_LEVELS], d[GENS_MAX_LEVELS];
     LevelConst lc[GENS_MAX_LEVELS];
     uint32_t first[GENS_MAX_LEVELS + 1];
@@ -428,13 +438,14 @@ struct VolumeLevels {
 __global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis) {
     int l = 0;
     while (l + 1 < lv.n && blockIdx.x >= lv.first[l + 1]) ++l;                     // scalar: blockIdx and the table are uniform
-    volume_build_chunk(blockIdx.x - lv.first[l], lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l]);
+    volume_build_chunk(blockIdx.x - lv.first[l], lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l]);
 }
 
 __global__ __launch_bounds__(256) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                                const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc,
-                                                               int min_vis, float* __restrict__ vol, float* __restrict__ mask) {
-    volume_build_chunk(blockIdx.x, feat, w2c, intr, nv, h, w, d, lc, min_vis, vol, mask);
+                                                               int min_vis, float* __restrict__ vol, float* __restrict__ mask,
+                                                               uint8_t* __restrict__ count) {
+    volume_build_chunk(blockIdx.x, feat, w2c, intr, nv, h, w, d, lc, min_vis, vol, mask, count);
 }
 
 // Self-test of the exact-division shortcuts used above: every float32 bit pattern b with a normal, finite reciprocal is
@@ -581,308 +592,6 @@ __global__ __launch_bounds__(256) void volume_build_bwd_k(const float4* __restri
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K1 backward, second generation: the IMAGE TILE owns the sum.
-//
-// The wave windows above reduce what one 4 x 16 voxel tile sends to a view by ~4 x (a z run slides 0 .. 1.4 pixels per voxel), and what is
-// left -- ~0.3 G global float atomics at 256^3 -- is the kernel's whole time (~66 G atomics/s on this chip, whatever the tile shape:
-// scripts/probe/README.md).  But a view's gradient image has only nv x H x W x 4 = 6 M floats for 1.3 G taps: nearly all of the reduction
-// is between voxels far apart in the volume that lie along the same viewing rays.  So the sum is turned around:
-//   prep   one pass over the voxels (the same 4 x 16 wave tiles): count / mean of the visible views, the per-voxel factors of
-//          g_view = A + B * (f_view - M)   (A = g_mean / count, B = 2 g_var / count, M = mean)   to scratch, and for every view the image
-//          tiles (BT_W x BT_H texels, by the north-west tap) the wave's voxels fall into: at most 2 x 2, else that wave / view pair
-//          scatters directly as before;
-//   bins   counting sort of the (wave tile, view) pairs by image tile (count, one-workgroup scan, fill: the lanes of a wave that address one
-//          bin send one atomic between them), cut into work items of at most `seg` wave tiles;
-//   tiles  a workgroup per work item keeps the gradient of its image tile (+ one texel of halo for the south / east taps) in LDS, walks
-//          its wave tiles -- reads A, B, M, re-projects into ITS view with the same arithmetic as prep, and adds the taps of the voxels
-//          that belong to the tile with LDS atomics (64-bit fixed point: tile_add4) -- and sends each touched texel to memory once.
-// Every (voxel, view) pair is owned by exactly one image tile, so the sums are those of the direct scatter in another order.
-#define BT_W 64
-#define BT_H 30          // (65 x 31 texels x 4 channels x 8 bytes = 63 KB of LDS per workgroup; 480 / 240 / 120 rows are whole tiles)
-#define BT_SEG 1024
-#define BT_THREADS 512
-#define BT_WIN ((BT_W + 1) * (BT_H + 1))
-
-struct BwdScratch {
-    float4 *a, *b, *m;              // per voxel
-    uint32_t* range;                // per (wave tile, view): tile range code, 0 = none
-    uint32_t *count, *cursor, *offset;   // per bin = (view, tile row, tile column); offset has one more
-    uint32_t *n_items, *gmax;       // gmax: bits of an upper bound of |g_view| over all voxels, views and channels (fixed-point scale)
-    uint4* items;                   // (bin, begin, end, -)
-    uint32_t* list;                 // wave tiles, bin after bin
-    int tiles_x, tiles_y, n_bins, seg;   // seg: wave tiles per work item
-    uint32_t max_items;
-    int64_t n_waves;
-};
-
-static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
-
-static int64_t bwd_scratch_layout(int nv, int h, int w, int d, char* base, BwdScratch* out) {
-    const int64_t n = (int64_t)d * d * d, nw = n / 64;
-    BwdScratch sc;
-    sc.tiles_x = (w + BT_W - 1) / BT_W;
-    sc.tiles_y = (h + BT_H - 1) / BT_H;
-    sc.n_bins = nv * sc.tiles_x * sc.tiles_y;
-    sc.n_waves = nw;
-    sc.seg = (int)std::min<int64_t>(BT_SEG, std::max<int64_t>(64, nw * nv / 512 / 64 * 64));     // (small levels: shorter items, more of them)
-    sc.max_items = (uint32_t)((nw * nv * 4 + sc.seg - 1) / sc.seg + sc.n_bins);
-    int64_t at = 0;
-    auto take = [&](int64_t bytes) { char* p = base ? base + at : nullptr; at += align256(bytes); return p; };
-    sc.a = (float4*)take(n * 16);
-    sc.b = (float4*)take(n * 16);
-    sc.m = (float4*)take(n * 16);
-    sc.range = (uint32_t*)take(nw * nv * 4);
-    sc.count = (uint32_t*)take((int64_t)sc.n_bins * 4);        // count, cursor, n_items, gmax: one block, zeroed per call
-    sc.cursor = (uint32_t*)take((int64_t)sc.n_bins * 4);
-    sc.n_items = (uint32_t*)take(4);
-    sc.gmax = (uint32_t*)take(4);
-    sc.offset = (uint32_t*)take((int64_t)(sc.n_bins + 1) * 4);
-    sc.items = (uint4*)take((int64_t)sc.max_items * 16);
-    sc.list = (uint32_t*)take(nw * nv * 4 * 4);
-    if (out) *out = sc;
-    return at;
-}
-
-// wave tile q = (ix / 4, jy, z piece), z piece fastest, as (z piece | jy << 8 | ix / 4 << 20): 16 consecutive z of 4 x-adjacent rows, lane = 16 row + z
-__device__ __forceinline__ uint32_t bwd_wave_code(uint32_t q, int d) {
-    const uint32_t zp = (uint32_t)d >> 4, r = q / zp;
-    return (q - r * zp) | ((r % (uint32_t)d) << 8) | ((r / (uint32_t)d) << 20);
-}
-struct WaveVoxel {
-    int ix, jy, kz;
-    int64_t vox;
-};
-__device__ __forceinline__ WaveVoxel bwd_wave_voxel(uint32_t code, int lane, int d) {
-    WaveVoxel o;
-    o.kz = (int)(code & 0xFFu) * 16 + (lane & 15);
-    o.jy = (int)((code >> 8) & 0xFFFu);
-    o.ix = (int)(code >> 20) * 4 + (lane >> 4);
-    o.vox = ((int64_t)o.ix * d + o.jy) * d + o.kz;
-    return o;
-}
-
-__global__ __launch_bounds__(256) void volume_build_bwd_prep_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
-                                                               const float* __restrict__ intr, float s, int nv, int h, int w, int d,
-                                                               const float* __restrict__ gvol, float* __restrict__ gfeat, BwdScratch sc) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t n = (int64_t)d * d * d;
-    const uint32_t q = blockIdx.x * 4u + (uint32_t)(tid >> 6);
-    const WaveVoxel wv = bwd_wave_voxel(bwd_wave_code(q, d), lane, d);              // (d a multiple of 16: every lane has a voxel)
-    const int64_t vox = wv.vox;
-    const float x = linspace_at(-1.0f, 1.0f, d, wv.ix), y = linspace_at(-1.0f, 1.0f, d, wv.jy), z = linspace_at(-1.0f, 1.0f, d, wv.kz);
-    float4 s1 = f4_zero();
-    float cnt = 0.0f;
-    uint32_t direct = 0;                                                            // (wave-uniform) views whose footprint spans more than 2 x 2 tiles
-    const float big = 1.0e9f;
-    float4 f_lo = make_float4(big, big, big, big), f_hi = make_float4(-big, -big, -big, -big);
-    for (int v = 0; v < nv; ++v) {
-        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
-        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-        if (p.vis) {
-            float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
-            s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
-            cnt += 1.0f;
-            f_lo = make_float4(fminf(f_lo.x, f.x), fminf(f_lo.y, f.y), fminf(f_lo.z, f.z), fminf(f_lo.w, f.w));
-            f_hi = make_float4(fmaxf(f_hi.x, f.x), fmaxf(f_hi.y, f.y), fmaxf(f_hi.z, f.z), fmaxf(f_hi.w, f.w));
-        }
-        uint32_t code = 0;
-        if (__any(p.vis)) {                                                         // visible: 0 <= x0 <= w - 1, 0 <= y0 <= h - 1
-            const int tx_lo = (int)-wave_max(p.vis ? -(float)t.x0 : -big) / BT_W, tx_hi = (int)wave_max(p.vis ? (float)t.x0 : -big) / BT_W;
-            const int ty_lo = (int)-wave_max(p.vis ? -(float)t.y0 : -big) / BT_H, ty_hi = (int)wave_max(p.vis ? (float)t.y0 : -big) / BT_H;
-            if (tx_hi - tx_lo > 1 || ty_hi - ty_lo > 1) {
-                direct |= 1u << v;
-            } else {
-                code = 0x80000000u | (uint32_t)tx_lo | ((uint32_t)ty_lo << 12) | ((uint32_t)(tx_hi - tx_lo) << 24) | ((uint32_t)(ty_hi - ty_lo) << 25);
-            }
-        }
-        if (lane == 0) sc.range[(int64_t)v * sc.n_waves + q] = code;
-    }
-    const bool live = cnt > 0.0f;
-    const float inv = live ? 1.0f / cnt : 0.0f;
-    const float4 mean = make_float4(s1.x * inv, s1.y * inv, s1.z * inv, s1.w * inv);
-    float4 ga = f4_zero(), gb = f4_zero();
-    if (live) {
-        ga = make_float4(gvol[vox] * inv, gvol[n + vox] * inv, gvol[2 * n + vox] * inv, gvol[3 * n + vox] * inv);
-        gb = make_float4(2.0f * gvol[4 * n + vox] * inv, 2.0f * gvol[5 * n + vox] * inv, 2.0f * gvol[6 * n + vox] * inv, 2.0f * gvol[7 * n + vox] * inv);
-    }
-    sc.a[vox] = ga;
-    sc.b[vox] = gb;
-    sc.m[vox] = mean;
-    // |g_view| <= |A| + |B| (max f - min f) in every channel: the scale of the tile kernel's fixed-point sums.  Compared as BITS of
-    // non-negative floats, so a NaN or an infinity (which sends that kernel to its float path) wins over every finite bound.
-    uint32_t bound = 0;
-    if (live) {
-        bound = max(max(__float_as_uint(fabsf(ga.x) + fabsf(gb.x) * (f_hi.x - f_lo.x)), __float_as_uint(fabsf(ga.y) + fabsf(gb.y) * (f_hi.y - f_lo.y))),
-                    max(__float_as_uint(fabsf(ga.z) + fabsf(gb.z) * (f_hi.z - f_lo.z)), __float_as_uint(fabsf(ga.w) + fabsf(gb.w) * (f_hi.w - f_lo.w))));
-        bound = max(bound, max(max(__float_as_uint(fabsf(mean.x)), __float_as_uint(fabsf(mean.y))), max(__float_as_uint(fabsf(mean.z)), __float_as_uint(fabsf(mean.w)))) >= 0x7f800000u ? 0x7fc00000u : 0u);
-    }
-    for (int o = 32; o; o >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, o));
-    if (lane == 0 && bound > *(volatile uint32_t*)sc.gmax) atomicMax(sc.gmax, bound);     // (a stale read only costs an atomic)
-    for (int v = 0; direct >> v; ++v) {                                             // (rare: very oblique or very wide views)
-        if (!((direct >> v) & 1u) || !live) continue;
-        Proj p = project_voxel(w2c + 16 * v, intr + 16 * v, s, h, w, x, y, z);
-        if (!p.vis) continue;
-        Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-        float4 f = sample_texel(feat + (int64_t)v * h * w, h, w, 1, 0, t);
-        const float4 g = make_float4(ga.x + gb.x * (f.x - mean.x), ga.y + gb.y * (f.y - mean.y), ga.z + gb.z * (f.z - mean.z), ga.w + gb.w * (f.w - mean.w));
-        float* base = gfeat + (((int64_t)v * h + t.y0) * w + t.x0) * 4;
-        if (t.ok00) atomic_add4(base, g, t.w00);
-        if (t.ok01) atomic_add4(base + 4, g, t.w01);
-        if (t.ok10) atomic_add4(base + (int64_t)w * 4, g, t.w10);
-        if (t.ok11) atomic_add4(base + (int64_t)w * 4 + 4, g, t.w11);
-    }
-}
-
-// offsets of the bins in the list and the work items (one workgroup; the bins number a few hundred)
-__global__ __launch_bounds__(256) void volume_build_bwd_scan_k(BwdScratch sc) {
-    __shared__ uint32_t part_c[256], part_i[256];
-    const int tid = threadIdx.x, per = (sc.n_bins + 255) / 256;
-    const uint32_t seg = (uint32_t)sc.seg;
-    const int lo = min(tid * per, sc.n_bins), hi = min(lo + per, sc.n_bins);
-    uint32_t c = 0, it = 0;
-    for (int b = lo; b < hi; ++b) {
-        c += sc.count[b];
-        it += (sc.count[b] + seg - 1) / seg;
-    }
-    part_c[tid] = c;
-    part_i[tid] = it;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t rc = 0, ri = 0;
-        for (int i = 0; i < 256; ++i) {
-            const uint32_t tc = part_c[i], ti = part_i[i];
-            part_c[i] = rc;
-            part_i[i] = ri;
-            rc += tc;
-            ri += ti;
-        }
-        sc.offset[sc.n_bins] = rc;
-        *sc.n_items = ri;
-    }
-    __syncthreads();
-    c = part_c[tid];
-    it = part_i[tid];
-    for (int b = lo; b < hi; ++b) {
-        const uint32_t k = sc.count[b];
-        sc.offset[b] = c;
-        for (uint32_t at = 0; at < k; at += seg) sc.items[it++] = make_uint4((uint32_t)b, c + at, c + min(at + seg, k), 0u);
-        c += k;
-    }
-}
-
-// The (wave tile, view) pairs of one view, counted per bin (FILL = false) or written to their bins' lists (FILL = true).  Neighbouring wave tiles
-// mostly share their bins: the lanes of a wave that address one bin send ONE atomic for all of them (the bins are a few hundred addresses).
-template <bool FILL>
-__global__ __launch_bounds__(256) void volume_build_bwd_bins_k(BwdScratch sc, int d) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y, lane = threadIdx.x & 63;
-    const uint32_t code = q < sc.n_waves ? sc.range[(int64_t)v * sc.n_waves + q] : 0u;
-    const uint32_t wave_code = FILL ? bwd_wave_code((uint32_t)min(q, sc.n_waves - 1), d) : 0u;
-    const int tx_lo = code & 0xFFF, ty_lo = (code >> 12) & 0xFFF, nx = (code >> 24) & 1, ny = (code >> 25) & 1;
-    for (int k = 0; k < 4; ++k) {                                                   // the up to 2 x 2 tiles of the pair
-        const int dx = k & 1, dy = k >> 1;
-        int bin = (code && dx <= nx && dy <= ny) ? (v * sc.tiles_y + ty_lo + dy) * sc.tiles_x + tx_lo + dx : -1;
-        unsigned long long todo = __ballot(bin >= 0);
-        while (todo) {
-            const int lead = __ffsll((long long)todo) - 1;
-            const int b = __builtin_amdgcn_readlane(bin, lead);
-            const unsigned long long same = __ballot(bin == b);
-            uint32_t base = 0;
-            if (lane == lead) base = atomicAdd((FILL ? sc.cursor : sc.count) + b, (uint32_t)__popcll(same));
-            if (FILL && bin == b) {
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
-                sc.list[sc.offset[b] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = wave_code;
-            }
-            todo &= ~same;
-            if (bin == b) bin = -1;
-        }
-    }
-}
-
-// One tap into the tile window.  FIXED: 64-bit fixed-point sums (ds_add_u64: ~18 cycles per wave instruction, against ~200-250 for ds_add_f32
-// on this chip -- scripts/probe/lds_atomic_probe.py -- and the window's adds are this kernel's whole time).  v * w * scale is rounded to an integer
-// by the 1.5 x 2^52 trick (|v w scale| < 2^42, one tap is exact to 2^-41 of the largest |g| of the call, a work item sums < 2^18 taps per texel:
-// no overflow, and the error of a texel is far below one float32 rounding of its sum).  Otherwise (a NaN / infinity among the gradients) float adds.
-template <bool FIXED>
-__device__ __forceinline__ void tile_add4(void* win, int at, float4 v, float w, double scale) {
-    if (FIXED) {
-        unsigned long long* q = (unsigned long long*)win + at;
-        const double ws = (double)w * scale, magic = 6755399441055744.0;
-        atomicAdd(q, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.x, ws, magic)) - 0x4338000000000000ull);
-        atomicAdd(q + BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.y, ws, magic)) - 0x4338000000000000ull);
-        atomicAdd(q + 2 * BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.z, ws, magic)) - 0x4338000000000000ull);
-        atomicAdd(q + 3 * BT_WIN, (unsigned long long)__double_as_longlong(__builtin_fma((double)v.w, ws, magic)) - 0x4338000000000000ull);
-    } else {
-        float* q = (float*)win + at;
-        atomicAdd(q, v.x * w);
-        atomicAdd(q + BT_WIN, v.y * w);
-        atomicAdd(q + 2 * BT_WIN, v.z * w);
-        atomicAdd(q + 3 * BT_WIN, v.w * w);
-    }
-}
-
-template <bool FIXED>
-__device__ __forceinline__ void bwd_tile_item(unsigned long long* win, const float4* __restrict__ feat, const float* __restrict__ w2c,
-                                              const float* __restrict__ intr, float s, int h, int w, int d, float* __restrict__ gfeat,
-                                              const BwdScratch& sc, double scale, double inv_scale) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint4 item = sc.items[blockIdx.x];
-    const int bin = (int)item.x, tx = bin % sc.tiles_x, ty = (bin / sc.tiles_x) % sc.tiles_y, v = bin / (sc.tiles_x * sc.tiles_y);
-    const int x_org = tx * BT_W, y_org = ty * BT_H;
-    for (int i = tid; i < 4 * BT_WIN; i += BT_THREADS) win[i] = 0ull;              // (the float path uses the first half)
-    __syncthreads();
-    const float4* img = feat + (int64_t)v * h * w;
-    const float *m = w2c + 16 * v, *k = intr + 16 * v;
-    for (uint32_t e0 = item.y + 64u * wave; e0 < item.z; e0 += 64u * (BT_THREADS / 64)) {
-        const uint32_t mine = e0 + lane < item.z ? sc.list[e0 + lane] : 0u;       // the wave's next 64 wave tiles, one per lane
-        const int cnt = (int)min(64u, item.z - e0);
-        for (int j = 0; j < cnt; ++j) {
-            const WaveVoxel wv = bwd_wave_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, j), lane, d);
-            const float4 ga = sc.a[wv.vox], gb = sc.b[wv.vox], mean = sc.m[wv.vox];
-            const float x = linspace_at(-1.0f, 1.0f, d, wv.ix), y = linspace_at(-1.0f, 1.0f, d, wv.jy), z = linspace_at(-1.0f, 1.0f, d, wv.kz);
-            Proj p = project_voxel(m, k, s, h, w, x, y, z);
-            Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-            const int cx = t.x0 - x_org, cy = t.y0 - y_org;
-            const bool live = ga.x != 0.0f || ga.y != 0.0f || ga.z != 0.0f || ga.w != 0.0f || gb.x != 0.0f || gb.y != 0.0f || gb.z != 0.0f || gb.w != 0.0f;
-            if (p.vis && live && cx >= 0 && cx < BT_W && cy >= 0 && cy < BT_H) {
-                float4 f = sample_texel(img, h, w, 1, 0, t);
-                const float4 g = make_float4(ga.x + gb.x * (f.x - mean.x), ga.y + gb.y * (f.y - mean.y), ga.z + gb.z * (f.z - mean.z), ga.w + gb.w * (f.w - mean.w));
-                const int at = cy * (BT_W + 1) + cx;
-                if (t.ok00) tile_add4<FIXED>(win, at, g, t.w00, scale);
-                if (t.ok01) tile_add4<FIXED>(win, at + 1, g, t.w01, scale);
-                if (t.ok10) tile_add4<FIXED>(win, at + (BT_W + 1), g, t.w10, scale);
-                if (t.ok11) tile_add4<FIXED>(win, at + (BT_W + 1) + 1, g, t.w11, scale);
-            }
-        }
-    }
-    __syncthreads();
-    float* out = gfeat + (int64_t)v * h * w * 4;
-    for (int i = tid; i < 4 * BT_WIN; i += BT_THREADS) {      // a lane per FLOAT: the lanes of an atomic instruction on consecutive addresses (L2 serves requests, not lanes)
-        const int texel = i >> 2, c = i & 3;
-        const float a = FIXED ? (float)((double)(long long)win[c * BT_WIN + texel] * inv_scale) : ((const float*)win)[c * BT_WIN + texel];
-        if (a != 0.0f) {
-            const int r = texel / (BT_W + 1), cc = texel - r * (BT_W + 1);
-            atomicAdd(out + ((int64_t)(y_org + r) * w + x_org + cc) * 4 + c, a);      // (only in-image taps were added: the texel exists)
-        }
-    }
-}
-
-__global__ __launch_bounds__(BT_THREADS) void volume_build_bwd_tiles_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
-                                                                      const float* __restrict__ intr, float s, int h, int w, int d,
-                                                                      float* __restrict__ gfeat, BwdScratch sc) {
-    __shared__ unsigned long long win[4 * BT_WIN];      // channel planes: the lanes of one add (one channel) spread over all banks
-    if (blockIdx.x >= *sc.n_items) return;
-    const uint32_t e = (*sc.gmax >> 23) & 0xFFu;                                    // biased exponent of the bound: 2^(e - 127) <= bound < 2^(e - 126)
-    if (e != 0xFFu) {
-        const double scale = __longlong_as_double((long long)(1023 + 40 + 127 - (int)e) << 52);      // bound * scale in [2^40, 2^41)
-        const double inv_scale = __longlong_as_double((long long)(1023 - 40 - 127 + (int)e) << 52);
-        bwd_tile_item<true>(win, feat, w2c, intr, s, h, w, d, gfeat, sc, scale, inv_scale);
-    } else {
-        bwd_tile_item<false>(win, feat, w2c, intr, s, h, w, d, gfeat, sc, 1.0, 1.0);
-    }
-}
-
 static int check_volume_args(const char* who, const void* a, const void* b, const void* c, int nv, int h, int w, int d) {
     GENS_CHECK_ARG(a && b && c, GENS_EINVAL, "%s: null pointer", who);
     GENS_CHECK_ARG(nv > 0 && h > 1 && w > 1 && d > 0, GENS_EINVAL, "%s: bad size nv=%d h=%d w=%d d=%d", who, nv, h, w, d);
@@ -902,8 +611,8 @@ static LevelConst level_const(int h, int w, int d) {      // the float32 operati
     return lc;
 }
 
-extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,
-                                     int h, int w, int d, int min_vis_view, float* volume, float* mask, void* stream) {
+static int volume_build_fwd_level(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h, int w, int d,
+                                  int min_vis_view, float* volume, float* mask, uint8_t* count, void* stream) {
     if (int e = check_volume_args("gens_volume_build_fwd", feat, w2c, intr, nv, h, w, d)) return e;
     GENS_CHECK_ARG(volume && mask, GENS_EINVAL, "gens_volume_build_fwd: null output");
     int64_t n = (int64_t)d * d * d;
@@ -912,39 +621,46 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
         const LevelConst lc = level_const(h, w, d);
         if (d >= 8 && nv <= K1_FAST_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
             volume_build_fwd_lean_k<<<(unsigned)(n / 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
-                                                                                     min_vis_view, volume, mask);
+                                                                                     min_vis_view, volume, mask, count);
             return gens_launch_status("gens_volume_build_fwd");
         }
         const unsigned rows_per_block = 256u >> lc.log2d;
         const unsigned grid = ((unsigned)d * (unsigned)d + rows_per_block - 1) / rows_per_block;
         if (intr_scale == 1.0f)
             volume_build_fwd_pow2_k<true><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, intr_scale, nv, h, w, d, lc,
-                                                                               min_vis_view, volume, mask);
+                                                                               min_vis_view, volume, mask, count);
         else
             volume_build_fwd_pow2_k<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, intr_scale, nv, h, w, d, lc,
-                                                                                min_vis_view, volume, mask);
+                                                                                min_vis_view, volume, mask, count);
         return gens_launch_status("gens_volume_build_fwd");
     }
     volume_build_fwd_k<<<gens_blocks(n, 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, intr_scale, nv,
-                                                                            h, w, d, min_vis_view, volume, mask);
+                                                                            h, w, d, min_vis_view, volume, mask, count);
     return gens_launch_status("gens_volume_build_fwd");
+}
+
+extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,
+                                     int h, int w, int d, int min_vis_view, float* volume, float* mask, void* stream) {
+    return volume_build_fwd_level(feat, w2c, intr, intr_scale, nv, h, w, d, min_vis_view, volume, mask, nullptr, stream);
 }
 
 extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
                                         const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
-                                        void* stream) {
+                                        uint8_t* const* counts, void* stream) {
     GENS_CHECK_ARG(feat && hw && dims && w2c && intr && volumes && masks, GENS_EINVAL, "gens_volume_build_levels: null table");
     GENS_CHECK_ARG(n_levels >= 1 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_volume_build_levels: %d levels (1..%d)", n_levels, GENS_MAX_LEVELS);
     bool one_launch = nv <= K1_FAST_VIEWS && !getenv("GENS_K1_GENERIC") && !getenv("GENS_K1_SINGLE") && !getenv("GENS_K1_PER_LEVEL");
     for (int l = 0; l < n_levels; ++l) {
         if (int e = check_volume_args("gens_volume_build_levels", feat[l], w2c, intr[l], nv, hw[2 * l], hw[2 * l + 1], dims[l])) return e;
         GENS_CHECK_ARG(volumes[l] && masks[l], GENS_EINVAL, "gens_volume_build_levels: null output (level %d)", l);
+        GENS_CHECK_ARG(!counts || !counts[l] || ((uintptr_t)counts[l] & 15) == 0, GENS_EINVAL, "gens_volume_build_levels: the count plane of level %d must be 16-byte aligned", l);
         const int d = dims[l];
         one_launch = one_launch && d >= 8 && d <= 256 && (d & (d - 1)) == 0;
     }
     if (!one_launch) {                                                             // sizes the fused kernel does not cover: level by level
         for (int l = 0; l < n_levels; ++l)
-            if (int e = gens_volume_build_fwd(feat[l], w2c, intr[l], 1.0f, nv, hw[2 * l], hw[2 * l + 1], dims[l], min_vis_view, volumes[l], masks[l], stream))
+            if (int e = volume_build_fwd_level(feat[l], w2c, intr[l], 1.0f, nv, hw[2 * l], hw[2 * l + 1], dims[l], min_vis_view, volumes[l], masks[l],
+                                               counts ? counts[l] : nullptr, stream))
                 return e;
         return 0;
     }
@@ -957,6 +673,7 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
         lv.intr[l] = intr[l];
         lv.vol[l] = volumes[l];
         lv.mask[l] = masks[l];
+        lv.count[l] = counts ? counts[l] : nullptr;
         lv.h[l] = hw[2 * l];
         lv.w[l] = hw[2 * l + 1];
         lv.d[l] = d;
@@ -967,33 +684,607 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
     return gens_launch_status("gens_volume_build_levels");
 }
 
-extern "C" int64_t gens_volume_build_bwd_scratch_bytes(int nv, int h, int w, int d) {
-    if (nv <= 0 || nv > GENS_MAX_VIEWS || h <= 1 || w <= 1 || d <= 0 || d > 4096 || (d & 15) || (w + BT_W - 1) / BT_W > 4095 || (h + BT_H - 1) / BT_H > 4095) return 0;
-    if ((int64_t)d * d * d / 64 * nv * 4 > 0xFFFFFFFFll) return 0;                  // (list offsets are 32-bit)
-    return bwd_scratch_layout(nv, h, w, d, nullptr, nullptr);
+// ---------------------------------------------------------------------------------------------------------------
+// K1 backward on the image-tile plan: the IMAGE owns the sum, ALL LEVELS in one launch set, nothing recomputed that the forward pass knows.
+//
+// The wave windows above reduce what one 4 x 16 voxel tile sends to a view by ~4 x (a z run slides 0 .. 1.4 pixels per voxel), and what is
+// left -- ~0.3 G global float atomics at 256^3 -- is that kernel's whole time (~66 G atomics/s on this chip, whatever the tile shape:
+// scripts/probe/README.md).  But a view's gradient image has only nv x H x W x 4 = 6 M floats for 1.3 G taps: nearly all of the reduction
+// is between voxels far apart in the volume that lie along the same viewing rays.  So the sum is turned around: the (wave tile, view) pairs
+// are sorted by the image tile (BL_W x BL_H texels, by the north-west tap) their voxels fall into, and a workgroup per image tile keeps that
+// tile's gradient (+ one texel of halo for the south / east taps) in LDS, walks its pairs, and sends each touched texel to memory once.
+// Every (voxel, view) pair is owned by exactly one image tile, so the sums are those of the direct scatter in another order.
+//   plan    a thread per (wave tile, view) pair: its range of image tiles from the FOUR CORNERS of the wave tile (a 4 x 16 rectangle of the
+//           lattice in the x-z plane: its image under a pinhole is a convex quadrilateral when all four depths are positive; the few pairs
+//           with a corner at or behind the camera walk their 64 voxels): <= 2 x 2 tiles, else the level's `direct` bin; counted per bin
+//   scan    offsets of all levels' bins in one list, work items of <= seg pairs
+//   fill    the pairs written to their bins
+//   tiles   a workgroup (16 waves) per work item.  Per voxel: 8 cotangent floats, 4 means (the forward's own output: the volume's first four
+//           planes), the count byte gens_volume_build_levels leaves -- planar, coalesced along z, through buffer descriptors --, the projection
+//           into the item's view with the forward kernel's arithmetic (same visibility and taps, bit for bit), the four texels, and sixteen
+//           adds into the window; direct items scatter with global atomics.
+// Five launches for any number of levels (memset, plan, scan, fill, tiles); scratch: 20 B per pair.
+//
+// History: the second generation re-derived count and mean per voxel in a `prep` pass (0.53 of its 1.27 ms at 256^3: every voxel
+// projected into every view with the generic arithmetic, 48 B of records per voxel written and read back once per visible view, four wave
+// reductions per pair for exact tile ranges) and summed in 64-bit FIXED POINT, which needed a bound of |g_view| over the whole call.
+// The window sums are DOUBLES now: ds_add_f64 costs what ds_add_u64 does on this chip (18 cycles per wave instruction on distinct words,
+// scripts/probe/lds_atomic_probe.py; ds_add_f32: 190 - 250), a float32 tap converts exactly, a sum of < 2^29 of them is exact to 2^-24 of one
+// float32 rounding -- no bound, no pass over the cotangent planes to find one, and NaN / infinity propagate like in the direct scatter.
+#define BL_W 64
+#define BL_H 60          // (65 x 61 texels x 4 channels x 8 bytes = 124 KB of LDS: one workgroup of 16 waves per CU; 480 / 240 / 120 rows are whole tiles)
+#define BL_SEG 512          // voxel tiles per work item (32 trips per wave; the window's zeroing and flush are a few per cent of that)
+#define BL_THREADS 1024
+#define BL_SEG_DIRECT 16     // pairs per work item of a direct bin
+#define BL_WIN ((BL_W + 1) * (BL_H + 1))
+#define BL_LDS_BYTES (4 * BL_WIN * 8)
+
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+// Voxel tile q = (ix / 4, jy, z piece), z piece fastest, as (z piece | jy << 8 | ix / 4 << 20): 16 consecutive z of 4 x-adjacent rows, lane = 16 row + z.
+// (Tiles of 128 voxels -- two z-adjacent voxels per lane, whole 128-byte lines per row and plane -- were measured slower: 0.99 against 0.81 ms at
+// 256^3.  Their longer z runs span three image tiles more often, and two voxels per lane leave no registers to keep the next tile's texels in flight.)
+__device__ __forceinline__ uint32_t bwd_tile_code(uint32_t q, int d) {
+    const uint32_t zp = (uint32_t)d >> 4, r = q / zp;
+    return (q - r * zp) | ((r % (uint32_t)d) << 8) | ((r / (uint32_t)d) << 20);
+}
+struct TileVoxel {
+    int ix, jy, kz;
+    uint32_t vox;                   // (d^3 < 2^30 is checked by the host: byte offsets into a plane fit 32 bits)
+};
+__device__ __forceinline__ TileVoxel bwd_tile_voxel(uint32_t code, int lane, int d) {
+    TileVoxel o;
+    o.kz = (int)(code & 0xFFu) * 16 + (lane & 15);
+    o.jy = (int)((code >> 8) & 0xFFFu);
+    o.ix = (int)(code >> 20) * 4 + (lane >> 4);
+    o.vox = ((uint32_t)o.ix * (uint32_t)d + (uint32_t)o.jy) * (uint32_t)d + (uint32_t)o.kz;
+    return o;
 }
 
-extern "C" int gens_volume_build_bwd_tiled(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,
-                                           int h, int w, int d, const float* g_volume, float* g_feat, void* scratch,
-                                           int64_t scratch_bytes, void* stream) {
-    if (int e = check_volume_args("gens_volume_build_bwd_tiled", feat, w2c, intr, nv, h, w, d)) return e;
-    GENS_CHECK_ARG(g_volume && g_feat && scratch, GENS_EINVAL, "gens_volume_build_bwd_tiled: null buffer");
-    GENS_CHECK_ARG(((uintptr_t)feat & 15) == 0, GENS_EINVAL, "gens_volume_build_bwd_tiled: the texels are read as float4 and must be 16-byte aligned");
-    const int64_t need = gens_volume_build_bwd_scratch_bytes(nv, h, w, d);
-    GENS_CHECK_ARG(need > 0, GENS_ELIMIT, "gens_volume_build_bwd_tiled: d=%d must be a multiple of 16 (image %d x %d, %d views): use gens_volume_build_bwd", d, h, w, nv);
+struct BwdLevel {
+    const float4* feat;
+    const float* intr;
+    const float* vol;               // forward output: planes 0-3 = mean
+    const uint8_t* count;           // forward output: visible views per voxel
+    const float* gvol;
+    float* gfeat;
+    uint32_t* codes;                // per (view, wave tile)
+    int h, w, d, tiles_x, tiles_y, seg;
+    uint32_t bin0, n_tile_bins;     // the level's bins are [bin0, bin0 + n_tile_bins] -- the last one is its direct bin
+    uint32_t n_waves;               // voxel tiles (64 voxels: one per lane)
+    uint32_t plan_b;                // first block of the level's pairs in plan_k and fill_k
+    LevelConst lc;
+};
+struct BwdLevels {
+    BwdLevel lv[GENS_MAX_LEVELS];
+    int n, nv;
+    uint32_t *count, *cursor, *offset, *n_items, *next_item;
+    uint4* items;                   // (bin, begin, end, level)
+    uint32_t* list;
+    uint32_t max_items, n_bins, plan_blocks;
+};
+
+struct LeanProj {
+    float fx, fy;
+    bool vis;
+};
+// volume_build_chunk's projection (same operations in the same order: the visibility and the taps of the backward pass are the forward's)
+__device__ __forceinline__ LeanProj project_lean(const float* __restrict__ m, const float* __restrict__ k, bool pinhole, const LevelConst& lc,
+                                                 float wm1, float hm1, float x, float y, float z) {
+    const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
+    const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
+    const float cz = m[8] * x + m[9] * y + m[10] * z + m[11];
+    float u, vv, dd;
+    if (pinhole) {
+        u = k[0] * cx + k[2] * cz;
+        vv = k[5] * cy + k[6] * cz;
+        dd = cz;
+    } else {
+        const float cw = m[12] * x + m[13] * y + m[14] * z + m[15];
+        u = k[0] * cx + k[1] * cy + k[2] * cz + k[3] * cw;
+        vv = k[4] * cx + k[5] * cy + k[6] * cz + k[7] * cw;
+        dd = k[8] * cx + k[9] * cy + k[10] * cz + k[11] * cw;
+    }
+    const float dn = dd + 1e-8f;                                                  // (Q3)
+    const float yd = rcp_rn(dn);
+    const float px = div_rn(u, dn, yd), py = div_rn(vv, dn, yd);
+    const float nx = div_rn(px, lc.cw, lc.rcw) - 1.0f, ny = div_rn(py, lc.ch, lc.rch) - 1.0f;
+    LeanProj o;
+    o.vis = (fmaxf(fabsf(nx), fabsf(ny)) <= 1.0f) && (dd > 0.0f);
+    o.fx = (nx + 1.0f) / 2.0f * wm1;
+    o.fy = (ny + 1.0f) / 2.0f * hm1;
+    return o;
+}
+__device__ __forceinline__ bool is_pinhole(const float* __restrict__ m, const float* __restrict__ k) {
+    const uint32_t* mb = (const uint32_t*)m;
+    const uint32_t* kb = (const uint32_t*)k;
+    const uint32_t must_be_zero = (mb[12] | mb[13] | mb[14] | kb[1] | kb[3] | kb[4] | kb[7] | kb[8] | kb[9] | kb[11]) << 1;   // +-0
+    const uint32_t must_be_one = (mb[15] ^ 0x3f800000u) | (kb[10] ^ 0x3f800000u);
+    return (must_be_zero | must_be_one) == 0u;
+}
+__device__ __forceinline__ float lattice_at(const LevelConst& lc, int d, int i) {      // torch.linspace(-1, 1, d)[i]
+    return i < (d >> 1) ? -1.0f + lc.step * (float)i : 1.0f - lc.step * (float)(d - 1 - i);
+}
+
+// Range of image tiles of one (wave tile, view) pair: 0 = no voxel of the wave tile is visible in the view for sure; bit 31 = some may be,
+// bit 30 = more than 2 x 2 tiles (the pair goes to the direct bin), else tx_lo | ty_lo << 12 | (nx - 1) << 24 | (ny - 1) << 25.
+__device__ uint32_t bwd_pair_code(const BwdLevel& L, const float* __restrict__ m, const float* __restrict__ k, uint32_t wave_code) {
+    const int d = L.d, w = L.w, h = L.h;
+    constexpr int zlen = 16, rows = 4;
+    const int kz0 = (int)(wave_code & 0xFFu) * zlen, jy = (int)((wave_code >> 8) & 0xFFFu), ix0 = (int)(wave_code >> 20) * rows;
+    const float y = lattice_at(L.lc, d, jy);
+    float x_lo = 1e30f, x_hi = -1e30f, y_lo = 1e30f, y_hi = -1e30f;
+    bool sure = true;
+    for (int c = 0; c < 4; ++c) {
+        const float x = lattice_at(L.lc, d, ix0 + ((c & 1) ? rows - 1 : 0)), z = lattice_at(L.lc, d, kz0 + ((c & 2) ? zlen - 1 : 0));
+        const float4 cam = mat4_point(m, x, y, z);
+        const float u = k[0] * cam.x + k[1] * cam.y + k[2] * cam.z + k[3] * cam.w;
+        const float vv = k[4] * cam.x + k[5] * cam.y + k[6] * cam.z + k[7] * cam.w;
+        const float dd = k[8] * cam.x + k[9] * cam.y + k[10] * cam.z + k[11] * cam.w;
+        const float mag = fabsf(k[8] * cam.x) + fabsf(k[9] * cam.y) + fabsf(k[10] * cam.z) + fabsf(k[11] * cam.w);
+        sure = sure && dd > 1e-3f * mag;
+        const float px = u / dd, py = vv / dd;
+        x_lo = fminf(x_lo, px);
+        x_hi = fmaxf(x_hi, px);
+        y_lo = fminf(y_lo, py);
+        y_hi = fmaxf(y_hi, py);
+    }
+    int x0_lo, x0_hi, y0_lo, y0_hi;
+    const float big = 1.0e8f;
+    if (sure && fabsf(x_lo) < big && fabsf(x_hi) < big && fabsf(y_lo) < big && fabsf(y_hi) < big) {
+        // every voxel of the wave tile projects into the corners' bounding box (+- the float32 rounding of the per-voxel arithmetic, < 0.01 texel)
+        const float margin = 0.05f;
+        x0_lo = max((int)floorf(x_lo - margin), 0);
+        x0_hi = min((int)floorf(x_hi + margin), w - 1);
+        y0_lo = max((int)floorf(y_lo - margin), 0);
+        y0_hi = min((int)floorf(y_hi + margin), h - 1);
+    } else {                                                                       // a corner at or behind the camera: the 64 voxels one by one
+        const bool pinhole = is_pinhole(m, k);
+        x0_lo = y0_lo = 0x7fffffff;
+        x0_hi = y0_hi = -1;
+        for (int i = 0; i < 64; ++i) {
+            const LeanProj p = project_lean(m, k, pinhole, L.lc, (float)(w - 1), (float)(h - 1), lattice_at(L.lc, d, ix0 + i / zlen), y, lattice_at(L.lc, d, kz0 + i % zlen));
+            if (!p.vis) continue;
+            const int x0 = (int)floorf(p.fx), y0 = (int)floorf(p.fy);
+            x0_lo = min(x0_lo, x0);
+            x0_hi = max(x0_hi, x0);
+            y0_lo = min(y0_lo, y0);
+            y0_hi = max(y0_hi, y0);
+        }
+    }
+    if (x0_lo > x0_hi || y0_lo > y0_hi) return 0u;
+    const int tx_lo = x0_lo / BL_W, tx_hi = x0_hi / BL_W, ty_lo = y0_lo / BL_H, ty_hi = y0_hi / BL_H;
+    if (tx_hi - tx_lo > 1 || ty_hi - ty_lo > 1) return 0xC0000000u;
+    return 0x80000000u | (uint32_t)tx_lo | ((uint32_t)ty_lo << 12) | ((uint32_t)(tx_hi - tx_lo) << 24) | ((uint32_t)(ty_hi - ty_lo) << 25);
+}
+
+// The pairs of one block of threads -- 256 consecutive wave tiles in ONE view -- counted per bin (FILL = false) or written to their bins' lists
+// (FILL = true).  Neighbouring wave tiles mostly share their bins, so the block first counts in LDS (a histogram over the view's tiles + the
+// direct bin; ds_add_rtn gives every pair its rank) and then sends ONE global atomic per bin it touched, all of them independent (the first
+// version elected a leader per wave and bin: four to eight dependent round trips to L2 per wave, 0.13 ms per pass at 256^3).
+#define BWD_HIST 2048           // tiles of a view + 1 the histogram holds (larger images: one global atomic per pair and bin)
+template <bool FILL>
+__device__ __forceinline__ void bwd_bin_pairs(const BwdLevels& a, const BwdLevel& L, uint32_t code, int v, uint32_t entry, uint32_t pair) {
+    __shared__ uint32_t hist[BWD_HIST], base[FILL ? BWD_HIST : 1];
+    const int tid = threadIdx.x;
+    const int per_view = L.tiles_x * L.tiles_y, nb = per_view + 1;
+    const int tx_lo = code & 0xFFF, ty_lo = (code >> 12) & 0xFFF, nx = (code >> 24) & 1, ny = (code >> 25) & 1;
+    const bool direct = (code >> 30) & 1u;
+    int bin[4];                                                                    // slot in the histogram: tile of the view, or per_view = the direct bin; -1 = none
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                                   // the up to 2 x 2 tiles of the pair
+        const int dx = k & 1, dy = k >> 1;
+        bin[k] = -1;
+        if (code && direct && k == 0) bin[k] = per_view;
+        if (code && !direct && dx <= nx && dy <= ny) bin[k] = (ty_lo + dy) * L.tiles_x + tx_lo + dx;
+    }
+    uint32_t* global = FILL ? a.cursor : a.count;
+    auto slot_bin = [&](int slot) { return slot == per_view ? L.bin0 + L.n_tile_bins : L.bin0 + (uint32_t)(v * per_view + slot); };
+    if (nb > BWD_HIST) {                                                            // (very large images)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (bin[k] < 0) continue;
+            const uint32_t b = slot_bin(bin[k]), at = atomicAdd(global + b, 1u);
+            if (FILL) a.list[a.offset[b] + at] = direct ? pair : entry;
+        }
+        return;
+    }
+    for (int i = tid; i < nb; i += 256) hist[i] = 0u;
+    __syncthreads();
+    uint32_t rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (bin[k] >= 0) rank[k] = atomicAdd(&hist[bin[k]], 1u);
+    __syncthreads();
+    for (int i = tid; i < nb; i += 256) {
+        const uint32_t c = hist[i];
+        if (!c) continue;
+        if (FILL) base[i] = a.offset[slot_bin(i)] + atomicAdd(global + slot_bin(i), c);
+        else atomicAdd(global + slot_bin(i), c);
+    }
+    if (!FILL) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (bin[k] >= 0) a.list[base[bin[k]] + rank[k]] = direct ? pair : entry;
+}
+
+__global__ __launch_bounds__(256) void volume_bwd_plan_k(BwdLevels a, const float* __restrict__ w2c) {
+    int l = 0;
+    while (l + 1 < a.n && blockIdx.x >= a.lv[l + 1].plan_b) ++l;                   // (scalar)
+    const BwdLevel& L = a.lv[l];
+    // a block per 256 wave tiles of one view
+    const uint32_t per_view = (L.n_waves + 255u) / 256u, b = blockIdx.x - L.plan_b;
+    const int v = (int)(b / per_view);
+    const uint32_t q = (b - (uint32_t)v * per_view) * 256u + (uint32_t)threadIdx.x;
+    uint32_t code = 0;
+    if (q < L.n_waves) {
+        code = bwd_pair_code(L, w2c + 16 * v, L.intr + 16 * v, bwd_tile_code(q, L.d));
+        L.codes[(uint32_t)v * L.n_waves + q] = code;
+    }
+    bwd_bin_pairs<false>(a, L, code, v, 0u, 0u);
+}
+
+// offsets of all levels' bins in the list and the work items (one workgroup; the bins number a few hundred to a few thousand)
+__global__ __launch_bounds__(256) void volume_bwd_scan_k(BwdLevels a) {
+    __shared__ uint32_t part_c[256], part_i[256];
+    const int tid = threadIdx.x, per = ((int)a.n_bins + 255) / 256;
+    const int lo = min(tid * per, (int)a.n_bins), hi = min(lo + per, (int)a.n_bins);
+    auto level_of = [&](int b) {
+        int l = 0;
+        while (l + 1 < a.n && (uint32_t)b >= a.lv[l + 1].bin0) ++l;
+        return l;
+    };
+    auto seg_of = [&](int b, int l) {       // pairs per work item: the direct bin (global atomics, no window) in pieces of a pair per wave
+        return (uint32_t)b == a.lv[l].bin0 + a.lv[l].n_tile_bins ? (uint32_t)BL_SEG_DIRECT : (uint32_t)a.lv[l].seg;
+    };
+    uint32_t c = 0, it = 0;
+    for (int b = lo; b < hi; ++b) {
+        const uint32_t seg = seg_of(b, level_of(b));
+        c += a.count[b];
+        it += (a.count[b] + seg - 1) / seg;
+    }
+    part_c[tid] = c;
+    part_i[tid] = it;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t rc = 0, ri = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t tc = part_c[i], ti = part_i[i];
+            part_c[i] = rc;
+            part_i[i] = ri;
+            rc += tc;
+            ri += ti;
+        }
+        a.offset[a.n_bins] = rc;
+        *a.n_items = ri;
+    }
+    __syncthreads();
+    c = part_c[tid];
+    it = part_i[tid];
+    for (int b = lo; b < hi; ++b) {
+        const int l = level_of(b);
+        const uint32_t seg = seg_of(b, l), k = a.count[b];
+        a.offset[b] = c;
+        for (uint32_t at = 0; at < k; at += seg) a.items[it++] = make_uint4((uint32_t)b, c + at, c + min(at + seg, k), (uint32_t)l);
+        c += k;
+    }
+}
+
+__global__ __launch_bounds__(256) void volume_bwd_fill_k(BwdLevels a) {
+    int l = 0;
+    while (l + 1 < a.n && blockIdx.x >= a.lv[l + 1].plan_b) ++l;
+    const BwdLevel& L = a.lv[l];
+    const uint32_t per_view = (L.n_waves + 255u) / 256u, b = blockIdx.x - L.plan_b;
+    const int v = (int)(b / per_view);
+    const uint32_t q = (b - (uint32_t)v * per_view) * 256u + threadIdx.x;
+    const uint32_t code = q < L.n_waves ? L.codes[(uint32_t)v * L.n_waves + q] : 0u;
+    bwd_bin_pairs<true>(a, L, code, v, bwd_tile_code(min(q, L.n_waves - 1u), L.d), (uint32_t)v * L.n_waves + q);
+}
+
+// One voxel of a tile in the item's view, in two steps so that ALL loads of the next tile are in flight while the current one is added to the window
+// (a wave waits 2 - 4 us for its 17 loads and the window leaves room for 4 waves per SIMD):
+//   bwd_issue    the projection (it depends on the lattice position only) and the loads: 8 cotangent floats, 4 means, the count byte -- planar, through
+//                buffer descriptors (a 32-bit offset per lane, the plane in an SGPR) --, 4 texels
+//   bwd_finish   g_view = (g_mean + 2 g_var (f_view - mean)) / count (the reference's formula term by term) and the taps
+struct BwdLoads {
+    float gm0, gm1, gm2, gm3, gv0, gv1, gv2, gv3, m0, m1, m2, m3;
+    uint32_t cnt;
+    f4 v00, v01, v10, v11;
+    float fx, fy;
+    bool vis;
+};
+struct BwdVoxel {
+    float4 g;
+    int x0, y0;
+    float w00, w01, w10, w11;
+    bool ok_x1, ok_y1, on;
+};
+struct BwdBuffers {                 // buffer descriptors of one level
+    __amdgpu_buffer_rsrc_t gvol, vol, count, texels;
+    uint32_t plane_bytes, row_bytes, view_bytes;
+};
+__device__ __forceinline__ BwdBuffers bwd_buffers(const BwdLevel& L, int nv) {
+    BwdBuffers b;
+    b.plane_bytes = L.n_waves * 256u;
+    b.row_bytes = (uint32_t)L.w * 16u;
+    b.view_bytes = (uint32_t)L.h * b.row_bytes;
+    b.gvol = __builtin_amdgcn_make_buffer_rsrc((void*)L.gvol, 0, (int)(8u * b.plane_bytes), 0x00020000);
+    b.vol = __builtin_amdgcn_make_buffer_rsrc((void*)L.vol, 0, (int)(4u * b.plane_bytes), 0x00020000);
+    b.count = __builtin_amdgcn_make_buffer_rsrc((void*)L.count, 0, (int)(L.n_waves * 64u), 0x00020000);
+    b.texels = __builtin_amdgcn_make_buffer_rsrc((void*)L.feat, 0, (int)((uint32_t)nv * b.view_bytes), 0x00020000);
+    return b;
+}
+__device__ __forceinline__ float buffer_f32(const __amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
+}
+__device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, const float* __restrict__ m,
+                                              const float* __restrict__ k, bool pinhole, const TileVoxel& tv) {
+    const int d = L.d, w = L.w, h = L.h;
+    const uint32_t at = tv.vox * 4u, pb = b.plane_bytes;
+    BwdLoads o;
+    o.cnt = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(b.count, tv.vox, 0, 0);
+    o.gm0 = buffer_f32(b.gvol, at, 0), o.gm1 = buffer_f32(b.gvol, at, pb), o.gm2 = buffer_f32(b.gvol, at, 2u * pb), o.gm3 = buffer_f32(b.gvol, at, 3u * pb);
+    o.gv0 = buffer_f32(b.gvol, at, 4u * pb), o.gv1 = buffer_f32(b.gvol, at, 5u * pb), o.gv2 = buffer_f32(b.gvol, at, 6u * pb), o.gv3 = buffer_f32(b.gvol, at, 7u * pb);
+    o.m0 = buffer_f32(b.vol, at, 0), o.m1 = buffer_f32(b.vol, at, pb), o.m2 = buffer_f32(b.vol, at, 2u * pb), o.m3 = buffer_f32(b.vol, at, 3u * pb);
+    const LeanProj p = project_lean(m, k, pinhole, L.lc, (float)(w - 1), (float)(h - 1), lattice_at(L.lc, d, tv.ix), lattice_at(L.lc, d, tv.jy), lattice_at(L.lc, d, tv.kz));
+    // a visible voxel reads inside the image: fx in [0, w - 1], fy in [0, h - 1]; the +1 taps may sit on column w / row h with weight exactly 0
+    o.vis = p.vis;
+    o.fx = p.vis ? p.fx : 0.0f;
+    o.fy = p.vis ? p.fy : 0.0f;
+    const int x0 = (int)floorf(o.fx), y0 = (int)floorf(o.fy);
+    const uint32_t xo0 = (uint32_t)x0 << 4, xo1 = (uint32_t)min(x0 + 1, w - 1) << 4, y1 = (uint32_t)min(y0 + 1, h - 1);
+    o.v00 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24((uint32_t)y0, b.row_bytes) + xo0, view_off, 0));
+    o.v01 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24((uint32_t)y0, b.row_bytes) + xo1, view_off, 0));
+    o.v10 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24(y1, b.row_bytes) + xo0, view_off, 0));
+    o.v11 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24(y1, b.row_bytes) + xo1, view_off, 0));
+    return o;
+}
+__device__ __forceinline__ BwdVoxel bwd_finish(const BwdLevel& L, const BwdLoads& r) {
+    BwdVoxel o;
+    // 1 / count: the count is a small integer, RN(1 / count) from the reciprocal instruction + one correction (rcp_rn) is the IEEE quotient
+    const float inv = r.cnt ? rcp_rn((float)r.cnt) : 0.0f;
+    const float4 ga = make_float4(r.gm0 * inv, r.gm1 * inv, r.gm2 * inv, r.gm3 * inv);
+    const float4 gb = make_float4(2.0f * r.gv0 * inv, 2.0f * r.gv1 * inv, 2.0f * r.gv2 * inv, 2.0f * r.gv3 * inv);
+    o.on = r.vis;                                                                   // (a visible voxel has count >= 1; zero cotangents add zeros)
+    const float x0f = floorf(r.fx), y0f = floorf(r.fy);
+    o.x0 = (int)x0f;
+    o.y0 = (int)y0f;
+    o.ok_x1 = o.x0 + 1 <= L.w - 1;
+    o.ok_y1 = o.y0 + 1 <= L.h - 1;
+    const float wx1 = r.fx - x0f, wx0 = (x0f + 1.0f) - r.fx, wy1 = r.fy - y0f, wy0 = (y0f + 1.0f) - r.fy;
+    o.w00 = wx0 * wy0;
+    o.w01 = wx1 * wy0;
+    o.w10 = wx0 * wy1;
+    o.w11 = wx1 * wy1;
+    float4 f;
+    f.x = __builtin_fmaf(r.v11.x, o.w11, __builtin_fmaf(r.v10.x, o.w10, __builtin_fmaf(r.v01.x, o.w01, __builtin_fmaf(r.v00.x, o.w00, 0.0f))));
+    f.y = __builtin_fmaf(r.v11.y, o.w11, __builtin_fmaf(r.v10.y, o.w10, __builtin_fmaf(r.v01.y, o.w01, __builtin_fmaf(r.v00.y, o.w00, 0.0f))));
+    f.z = __builtin_fmaf(r.v11.z, o.w11, __builtin_fmaf(r.v10.z, o.w10, __builtin_fmaf(r.v01.z, o.w01, __builtin_fmaf(r.v00.z, o.w00, 0.0f))));
+    f.w = __builtin_fmaf(r.v11.w, o.w11, __builtin_fmaf(r.v10.w, o.w10, __builtin_fmaf(r.v01.w, o.w01, __builtin_fmaf(r.v00.w, o.w00, 0.0f))));
+    o.g = make_float4(ga.x + gb.x * (f.x - r.m0), ga.y + gb.y * (f.y - r.m1), ga.z + gb.z * (f.z - r.m2), ga.w + gb.w * (f.w - r.m3));
+    return o;
+}
+
+// One tap into the window: the four channels of g * w (the float32 products the direct scatter adds, converted exactly) into the four channel planes.
+// Lane l adds channel (c + l) & 3 in the c-th instruction: the z-neighbours of a lattice row mostly share their texel, and four lanes on one
+// WORD cost an instruction 45 cycles instead of 18 (sixteen: 190) -- rotated, runs of four lanes address four different planes.
+struct RotatedLane {
+    int plane[4];                   // ((c + lane) & 3) * BL_WIN
+    bool b0, b1;
+};
+__device__ __forceinline__ float4 rotate4(const RotatedLane& rl, float4 g) {        // -> (g[(0 + l) & 3], g[(1 + l) & 3], g[(2 + l) & 3], g[(3 + l) & 3])
+    const float t0 = rl.b0 ? g.y : g.x, t1 = rl.b0 ? g.z : g.y, t2 = rl.b0 ? g.w : g.z, t3 = rl.b0 ? g.x : g.w;
+    return make_float4(rl.b1 ? t2 : t0, rl.b1 ? t3 : t1, rl.b1 ? t0 : t2, rl.b1 ? t1 : t3);
+}
+__device__ __forceinline__ void window_add4(double* win, const RotatedLane& rl, int at, float4 g_rot, float w) {
+    atomicAdd(win + rl.plane[0] + at, (double)(g_rot.x * w));
+    atomicAdd(win + rl.plane[1] + at, (double)(g_rot.y * w));
+    atomicAdd(win + rl.plane[2] + at, (double)(g_rot.z * w));
+    atomicAdd(win + rl.plane[3] + at, (double)(g_rot.w * w));
+}
+__device__ __forceinline__ void window_voxel(double* win, const RotatedLane& rl, const BwdVoxel& o, int x_org, int y_org) {
+    const int cx = o.x0 - x_org, cy = o.y0 - y_org;
+    if (o.on && cx >= 0 && cx < BL_W && cy >= 0 && cy < BL_H) {                     // the voxel belongs to this image tile
+        const int at = cy * (BL_W + 1) + cx;
+        const float4 gr = rotate4(rl, o.g);
+        window_add4(win, rl, at, gr, o.w00);
+        if (o.ok_x1) window_add4(win, rl, at + 1, gr, o.w01);
+        if (o.ok_y1) window_add4(win, rl, at + (BL_W + 1), gr, o.w10);
+        if (o.ok_x1 && o.ok_y1) window_add4(win, rl, at + (BL_W + 1) + 1, gr, o.w11);
+    }
+}
+__device__ __forceinline__ void direct_voxel(const BwdLevel& L, int v, const BwdVoxel& o) {
+    if (!o.on) return;
+    float* base = L.gfeat + (((int64_t)v * L.h + o.y0) * L.w + o.x0) * 4;
+    atomic_add4(base, o.g, o.w00);
+    if (o.ok_x1) atomic_add4(base + 4, o.g, o.w01);
+    if (o.ok_y1) atomic_add4(base + (int64_t)L.w * 4, o.g, o.w10);
+    if (o.ok_x1 && o.ok_y1) atomic_add4(base + (int64_t)L.w * 4 + 4, o.g, o.w11);
+}
+
+__global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, const float* __restrict__ w2c) {
+    extern __shared__ double win[];                    // 4 channel planes of BL_WIN sums: the lanes of one add spread over all banks
+    __shared__ uint32_t taken;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // One workgroup per CU takes work items off a counter until none is left: the items differ in length (a bin's last piece, the short pieces
+    // of the direct bins), and a grid of one workgroup per POSSIBLE item was mostly empty workgroups (10 000 launched for 1 700 items at 256^3).
+    const uint32_t n_items = *a.n_items;
+    for (;;) {
+    if (tid == 0) taken = atomicAdd(a.next_item, 1u);
+    __syncthreads();
+    const uint32_t mine_item = taken;
+    __syncthreads();
+    if (mine_item >= n_items) return;
+    const uint4 item = a.items[mine_item];
+    const BwdLevel& L = a.lv[__builtin_amdgcn_readfirstlane((int)item.w)];
+    const int d = L.d, w = L.w, h = L.h;
+    const uint32_t local = item.x - L.bin0;
+    const BwdBuffers buf = bwd_buffers(L, a.nv);
+    constexpr uint32_t NW = BL_THREADS / 64;
+    if (local == L.n_tile_bins) {                                                  // the direct bin: pairs whose footprint spans more than 2 x 2 tiles
+        for (uint32_t e = item.y + (uint32_t)wave; e < item.z; e += NW) {
+            const uint32_t pair = a.list[e];
+            const int v = (int)(pair / L.n_waves);
+            const TileVoxel tv = bwd_tile_voxel(bwd_tile_code(pair - (uint32_t)v * L.n_waves, d), lane, d);
+            const float *m = w2c + 16 * v, *k = L.intr + 16 * v;
+            direct_voxel(L, v, bwd_finish(L, bwd_issue(L, buf, (uint32_t)v * buf.view_bytes, m, k, is_pinhole(m, k), tv)));
+        }
+        continue;
+    }
+    const int tx = (int)(local % (uint32_t)L.tiles_x), ty = (int)((local / (uint32_t)L.tiles_x) % (uint32_t)L.tiles_y), v = (int)(local / (uint32_t)(L.tiles_x * L.tiles_y));
+    const int x_org = tx * BL_W, y_org = ty * BL_H;
+    for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) win[i] = 0.0;
+    __syncthreads();
+    const float *m = w2c + 16 * v, *k = L.intr + 16 * v;
+    const bool pinhole = is_pinhole(m, k);
+    const uint32_t view_off = (uint32_t)v * buf.view_bytes;
+    RotatedLane rl;
+    rl.b0 = lane & 1;
+    rl.b1 = lane & 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rl.plane[c] = ((c + lane) & 3) * BL_WIN;
+    // the waves take interleaved entries (wave w: e0 + w, e0 + w + 16, ...): neighbours in the list are neighbours in the volume and read the same texels
+    for (uint32_t e0 = item.y; e0 + (uint32_t)wave < item.z; e0 += 64u * NW) {
+        const uint32_t mine_at = e0 + (uint32_t)wave + NW * (uint32_t)lane;
+        const uint32_t mine = mine_at < item.z ? a.list[mine_at] : 0u;            // the wave's next 64 tiles, one per lane
+        const int cnt = (int)min(64u, (item.z - e0 - (uint32_t)wave + NW - 1u) / NW);
+        BwdLoads cur = bwd_issue(L, buf, view_off, m, k, pinhole, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, 0), lane, d));
+        for (int j = 0; j < cnt; ++j) {
+            // (the last trip loads its own tile again: no branch around the loads, and the lines are in L1)
+            const BwdLoads nxt = bwd_issue(L, buf, view_off, m, k, pinhole, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, min(j + 1, cnt - 1)), lane, d));
+            window_voxel(win, rl, bwd_finish(L, cur), x_org, y_org);
+            cur = nxt;
+        }
+    }
+    __syncthreads();
+    float* out = L.gfeat + (int64_t)v * h * w * 4;
+    for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) {      // a lane per FLOAT: the lanes of an atomic instruction on consecutive addresses (L2 serves requests, not lanes)
+        const int texel = i >> 2, c = i & 3;
+        const float s = (float)win[c * BL_WIN + texel];
+        if (s != 0.0f) {
+            const int r = texel / (BL_W + 1), cc = texel - r * (BL_W + 1);
+            atomicAdd(out + ((int64_t)(y_org + r) * w + x_org + cc) * 4 + c, s);      // (only in-image taps were added: the texel exists)
+        }
+    }
+    __syncthreads();                                                               // (the window is zeroed again by the next item)
+    }
+}
+
+static int64_t bwd_levels_layout(const int* hw, const int* dims, int n_levels, int nv, const bool* on, char* base, BwdLevels* out) {
+    BwdLevels a = {};
+    a.n = n_levels;
+    a.nv = nv;
+    int64_t pairs = 0, items = 0;
+    uint32_t bins = 0, plan = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        BwdLevel& L = a.lv[l];
+        const int d = dims[l], h = hw[2 * l], w = hw[2 * l + 1];
+        const bool live = !on || on[l];
+        const int64_t n = (int64_t)d * d * d, nw = live ? n / 64 : 0;                  // voxel tiles
+        L.h = h;
+        L.w = w;
+        L.d = d;
+        L.tiles_x = (w + BL_W - 1) / BL_W;
+        L.tiles_y = (h + BL_H - 1) / BL_H;
+        L.n_tile_bins = live ? (uint32_t)(nv * L.tiles_x * L.tiles_y) : 0u;
+        L.n_waves = (uint32_t)nw;
+        L.seg = (int)std::min<int64_t>(BL_SEG, std::max<int64_t>(64, nw * nv / 512 / 64 * 64));       // (small levels: shorter items, more of them)
+        L.bin0 = bins;
+        L.lc = level_const(h, w, d);
+        L.plan_b = plan;
+        plan += (uint32_t)((nw + 255) / 256 * nv);                                 // (blocks do not straddle views)
+        if (live) {
+            bins += L.n_tile_bins + 1;
+            items += (nw * nv * 4 + L.seg - 1) / L.seg + L.n_tile_bins + (nw * nv + BL_SEG_DIRECT - 1) / BL_SEG_DIRECT + 1;
+            pairs += nw * nv;
+        }
+    }
+    a.n_bins = bins;
+    a.plan_blocks = plan;
+    a.max_items = (uint32_t)items;
+    int64_t at = 0;
+    auto take = [&](int64_t bytes) { char* p = base ? base + at : nullptr; at += align256(bytes); return p; };
+    a.count = (uint32_t*)take((int64_t)bins * 4);               // count, cursor, n_items: one block, zeroed per call
+    a.cursor = (uint32_t*)take((int64_t)bins * 4);
+    a.n_items = (uint32_t*)take(4);
+    a.next_item = (uint32_t*)take(4);
+    a.offset = (uint32_t*)take((int64_t)(bins + 1) * 4);
+    a.items = (uint4*)take(items * 16);
+    a.list = (uint32_t*)take(pairs * 4 * 4);
+    for (int l = 0; l < n_levels; ++l) a.lv[l].codes = (uint32_t*)take((int64_t)a.lv[l].n_waves * nv * 4);
+    if (out) *out = a;
+    return at;
+}
+
+static bool bwd_levels_supported(const int* hw, const int* dims, int n_levels, int nv) {
+    if (!hw || !dims || n_levels < 1 || n_levels > GENS_MAX_LEVELS || nv <= 0 || nv > GENS_MAX_VIEWS) return false;
+    int64_t pairs = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int d = dims[l], h = hw[2 * l], w = hw[2 * l + 1];
+        if (h <= 1 || w <= 1 || d <= 0 || d > 4096 || (d & 15) || (w + BL_W - 1) / BL_W > 4095 || (h + BL_H - 1) / BL_H > 4095) return false;
+        if ((int64_t)nv * h * w * 16 > 0x7fffffffll) return false;                 // (texels are addressed with 32-bit byte offsets)
+        if ((int64_t)d * d * d >= (1ll << 30)) return false;                       // (byte offsets into a plane are 32-bit)
+        pairs += (int64_t)d * d * d / 64 * nv;
+    }
+    return pairs * 4 <= 0xFFFFFFFFll;                                               // (list offsets are 32-bit)
+}
+
+extern "C" int64_t gens_volume_build_bwd_levels_scratch_bytes(const int* hw, const int* dims, int n_levels, int nv) {
+    if (!bwd_levels_supported(hw, dims, n_levels, nv)) return 0;
+    return bwd_levels_layout(hw, dims, n_levels, nv, nullptr, nullptr, nullptr);
+}
+
+extern "C" int gens_volume_build_bwd_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                            const float* const* intr, int nv, const float* const* volumes, const uint8_t* const* counts,
+                                            const float* const* g_volumes, float* const* g_feat, void* scratch, int64_t scratch_bytes,
+                                            void* stream) {
+    GENS_CHECK_ARG(feat && hw && dims && w2c && intr && volumes && counts && g_volumes && g_feat && scratch, GENS_EINVAL, "gens_volume_build_bwd_levels: null table");
+    GENS_CHECK_ARG(bwd_levels_supported(hw, dims, n_levels, nv), GENS_ELIMIT,
+                   "gens_volume_build_bwd_levels: every volume side must be a multiple of 16 (%d levels, %d views): use gens_volume_build_bwd", n_levels, nv);
+    bool on[GENS_MAX_LEVELS];
+    bool any = false;
+    for (int l = 0; l < n_levels; ++l) {
+        on[l] = g_volumes[l] != nullptr;
+        any = any || on[l];
+        if (!on[l]) continue;
+        if (int e = check_volume_args("gens_volume_build_bwd_levels", feat[l], w2c, intr[l], nv, hw[2 * l], hw[2 * l + 1], dims[l])) return e;
+        GENS_CHECK_ARG(volumes[l] && counts[l] && g_feat[l], GENS_EINVAL, "gens_volume_build_bwd_levels: null buffer (level %d)", l);
+        GENS_CHECK_ARG(((uintptr_t)feat[l] & 15) == 0, GENS_EINVAL, "gens_volume_build_bwd_levels: the texels are read as float4 and must be 16-byte aligned (level %d)", l);
+    }
+    if (!any) return 0;
+    const int64_t need = bwd_levels_layout(hw, dims, n_levels, nv, nullptr, nullptr, nullptr);    // (the caller sizes for all levels)
     GENS_CHECK_ARG(scratch_bytes >= need && ((uintptr_t)scratch & 15) == 0, GENS_EINVAL,
-                   "gens_volume_build_bwd_tiled: scratch of %lld bytes, 16-byte aligned, needed (got %lld)", (long long)need, (long long)scratch_bytes);
-    BwdScratch sc;
-    bwd_scratch_layout(nv, h, w, d, (char*)scratch, &sc);
+                   "gens_volume_build_bwd_levels: scratch of %lld bytes, 16-byte aligned, needed (got %lld)", (long long)need, (long long)scratch_bytes);
+    BwdLevels a;
+    bwd_levels_layout(hw, dims, n_levels, nv, on, (char*)scratch, &a);
+    for (int l = 0; l < n_levels; ++l) {
+        if (!on[l]) continue;
+        a.lv[l].feat = (const float4*)feat[l];
+        a.lv[l].intr = intr[l];
+        a.lv[l].vol = volumes[l];
+        a.lv[l].count = counts[l];
+        a.lv[l].gvol = g_volumes[l];
+        a.lv[l].gfeat = g_feat[l];
+    }
+    static bool lds_set = false;                                                    // (the window is more than the 64 KB a kernel gets by default)
+    if (!lds_set) {
+        if (hipFuncSetAttribute((const void*)volume_bwd_tiles_k, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES) != hipSuccess)
+            return gens_launch_status("gens_volume_build_bwd_levels");
+        lds_set = true;
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sc.count, 0, (char*)sc.offset - (char*)sc.count, st) != hipSuccess) return gens_launch_status("gens_volume_build_bwd_tiled");
-    volume_build_bwd_prep_k<<<(unsigned)(sc.n_waves / 4), 256, 0, st>>>((const float4*)feat, w2c, intr, intr_scale, nv, h, w, d, g_volume, g_feat, sc);
-    const dim3 bins_grid(gens_blocks(sc.n_waves, 256), (unsigned)nv);
-    volume_build_bwd_bins_k<false><<<bins_grid, 256, 0, st>>>(sc, d);
-    volume_build_bwd_scan_k<<<1, 256, 0, st>>>(sc);
-    volume_build_bwd_bins_k<true><<<bins_grid, 256, 0, st>>>(sc, d);
-    volume_build_bwd_tiles_k<<<sc.max_items, BT_THREADS, 0, st>>>((const float4*)feat, w2c, intr, intr_scale, h, w, d, g_feat, sc);
-    return gens_launch_status("gens_volume_build_bwd_tiled");
+    if (hipMemsetAsync(a.count, 0, (char*)a.offset - (char*)a.count, st) != hipSuccess) return gens_launch_status("gens_volume_build_bwd_levels");
+    volume_bwd_plan_k<<<a.plan_blocks, 256, 0, st>>>(a, w2c);
+    volume_bwd_scan_k<<<1, 256, 0, st>>>(a);
+    volume_bwd_fill_k<<<a.plan_blocks, 256, 0, st>>>(a);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    volume_bwd_tiles_k<<<std::min<uint32_t>((uint32_t)n_cu, a.max_items), BL_THREADS, BL_LDS_BYTES, st>>>(a, w2c);
+    return gens_launch_status("gens_volume_build_bwd_levels");
 }
 
 extern "C" int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv,

@@ -55,9 +55,9 @@ SIGNATURES = {
     "gens_pack_volume": [_p, _p, _i, _i, _i, _p],
     "gens_volume_build_fwd": [_p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _p, _p],
     "gens_volume_build_bwd": [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
-    "gens_volume_build_bwd_tiled": [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _l, _p],
     "gens_selftest_division": [_p, _p],
-    "gens_volume_build_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _p],
+    "gens_volume_build_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _pp, _p],
+    "gens_volume_build_bwd_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _pp, _pp, _pp, _pp, _p, _l, _p],
     "gens_gemm_tn_slabs": [_l, _i, _i],
     "gens_gemm_tn": [_p, _p, _l, _i, _i, _p, _p, _p],
     "gens_conv3d_gather": [_p, _p, _p, _i, _i, _ip, _i, _p, _p],
@@ -155,8 +155,8 @@ def load():
     lib.gens_abi_version.argtypes = []
     lib.gens_tv_blocks.restype = _i
     lib.gens_tv_blocks.argtypes = [_l]
-    lib.gens_volume_build_bwd_scratch_bytes.restype = _l
-    lib.gens_volume_build_bwd_scratch_bytes.argtypes = [_i, _i, _i, _i]
+    lib.gens_volume_build_bwd_levels_scratch_bytes.restype = _l
+    lib.gens_volume_build_bwd_levels_scratch_bytes.argtypes = [_ip, _ip, _i, _i]
     lib.gens_sdf_train_stash_bytes.restype = _l
     lib.gens_sdf_train_stash_bytes.argtypes = [_l, _i]
     lib.gens_blend_train_rows.restype = _l

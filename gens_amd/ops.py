@@ -22,7 +22,7 @@ class KernelChoice:
         sdf_value / sdf_grad   "transposed" (k6t / k6g: register-chained, the default) | "rowmajor" (k6_sdfmlp.hip: cross-check, other shapes)
         blend                  "transposed" (k7t, two to four source views) | "rowmajor" (k7_blend.hip)
         blend_train_fwd        "transposed" (the training step's forward through k7t + gens_blend_pack_t) | "rowmajor" (k18's own forward)
-        k1_bwd                 "auto" (image-tile kernel from D = 128 up) | "window" | "tiled"
+        k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
         tex_cache              texel copies kept on the map tensors (pack_maps)"""
 
     def __init__(self, env=os.environ):
@@ -30,7 +30,7 @@ class KernelChoice:
         self.sdf_grad = "rowmajor" if env.get("GENS_SDF_GRAD_ROWMAJOR") else "transposed"
         self.blend = "rowmajor" if env.get("GENS_BLEND_ROWMAJOR") else "transposed"
         self.blend_train_fwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_ROWMAJOR") else "transposed"
-        self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else ("tiled" if env.get("GENS_K1_BWD_TILED") else "auto")
+        self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
 
 
@@ -251,49 +251,19 @@ class VolumeSet:
 # ------------------------------------------------------------------------------------------------------------------
 # K1  Volume.agg_mean_var (volume.py:13-63)
 # ------------------------------------------------------------------------------------------------------------------
-class _VolumeBuild(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feat_tex, w2c, intr, scale, d, min_vis):
-        nv, h, w, cp = feat_tex.shape
-        assert cp == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
-        vol = torch.empty(1, 8, d, d, d, device=feat_tex.device, dtype=_f32)
-        mask = torch.empty(1, 1, d, d, d, device=feat_tex.device, dtype=_f32)
-        L.call("gens_volume_build_fwd", L.ptr(aligned16(feat_tex), align=16), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
-               L.ptr(mask), L.stream(), nbytes=nv * h * w * 16 + 36 * d ** 3)
-        ctx.save_for_backward(feat_tex, w2c, intr)
-        ctx.meta = (scale, d)
-        ctx.mark_non_differentiable(mask)
-        return vol, mask
-
-    @staticmethod
-    def backward(ctx, g_vol, _g_mask):
-        feat_tex, w2c, intr = ctx.saved_tensors
-        scale, d = ctx.meta
-        nv, h, w, _ = feat_tex.shape
-        return _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol), None, None, None, None, None
-
-
 def _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol):
-    """d(volume)/d(texels) of one level: the image-tile kernel (gens_volume_build_bwd_tiled: 1.27 against 4.31 ms at 256^3, 0.31 / 0.56 at
-    128^3) from D = 128 up, the wave-window kernel below (0.09 against 0.13 ms at 64^3: five launches do not pay there).  GENS_K1_BWD_WINDOW /
-    GENS_K1_BWD_TILED force one of them wherever it applies.  Both are labelled gens_volume_build_bwd in the kernel table."""
+    """d(volume)/d(texels) of one level with the wave-window kernel (gens_volume_build_bwd): what the all-level image-tile kernel does not cover
+    (volume sides that are not multiples of 16), and its cross-check (kernels.k1_bwd = "window")."""
     nv, h, w, _ = feat_tex.shape
     g = torch.zeros_like(feat_tex)
-    nbytes = 2 * nv * h * w * 16 + 32 * d ** 3                # texels read + their gradient written, 8 cotangent planes read
-    tiled = kernels.k1_bwd != "window" and (d >= 128 or kernels.k1_bwd == "tiled")
-    need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d) if tiled else 0
-    if need > 0:
-        scratch = torch.empty(need, device=g.device, dtype=torch.uint8)
-        L.call("gens_volume_build_bwd_tiled", L.ptr(aligned16(feat_tex), align=16), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
-               L.ptr(scratch, torch.uint8), need, L.stream(), nbytes=nbytes, label="gens_volume_build_bwd")
-    else:
-        L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
-               L.stream(), nbytes=nbytes)
+    L.call("gens_volume_build_bwd", L.ptr(_c(feat_tex)), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, L.ptr(_c(g_vol)), L.ptr(g),
+           L.stream(), nbytes=2 * nv * h * w * 16 + 32 * d ** 3)                  # texels read + their gradient written, 8 cotangent planes read
     return g
 
 
 class _VolumeBuildLevels(torch.autograd.Function):
-    """All levels of a scene in one launch (gens_volume_build_levels); the backward runs level by level."""
+    """All levels of a scene in one launch (gens_volume_build_levels); the backward of all levels in one launch set
+    (gens_volume_build_bwd_levels), from the means and visible-view counts the forward pass leaves."""
 
     @staticmethod
     def forward(ctx, w2c, dims, min_vis, *tex_and_intr):
@@ -307,10 +277,15 @@ class _VolumeBuildLevels(torch.autograd.Function):
         for t in texs:
             assert t.shape[0] == nv and t.shape[3] == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
         texs_c = [aligned16(t) for t in texs]
+        want = any(ctx.needs_input_grad[3:3 + n])
+        levels_bwd = want and kernels.k1_bwd == "auto" and L.load().gens_volume_build_bwd_levels_scratch_bytes(L.int_table(hw), L.int_table(dims), n, nv) > 0
+        counts = [torch.empty(d ** 3, device=dev, dtype=torch.uint8) for d in dims] if levels_bwd else None
         L.call("gens_volume_build_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv, min_vis,
-               L.ptr_table(vols), L.ptr_table(masks), L.stream(), nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)))
-        ctx.save_for_backward(w2c, *texs, *intrs)
+               L.ptr_table(vols), L.ptr_table(masks), L.ptr_table(counts, torch.uint8), L.stream(),
+               nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)))
+        ctx.save_for_backward(w2c, *texs, *intrs, *(vols + counts if levels_bwd else []))
         ctx.dims = list(dims)
+        ctx.levels_bwd = levels_bwd
         ctx.mark_non_differentiable(*masks)
         return (*vols, *masks)
 
@@ -318,13 +293,31 @@ class _VolumeBuildLevels(torch.autograd.Function):
     def backward(ctx, *grads):
         n = len(ctx.dims)
         w2c, rest = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        texs, intrs = rest[:n], rest[n:]
+        texs, intrs = rest[:n], rest[n:2 * n]
+        on = [grads[l] is not None and ctx.needs_input_grad[3 + l] for l in range(n)]
+        if ctx.levels_bwd and any(on):
+            vols, counts = rest[2 * n:3 * n], rest[3 * n:4 * n]
+            nv = texs[0].shape[0]
+            hw = [x for t in texs for x in (t.shape[1], t.shape[2])]
+            texs_c = [aligned16(t) for t in texs]
+            g_vols = [aligned16(_c(grads[l])) if on[l] else None for l in range(n)]
+            # one zeroed buffer for all levels' gradients (one fill), handed out as per-level views
+            sizes = [t.numel() if on[l] else 0 for l, t in enumerate(texs)]
+            flat = torch.zeros(sum(sizes), device=w2c.device, dtype=_f32)
+            out, at = [], 0
+            for l, t in enumerate(texs):
+                out.append(flat[at:at + sizes[l]].view(t.shape) if on[l] else None)
+                at += sizes[l]
+            need = L.load().gens_volume_build_bwd_levels_scratch_bytes(L.int_table(hw), L.int_table(ctx.dims), n, nv)
+            scratch = torch.empty(need, device=w2c.device, dtype=torch.uint8)
+            L.call("gens_volume_build_bwd_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(ctx.dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv,
+                   L.ptr_table(list(vols)), L.ptr_table(list(counts), torch.uint8), L.ptr_table(g_vols), L.ptr_table(out), L.ptr(scratch, torch.uint8), need,
+                   L.stream(), nbytes=sum(2 * nv * t.shape[1] * t.shape[2] * 16 + 49 * d ** 3 for t, d, o in zip(texs, ctx.dims, on) if o),
+                   label="gens_volume_build_bwd")
+            return (None, None, None, *out, *([None] * n))
         out = []
         for l, d in enumerate(ctx.dims):
-            if grads[l] is None or not ctx.needs_input_grad[3 + l]:
-                out.append(None)
-                continue
-            out.append(_volume_build_bwd(texs[l], w2c, intrs[l], 1.0, d, grads[l]))
+            out.append(_volume_build_bwd(texs[l], w2c, intrs[l], 1.0, d, grads[l]) if on[l] else None)
         return (None, None, None, *out, *([None] * n))
 
 

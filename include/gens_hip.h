@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 5 */
+int gens_abi_version(void);   /* 6 */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -66,21 +66,27 @@ int gens_volume_build_fwd(const float* feat, const float* w2c, const float* intr
                           int w, int d, int min_vis_view, float* volume, float* mask, void* stream);
 int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
                           int w, int d, const float* g_volume, float* g_feat, void* stream);
-/* The same gradient with the sum owned by the IMAGE: voxels are binned by the 64 x 32-texel tile of each view they project into, a
- * workgroup per tile keeps that tile's gradient in LDS and writes every touched texel once (the wave-window kernel above is bound by its
- * ~0.3 G global atomics at 256^3).  D must be a multiple of 16; scratch: gens_volume_build_bwd_scratch_bytes(nv, H, W, D) bytes of device
- * memory (48 bytes per voxel + the bins; 0 = this size is not covered, use gens_volume_build_bwd), contents irrelevant before and after.
- * Results equal gens_volume_build_bwd's up to the order of the float32 sums. */
-int64_t gens_volume_build_bwd_scratch_bytes(int nv, int h, int w, int d);
-int gens_volume_build_bwd_tiled(const float* feat, const float* w2c, const float* intr, float intr_scale, int nv, int h,
-                                int w, int d, const float* g_volume, float* g_feat, void* scratch, int64_t scratch_bytes,
-                                void* stream);
 /* All levels of one scene in a single launch (volume.py:21-61 is a loop over the levels): feat[l] (nv, H_l, W_l, 4) texels,
  * hw = {H_0, W_0, H_1, W_1, ...}, intr[l] (nv, 4, 4) with rows 0-1 already multiplied by 0.5^l, volumes[l] (8, D_l^3), masks[l] (D_l^3).
  * Same results as n_levels calls of gens_volume_build_fwd with intr_scale = 1 (which it falls back to for sizes the fused kernel
- * does not cover). */
+ * does not cover).  counts: NULL, or a HOST array of device pointers (an entry may be NULL) to (D_l^3) uint8 planes, 16-byte aligned,
+ * that receive the number of views each voxel is visible in (volume.py:50 `count`) -- what gens_volume_build_bwd_levels reads back. */
 int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
-                             const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks, void* stream);
+                             const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
+                             uint8_t* const* counts, void* stream);
+/* d(volumes)/d(texels) of ALL levels in one launch set (five launches whatever n_levels is) with the sum owned by the IMAGE: the (64-voxel tile,
+ * view) pairs are sorted by the 64 x 60-texel image tile they project into, a workgroup per tile keeps that tile's gradient in LDS (double
+ * sums) and writes every touched texel once (gens_volume_build_bwd, the wave-window kernel, is bound by its ~0.3 G global atomics at 256^3).
+ * It reads what the forward pass left: the means (volumes[l], planes 0-3) and the visible-view counts (counts[l]) of gens_volume_build_levels
+ * on the same inputs; nothing is re-derived per voxel except the projection into the one view a work item serves.  g_volumes[l] (8, D_l^3)
+ * or NULL (no gradient for that level), g_feat[l] (nv, H_l, W_l, 4) accumulates.  Every D_l must be a multiple of 16; intrinsics pre-scaled
+ * per level as for gens_volume_build_levels.  scratch: gens_volume_build_bwd_levels_scratch_bytes bytes of device memory (20 bytes per
+ * (64-voxel tile, view) pair + the bins; 0 = sizes not covered: use gens_volume_build_bwd level by level), contents irrelevant before and
+ * after.  Results equal gens_volume_build_bwd's up to the order of the float32 sums. */
+int64_t gens_volume_build_bwd_levels_scratch_bytes(const int* hw, const int* dims, int n_levels, int nv);
+int gens_volume_build_bwd_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                 const float* const* intr, int nv, const float* const* volumes, const uint8_t* const* counts,
+                                 const float* const* g_volumes, float* const* g_feat, void* scratch, int64_t scratch_bytes, void* stream);
 /* Self-test of K1's exact-division shortcuts (RN(1/b) from v_rcp_f32 + one FMA refinement; a/b from that reciprocal + FMA
  * correction) against the IEEE division over all 2^32 float32 bit patterns: counts[0] += reciprocal mismatches,
  * counts[1] += quotient mismatches (device array of 2, zeroed by the caller).  Both stay 0. */

@@ -39,13 +39,13 @@ def test_library_exports_every_declared_symbol(libpath):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in gens_hip.h but not exported"
     lib.gens_abi_version.restype = ctypes.c_int
-    assert lib.gens_abi_version() == 5
+    assert lib.gens_abi_version() == 6
 
 
 def test_ctypes_table_covers_header(libpath):
     from gens_amd import lib as L
     declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks", "gens_sdf_train_stash_bytes", "gens_gemm_tn_batch_workspace", "gens_blend_train_rows",
-                                              "gens_volume_build_bwd_scratch_bytes", "gens_scene_cams_floats", "gens_compact_points_scratch"}
+                                              "gens_volume_build_bwd_levels_scratch_bytes", "gens_scene_cams_floats", "gens_compact_points_scratch"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     L.load()
 
@@ -56,8 +56,9 @@ def test_argument_errors_are_reported_without_a_gpu(libpath):
     lib = L.load()
     rc = lib.gens_volume_build_fwd(None, None, None, 1.0, 3, 30, 40, 16, 1, None, None, None)
     assert rc == -1 and b"null" in lib.gens_last_error()
-    assert lib.gens_volume_build_bwd_scratch_bytes(5, 480, 640, 256) >= 48 * 256 ** 3 and lib.gens_volume_build_bwd_scratch_bytes(5, 480, 640, 250) == 0
-    rc = lib.gens_volume_build_bwd_tiled(None, None, None, 1.0, 3, 30, 40, 16, None, None, None, 0, None)
+    hw, ok, bad = L.int_table([480, 640]), L.int_table([256]), L.int_table([250])
+    assert 0 < lib.gens_volume_build_bwd_levels_scratch_bytes(hw, ok, 1, 5) < 2 ** 26 and lib.gens_volume_build_bwd_levels_scratch_bytes(hw, bad, 1, 5) == 0
+    rc = lib.gens_volume_build_bwd_levels(None, hw, ok, 1, None, None, 5, None, None, None, None, None, 0, None)
     assert rc == -1 and b"null" in lib.gens_last_error()
     rc = lib.gens_merge_samples(None, None, None, None, None, None, 4, 120, 16, None, None, None, None)
     assert rc == -2

@@ -30,7 +30,7 @@ def ops():
 
 
 # --------------------------------------------------------------------------------------------------- K1
-@pytest.mark.parametrize("bwd", ["window", "tiled"])
+@pytest.mark.parametrize("bwd", ["window", "auto"])
 def test_k1_volume_golden_c1(ops, golden, bwd, monkeypatch):
     monkeypatch.setattr(ops.kernels, "k1_bwd", bwd)      # both backward kernels against the reference
     g = golden("g1a_volume_c1")
@@ -42,9 +42,9 @@ def test_k1_volume_golden_c1(ops, golden, bwd, monkeypatch):
     close(feat.grad, g["gfeat"], atol=2e-5, what="d/dfeat")
 
 
-@pytest.mark.parametrize("bwd", ["window", "tiled"])
+@pytest.mark.parametrize("bwd", ["window", "auto"])
 def test_k1_volume_golden_backward_over_image_tiles(ops, golden, bwd, monkeypatch):
-    """4 views 96 x 160, one 32^3 volume: the image-tile backward spreads every view over 3 x 4 tiles (and the 4 x 16 voxel wave tiles over up to
+    """4 views 96 x 160, one 32^3 volume: the image-tile backward spreads every view over 2 x 3 tiles (and the 4 x 16 voxel wave tiles over up to
     2 x 2 of them); the reference's own gradient."""
     monkeypatch.setattr(ops.kernels, "k1_bwd", bwd)
     g = golden("g1c_volume_tiles")

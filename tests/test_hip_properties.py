@@ -222,17 +222,10 @@ def test_k1_fast_path_is_bit_identical_to_the_generic_kernel(scene):
 
 
 def _k1_bwd(L, tex, w2c, intrs, scale, d, gvol, how):
-    """gens_volume_build_bwd (how = "window" / "direct": every tap a global atomic) or gens_volume_build_bwd_tiled through the C ABI."""
+    """gens_volume_build_bwd through the C ABI: how = "window" (the wave-window kernel) or "direct" (every tap a global atomic)."""
     import os
     nv, h, w, _ = tex.shape
     gf = torch.zeros_like(tex)
-    if how == "tiled":
-        need = L.load().gens_volume_build_bwd_scratch_bytes(nv, h, w, d)
-        assert need > 0
-        scratch = torch.empty(need, device="cuda", dtype=torch.uint8).fill_(0xA5)        # (contents irrelevant: the call initialises what it reads)
-        L.call("gens_volume_build_bwd_tiled", L.ptr(tex), L.ptr(w2c), L.ptr(intrs), scale, nv, h, w, d, L.ptr(gvol), L.ptr(gf),
-               L.ptr(scratch, torch.uint8), need, L.stream())
-        return gf
     if how == "direct":
         os.environ["GENS_K1_BWD_DIRECT"] = "1"
     try:
@@ -242,30 +235,86 @@ def _k1_bwd(L, tex, w2c, intrs, scale, d, gvol, how):
     return gf
 
 
-def test_k1_backward_window_and_tile_kernels_equal_direct_atomics(scene):
-    """The backward's two production kernels -- the LDS-window scatter (one global atomic per touched texel and channel of a wave's 4 x 16 voxel
-    tile) and the image-tile kernel (voxels binned by the 64 x 30 tile of each view they project into, 64-bit fixed-point sums in LDS) -- against
-    one global atomic per tap, at full size (19 M voxels x 5 views): the same sums in a different order.  At 32^3 and 16^3 the wave tiles span
-    more than 2 x 2 image tiles in most views: the tile kernel's direct-scatter branch."""
+def test_k1_backward_window_kernel_equals_direct_atomics(scene):
+    """The LDS-window scatter (one global atomic per touched texel and channel of a wave's 4 x 16 voxel tile) against one global atomic per tap, at full
+    size (19 M voxels x 5 views): the same sums in a different order."""
     from gens_amd import lib as L, ops
     feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
     w2c = torch.linalg.inv(c2ws).contiguous()
     g = torch.Generator(device="cuda").manual_seed(5)
-    for lvl, d in [(0, 256), (1, 128), (2, 64), (3, 32), (0, 32), (0, 16), (1, 48)]:
+    for lvl, d in [(0, 256), (1, 128), (2, 64), (3, 32), (0, 32), (0, 16), (1, 48), (2, 20)]:
         tex = ops.pack_nchw(feats[lvl])
         gvol = torch.randn(8, d, d, d, device="cuda", generator=g)
         ref = _k1_bwd(L, tex, w2c, intrs, 0.5 ** lvl, d, gvol, "direct")
         scale = float(ref.abs().max())
         assert scale > 1.0
-        for how in ("window", "tiled"):
-            out = _k1_bwd(L, tex, w2c, intrs, 0.5 ** lvl, d, gvol, how)
-            assert float((out - ref).abs().max()) <= 2e-6 * scale + 1e-6, (how, d, float((out - ref).abs().max()), scale)
+        out = _k1_bwd(L, tex, w2c, intrs, 0.5 ** lvl, d, gvol, "window")
+        assert float((out - ref).abs().max()) <= 2e-6 * scale + 1e-6, (d, float((out - ref).abs().max()), scale)
+
+
+def _k1_bwd_levels(L, texs, w2c, intrs, dims, gvols, min_vis=1):
+    """gens_volume_build_levels (with the count planes) followed by gens_volume_build_bwd_levels through the C ABI; intrs: per level, rows 0-1 pre-scaled.
+    gvols[l] = None: no gradient for that level."""
+    n, nv = len(dims), texs[0].shape[0]
+    hw = [x for t in texs for x in (t.shape[1], t.shape[2])]
+    vols = [torch.empty(8, d, d, d, device="cuda") for d in dims]
+    masks = [torch.empty(d, d, d, device="cuda") for d in dims]
+    counts = [torch.empty(d ** 3, device="cuda", dtype=torch.uint8) for d in dims]
+    L.call("gens_volume_build_levels", L.ptr_table(texs), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(intrs), nv, min_vis, L.ptr_table(vols),
+           L.ptr_table(masks), L.ptr_table(counts, torch.uint8), L.stream())
+    need = L.load().gens_volume_build_bwd_levels_scratch_bytes(L.int_table(hw), L.int_table(dims), n, nv)
+    assert need > 0
+    scratch = torch.empty(need, device="cuda", dtype=torch.uint8).fill_(0xA5)            # (contents irrelevant: the call initialises what it reads)
+    out = [torch.zeros_like(t) for t in texs]
+    L.call("gens_volume_build_bwd_levels", L.ptr_table(texs), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(intrs), nv, L.ptr_table(vols),
+           L.ptr_table(counts, torch.uint8), L.ptr_table(gvols), L.ptr_table(out), L.ptr(scratch, torch.uint8), need, L.stream())
+    return out, counts
+
+
+def _scaled_intrinsics(intrs, n):
+    out = []
+    for l in range(n):
+        k = intrs.clone()
+        k[:, :2] *= 0.5 ** l
+        out.append(k.contiguous())
+    return out
+
+
+def test_k1_backward_all_levels_in_one_launch_set_equals_direct_atomics(scene):
+    """gens_volume_build_bwd_levels (means and visible-view counts from the forward pass, tile ranges from the corners of the 4 x 16 wave tiles, 64-bit
+    double sums in LDS) against one global atomic per tap: the shipped five-level pyramid at full size in ONE call, a
+    call with levels switched off, and single levels down to 16^3 (where most wave tiles span more than 2 x 2 image tiles: the direct bin)."""
+    from gens_amd import lib as L, ops
+    feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
+    w2c = torch.linalg.inv(c2ws).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dims = [256, 128, 64, 32, 16]
+    texs = [ops.pack_nchw(feats[l]) for l in range(5)]
+    ks = _scaled_intrinsics(intrs, 5)
+    gvols = [torch.randn(8, d, d, d, device="cuda", generator=g) for d in dims]
+    refs = [_k1_bwd(L, texs[l], w2c, ks[l], 1.0, dims[l], gvols[l], "direct") for l in range(5)]
+    out, counts = _k1_bwd_levels(L, texs, w2c, ks, dims, gvols)
+    assert 0.5 < float(counts[0].float().mean()) < 4.5                                    # (the scene's volume is neither invisible nor seen by every view)
+    for l in range(5):
+        scale = float(refs[l].abs().max())
+        assert scale > 1.0 and float((out[l] - refs[l]).abs().max()) <= 2e-6 * scale + 1e-6, (dims[l], float((out[l] - refs[l]).abs().max()), scale)
+    part, _ = _k1_bwd_levels(L, texs, w2c, ks, dims, [None, gvols[1], None, gvols[3], None])
+    for l in range(5):
+        if l in (1, 3):
+            assert float((part[l] - refs[l]).abs().max()) <= 2e-6 * float(refs[l].abs().max()) + 1e-6
+        else:
+            assert float(part[l].abs().max()) == 0.0
+    for lvl, d in [(0, 32), (0, 16), (1, 48), (2, 16)]:                                   # other pairings of map and volume size
+        gv = torch.randn(8, d, d, d, device="cuda", generator=g)
+        ref = _k1_bwd(L, texs[lvl], w2c, ks[lvl], 1.0, d, gv, "direct")
+        one, _ = _k1_bwd_levels(L, [texs[lvl]], w2c, [ks[lvl]], [d], [gv])
+        assert float((one[0] - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6, (lvl, d)
 
 
 @pytest.mark.parametrize("nv,h,w,d", [(11, 50, 70, 48), (2, 31, 65, 32), (16, 24, 20, 16), (3, 200, 130, 64)])
-def test_k1_backward_tile_kernel_other_view_counts_and_image_sizes(nv, h, w, d):
-    """Image-tile kernel against the direct scatter with up to GENS_MAX_VIEWS views and images that are not whole tiles (64 x 30): one partial
-    tile, a tile row of one texel, an image smaller than a tile."""
+def test_k1_backward_levels_other_view_counts_and_image_sizes(nv, h, w, d):
+    """The all-level backward with up to GENS_MAX_VIEWS views (the forward pass then takes its generic kernel, which writes the counts too) and images
+    that are not whole tiles (64 x 30): one partial tile, a tile row of one texel, an image smaller than a tile."""
     from gens_amd import lib as L, ops, synthetic
     sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=1, seed=nv + d)
     tex = ops.pack_nchw(sc["features"][0].cuda())
@@ -274,65 +323,94 @@ def test_k1_backward_tile_kernel_other_view_counts_and_image_sizes(nv, h, w, d):
     g = torch.Generator(device="cuda").manual_seed(d)
     gvol = torch.randn(8, d, d, d, device="cuda", generator=g)
     ref = _k1_bwd(L, tex, w2c, intrs, 1.0, d, gvol, "direct")
-    out = _k1_bwd(L, tex, w2c, intrs, 1.0, d, gvol, "tiled")
+    out, _ = _k1_bwd_levels(L, [tex], w2c, [intrs], [d], [gvol])
     scale = float(ref.abs().max())
     # (a 48^3 volume over a 50 x 70 image sums ~350 taps per texel and view: the float32 atomics of the direct scatter carry 4e-6 of the largest entry
-    # in their order of arrival; the tile kernel's fixed-point sums are exact up to the final conversion)
-    assert scale > 0.5 and float((out - ref).abs().max()) <= 1e-5 * scale + 1e-6, (float((out - ref).abs().max()), scale)
+    # in their order of arrival; the window's double sums are exact up to the final conversion)
+    assert scale > 0.5 and float((out[0] - ref).abs().max()) <= 1e-5 * scale + 1e-6, (float((out[0] - ref).abs().max()), scale)
 
 
-def test_k1_backward_tile_kernel_sparse_and_nonfinite_gradients(scene):
-    """Image-tile kernel: a cotangent that is zero almost everywhere with entries 1e-30 .. 1e+30 (the fixed-point scale follows the largest
-    |gradient| of the call; what is far below it is below float32 resolution of any sum it shares a texel with), and a NaN / an infinity among
-    the cotangents (float path: the same texels turn NaN / inf as with the wave-window kernel)."""
+def test_k1_backward_levels_cameras_inside_and_behind_the_volume():
+    """Wave tiles with a corner at or behind a camera (their image is not the corners' convex hull: the pair's 64 voxels are walked one by one) and
+    views that see none of the volume: cameras moved into the cube and turned away from it."""
+    from gens_amd import lib as L, ops, synthetic
+    sc = synthetic.make_scene(nv=4, h=120, w=160, n_levels=1, seed=3)
+    c2ws = sc["c2ws"].clone()
+    c2ws[1, :3, 3] = torch.tensor([0.1, -0.2, 0.05])                                      # inside the cube
+    c2ws[2, :3, 3] *= 0.45                                                                  # close to / inside a face
+    c2ws[3, :3, :3] = c2ws[3, :3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))        # looks away
+    tex = ops.pack_nchw(sc["features"][0].cuda())
+    w2c = torch.linalg.inv(c2ws.cuda()).contiguous()
+    intrs = sc["intrs"].cuda()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for d in (32, 64):
+        gvol = torch.randn(8, d, d, d, device="cuda", generator=g)
+        ref = _k1_bwd(L, tex, w2c, intrs, 1.0, d, gvol, "direct")
+        out, counts = _k1_bwd_levels(L, [tex], w2c, [intrs], [d], [gvol])
+        scale = float(ref.abs().max())
+        assert scale > 0.5 and float((out[0] - ref).abs().max()) <= 1e-5 * scale + 1e-6, (d, float((out[0] - ref).abs().max()), scale)
+        assert float(ref[1].abs().max()) > 0 and float(out[0][3].abs().max()) == float(ref[3].abs().max())
+
+
+def test_k1_backward_levels_sparse_and_nonfinite_gradients(scene):
+    """A cotangent that is zero almost everywhere with entries 1e-30 .. 1e+30 (double sums: no scale to choose), an all-zero cotangent, and a NaN / an
+    infinity among the cotangents (the same texels turn NaN / inf as with the wave-window kernel)."""
     from gens_amd import lib as L, ops
     feats, intrs, c2ws = scene["features"], scene["intrs"], scene["c2ws"]
     w2c = torch.linalg.inv(c2ws).contiguous()
     tex = ops.pack_nchw(feats[1])
+    k1 = _scaled_intrinsics(intrs, 2)[1]
     d = 64
     g = torch.Generator(device="cuda").manual_seed(9)
     for amp in (1e-30, 1.0, 1e30):
         gvol = torch.zeros(8, d, d, d, device="cuda")
         gvol[:4, 20:24, 30:34, 8:40] = amp * torch.randn(4, 4, 4, 32, device="cuda", generator=g)       # (mean planes: finite at 1e30; the variance planes multiply by features)
         gvol[4:, 40, 20, 10:20] = amp * 1e-3
-        ref = _k1_bwd(L, tex, w2c, intrs, 0.5, d, gvol, "direct")
-        out = _k1_bwd(L, tex, w2c, intrs, 0.5, d, gvol, "tiled")
+        ref = _k1_bwd(L, tex, w2c, k1, 1.0, d, gvol, "direct")
+        out = _k1_bwd_levels(L, [tex], w2c, [k1], [d], [gvol])[0][0]
         scale = float(ref.abs().max())
         assert scale > 0.1 * amp and bool(torch.isfinite(ref).all())
         assert float((out - ref).abs().max()) <= 2e-6 * scale, (amp, float((out - ref).abs().max()), scale)
         assert torch.equal(out == 0, ref == 0)                                       # untouched texels stay exactly zero
-    zero = _k1_bwd(L, tex, w2c, intrs, 0.5, d, torch.zeros(8, d, d, d, device="cuda"), "tiled")
+    zero = _k1_bwd_levels(L, [tex], w2c, [k1], [d], [torch.zeros(8, d, d, d, device="cuda")])[0][0]
     assert float(zero.abs().max()) == 0.0
     for bad in (float("nan"), float("inf")):
         gvol = torch.randn(8, d, d, d, device="cuda", generator=g)
         gvol[2, 31, 33, 17] = bad
-        ref = _k1_bwd(L, tex, w2c, intrs, 0.5, d, gvol, "window")
-        out = _k1_bwd(L, tex, w2c, intrs, 0.5, d, gvol, "tiled")
+        ref = _k1_bwd(L, tex, w2c, k1, 1.0, d, gvol, "window")
+        out = _k1_bwd_levels(L, [tex], w2c, [k1], [d], [gvol])[0][0]
         assert int((~torch.isfinite(ref)).sum()) > 0
         assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(torch.isinf(out), torch.isinf(ref))
         ok = torch.isfinite(ref)
         assert float((out[ok] - ref[ok]).abs().max()) <= 2e-6 * float(ref[ok].abs().max()) + 1e-6
 
 
-def test_k1_backward_tile_kernel_rejects_what_it_does_not_cover(scene):
+def test_k1_backward_levels_rejects_what_it_does_not_cover(scene):
     from gens_amd import lib as L, ops
     lib = L.load()
-    assert lib.gens_volume_build_bwd_scratch_bytes(5, 480, 640, 24) == 0             # D must be a multiple of 16
-    assert lib.gens_volume_build_bwd_scratch_bytes(17, 480, 640, 64) == 0            # GENS_MAX_VIEWS
-    need = lib.gens_volume_build_bwd_scratch_bytes(5, 240, 320, 64)
-    assert need >= 48 * 64 ** 3
+    assert lib.gens_volume_build_bwd_levels_scratch_bytes(L.int_table([480, 640]), L.int_table([24]), 1, 5) == 0        # D must be a multiple of 16
+    assert lib.gens_volume_build_bwd_levels_scratch_bytes(L.int_table([480, 640]), L.int_table([64]), 1, 17) == 0       # GENS_MAX_VIEWS
+    need = lib.gens_volume_build_bwd_levels_scratch_bytes(L.int_table([240, 320]), L.int_table([64]), 1, 5)
+    assert 0 < need < 48 * 64 ** 3 // 8                                                # (the previous generation kept 48 bytes per voxel)
     tex = ops.pack_nchw(scene["features"][1])
     w2c = torch.linalg.inv(scene["c2ws"]).contiguous()
-    gvol = torch.zeros(8, 64, 64, 64, device="cuda")
+    k1 = _scaled_intrinsics(scene["intrs"], 2)[1]
+    gvol, vol = torch.zeros(8, 64, 64, 64, device="cuda"), torch.zeros(8, 64, 64, 64, device="cuda")
+    cnt = torch.zeros(64 ** 3, device="cuda", dtype=torch.uint8)
     gf = torch.zeros_like(tex)
     scratch = torch.empty(need, device="cuda", dtype=torch.uint8)
-    args = (L.ptr(tex), L.ptr(w2c), L.ptr(scene["intrs"]), 0.5, 5, 240, 320)
+
+    def call(dims, scr, nbytes, counts=(cnt,)):
+        L.call("gens_volume_build_bwd_levels", L.ptr_table([tex]), L.int_table([240, 320]), L.int_table(dims), 1, L.ptr(w2c), L.ptr_table([k1]), 5, L.ptr_table([vol]),
+               L.ptr_table(list(counts), torch.uint8), L.ptr_table([gvol]), L.ptr_table([gf]), scr, nbytes, L.stream())
     with pytest.raises(RuntimeError, match="scratch"):
-        L.call("gens_volume_build_bwd_tiled", *args, 64, L.ptr(gvol), L.ptr(gf), L.ptr(scratch, torch.uint8), need - 1, L.stream())
+        call([64], L.ptr(scratch, torch.uint8), need - 1)
     with pytest.raises(RuntimeError, match="multiple of 16"):
-        L.call("gens_volume_build_bwd_tiled", *args, 24, L.ptr(gvol), L.ptr(gf), L.ptr(scratch, torch.uint8), need, L.stream())
+        call([24], L.ptr(scratch, torch.uint8), need)
     with pytest.raises(RuntimeError, match="null"):
-        L.call("gens_volume_build_bwd_tiled", *args, 64, L.ptr(gvol), L.ptr(gf), None, need, L.stream())
+        call([64], None, need)
+    with pytest.raises(RuntimeError, match="null"):
+        call([64], L.ptr(scratch, torch.uint8), need, counts=(None,))
 
 
 @pytest.mark.parametrize("layout", ["planar", "packed"])
