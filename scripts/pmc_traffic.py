@@ -25,7 +25,15 @@ ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_value_t_k": "gens_sdf_value", "sdf_gr
          "sdf_train_fwd_k": "gens_sdf_train_fwd", "sdf_train_bwd_k": "gens_sdf_train_bwd", "sdf_train_scatter_k": "gens_sdf_train_scatter",
          "sdf_train_pack_k": "gens_sdf_train_pack", "blend_train_k": "gens_blend_train", "gemm_tn_batch2_partial_k": "gens_gemm_tn_batch",
          "gemm_tn_batch_partial_k": "gens_gemm_tn_batch", "volume_build_bwd_k": "gens_volume_build_bwd", "tv_fwd4_k": "gens_tv_fwd",
-         "tv_bwd4_k": "gens_tv_bwd", "lookup_feature_bwd_k": "gens_lookup_feature_bwd", "mc_classify4_k": "gens_mc_classify"}
+         "tv_bwd4_k": "gens_tv_bwd", "lookup_feature_bwd_k": "gens_lookup_feature_bwd", "mc_classify4_k": "gens_mc_classify",
+         # round 3: the all-level K1 backward (four device kernels per entry-point launch) and the step-boundary kernels
+         "volume_bwd_plan_k": "gens_volume_build_bwd_levels", "volume_bwd_scan_k": "gens_volume_build_bwd_levels", "volume_bwd_fill_k": "gens_volume_build_bwd_levels",
+         "volume_bwd_tiles_k": "gens_volume_build_bwd_levels", "sdf_train_wgrad_k": "gens_sdf_train_wgrad", "sdf_train_norm_k": "gens_sdf_train_pack_wn",
+         "blend_wgrad_k": "gens_blend_train_wgrad", "tv_levels_fwd_k": "gens_tv_levels_fwd", "tv_levels_bwd_k": "gens_tv_levels_bwd",
+         "patch_warp_fwd_k": "gens_patch_warp_fwd", "patch_warp_bwd_k": "gens_patch_warp_bwd", "loss_fwd_k": "gens_loss_fwd", "loss_bwd_k": "gens_loss_bwd",
+         "lncc_fwd_k": "gens_lncc_fwd", "lncc_bwd_k": "gens_lncc_bwd", "composite_bwd_k": "gens_composite_bwd"}
+# entry points made of several device kernels: the launches of this one are the entry point's
+ONE_PER_ENTRY = {"gens_volume_build_bwd_levels": "volume_bwd_tiles_k"}
 
 
 def kernel_source_hash():
@@ -66,6 +74,8 @@ def main():
         d["fetch_bytes"] += ft.get(k, 0.0)
         d["write_bytes"] += wt.get(k, 0.0)
         d["device_kernels"].append(k)
+        if e in ONE_PER_ENTRY and k != ONE_PER_ENTRY[e]:
+            continue
         if not k.startswith("compact_") or k in ("compact_scan_k", "compact_points_write_k"):      # one entry-point launch = 3 (2) device kernels for the compaction
             d["launches_f"] += len(fd.get(k, ()))
             d["launches_w"] += len(wd.get(k, ()))
