@@ -269,9 +269,10 @@ def main():
                 traffic_source = "profiles/" + os.path.basename(tpath) + " (mean over the entry point's launches)"
                 break
         common = {"kernel": dom_name, "slowest_kernel_of_the_step": slowest, "traffic": traffic, "traffic_source": traffic_source,
-                  "traffic_note": ("gens_sdf_grad keeps softplus' of one layer in private memory: 16 KB per 32 points written once and read once "
-                                   "(2 x 2.1 GB per launch, evicted from the write-back L2 in between) on top of ~0.15 GB of algorithmic bytes; "
-                                   "0.36 TB/s of HBM on a matrix-pipe-bound kernel (DESIGN.md section 4b')") if dom_name == "gens_sdf_grad" else None,
+                  "traffic_note": ("gens_sdf_grad parks softplus' of one layer (16 KB per 32 points) in a SIMD-private slot of global memory between the "
+                                   "forward and the reverse chain: the slots (2 MB per XCD) are read back from L2, but every store still reaches the fabric "
+                                   "(WRITE_SIZE 2.2 GB per launch; as compiler-private memory the reads missed too: 4.8 GB) on top of ~0.15 GB of "
+                                   "algorithmic bytes; a matrix-pipe-bound kernel (DESIGN.md section 4b')") if dom_name == "gens_sdf_grad" else None,
                   "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                   "hip_kernels_ms_per_step": round(hip_ms / args.steps, 2)}
         if dom.get("flops"):      # the fused MLP is matrix-core bound: price it against the dense MFMA peak of the operand type

@@ -20,6 +20,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#define TG_SLOT_F4 (16 * 64 + 16)       // float4 per stash slot: 16 KB of softplus' + the lock word's 256 bytes
+#ifndef TG_STASH_LOAD_POLICY
+#define TG_STASH_LOAD_POLICY 0
+#endif
+#define TG_SLOTS 2048                   // (XCC 3 bits, SE 2, CU 4, SIMD 2)
 #define TG_C 144.26950408889634f        // 100 / ln 2: hidden units travel as c * softplus (k6_sdfmlp.hip::softplus_t)
 
 // value of one packed (X, Y, Z, 4) volume at x and its derivative with respect to x (zero padding, align_corners=True)
@@ -79,7 +84,7 @@ template <int NLEV>
 __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float4* __restrict__ wstream, const float* w_out, float b_last, float scale,
                                                       float inv_scale, const float* __restrict__ pts, const int64_t* __restrict__ index,
                                                       int64_t n_max, const int32_t* __restrict__ n_dev, float* __restrict__ sdf_out,
-                                                      float* __restrict__ grad_out) {
+                                                      float* __restrict__ grad_out, float4* __restrict__ stash_all) {
     typedef GradShapeT<NLEV> S;
     constexpr int NCH = S::NCH, NCS = S::NCS, GC = S::GC, GP = S::GP, TC = S::TC, MID = NLEV / 2;
     static_assert(TC % 2 == 0, "the conditioning gradient is accumulated two tiles at a time");
@@ -90,6 +95,24 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
     if (m0 >= n) return;
+    // softplus' of layer 2 (16 KB per wave) waits in GLOBAL memory, in a slot that belongs to the SIMD this wave runs on: with 512 registers a
+    // SIMD holds one wave of this kernel at a time, so 1 024 slots (16 MB, 2 MB per XCD: resident in its L2) serve the whole launch.  As the
+    // compiler's private memory the same 16 KB went to whichever of a SIMD's wave slots the wave landed in, the footprint outgrew the L2, and
+    // 4.3 GB per launch crossed the fabric for 0.15 GB of algorithmic bytes (PMC: FETCH_SIZE / WRITE_SIZE).  The slot's lock word makes the
+    // one-wave-per-SIMD argument a performance assumption instead of a correctness one (it is always found free).
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));          // [5:4] SIMD, [11:8] CU, [15:13] SE (scripts/probe/hwid_probe.py)
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const uint32_t slot = ((((xcc_id & 7u) << 2 | ((hw_id >> 13) & 3u)) << 4 | ((hw_id >> 8) & 15u)) << 2) | ((hw_id >> 4) & 3u);
+    float4* const stash_slot = stash_all + (size_t)slot * TG_SLOT_F4;
+    uint32_t* const lock = (uint32_t*)(stash_slot + 16 * 64);
+    if (lane == 0)
+        while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(32);
+    // (a buffer descriptor: the slot's base in SGPRs, 16 lane in ONE VGPR, the register's offset as a scalar -- no vector address arithmetic)
+    const __amdgpu_buffer_rsrc_t stash = __builtin_amdgcn_make_buffer_rsrc((void*)stash_slot, 0, 16 * 64 * 16, 0x00020000);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const uint32_t stash_lane = (uint32_t)lane * 16u;
 
     // the weight stream: a wave-uniform (scalar) base that advances by one group + 16 lane + an immediate per tile; three register
     // sets rotate: this group's weights and the next TWO groups' (in flight): with one wave per SIMD nothing else hides an L2 miss
@@ -190,13 +213,8 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 
     f32x16 acc[4], H[4];          // the product being accumulated / the operand of the running product (activations, then G_l)
     f32x16 D3[4], D4[4];          // softplus' of layers 3, 4
-    // softplus' of layer 2 waits in this wave's PRIVATE memory (scratch: 16 KB per wave slot, L2-resident): with it in registers the
-    // allocator spilled ~200 values at places of its own choosing, and every reload drained the weight prefetch (vmcnt counts in
-    // order).  The opaque zero makes the index dynamic, or the array would be promoted back into registers.
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 D2s[16];
-    int opaque0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+    // (softplus' of layer 2: the stash above -- with it in registers the allocator spilled ~200 values at places of its own choosing, and
+    // every reload drained the weight prefetch, vmcnt counting in order)
     f32x16 gc[TC], gp;            // d sdf / d (this lane's conditioning slots), d sdf / d (its point-encoding slots)
 
     // one group = 4 float4 of weights per lane (requested NB - 1 groups ahead, into the register set just freed) and up to 16 MFMAs
@@ -308,7 +326,11 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
                 f32x16 d;
                 TG_SOFTPLUS_TILE(acc[t], H[t], d);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) D2s[4 * t + q + opaque0] = (f32x4){d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+                for (int q = 0; q < 4; ++q)
+                    // (the register's offset in the VECTOR offset: a 16-byte buffer store with an SGPR offset whose data registers the next VALU
+                    // instruction overwrites lost values here -- hipcc 7.0 leaves no wait state between the two on gfx950)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4s){d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]}), stash,
+                                                           stash_lane + (uint32_t)(4 * t + q) * 1024u, 0, 0);
             }
             if (l == 3) TG_SOFTPLUS_TILE(acc[t], H[t], D3[t]);
             if (l == 4) TG_SOFTPLUS_TILE(acc[t], H[t], D4[t]);
@@ -383,7 +405,10 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
                 float4 d;
                 if (l == 5) d = make_float4(D4[t][4 * q], D4[t][4 * q + 1], D4[t][4 * q + 2], D4[t][4 * q + 3]);
                 if (l == 4) d = make_float4(D3[t][4 * q], D3[t][4 * q + 1], D3[t][4 * q + 2], D3[t][4 * q + 3]);
-                if (l == 3) { const f32x4 v = D2s[4 * t + q + opaque0]; d = make_float4(v[0], v[1], v[2], v[3]); }
+                if (l == 3) {
+                    const f32x4s v = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(stash, stash_lane, (uint32_t)(4 * t + q) * 1024u, TG_STASH_LOAD_POLICY));
+                    d = make_float4(v[0], v[1], v[2], v[3]);
+                }
                 if (l == 2) d = DS[1][4 * t + q][lane];
                 if (l == 1) d = DS[0][4 * t + q][lane];
                 H[t][4 * q] = acc[t][4 * q] * d.x;
@@ -453,6 +478,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
             grad_out[3 * src + 2] = g[2] * inv_scale;
         }
     }
+    if (lane == 0) atomicExch(lock, 0u);                                            // (the stash was read long before: its values fed the reverse pass)
 }
 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
@@ -461,9 +487,11 @@ extern "C" int gens_sdf_grad_groups(int n_levels) {
     return n_levels == 3 ? GradShapeT<3>::NG_FWD + GradShapeT<3>::NG_BWD : n_levels == 5 ? GradShapeT<5>::NG_FWD + GradShapeT<5>::NG_BWD : 0;
 }
 
+extern "C" int64_t gens_sdf_grad_stash_bytes(void) { return (int64_t)TG_SLOTS * TG_SLOT_F4 * 16; }
+
 extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
                              float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
-                             float* sdf_out, float* grad_out, void* stream) {
+                             float* sdf_out, float* grad_out, void* stash, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_grad", &vs, vols_packed, dims, n_levels)) return e;
     GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_grad: built for 3 or 5 volume levels, got %d", n_levels);
@@ -471,13 +499,14 @@ extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, i
     GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_sdf_grad: the weight stream must be 16-byte aligned");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out && grad_out)), GENS_EINVAL, "gens_sdf_grad: null pts / output");
     GENS_CHECK_ARG(scale != 0.0f, GENS_EINVAL, "gens_sdf_grad: scale must be non-zero");
+    GENS_CHECK_ARG(stash && ((uintptr_t)stash & 15) == 0, GENS_EINVAL, "gens_sdf_grad: null or misaligned stash (gens_sdf_grad_stash_bytes() bytes, zeroed once)");
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, 32);
     if (n_levels == 3)
         sdf_grad_t_k<3><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
-                                                             sdf_out, grad_out);
+                                                             sdf_out, grad_out, (float4*)stash);
     else
         sdf_grad_t_k<5><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
-                                                             sdf_out, grad_out);
+                                                             sdf_out, grad_out, (float4*)stash);
     return gens_launch_status("gens_sdf_grad");
 }

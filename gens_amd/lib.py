@@ -99,7 +99,7 @@ SIGNATURES = {
     "gens_compact_valid": [_p, _l, _p, _p, _p, _p],
     "gens_sdf_value": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p],
     "gens_sdf_value_groups": [_i],
-    "gens_sdf_grad": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
+    "gens_sdf_grad": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_grad_groups": [_i],
     "gens_sdf_value_f16": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_value_f16_units": [_i],
@@ -158,6 +158,8 @@ def load():
     lib.gens_volume_build_bwd_levels_scratch_bytes.restype = _l
     lib.gens_volume_build_bwd_levels_scratch_bytes.argtypes = [_ip, _ip, _i, _i]
     lib.gens_sdf_train_stash_bytes.restype = _l
+    lib.gens_sdf_grad_stash_bytes.restype = _l
+    lib.gens_sdf_grad_stash_bytes.argtypes = []
     lib.gens_sdf_train_stash_bytes.argtypes = [_l, _i]
     lib.gens_blend_train_rows.restype = _l
     lib.gens_blend_train_rows.argtypes = [_l, _i]

@@ -41,6 +41,19 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_SDF_GRAD_STASH = {}
+
+
+def sdf_grad_stash(device):
+    """gens_sdf_grad's SIMD-private slots (softplus' of one layer between the forward and the reverse chain): one zeroed buffer per device for the
+    life of the process, shared by every call."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _SDF_GRAD_STASH.get(key)
+    if buf is None:
+        buf = _SDF_GRAD_STASH[key] = torch.zeros(L.load().gens_sdf_grad_stash_bytes(), device=torch.device("cuda", key), dtype=torch.uint8)
+    return buf
+
+
 def aligned16(t):
     """Contiguous and 16-byte aligned (what the float4 / float2 accesses of the texel, packed-volume, K15 and K16 kernels need): a
     contiguous VIEW that starts mid-allocation (flat[1:].view(c, n)) is copied; everything torch allocates itself already qualifies."""
@@ -1372,7 +1385,8 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     if want_grad and kernels.sdf_grad == "transposed":
         # (also under "f16x2": the value + gradient pass stays float32 -- the split-half arithmetic covers the value-only passes)
         L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
-               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out), L.stream(),
+               plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out),
+               L.ptr(sdf_grad_stash(pts.device), torch.uint8), L.stream(),
                nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad")
     elif precision == "f16x2" and not want_grad and plan.value_ok:
         L.call("gens_sdf_value_f16", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.value_units, torch.float16), L.ptr(plan.value_w_out),

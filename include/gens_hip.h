@@ -277,10 +277,13 @@ int gens_sdf_value_groups(int n_levels);
  *   wstream: DEVICE, 16-byte aligned, (gens_sdf_grad_groups(n_levels) + 2) x 4 KB in the order of gens_amd.ops._pack_grad_stream: the
  *   forward groups of gens_sdf_value, then the reverse pass on the plain transposed matrices; the two trailing groups are zero
  *   (the kernel requests weights two groups ahead).
- *   w_out: DEVICE (2, 64 + 16 * TC) float32: row 0 of lin6 per lane half (hidden part / (100 / ln 2), then the conditioning slots). */
+ *   w_out: DEVICE (2, 64 + 16 * TC) float32: row 0 of lin6 per lane half (hidden part / (100 / ln 2), then the conditioning slots).
+ *   stash: DEVICE, 16-byte aligned, gens_sdf_grad_stash_bytes() bytes, ZEROED ONCE by the caller and then left alone (it may be shared by all
+ *   calls on a device, concurrent ones included): a 16 KB slot + lock word per SIMD where softplus' of layer 2 waits for the reverse pass. */
 int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
                   float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
-                  float* sdf_out, float* grad_out, void* stream);
+                  float* sdf_out, float* grad_out, void* stash, void* stream);
+int64_t gens_sdf_grad_stash_bytes(void);
 /* number of 4 KB groups in the weight stream of gens_sdf_grad, without the trailing zero groups (0 = unsupported level count) */
 int gens_sdf_grad_groups(int n_levels);
 

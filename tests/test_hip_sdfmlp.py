@@ -144,10 +144,13 @@ def test_new_sdf_kernels_reject_bad_arguments():
                L.stream())
     with pytest.raises(RuntimeError, match="scale must be non-zero"):
         L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 0.0, L.ptr(pts), None, 8,
-               None, L.ptr(out), L.ptr(pts), L.stream())
+               None, L.ptr(out), L.ptr(pts), L.ptr(ops.sdf_grad_stash("cuda"), torch.uint8), L.stream())
     with pytest.raises(RuntimeError, match="3 or 5 volume levels"):
         L.call("gens_sdf_grad", packed.table, packed.dim_table, 2, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
-               None, L.ptr(out), L.ptr(pts), L.stream())
+               None, L.ptr(out), L.ptr(pts), L.ptr(ops.sdf_grad_stash("cuda"), torch.uint8), L.stream())
+    with pytest.raises(RuntimeError, match="stash"):
+        L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
+               None, L.ptr(out), L.ptr(pts), None, L.stream())
     # empty launches are no-ops
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), want_grad=True)
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"))
