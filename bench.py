@@ -361,17 +361,29 @@ def main():
                                  "points, the reference's Loss (gens_amd.losses.Loss, shipped weights) + backward + Adam (torch.optim.Adam as "
                                  "runner.py:97 builds it); 30 timed steps after 5 warm-up each, the loss read back every step as runner.py does",
                      "note": "secondary figures; not the headline"}
-            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"])):
-                ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
+            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
+                               ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"])):
+                try:
+                    ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
+                except Exception as e:                                 # (a secondary of the secondaries: report, do not lose the others)
+                    train[key] = {"error": f"{type(e).__name__}: {e}"}
+                    continue
                 from scripts.train_step_bench import _measure as _m
                 train[key] = {"ms_per_step": round(ms, 2), "ms_per_step_stats": dict(getattr(_m, "stats", {})),
                               "ray_samples_per_s": round(512 * 128 / ms * 1e3, 1), "launches_per_step_c_abi": sum(k["launches"] for k in kt.values()),
                               "hip_kernels": kernel_rows(kt, 8)}
-                train[key]["roofline"] = kernel_roofline(kt)
+                if kt:
+                    train[key]["roofline"] = kernel_roofline(kt)
+                else:                                                  # (a graph replay: the kernels are the eager key's)
+                    del train[key]["hip_kernels"], train[key]["launches_per_step_c_abi"]
                 torch.cuda.empty_cache()
             train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "
                                                   "volume_dims 256/128/64/32/16 as parameters, 512 rays + 2048 pseudo points")
             train["ms_per_step"] = train["full"]["ms_per_step"]
+            for key in ("hot_path_graph", "finetune_graph"):
+                if "error" not in train[key]:
+                    train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; Adam with capturable=True): "
+                                          "one launch per step, independent of the host's pace")
         except Exception as e:                                             # never let a secondary figure take the headline down
             train = {"error": f"{type(e).__name__}: {e}"}
         # secondary figure: one whole `--mode val` item (volume build, 512^3 SDF lattice, marching cubes on the device, 480x640 render)

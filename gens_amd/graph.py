@@ -1,0 +1,54 @@
+"""A training step captured ONCE into a HIP graph and replayed (torch.cuda.CUDAGraph = hipGraph on ROCm).
+
+A fused training step is ~140 launches of 5 - 1 600 us each: the GPU needs 7.4 ms for them and the host about as long to
+enqueue them, so any hiccup of the host thread (a busy node, a cold page cache: the first process on a fresh box measured 12 - 30 ms per
+step for the same kernels) lands in the step time.  Nothing in such a step depends on the host any more -- the point selections are
+device-side index lists, the reference's mid-step errors are device flags (ImplicitSurface.check_deferred), the generator draws reach the
+device through a page-locked buffer -- so the whole step (forward, loss, backward, optimiser) is a fixed sequence of launches: capture it
+once, replay it with ONE launch per step.
+
+    step = GraphedStep(body, surfaces=[model.implicit_surface], optimizer=opt)     # body(): forward + loss + backward + optimizer.step() -> loss
+    for _ in range(n):
+        copy the step's inputs into the tensors body() reads (rays, pixels, ... : tensor.copy_(new), same shapes)
+        loss = step()                     # refreshes the host draws, replays, returns the captured loss tensor
+        float(loss)                       # the read-back synchronises; step.check() then raises what the reference would have raised
+
+What must hold (checked where it can be): the optimiser is capturable (torch.optim.Adam(..., capturable=True)), shapes and the set of
+tensors body() touches do not change between replays, inputs are updated IN PLACE, and body() does not synchronise with the host.  The eager
+path stays the reference-compatible default (runner.py calls the model step by step); this is the opt-in for loops that own their step.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, body, surfaces, optimizer, warmup=3):
+        """body: callable -> scalar loss tensor, running forward + loss + backward + optimizer.step() on the current stream.  surfaces: the
+        ImplicitSurface modules whose host draws the step uses.  optimizer: zero_grad(set_to_none=True) is called around the capture."""
+        self.surfaces = list(surfaces)
+        for group in optimizer.param_groups:
+            assert group.get("capturable", False) or group.get("fused", False), "build the optimiser with capturable=True (its step counter must live on the device)"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # (warm-up off the default stream, as torch.cuda.graph requires)
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for s in self.surfaces:
+            s.check_deferred()
+        optimizer.zero_grad(set_to_none=True)                  # the captured backward then ASSIGNS the gradients (no accumulation across replays)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+
+    def __call__(self):
+        for s in self.surfaces:
+            s.refresh_host_draws()                             # the reference's generator, its order: the graph's copy node carries them over
+        self.graph.replay()
+        return self.loss
+
+    def check(self):
+        """After the caller synchronised with the replay (the loss read-back): the errors the reference raises mid-step."""
+        for s in self.surfaces:
+            s.check_deferred_host()

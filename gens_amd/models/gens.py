@@ -136,6 +136,17 @@ class GenS(nn.Module):
         else:
             view_ids = ipts["view_ids"] if mode != "val" else list(range(ipts["imgs"].shape[0]))
             volumes, mask_volmes = list(self.volumes), list(self.mask_volmes)
-            features = [f[view_ids] for f in self.features]
-            match_features = [f[view_ids] for f in self.features]
+            # (gens.py:151-153: `self.features[i][view_ids]` with a Python list builds an index tensor on the host and copies it over -- every
+            # step, a pageable host-to-device copy, and not capturable into a graph: the index tensor is kept per list of ids; one gather serves
+            # both uses, the reference's two copies hold the same values)
+            ids = tuple(int(v) for v in view_ids) if not torch.is_tensor(view_ids) else None
+            if ids is None:
+                index = view_ids
+            else:
+                cache = getattr(self, "_view_index", None)
+                if cache is None or cache[0] != ids or cache[1].device != self.features[0].device:
+                    cache = self._view_index = (ids, torch.tensor(ids, dtype=torch.long, device=self.features[0].device))
+                index = cache[1]
+            features = [f.index_select(0, index) for f in self.features]
+            match_features = features
         return self.implicit_surface(mode, ipts, volumes, mask_volmes, features, match_features, cos_anneal_ratio, step)

@@ -262,20 +262,31 @@ class ImplicitSurface(nn.Module):
         on ROCm (the launch queue ran empty once per step), a pinned one is just another asynchronous launch.  -> (t_rand (B,1) or None,
         pts_random (1024,3) in [-1, 1)) on the device.  The ` * 2 - 1` of :256 happens on the host: the same two float32 operations."""
         n_t = 0 if b is None else b
+        capturing = torch.cuda.is_current_stream_capturing()
         buf = getattr(self, "_pinned_draws", None)
         if buf is None or buf.numel() != n_t + 3 * N_RANDOM_PTS:
             buf = torch.empty(n_t + 3 * N_RANDOM_PTS, dtype=torch.float32, pin_memory=True)
             self._pinned_draws = buf
             self._pinned_draws_event = None
-        elif self._pinned_draws_event is not None:
+        elif self._pinned_draws_event is not None and not capturing:
             self._pinned_draws_event.synchronize()           # the previous step's copy out of this buffer has long finished
+        self._pinned_draws_layout = (n_t, b)
+        self.refresh_host_draws()
+        on_dev = buf.to(dev, non_blocking=True)              # (captured into a graph this is a copy node that reads the buffer at every replay)
+        if not capturing:
+            self._pinned_draws_event = torch.cuda.Event()
+            self._pinned_draws_event.record()
+        return (on_dev[:n_t].view(b, 1) if n_t else None), on_dev[n_t:].view(N_RANDOM_PTS, 3)
+
+    def refresh_host_draws(self):
+        """Draw the step's host random numbers into the page-locked staging buffer (the reference's generator, its order and shapes).  A step
+        replayed from a captured graph (gens_amd.graph.GraphedStep) calls this before every replay: the graph's copy node then carries the new
+        draws to the device.  The previous replay must have finished (the loss read-back of a training loop guarantees it)."""
+        n_t, b = self._pinned_draws_layout
+        buf = self._pinned_draws
         if n_t:
             buf[:n_t] = torch.rand([b, 1]).reshape(-1)
         buf[n_t:] = (torch.rand([N_RANDOM_PTS, 3]) * 2 - 1).reshape(-1)
-        on_dev = buf.to(dev, non_blocking=True)
-        self._pinned_draws_event = torch.cuda.Event()
-        self._pinned_draws_event.record()
-        return (on_dev[:n_t].view(b, 1) if n_t else None), on_dev[n_t:].view(N_RANDOM_PTS, 3)
 
     def _train_fused_ok(self, scene, net, lean):
         """The fused TRAINING path of render_core: K17 (net) + K18 on a device-side selection (ops.StepPoints), no host synchronisation."""
@@ -677,6 +688,9 @@ class ImplicitSurface(nn.Module):
             host = self._deferred_host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
         host[:3].copy_(counts, non_blocking=True)
         host[3:4].copy_(cam_status, non_blocking=True)
+        if torch.cuda.is_current_stream_capturing():         # (a captured step: the copies are graph nodes; the replaying loop checks after its own synchronisation)
+            self._deferred = None
+            return
         ev = torch.cuda.Event()
         ev.record()
         self._deferred = ev
@@ -685,11 +699,18 @@ class ImplicitSurface(nn.Module):
         """Raise what the last fused training step would have raised in the reference (no valid pseudo point, implicit_surface.py:494-495; a
         singular camera matrix, torch.inverse).  Called at the start of every forward(); call it yourself after the last step of a loop."""
         ev = getattr(self, "_deferred", None)
-        if ev is None:
+        if ev is None or torch.cuda.is_current_stream_capturing():
             return
         self._deferred = None
         ev.synchronize()
-        host = self._deferred_host
+        self.check_deferred_host()
+
+    def check_deferred_host(self):
+        """The same checks on what the last step left in page-locked memory; the caller has synchronised with that step (a graph replay
+        followed by the loss read-back)."""
+        host = getattr(self, "_deferred_host", None)
+        if host is None:
+            return
         if int(host[3]) != 0:
             raise RuntimeError("linalg.inv: a camera pose or intrinsics matrix of the previous step's scene is singular")
         if int(host[2]) < 1:

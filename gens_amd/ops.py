@@ -264,6 +264,30 @@ class VolumeSet:
 # ------------------------------------------------------------------------------------------------------------------
 # K1  Volume.agg_mean_var (volume.py:13-63)
 # ------------------------------------------------------------------------------------------------------------------
+class _VolumeBuild(torch.autograd.Function):
+    """One level through gens_volume_build_fwd / gens_volume_build_bwd (the wave-window backward): the measurement scripts' and the cross-checks'
+    single-level form; a scene's pyramid goes through _VolumeBuildLevels."""
+
+    @staticmethod
+    def forward(ctx, feat_tex, w2c, intr, scale, d, min_vis):
+        nv, h, w, cp = feat_tex.shape
+        assert cp == 4, "volume build expects 4-channel feature levels (confs/gens.conf:60-62)"
+        vol = torch.empty(1, 8, d, d, d, device=feat_tex.device, dtype=_f32)
+        mask = torch.empty(1, 1, d, d, d, device=feat_tex.device, dtype=_f32)
+        L.call("gens_volume_build_fwd", L.ptr(aligned16(feat_tex), align=16), L.ptr(w2c), L.ptr(intr), scale, nv, h, w, d, min_vis, L.ptr(vol),
+               L.ptr(mask), L.stream(), nbytes=nv * h * w * 16 + 36 * d ** 3)
+        ctx.save_for_backward(feat_tex, w2c, intr)
+        ctx.meta = (scale, d)
+        ctx.mark_non_differentiable(mask)
+        return vol, mask
+
+    @staticmethod
+    def backward(ctx, g_vol, _g_mask):
+        feat_tex, w2c, intr = ctx.saved_tensors
+        scale, d = ctx.meta
+        return _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol), None, None, None, None, None
+
+
 def _volume_build_bwd(feat_tex, w2c, intr, scale, d, g_vol):
     """d(volume)/d(texels) of one level with the wave-window kernel (gens_volume_build_bwd): what the all-level image-tile kernel does not cover
     (volume sides that are not multiples of 16), and its cross-check (kernels.k1_bwd = "window")."""

@@ -70,8 +70,15 @@ def main():
     with torch.no_grad():
         # clocks up first: the first ~10 ms of work after idle run up to 25 % slower (scripts/probe/README.md)
         tex0 = ops.pack_nchw(feats[0])
+
+        def k1_fwd(tex, k, d, vol, mask):
+            nv_, h_, w_, _ = tex.shape
+            L.call("gens_volume_build_fwd", L.ptr(tex), L.ptr(w2c), L.ptr(k), 1.0, nv_, h_, w_, d, 1, L.ptr(vol), L.ptr(mask), L.stream(),
+                   nbytes=nv_ * h_ * w_ * 16 + 36 * d ** 3)
+
+        vol0, mask0 = torch.empty(8, dims[0], dims[0], dims[0], device=dev), torch.empty(dims[0], dims[0], dims[0], device=dev)
         for _ in range(300):
-            ops._VolumeBuild.apply(tex0, w2c, intrs, 1.0, dims[0], 1)
+            k1_fwd(tex0, intrs, dims[0], vol0, mask0)
         torch.cuda.synchronize()
         # ---- K1 per level
         for lvl, d in enumerate(dims):
@@ -79,8 +86,30 @@ def main():
             nv, h, w, _ = tex.shape
             k = intrs.clone()
             k[:, :2] = k[:, :2] * 0.5 ** lvl                     # pre-scaled intrinsics, as ops.volume_build passes them
-            per = measure(lambda: ops._VolumeBuild.apply(tex, w2c, k, 1.0, d, 1), max(20, args.iters // 4))
+            vol, mask = torch.empty(8, d, d, d, device=dev), torch.empty(d, d, d, device=dev)
+            per = measure(lambda: k1_fwd(tex, k, d, vol, mask), max(20, args.iters // 4))
             add(f"K1 volume build D={d} ({nv} views {h}x{w})", "gens_volume_build_fwd", per, nv * h * w * 16 + 36 * d ** 3)
+        # ---- K1 backward: all levels in one launch set (the training step's call), from the forward's means and counts
+        cams = ops.SceneCams.of(intrs, c2ws)
+        texs = [ops.pack_nchw(feats[l]) for l in range(len(dims))]
+        hw = [x for t in texs for x in (t.shape[1], t.shape[2])]
+        vols_f = [torch.empty(8, d, d, d, device=dev) for d in dims]
+        masks_f = [torch.empty(d, d, d, device=dev) for d in dims]
+        counts = [torch.empty(d ** 3, device=dev, dtype=torch.uint8) for d in dims]
+        ks = [cams.ks[l] for l in range(len(dims))]
+        L.call("gens_volume_build_levels", L.ptr_table(texs), L.int_table(hw), L.int_table(dims), len(dims), L.ptr(cams.w2c), L.ptr_table(ks), 5, 1,
+               L.ptr_table(vols_f), L.ptr_table(masks_f), L.ptr_table(counts, torch.uint8), L.stream())
+        gvols = [torch.randn(8, d, d, d, device=dev) for d in dims]
+        gfeat = [torch.zeros_like(t) for t in texs]
+        need = L.load().gens_volume_build_bwd_levels_scratch_bytes(L.int_table(hw), L.int_table(dims), len(dims), 5)
+        scratch = torch.empty(need, device=dev, dtype=torch.uint8)
+        a_bwd = sum(2 * t.numel() * 4 + 32 * d ** 3 for t, d in zip(texs, dims))          # texels read + their gradient written, 8 cotangent planes read
+        per = measure(lambda: L.call("gens_volume_build_bwd_levels", L.ptr_table(texs), L.int_table(hw), L.int_table(dims), len(dims), L.ptr(cams.w2c),
+                                     L.ptr_table(ks), 5, L.ptr_table(vols_f), L.ptr_table(counts, torch.uint8), L.ptr_table(gvols), L.ptr_table(gfeat),
+                                     L.ptr(scratch, torch.uint8), need, L.stream(), nbytes=a_bwd), max(20, args.iters // 4))
+        add("K1 backward, levels 256/128/64 in one launch set", "gens_volume_build_bwd_levels", per, a_bwd,
+            note="five launches (memset, plan, scan, fill, tiles); what it must read at 1.5 window visits per (voxel tile, view) pair is ~4 x the algorithmic bytes (DESIGN 4e)")
+        del vols_f, gvols, scratch
         _, masks = ops.volume_build(feats[:3], intrs, c2ws, dims)
         mset = ops.VolumeSet.masks(masks)
         vpack = ops.VolumeSet.packed(vols)

@@ -57,6 +57,9 @@ def _measure(quiet, kernels=False):
     if "--freeze-color" in sys.argv:             # probe: what the colour network's PyTorch-layer training costs (fine-tune: the feature maps are frozen too)
         surf.color_network.requires_grad_(False)
     adam = {"fused": True} if "--fused-adam" in sys.argv else {}      # (runner.py:97 builds the default, multi-tensor Adam: measured as such; the flag: one fused kernel)
+    graph = "--graph" in sys.argv               # the step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep): one launch per step
+    if graph:
+        adam["capturable"] = True
     opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4, **adam)
 
     finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
@@ -66,24 +69,38 @@ def _measure(quiet, kernels=False):
         ft_feats = [f.detach() for f in feats]
         ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4, **adam)
 
-    def ft_step():
+    def ft_body():
         out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
         loss = ft_loss(out, targets)["loss"]                                        # runner.py:304-305 with confs/gens_finetune.conf's weights
-        ft_opt.zero_grad(set_to_none=True)
         loss.backward()
         ft_opt.step()
         return loss.detach()
 
-    def step():
-        if finetune:
-            return ft_step()
+    def hot_body():
         cost, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)        # K1 with autograd to the features, once per step (gens.py:139)
         out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
         loss = train_loss(out, targets)["loss"] + 1e-6 * sum(c.mean() for c in cost)  # runner.py:161-162; the cost volumes stand in for the U-Net's use of them
-        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         return loss.detach()
+
+    def step():
+        (ft_opt if finetune else opt).zero_grad(set_to_none=True)
+        if not finetune:
+            for t in feats + vols:               # leaves that stand in for the CNNs' outputs: a fresh gradient per step, as for a non-leaf
+                t.grad = None
+        return ft_body() if finetune else hot_body()
+
+    if graph:
+        from gens_amd.graph import GraphedStep
+        for f in feats:                          # (leaves outside the optimiser: their gradients are assigned by every replay too)
+            f.grad = None
+        for v in vols:
+            v.grad = None
+        graphed = GraphedStep(ft_body if finetune else hot_body, [surf], ft_opt if finetune else opt)
+
+        def step():  # noqa: F811
+            return graphed()
 
     full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen
     if full:                                     # matching copy too) and the 3-D U-Net inside the step
@@ -118,7 +135,9 @@ def _measure(quiet, kernels=False):
     per_step.sort()
     _measure.stats = {"median_ms": round(per_step[len(per_step) // 2] * 1e3, 3), "p10_ms": round(per_step[len(per_step) // 10] * 1e3, 3),
                       "p90_ms": round(per_step[(9 * len(per_step)) // 10] * 1e3, 3), "steps": n}
-    label = "full (CNNs + hot path)" if full else "fine-tune" if finetune else "train"
+    if graph:
+        graphed.check()
+    label = ("full (CNNs + hot path)" if full else "fine-tune" if finetune else "train") + (", HIP graph replay" if graph else "")
     if not quiet:
         print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step)")
     if os.environ.get("GENS_TRAIN_OPS"):         # which torch operators make up the step's launches (torch.profiler over one step)
@@ -133,6 +152,8 @@ def _measure(quiet, kernels=False):
             print(f"{e.key[:38]:38s} {e.count:6d} {e.device_time_total / 1e3:8.3f}  {str(e.input_shapes)[:110]}")
     if kernels:
         from gens_amd import lib as L
+        if graph:                                # (a replay launches nothing through the C ABI's host side)
+            return dt * 1e3, label, {}
         L.profile_begin()
         step()
         return dt * 1e3, label, L.profile_end()
