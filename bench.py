@@ -360,7 +360,9 @@ def main():
             train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
                                  "points, the reference's Loss (gens_amd.losses.Loss, shipped weights) + backward + Adam (torch.optim.Adam as "
                                  "runner.py:97 builds it); 30 timed steps after 5 warm-up each, the loss read back every step as runner.py does",
-                     "note": "secondary figures; not the headline"}
+                     "note": ("secondary figures; not the headline.  The eager keys enqueue ~140 launches per step from Python, about as long as the GPU needs "
+                              "to run them (see ms_per_step_stats: on a busy or cold host the median leaves p10); the *_graph keys replay the same step from a "
+                              "HIP graph and do not depend on the host's pace")}
             for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
                                ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"])):
                 try:
