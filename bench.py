@@ -364,7 +364,8 @@ def main():
                               "to run them (see ms_per_step_stats: on a busy or cold host the median leaves p10); the *_graph keys replay the same step from a "
                               "HIP graph and do not depend on the host's pace")}
             for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
-                               ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"])):
+                               ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"]),
+                               ("finetune_fused_adam", ["--finetune", "--fused-adam"])):
                 try:
                     ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
                 except Exception as e:                                 # (a secondary of the secondaries: report, do not lose the others)
@@ -382,6 +383,8 @@ def main():
             train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "
                                                   "volume_dims 256/128/64/32/16 as parameters, 512 rays + 2048 pseudo points")
             train["ms_per_step"] = train["full"]["ms_per_step"]
+            if "error" not in train["finetune_fused_adam"]:
+                train["finetune_fused_adam"]["note"] = "the fine-tune step with torch.optim.Adam(fused=True): one pass over the 307 MB of volumes instead of ten (INTEGRATION.md)"
             for key in ("hot_path_graph", "finetune_graph"):
                 if "error" not in train[key]:
                     train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; Adam with capturable=True): "
