@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 DIMS5 = [256, 128, 64, 32, 16]
 
 
-def _surface(seed=0, perturb_weights=0.02):
+def _surface(seed=0, perturb_weights=0.02, dims=DIMS5):
     from gens_amd.config import gens_model_conf
     from gens_amd.models.modules.implicit_surface import ImplicitSurface
     torch.manual_seed(seed)
-    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(DIMS5))["implicit_surface"])
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"])
     with torch.no_grad():                                  # off the geometric initialisation, so that the volume features matter
         for p in surf.sdf_network.parameters():
             p.add_(perturb_weights * torch.randn_like(p))
@@ -28,7 +28,7 @@ def _surface(seed=0, perturb_weights=0.02):
     return surf
 
 
-def _scene(nv, h, w, seed):
+def _scene(nv, h, w, seed, dims=DIMS5):
     from gens_amd import ops, synthetic
     sc = synthetic.make_scene(nv=nv, h=h, w=w, n_levels=5, seed=seed)
     dev = torch.device("cuda")
@@ -36,19 +36,21 @@ def _scene(nv, h, w, seed):
     d["features"] = [f.to(dev) for f in sc["features"]]
     d["cpu"] = sc
     with torch.no_grad():
-        _, d["masks"] = ops.volume_build(d["features"], d["intrs"], d["c2ws"], DIMS5)
-    d["vols_cpu"] = synthetic.make_volumes(DIMS5, seed=seed + 1)
+        _, d["masks"] = ops.volume_build(d["features"][:len(dims)], d["intrs"], d["c2ws"], dims)
+    d["vols_cpu"] = synthetic.make_volumes(dims, seed=seed + 1)
     d["vols"] = [v.to(dev) for v in d["vols_cpu"]]
     return d
 
 
-def test_validate_three_views_five_levels_480x640():
-    """BASELINE config[3] shape on one GPU: the full 307 200-ray image, two source views, five levels."""
+@pytest.mark.parametrize("nv,dims", [(3, DIMS5), (5, [256, 128, 64])])
+def test_validate_full_image_480x640(nv, dims):
+    """The full 307 200-ray image of `validate` against the oracle on a ray sample: BASELINE config[3]'s shape on one GPU (two source views, five
+    levels) and config[1] -- the headline workload of bench.py (four source views, volume_dims 256 / 128 / 64)."""
     from gens_amd import synthetic
     from gens_amd.models.modules.implicit_surface import Scene, reference_jitter
     from oracle import render_oracle as R
-    sc = _scene(3, 480, 640, seed=30)
-    surf = _surface(1).cuda().eval()
+    sc = _scene(nv, 480, 640, seed=30, dims=dims)
+    surf = _surface(1, dims=dims).cuda().eval()
     ro, rd = synthetic.make_rays(sc["cpu"]["intrs"], sc["cpu"]["c2ws"], 480, 640)
     n_rays = ro.shape[0]
     hw = torch.tensor([480, 640]).int()
