@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's models/modules/projector.py for the functions on the hot path
 (lookup_volume :217-245, lookup_feature :294-349, surface_patch_warp :353-419, patch_homography :422-437).
 
-Same names, argument meaning and return shapes; the arithmetic runs in libgens_hip.so (see gens_amd/ops.py).
+Same names, argument meaning and return shapes; the arithmetic runs in libgens_hip.so (see gens_amd/ops/).
 There is no CPU path: tensors must live on the MI355X.
 """
 import torch
