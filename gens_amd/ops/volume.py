@@ -91,7 +91,7 @@ class _VolumeBuildLevels(torch.autograd.Function):
             scratch = torch.empty(need, device=w2c.device, dtype=torch.uint8)
             L.call("gens_volume_build_bwd_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(ctx.dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv,
                    L.ptr_table(list(vols)), L.ptr_table(list(counts), torch.uint8), L.ptr_table(g_vols), L.ptr_table(out), L.ptr(scratch, torch.uint8), need,
-                   L.stream(), nbytes=sum(2 * nv * t.shape[1] * t.shape[2] * 16 + 49 * d ** 3 for t, d, o in zip(texs, ctx.dims, on) if o),
+                   L.stream(), nbytes=sum(2 * nv * t.shape[1] * t.shape[2] * 16 + 32 * d ** 3 for t, d, o in zip(texs, ctx.dims, on) if o),      # texels read + their gradient written, 8 cotangent planes read (the means and counts it also reads are the design's, not the algorithm's)
                    label="gens_volume_build_bwd")
             return (None, None, None, *out, *([None] * n))
         out = []
