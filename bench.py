@@ -369,7 +369,7 @@ def main():
                               "to run them (see ms_per_step_stats: on a busy or cold host the median leaves p10); the *_graph keys replay the same step from a "
                               "HIP graph and do not depend on the host's pace")}
             for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
-                               ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"]),
+                               ("hot_path_graph", ["--graph", "--fused-adam"]), ("finetune_graph", ["--finetune", "--graph", "--fused-adam"]),
                                ("finetune_fused_adam", ["--finetune", "--fused-adam"])):
                 try:
                     ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
@@ -392,8 +392,9 @@ def main():
                 train["finetune_fused_adam"]["note"] = "the fine-tune step with torch.optim.Adam(fused=True): one pass over the 307 MB of volumes instead of ten (INTEGRATION.md)"
             for key in ("hot_path_graph", "finetune_graph"):
                 if "error" not in train[key]:
-                    train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; Adam with capturable=True): "
-                                          "one launch per step, independent of the host's pace")
+                    train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; torch.optim.Adam(fused=True, "
+                                          "capturable=True): one pass over the parameters): one launch per step, independent of the host's pace.  The eager "
+                                          "fine-tune step is host-bound -- the fused optimiser alone changes nothing there (finetune_fused_adam)")
         except Exception as e:                                             # never let a secondary figure take the headline down
             train = {"error": f"{type(e).__name__}: {e}"}
         # secondary figure: one whole `--mode val` item (volume build, 512^3 SDF lattice, marching cubes on the device, 480x640 render)
