@@ -101,6 +101,8 @@ SIGNATURES = {
     "gens_sdf_value_groups": [_i],
     "gens_sdf_grad": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p],
     "gens_sdf_grad_groups": [_i],
+    "gens_sdf_grad_f16": [_pp, _ip, _i, _p, _p, _f, _f, _f, _p, _p, _l, _p, _p, _p, _p, _p, _p],
+    "gens_sdf_grad_f16_pieces": [_i],
     "gens_sdf_value_f16": [_pp, _ip, _i, _p, _p, _f, _f, _p, _p, _l, _p, _p, _p, _p],
     "gens_sdf_value_f16_units": [_i],
     "gens_lncc_fwd": [_p, _p, _l, _i, _i, _i, _p, _p, _p],
@@ -160,6 +162,8 @@ def load():
     lib.gens_sdf_train_stash_bytes.restype = _l
     lib.gens_sdf_grad_stash_bytes.restype = _l
     lib.gens_sdf_grad_stash_bytes.argtypes = []
+    lib.gens_sdf_grad_f16_stash_bytes.restype = _l
+    lib.gens_sdf_grad_f16_stash_bytes.argtypes = []
     lib.gens_sdf_train_stash_bytes.argtypes = [_l, _i]
     lib.gens_blend_train_rows.restype = _l
     lib.gens_blend_train_rows.argtypes = [_l, _i]

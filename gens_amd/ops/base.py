@@ -22,12 +22,14 @@ class KernelChoice:
         sdf_value / sdf_grad   "transposed" (k6t / k6g: register-chained, the default) | "rowmajor" (k6_sdfmlp.hip: cross-check, other shapes)
         blend                  "transposed" (k7t, two to four source views) | "rowmajor" (k7_blend.hip)
         blend_train_fwd        "transposed" (the training step's forward through k7t + gens_blend_pack_t) | "rowmajor" (k18's own forward)
+        sdf_grad_f16           True: under sdf_precision "f16x2" the value + gradient pass runs on the split-half kernel too (k6gh) | False: float32
         k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
         tex_cache              texel copies kept on the map tensors (pack_maps)"""
 
     def __init__(self, env=os.environ):
         self.sdf_value = "rowmajor" if env.get("GENS_SDF_VALUE_ROWMAJOR") else "transposed"
         self.sdf_grad = "rowmajor" if env.get("GENS_SDF_GRAD_ROWMAJOR") else "transposed"
+        self.sdf_grad_f16 = not env.get("GENS_SDF_GRAD_F32_ONLY")
         self.blend = "rowmajor" if env.get("GENS_BLEND_ROWMAJOR") else "transposed"
         self.blend_train_fwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_ROWMAJOR") else "transposed"
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
@@ -51,6 +53,18 @@ def sdf_grad_stash(device):
     buf = _SDF_GRAD_STASH.get(key)
     if buf is None:
         buf = _SDF_GRAD_STASH[key] = torch.zeros(L.load().gens_sdf_grad_stash_bytes(), device=torch.device("cuda", key), dtype=torch.uint8)
+    return buf
+
+
+_SDF_GRAD_F16_STASH = {}
+
+
+def sdf_grad_f16_stash(device):
+    """gens_sdf_grad_f16's (CU, wave)-private slots (softplus' of one layer and the trilinear Jacobians): one zeroed buffer per device."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _SDF_GRAD_F16_STASH.get(key)
+    if buf is None:
+        buf = _SDF_GRAD_F16_STASH[key] = torch.zeros(L.load().gens_sdf_grad_f16_stash_bytes(), device=torch.device("cuda", key), dtype=torch.uint8)
     return buf
 
 

@@ -271,6 +271,93 @@ def _pack_grad_stream(ws, bs, n_levels):
     return stream, w_out
 
 
+def _pack_grad_pieces(ws, bs, n_levels):
+    """The piece stream of gens_sdf_grad_f16 (k6gh_sdf_grad_f16.hip): 1 KB pieces = the A operand (hi or lo halfs) of one 32-row output
+    tile and one 16-deep K block, lane (m, kh) holding row m's weights for the eight reduction slots of lane half kh (_value_slots).
+    Forward: layer 0's two point-encoding K blocks, then per layer the conditioning K blocks, (layer 3: the point-encoding blocks,) the
+    eight hidden blocks -- the scaling of _pack_value_units, 4 tiles x {hi, lo} per block.  Reverse, on the TRUE transposed matrices,
+    layer 5 down to 1: per K block of G_l (layer 2: seven) the four hidden tiles, the conditioning tiles and at layer 3 the
+    point-encoding tile, rows ordered as in _pack_grad_stream; then the eight blocks of G_0 for the point-encoding tile.  Padded with
+    zeros to whole chunks of eight pieces.  -> (pieces (N, 64, 8) float16, largest magnitude handed to half precision)."""
+    dev = ws[0].device
+    c = 100.0 / math.log(2.0)
+    r2 = 1.0 / math.sqrt(2.0)
+    hid, pe, cond = (t.to(dev) for t in _value_slots(n_levels))
+    nch = 2 * n_levels
+    tc = (5 * nch + 15) // 16
+    zero = torch.zeros(128, 1, device=dev, dtype=_f32)
+
+    def blocks(mat, table):
+        """mat (32 NT, K + 2): column K = what the constant-one slot multiplies, column K + 1 zeros; table (B, 2, 8) of column numbers
+        (-1 the one, -2 nothing) -> (B, NT, 64, 8): block, tile, lane = 32 half + m, slot."""
+        nt, k = mat.shape[0] // 32, mat.shape[1] - 2
+        cols = torch.where(table >= 0, table, torch.where(table == -1, torch.full_like(table, k), torch.full_like(table, k + 1)))
+        g = mat[:, cols.reshape(-1)].reshape(nt, 32, *table.shape)                # [tile][m][block][half][slot]
+        return g.permute(2, 0, 3, 1, 4).reshape(table.shape[0], nt, 64, 8)
+
+    out = []
+    for l in range(6):
+        w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+        w[:ws[l].shape[0]] = ws[l]
+        b = torch.zeros(128, 1, device=dev, dtype=_f32)
+        b[:bs[l].shape[0], 0] = bs[l]
+        if l == 0:
+            out.append(blocks(torch.cat([c * w, c * b, zero], 1), pe).reshape(-1, 64, 8))
+            continue
+        h = w[:, :128].clone()
+        if l == 3:                                                               # x = cat([h[:101], pe]) / sqrt(2)   (sdf_network.py:111-112)
+            h = r2 * h
+            h[:, 101:] = 0.0
+        out.append(blocks(torch.cat([c * w[:, 128:], c * b, zero], 1), cond).reshape(-1, 64, 8))
+        if l == 3:                                                               # (the one slot of the point encoding carries nothing here)
+            out.append(blocks(torch.cat([c * r2 * w[:, 101:128], zero, zero], 1), torch.where(pe == -1, torch.full_like(pe, -2), pe)).reshape(-1, 64, 8))
+        out.append(blocks(torch.cat([h, zero, zero], 1), hid).reshape(-1, 64, 8))
+    fwd = torch.cat(out, 0)                                                       # (units x 4 tiles, 64, 8)
+    # accumulator row m of a tile <-> (lane half, register): m = 8 (r >> 2) + 4 half + (r & 3)
+    m = torch.arange(32, device=dev)
+    row_half, row_reg = (m >> 2) & 1, ((m >> 3) << 2) | (m & 3)
+    cond_flat = cond.permute(1, 0, 2).reshape(2, -1)                              # [half][slot] -> feature column, -1 one, -2 nothing
+    pe_flat = pe.permute(1, 0, 2).reshape(2, -1)
+
+    def slot_rows(src, flat, n_tiles):
+        """(32 n_tiles, 128): row 32 c + m = src[:, column of slot 16 c + reg(m) of half(m)] (zero where the slot carries no column)."""
+        mat = torch.zeros(32 * n_tiles, 128, device=dev, dtype=_f32)
+        for cc in range(n_tiles):
+            slot = 16 * cc + row_reg
+            col = torch.where(slot < flat.shape[1], flat[row_half, slot.clamp(max=flat.shape[1] - 1)], torch.full_like(slot, -2))
+            live = col >= 0
+            mat[32 * cc + m[live]] = src[:, col[live]].t()
+        return mat
+
+    rev = []
+    zz = torch.zeros(1, 2, device=dev, dtype=_f32)
+    for l in range(5, 0, -1):
+        w = torch.zeros(128, ws[l].shape[1], device=dev, dtype=_f32)
+        w[:ws[l].shape[0]] = ws[l]
+        wt = w[:, :128].t().clone()                                               # rows: hidden inputs, columns: units of layer l
+        if l == 3:
+            wt = r2 * wt
+            wt[101:] = 0.0
+        rows = [wt, slot_rows(w[:, 128:], cond_flat, tc)]
+        if l == 3:
+            rows.append(slot_rows(r2 * w[:, 101:128], pe_flat, 1))
+        mat = torch.cat(rows, 0)
+        mat = torch.cat([mat, zz.expand(mat.shape[0], 2)], 1)
+        rev.append(blocks(mat, hid if l != 2 else hid[:7]).reshape(-1, 64, 8))  # [block][tile]
+    w0 = torch.zeros(128, 27, device=dev, dtype=_f32)
+    w0[:ws[0].shape[0]] = ws[0]
+    mat = slot_rows(w0, pe_flat, 1)
+    rev.append(blocks(torch.cat([mat, zz.expand(32, 2)], 1), hid).reshape(-1, 64, 8))
+    tiles = torch.cat([fwd] + rev, 0)                                             # one row per (block, tile)
+    hi = tiles.half()
+    lo = (tiles - hi.float()).half()
+    pieces = torch.stack([hi, lo], 1).reshape(-1, 64, 8)                          # [block][tile][hi, lo]
+    pad = (-pieces.shape[0]) % 8
+    if pad:
+        pieces = torch.cat([pieces, torch.zeros(pad, 64, 8, device=dev, dtype=torch.float16)], 0)
+    return pieces.contiguous(), float(tiles.abs().max())
+
+
 class SdfMlpPlan:
     """Weights of an SDFNetwork re-packed for gens_sdf_mlp.  Only the shipped architecture is supported
     (`supported(net)`); anything else keeps using the PyTorch layers on top of the K2 look-up kernels."""
@@ -321,6 +408,16 @@ class SdfMlpPlan:
             assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(self.n_levels) + 2
             self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
             self.value_ok = vmax < 6.0e4
+            self.grad_pieces = None                        # the split-half value + gradient kernel: three volume levels (confs/gens.conf)
+            n_pieces = L.load().gens_sdf_grad_f16_pieces(self.n_levels)
+            if n_pieces:
+                self.grad_pieces, gvmax = _pack_grad_pieces(ws, bs, self.n_levels)
+                assert self.grad_pieces.shape[0] == n_pieces
+                top = float(ws[6][0, :128].abs().max())
+                # gradients travel times a power of two that puts |w_last| near 256: lo parts of normal halfs, 128 x of head room
+                self.grad_scale = 2.0 ** min(14, max(-10, round(math.log2(256.0 / top)))) if top > 0 and math.isfinite(top) else 1.0
+                if not gvmax < 6.0e4:
+                    self.grad_pieces = None
             self.overflow = torch.zeros(1, device=dev, dtype=torch.int32)
         self.wf_table, self.wb_table, self.bias_table = L.ptr_table(self.wf), L.ptr_table(self.wb), L.ptr_table(self.bias)
         self.key = SdfMlpPlan.version(net)
@@ -336,7 +433,8 @@ class SdfMlpPlan:
 def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_out=None, precision="f32", count=None):
     """sdf (and d sdf/dx) of pts[index] written to sdf_out[index] / grad_out[index] (fresh, densely indexed outputs if
     no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference).
-    precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed()).
+    precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed()) -- value-only
+    launches on gens_sdf_value_f16, value + gradient launches on gens_sdf_grad_f16 (three volume levels; float32 otherwise).
     count: optional (1,) int32 device tensor from compact_valid(): only the first `count` entries of `index` are evaluated."""
     assert isinstance(volumes, VolumeSet) and volumes.layout == L.LAYOUT_PACKED and volumes.n == plan.n_levels
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
@@ -356,8 +454,13 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(grad_out) if want_grad else None, L.stream(), nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n),
                label="gens_sdf_mlp" + tag)
         return (sdf_out, grad_out) if want_grad else sdf_out
-    if want_grad and kernels.sdf_grad == "transposed":
-        # (also under "f16x2": the value + gradient pass stays float32 -- the split-half arithmetic covers the value-only passes)
+    if want_grad and precision == "f16x2" and kernels.sdf_grad_f16 and getattr(plan, "grad_pieces", None) is not None:
+        L.call("gens_sdf_grad_f16", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_pieces, torch.float16), L.ptr(plan.grad_row), plan.b_last,
+               plan.scale, plan.grad_scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out),
+               L.ptr(sdf_grad_f16_stash(pts.device), torch.uint8), L.ptr(plan.overflow, torch.int32), L.stream(),
+               nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad_f16")
+    elif want_grad and kernels.sdf_grad == "transposed":
+        # (under "f16x2" without the split-half gradient kernel -- five levels, weights out of the half range -- this pass stays float32)
         L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out),
                L.ptr(sdf_grad_stash(pts.device), torch.uint8), L.stream(),

@@ -303,6 +303,24 @@ int gens_sdf_value_f16(const float* const* vols_packed, const int* dims, int n_l
 /* number of 8 KB K blocks in the weight stream of gens_sdf_value_f16 (64 for 3 levels, 80 for 5; 0 = unsupported level count) */
 int gens_sdf_value_f16_units(int n_levels);
 
+/* Value AND gradient with SPLIT operands on the f16 matrix cores (k6gh_sdf_grad_f16.hip): gens_sdf_grad's dataflow and outputs,
+ * gens_sdf_value_f16's arithmetic contract (hi*hi + hi*lo + lo*hi, float32 accumulation, softplus' kept in float32) -- the value +
+ * gradient pass of render_core (implicit_surface.py:179-191 -> sdf_network.py:98-154) under the opt-in "f16x2" arithmetic.  Three
+ * volume levels (confs/gens.conf); GENS_ELIMIT otherwise: the caller uses gens_sdf_grad.
+ *   pieces: DEVICE, 16-byte aligned, gens_sdf_grad_f16_pieces(n_levels) x 1024 bytes in the order of gens_amd.ops._pack_grad_pieces:
+ *   [64 lanes][8 halfs] per (K block, output tile, hi | lo).
+ *   w_out: the output row of gens_sdf_grad (same layout).   g_scale: a power of two the gradients travel multiplied by (lo parts stay
+ *   normal halfs); the result is divided by it.
+ *   stash: DEVICE, 16-byte aligned, gens_sdf_grad_f16_stash_bytes() bytes, ZEROED ONCE by the caller and then left alone.
+ *   overflow_flag: DEVICE int, OR-ed with 1 when an input, a hidden unit or a gradient leaves the half range or is not a number: the
+ *   caller redoes the batch with gens_sdf_grad. */
+int gens_sdf_grad_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* pieces, const float* w_out,
+                      float b_last, float scale, float g_scale, const float* pts, const int64_t* index, int64_t n,
+                      const int32_t* n_device, float* sdf_out, float* grad_out, void* stash, int* overflow_flag, void* stream);
+int64_t gens_sdf_grad_f16_stash_bytes(void);
+/* number of 1 KB pieces in the weight stream of gens_sdf_grad_f16, padding included (0 = unsupported level count) */
+int gens_sdf_grad_f16_pieces(int n_levels);
+
 /* ------------------------------------------------------------------------------------------------------------
  * K17  the SDF network of a training / fine-tune step: value, gradient, `smooth` vector and the loss backward
  *      (sdf_network.py:98-154: SDFNetwork.sdf, SDFNetwork.gradient with create_graph twice; their autograd backward under
