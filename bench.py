@@ -324,8 +324,9 @@ def main():
                  "colour_L1_vs_f32": float(diff[:, 0:3].mean()), "depth_L1_vs_f32": float(diff[:, 7].mean()),
                  "depth_max_abs_vs_f32": float(diff[:, 7].max()),
                  "rays_with_depth_moved_by_more_than_1e-4": int((diff[:, 7] > 1e-4).sum()), "rays": int(diff.shape[0]),
-                 "note": "opt-in: the value-only passes of the SDF network (hierarchical sampling) in split-half f16 arithmetic "
-                         "(gens_sdf_value_f16); the value + gradient pass stays float32; not the headline"}
+                 "note": "opt-in: every pass of the SDF network in split-half f16 arithmetic -- the value-only passes of the hierarchical "
+                         "sampling on gens_sdf_value_f16, render_core's value + gradient pass on gens_sdf_grad_f16 (operands as f16 hi + lo "
+                         "pairs, three f16 MFMAs per product, float32 accumulation, softplus' in float32); not the headline"}
 
     cpu = None
     if world == 1 and args.cpu_rays > 0:

@@ -182,10 +182,14 @@ class ImplicitSurface(nn.Module):
         return self._blend_plan if self._blend_plan.n_feat == 3 + 4 * len(views.feat_tex) else None
 
     def _precision(self, plan, want_grad=False):
-        """The arithmetic of one SDF launch.  The split-half VALUE kernel pre-scales its weight stream by 100 / ln 2, so it has its own range
-        condition (plan.value_ok: |w|, |b| below ~416); a network that fails it is evaluated in float32, it does not raise."""
-        if self.sdf_precision != "f16x2" or want_grad:            # (the value + gradient launch is float32 under either setting)
+        """The arithmetic of one SDF launch.  The split-half kernels pre-scale their weight streams by 100 / ln 2, so they have their own
+        range condition (plan.value_ok / plan.grad_pieces: |w|, |b| below ~416); a network that fails it is evaluated in float32, it does
+        not raise.  The value + gradient launch has a split-half kernel for three volume levels (gens_sdf_grad_f16); ops.sdf_mlp falls
+        back to the float32 kernel for anything else."""
+        if self.sdf_precision != "f16x2":
             return "f32"
+        if want_grad:
+            return "f16x2" if getattr(plan, "grad_pieces", None) is not None else "f32"
         return "f16x2" if getattr(plan, "value_ok", False) else "f32"
 
     def _train_net(self, scene, lean=False):

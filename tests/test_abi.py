@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(libpath):
 def test_ctypes_table_covers_header(libpath):
     from gens_amd import lib as L
     declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks", "gens_sdf_train_stash_bytes", "gens_gemm_tn_batch_workspace", "gens_blend_train_rows",
-                                              "gens_volume_build_bwd_levels_scratch_bytes", "gens_sdf_grad_stash_bytes", "gens_scene_cams_floats", "gens_compact_points_scratch"}
+                                              "gens_volume_build_bwd_levels_scratch_bytes", "gens_sdf_grad_stash_bytes", "gens_sdf_grad_f16_stash_bytes", "gens_scene_cams_floats", "gens_compact_points_scratch"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     L.load()
 
@@ -62,6 +62,9 @@ def test_argument_errors_are_reported_without_a_gpu(libpath):
     assert rc == -1 and b"null" in lib.gens_last_error()
     rc = lib.gens_merge_samples(None, None, None, None, None, None, 4, 120, 16, None, None, None, None)
     assert rc == -2
+    # the split-half value + gradient kernel: three levels (1016 pieces of 1 KB), nothing else; one stash slot per (CU, wave)
+    assert lib.gens_sdf_grad_f16_pieces(3) == 1016 and lib.gens_sdf_grad_f16_pieces(5) == 0
+    assert lib.gens_sdf_grad_f16_stash_bytes() == 2048 * (16384 + 32 * 256 + 256)
     with pytest.raises(RuntimeError):
         L.call("gens_tv_fwd", None, None, 0, 0, 0, None, None)
 

@@ -74,10 +74,10 @@ def test_fused_matches_cpu_oracle(golden):
     assert (gr.cpu() - ref_g.detach()).abs().max() < 2e-4
 
 
-@pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 33)])
+@pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 33), (3, 1), (3, 129)])
 def test_split_half_kernel_matches_float32_kernel(n_levels, n):
-    """gens_sdf_value_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation; the value + gradient launch stays
-    float32 under "f16x2" (round 2's split-half gradient kernel was slower than the float32 transposed one and is retired)."""
+    """gens_sdf_value_f16 and gens_sdf_grad_f16: (hi, lo) half operands, three f16 MFMAs per product, float32 accumulation.  The value +
+    gradient kernel is built for three volume levels; with five the launch stays float32 under "f16x2"."""
     from gens_amd import ops, synthetic
     net, dims = _net(n_levels, seed=10 + n_levels)
     vols = ops.VolumeSet.packed([v.cuda() * 3 for v in synthetic.make_volumes(dims, seed=9)])
@@ -88,7 +88,58 @@ def test_split_half_kernel_matches_float32_kernel(n_levels, n):
     only = ops.sdf_mlp(plan, vols, pts, precision="f16x2")
     assert not plan.overflowed()
     assert (only - s32).abs().max() < 1e-5
-    assert torch.equal(s16, s32) and torch.equal(g16, g32)
+    if n_levels == 3:
+        assert plan.grad_pieces is not None
+        assert (s16 - s32).abs().max() < 1e-5                                   # measured 1.1e-6
+        assert (g16 - g32).abs().max() < 2e-5 * max(1.0, float(g32.abs().max()))  # measured 2.0e-6 at |grad| <= 1.15
+    else:
+        assert plan.grad_pieces is None and torch.equal(s16, s32) and torch.equal(g16, g32)
+
+
+def test_split_half_gradient_kernel_scatters_like_the_float32_kernel(monkeypatch):
+    """Index map + device-side count: the rows the launch does not own keep their defaults, the owned ones match the float32 kernel; and
+    kernels.sdf_grad_f16 = False keeps the value + gradient pass on the float32 kernel bit for bit."""
+    from gens_amd import ops, synthetic
+    net, dims = _net(3, seed=21)
+    vols = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims, seed=3)])
+    g = torch.Generator().manual_seed(4)
+    pts = (torch.rand(700, 3, generator=g) * 2.2 - 1.1).cuda()
+    idx = torch.randperm(700, generator=g)[:400].cuda()
+    count = torch.tensor([333], dtype=torch.int32, device="cuda")
+    plan = ops.SdfMlpPlan(net)
+    outs = {}
+    for prec in ("f32", "f16x2"):
+        sdf, grad = torch.full((700, 1), 100.0, device="cuda"), torch.full((700, 3), -7.0, device="cuda")
+        ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=sdf, grad_out=grad, precision=prec, count=count)
+        outs[prec] = (sdf, grad)
+    assert not plan.overflowed()
+    owned = torch.zeros(700, dtype=torch.bool, device="cuda")
+    owned[idx[:333]] = True
+    assert torch.equal(outs["f16x2"][0][~owned], outs["f32"][0][~owned]) and bool((outs["f16x2"][1][~owned] == -7.0).all())
+    assert (outs["f16x2"][0][owned] - outs["f32"][0][owned]).abs().max() < 1e-5
+    assert (outs["f16x2"][1][owned] - outs["f32"][1][owned]).abs().max() < 2e-5 * max(1.0, float(outs["f32"][1].abs().max()))
+    assert not torch.equal(outs["f16x2"][1][owned], outs["f32"][1][owned])       # (it IS the other kernel)
+    monkeypatch.setattr(ops.kernels, "sdf_grad_f16", False)
+    s, gr = ops.sdf_mlp(plan, vols, pts, want_grad=True, precision="f16x2")
+    s32, g32 = ops.sdf_mlp(plan, vols, pts, want_grad=True)
+    assert torch.equal(s, s32) and torch.equal(gr, g32)
+
+
+def test_split_half_gradient_kernel_many_workgroups_reuse_their_slots():
+    """More workgroups than CUs (every (CU, wave) slot of the stash is taken and released many times), a ragged tail, twice in a row on
+    the same stash: the same answer as the float32 kernel everywhere."""
+    from gens_amd import ops, synthetic
+    net, dims = _net(3, seed=5)
+    vols = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims, seed=2)])
+    n = 128 * 256 * 5 + 77
+    pts = (torch.rand(n, 3, generator=torch.Generator().manual_seed(8)) * 2.2 - 1.1).cuda()
+    plan = ops.SdfMlpPlan(net)
+    s32, g32 = ops.sdf_mlp(plan, vols, pts, want_grad=True)
+    for _ in range(2):
+        s16, g16 = ops.sdf_mlp(plan, vols, pts, want_grad=True, precision="f16x2")
+        assert (s16 - s32).abs().max() < 1e-5
+        assert (g16 - g32).abs().max() < 2e-5 * max(1.0, float(g32.abs().max()))
+    assert not plan.overflowed()
 
 
 def test_split_half_overflow_is_flagged():
@@ -98,6 +149,16 @@ def test_split_half_overflow_is_flagged():
     plan = ops.SdfMlpPlan(net)
     ops.sdf_mlp(plan, ops.VolumeSet.packed(big), torch.zeros(64, 3, device="cuda"), precision="f16x2")
     assert plan.overflowed() and not plan.overflowed()                      # reading the flag clears it
+    ops.sdf_mlp(plan, ops.VolumeSet.packed(big), torch.zeros(64, 3, device="cuda"), want_grad=True, precision="f16x2")
+    assert plan.overflowed() and not plan.overflowed()                      # the value + gradient kernel raises the same flag
+    vols = [v.cuda() for v in synthetic.make_volumes(dims, seed=9)]
+    vols[1][0, 2, 3:6, 3:6, 3:6] = float("nan")                             # not-a-number inputs: flagged, the caller re-runs in float32
+    pts = (torch.rand(4000, 3, generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
+    ops.sdf_mlp(plan, ops.VolumeSet.packed(vols), pts, want_grad=True, precision="f16x2")
+    assert plan.overflowed()
+    plan.grad_scale = 2.0 ** 30                                              # gradients pushed out of the half range: flagged
+    ops.sdf_mlp(plan, ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes(dims, seed=9)]), pts, want_grad=True, precision="f16x2")
+    assert plan.overflowed()
 
 
 @pytest.mark.parametrize("n_levels,n", [(3, 1), (3, 33), (3, 129), (3, 4097), (5, 257)])
@@ -151,7 +212,22 @@ def test_new_sdf_kernels_reject_bad_arguments():
     with pytest.raises(RuntimeError, match="stash"):
         L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
                None, L.ptr(out), L.ptr(pts), None, L.stream())
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g16 = lambda n_levels=3, pieces=L.ptr(plan.grad_pieces, torch.float16), scale=1.0, g_scale=1.0, stash=L.ptr(ops.sdf_grad_f16_stash("cuda"), torch.uint8), fl=L.ptr(flag, torch.int32): \
+        L.call("gens_sdf_grad_f16", packed.table, packed.dim_table, n_levels, pieces, L.ptr(plan.grad_row), 0.0, scale, g_scale, L.ptr(pts), None, 8, None,
+               L.ptr(out), L.ptr(pts), stash, fl, L.stream())
+    with pytest.raises(RuntimeError, match="built for 3 volume levels"):
+        g16(n_levels=2)
+    with pytest.raises(RuntimeError, match="null weight stream / flag"):
+        g16(pieces=None)
+    with pytest.raises(RuntimeError, match="null weight stream / flag"):
+        g16(fl=None)
+    with pytest.raises(RuntimeError, match="g_scale positive"):
+        g16(g_scale=0.0)
+    with pytest.raises(RuntimeError, match="stash"):
+        g16(stash=None)
     # empty launches are no-ops
+    ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), want_grad=True, precision="f16x2")
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), want_grad=True)
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"))
     ops.sdf_mlp(plan, packed, torch.zeros(0, 3, device="cuda"), precision="f16x2")
