@@ -27,8 +27,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define GH_WAVES 4
 #define GH_PIECE 1024                       // bytes of one piece: 64 lanes x 8 halfs
+#ifndef GH_CH
 #define GH_CH 8                             // pieces per chunk of the ring
 #define GH_RING 4
+#endif
 #define GH_LPW (GH_CH / GH_WAVES)           // LDS-direct loads per wave and chunk
 #define GH_W_BYTES (GH_RING * GH_CH * GH_PIECE)
 #define GH_D_BYTES (2 * 16 * 64 * 16)       // softplus' of layers 0 and 1 of one wave
@@ -48,10 +50,11 @@ struct SplitWord {
     uint32_t hi, lo;
 };
 __device__ __forceinline__ SplitWord split_pair(float a, float b) {
-    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = __builtin_fmaf((float)h[0], -1.0f, a), rb = __builtin_fmaf((float)h[1], -1.0f, b);
-    const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
-    return {__builtin_bit_cast(uint32_t, h), __builtin_bit_cast(uint32_t, l)};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float ra, rb;      // a - (float)hi in ONE instruction: the mixed-precision fma reads the half straight out of the packed word
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+    return {h, __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb))};
 }
 #define GH_PUT(BLK_, W_, A_, B_)                     \
     {                                                \
@@ -142,15 +145,17 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
     if (m0 >= n) return;
     float4* const DS = (float4*)(lds + GH_W_BYTES + wave * GH_D_BYTES);       // [layer][accumulator register / 4][lane]
 
-    // chunk c of the stream -> ring slot c % GH_RING: wave w brings pieces w, w + 4 (LDS-direct: lane i lands at the piece's base + 16 i)
+    // chunk c of the stream -> ring slot c % GH_RING: wave w brings pieces w, w + 4, .. (LDS-direct buffer loads: the piece's offset in
+    // the stream is a scalar, 16 lane the one vector offset, lane i lands at the piece's base in LDS + 16 i)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)pieces, 0, NCHUNK * GH_CH * GH_PIECE, 0x00020000);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto stage = [&](int c) {
-        const char* src = pieces + (size_t)c * (GH_CH * GH_PIECE) + lane * 16;
         char* dst = lds + (c % GH_RING) * (GH_CH * GH_PIECE);
 #pragma unroll
         for (int p = 0; p < GH_LPW; ++p) {
             const int piece = wave + GH_WAVES * p;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * GH_PIECE),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * GH_PIECE), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(dst + piece * GH_PIECE), 16, lane16,
+                                                     (uint32_t)(c * (GH_CH * GH_PIECE) + piece * GH_PIECE), 0, 0);
         }
     };
 #pragma unroll
@@ -164,8 +169,7 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
     const uint32_t slot = ((((xcc_id & 7u) << 2 | ((hw_id >> 13) & 3u)) << 4 | ((hw_id >> 8) & 15u)) << 2) | (uint32_t)wave;
     char* const stash_slot = stash_all + (size_t)slot * GH_SLOT_BYTES;
     uint32_t* const lock = (uint32_t*)(stash_slot + GH_LOCK_OFF);
-    if (lane == 0)
-        while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(32);
+    uint32_t lock_seen = lane == 0 ? atomicCAS(lock, 0u, 1u) : 0u;      // (asked for here, looked at before the first store into the slot)
     const __amdgpu_buffer_rsrc_t stash = __builtin_amdgcn_make_buffer_rsrc((void*)stash_slot, 0, GH_LOCK_OFF, 0x00020000);
     const uint32_t stash_lane = (uint32_t)lane * 16u, jl_lane = GH_JL_OFF + (uint32_t)lane * 4u;
 
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
     float s_cond = 0.0f;
     float f[NCH];        // the raw features: the chain rule at the end re-derives the encodings from them
     {
+        float jl[3 * NCH];
 #pragma unroll
         for (int j = 0; j <= MID; ++j) {     // whole levels of this half (j < MID); level MID is shared, two channels each
             const int l = j < MID ? (half ? MID + 1 + j : j) : MID;
@@ -219,11 +224,16 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
             for (int c = 0; c < (j < MID ? 4 : 2); ++c) {
                 const int ch = 4 * j + c;
                 f[ch] = tv[c];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ax[c]), stash, jl_lane + (uint32_t)(3 * ch) * 256u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ay[c]), stash, jl_lane + (uint32_t)(3 * ch + 1) * 256u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, az[c]), stash, jl_lane + (uint32_t)(3 * ch + 2) * 256u, 0, 0);
+                jl[3 * ch] = ax[c]; jl[3 * ch + 1] = ay[c]; jl[3 * ch + 2] = az[c];
             }
         }
+        if (lane == 0)
+            while (lock_seen != 0u) {
+                __builtin_amdgcn_s_sleep(32);
+                lock_seen = atomicCAS(lock, 0u, 1u);
+            }
+#pragma unroll
+        for (int k = 0; k < 3 * NCH; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, jl[k]), stash, jl_lane + (uint32_t)k * 256u, 0, 0);
         float e[8 * NC];
 #pragma unroll
         for (int k = 5 * NCH; k < 8 * NC; ++k) e[k] = (k == 5 * NCH && half == 0) ? 1.0f : 0.0f;

@@ -271,7 +271,7 @@ def _pack_grad_stream(ws, bs, n_levels):
     return stream, w_out
 
 
-def _pack_grad_pieces(ws, bs, n_levels):
+def _pack_grad_pieces(ws, bs, n_levels, n_pieces=None):
     """The piece stream of gens_sdf_grad_f16 (k6gh_sdf_grad_f16.hip): 1 KB pieces = the A operand (hi or lo halfs) of one 32-row output
     tile and one 16-deep K block, lane (m, kh) holding row m's weights for the eight reduction slots of lane half kh (_value_slots).
     Forward: layer 0's two point-encoding K blocks, then per layer the conditioning K blocks, (layer 3: the point-encoding blocks,) the
@@ -352,7 +352,7 @@ def _pack_grad_pieces(ws, bs, n_levels):
     hi = tiles.half()
     lo = (tiles - hi.float()).half()
     pieces = torch.stack([hi, lo], 1).reshape(-1, 64, 8)                          # [block][tile][hi, lo]
-    pad = (-pieces.shape[0]) % 8
+    pad = (-pieces.shape[0]) % 8 if n_pieces is None else n_pieces - pieces.shape[0]      # (whole chunks of the kernel's ring)
     if pad:
         pieces = torch.cat([pieces, torch.zeros(pad, 64, 8, device=dev, dtype=torch.float16)], 0)
     return pieces.contiguous(), float(tiles.abs().max())
@@ -411,7 +411,7 @@ class SdfMlpPlan:
             self.grad_pieces = None                        # the split-half value + gradient kernel: three volume levels (confs/gens.conf)
             n_pieces = L.load().gens_sdf_grad_f16_pieces(self.n_levels)
             if n_pieces:
-                self.grad_pieces, gvmax = _pack_grad_pieces(ws, bs, self.n_levels)
+                self.grad_pieces, gvmax = _pack_grad_pieces(ws, bs, self.n_levels, n_pieces)
                 assert self.grad_pieces.shape[0] == n_pieces
                 top = float(ws[6][0, :128].abs().max())
                 # gradients travel times a power of two that puts |w_last| near 256: lo parts of normal halfs, 128 x of head room
