@@ -31,6 +31,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define GH_CH 8                             // pieces per chunk of the ring
 #define GH_RING 4
 #endif
+#ifndef GH_GT
+#define GH_GT 2                             // output tiles per group of A operands (measured: 2 5.90 ms, 3 6.07, 4 6.09 per 3.4 M points)
+#endif
 #define GH_LPW (GH_CH / GH_WAVES)           // LDS-direct loads per wave and chunk
 #define GH_W_BYTES (GH_RING * GH_CH * GH_PIECE)
 #define GH_D_BYTES (2 * 16 * 64 * 16)       // softplus' of layers 0 and 1 of one wave
@@ -124,7 +127,6 @@ struct GradShapeH {
     }
     static constexpr int PIECES = rev(0) + 16;
     static constexpr int NCHUNK = (PIECES + GH_CH - 1) / GH_CH;
-    static constexpr int MAXA = 2 * (4 + TC + 1);          // A operands of the widest K block
 };
 
 template <int NLEV>
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
     SplitBlock H[8];               // the operand of the running product: activations, then G_l (block 2 t + (r >> 3), slot r & 7 <- tile t, register r)
     f32x16 D3[4], D4[4];           // softplus' of layers 3, 4
     f32x16 gc[TC], gp;             // d sdf / d (this lane's conditioning slots), d sdf / d (its point-encoding slots), times g_scale
-    u32x4 abuf[2][S::MAXA];        // A operands: this K block's and the next one's
+    u32x4 abuf[2][2 * GH_GT];      // A operands: this group's and the next one's
     int par = 0;                   // (compile-time after unrolling, like every index below)
     int dirty = 1;                 // stores are outstanding: the next chunk boundary waits for everything
 
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
     }
     // pieces P0_ .. P0_ + CNT_ -> A register set SET_
 #define GH_LOAD(SET_, P0_, CNT_)                                                                         \
-    _Pragma("unroll") for (int j_ = 0; j_ < (CNT_); ++j_) {                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2 * GH_GT; ++j_) if (j_ < (CNT_)) {                           \
         const int p_ = (P0_) + j_;                                                                       \
         if (p_ % GH_CH == 0) GH_BOUNDARY(p_ / GH_CH)                                                     \
         abuf[SET_][j_] = *((const u32x4*)(lds + ((p_ / GH_CH) % GH_RING) * (GH_CH * GH_PIECE) + (p_ % GH_CH) * GH_PIECE) + lane); \
@@ -283,16 +285,23 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
 #define GH_MFMA(ACC_, A_, B_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (A_)), __builtin_bit_cast(f16x8, (B_)), ACC_, 0, 0, 0)
     // accumulator of output tile T_ of a reverse K block: hidden tiles, conditioning tiles, the point-encoding tile
 #define GH_RACC(T_) (*((T_) < 4 ? &acc[(T_) < 4 ? (T_) : 0] : (T_) < 4 + TC ? &gc[(T_) < 4 + TC && (T_) >= 4 ? (T_) - 4 : 0] : &gp))
-    // CNT_ K blocks of NT_ output tiles from piece P0_ on, B operands B_[0 .. CNT_); REV_: the accumulators of a reverse block
+    // CNT_ K blocks of NT_ output tiles from piece P0_ on, B operands B_[0 .. CNT_); REV_: the accumulators of a reverse block.  The A
+    // operands arrive in groups of GH_GT tiles (hi and lo pieces), one group ahead of the MFMAs that read them: two register sets of 24
+    // instead of two whole K blocks of up to 56.  Within a group the accumulators alternate, so an MFMA never waits for the one before it.
 #define GH_SEGMENT(P0_, CNT_, NT_, B_, REV_)                                                             \
     {                                                                                                    \
-        GH_LOAD(par, (P0_), 2 * (NT_))                                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < (CNT_); ++i_) {                                          \
-            if (i_ + 1 < (CNT_)) { GH_LOAD(par ^ 1, (P0_) + 2 * (NT_) * (i_ + 1), 2 * (NT_)) }           \
+        constexpr int ng__ = ((NT_) + GH_GT - 1) / GH_GT;      /* (CNT_ and NT_ are constant expressions at every call) */ \
+        GH_LOAD(par, (P0_), 2 * ((NT_) < GH_GT ? (NT_) : GH_GT))                                         \
+        _Pragma("unroll") for (int q_ = 0; q_ < (CNT_) * ng__; ++q_) {                                   \
+            const int i_ = q_ / ng__, t0_ = (q_ % ng__) * GH_GT, nt_ = (NT_) - t0_ < GH_GT ? (NT_) - t0_ : GH_GT; \
+            if (q_ + 1 < (CNT_) * ng__) {                                                                \
+                const int i2_ = (q_ + 1) / ng__, t2_ = ((q_ + 1) % ng__) * GH_GT, n2_ = (NT_) - t2_ < GH_GT ? (NT_) - t2_ : GH_GT; \
+                GH_LOAD(par ^ 1, (P0_) + 2 * (NT_) * i2_ + 2 * t2_, 2 * n2_)                              \
+            }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            _Pragma("unroll") for (int t_ = 0; t_ < (NT_); ++t_) { if (REV_) GH_MFMA(GH_RACC(t_), abuf[par][2 * t_], (B_)[i_].h); else GH_MFMA(acc[t_ & 3], abuf[par][2 * t_], (B_)[i_].h); } \
-            _Pragma("unroll") for (int t_ = 0; t_ < (NT_); ++t_) { if (REV_) GH_MFMA(GH_RACC(t_), abuf[par][2 * t_], (B_)[i_].l); else GH_MFMA(acc[t_ & 3], abuf[par][2 * t_], (B_)[i_].l); } \
-            _Pragma("unroll") for (int t_ = 0; t_ < (NT_); ++t_) { if (REV_) GH_MFMA(GH_RACC(t_), abuf[par][2 * t_ + 1], (B_)[i_].h); else GH_MFMA(acc[t_ & 3], abuf[par][2 * t_ + 1], (B_)[i_].h); } \
+            _Pragma("unroll") for (int t_ = 0; t_ < GH_GT; ++t_) if (t_ < nt_) { if (REV_) GH_MFMA(GH_RACC(t0_ + t_), abuf[par][2 * t_], (B_)[i_].h); else GH_MFMA(acc[(t0_ + t_) & 3], abuf[par][2 * t_], (B_)[i_].h); } \
+            _Pragma("unroll") for (int t_ = 0; t_ < GH_GT; ++t_) if (t_ < nt_) { if (REV_) GH_MFMA(GH_RACC(t0_ + t_), abuf[par][2 * t_], (B_)[i_].l); else GH_MFMA(acc[(t0_ + t_) & 3], abuf[par][2 * t_], (B_)[i_].l); } \
+            _Pragma("unroll") for (int t_ = 0; t_ < GH_GT; ++t_) if (t_ < nt_) { if (REV_) GH_MFMA(GH_RACC(t0_ + t_), abuf[par][2 * t_ + 1], (B_)[i_].h); else GH_MFMA(acc[(t0_ + t_) & 3], abuf[par][2 * t_ + 1], (B_)[i_].h); } \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             par ^= 1;                                                                                    \
         }                                                                                                \
@@ -393,7 +402,13 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
                     D4[t][4 * q] = v[0]; D4[t][4 * q + 1] = v[1]; D4[t][4 * q + 2] = v[2]; D4[t][4 * q + 3] = v[3];
                 }
         }
-        GH_SEGMENT(S::rev(l), S::rev_blocks(l), S::rev_tiles(l), H, true);
+        if (l == 3) {
+            GH_SEGMENT(S::rev(3), 8, 4 + TC + 1, H, true);
+        } else if (l == 2) {
+            GH_SEGMENT(S::rev(2), 7, 4 + TC, H, true);
+        } else {
+            GH_SEGMENT(S::rev(l), 8, 4 + TC, H, true);
+        }
         // G_{l-1} = (W_l^T G_l) * softplus'(a_{l-1})
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
