@@ -528,6 +528,16 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
         pending[1].join()
     res = {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
            "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
+    if not kernels:      # the same steps in the opt-in split-half arithmetic (gens_sdf_value_f16 / gens_sdf_grad_f16 at five levels)
+        surf.sdf_precision = "f16x2"
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        res["split_half_ms_per_step"] = round((time.perf_counter() - t0) / 2 * 1e3, 2)
+        surf.sdf_precision = "f32"
     if kernels:
         from gens_amd import lib as L
         L.profile_begin()

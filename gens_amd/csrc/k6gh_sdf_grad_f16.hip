@@ -505,7 +505,9 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
-extern "C" int gens_sdf_grad_f16_pieces(int n_levels) { return n_levels == 3 ? GradShapeH<3>::NCHUNK * GH_CH : 0; }
+extern "C" int gens_sdf_grad_f16_pieces(int n_levels) {
+    return n_levels == 3 ? GradShapeH<3>::NCHUNK * GH_CH : n_levels == 5 ? GradShapeH<5>::NCHUNK * GH_CH : 0;
+}
 
 extern "C" int64_t gens_sdf_grad_f16_stash_bytes(void) { return (int64_t)GH_SLOTS * GH_SLOT_BYTES; }
 
@@ -514,7 +516,7 @@ extern "C" int gens_sdf_grad_f16(const float* const* vols_packed, const int* dim
                                  const int32_t* n_device, float* sdf_out, float* grad_out, void* stash, int* overflow_flag, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_grad_f16", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3, GENS_ELIMIT, "gens_sdf_grad_f16: built for 3 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_grad_f16: built for 3 or 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(pieces && w_out && overflow_flag, GENS_EINVAL, "gens_sdf_grad_f16: null weight stream / flag");
     GENS_CHECK_ARG(((uintptr_t)pieces & 15) == 0, GENS_EINVAL, "gens_sdf_grad_f16: the weight stream must be 16-byte aligned");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out && grad_out)), GENS_EINVAL, "gens_sdf_grad_f16: null pts / output");
@@ -524,7 +526,8 @@ extern "C" int gens_sdf_grad_f16(const float* const* vols_packed, const int* dim
     if (n == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdf_grad_h_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)sdf_grad_h_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)sdf_grad_h_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
             gens_set_error("gens_sdf_grad_f16: the device does not grant %d bytes of LDS to one workgroup", GH_LDS_BYTES);
             return GENS_ELIMIT;
@@ -532,8 +535,13 @@ extern "C" int gens_sdf_grad_f16(const float* const* vols_packed, const int* dim
         attr_set = true;
     }
     const unsigned grid = gens_blocks(n, 32 * GH_WAVES);
-    sdf_grad_h_k<3><<<grid, 64 * GH_WAVES, GH_LDS_BYTES, (hipStream_t)stream>>>(vs, (const char*)pieces, w_out, b_last, scale, 1.0f / scale, g_scale,
-                                                                               1.0f / g_scale, pts, index, n, n_device, sdf_out, grad_out,
-                                                                               (char*)stash, overflow_flag);
+    if (n_levels == 3)
+        sdf_grad_h_k<3><<<grid, 64 * GH_WAVES, GH_LDS_BYTES, (hipStream_t)stream>>>(vs, (const char*)pieces, w_out, b_last, scale, 1.0f / scale, g_scale,
+                                                                                   1.0f / g_scale, pts, index, n, n_device, sdf_out, grad_out,
+                                                                                   (char*)stash, overflow_flag);
+    else
+        sdf_grad_h_k<5><<<grid, 64 * GH_WAVES, GH_LDS_BYTES, (hipStream_t)stream>>>(vs, (const char*)pieces, w_out, b_last, scale, 1.0f / scale, g_scale,
+                                                                                   1.0f / g_scale, pts, index, n, n_device, sdf_out, grad_out,
+                                                                                   (char*)stash, overflow_flag);
     return gens_launch_status("gens_sdf_grad_f16");
 }

@@ -184,8 +184,7 @@ class ImplicitSurface(nn.Module):
     def _precision(self, plan, want_grad=False):
         """The arithmetic of one SDF launch.  The split-half kernels pre-scale their weight streams by 100 / ln 2, so they have their own
         range condition (plan.value_ok / plan.grad_pieces: |w|, |b| below ~416); a network that fails it is evaluated in float32, it does
-        not raise.  The value + gradient launch has a split-half kernel for three volume levels (gens_sdf_grad_f16); ops.sdf_mlp falls
-        back to the float32 kernel for anything else."""
+        not raise."""
         if self.sdf_precision != "f16x2":
             return "f32"
         if want_grad:

@@ -408,7 +408,7 @@ class SdfMlpPlan:
             assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(self.n_levels) + 2
             self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
             self.value_ok = vmax < 6.0e4
-            self.grad_pieces = None                        # the split-half value + gradient kernel: three volume levels (confs/gens.conf)
+            self.grad_pieces = None                        # the split-half value + gradient kernel: None if a weight leaves the half range
             n_pieces = L.load().gens_sdf_grad_f16_pieces(self.n_levels)
             if n_pieces:
                 self.grad_pieces, gvmax = _pack_grad_pieces(ws, bs, self.n_levels, n_pieces)
@@ -434,7 +434,7 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
     """sdf (and d sdf/dx) of pts[index] written to sdf_out[index] / grad_out[index] (fresh, densely indexed outputs if
     no buffers are given).  volumes: packed VolumeSet with 3 or 5 levels.  No autograd graph is built (inference).
     precision: "f32" (exact float32 MFMA) or "f16x2" (split-half operands, ~1e-6 relative; check plan.overflowed()) -- value-only
-    launches on gens_sdf_value_f16, value + gradient launches on gens_sdf_grad_f16 (three volume levels; float32 otherwise).
+    launches on gens_sdf_value_f16, value + gradient launches on gens_sdf_grad_f16 (float32 if the weights leave the half range).
     count: optional (1,) int32 device tensor from compact_valid(): only the first `count` entries of `index` are evaluated."""
     assert isinstance(volumes, VolumeSet) and volumes.layout == L.LAYOUT_PACKED and volumes.n == plan.n_levels
     pts = _c(pts.detach().reshape(-1, 3).to(_f32))
@@ -460,7 +460,7 @@ def sdf_mlp(plan, volumes, pts, index=None, want_grad=False, sdf_out=None, grad_
                L.ptr(sdf_grad_f16_stash(pts.device), torch.uint8), L.ptr(plan.overflow, torch.int32), L.stream(),
                nbytes=nbytes, flops=n * flops, live=None if count is None else (count, n), label="gens_sdf_grad_f16")
     elif want_grad and kernels.sdf_grad == "transposed":
-        # (under "f16x2" without the split-half gradient kernel -- five levels, weights out of the half range -- this pass stays float32)
+        # (under "f16x2" with weights out of the half range this pass stays float32)
         L.call("gens_sdf_grad", volumes.table, volumes.dim_table, volumes.n, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), plan.b_last,
                plan.scale, L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(sdf_out), L.ptr(grad_out),
                L.ptr(sdf_grad_stash(pts.device), torch.uint8), L.stream(),

@@ -305,8 +305,8 @@ int gens_sdf_value_f16_units(int n_levels);
 
 /* Value AND gradient with SPLIT operands on the f16 matrix cores (k6gh_sdf_grad_f16.hip): gens_sdf_grad's dataflow and outputs,
  * gens_sdf_value_f16's arithmetic contract (hi*hi + hi*lo + lo*hi, float32 accumulation, softplus' kept in float32) -- the value +
- * gradient pass of render_core (implicit_surface.py:179-191 -> sdf_network.py:98-154) under the opt-in "f16x2" arithmetic.  Three
- * volume levels (confs/gens.conf); GENS_ELIMIT otherwise: the caller uses gens_sdf_grad.
+ * gradient pass of render_core (implicit_surface.py:179-191 -> sdf_network.py:98-154) under the opt-in "f16x2" arithmetic.  Three or
+ * five volume levels (BASELINE config[1] / confs/gens.conf:63-67); GENS_ELIMIT otherwise.
  *   pieces: DEVICE, 16-byte aligned, gens_sdf_grad_f16_pieces(n_levels) x 1024 bytes in the order of gens_amd.ops._pack_grad_pieces:
  *   [64 lanes][8 halfs] per (K block, output tile, hi | lo).
  *   w_out: the output row of gens_sdf_grad (same layout).   g_scale: a power of two the gradients travel multiplied by (lo parts stay

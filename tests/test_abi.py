@@ -62,8 +62,8 @@ def test_argument_errors_are_reported_without_a_gpu(libpath):
     assert rc == -1 and b"null" in lib.gens_last_error()
     rc = lib.gens_merge_samples(None, None, None, None, None, None, 4, 120, 16, None, None, None, None)
     assert rc == -2
-    # the split-half value + gradient kernel: three levels (1016 pieces of 1 KB), nothing else; one stash slot per (CU, wave)
-    assert lib.gens_sdf_grad_f16_pieces(3) == 1016 and lib.gens_sdf_grad_f16_pieces(5) == 0
+    # the split-half value + gradient kernel: three or five levels (whole chunks of eight 1 KB pieces); one stash slot per (CU, wave)
+    assert lib.gens_sdf_grad_f16_pieces(3) == 1016 and lib.gens_sdf_grad_f16_pieces(5) == 1288 and lib.gens_sdf_grad_f16_pieces(4) == 0
     assert lib.gens_sdf_grad_f16_stash_bytes() == 2048 * (16384 + 32 * 256 + 256)
     with pytest.raises(RuntimeError):
         L.call("gens_tv_fwd", None, None, 0, 0, 0, None, None)

@@ -166,9 +166,8 @@ def _emulate(pieces, w_out, b_last, scale, g_scale, n_levels, x, f0, jac):
     return sdf[:, None], g
 
 
-@pytest.mark.parametrize("seed", [0, 1])
-def test_piece_stream_reproduces_the_network(seed):
-    n_levels = 3
+@pytest.mark.parametrize("n_levels,seed", [(3, 0), (3, 1), (5, 2)])
+def test_piece_stream_reproduces_the_network(n_levels, seed):
     ws, bs = _network(n_levels, seed)
     pieces, vmax = ops._pack_grad_pieces(ws, bs, n_levels)
     assert pieces.dtype == torch.float16 and pieces.shape[1:] == (64, 8) and pieces.shape[0] % 8 == 0 and vmax < 6.0e4
