@@ -310,6 +310,13 @@ def main():
             step()
         sync()
         dt = (time.perf_counter() - t1) / 2
+        L.profile_begin()                          # the C-ABI kernel table of one extra step in this arithmetic (HIP events per launch)
+        step()
+        sync()
+        split_rows = kernel_rows(L.profile_end(), 4)
+        for name_, row_ in split_rows.items():     # f16 products issued: three per float32 product, against the dense f16 peak
+            if name_.endswith("_f16") and "TFLOPs" in row_:
+                row_["f16_pipe_frac"] = round(3 * row_["TFLOPs"] / F16_MFMA_PEAK_TFLOPS, 4)
         # what the arithmetic costs in the image: the same rays without jitter under both settings, L1 of colour and rendered depth
         perturb, surf.perturb = surf.perturb, 0
         images = {}
@@ -323,7 +330,7 @@ def main():
         split = {"sdf_precision": "f16x2", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": dt * 1e3, "steps": 2,
                  "colour_L1_vs_f32": float(diff[:, 0:3].mean()), "depth_L1_vs_f32": float(diff[:, 7].mean()),
                  "depth_max_abs_vs_f32": float(diff[:, 7].max()),
-                 "rays_with_depth_moved_by_more_than_1e-4": int((diff[:, 7] > 1e-4).sum()), "rays": int(diff.shape[0]),
+                 "rays_with_depth_moved_by_more_than_1e-4": int((diff[:, 7] > 1e-4).sum()), "rays": int(diff.shape[0]), "hip_kernels": split_rows,
                  "note": "opt-in: every pass of the SDF network in split-half f16 arithmetic -- the value-only passes of the hierarchical "
                          "sampling on gens_sdf_value_f16, render_core's value + gradient pass on gens_sdf_grad_f16 (operands as f16 hi + lo "
                          "pairs, three f16 MFMAs per product, float32 accumulation, softplus' in float32); not the headline"}

@@ -22,7 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-#define HV_WAVES 4                    // waves per workgroup = 128 points per pass of the weight stream
+#ifndef HV_WAVES
+#define HV_WAVES 4                    // waves per workgroup = 128 points per pass of the weight stream (8 waves sharing one pass, one workgroup per CU: 2.71 against 2.61 ms per 3.4 M points -- the two workgroups of a CU run out of phase, one pass in lock step does not)
+#endif
 #define HV_UNIT 8192                  // bytes of one K block of weights: 4 tiles x 2 parts x 64 lanes x 16 B
 #define HV_CHUNK_UNITS 4
 #define HV_CHUNK (HV_UNIT * HV_CHUNK_UNITS)
@@ -83,7 +85,7 @@ struct ValueShape {
 };
 
 template <int NLEV>
-__global__ __launch_bounds__(64 * HV_WAVES, 2) void sdf_value_h_k(LevelSet vols, const char* __restrict__ units, const float* w_out,
+__global__ __launch_bounds__(64 * HV_WAVES, 8 / HV_WAVES) void sdf_value_h_k(LevelSet vols, const char* __restrict__ units, const float* w_out,
                                                                   float b_last, float scale, float inv_scale, const float* __restrict__ pts,
                                                                   const int64_t* __restrict__ index, int64_t n_max,
                                                                   const int32_t* __restrict__ n_dev, float* __restrict__ sdf_out,
@@ -187,21 +189,38 @@ __global__ __launch_bounds__(64 * HV_WAVES, 2) void sdf_value_h_k(LevelSet vols,
     HalfPair H[8];
     float hmax = 0.0f;
 
-    // products of CNT consecutive K blocks (global unit numbers U0 ..) with the B operands b[0 .. CNT)
-#define HV_GEMM(U0, CNT, B)                                                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < (CNT); ++i_) {                                                           \
-        const int u_ = (U0) + i_;                                                                                   \
-        if ((u_ & (HV_CHUNK_UNITS - 1)) == 0) {       /* chunk boundary: this chunk has landed, the other buffer is free */ \
+    // products of CNT consecutive K blocks (global unit numbers U0 ..) with the B operands b[0 .. CNT).  The A operands of a K block come
+    // out of LDS in two groups of two feature tiles (hi and lo), ONE GROUP AHEAD of the MFMAs that read them (two register sets of 16:
+    // what one K block took before) -- also across calls: with NXT the last group asks for the first group of the unit that follows in the
+    // stream, and that call says PRE.  Within a group the two accumulators alternate.
+    f16x8 abuf[2][4];
+    int par = 0;
+    // group G_ (tiles 2 G_, 2 G_ + 1) of unit U_ -> register set SET_; the first group of a chunk waits for the chunk and refills the other buffer
+#define HV_LOADG(SET_, U_, G_)                                                                                      \
+    {                                                                                                               \
+        const int u__ = (U_);                                                                                       \
+        if ((G_) == 0 && (u__ & (HV_CHUNK_UNITS - 1)) == 0) {     /* chunk boundary: this chunk has landed, the other buffer is free */ \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
             __syncthreads();                                                                                        \
-            if (u_ / HV_CHUNK_UNITS + 1 < S::NCHUNK) stage(u_ / HV_CHUNK_UNITS + 1);                                \
+            if (u__ / HV_CHUNK_UNITS + 1 < S::NCHUNK) stage(u__ / HV_CHUNK_UNITS + 1);                              \
         }                                                                                                           \
-        const f16x8* A_ = (const f16x8*)(WBUF + ((u_ / HV_CHUNK_UNITS) & 1) * HV_CHUNK + (u_ & (HV_CHUNK_UNITS - 1)) * HV_UNIT) + lane; \
-        f16x8 ah_[4], al_[4];      /* consecutive MFMAs go to DIFFERENT accumulators: each is reused after three others */ \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { ah_[t_] = A_[(2 * t_) * 64]; al_[t_] = A_[(2 * t_ + 1) * 64]; } \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[t_], (B)[i_].h, acc[t_], 0, 0, 0); \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[t_], (B)[i_].l, acc[t_], 0, 0, 0); \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[t_], (B)[i_].h, acc[t_], 0, 0, 0); \
+        const f16x8* A__ = (const f16x8*)(WBUF + ((u__ / HV_CHUNK_UNITS) & 1) * HV_CHUNK + (u__ & (HV_CHUNK_UNITS - 1)) * HV_UNIT) + lane; \
+        _Pragma("unroll") for (int j__ = 0; j__ < 4; ++j__) abuf[SET_][j__] = A__[(4 * (G_) + j__) * 64];           \
+    }
+#define HV_GEMM(U0, CNT, B, PRE, NXT)                                                                               \
+    {                                                                                                               \
+        if (!(PRE)) HV_LOADG(par, (U0), 0)                                                                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * (CNT); ++q_) {                                                  \
+            const int i_ = q_ >> 1, g_ = q_ & 1;                                                                    \
+            if (q_ + 1 < 2 * (CNT)) HV_LOADG(par ^ 1, (U0) + ((q_ + 1) >> 1), (q_ + 1) & 1)                         \
+            else if (NXT) HV_LOADG(par ^ 1, (U0) + (CNT), 0)                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) acc[2 * g_ + t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[par][2 * t_], (B)[i_].h, acc[2 * g_ + t_], 0, 0, 0); \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) acc[2 * g_ + t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[par][2 * t_], (B)[i_].l, acc[2 * g_ + t_], 0, 0, 0); \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) acc[2 * g_ + t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[par][2 * t_ + 1], (B)[i_].h, acc[2 * g_ + t_], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            par ^= 1;                                                                                               \
+        }                                                                                                           \
     }
 #define HV_ZERO()                                             \
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)          \
@@ -222,30 +241,31 @@ __global__ __launch_bounds__(64 * HV_WAVES, 2) void sdf_value_h_k(LevelSet vols,
     constexpr int U1 = 2, U2 = U1 + LW, U3 = U2 + LW, U4 = U3 + LW + 2, U5 = U4 + LW;
     static_assert(U5 + LW == S::NU, "unit count");
     HV_ZERO();
-    HV_GEMM(0, 2, P);
+    HV_GEMM(0, 2, P, 0, 1);
     HV_ACTIVATE(true);
     HV_ZERO();
-    HV_GEMM(U1, 8, H);
-    HV_GEMM(U1 + 8, NC, C);
+    HV_GEMM(U1, 8, H, 1, 1);
+    HV_GEMM(U1 + 8, NC, C, 1, 1);
     HV_ACTIVATE(true);
     HV_ZERO();
-    HV_GEMM(U2, 8, H);
-    HV_GEMM(U2 + 8, NC, C);
+    HV_GEMM(U2, 8, H, 1, 1);
+    HV_GEMM(U2 + 8, NC, C, 1, 1);
     HV_ACTIVATE(true);
     HV_ZERO();                                 // layer 3: hidden (skip rows 101.. have zero weights), point encoding, conditioning
-    HV_GEMM(U3, 8, H);
-    HV_GEMM(U3 + 8, 2, P);
-    HV_GEMM(U3 + 10, NC, C);
+    HV_GEMM(U3, 8, H, 1, 1);
+    HV_GEMM(U3 + 8, 2, P, 1, 1);
+    HV_GEMM(U3 + 10, NC, C, 1, 1);
     HV_ACTIVATE(true);
     HV_ZERO();
-    HV_GEMM(U4, 8, H);
-    HV_GEMM(U4 + 8, NC, C);
+    HV_GEMM(U4, 8, H, 1, 1);
+    HV_GEMM(U4 + 8, NC, C, 1, 1);
     HV_ACTIVATE(true);
     HV_ZERO();
-    HV_GEMM(U5, 8, H);
-    HV_GEMM(U5 + 8, NC, C);
+    HV_GEMM(U5, 8, H, 1, 1);
+    HV_GEMM(U5 + 8, NC, C, 1, 0);
     HV_ACTIVATE(false);
 #undef HV_GEMM
+#undef HV_LOADG
 #undef HV_ZERO
 #undef HV_ACTIVATE
 

@@ -15,7 +15,7 @@ import json
 import sys
 from collections import defaultdict
 
-ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_value_t_k": "gens_sdf_value", "sdf_grad_t_k": "gens_sdf_grad", "sdf_value_h_k": "gens_sdf_value_f16", "blend_k": "gens_blend_views", "blend_t_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
+ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_value_t_k": "gens_sdf_value", "sdf_grad_t_k": "gens_sdf_grad", "sdf_value_h_k": "gens_sdf_value_f16", "sdf_grad_h_k": "gens_sdf_grad_f16", "blend_k": "gens_blend_views", "blend_t_k": "gens_blend_views", "composite_fwd_k": "gens_composite_fwd",
          "upsample_k": "gens_upsample", "merge_k": "gens_merge_samples", "volume_build_fwd_k": "gens_volume_build_fwd", "volume_build_fwd_lean_k": "gens_volume_build_fwd", "volume_build_fwd_levels_k": "gens_volume_build_levels", "volume_build_fwd_pow2_k": "gens_volume_build_fwd",
          "ray_points_k": "gens_ray_points", "compact_count_k": "gens_compact_valid", "compact_write_k": "gens_compact_valid",
          "compact_scan_k": "gens_compact_valid", "compact_points_count_k": "gens_compact_valid", "compact_points_write_k": "gens_compact_valid", "mc_classify_k": "gens_mc_classify", "mc_emit_k": "gens_mc_emit",

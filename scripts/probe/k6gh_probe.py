@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--dims", type=int, nargs="+", default=[256, 128, 64])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--small", action="store_true", help="the tests' tiny volumes (16, 12, 8)")
+    ap.add_argument("--value", action="store_true", help="time the value-only kernels too (gens_sdf_value / gens_sdf_value_f16)")
     args = ap.parse_args()
     from gens_amd import ops, synthetic
     from gens_amd.config import gens_model_conf
@@ -50,6 +51,20 @@ def main():
         torch.cuda.synchronize()
         ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps))
         print("%-6s %.3f ms per launch of %d points (median of %d; min %.3f)" % (prec, ms[len(ms) // 2], args.n, args.reps, ms[0]))
+    if args.value:
+        v32 = ops.sdf_mlp(plan, vols, pts)
+        v16 = ops.sdf_mlp(plan, vols, pts, precision="f16x2")
+        print("value-only: max abs err %.3e, overflowed %s" % ((v16 - v32).abs().max(), plan.overflowed()))
+        for prec in ("f32", "f16x2"):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.reps + 1)]
+            ops.sdf_mlp(plan, vols, pts, precision=prec)
+            ev[0].record()
+            for i in range(args.reps):
+                ops.sdf_mlp(plan, vols, pts, precision=prec)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps))
+            print("value %-6s %.3f ms per launch of %d points (median of %d; min %.3f)" % (prec, ms[len(ms) // 2], args.n, args.reps, ms[0]))
 
 
 if __name__ == "__main__":
