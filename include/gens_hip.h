@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 6 */
+int gens_abi_version(void);   /* 7 (6 + gens_sdf_grad_f16: the split-half value + gradient kernel) */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).

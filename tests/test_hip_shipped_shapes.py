@@ -87,6 +87,19 @@ def test_validate_full_image_480x640(nv, dims):
     assert (got[:, 6] - ref["sdf_depth"].reshape(-1)).abs().mean() < 1e-4
     normal = (ref["gradients"] * ref["weights"][..., None] * ref["inside_sphere"][..., None]).sum(1)
     assert (got[:, 3:6] - normal).abs().mean() < 1e-4
+    # the opt-in split-half arithmetic (gens_sdf_value_f16 + gens_sdf_grad_f16 at three and at five levels): the same image, same jitter,
+    # within a tenth of the north-star bound of the float32 image over ALL rays, and within the bound of the oracle on the sample
+    surf.sdf_precision = "f16x2"
+    try:
+        _, half_image = image(32768)
+    finally:
+        surf.sdf_precision = "f32"
+    assert surf._sdf_plan.grad_pieces is not None and not torch.equal(half_image, dev_image)
+    assert (half_image[:, 0:3] - dev_image[:, 0:3]).abs().mean() < 1e-5        # measured 3.4e-6
+    assert (half_image[:, 7] - dev_image[:, 7]).abs().mean() < 1e-5            # measured 6.4e-7
+    assert (half_image[:, 3:6] - dev_image[:, 3:6]).abs().mean() < 1e-5
+    got_h = half_image[pick.cuda()].cpu()
+    assert (got_h[:, 0:3] - ref["color_fine"]).abs().mean() < 1e-4 and (got_h[:, 7] - ref["render_depth"].reshape(-1)).abs().mean() < 1e-4
 
 
 def _finetune_loss(out):
