@@ -412,6 +412,9 @@ def main():
             from scripts.val_full_bench import measure as val_measure
             val_item = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in val_measure(repeats=2).items()}
             val_item["workload"] = "BASELINE config[1] as runner.py --mode val runs it: K1 + 512^3 lattice + iso-surface + 307 200-ray render"
+            half = val_measure(repeats=2, sdf_precision="f16x2")      # the same item in the opt-in split-half arithmetic
+            val_item["split_half"] = {k: round(half[k], 2) if isinstance(half[k], float) else half[k]
+                                      for k in ("lattice_ms", "render_ms", "total_ms", "vertices", "triangles")}
         except Exception as e:
             val_item = {"error": f"{type(e).__name__}: {e}"}
 

@@ -13,8 +13,9 @@ from gens_amd.config import gens_model_conf  # noqa: E402
 from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene  # noqa: E402
 
 
-def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True):
-    """-> dict of milliseconds (last of `repeats` items): volume_build, lattice, marching_cubes, render, total; mesh sizes."""
+def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True, sdf_precision="f32"):
+    """-> dict of milliseconds (last of `repeats` items): volume_build, lattice, marching_cubes, render, total; mesh sizes.
+    sdf_precision: "f32" or the opt-in "f16x2" (the lattice on gens_sdf_value_f16, the render's SDF passes on the split-half kernels)."""
     dev = torch.device("cuda:0")
     dims = list(dims)
     sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
@@ -27,6 +28,7 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True):
     torch.manual_seed(0)
     surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
     surf.val_chunk = 32768
+    surf.sdf_precision = sdf_precision
     bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
 
     def T():
@@ -61,3 +63,4 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True):
 
 if __name__ == "__main__":
     measure(quiet=False)
+    measure(quiet=False, sdf_precision="f16x2")
