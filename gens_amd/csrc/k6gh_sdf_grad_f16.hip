@@ -11,7 +11,8 @@
 //   * the f16 pipe runs 16 x the float32 rate, three products per operand pair: 5.3 x less matrix time than K6g -- and five times the
 //     weight bytes per unit time.  The weight stream (1 KB "pieces": the A operand of one output tile and one 16-deep K block, hi or
 //     lo) therefore goes global -> LDS ONCE per workgroup of four waves (128 points), by LDS-direct loads into a ring of four 8 KB
-//     chunks filled three chunks ahead, and each wave reads its A operands from there one K block ahead of its MFMAs.
+//     chunks filled three chunks ahead, and each wave reads its A operands from there in groups of two output tiles, one group ahead of the six
+//     MFMAs that use them (also across layers: the stream is consumed strictly in order).
 //   * softplus' of the six layers (float32: the gradient's precision is theirs): layer 5 is consumed on the spot, layers 3 and 4 stay
 //     in registers, layers 0 and 1 wait in LDS (32 KB per wave: with the ring exactly the CU's 160 KB, so ONE workgroup per CU, one
 //     wave per SIMD, 512 registers), layer 2 and the trilinear Jacobians in a slot of global memory that belongs to the wave's
