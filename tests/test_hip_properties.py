@@ -605,3 +605,49 @@ def test_value_and_gradient_kernels_return_the_same_value_at_full_chunk_size():
     an = (grad[::4099] * d).sum(-1)
     err = (fd - an).abs()
     assert err.median() < 5e-3 and (err < 0.05 * (1 + an.abs())).float().mean() > 0.97     # (kinks of the trilinear volumes and of softplus-100 excepted)
+
+
+def test_split_half_kernels_at_full_chunk_size_agree_with_float32_and_with_each_other():
+    """K6v (gens_sdf_value_f16) and K6gh (gens_sdf_grad_f16) at the size of one bench.py ray chunk (32 768 rays x 128 samples, volumes
+    256 / 128 / 64): both stay within 1e-5 of the float32 value everywhere (their forward chains differ in the order of a layer's K
+    blocks, so they are not bit-identical to each other), the split-half gradient within 1e-4 (1 + |grad|) of the float32 one, the
+    directional finite difference of the split-half VALUE agrees with the split-half GRADIENT like the float32 pair does, the overflow
+    flag stays clear, and the rows beyond the device-side count are not written."""
+    from gens_amd import ops, synthetic
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface
+    dims = [256, 128, 64]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
+    vols = ops.VolumeSet.packed([v.to(dev) for v in synthetic.make_volumes(dims, seed=3)])
+    n = 32768 * 128
+    pts = torch.rand(n, 3, device=dev) * 2.2 - 1.1
+    plan = ops.SdfMlpPlan(surf.sdf_network)
+    assert plan.value_ok and plan.grad_pieces is not None
+    sdf32, grad32 = ops.sdf_mlp(plan, vols, pts, want_grad=True)
+    value16 = ops.sdf_mlp(plan, vols, pts, precision="f16x2")
+    sdf16, grad16 = ops.sdf_mlp(plan, vols, pts, want_grad=True, precision="f16x2")
+    assert not plan.overflowed()
+    assert (value16 - sdf32).abs().max() < 1e-5 and (sdf16 - sdf32).abs().max() < 1e-5
+    assert torch.isfinite(grad16).all()
+    assert ((grad16 - grad32).abs() <= 1e-4 * (1 + grad32.abs())).all()
+    sub = pts[::4099].contiguous()
+    d = torch.tensor([0.3, -0.5, 0.8], device=dev)
+    d = d / d.norm()
+    h = 2e-3
+    fd = (ops.sdf_mlp(plan, vols, sub + h * d, precision="f16x2") - ops.sdf_mlp(plan, vols, sub - h * d, precision="f16x2"))[:, 0] / (2 * h)
+    an = (grad16[::4099] * d).sum(-1)
+    err = (fd - an).abs()
+    assert err.median() < 5e-3 and (err < 0.05 * (1 + an.abs())).float().mean() > 0.97
+    # index map + device-side count at this size: a ragged count in the middle of a 128-point tile
+    idx = torch.randperm(n, device=dev)[:n // 2]
+    count = torch.tensor([n // 2 - 12345], dtype=torch.int32, device=dev)
+    s_out, g_out = torch.full((n, 1), 100.0, device=dev), torch.full((n, 3), -7.0, device=dev)
+    ops.sdf_mlp(plan, vols, pts, index=idx, want_grad=True, sdf_out=s_out, grad_out=g_out, precision="f16x2", count=count)
+    live = idx[:n // 2 - 12345]
+    assert torch.equal(s_out[live], sdf16[live]) and torch.equal(g_out[live], grad16[live])      # the same numbers whatever tile a point lands in
+    untouched = torch.ones(n, dtype=torch.bool, device=dev)
+    untouched[live] = False
+    assert bool((s_out[untouched] == 100.0).all()) and bool((g_out[untouched] == -7.0).all())
+    assert not plan.overflowed()
