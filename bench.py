@@ -12,7 +12,8 @@ path: the renderer reads a synthetic stand-in for the regu
 runs inside every timed step and supplies the visibility masks.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (one scene per rank, weak scaling)
+    python bench.py --gpus N                                                   (starts its own N rank processes: launch_ranks below)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (one scene per rank, weak scaling; --gpus must equal WORLD_SIZE)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant HIP kernel, HIP-event
 timed inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded ray sample, rank 0, N=1 only).
@@ -23,7 +24,9 @@ import os
 import sys
 import time
 
-import torch
+# torch is imported by main() of a RANK process only: the launching parent of `--gpus N` (launch_ranks) starts its children and relays
+# rank 0's line without ever loading torch, let alone touching HIP
+torch = None
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -75,6 +78,64 @@ def gpu_clocks():
     return out
 
 
+def balanced_chunk(n_rays, max_chunk, unit=256):
+    """Rays per render() chunk for a ray range of n_rays: the fewest chunks of at most max_chunk rays, of EQUAL length (a multiple of the
+    reference's 256-ray chunk), instead of full chunks + a short tail that runs at a fraction of the chip's occupancy (an eighth of a
+    480 x 640 image is 38 400 rays: 2 x 19 200, not 32 768 + 5 632).  The jitter is drawn in 256-ray groups whatever the chunk (JitterStream)."""
+    n_chunks = max(1, -(-n_rays // max_chunk))
+    per = -(-n_rays // n_chunks)
+    return min(max_chunk, -(-per // unit) * unit)
+
+
+class ClockSampler:
+    """Shader / memory clock levels read from sysfs WHILE the timed region runs (a helper thread, one read every `period` seconds; no child
+    process): a reading taken before or after the region sees an idle GPU and says nothing about it."""
+
+    def __init__(self, period=0.05):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = gpu_clocks()
+            if c:
+                self.samples.append(c)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self.thread.join()
+
+    def summary(self):
+        out = {"samples": len(self.samples), "where": "sysfs pp_dpm_*, sampled inside the timed region"}
+        for key in ("sclk_mhz", "mclk_mhz"):
+            v = sorted(c[key] for c in self.samples if key in c)
+            if v:
+                out[key] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        return out
+
+
+SECONDARY_STEPS = 5      # timed steps of every secondary figure (the headline takes --steps)
+
+
+def timed_steps(step, n=SECONDARY_STEPS):
+    """n steps, each timed on the host (every step here ends with validate()'s stream synchronisation) -> (mean seconds, per-step ms)."""
+    ms = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        t1 = time.perf_counter()
+        step()
+        ms.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, ms
+
+
 def percentiles(ms):
     """median / p10 / p90 of per-step wall times (SURVEY section 8d's protocol)."""
     s = sorted(ms)
@@ -93,9 +154,68 @@ def build_model(dims, device):
     return surf, vol
 
 
+def launch_ranks(n, argv, env=None, child=None, poll_s=0.05):
+    """`bench.py --gpus N` without a launcher around it: start N fresh rank processes of this file (what the reference's scripts/run.sh:3 does
+    with torch.distributed.launch and utils/distribute.py:66-88 reads back from the environment), one per GPU, rendezvous on 127.0.0.1.
+
+    The parent never initialises HIP (it does not even import torch): it starts the children, relays rank 0's stdout -- the ONE JSON line --
+    to its own stdout, sends the other ranks' stdout to stderr, and returns the first non-zero exit code.  A rank that dies takes the others
+    down with it (they would otherwise wait in a collective for ever): the exact child processes are terminated, nothing is retried.
+
+    child: the command of a rank process (tests substitute a stub); default: this interpreter on this file with the same arguments."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:        # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                      # dmabuf IPC: what RCCL needs on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    # rank 0 writes its line once, at the end: reading its pipe on a helper thread keeps a chatty library from filling it
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                for o in sorted(live):
+                    procs[o].terminate()                                    # these exact children; never a pattern
+        if live:
+            time.sleep(poll_s)
+    reader.join(10)
+    out = b"".join(chunks)
+    if rc == 0:
+        os.write(1, out)
+    elif out:
+        os.write(2, out)
+    return rc
+
+
 def main():
-    global DOMINANT
+    global DOMINANT, torch
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher around us: become the launcher.  Nothing above this line has loaded torch or HIP, and nothing below it runs in the parent.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher's --nproc-per-node and --gpus must agree" % (args.gpus, env_world))
+    import torch
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner through the C stdio buffer, which is flushed
     # at exit, i.e. after the line): everything else that goes to file descriptor 1 is sent to stderr, the line is written to the real stdout.
     sys.stdout.flush()
@@ -146,6 +266,8 @@ def main():
     if by_rays:
         from gens_amd.distributed import Shard
         shard = Shard()
+        r0, r1 = shard.rays(n_rays)
+        surf.val_chunk = balanced_chunk(r1 - r0, args.chunk)          # equal chunks over THIS rank's ray range
 
     def step():
         # the previous step's 690 MB of cost volumes and masks go back to the allocator BEFORE this step's are built (no second set of segments)
@@ -190,16 +312,16 @@ def main():
     # kernels comes from one extra, untimed step so that ~600 event records per step do not sit in the measured time
     if not args.no_kernel_timing:
         L.profile_begin(only={DOMINANT})
-    clocks_before = gpu_clocks()
     step_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        t_step = time.perf_counter()
-        step()                           # (validate() ends with the image's device-to-host copy: a step's wall time is its own)
-        step_ms.append((time.perf_counter() - t_step) * 1e3)
-    sync()
-    elapsed = time.perf_counter() - t0
-    clocks_after = gpu_clocks()
+    clocks = ClockSampler()
+    with clocks:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t_step = time.perf_counter()
+            step()                           # (validate() ends with the image's device-to-host copy: a step's wall time is its own)
+            step_ms.append((time.perf_counter() - t_step) * 1e3)
+        sync()
+        elapsed = time.perf_counter() - t0
     kernels = L.profile_end() if not args.no_kernel_timing else {}
     timed_steps = {k: args.steps for k in kernels}
     if not args.no_kernel_timing:
@@ -305,11 +427,7 @@ def main():
         surf.sdf_precision = "f16x2"
         step()
         sync()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        sync()
-        dt = (time.perf_counter() - t1) / 2
+        dt, split_ms = timed_steps(step)
         L.profile_begin()                          # the C-ABI kernel table of one extra step in this arithmetic (HIP events per launch)
         step()
         sync()
@@ -327,8 +445,8 @@ def main():
             images[prec] = surf.last_device_image.clone()
         surf.perturb, surf.sdf_precision = perturb, "f32"
         diff = (images["f16x2"] - images["f32"]).abs()
-        split = {"sdf_precision": "f16x2", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": dt * 1e3, "steps": 2,
-                 "colour_L1_vs_f32": float(diff[:, 0:3].mean()), "depth_L1_vs_f32": float(diff[:, 7].mean()),
+        split = {"sdf_precision": "f16x2", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": dt * 1e3, "steps": SECONDARY_STEPS,
+                 "ms_per_step_stats": percentiles(split_ms), "colour_L1_vs_f32": float(diff[:, 0:3].mean()), "depth_L1_vs_f32": float(diff[:, 7].mean()),
                  "depth_max_abs_vs_f32": float(diff[:, 7].max()),
                  "rays_with_depth_moved_by_more_than_1e-4": int((diff[:, 7] > 1e-4).sum()), "rays": int(diff.shape[0]), "hip_kernels": split_rows,
                  "note": "opt-in: every pass of the SDF network in split-half f16 arithmetic -- the value-only passes of the hierarchical "
@@ -340,6 +458,16 @@ def main():
         cpu = cpu_baseline(args, surf, sc, vols, state["masks"], n_final)
 
     secondary = world == 1 and not args.headline_only
+    # secondary figure (N = 1): what one rank of an 8-way ray-sharded image (BASELINE config[3]) has to do, timed alone on this GPU
+    projection = None
+    if secondary and dist is None and args.sdf_precision == "f32":
+        try:
+            projection = ray_sharded_variant(args, dev, None, surf, volume, n_final, torch.cuda.synchronize, projection=(7, 8))
+            projection["implied_speedup_upper_bound"] = round(elapsed / args.steps * 1e3 / projection["ms"], 2)
+            projection["note"] = ("implied_speedup_upper_bound = the headline's ms_per_step / ms: the most an 8-GPU ray-sharded image can gain if the gather "
+                                  "and the slowest rank cost nothing extra; the K1 build and the per-image host work do not shrink with the ray count")
+        except Exception as e:
+            projection = {"error": f"{type(e).__name__}: {e}"}
     # secondary figure (N = 1): the headline step at the SHIPPED level count (confs/gens.conf:63-67: five volume levels, sdf_mlp_k<100>)
     levels5 = views3 = None
     if secondary and args.sdf_precision == "f32" and len(args.dims) == 3:
@@ -396,9 +524,10 @@ def main():
                 else:                                                  # (a graph replay: the kernels are the eager key's)
                     del train[key]["hip_kernels"], train[key]["launches_per_step_c_abi"]
                 torch.cuda.empty_cache()
+            train["finetune_conf"].setdefault("workload", None)
             train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "
                                                   "volume_dims 256/128/64/32/16 as parameters, 512 rays + 2048 pseudo points")
-            train["ms_per_step"] = train["full"]["ms_per_step"]
+            train["ms_per_step"] = train["full"].get("ms_per_step")
             if "error" not in train["finetune_fused_adam"]:
                 train["finetune_fused_adam"]["note"] = "the fine-tune step with torch.optim.Adam(fused=True): one pass over the 307 MB of volumes instead of ten (INTEGRATION.md)"
             for key in ("hot_path_graph", "finetune_graph"):
@@ -410,11 +539,11 @@ def main():
         # secondary figure: one whole `--mode val` item (volume build, 512^3 SDF lattice, marching cubes on the device, 480x640 render)
         try:
             from scripts.val_full_bench import measure as val_measure
-            val_item = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in val_measure(repeats=2).items()}
+            val_item = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in val_measure(repeats=SECONDARY_STEPS + 1).items()}
             val_item["workload"] = "BASELINE config[1] as runner.py --mode val runs it: K1 + 512^3 lattice + iso-surface + 307 200-ray render"
-            half = val_measure(repeats=2, sdf_precision="f16x2")      # the same item in the opt-in split-half arithmetic
+            half = val_measure(repeats=SECONDARY_STEPS + 1, sdf_precision="f16x2")      # the same item in the opt-in split-half arithmetic
             val_item["split_half"] = {k: round(half[k], 2) if isinstance(half[k], float) else half[k]
-                                      for k in ("lattice_ms", "render_ms", "total_ms", "vertices", "triangles")}
+                                      for k in ("lattice_ms", "render_ms", "total_ms", "total_ms_stats", "vertices", "triangles")}
         except Exception as e:
             val_item = {"error": f"{type(e).__name__}: {e}"}
 
@@ -422,7 +551,7 @@ def main():
         "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "ms_per_step_stats": percentiles(step_ms), "ms_per_step_by_rank": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
-        "clocks": {"before": clocks_before, "after": clocks_after},
+        "clocks": clocks.summary(),
         "higher_is_better": True, "scaling": "strong" if by_rays else "weak", "vs_baseline": None,
         "dtype": "f32" if args.sdf_precision == "f32" else "f32 (SDF-MLP operands as split f16 hi+lo pairs, f32 accumulate)", "data": "synthetic",
         "config": {"workload": "BASELINE config[1]: 5-view 480x640, volume_dims=%s, inference of %d rays x %d samples per scene "
@@ -433,7 +562,7 @@ def main():
                    "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
                                    if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
         "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "views3": views3, "train_step": train, "val_item": val_item,
-        "ray_sharded": ray_sharded,
+        "ray_sharded": ray_sharded, "ray_sharded_projection": projection,
         "hip_kernels": table,
     }
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
@@ -467,9 +596,12 @@ def kernel_roofline(table):
             "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 1)}
 
 
-def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
+def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync, projection=None):
     """ONE scene (seed 0 on every rank), its 307 200 rays split into contiguous ranges across the ranks, K1 replicated, the rendered (P, 8)
-    buffers all-gathered over RCCL inside the timed region: whole-job ray-samples/s with the work FIXED as N grows (strong scaling)."""
+    buffers all-gathered over RCCL inside the timed region: whole-job ray-samples/s with the work FIXED as N grows (strong scaling).
+
+    projection=(rank, world), one GPU, no process group: the time of THAT rank's share rendered alone (Shard.single: K1 + its ray range, no
+    gather) -- a labelled 1-GPU projection of the ray-sharded step, not a scaling measurement."""
     from gens_amd import synthetic
     from gens_amd.distributed import Shard
     from gens_amd.models.modules.implicit_surface import Scene
@@ -481,9 +613,13 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
     rays_o, rays_d = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
     rays_o, rays_d = rays_o[:args.rays].to(dev), rays_d[:args.rays].to(dev)
     n_rays = rays_o.shape[0]
-    shard = Shard()
+    sink = {}
+    shard = Shard() if projection is None else Shard.single(projection[0], projection[1], sink)
+    r0, r1 = shard.rays(n_rays)
+    saved_chunk, surf.val_chunk = surf.val_chunk, balanced_chunk(r1 - r0, args.chunk)
 
     def step():
+        sink.clear()
         with torch.no_grad():
             _, masks = volume.agg_mean_var(feats, intrs, c2ws)
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
@@ -491,23 +627,32 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync):
                           scene=scene, shard=shard)
             surf.prefetch_jitter(n_rays)       # (see ImplicitSurface.prefetch_jitter: the last rank would otherwise wait ~12 ms for its draws)
     torch.manual_seed(4321)                    # the same CPU generator state on every rank: identical jitter for every ray
-    step()
-    sync()
-    t0 = time.perf_counter()
-    steps = 5
-    for _ in range(steps):
+    try:
         step()
-    sync()
-    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        sync()
+        steps = SECONDARY_STEPS
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        surf.val_chunk = saved_chunk
+    if projection is not None:
+        return {"ms": round(dt * 1e3, 2), "steps": steps, "rank": projection[0], "world": projection[1], "rays": r1 - r0, "ray_chunk": balanced_chunk(r1 - r0, args.chunk),
+                "what": "ONE GPU renders rank %d's share of a %d-way ray-sharded image alone: K1 (replicated on every rank) + rays [%d, %d) of %d, "
+                        "no gather; a projection of the ray-sharded step, NOT a multi-GPU measurement" % (projection[0], projection[1], r0, r1, n_rays)}
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t) / steps
+    dt = float(t)
     return {"scaling": "strong", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
-            "n_gpus": dist.get_world_size(), "workload": "one scene, %d rays split across the ranks, all_gather of the (P, 8) buffers in the timed region" % n_rays,
+            "n_gpus": dist.get_world_size(), "ray_chunk": balanced_chunk(r1 - r0, args.chunk),
+            "workload": "one scene, %d rays split across the ranks, all_gather of the (P, 8) buffers in the timed region" % n_rays,
             "note": "secondary figure of the same run; `python bench.py --gpus N --shard rays` reports it as the headline"}
 
 
 def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_o, rays_d, n_final, kernels=False):
-    """The headline step with the shipped five-level pyramid (volume_dims 256 / 128 / 64 / 32 / 16: sdf_mlp_k<100>): 3 timed steps.
+    """The headline step with the shipped five-level pyramid (volume_dims 256 / 128 / 64 / 32 / 16: sdf_mlp_k<100>): SECONDARY_STEPS timed steps.
     kernels: add the C-ABI kernel table of one extra, untimed step (HIP events per launch)."""
     from gens_amd import synthetic
     from gens_amd.models.modules.implicit_surface import Scene
@@ -528,25 +673,17 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
     torch.cuda.synchronize()
     import gc
     gc.collect()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
+    dt, ms = timed_steps(step)
     pending = getattr(surf, "_jitter_ahead", None)
     if pending is not None:
         pending[1].join()
-    res = {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
-           "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
+    res = {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": SECONDARY_STEPS,
+           "ms_per_step_stats": percentiles(ms), "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
     if not kernels:      # the same steps in the opt-in split-half arithmetic (gens_sdf_value_f16 / gens_sdf_grad_f16 at five levels)
         surf.sdf_precision = "f16x2"
         step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        res["split_half_ms_per_step"] = round((time.perf_counter() - t0) / 2 * 1e3, 2)
+        res["split_half_ms_per_step"] = round(timed_steps(step)[0] * 1e3, 2)
         surf.sdf_precision = "f32"
     if kernels:
         from gens_amd import lib as L

@@ -245,5 +245,10 @@ class FinetuneStepper:
         loss = self.loss_fn(outputs, ipts)
         loss.backward()
         self.flat.sync()
+        # what the reference raises inside forward() (no valid pseudo point, a singular camera: implicit_surface.py:494-495) the fused step leaves
+        # as device flags: look at them BEFORE the update is applied (waits for this step's forward only; the backward is already enqueued)
+        for m in self.model.modules():
+            if hasattr(m, "check_deferred"):
+                m.check_deferred()
         self.optimizer.step()
         return loss.detach(), outputs

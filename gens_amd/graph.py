@@ -13,6 +13,10 @@ once, replay it with ONE launch per step.
         loss = step()                     # refreshes the host draws, replays, returns the captured loss tensor
         float(loss)                       # the read-back synchronises; step.check() then raises what the reference would have raised
 
+Warm-up: torch.cuda.graph needs a few eager runs of body() first.  They would apply real optimiser steps and consume host generator draws, so
+a graphed run would start from other parameters and another draw sequence than an eager one: the parameters, the optimiser state and the CPU
+generator state are saved before the warm-up and put back after it -- replay k is step k.
+
 What must hold (checked where it can be): the optimiser is capturable (torch.optim.Adam(..., capturable=True)), shapes and the set of
 tensors body() touches do not change between replays, inputs are updated IN PLACE, and body() does not synchronise with the host.  The eager
 path stays the reference-compatible default (runner.py calls the model step by step); this is the opt-in for loops that own their step.
@@ -27,6 +31,11 @@ class GraphedStep:
         self.surfaces = list(surfaces)
         for group in optimizer.param_groups:
             assert group.get("capturable", False) or group.get("fused", False), "build the optimiser with capturable=True (its step counter must live on the device)"
+        import copy
+        params = [p for group in optimizer.param_groups for p in group["params"]]
+        saved_params = [p.detach().clone() for p in params]
+        saved_opt = copy.deepcopy(optimizer.state_dict())
+        saved_rng = torch.get_rng_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                          # (warm-up off the default stream, as torch.cuda.graph requires)
@@ -37,15 +46,35 @@ class GraphedStep:
         torch.cuda.synchronize()
         for s in self.surfaces:
             s.check_deferred()
+        with torch.no_grad():                                  # the warm-up never happened: parameters, Adam moments / step counters, generator
+            for p, q in zip(params, saved_params):
+                p.copy_(q)
+        state_before = optimizer.state_dict()["state"]
+        if saved_opt["state"]:
+            optimizer.load_state_dict(saved_opt)
+        else:                                                  # a fresh optimiser: its state tensors exist now (capture needs them) -- zero them in place
+            for st in state_before.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.set_rng_state(saved_rng)
         optimizer.zero_grad(set_to_none=True)                  # the captured backward then ASSIGNS the gradients (no accumulation across replays)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = body()
+        torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
+        self._replayed = None
 
     def __call__(self):
+        if self._replayed is not None:
+            # the previous replay's copy node must have READ the page-locked draw buffer before it is overwritten (free when the caller already
+            # read the loss back; a loop that does not would otherwise replay with torn or duplicated draws)
+            self._replayed.synchronize()
         for s in self.surfaces:
             s.refresh_host_draws()                             # the reference's generator, its order: the graph's copy node carries them over
         self.graph.replay()
+        self._replayed = torch.cuda.Event()
+        self._replayed.record()
         return self.loss
 
     def check(self):

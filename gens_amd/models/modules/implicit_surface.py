@@ -700,7 +700,10 @@ class ImplicitSurface(nn.Module):
 
     def check_deferred(self):
         """Raise what the last fused training step would have raised in the reference (no valid pseudo point, implicit_surface.py:494-495; a
-        singular camera matrix, torch.inverse).  Called at the start of every forward(); call it yourself after the last step of a loop."""
+        singular camera matrix, torch.inverse).  Called at the start of every forward().  The reference raises INSIDE the bad step's forward
+        (before its backward and optimiser step); here the bad step's pseudo-point term is zero (value and gradient) and the error arrives one
+        call later, so a loop that must not apply the bad step's update -- or that ends -- calls this itself once the step's forward has run:
+        after the loss read-back (free: the read-back synchronised) and before optimizer.step(), as distributed.FinetuneStepper does."""
         ev = getattr(self, "_deferred", None)
         if ev is None or torch.cuda.is_current_stream_capturing():
             return
@@ -739,6 +742,11 @@ class ImplicitSurface(nn.Module):
             outputs["pseudo_sdf"] = outputs.pop("_extra_sdf_dense")
             self._defer_checks(self._last_step_counts, scene.views.cams.status)
             return outputs
+        host = getattr(self, "_deferred_host", None)
+        if host is not None and not torch.cuda.is_current_stream_capturing():
+            # this step leaves nothing to verify later (it raises on the spot, or carries no pseudo points): what an EARLIER fused step parked in
+            # page-locked memory was checked two lines up and must not be read again by check_deferred_host() / GraphedStep.check()
+            host[2], host[3] = 1, 0
         if "pseudo_pts" in ipts:                       # (:484-497) the mask look-up draws nothing from the generator, so it can come first
             pseudo_pts = ipts["pseudo_pts"].float()
             valid = ops.lookup_mask(pseudo_pts, scene.masks)

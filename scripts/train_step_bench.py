@@ -129,6 +129,7 @@ def _measure(quiet, kernels=False):
         loss = step()
         host += time.perf_counter() - t1                                 # the host's share: every launch of the step enqueued
         float(loss)                                                      # (runner.py reads the loss every step: one synchronisation per step)
+        (model.implicit_surface if full else surf).check_deferred()                                         # the reference's mid-step errors, raised at the step they belong to (the read-back synchronised)
         per_step.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n

@@ -36,6 +36,7 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True, sdf_prec
         return time.perf_counter()
 
     res = None
+    totals = []
     import gc
     for it in range(repeats):
         gc.collect()          # (a full pass of Python's cyclic collector costs ~30 ms here: keep it out of the timed item, as bench.py does for the headline)
@@ -54,10 +55,15 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True, sdf_prec
         res = {"volume_build_ms": 1e3 * (t1 - t0), "lattice_ms": 1e3 * (t2 - t1), "lattice_Mpoints_per_s": resolution ** 3 / (t2 - t1) / 1e6,
                "marching_cubes_ms": 1e3 * (t3 - t2), "render_ms": 1e3 * (t4 - t3), "total_ms": 1e3 * (t4 - t0), "vertices": int(v.shape[0]),
                "triangles": int(t.shape[0])}
+        totals.append(res["total_ms"])
         if not quiet:
             print(f"volume build + scene {res['volume_build_ms']:.1f} ms | {resolution}^3 SDF lattice {res['lattice_ms']:.1f} ms "
                   f"({res['lattice_Mpoints_per_s']:.0f} M points/s) | marching cubes + mesh read-back {res['marching_cubes_ms']:.1f} ms "
                   f"({res['vertices']} vertices, {res['triangles']} triangles) | render {res['render_ms']:.1f} ms | total {res['total_ms']:.1f} ms")
+    if len(totals) > 1:            # the first item of a process carries plan construction and allocator growth: statistics over the others
+        rest = sorted(totals[1:])
+        res["items"] = len(totals)
+        res["total_ms_stats"] = {"median": round(rest[len(rest) // 2], 2), "min": round(rest[0], 2), "max": round(rest[-1], 2), "over_items": len(rest)}
     return res
 
 

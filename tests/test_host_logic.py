@@ -58,3 +58,104 @@ def test_bench_command_line_contract():
         assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
     finally:
         sys.argv = saved
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N launches its own rank processes (the reference: scripts/run.sh:3 + utils/distribute.py:66-88)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _run_py(code, env=None, timeout=120):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ if env is None else env)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    return subprocess.run([sys.executable, "-c", code], env=e, cwd=root, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks_and_relays_rank_zero_without_loading_torch():
+    """The parent of `bench.py --gpus N` starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's stdout (the
+    one JSON line) and sends the others' to stderr -- and never loads torch, so it cannot have initialised HIP."""
+    code = r'''
+import json, sys
+import bench
+stub = [sys.executable, "-c", "import os, json; print(json.dumps({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))"]
+rc = bench.launch_ranks(3, ["--gpus", "3"], child=stub)
+assert rc == 0, rc
+assert "torch" not in sys.modules, "the launching parent loaded torch"
+'''
+    r = _run_py(code)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                              # ONE line on stdout: rank 0's
+    import json
+    zero = json.loads(lines[0])
+    assert zero["RANK"] == "0" and zero["LOCAL_RANK"] == "0" and zero["WORLD_SIZE"] == "3" and zero["MASTER_ADDR"] == "127.0.0.1"
+    others = sorted(json.loads(ln)["RANK"] for ln in r.stderr.splitlines() if ln.startswith("{"))
+    assert others == ["1", "2"]
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that exits non-zero ends the run: the others (here: one that would sleep for ten minutes) are terminated and the parent's exit
+    status is the failing rank's; nothing of rank 0's output reaches stdout."""
+    import time
+    code = r'''
+import sys
+import bench
+stub = [sys.executable, "-c", "import os, sys, time; r = int(os.environ['RANK']); print('line of rank', r); sys.stdout.flush(); sys.exit(7) if r == 1 else time.sleep(600)"]
+sys.exit(bench.launch_ranks(2, [], child=stub))
+'''
+    t0 = time.time()
+    r = _run_py(code)
+    assert r.returncode == 7, (r.returncode, r.stderr)
+    assert time.time() - t0 < 60
+    assert r.stdout.strip() == ""
+    assert "rank 1 exited with status 7" in r.stderr
+
+
+def test_bench_main_becomes_the_launcher_only_without_a_launcher_around_it():
+    """--gpus 2 with no WORLD_SIZE: main() hands over to launch_ranks before torch is imported.  Under a launcher (WORLD_SIZE set) --gpus must
+    equal the world size or the run aborts."""
+    code = r'''
+import sys
+import bench
+calls = []
+bench.launch_ranks = lambda n, argv, **kw: calls.append((n, list(argv), "torch" in sys.modules)) or 0
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2"]
+try:
+    bench.main()
+except SystemExit as e:
+    assert e.code == 0, e.code
+assert calls == [(2, ["--gpus", "2", "--steps", "2"], False)], calls
+'''
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = _run_py(code, env=env)
+    assert r.returncode == 0, r.stderr
+    code = r'''
+import sys
+import bench
+sys.argv = ["bench.py", "--gpus", "8"]
+try:
+    bench.main()
+except SystemExit as e:
+    assert "WORLD_SIZE=2" in str(e.code) and "--gpus 8" in str(e.code), e.code
+    assert "torch" not in sys.modules
+else:
+    raise AssertionError("a world size that contradicts --gpus was accepted")
+'''
+    r = _run_py(code, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 0, r.stderr
+
+
+def test_bench_balanced_chunks_cover_a_shard_without_a_short_tail():
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.balanced_chunk(38400, 32768) == 19200            # an eighth of 480 x 640: 2 x 19 200, not 32 768 + 5 632
+    assert bench.balanced_chunk(153600, 32768) == 30720
+    assert bench.balanced_chunk(32768, 32768) == 32768
+    for n in (1, 255, 256, 257, 5000, 38400, 76800, 307200):
+        c = bench.balanced_chunk(n, 32768)
+        assert c % 256 == 0 and c <= 32768
+        lens = [min(c, n - s) for s in range(0, n, c)]
+        assert sum(lens) == n and len(lens) == -(-n // 32768) or n <= 32768
