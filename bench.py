@@ -62,19 +62,37 @@ def parse():
     return p.parse_args()
 
 
-def gpu_clocks():
-    """Current shader / memory clock levels from sysfs (no child process: nothing may exec once the GPU is initialised), e.g.
-    {"sclk_mhz": 2400, "mclk_mhz": 2000}; {} where the files are not readable."""
+def gpu_sysfs_dir(device_index=0):
+    """/sys/class/drm/cardN/device of the GPU this process computes on.  A box exposes EVERY GPU of the node in sysfs, whatever the process
+    may use: the card is matched by its PCI address (torch's device properties; no HIP call beyond what the bench already made)."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+    for path in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if os.path.basename(os.path.realpath(path)).lower().startswith(want):
+            return path
+    return None
+
+
+def gpu_clocks(card_dir):
+    """One reading of the card's hwmon: shader / memory clock (MHz), socket power (W), busy percent; {} where the files are not readable."""
     import glob
     out = {}
-    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
-        for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name)):
+    if not card_dir:
+        return out
+    for hw in glob.glob(os.path.join(card_dir, "hwmon", "hwmon*")):
+        for key, name, scale in (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_input", 1e-6)):
             try:
-                for row in open(path).read().splitlines():
-                    if row.rstrip().endswith("*"):
-                        out.setdefault(key, int("".join(ch for ch in row.split(":")[1] if ch.isdigit())))
-            except (OSError, ValueError, IndexError):
+                out[key] = int(round(int(open(os.path.join(hw, name)).read()) * scale))
+            except (OSError, ValueError):
                 pass
+    try:
+        out["busy_percent"] = int(open(os.path.join(card_dir, "gpu_busy_percent")).read())
+    except (OSError, ValueError):
+        pass
     return out
 
 
@@ -88,17 +106,18 @@ def balanced_chunk(n_rays, max_chunk, unit=256):
 
 
 class ClockSampler:
-    """Shader / memory clock levels read from sysfs WHILE the timed region runs (a helper thread, one read every `period` seconds; no child
+    """Shader / memory clock, power and busy readings from sysfs WHILE the timed region runs (a helper thread, one read every `period` seconds; no child
     process): a reading taken before or after the region sees an idle GPU and says nothing about it."""
 
-    def __init__(self, period=0.05):
+    def __init__(self, device_index=0, period=0.05):
         import threading
+        self.card = gpu_sysfs_dir(device_index)
         self.period, self.samples, self._stop = period, [], threading.Event()
         self.thread = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
-            c = gpu_clocks()
+            c = gpu_clocks(self.card)
             if c:
                 self.samples.append(c)
             self._stop.wait(self.period)
@@ -112,8 +131,8 @@ class ClockSampler:
         self.thread.join()
 
     def summary(self):
-        out = {"samples": len(self.samples), "where": "sysfs pp_dpm_*, sampled inside the timed region"}
-        for key in ("sclk_mhz", "mclk_mhz"):
+        out = {"samples": len(self.samples), "where": "%s/hwmon (this process' GPU by PCI address), sampled inside the timed region" % self.card}
+        for key in ("sclk_mhz", "mclk_mhz", "power_w", "busy_percent"):
             v = sorted(c[key] for c in self.samples if key in c)
             if v:
                 out[key] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
@@ -123,7 +142,7 @@ class ClockSampler:
 SECONDARY_STEPS = 5      # timed steps of every secondary figure (the headline takes --steps)
 
 
-def timed_steps(step, n=SECONDARY_STEPS):
+def run_timed(step, n=SECONDARY_STEPS):
     """n steps, each timed on the host (every step here ends with validate()'s stream synchronisation) -> (mean seconds, per-step ms)."""
     ms = []
     torch.cuda.synchronize()
@@ -313,7 +332,7 @@ def main():
     if not args.no_kernel_timing:
         L.profile_begin(only={DOMINANT})
     step_ms = []
-    clocks = ClockSampler()
+    clocks = ClockSampler(local)
     with clocks:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -427,7 +446,7 @@ def main():
         surf.sdf_precision = "f16x2"
         step()
         sync()
-        dt, split_ms = timed_steps(step)
+        dt, split_ms = run_timed(step)
         L.profile_begin()                          # the C-ABI kernel table of one extra step in this arithmetic (HIP events per launch)
         step()
         sync()
@@ -673,7 +692,7 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
     torch.cuda.synchronize()
     import gc
     gc.collect()
-    dt, ms = timed_steps(step)
+    dt, ms = run_timed(step)
     pending = getattr(surf, "_jitter_ahead", None)
     if pending is not None:
         pending[1].join()
@@ -683,7 +702,7 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
         surf.sdf_precision = "f16x2"
         step()
         torch.cuda.synchronize()
-        res["split_half_ms_per_step"] = round(timed_steps(step)[0] * 1e3, 2)
+        res["split_half_ms_per_step"] = round(run_timed(step)[0] * 1e3, 2)
         surf.sdf_precision = "f32"
     if kernels:
         from gens_amd import lib as L

@@ -75,21 +75,27 @@ def _trilinear(vol, pts):
 # ----------------------------------------------------------------------------------------------
 # K1  Volume.agg_mean_var  (models/modules/volume.py:13-63)
 # ----------------------------------------------------------------------------------------------
-def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
-    """-> (volumes [(1,2C,D,D,D)], masks [(1,1,D,D,D)]).  Differentiable w.r.t. features only."""
+def volume_build(features, intrs, c2ws, dims, min_vis_view=1, x_ranges=None):
+    """-> (volumes [(1,2C,D,D,D)], masks [(1,1,D,D,D)]).  Differentiable w.r.t. features only.
+
+    x_ranges (tests at BASELINE's full volume sizes): per level an index range (x0, x1) along the SLOWEST volume axis (world x, Q1) -- only
+    that slab of voxels is built, -> (1,2C,x1-x0,D,D) / (1,1,x1-x0,D,D); voxels are independent (volume.py:27-61), so the slab is the
+    corresponding slice of the whole cube (tests/test_oracle_golden.py checks that on the golden sizes)."""
     w2cs = torch.inverse(c2ws)
     vols, masks = [], []
     for lvl, d in enumerate(dims):
+        x0, x1 = (0, d) if x_ranges is None or x_ranges[lvl] is None else x_ranges[lvl]
+        n_slab = x1 - x0
         feat = features[lvl]
         nv, c, h, w = feat.shape
         k = intrs.clone()
         k[:, :2] = k[:, :2] * 0.5 ** lvl                                   # volume.py:24-25 (Q2)
         g = torch.linspace(-1, 1, d, dtype=F32)
-        xs, ys, zs = torch.meshgrid(g, g, g, indexing="ij")               # (Q1) x is the slowest axis
-        world = torch.stack([xs.reshape(-1), ys.reshape(-1), zs.reshape(-1), torch.ones(d ** 3)], 0)
-        s1 = torch.zeros(c, d ** 3)
-        s2 = torch.zeros(c, d ** 3)
-        cnt = torch.zeros(d ** 3)
+        xs, ys, zs = torch.meshgrid(g[x0:x1], g, g, indexing="ij")        # (Q1) x is the slowest axis
+        world = torch.stack([xs.reshape(-1), ys.reshape(-1), zs.reshape(-1), torch.ones(n_slab * d * d)], 0)
+        s1 = torch.zeros(c, n_slab * d * d)
+        s2 = torch.zeros(c, n_slab * d * d)
+        cnt = torch.zeros(n_slab * d * d)
         for v in range(nv):
             with torch.no_grad():
                 cam = w2cs[v] @ world
@@ -108,8 +114,8 @@ def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
         den = torch.where(cnt <= 0, torch.full_like(cnt, 1e-8), cnt)      # volume.py:53 (Q5)
         mean = s1 / den
         var = s2 / den - mean ** 2
-        vols.append(torch.cat([mean, var], 0).reshape(1, 2 * c, d, d, d))
-        masks.append((cnt > min_vis_view).to(F32).reshape(1, 1, d, d, d))  # (Q4)
+        vols.append(torch.cat([mean, var], 0).reshape(1, 2 * c, n_slab, d, d))
+        masks.append((cnt > min_vis_view).to(F32).reshape(1, 1, n_slab, d, d))  # (Q4)
     return vols, masks
 
 

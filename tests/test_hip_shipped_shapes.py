@@ -13,18 +13,28 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DIMS5 = [256, 128, 64, 32, 16]
+# parameters with <= 4 elements (the variance, the blending network's temperature) are sums of cancelling per-sample terms: relative to their
+# own magnitude they carry more float32 round-off than a weight matrix.  Bound = 3 x the worst value measured over both full-size steps below.
+SCALAR_GRAD_TOL = 0.15
 
 
-def _surface(seed=0, perturb_weights=0.02, dims=DIMS5):
+def _surface(seed=0, perturb_weights=0.04, dims=DIMS5, radius=0.5):
+    """Geometric initialisation (a sphere of `radius`: sdf_network.py:63-88 with bias = radius) moved off it so that the volume features
+    matter: every parameter by `perturb_weights` x N(0, 1) x (its mean magnitude + 0.02), the recipe of the render goldens
+    (tests/golden/make_golden.py:_perturb).  (Until round 4 the perturbation was ABSOLUTE, 0.02 N(0, 1): that pushed the SDF above +1
+    everywhere -- no ray of the full-size tests had a zero crossing, so `sdf_depth` and the surface gate were compared on zeros.)"""
     from gens_amd.config import gens_model_conf
     from gens_amd.models.modules.implicit_surface import ImplicitSurface
     torch.manual_seed(seed)
     surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"])
-    with torch.no_grad():                                  # off the geometric initialisation, so that the volume features matter
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
         for p in surf.sdf_network.parameters():
-            p.add_(perturb_weights * torch.randn_like(p))
+            p.add_(perturb_weights * torch.randn(p.shape, generator=g) * (p.abs().mean() + 0.02))
         for p in surf.color_network.parameters():
-            p.add_(0.05 * torch.randn_like(p))
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        last = getattr(surf.sdf_network, f"lin{surf.sdf_network.num_layers - 2}")
+        last.bias[0] -= (radius - 0.5)                     # row 0 is the SDF: |x| - radius
     return surf
 
 
@@ -42,6 +52,36 @@ def _scene(nv, h, w, seed, dims=DIMS5):
     return d
 
 
+def _ray_strata(surf, scene, sc, ro, rd, jitter, g, n_cand=24576):
+    """Ray indices by category, estimated ON THE DEVICE from the samples validate() will use (same jitter): per-sample SDF through the
+    PyTorch layers on K2, the masked first sign change and the unit-sphere gate as render_core applies them (implicit_surface.py:262-281)."""
+    from gens_amd import ops
+    h, w = 480, 640
+    n_rays = ro.shape[0]
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    border = ((xx == 0) | (xx == w - 1) | (yy == 0) | (yy == h - 1)).reshape(-1)
+    border_idx = torch.nonzero(border)[:, 0]
+    assert ro.shape[0] == h * w
+    cand = torch.unique(torch.cat([border_idx, torch.randint(0, n_rays, (n_cand,), generator=g)]))
+    dev = torch.device("cuda")
+    ro_c, rd_c = ro[cand].to(dev).contiguous(), rd[cand].to(dev).contiguous()
+    with torch.no_grad():
+        z0 = ops.coarse_z(sc["near"], sc["far"], surf._coarse_steps(dev), jitter[cand].to(dev), cand.numel())
+        z = surf._sample_rays(ro_c, rd_c, z0, scene)
+        pts, valid = ops.ray_points(ro_c, rd_c, z, scene.masks, mid=True, sample_dist=2.0 / 64)
+        sdf = surf.sdf_network.sdf(pts, scene.volumes_nograd()).reshape(z.shape)
+        vm = valid.reshape(z.shape).bool()
+        sdf = torch.where(vm, sdf, torch.full_like(sdf, 100.0))
+        inside = (pts.norm(dim=-1).reshape(z.shape) < 1.0) & vm
+        change = (sdf[:, :-1] * sdf[:, 1:] <= 0) & vm[:, :-1] & vm[:, 1:]
+        rank = torch.arange(z.shape[1] - 1, 0, -1, device=dev, dtype=torch.float32)
+        i0 = torch.argmax(change.float() * rank[None], 1, keepdim=True)
+        both_in = inside.gather(1, i0) & inside.gather(1, i0 + 1)
+        any_change = change.any(1)
+    any_change, both_in = any_change.cpu(), both_in.reshape(-1).cpu()
+    return {"border": border_idx, "sphere_gated": cand[any_change & ~both_in], "crossing": cand[any_change & both_in], "no_crossing": cand[~any_change]}
+
+
 @pytest.mark.parametrize("nv,dims", [(3, DIMS5), (5, [256, 128, 64])])
 def test_validate_full_image_480x640(nv, dims):
     """The full 307 200-ray image of `validate` against the oracle on a ray sample: BASELINE config[3]'s shape on one GPU (two source views, five
@@ -50,7 +90,7 @@ def test_validate_full_image_480x640(nv, dims):
     from gens_amd.models.modules.implicit_surface import Scene, reference_jitter
     from oracle import render_oracle as R
     sc = _scene(nv, 480, 640, seed=30, dims=dims)
-    surf = _surface(1, dims=dims).cuda().eval()
+    surf = _surface(1, dims=dims, radius=0.97 if nv == 5 else 0.6).cuda().eval()      # nv = 5: a surface AT the unit sphere, where render_core's gate decides
     ro, rd = synthetic.make_rays(sc["cpu"]["intrs"], sc["cpu"]["c2ws"], 480, 640)
     n_rays = ro.shape[0]
     hw = torch.tensor([480, 640]).int()
@@ -70,23 +110,55 @@ def test_validate_full_image_480x640(nv, dims):
     # rays are independent: another chunking renders the same image (same jitter per ray) bit for bit
     _, dev_image2 = image(8192)
     assert torch.equal(dev_image, dev_image2)
-    # the oracle on a sample of rays with the SAME jitter (the reference's draw order, chunk by chunk)
+    # the oracle on a STRATIFIED sample of rays with the SAME jitter (the reference's draw order, chunk by chunk): image-border pixels, rays
+    # whose first masked sign change is rejected by the unit-sphere gate (implicit_surface.py:277-281), rays with a crossing that passes, rays
+    # without any crossing, plus a uniform draw -- 512 rays for config[1] (the headline shape), 128 for the five-level protocol
     torch.manual_seed(77)
     jitter = reference_jitter(n_rays)
     g = torch.Generator().manual_seed(3)
-    pick = torch.randint(0, n_rays, (24,), generator=g)
+    n_oracle = 512 if nv == 5 else 128
+    strata = _ray_strata(surf, scene, sc, ro, rd, jitter, g)
+    quota = {"border": n_oracle // 4, "sphere_gated": n_oracle // 8, "crossing": n_oracle // 8, "no_crossing": n_oracle // 8}
+    chosen, taken = [], {}
+    for name, share in quota.items():
+        cand = strata[name]
+        take = cand[torch.randperm(cand.numel(), generator=g)[:share]]
+        taken[name] = int(take.numel())
+        chosen.append(take)
+    chosen.append(torch.randint(0, n_rays, (n_oracle - sum(taken.values()),), generator=g))
+    pick = torch.cat(chosen)
+    print("oracle rays per stratum:", taken, "+ uniform", int(chosen[-1].numel()), "| candidates:", {k: int(v.numel()) for k, v in strata.items()})
+    assert taken["border"] == quota["border"] and taken["crossing"] > 0
     sd = {k: v.detach().cpu() for k, v in surf.state_dict().items()}
     masks_c = [m.cpu() for m in sc["masks"]]
     cpu = sc["cpu"]
     ref = R.render(sd, ro[pick], rd[pick], cpu["near"], cpu["far"], sc["vols_cpu"], masks_c, cpu["imgs"], cpu["features"], cpu["features"],
                    cpu["intrs"], cpu["c2ws"], 1.0, None, jitter[pick], torch.rand(1024, 3, generator=g) * 2 - 1)
     got = dev_image[pick.cuda()].cpu()
-    # north-star bound: colour / depth L1 within 1e-4 of the reference
-    assert (got[:, 0:3] - ref["color_fine"]).abs().mean() < 1e-4
-    assert (got[:, 7] - ref["render_depth"].reshape(-1)).abs().mean() < 1e-4
-    assert (got[:, 6] - ref["sdf_depth"].reshape(-1)).abs().mean() < 1e-4
+    # what the ORACLE says the sample contains (the strata were drawn from a device-side estimate): gated crossings, accepted ones, none
+    n_ = ref["weights"].shape[1]
+    sdf_o = ref["sparse_sdf"][1024:].reshape(-1, n_)
+    accepted = ref["mid_inside_sphere"].reshape(-1) > 0
+    has_change = ((sdf_o[:, :-1] * sdf_o[:, 1:] <= 0) & (sdf_o[:, :-1] < 99) & (sdf_o[:, 1:] < 99)).any(1)
+    print("oracle: accepted crossings %d, sign change but rejected %d, no sign change %d, rays failing the >8-visible-samples test %d"
+          % (int(accepted.sum()), int((has_change & ~accepted).sum()), int((~has_change).sum()), int((~ref["valid_mask"].reshape(-1)).sum())))
+    assert int(accepted.sum()) >= n_oracle // 16 and int((~accepted).sum()) >= n_oracle // 16
+    # north-star bound: colour / depth L1 within 1e-4 of the reference -- over the sample AND inside every stratum
     normal = (ref["gradients"] * ref["weights"][..., None] * ref["inside_sphere"][..., None]).sum(1)
-    assert (got[:, 3:6] - normal).abs().mean() < 1e-4
+    bounds = [0] + torch.cumsum(torch.tensor([c.numel() for c in chosen]), 0).tolist()
+    for name, a, b in [("all", 0, pick.numel())] + [(nm, bounds[i], bounds[i + 1]) for i, nm in enumerate(list(quota) + ["uniform"])]:
+        if b == a:
+            continue
+        sl = slice(a, b)
+        err = {"colour": (got[sl, 0:3] - ref["color_fine"][sl]).abs().mean(), "render_depth": (got[sl, 7] - ref["render_depth"].reshape(-1)[sl]).abs().mean(),
+               "sdf_depth": (got[sl, 6] - ref["sdf_depth"].reshape(-1)[sl]).abs().mean(), "normal": (got[sl, 3:6] - normal[sl]).abs().mean()}
+        print("  %-12s %4d rays  " % (name, b - a) + "  ".join("%s %.2e" % (k, float(v)) for k, v in err.items()))
+        for k, v in err.items():
+            assert float(v) < 1e-4, (name, k, float(v))
+    # the accept / reject decision of the zero-crossing depth itself, ray by ray: a ray may flip only if its crossing sits ON a gate
+    flipped = ((got[:, 6] != 0) != (ref["sdf_depth"].reshape(-1) != 0))
+    assert int(flipped.sum()) <= max(1, n_oracle // 128), int(flipped.sum())
+
     # the opt-in split-half arithmetic (gens_sdf_value_f16 + gens_sdf_grad_f16 at three and at five levels): the same image, same jitter,
     # within a tenth of the north-star bound of the float32 image over ALL rays, and within the bound of the oracle on the sample
     surf.sdf_precision = "f16x2"
@@ -171,5 +243,168 @@ def test_finetune_step_three_views_1152x1600_five_levels():
         worst[f"volume{i}"] = float((a.grad.cpu() - b.grad).abs().max()) / max(float(b.grad.abs().max()), 1e-12)
     print({k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
     scalars = {k for k, p in surf.named_parameters() if p.numel() <= 4}          # sums of cancelling per-sample terms: compared loosely
-    bad = {k: v for k, v in worst.items() if v >= (0.15 if k in scalars else 2e-3)}
+    print("scalar parameters:", {k: f"{worst[k]:.1e}" for k in scalars})
+    bad = {k: v for k, v in worst.items() if v >= (SCALAR_GRAD_TOL if k in scalars else 2e-3)}
+    assert not bad, bad
+
+
+def _band_limited(features):
+    """Feature maps with period >= 40 px (tests/test_hip_kernels.py::test_k1_volume_vs_oracle_480x640: white noise turns the 1e-4 px float32
+    uncertainty of a projected coordinate into 1e-3 value differences between ANY two implementations)."""
+    out = []
+    for i, f in enumerate(features):
+        nv, c, h, w = f.shape
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        ph = torch.arange(nv * c, dtype=torch.float32).reshape(nv, c, 1, 1)
+        out.append(torch.sin(xx * (0.15 * 2 ** i / (1 + ph % 3)) + yy * (0.11 * 2 ** i) + ph) * (1 + 0.1 * ph))
+    return out
+
+
+def _rel_off(a, b, tol, floor):
+    """Fraction of elements of a that differ from b by more than tol * max(|b|.max(), floor)."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float(((a - b).abs() > tol * max(float(b.abs().max()), floor)).float().mean()), float((a - b).abs().max())
+
+
+def test_training_step_config2_shape_five_views_480x640_volumes_256_128_64():
+    """BASELINE config[2] at its OWN size: 5 views 480 x 640, volume_dims 256 / 128 / 64, 512 rays + 2048 pseudo points, the reference's Loss,
+    backward through every kernel -- with the K1 build inside the differentiated graph.
+
+      leg 1  K1 forward AND backward at 256^3 / 128^3 / 64^3 against the oracle on voxel slabs: the cotangent lives on a 8 x 256 x 256 slab of
+             level 0, a 16 x 128 x 128 slab of level 1 and the whole of level 2, so the CPU builds those voxels only (volume.py:27-61: voxels are
+             independent; the oracle's slab form is pinned on the golden sizes by tests/test_oracle_golden.py).
+      leg 2  the whole 512-ray step (GenS.forward's render + Loss + backward, K1 backward in the same graph): every parameter, every volume
+             level and every feature level receives a finite gradient.
+      leg 3  a 32-ray sub-batch of the same step against the oracle: render (samples pinned to the device's), oracle/loss_oracle.py
+             (= loss.py:23-84), backward into the MLPs, the volumes and the feature pyramid (K4's scatter + K1's slab term)."""
+    from gens_amd import ops, synthetic
+    from gens_amd.config import gens_loss_conf
+    from gens_amd.losses import Loss
+    from gens_amd.models.modules.implicit_surface import Scene
+    from oracle import gens_oracle as K
+    from oracle import loss_oracle
+    from oracle import render_oracle as R
+    dims = [256, 128, 64]
+    h, w = 480, 640
+    dev = torch.device("cuda")
+    cpu = synthetic.make_scene(nv=5, h=h, w=w, n_levels=5, seed=50)
+    cpu["features"] = _band_limited(cpu["features"])
+    intrs, c2ws, imgs = cpu["intrs"].to(dev), cpu["c2ws"].to(dev), cpu["imgs"].to(dev)
+    g = torch.Generator().manual_seed(11)
+    ranges = [(124, 132), (40, 56), (0, 64)]
+    cots_c = []
+    for d, (x0, x1) in zip(dims, ranges):
+        c = torch.zeros(1, 8, d, d, d)
+        c[:, :, x0:x1] = torch.randn(1, 8, x1 - x0, d, d, generator=g)
+        cots_c.append(c)
+    cots = [c.to(dev) for c in cots_c]
+
+    # ---- leg 1: K1 at full size against the oracle on the slabs
+    feats = [f.to(dev).requires_grad_(True) for f in cpu["features"]]
+    cost, masks = ops.volume_build(feats[:3], intrs, c2ws, dims)
+    g_k1 = torch.autograd.grad(sum((a * b).sum() for a, b in zip(cost, cots)), feats[:3])
+    feats_c = [f.clone().requires_grad_(True) for f in cpu["features"]]
+    cost_o, masks_o = K.volume_build(feats_c[:3], cpu["intrs"], cpu["c2ws"], dims, x_ranges=ranges)
+    sum((a * c[:, :, x0:x1]).sum() for a, c, (x0, x1) in zip(cost_o, cots_c, ranges)).backward()
+    for i, (x0, x1) in enumerate(ranges):
+        got_m, got_v = masks[i][:, :, x0:x1].cpu(), cost[i][:, :, x0:x1].detach().cpu()
+        # a voxel projecting within an ulp of an image border may flip visibility in one view
+        assert float((got_m != masks_o[i]).float().mean()) <= 1e-4, ("mask", i)
+        bad = (got_v - cost_o[i].detach()).abs() > 5e-5 + 1e-4 * cost_o[i].detach().abs()
+        assert float(bad.float().mean()) <= 1e-4, ("cost volume", i, int(bad.sum()))
+        off, worst = _rel_off(g_k1[i], feats_c[i].grad, 2e-4, 1e-6)
+        print("K1 backward level %d (D = %d, slab %d..%d): worst |diff| %.2e of max %.2e, %.2e of the texels beyond 2e-4 of the max"
+              % (i, dims[i], x0, x1, worst, float(feats_c[i].grad.abs().max()), off))
+        assert off <= 1e-4 and worst <= 5e-3 * float(feats_c[i].grad.abs().max()), (i, off, worst)
+    k1_grads_c = [f.grad.clone() for f in feats_c[:3]]
+    del cost, g_k1
+
+    # ---- leg 2: the whole 512-ray step with the K1 build in the graph
+    surf = _surface(3, dims=dims).cuda().train()
+    vols_cpu = synthetic.make_volumes(dims, seed=51)
+    pix = torch.stack([torch.randint(0, w, (512,), generator=g), torch.randint(0, h, (512,), generator=g)], -1)
+    ro, rd = synthetic.make_rays(cpu["intrs"], cpu["c2ws"], h, w, pixels=pix)
+    pseudo = torch.rand(2048, 3, generator=g) - 0.5
+    near, far = cpu["near"].to(dev), cpu["far"].to(dev)
+    ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": near, "far": far, "pseudo_pts": pseudo.to(dev)}
+    pseudo_depth = torch.where(torch.rand(512, generator=g) < 0.3, torch.zeros(512), 1.0 + 2.0 * torch.rand(512, generator=g))
+    targets_c = {"color": torch.rand(512, 3, generator=g), "pseudo_depth": pseudo_depth}
+    targets = {k: v.to(dev) for k, v in targets_c.items()}
+    loss_fn = Loss(gens_loss_conf()).to(dev)
+    vols = [v.to(dev).requires_grad_(True) for v in vols_cpu]
+    for f in feats:
+        f.grad = None
+    torch.manual_seed(5)
+    cost, masks = ops.volume_build(feats[:3], intrs, c2ws, dims)
+    out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
+    terms = loss_fn(out, targets)
+    assert out["color_fine"].shape == (512, 3) and out["pseudo_sdf"].shape == (2048, 1) and out["sampled_gray_val"].shape == (4, 512, 121, 12)
+    (terms["loss"] + sum((a * b).sum() for a, b in zip(cost, cots))).backward()
+    surf.check_deferred()
+    for k, p in surf.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    for v in vols:
+        assert v.grad is not None and torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) > 0
+    for i, f in enumerate(feats):
+        assert f.grad is not None and torch.isfinite(f.grad).all() and float(f.grad.abs().sum()) > 0, i
+    del out, terms, cost
+
+    # ---- leg 3: a 32-ray sub-batch of that step against the oracle (samples pinned to the device's)
+    nb = 32
+    sub = slice(0, nb)
+    t_rand = torch.rand(nb, 1, generator=g)
+    pts_rand = torch.rand(1024, 3, generator=g) * 2 - 1
+    masks_c = [m.cpu() for m in masks]
+    ok_c = K.point_valid(masks_c, pseudo).reshape(-1)
+    pseudo_ok = pseudo[ok_c]
+    assert 0 < pseudo_ok.shape[0] < 2048 or pseudo_ok.shape[0] == 2048
+    with torch.no_grad():
+        scene = Scene([v.detach() for v in vols], masks, imgs, [f.detach() for f in feats], [f.detach() for f in feats], intrs, c2ws)
+        z0 = ops.coarse_z(near, far, surf._coarse_steps(dev), t_rand.to(dev), nb)
+        z = surf._sample_rays(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z0, scene)
+    for p in surf.parameters():
+        p.grad = None
+    vols_d = [v.detach().clone().requires_grad_(True) for v in vols]
+    feats_d = [f.detach().clone().requires_grad_(True) for f in feats]
+    cost, masks_d = ops.volume_build(feats_d[:3], intrs, c2ws, dims)
+    out = surf.render_core(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z, 2.0 / 64, vols_d, masks_d, feats_d, [f.detach() for f in feats_d],
+                           imgs, intrs, c2ws, 0.5, 1.0, pts_random=pts_rand.to(dev), extra_pts=pseudo_ok.to(dev))
+    out["pseudo_sdf"] = out.pop("_extra_sdf")
+    sub_targets = {k: v[sub] for k, v in targets.items()}
+    terms = loss_fn(out, sub_targets)
+    (terms["loss"] + sum((a * b).sum() for a, b in zip(cost, cots))).backward()
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in surf.state_dict().items()}
+    vols_c = [v.clone().requires_grad_(True) for v in vols_cpu]
+    for f in feats_c:
+        f.grad = None
+    ref = R.render(sd, ro[sub], rd[sub], cpu["near"], cpu["far"], vols_c, masks_c, cpu["imgs"], feats_c, [f.detach() for f in feats_c],
+                   cpu["intrs"], cpu["c2ws"], 0.5, 1.0, t_rand, pts_rand, truncated=True, z=z.cpu())
+    ref["pseudo_sdf"] = R.sdf_mlp(sd, pseudo_ok, vols_c, lookup=K.lookup_volume_truncated)[:, :1]
+    conf = gens_loss_conf()
+    names = ("color_weight", "igr_weight", "sparse_weight", "mfc_weight", "smooth_weight", "tv_weight", "pseudo_sdf_weight", "pseudo_depth_weight",
+             "sparse_scale_factor")
+    ref_terms = loss_oracle.loss(ref, {k: v[sub] for k, v in targets_c.items()}, {k: conf.get_float(k) for k in names})
+    ref_terms["loss"].backward()
+    for k in loss_oracle.TERMS:
+        a, b = float(terms[k]), float(ref_terms[k])
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (k, a, b)
+    assert (out["color_fine"].detach().cpu() - ref["color_fine"].detach()).abs().mean() < 1e-4
+    assert (out["render_depth"].detach().cpu() - ref["render_depth"].detach()).abs().mean() < 1e-4
+    top = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    worst = {}
+    for name, p in surf.named_parameters():
+        r = sd[name].grad
+        worst[name] = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-4 * top)
+    for i, (a, b) in enumerate(zip(vols_d, vols_c)):
+        worst[f"volume{i}"] = float((a.grad.cpu() - b.grad).abs().max()) / max(float(b.grad.abs().max()), 1e-12)
+    for i, (a, b) in enumerate(zip(feats_d, feats_c)):
+        want = b.grad + (k1_grads_c[i] if i < 3 else 0)          # the render's share (K4 scatter) + K1's slab term (leg 1's oracle gradient)
+        off, err = _rel_off(a.grad, want, 2e-3, 1e-12)
+        worst[f"feature{i}"] = err / max(float(want.abs().max()), 1e-12)
+        assert off <= 1e-4, (i, off)
+    print({k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:10]})
+    scalars = {k for k, p in surf.named_parameters() if p.numel() <= 4}
+    print("scalar parameters:", {k: f"{worst[k]:.1e}" for k in scalars})
+    bad = {k: v for k, v in worst.items() if v >= (SCALAR_GRAD_TOL if k in scalars else 5e-3 if k.startswith("feature") else 2e-3)}
     assert not bad, bad

@@ -219,3 +219,56 @@ def test_render_config0_coarsest_volume_only(golden):
     assert torch.equal(out["mid_inside_sphere"], g["out.mid_inside_sphere"][:n])
     close(out["gradients"], g["out.gradients"][:n], atol=5e-4, rtol=1e-3, what="gradients")
     close(out["weights"], g["out.weights"][:n], atol=1e-4, rtol=1e-3, what="weights")
+
+
+def test_k1_volume_slabs_are_slices_of_the_whole_cube(golden):
+    """oracle volume_build(x_ranges=...): the slab form the full-size GPU tests use (256^3 does not fit a CPU test) against the reference's
+    golden volumes, values, masks and the feature gradient of a cotangent that lives on the slabs only."""
+    g = golden("g1b_volume_ms")
+    dims = [int(d) for d in g["dims"]]
+    ranges = [(d // 4, d // 4 + max(2, d // 8)) for d in dims]
+    feats = [g[f"feat{i}"].clone().requires_grad_(True) for i in range(3)]
+    v, m = K.volume_build(feats, g["intrs"], g["c2ws"], dims, x_ranges=ranges)
+    for i, (x0, x1) in enumerate(ranges):
+        close(v[i], g[f"volume{i}"][:, :, x0:x1], what=f"volume{i} slab")
+        assert torch.equal(m[i], g[f"mask{i}"][:, :, x0:x1])
+    sum((a * g[f"cot{i}"][:, :, x0:x1]).sum() for i, (a, (x0, x1)) in enumerate(zip(v, ranges))).backward()
+    whole = [g[f"feat{i}"].clone().requires_grad_(True) for i in range(3)]
+    vw, _ = K.volume_build(whole, g["intrs"], g["c2ws"], dims)
+    cots = []
+    for i, (x0, x1) in enumerate(ranges):
+        c = torch.zeros_like(g[f"cot{i}"])
+        c[:, :, x0:x1] = g[f"cot{i}"][:, :, x0:x1]
+        cots.append(c)
+    sum((a * c).sum() for a, c in zip(vw, cots)).backward()
+    for a, b in zip(feats, whole):
+        close(a.grad, b.grad, atol=1e-6, what="slab gradient")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_loss_oracle_matches_the_reference_loss(tag):
+    """oracle/loss_oracle.py against golden g19: the reference's Loss.forward (models/losses/loss.py:23-84), every term and d loss / d prediction."""
+    import os
+    from oracle import loss_oracle
+    from .conftest import GOLDEN
+    raw = np.load(os.path.join(GOLDEN, "g19_loss.npz"))
+    g = {k[2:]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(tag + ".")}
+    names = ("color_weight", "igr_weight", "sparse_weight", "mfc_weight", "smooth_weight", "tv_weight", "pseudo_sdf_weight", "pseudo_depth_weight",
+             "sparse_scale_factor")
+    weights = {k: float(v) for k, v in zip(names, g["conf"].tolist())}
+    preds = {k[5:]: v for k, v in g.items() if k.startswith("pred.")}
+    targets = {k[7:]: v for k, v in g.items() if k.startswith("target.")}
+    diff = [k[5:] for k in g if k.startswith("grad.")]
+    for k in diff:
+        preds[k] = preds[k].clone().requires_grad_(True)
+    res = loss_oracle.loss(preds, targets, weights)
+    assert tuple(res) == loss_oracle.TERMS
+    for k in loss_oracle.TERMS:
+        a, b = float(res[k]), float(g["out." + k])
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (k, a, b)
+    res["loss"].backward()
+    for k in diff:
+        want = g["grad." + k]
+        got = preds[k].grad if preds[k].grad is not None else torch.zeros_like(want)
+        scale = max(float(want.abs().max()), 1e-12)
+        assert float((got - want).abs().max()) <= 1e-4 * scale + 1e-9, (k, float((got - want).abs().max()), scale)
