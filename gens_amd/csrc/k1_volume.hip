@@ -146,6 +146,7 @@ struct LevelConst {
     float cw, ch;        // (w - 1) / 2, (h - 1) / 2
     float rcw, rch;      // RN(1 / cw), RN(1 / ch)
     int log2d;
+    int no_shortcut;     // (A/B switch GENS_K1_NO_EMPTY_SHORTCUT: tiles no view reaches take the general path too)
 };
 
 template <bool PRESCALED>
@@ -280,6 +281,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // The exact per-voxel test below still decides visibility; the intervals only have to be supersets, and the bit-for-bit
     // comparisons with the unculled kernels check that they are.
     __shared__ int2 row_span[32][K1_FAST_VIEWS];
+    int seen = 0;                                                                 // this thread's (row, view) pair has a span
     {
         const int rows = tiled ? 4 : 256 >> lc.log2d;                             // z-rows the workgroup touches (d <= 256)
         const int r = threadIdx.x >> 3, v = threadIdx.x & 7;
@@ -315,9 +317,33 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
             span.y = min((int)ceilf(hi * (float)(d - 1)) + 2, d - 1);
             if (empty) span = make_int2(1, 0);
             row_span[r][v] = span;
+            seen = span.x <= span.y;
         }
     }
-    __syncthreads();
+    // (the barrier that publishes the spans also tells every wave whether ANY (row, view) pair of the workgroup's tile has one)
+    if (!__syncthreads_or(seen | lc.no_shortcut)) {
+        // No view reaches any voxel of the tile -- more than half of the tiles at the benchmark geometry (five 31 x 23 degree frusta
+        // cover a third of the cube): mean = var = mask = count = +0, exactly what the general path computes for cnt = 0
+        // (div_rn(0, 1e-8, y) = +0, 0 - 0 * 0 = +0), stored straight from registers: no view loop, no divisions, no staging,
+        // no second barrier.  185.8 -> 178.2 us at 256^3 (42.3 -> 44.1 % of the HBM peak by algorithmic bytes, back-to-back launches;
+        // scripts/probe/k1_fwd_ab.py).  The same test per WAVE inside the other tiles (skip the divisions of 64 unseen voxels) measured
+        // nothing (179.4): their waves wait at the staging barrier for the slowest anyway.
+        const uint32_t plane = (uint32_t)d << (2 * lc.log2d + 2);
+        const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc((void*)vol, 0, (int)(8u * plane), 0x00020000);
+        const __amdgpu_buffer_rsrc_t mplane = __builtin_amdgcn_make_buffer_rsrc((void*)mask, 0, (int)plane, 0x00020000);
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 zero = {0u, 0u, 0u, 0u};
+        const uint32_t q = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t off = tiled ? ((((t_ix0 + (q >> 4)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 15u) << 2))) << 2) : chunk * 1024u + q * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(zero, planes, off, wave * plane, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(zero, planes, off, (wave + 4u) * plane, 2);
+        if (wave == 0) __builtin_amdgcn_raw_buffer_store_b128(zero, mplane, off, 0u, 2);
+        if (count && wave == 1 && q < 16u) {
+            const uint32_t at = tiled ? (((t_ix0 + (q >> 2)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 3u) << 4))) : chunk * 256u + q * 16u;
+            *(u4*)(count + at) = zero;
+        }
+        return;
+    }
     const int my_row = tiled ? (int)t_row : (int)(threadIdx.x >> lc.log2d);
     // torch.linspace(-1, 1, d)[i]: lower half counts up from the start, upper half down from the end
     const float x = ix < half ? -1.0f + lc.step * (float)ix : 1.0f - lc.step * (float)(d - 1 - ix);
@@ -608,6 +634,7 @@ static LevelConst level_const(int h, int w, int d) {      // the float32 operati
     lc.rch = 1.0f / lc.ch;
     lc.log2d = 0;
     while ((1 << lc.log2d) < d) ++lc.log2d;
+    lc.no_shortcut = getenv("GENS_K1_NO_EMPTY_SHORTCUT") != nullptr;
     return lc;
 }
 
