@@ -29,6 +29,50 @@ static inline int gens_launch_status(const char* what) {
 
 static inline unsigned gens_blocks(int64_t work, int per_block) { return (unsigned)((work + per_block - 1) / per_block); }
 
+// Kernels that need more LDS than the 64 KB a launch gets by default opt in with hipFuncSetAttribute -- which acts on the CURRENT device's
+// copy of the function.  Done once per (kernel, device): a bit per device, set after the call succeeded (setting it twice from two threads is
+// harmless); a refusal is an error of the entry point, not a launch that fails later.
+#include <atomic>
+struct GensLdsOptIn {
+    std::atomic<uint64_t> done{0};
+};
+static inline int gens_lds_opt_in(GensLdsOptIn& state, const void* kernel, int bytes, const char* who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) {
+        gens_set_error("%s: no usable current device (hipGetDevice -> %d; at most 64 devices per process)", who, dev);
+        (void)hipGetLastError();
+        return GENS_EINVAL;
+    }
+    const uint64_t bit = 1ull << dev;
+    if (state.done.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        gens_set_error("%s: device %d does not grant %d bytes of LDS to one workgroup", who, dev, bytes);
+        return GENS_ELIMIT;
+    }
+    state.done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
+// The hardware-id fields the stash slots of K6g / K6gh are built from (HW_REG_HW_ID: SIMD [5:4], CU [11:8], SE [15:13]; HW_REG_XCC_ID [2:0])
+// are gfx950's; another target needs its own decode (the slot index is masked into range and every slot is guarded by a lock word, so a
+// wrong decode costs speed, never correctness -- but it must not go unnoticed).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgens_hip is written for gfx950 (MI355X): the hardware-id decode of the K6g / K6gh stash slots and the MFMA shapes are that target's"
+#endif
+
+// Bounded wait for a stash slot's lock word: a slot is always found free unless two waves were mapped to one slot (another partition mode: a
+// few sleeps) or an earlier launch died holding it (nothing will ever free it: trap, so that the host sees a failed launch instead of a hang;
+// gens_sdf_grad*_stash_reset re-zeroes the stash afterwards).  ~2^22 x s_sleep(32) is seconds.
+__device__ __forceinline__ void gens_lock_slot(uint32_t* lock, uint32_t seen) {
+    uint32_t tries = 0;
+    while (seen != 0u) {
+        __builtin_amdgcn_s_sleep(32);
+        seen = atomicCAS(lock, 0u, 1u);
+        if (++tries > (1u << 22)) __builtin_trap();
+    }
+}
+
 // Up to GENS_MAX_LEVELS volumes / maps passed by value in the kernel argument block (scalar loads, no indirection
 // through HBM).
 struct LevelSet {

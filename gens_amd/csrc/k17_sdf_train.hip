@@ -987,18 +987,12 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
     const unsigned grid = gens_blocks(n, TR_M);
     hipStream_t s = (hipStream_t)stream;
     if (n_levels == 3) {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<60>());
-            once = true;
-        }
+        static GensLdsOptIn lds;
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_fwd_k<60>, (int)fwd_lds_bytes<60>(), "gens_sdf_train_fwd")) return e;
         sdf_train_fwd_k<60><<<grid, 256, fwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
     } else {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void*)sdf_train_fwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes<100>());
-            once = true;
-        }
+        static GensLdsOptIn lds;
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_fwd_k<100>, (int)fwd_lds_bytes<100>(), "gens_sdf_train_fwd")) return e;
         sdf_train_fwd_k<100><<<grid, 256, fwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
     }
     return gens_launch_status("gens_sdf_train_fwd");
@@ -1020,18 +1014,12 @@ extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* di
     SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, w6_part, (int64_t)grid * TR_M};
     hipStream_t s = (hipStream_t)stream;
     if (n_levels == 3) {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<60>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<60>());
-            once = true;
-        }
+        static GensLdsOptIn lds;
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_bwd_k<60>, (int)bwd_lds_bytes<60>(), "gens_sdf_train_bwd")) return e;
         sdf_train_bwd_k<60><<<grid, 256, bwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
     } else {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void*)sdf_train_bwd_k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<100>());
-            once = true;
-        }
+        static GensLdsOptIn lds;
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_bwd_k<100>, (int)bwd_lds_bytes<100>(), "gens_sdf_train_bwd")) return e;
         sdf_train_bwd_k<100><<<grid, 256, bwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
     }
     return gens_launch_status("gens_sdf_train_bwd");

@@ -557,13 +557,10 @@ static int bt_launch(const char* who, const float* const* feats, const int* hw, 
     const int ppw = 32 / (nv - 1);
     const unsigned grid = gens_blocks(io.n, ppw);
     hipStream_t st = (hipStream_t)stream;
-    static bool once[6][2] = {};
+    static GensLdsOptIn once[6][2];
 #define BT_LAUNCH(NL)                                                                                                              \
     {                                                                                                                              \
-        if (!once[NL][BWD]) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)blend_train_k<NL, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_lds_bytes()); \
-            once[NL][BWD] = true;                                                                                                  \
-        }                                                                                                                          \
+        if (int e_ = gens_lds_opt_in(once[NL][BWD], (const void*)blend_train_k<NL, BWD>, (int)bt_lds_bytes(), "gens_blend_train")) return e_; \
         blend_train_k<NL, BWD><<<grid, BT_THREADS, bt_lds_bytes(), st>>>(W, fs, io);                                                       \
     }
     switch (n_levels) {

@@ -1294,12 +1294,8 @@ extern "C" int gens_volume_build_bwd_levels(const float* const* feat, const int*
         a.lv[l].gvol = g_volumes[l];
         a.lv[l].gfeat = g_feat[l];
     }
-    static bool lds_set = false;                                                    // (the window is more than the 64 KB a kernel gets by default)
-    if (!lds_set) {
-        if (hipFuncSetAttribute((const void*)volume_bwd_tiles_k, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES) != hipSuccess)
-            return gens_launch_status("gens_volume_build_bwd_levels");
-        lds_set = true;
-    }
+    static GensLdsOptIn lds_set;                                                    // (the window is more than the 64 KB a kernel gets by default)
+    if (int e = gens_lds_opt_in(lds_set, (const void*)volume_bwd_tiles_k, BL_LDS_BYTES, "gens_volume_build_bwd_levels")) return e;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a.count, 0, (char*)a.offset - (char*)a.count, st) != hipSuccess) return gens_launch_status("gens_volume_build_bwd_levels");
     volume_bwd_plan_k<<<a.plan_blocks, 256, 0, st>>>(a, w2c);

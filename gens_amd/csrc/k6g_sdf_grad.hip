@@ -106,8 +106,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     const uint32_t slot = ((((xcc_id & 7u) << 2 | ((hw_id >> 13) & 3u)) << 4 | ((hw_id >> 8) & 15u)) << 2) | ((hw_id >> 4) & 3u);
     float4* const stash_slot = stash_all + (size_t)slot * TG_SLOT_F4;
     uint32_t* const lock = (uint32_t*)(stash_slot + 16 * 64);
-    if (lane == 0)
-        while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(32);
+    if (lane == 0) gens_lock_slot(lock, atomicCAS(lock, 0u, 1u));
     // (a buffer descriptor: the slot's base in SGPRs, 16 lane in ONE VGPR, the register's offset as a scalar -- no vector address arithmetic)
     const __amdgpu_buffer_rsrc_t stash = __builtin_amdgcn_make_buffer_rsrc((void*)stash_slot, 0, 16 * 64 * 16, 0x00020000);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -488,6 +487,12 @@ extern "C" int gens_sdf_grad_groups(int n_levels) {
 }
 
 extern "C" int64_t gens_sdf_grad_stash_bytes(void) { return (int64_t)TG_SLOTS * TG_SLOT_F4 * 16; }
+
+extern "C" int gens_sdf_grad_stash_reset(void* stash, void* stream) {
+    GENS_CHECK_ARG(stash, GENS_EINVAL, "gens_sdf_grad_stash_reset: null stash");
+    if (hipMemsetAsync(stash, 0, (size_t)gens_sdf_grad_stash_bytes(), (hipStream_t)stream) != hipSuccess) return gens_launch_status("gens_sdf_grad_stash_reset");
+    return 0;
+}
 
 extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
                              float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,

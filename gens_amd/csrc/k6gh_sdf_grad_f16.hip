@@ -230,11 +230,7 @@ __global__ __launch_bounds__(64 * GH_WAVES, 1) void sdf_grad_h_k(LevelSet vols, 
                 jl[3 * ch] = ax[c]; jl[3 * ch + 1] = ay[c]; jl[3 * ch + 2] = az[c];
             }
         }
-        if (lane == 0)
-            while (lock_seen != 0u) {
-                __builtin_amdgcn_s_sleep(32);
-                lock_seen = atomicCAS(lock, 0u, 1u);
-            }
+        if (lane == 0) gens_lock_slot(lock, lock_seen);
 #pragma unroll
         for (int k = 0; k < 3 * NCH; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, jl[k]), stash, jl_lane + (uint32_t)k * 256u, 0, 0);
         float e[8 * NC];
@@ -512,6 +508,13 @@ extern "C" int gens_sdf_grad_f16_pieces(int n_levels) {
 
 extern "C" int64_t gens_sdf_grad_f16_stash_bytes(void) { return (int64_t)GH_SLOTS * GH_SLOT_BYTES; }
 
+extern "C" int gens_sdf_grad_f16_stash_reset(void* stash, void* stream) {
+    GENS_CHECK_ARG(stash, GENS_EINVAL, "gens_sdf_grad_f16_stash_reset: null stash");
+    if (hipMemsetAsync(stash, 0, (size_t)gens_sdf_grad_f16_stash_bytes(), (hipStream_t)stream) != hipSuccess)
+        return gens_launch_status("gens_sdf_grad_f16_stash_reset");
+    return 0;
+}
+
 extern "C" int gens_sdf_grad_f16(const float* const* vols_packed, const int* dims, int n_levels, const void* pieces, const float* w_out,
                                  float b_last, float scale, float g_scale, const float* pts, const int64_t* index, int64_t n,
                                  const int32_t* n_device, float* sdf_out, float* grad_out, void* stash, int* overflow_flag, void* stream) {
@@ -525,16 +528,10 @@ extern "C" int gens_sdf_grad_f16(const float* const* vols_packed, const int* dim
     GENS_CHECK_ARG(stash && ((uintptr_t)stash & 15) == 0, GENS_EINVAL,
                    "gens_sdf_grad_f16: null or misaligned stash (gens_sdf_grad_f16_stash_bytes() bytes, zeroed once)");
     if (n == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sdf_grad_h_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)sdf_grad_h_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            gens_set_error("gens_sdf_grad_f16: the device does not grant %d bytes of LDS to one workgroup", GH_LDS_BYTES);
-            return GENS_ELIMIT;
-        }
-        attr_set = true;
-    }
+    static GensLdsOptIn lds3, lds5;
+    if (int e = n_levels == 3 ? gens_lds_opt_in(lds3, (const void*)sdf_grad_h_k<3>, GH_LDS_BYTES, "gens_sdf_grad_f16")
+                              : gens_lds_opt_in(lds5, (const void*)sdf_grad_h_k<5>, GH_LDS_BYTES, "gens_sdf_grad_f16"))
+        return e;
     const unsigned grid = gens_blocks(n, 32 * GH_WAVES);
     if (n_levels == 3)
         sdf_grad_h_k<3><<<grid, 64 * GH_WAVES, GH_LDS_BYTES, (hipStream_t)stream>>>(vs, (const char*)pieces, w_out, b_last, scale, 1.0f / scale, g_scale,

@@ -124,6 +124,8 @@ SIGNATURES = {
     "gens_sdf_train_scatter": [_ip, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _pp, _p],
     "gens_scene_setup": [_p, _p, _i, _p, _p],
     "gens_coarse_z": [_p, _p, _i, _p, _p, _l, _i, _p, _p],
+    "gens_sdf_grad_stash_reset": [_p, _p],
+    "gens_sdf_grad_f16_stash_reset": [_p, _p],
     "gens_blend_train_wgrad": [_p, _p, _i, _p, _i, _pp, _p],
     "gens_loss_fwd": [_p, _p],
     "gens_loss_bwd": [_p, _p],

@@ -56,6 +56,17 @@ def sdf_grad_stash(device):
     return buf
 
 
+def reset_sdf_grad_stashes():
+    """Re-zero every stash of this process on the current stream (gens_sdf_grad_stash_reset / gens_sdf_grad_f16_stash_reset): the lock words of
+    slots a failed launch may have left taken.  A wave that finds its slot taken waits a bounded time and traps -- a loud failure, not a hang."""
+    for key, buf in _SDF_GRAD_STASH.items():
+        with torch.cuda.device(key):
+            L.call("gens_sdf_grad_stash_reset", L.ptr(buf, torch.uint8), L.stream())
+    for key, buf in _SDF_GRAD_F16_STASH.items():
+        with torch.cuda.device(key):
+            L.call("gens_sdf_grad_f16_stash_reset", L.ptr(buf, torch.uint8), L.stream())
+
+
 _SDF_GRAD_F16_STASH = {}
 
 

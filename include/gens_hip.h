@@ -284,6 +284,9 @@ int gens_sdf_grad(const float* const* vols_packed, const int* dims, int n_levels
                   float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
                   float* sdf_out, float* grad_out, void* stash, void* stream);
 int64_t gens_sdf_grad_stash_bytes(void);
+/* Re-zero the stash (its lock words) on `stream`: after a launch that died holding a slot -- a wave that finds its slot taken waits a
+ * bounded time (seconds) and then traps, so that the host sees a failed launch instead of a hang. */
+int gens_sdf_grad_stash_reset(void* stash, void* stream);
 /* number of 4 KB groups in the weight stream of gens_sdf_grad, without the trailing zero groups (0 = unsupported level count) */
 int gens_sdf_grad_groups(int n_levels);
 
@@ -318,6 +321,7 @@ int gens_sdf_grad_f16(const float* const* vols_packed, const int* dims, int n_le
                       float b_last, float scale, float g_scale, const float* pts, const int64_t* index, int64_t n,
                       const int32_t* n_device, float* sdf_out, float* grad_out, void* stash, int* overflow_flag, void* stream);
 int64_t gens_sdf_grad_f16_stash_bytes(void);
+int gens_sdf_grad_f16_stash_reset(void* stash, void* stream);      /* as gens_sdf_grad_stash_reset */
 /* number of 1 KB pieces in the weight stream of gens_sdf_grad_f16, padding included (0 = unsupported level count) */
 int gens_sdf_grad_f16_pieces(int n_levels);
 
