@@ -125,6 +125,9 @@ SIGNATURES = {
     "gens_scene_setup": [_p, _p, _i, _p, _p],
     "gens_coarse_z": [_p, _p, _i, _p, _p, _l, _i, _p, _p],
     "gens_sdf_grad_stash_reset": [_p, _p],
+    "gens_grid_sample_fwd": [_p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p],
+    "gens_grid_sample_bwd": [_p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p],
+    "gens_grid_sample_bwd2": [_p, _p, _p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p, _p],
     "gens_sdf_grad_f16_stash_reset": [_p, _p],
     "gens_blend_train_wgrad": [_p, _p, _i, _p, _i, _pp, _p],
     "gens_loss_fwd": [_p, _p],

@@ -326,6 +326,27 @@ int gens_sdf_grad_f16_stash_reset(void* stash, void* stream);      /* as gens_sd
 int gens_sdf_grad_f16_pieces(int n_levels);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K20  the reference's sampler boundary in full generality (k20_grid_sample.hip): what cuda_gridsample.py:7-14 exports and K2 does not
+ *      cover -- grid_sample_2d, padding_mode 'border', align_corners=False, batches, channel counts that are not multiples of four.
+ *     forward            F.grid_sample(bilinear) = aten::grid_sampler_2d / _3d        (cuda_gridsample.py:28, 79)
+ *     backward           aten::grid_sampler_2d_backward / _3d_backward                 (cuda_gridsample.py:38-50, 94-108)
+ *     backward-backward  gridsample_grad2.grad2_2d / grad2_3d                          (gridsample_cuda.cpp:26-56, gridsample_cuda.cu:27-533)
+ *   ndim      2 or 3;  in_size HOST int[ndim]: the input's spatial shape, slowest axis first ((H, W) or (D, H, W))
+ *   input     (n, c, *in_size) contiguous float32 (the reference's NCHW / NCDHW);  grid (n, n_out, ndim), last axis (x, y[, z]) -> (W, H[, D])
+ *   out / grad_out / gg_out  (n, c, n_out);  grad_grid / gg_grid (n, n_out, ndim)
+ *   padding_mode  0 = 'zeros', 1 = 'border' (the two the reference asserts, cuda_gridsample.py:8,13; it passes the index, :32,83)
+ *   grad_input    like input, ACCUMULATES (float atomics): zero it first, as the reference does (gridsample_cuda.cu:553-555, 620-622); NULL = not
+ *                 wanted (bwd) / the reference's unused output (bwd2).  gg_input: like input or NULL (`grad2_grad_input is None`, :113-114).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_grid_sample_fwd(const float* input, const float* grid, int ndim, int n, int c, const int* in_size, int64_t n_out,
+                         int padding_mode, int align_corners, float* out, void* stream);
+int gens_grid_sample_bwd(const float* grad_out, const float* input, const float* grid, int ndim, int n, int c, const int* in_size,
+                         int64_t n_out, int padding_mode, int align_corners, float* grad_input, float* grad_grid, void* stream);
+int gens_grid_sample_bwd2(const float* gg_input, const float* gg_grid, const float* grad_out, const float* input, const float* grid,
+                          int ndim, int n, int c, const int* in_size, int64_t n_out, int padding_mode, int align_corners,
+                          float* gg_out, float* grad_input, float* grad_grid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K17  the SDF network of a training / fine-tune step: value, gradient, `smooth` vector and the loss backward
  *      (sdf_network.py:98-154: SDFNetwork.sdf, SDFNetwork.gradient with create_graph twice; their autograd backward under
  *      loss.backward(); call sites implicit_surface.py:179-191,257,305,490; sampler Function pair cuda_gridsample.py:71-123,
