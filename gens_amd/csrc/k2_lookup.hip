@@ -16,6 +16,8 @@
 // every call (gridsample_cuda.cu:620-622, cuda_gridsample.py:113-114).
 //
 // Axis convention (Q1): p = (px,py,pz) reads element [ix(px)][iy(py)][iz(pz)]; align_corners=True, zeros padding.
+#include <stdlib.h>
+
 #include "common.h"
 
 template <int LAYOUT>
@@ -70,8 +72,14 @@ __device__ __forceinline__ Cell axis_cell(float p, int size) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void lookup_fwd_k(LevelSet vs, const float* __restrict__ pts, int64_t n,
-                                                    float4* __restrict__ out) {
-    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                    float4* __restrict__ out, int xcd_remap) {
+    // (XCD x takes the x-th contiguous eighth of the blocks: neighbouring points then share their texel lines in ONE L2; see k4_feature.hip)
+    uint32_t blk = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t per = gridDim.x >> 3;
+        if (blk < 8u * per) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    int64_t gid = (int64_t)blk * 256 + threadIdx.x;
     int L = vs.n;
     if (gid >= n * L) return;
     int l = (int)(gid % L);
@@ -286,8 +294,20 @@ __global__ __launch_bounds__(256) void ray_points_k(const float* __restrict__ ra
                                                     uint8_t* __restrict__ valid) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    int64_t r = i / n;
-    int j = (int)(i % n);
+    int64_t r;
+    int j;
+    if ((n & (n - 1)) == 0) {                           // 64 coarse / 128 final samples: a shift and a mask instead of two 64-bit divisions
+        const int sh = __builtin_ctz((unsigned)n);      // (the divisions were most of this kernel's instructions)
+        r = i >> sh;
+        j = (int)(i & (int64_t)(n - 1));
+    } else if (total < ((int64_t)1 << 31)) {
+        const uint32_t iu = (uint32_t)i, q = iu / (uint32_t)n;
+        r = q;
+        j = (int)(iu - q * (uint32_t)n);
+    } else {
+        r = i / n;
+        j = (int)(i % n);
+    }
     float t = z[i];
     if (mid) {
         float dist = (j + 1 < n) ? z[i + 1] - t : sample_dist;               // (Q10)
@@ -442,7 +462,7 @@ extern "C" int gens_lookup_volume_fwd(const float* const* vols, const int* dims,
     GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_fwd: bad layout %d", layout);
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out)), GENS_EINVAL, "gens_lookup_volume_fwd: null pts/out");
     if (n == 0) return 0;
-    DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out);
+    DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out, (int)(getenv("GENS_NO_XCD_REMAP") == nullptr));
     return gens_launch_status("gens_lookup_volume_fwd");
 }
 

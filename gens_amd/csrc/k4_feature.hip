@@ -10,6 +10,8 @@
 //
 // Quirks kept: no epsilon in the perspective divide and the half-open pixel test (Q3); coordinates are normalised
 // with (W-1)/2 but READ with align_corners=False, i.e. pixel = ((g+1)*W-1)/2 (Q6).
+#include <stdlib.h>
+
 #include "common.h"
 
 #include "k4_common.h"
@@ -21,12 +23,24 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
                                                                  const float* __restrict__ w2c, const float* __restrict__ intr,
                                                                  const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
                                                                  int64_t n, float* __restrict__ out, float4* __restrict__ ray_diff,
-                                                                 uint8_t* __restrict__ vis) {
-    extern __shared__ float row_lds[];  // K4_BLOCK rows of `row` floats, row stride padded to an odd count
+                                                                 uint8_t* __restrict__ vis, int plain_copy, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];  // K4_BLOCK rows of `row` floats, row stride padded to an odd count
     const int S = nv - 1;
     const int row = 3 + 4 * fs.n;
     const int stride = row | 1;
-    int64_t gid = (int64_t)blockIdx.x * K4_BLOCK + threadIdx.x;
+    // Workgroups are dealt to the eight XCDs round robin: with block b = its launch index, neighbouring points (consecutive samples of a ray,
+    // neighbouring rays) read their shared texel lines through eight different L2s.  xcd_remap (probe switch GENS_K4_XCD_REMAP): XCD x takes
+    // the x-th CONTIGUOUS eighth of the blocks instead (b % 8 = XCD is a placement hint, not a contract: any mapping is correct).  Measured
+    // (scripts/probe/gather_ab.py, 3.8 M points x 4 views): 686 us against 664 without -- this kernel is bound by its 1.7 GB of row stores
+    // and its arithmetic, not by texel traffic, and the contiguous order serialises the store streams of an XCD; OFF.  The same remap in K2's
+    // forward (texel-bound) gains 3 % and is on.
+    const uint32_t nb = gridDim.x;
+    uint32_t blk = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t per = nb >> 3;                      // blocks [0, 8 per) are remapped, the remainder keeps its place
+        if (blk < 8u * per) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    int64_t gid = (int64_t)blk * K4_BLOCK + threadIdx.x;
     int64_t total = n * S;
     float* mine = row_lds + threadIdx.x * stride;
     if (gid < total) {
@@ -65,12 +79,22 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
         ray_diff[gid] = make_float4(dx / dn, dy / dn, dz / dn, rx * sx + ry * sy + rz * sz);
     }
     __syncthreads();
-    // cooperative, coalesced write of this block's rows
-    int64_t first = (int64_t)blockIdx.x * K4_BLOCK;
+    // cooperative, coalesced write of this block's rows.  3 + 4 L is odd, so the padded stride IS the row length: the block's rows are one
+    // contiguous span in LDS and in the output (which starts 16-byte aligned: 256 rows are a multiple of 16 bytes) -- copied as float4 with
+    // streaming stores (the texels, not these rows, are what should stay in L2); the element-wise loop this replaces spent a division and a
+    // remainder by `row` per float (23 trips per thread at five levels: as many instructions as the look-up itself).
+    int64_t first = (int64_t)blk * K4_BLOCK;
     int rows_here = (int)min((int64_t)K4_BLOCK, total - first);
     int span = rows_here * row;
     float* dst = out + first * row;
-    for (int e = threadIdx.x; e < span; e += K4_BLOCK) dst[e] = row_lds[(e / row) * stride + (e % row)];
+    if (plain_copy) {
+        for (int e = threadIdx.x; e < span; e += K4_BLOCK) dst[e] = row_lds[(e / row) * stride + (e % row)];
+        return;
+    }
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int quads = span >> 2;
+    for (int e = threadIdx.x; e < quads; e += K4_BLOCK) __builtin_nontemporal_store(((const f4v*)row_lds)[e], (f4v*)dst + e);
+    for (int e = 4 * quads + threadIdx.x; e < span; e += K4_BLOCK) dst[e] = row_lds[e];
 }
 
 // Backward of the look-up: the bilinear taps of every (point, source view, level) scattered into the maps' gradients.  Bound by the float
@@ -152,7 +176,8 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
     int row = 3 + 4 * n_levels;
     size_t lds = (size_t)K4_BLOCK * (row | 1) * sizeof(float);
     lookup_feature_fwd_k<<<gens_blocks(n * (nv - 1), K4_BLOCK), K4_BLOCK, lds, (hipStream_t)stream>>>(
-        fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis);
+        fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, getenv("GENS_K4_PLAIN_COPY") != nullptr,
+        getenv("GENS_K4_XCD_REMAP") != nullptr);
     return gens_launch_status("gens_lookup_feature_fwd");
 }
 
