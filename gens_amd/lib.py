@@ -125,6 +125,10 @@ SIGNATURES = {
     "gens_scene_setup": [_p, _p, _i, _p, _p],
     "gens_coarse_z": [_p, _p, _i, _p, _p, _l, _i, _p, _p],
     "gens_sdf_grad_stash_reset": [_p, _p],
+    "gens_depthwise_conv2d_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "gens_depthwise_conv2d_dgrad": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "gens_depthwise_conv2d_wgrad_parts": [_i, _i, _i, _i, _i, _i],
+    "gens_depthwise_conv2d_wgrad": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "gens_grid_sample_fwd": [_p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p],
     "gens_grid_sample_bwd": [_p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p],
     "gens_grid_sample_bwd2": [_p, _p, _p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p, _p],

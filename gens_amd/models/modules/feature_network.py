@@ -12,11 +12,28 @@ inverted residuals (out, kernel, stride, expansion, repeats) = (24,3,2,3,3) (40,
 the wiring around it is pinned by tests/golden/g16_backbones.npz.  Weights: random initialisation (there is no network for the ImageNet
 checkpoint); training / validation load theirs from the run's checkpoint as the reference does (runner.py:80).
 
-Dense convolutions: MIOpen's territory, no hand-written kernel here -- the module exists so that `GenS(confs)` runs without the reference
-tree on sys.path (gens_amd.models.gens._backbone)."""
+Dense convolutions: MIOpen's territory -- the module exists so that `GenS(confs)` runs without the reference tree on sys.path
+(gens_amd.models.gens._backbone).  The DEPTH-WISE convolutions are the exception: MIOpen has no tuned solver for them on gfx950 and runs its
+naive kernels (3.9 ms of a 41 ms training step); `DepthwiseConv2d` is an nn.Conv2d (same parameter, same state-dict key) whose forward goes to
+K21 (gens_depthwise_conv2d_*, csrc/k21_depthwise.hip) whenever the call is one K21 covers -- float32 on the device, k in {3, 5}, stride in
+{1, 2}, padding k // 2 -- and to nn.Conv2d's own forward otherwise (CPU tensors, other dtypes: PyTorch's convolution, as before)."""
+import os
+
 import torch.nn as nn
 
 _BN_MOMENTUM = 1 - 0.9997
+
+
+class DepthwiseConv2d(nn.Conv2d):
+    """nn.Conv2d(c, c, k, padding=k // 2, stride=s, groups=c, bias=False) on K21 where it applies."""
+
+    use_k21 = os.environ.get("GENS_NO_K21") is None          # (switch for A/B measurements and for the test that compares the two paths)
+
+    def forward(self, x):
+        from ... import ops
+        if self.use_k21 and ops.depthwise_supported(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups):
+            return ops.depthwise_conv2d(x, self.weight, self.stride[0])
+        return super().forward(x)
 
 
 class _InvertedResidual(nn.Module):
@@ -29,7 +46,7 @@ class _InvertedResidual(nn.Module):
         self.apply_residual = cin == cout and stride == 1
         self.layers = nn.Sequential(
             nn.Conv2d(cin, mid, 1, bias=False), nn.BatchNorm2d(mid, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-            nn.Conv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False),
+            DepthwiseConv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False),
             nn.BatchNorm2d(mid, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
             nn.Conv2d(mid, cout, 1, bias=False), nn.BatchNorm2d(cout, momentum=_BN_MOMENTUM))
 
@@ -46,7 +63,7 @@ def _mnasnet_trunk():
     """The first 14 children of torchvision's `MNASNet(alpha=1.0).layers` (the reference uses [0:14], :59-63)."""
     layers = [
         nn.Conv2d(3, 32, 3, padding=1, stride=2, bias=False), nn.BatchNorm2d(32, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-        nn.Conv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), nn.BatchNorm2d(32, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
+        DepthwiseConv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), nn.BatchNorm2d(32, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
         nn.Conv2d(32, 16, 1, padding=0, stride=1, bias=False), nn.BatchNorm2d(16, momentum=_BN_MOMENTUM),
         _stack(16, 24, 3, 2, 3, 3), _stack(24, 40, 5, 2, 3, 3), _stack(40, 80, 5, 2, 6, 3),
         _stack(80, 96, 3, 1, 6, 2), _stack(96, 192, 5, 2, 6, 4), _stack(192, 320, 3, 1, 6, 1)]

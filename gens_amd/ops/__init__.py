@@ -15,6 +15,7 @@ is what it was when ops was one module:
     ops.gemm      K14: a^T b for tall operands, the weight-gradient product of the training step.
     ops.conv3d    K15 / K16: the 3 x 3 x 3 convolutions and the instance norm + ReLU of the cost-volume U-Net.
     ops.blend     K7 (fused source-view look-up + BlendingNetwork in inference) and K18 (the same for a training step).
+    ops.conv2d    K21: the depth-wise 2-D convolutions of the MnasNet trunk.
 """
 from .base import *  # noqa: F401,F403
 from .volume import *  # noqa: F401,F403
@@ -25,3 +26,4 @@ from .sdf import *  # noqa: F401,F403
 from .gemm import *  # noqa: F401,F403
 from .conv3d import *  # noqa: F401,F403
 from .blend import *  # noqa: F401,F403
+from .conv2d import *  # noqa: F401,F403

@@ -326,6 +326,21 @@ int gens_sdf_grad_f16_stash_reset(void* stash, void* stream);      /* as gens_sd
 int gens_sdf_grad_f16_pieces(int n_levels);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K21  depth-wise 2-D convolutions of the MnasNet trunk (k21_depthwise.hip): nn.Conv2d(c, c, k, padding = k / 2, stride, groups = c,
+ *      bias = False) with k in {3, 5}, stride in {1, 2} -- torchvision's MNASNet layers used by feature_network_mnasnet.py:53-103 -- for which
+ *      MIOpen falls back to its naive kernels on gfx950.  NCHW float32, contiguous.
+ *   in (n, c, h, w), weight (c, 1, k, k), out / grad_out (n, c, oh, ow) with oh = (h + 2 (k / 2) - k) / stride + 1 (ow likewise).
+ *   wgrad: partial (gens_depthwise_conv2d_wgrad_parts(...), c, k, k) receives per-slice sums; the weight gradient is their sum over axis 0
+ *   in slice order (deterministic).  Other kernel sizes / strides: GENS_ELIMIT (the caller keeps its own convolution for those).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gens_depthwise_conv2d_fwd(const float* in, const float* weight, int n, int c, int h, int w, int k, int stride, float* out, void* stream);
+int gens_depthwise_conv2d_dgrad(const float* grad_out, const float* weight, int n, int c, int h, int w, int k, int stride, float* grad_in,
+                                void* stream);
+int gens_depthwise_conv2d_wgrad_parts(int n, int c, int h, int w, int k, int stride);
+int gens_depthwise_conv2d_wgrad(const float* in, const float* grad_out, int n, int c, int h, int w, int k, int stride, float* partial,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K20  the reference's sampler boundary in full generality (k20_grid_sample.hip): what cuda_gridsample.py:7-14 exports and K2 does not
  *      cover -- grid_sample_2d, padding_mode 'border', align_corners=False, batches, channel counts that are not multiples of four.
  *     forward            F.grid_sample(bilinear) = aten::grid_sampler_2d / _3d        (cuda_gridsample.py:28, 79)
