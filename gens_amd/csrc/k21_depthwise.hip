@@ -16,6 +16,8 @@
 //   wgrad     dw[c][ky][kx]     = sum_{n,oy,ox} dout[n][c][oy][ox] in[n][c][s oy + ky - p][s ox + kx - p]
 // wgrad: a workgroup owns a channel and a slice of its n * OH * OW outputs, every thread keeps the k^2 partial sums in registers, the wave and
 // then the workgroup reduce them, and the slices' partials (parts, C, k^2) are added by the caller in slice order (deterministic: no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 struct DwGeom {
@@ -51,19 +53,86 @@ __global__ __launch_bounds__(256) void dw_fwd_k(DwGeom g, const float* __restric
     const float* ip = in + (int64_t)plane * g.h * g.w;
     const float* wp = wt + c * K * K;
     const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
-    float acc = 0.0f;
+    // branch-free taps: every load is issued (from an index clamped into the plane) before the first multiply-add needs one -- K^2 independent
+    // loads in flight instead of K^2 load-use pairs under their own exec masks; a tap in the zero padding contributes an exact 0
+    float v[K * K];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int iy = iy0 + ky;
-        if ((unsigned)iy >= (unsigned)g.h) continue;
-        const float* row = ip + (int64_t)iy * g.w;
+        const bool rok = (unsigned)iy < (unsigned)g.h;
+        const float* row = ip + (int64_t)min(max(iy, 0), g.h - 1) * g.w;
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const int ix = ix0 + kx;
-            if ((unsigned)ix < (unsigned)g.w) acc = __builtin_fmaf(wp[ky * K + kx], row[ix], acc);
+            const float t = row[min(max(ix, 0), g.w - 1)];
+            v[ky * K + kx] = (rok && (unsigned)ix < (unsigned)g.w) ? t : 0.0f;
         }
     }
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc = __builtin_fmaf(wp[t], v[t], acc);
     out[((int64_t)plane * g.oh + oy) * g.ow + ox] = acc;
+}
+
+// The production forward (and the stride-1 data gradient, which is the same correlation with the taps reversed): a thread owns RY = 4
+// vertically consecutive outputs of one column, so an input row is loaded ONCE for the up to K outputs it feeds -- (3 S + K) K loads per four
+// outputs instead of 4 K^2 -- and the column offsets / bounds are computed once per thread.  A wave = G = 64 / TX row groups of TX columns
+// (TX = 16, 32 or 64, the smallest that covers the plane's width: the 15 x 20 ... 60 x 80 planes of the deep stages keep >= 62 % of their
+// lanes busy); no LDS, no barriers.  The simple kernels above (one output per thread) measured 20 - 27 us even on 1.7 M outputs: ~300
+// instructions per output of address arithmetic and clamps around 25 loads -- instruction-bound at a tenth of the HBM rate.
+template <int K, int S, int TXLOG, bool FLIP>
+__global__ __launch_bounds__(256) void dw_tile_k(DwGeom g, const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out) {
+    constexpr int TX = 1 << TXLOG, G = 64 >> TXLOG, RY = 4, IR = (RY - 1) * S + K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox = blockIdx.x * TX + (lane & (TX - 1));
+    const int oy0 = ((int)blockIdx.y * 4 * G + wave * G + (lane >> TXLOG)) * RY;
+    const int plane = blockIdx.z, c = plane % g.c;
+    if (ox >= g.ow || oy0 >= g.oh) return;
+    const float* ip = in + (int64_t)plane * g.h * g.w;
+    const float* wp = wt + c * K * K;
+    const int ix0 = ox * S - g.pad, iy0 = oy0 * S - g.pad;
+    int ixc[K];
+    bool cok[K];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        const int ix = ix0 + kx;
+        cok[kx] = (unsigned)ix < (unsigned)g.w;
+        ixc[kx] = min(max(ix, 0), g.w - 1);
+    }
+    float acc[RY];
+#pragma unroll
+    for (int j = 0; j < RY; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < IR; ++r) {
+        const int iy = iy0 + r;
+        const bool rok = (unsigned)iy < (unsigned)g.h;
+        const float* row = ip + (int64_t)min(max(iy, 0), g.h - 1) * g.w;
+        float v[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const float t = row[ixc[kx]];
+            v[kx] = (rok && cok[kx]) ? t : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < RY; ++j) {
+            const int ky = r - j * S;                       // (compile time: the loops are unrolled)
+            if (ky < 0 || ky >= K) continue;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[j] = __builtin_fmaf(FLIP ? wp[(K - 1 - ky) * K + (K - 1 - kx)] : wp[ky * K + kx], v[kx], acc[j]);
+        }
+    }
+    float* op = out + ((int64_t)plane * g.oh + oy0) * g.ow + ox;
+#pragma unroll
+    for (int j = 0; j < RY; ++j)
+        if (oy0 + j < g.oh) op[(int64_t)j * g.ow] = acc[j];
+}
+
+template <int K, int S, bool FLIP>
+static void dw_tile_launch(const DwGeom& g, int tw, int th, unsigned planes, const float* in, const float* wt, float* out, hipStream_t s) {
+    // tw x th: the OUTPUT plane of the launch (forward: oh x ow; stride-1 data gradient: the input plane, with the roles of in / out swapped)
+    if (tw <= 16) dw_tile_k<K, S, 4, FLIP><<<dim3(gens_blocks(tw, 16), gens_blocks(th, 64), planes), 256, 0, s>>>(g, in, wt, out);
+    else if (tw <= 32) dw_tile_k<K, S, 5, FLIP><<<dim3(gens_blocks(tw, 32), gens_blocks(th, 32), planes), 256, 0, s>>>(g, in, wt, out);
+    else dw_tile_k<K, S, 6, FLIP><<<dim3(gens_blocks(tw, 64), gens_blocks(th, 16), planes), 256, 0, s>>>(g, in, wt, out);
 }
 
 template <int K, int S>
@@ -74,22 +143,24 @@ __global__ __launch_bounds__(256) void dw_dgrad_k(DwGeom g, const float* __restr
     if (!dw_pixel(g.w, g.h, ix, iy)) return;
     const float* dp = dout + (int64_t)plane * g.oh * g.ow;
     const float* wp = wt + c * K * K;
-    float acc = 0.0f;
+    float v[K * K];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int ty = iy + g.pad - ky;
-        if (ty < 0 || (S == 2 && (ty & 1))) continue;
         const int oy = S == 2 ? ty >> 1 : ty;
-        if (oy >= g.oh) continue;
-        const float* row = dp + (int64_t)oy * g.ow;
+        const bool rok = ty >= 0 && !(S == 2 && (ty & 1)) && oy < g.oh;
+        const float* row = dp + (int64_t)min(max(oy, 0), g.oh - 1) * g.ow;
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const int tx = ix + g.pad - kx;
-            if (tx < 0 || (S == 2 && (tx & 1))) continue;
             const int ox = S == 2 ? tx >> 1 : tx;
-            if (ox < g.ow) acc = __builtin_fmaf(wp[ky * K + kx], row[ox], acc);
+            const float t = row[min(max(ox, 0), g.ow - 1)];
+            v[ky * K + kx] = (rok && tx >= 0 && !(S == 2 && (tx & 1)) && ox < g.ow) ? t : 0.0f;
         }
     }
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc = __builtin_fmaf(wp[t], v[t], acc);
     din[((int64_t)plane * g.h + iy) * g.w + ix] = acc;
 }
 
@@ -103,25 +174,92 @@ __global__ __launch_bounds__(256) void dw_wgrad_k(DwGeom g, const float* __restr
     float acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
-    const int lane_x = threadIdx.x & 63, sub = threadIdx.x >> 6;          // a wave walks along x, the four waves take rows r0 + sub, + 4, ...
-    for (int r = r0 + sub; r < r1; r += 4) {
+    const int lane_x = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    // the part's outputs, 256 consecutive ones per trip whatever the row length (the 15 x 20 planes of the deepest stage would leave two
+    // thirds of a wave idle in a walk along x)
+    const int p_end = r1 * g.ow;
+    for (int p = r0 * g.ow + (int)threadIdx.x; p < p_end; p += 256) {
+        const int r = p / g.ow, ox = p - r * g.ow;
         const int n = r / g.oh, oy = r - n * g.oh;
         const int64_t plane = (int64_t)n * g.c + c;
-        const float* dp = dout + (plane * g.oh + oy) * g.ow;
+        const float d = dout[(plane * g.oh + oy) * g.ow + ox];
         const float* ip = in + plane * g.h * g.w;
-        const int iy0 = oy * g.stride - g.pad;
-        for (int ox = lane_x; ox < g.ow; ox += 64) {
-            const float d = dp[ox];
-            const int ix0 = ox * g.stride - g.pad;
+        const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
+        float v[K * K];
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int iy = iy0 + ky;
-                if ((unsigned)iy >= (unsigned)g.h) continue;
-                const float* row = ip + (int64_t)iy * g.w;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = iy0 + ky;
+            const bool rok = (unsigned)iy < (unsigned)g.h;
+            const float* row = ip + (int64_t)min(max(iy, 0), g.h - 1) * g.w;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ix0 + kx;
+                const float t = row[min(max(ix, 0), g.w - 1)];
+                v[ky * K + kx] = (rok && (unsigned)ix < (unsigned)g.w) ? t : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) acc[t] = __builtin_fmaf(d, v[t], acc[t]);
+    }
+    __shared__ float red[4][K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        const float s = wave_sum(acc[t]);
+        if (lane_x == 0) red[sub][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) {
+        const int t = threadIdx.x;
+        partial[((int64_t)part * g.c + c) * (K * K) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    }
+}
+
+// The production weight gradient: the same register tile as dw_tile_k -- a thread takes four vertically consecutive outputs of a column per
+// trip, loads the (3 S + K) input rows they touch once, and adds d[j] * in[j S + ky][kx] into its K^2 sums.  A work unit = (image, group of
+// four output rows); a part = a contiguous range of units of one channel.
+template <int K, int S, int TXLOG>
+__global__ __launch_bounds__(256) void dw_wgrad_tile_k(DwGeom g, const float* __restrict__ in, const float* __restrict__ dout, int units_per_part,
+                                                       float* __restrict__ partial) {
+    constexpr int TX = 1 << TXLOG, G = 64 >> TXLOG, RY = 4, IR = (RY - 1) * S + K;
+    const int part = blockIdx.x, c = blockIdx.y;
+    const int groups = (g.oh + RY - 1) / RY, units = g.n * groups;
+    const int u0 = part * units_per_part, u1 = min(u0 + units_per_part, units);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = lane & (TX - 1), lu = wave * G + (lane >> TXLOG);
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
+    for (int ub = u0; ub < u1; ub += 4 * G) {
+        const int u = ub + lu;
+        if (u >= u1) continue;
+        const int n = u / groups, oy0 = (u - n * groups) * RY;
+        const int64_t plane = (int64_t)n * g.c + c;
+        const float* ip = in + plane * g.h * g.w;
+        const float* dp = dout + (plane * g.oh + oy0) * g.ow;
+        const int iy0 = oy0 * S - g.pad;
+        for (int ox = lx; ox < g.ow; ox += TX) {
+            const int ix0 = ox * S - g.pad;
+            float d[RY];
+#pragma unroll
+            for (int j = 0; j < RY; ++j) d[j] = oy0 + j < g.oh ? dp[(int64_t)j * g.ow + ox] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < IR; ++r) {
+                const int iy = iy0 + r;
+                const bool rok = (unsigned)iy < (unsigned)g.h;
+                const float* row = ip + (int64_t)min(max(iy, 0), g.h - 1) * g.w;
+                float v[K];
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const int ix = ix0 + kx;
-                    if ((unsigned)ix < (unsigned)g.w) acc[ky * K + kx] = __builtin_fmaf(d, row[ix], acc[ky * K + kx]);
+                    const float t = row[min(max(ix, 0), g.w - 1)];
+                    v[kx] = (rok && (unsigned)ix < (unsigned)g.w) ? t : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < RY; ++j) {
+                    const int ky = r - j * S;
+                    if (ky < 0 || ky >= K) continue;
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) acc[ky * K + kx] = __builtin_fmaf(d[j], v[kx], acc[ky * K + kx]);
                 }
             }
         }
@@ -130,7 +268,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_k(DwGeom g, const float* __restr
 #pragma unroll
     for (int t = 0; t < K * K; ++t) {
         const float s = wave_sum(acc[t]);
-        if (lane_x == 0) red[sub][t] = s;
+        if (lane == 0) red[wave][t] = s;
     }
     __syncthreads();
     if (threadIdx.x < K * K) {
@@ -166,8 +304,13 @@ extern "C" int gens_depthwise_conv2d_fwd(const float* in, const float* weight, i
         const dim3 grid = dw_grid(g.ow, g.oh, (unsigned)(nn * c));
         const float* ip = in + (int64_t)n0 * c * in_plane;
         float* op = out + (int64_t)n0 * c * out_plane;
-        if (k == 3) dw_fwd_k<3><<<grid, 256, 0, s>>>(g, ip, weight, op);
-        else dw_fwd_k<5><<<grid, 256, 0, s>>>(g, ip, weight, op);
+        if (getenv("GENS_K21_SIMPLE")) {                        // (the one-output-per-thread kernels: A/B switch and cross-check)
+            if (k == 3) dw_fwd_k<3><<<grid, 256, 0, s>>>(g, ip, weight, op);
+            else dw_fwd_k<5><<<grid, 256, 0, s>>>(g, ip, weight, op);
+        } else if (k == 3 && stride == 1) dw_tile_launch<3, 1, false>(g, g.ow, g.oh, (unsigned)(nn * c), ip, weight, op, s);
+        else if (k == 3) dw_tile_launch<3, 2, false>(g, g.ow, g.oh, (unsigned)(nn * c), ip, weight, op, s);
+        else if (stride == 1) dw_tile_launch<5, 1, false>(g, g.ow, g.oh, (unsigned)(nn * c), ip, weight, op, s);
+        else dw_tile_launch<5, 2, false>(g, g.ow, g.oh, (unsigned)(nn * c), ip, weight, op, s);
     }
     return gens_launch_status("gens_depthwise_conv2d_fwd");
 }
@@ -186,7 +329,10 @@ extern "C" int gens_depthwise_conv2d_dgrad(const float* grad_out, const float* w
         const dim3 grid = dw_grid(w, h, (unsigned)(nn * c));
         const float* dp = grad_out + (int64_t)n0 * c * out_plane;
         float* ip = grad_in + (int64_t)n0 * c * in_plane;
-        if (k == 3 && stride == 1) dw_dgrad_k<3, 1><<<grid, 256, 0, s>>>(g, dp, weight, ip);
+        if (stride == 1 && !getenv("GENS_K21_SIMPLE")) {        // stride 1: din = the forward correlation of dout with the taps reversed (oh = h, ow = w)
+            if (k == 3) dw_tile_launch<3, 1, true>(g, w, h, (unsigned)(nn * c), dp, weight, ip, s);
+            else dw_tile_launch<5, 1, true>(g, w, h, (unsigned)(nn * c), dp, weight, ip, s);
+        } else if (k == 3 && stride == 1) dw_dgrad_k<3, 1><<<grid, 256, 0, s>>>(g, dp, weight, ip);
         else if (k == 3) dw_dgrad_k<3, 2><<<grid, 256, 0, s>>>(g, dp, weight, ip);
         else if (stride == 1) dw_dgrad_k<5, 1><<<grid, 256, 0, s>>>(g, dp, weight, ip);
         else dw_dgrad_k<5, 2><<<grid, 256, 0, s>>>(g, dp, weight, ip);
@@ -194,13 +340,16 @@ extern "C" int gens_depthwise_conv2d_dgrad(const float* grad_out, const float* w
     return gens_launch_status("gens_depthwise_conv2d_dgrad");
 }
 
-// number of partial sums (slices of the output rows) gens_depthwise_conv2d_wgrad writes: partial is (parts, c, k, k) floats
+// number of partial sums gens_depthwise_conv2d_wgrad writes: partial is (parts, c, k, k) floats.  A part = a contiguous range of work units
+// (image, group of four output rows) of one channel.
+static int dw_wgrad_units(const DwGeom& g) { return g.n * ((g.oh + 3) / 4); }
+static int dw_wgrad_units_per_trip(const DwGeom& g) { return g.ow <= 16 ? 16 : g.ow <= 32 ? 8 : 4; }      // 4 waves x (64 / TX) units
 extern "C" int gens_depthwise_conv2d_wgrad_parts(int n, int c, int h, int w, int k, int stride) {
     DwGeom g;
     if (dw_geom("gens_depthwise_conv2d_wgrad_parts", n, c, h, w, k, stride, g)) return 0;
-    const int rows = n * g.oh;
+    const int units = dw_wgrad_units(g), trip = dw_wgrad_units_per_trip(g);
     int parts = (2048 + c - 1) / c;                              // ~2 048 workgroups per launch
-    if (parts > (rows + 3) / 4) parts = (rows + 3) / 4;          // at least four rows (one per wave) per part
+    if (parts > (units + trip - 1) / trip) parts = (units + trip - 1) / trip;          // at least one trip of the workgroup per part
     return parts < 1 ? 1 : parts;
 }
 
@@ -208,13 +357,26 @@ extern "C" int gens_depthwise_conv2d_wgrad(const float* in, const float* grad_ou
                                            void* stream) {
     DwGeom g;
     if (int e = dw_geom("gens_depthwise_conv2d_wgrad", n, c, h, w, k, stride, g)) return e;
-    GENS_CHECK_ARG(c <= 65535, GENS_ELIMIT, "gens_depthwise_conv2d_wgrad: %d channels", c);
     GENS_CHECK_ARG(partial && (n == 0 || (in && grad_out)), GENS_EINVAL, "gens_depthwise_conv2d_wgrad: null pointer");
     const int parts = gens_depthwise_conv2d_wgrad_parts(n, c, h, w, k, stride);
-    const int rows = n * g.oh, rpp = (rows + parts - 1) / parts;
+    const int units = dw_wgrad_units(g), upp = (units + parts - 1) / parts;
     const dim3 grid((unsigned)parts, (unsigned)c);
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3) dw_wgrad_k<3><<<grid, 256, 0, s>>>(g, in, grad_out, rpp, partial);
-    else dw_wgrad_k<5><<<grid, 256, 0, s>>>(g, in, grad_out, rpp, partial);
+#define DW_WGRAD(K_, S_)                                                                                        \
+    do {                                                                                                        \
+        if (g.ow <= 16) dw_wgrad_tile_k<K_, S_, 4><<<grid, 256, 0, s>>>(g, in, grad_out, upp, partial);         \
+        else if (g.ow <= 32) dw_wgrad_tile_k<K_, S_, 5><<<grid, 256, 0, s>>>(g, in, grad_out, upp, partial);    \
+        else dw_wgrad_tile_k<K_, S_, 6><<<grid, 256, 0, s>>>(g, in, grad_out, upp, partial);                    \
+    } while (0)
+    if (getenv("GENS_K21_SIMPLE")) {
+        // (the one-output-per-thread kernel walks output ROWS: the same parts, read as row ranges of four rows per unit)
+        const int rpp = upp * 4;
+        if (k == 3) dw_wgrad_k<3><<<grid, 256, 0, s>>>(g, in, grad_out, rpp, partial);
+        else dw_wgrad_k<5><<<grid, 256, 0, s>>>(g, in, grad_out, rpp, partial);
+    } else if (k == 3 && stride == 1) DW_WGRAD(3, 1);
+    else if (k == 3) DW_WGRAD(3, 2);
+    else if (stride == 1) DW_WGRAD(5, 1);
+    else DW_WGRAD(5, 2);
+#undef DW_WGRAD
     return gens_launch_status("gens_depthwise_conv2d_wgrad");
 }
