@@ -407,6 +407,182 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// wgrad on the matrix cores (stride 1, z a multiple of 64): dW[a][b][tx][ty][tz] = sum_o P[a][o] Q[b][o + t - 1] as three 32 x 32 products
+// per (x, y) row -- one per tx -- whose reduction index runs along z:
+//     D_tx[(a, tz)][(b, ty)] += sum_z  P[a][x][y][z - tz + 1]  *  Q[b][x + tx - 1][y + ty - 1][z]
+// (24 of 32 rows and columns carry eight channels x three taps: 56 % of the MFMA's products are useful, against the 23 - 30 TFLOP/s the
+// vector-ALU kernel above reaches on a quarter of the float32 peak).  A workgroup = four waves = four consecutive y of one 64-voxel z segment,
+// marching along x: the three x-planes of Q it needs (six y rows x eight channels x 64 z) live in LDS as a ring -- one new plane per step, 12 KB --
+// beside the step's four P rows with their z halo; both are loaded as 16-byte buffer reads one step AHEAD of their use (out-of-volume rows are
+// out-of-range offsets: the hardware returns the zero padding).  MFMA operands come from LDS one float per lane and step (row pitches 65 / 67
+// floats: conflict-free).  Every (P voxel, Q voxel) pair is counted once: the z sum is partitioned by the Q position (the P halo supplies the
+// neighbouring segment's voxels), x and y by the P position.  A workgroup leaves its 8 x 8 x 27 sums in ws[part]; the host adds the parts.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+#define WM_QP 65
+#define WM_PP 67
+typedef float wm_f32x16 __attribute__((ext_vector_type(16)));
+typedef float wm_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int y_blocks, int z_segs,
+                                                           int xc, float* __restrict__ ws) {
+    __shared__ float Ql[3][6][8][WM_QP];
+    __shared__ float Pl[4][8][WM_PP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = g.cqp / 8, n_col = ((g.cpp + 7) / 8) * nqb;
+    const int part = (int)blockIdx.x / n_col, col = (int)blockIdx.x % n_col;
+    const int pb = (col / nqb) * 8, qb = (col % nqb) * 8;
+    const int zs = part % z_segs, yb = (part / z_segs) % y_blocks, xk = part / (z_segs * y_blocks);
+    const int z0 = zs * 64, y0 = yb * 4, x0 = xk * xc, x1 = min(x0 + xc, g.x);
+    const uint32_t pn_bytes = (uint32_t)g.x * g.y * g.z * 4u;
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * g.x * g.y * g.z);
+    const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * g.x * g.y * g.z);
+
+    // ---- this thread's share of a step's loads: 3 float4 of the Q plane, 2 float4 of the P rows, (64 threads) one halo float
+    int q_row[3], q_f4[3], p_row[2], p_f4[2];
+    uint32_t q_soff[3], p_soff[2];
+    bool q_ok[3], p_ok[2];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int idx = tid + 256 * it;
+        q_row[it] = idx >> 4;                                                       // 0..47 = yrow * 8 + b
+        q_f4[it] = idx & 15;
+        const int yy = y0 - 1 + (q_row[it] >> 3), b = q_row[it] & 7;
+        q_ok[it] = (unsigned)yy < (unsigned)g.y && qb + b < g.cq;
+        q_soff[it] = (uint32_t)(qb + b) * pn_bytes;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it;
+        p_row[it] = idx >> 4;                                                       // 0..31 = w * 8 + a
+        p_f4[it] = idx & 15;
+        const int yy = y0 + (p_row[it] >> 3), a = p_row[it] & 7;
+        p_ok[it] = yy < g.y && pb + a < g.cp;
+        p_soff[it] = (uint32_t)(pb + a) * pn_bytes;
+    }
+    const int h_row = (tid >> 1) & 31, h_side = tid & 1;                           // (threads 0..63) halo of P row h_row: z0 - 1 or z0 + 64
+    const int h_z = h_side ? z0 + 64 : z0 - 1;
+    const bool h_ok = tid < 64 && y0 + (h_row >> 3) < g.y && pb + (h_row & 7) < g.cp && (unsigned)h_z < (unsigned)g.z;
+    const uint32_t h_soff = (uint32_t)(pb + (h_row & 7)) * pn_bytes;
+
+    wm_f32x4 qv[3], pv[2];
+    float hv = 0.0f;
+    auto load_q = [&](int xq) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int yy = y0 - 1 + (q_row[it] >> 3);
+            const uint32_t off = (q_ok[it] && (unsigned)xq < (unsigned)g.x) ? (uint32_t)(((xq * g.y + yy) * g.z + z0 + 4 * q_f4[it]) * 4) : CONV_OOB;
+            qv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, off, q_soff[it], 0));
+        }
+    };
+    auto store_q = [&](int xq) {
+        const int slot = (xq + 3) % 3;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            float* dst = &Ql[slot][q_row[it] >> 3][q_row[it] & 7][4 * q_f4[it]];
+            dst[0] = qv[it].x; dst[1] = qv[it].y; dst[2] = qv[it].z; dst[3] = qv[it].w;
+        }
+    };
+    auto load_p = [&](int xp) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int yy = y0 + (p_row[it] >> 3);
+            const uint32_t off = p_ok[it] ? (uint32_t)(((xp * g.y + yy) * g.z + z0 + 4 * p_f4[it]) * 4) : CONV_OOB;
+            pv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, p_soff[it], 0));
+        }
+        const uint32_t hoff = h_ok ? (uint32_t)(((xp * g.y + y0 + (h_row >> 3)) * g.z + h_z) * 4) : CONV_OOB;
+        hv = conv_load(pr, hoff, h_soff);
+    };
+    auto store_p = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float* dst = &Pl[p_row[it] >> 3][p_row[it] & 7][1 + 4 * p_f4[it]];
+            dst[0] = pv[it].x; dst[1] = pv[it].y; dst[2] = pv[it].z; dst[3] = pv[it].w;
+        }
+        if (tid < 64) Pl[h_row >> 3][h_row & 7][h_side ? 65 : 0] = hv;
+    };
+
+    // ---- MFMA operand rows of this lane: A row i = (a, tz), B column j = (b, ty); lanes 24..31 of a half repeat rows 0..7 (their products are dropped)
+    const int i32 = lane & 31, kk = lane >> 5;
+    const int ii = i32 < 24 ? i32 : i32 - 24;
+    const int oa = ii / 3, ot = ii - 3 * oa;                                        // a (or b), tz (or ty)
+    const float* a_ptr = &Pl[wave][oa][2 - ot + 32 * kk];
+    wm_f32x16 acc[3];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tx][r] = 0.0f;
+
+    load_q(x0 - 1);
+    store_q(x0 - 1);
+    load_q(x0);
+    store_q(x0);
+    load_q(x0 + 1);
+    load_p(x0);
+    for (int x = x0; x < x1; ++x) {
+        store_q(x + 1);
+        store_p();
+        __syncthreads();
+        if (x + 1 < x1) {                                                           // the next step's tensors are on their way while this one multiplies
+            load_q(x + 2);
+            load_p(x + 1);
+        }
+        const float* b_ptr[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) b_ptr[tx] = &Ql[(x - 1 + tx + 3) % 3][wave + ot][oa][32 * kk];
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) {
+            const float av = a_ptr[t];
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) acc[tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ptr[tx][t], acc[tx], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- the four waves' sums, then the workgroup's block of ws[part]
+    float* R = &Ql[0][0][0][0];                                                     // 3 x 16 x 64 floats
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* dst = R + (tx * 16 + r) * 64 + lane;
+                    *dst = w == 0 ? acc[tx][r] : *dst + acc[tx][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 3 * 16 * 64; e += 256) {
+        const int tx = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;            // row / column of accumulator register r in lane l
+        if (i >= 24 || j >= 24) continue;
+        const int a = i / 3, tz = i - 3 * a, b = j / 3, ty = j - 3 * b;
+        if (pb + a < g.cpp && qb + b < g.cqp) ws[(((int64_t)part * g.cpp + pb + a) * g.cqp + qb + b) * 27 + (tx * 3 + ty) * 3 + tz] = R[e];
+    }
+}
+
+struct WgradMfmaPlan {
+    bool use;
+    int y_blocks, z_segs, x_chunks, xc, n_col;
+};
+static WgradMfmaPlan wgrad_mfma_plan(int cp, int cq, const int* dims_p, int stride) {
+    WgradMfmaPlan pl = {};
+    pl.use = stride == 1 && (dims_p[2] & 63) == 0 && getenv("GENS_K15_NO_MFMA_WGRAD") == nullptr;
+    if (!pl.use) return pl;
+    const int cpp = (cp + 3) / 4 * 4, cqp = (cq + 7) / 8 * 8;
+    pl.n_col = ((cpp + 7) / 8) * (cqp / 8);
+    pl.y_blocks = (dims_p[1] + 3) / 4;
+    pl.z_segs = dims_p[2] / 64;
+    const int tiles = pl.y_blocks * pl.z_segs * pl.n_col;
+    int chunks = (1536 + tiles - 1) / tiles;                                      // ~1 500 workgroups: two or three per CU
+    const int max_chunks = (dims_p[0] + 3) / 4;                                   // at least four steps per chunk (each chunk loads two extra planes)
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    pl.xc = (dims_p[0] + chunks - 1) / chunks;
+    pl.x_chunks = (dims_p[0] + pl.xc - 1) / pl.xc;
+    return pl;
+}
+
 static int conv_geom(const int* dims_p, int cp, int cq, int stride, ConvGeom& g, const char* what) {
     GENS_CHECK_ARG(dims_p && dims_p[0] > 0 && dims_p[1] > 0 && dims_p[2] > 0 && cp > 0 && cq > 0, GENS_EINVAL, "%s: bad shape", what);
     GENS_CHECK_ARG(stride == 1 || stride == 2, GENS_EINVAL, "%s: stride %d (1 or 2)", what, stride);
@@ -484,6 +660,14 @@ extern "C" int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p) {
     return n_ranges * 4;
 }
 
+// the same for a given stride: the stride-1 matrix-core kernel (z a multiple of 64) cuts the volume into its own parts
+extern "C" int gens_conv3d_wgrad_parts_strided(int cp, int cq, const int* dims_p, int stride) {
+    if (!dims_p || cp <= 0 || cq <= 0) return 0;
+    const WgradMfmaPlan pl = wgrad_mfma_plan(cp, cq, dims_p, stride);
+    if (pl.use) return pl.x_chunks * pl.y_blocks * pl.z_segs;
+    return gens_conv3d_wgrad_parts(cp, cq, dims_p);
+}
+
 extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream) {
     ConvGeom g;
     if (int rc = conv_geom(dims_p, cp, cq, stride, g, "gens_conv3d_wgrad")) return rc;
@@ -492,6 +676,12 @@ extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq,
     wgrad_shape(cp, cq, (int64_t)g.x * g.y * g.z, g.cpp, g.cqp, ny, n_ranges, cpr);
     const dim3 grid(8u * (unsigned)ny * (unsigned)((n_ranges + 7) / 8));
     hipStream_t s = (hipStream_t)stream;
+    const WgradMfmaPlan pl = wgrad_mfma_plan(cp, cq, dims_p, stride);
+    if (pl.use) {          // (workspace: gens_conv3d_wgrad_parts_strided(..., stride) parts)
+        const unsigned blocks = (unsigned)(pl.x_chunks * pl.y_blocks * pl.z_segs * pl.n_col);
+        hipLaunchKernelGGL(conv3d_wgrad_mfma_k, dim3(blocks), dim3(256), 0, s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        return gens_launch_status("gens_conv3d_wgrad");
+    }
     if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr)
         hipLaunchKernelGGL((conv3d_wgrad_k<1, 4, true>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);
     else if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_k<1, 4, false>), grid, dim3(256), 0, s, p, q, g, n_ranges, cpr, workspace);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "gens_conv3d_gather": [_p, _p, _p, _i, _i, _ip, _i, _p, _p],
     "gens_conv3d_scatter2": [_p, _p, _i, _i, _ip, _p, _p],
     "gens_conv3d_wgrad_parts": [_i, _i, _ip],
+    "gens_conv3d_wgrad_parts_strided": [_i, _i, _ip, _i],
     "gens_conv3d_wgrad": [_p, _p, _i, _i, _ip, _i, _p, _p],
     "gens_instnorm_blocks": [_i, _l],
     "gens_instnorm_stats": [_p, _i, _l, _p, _p],

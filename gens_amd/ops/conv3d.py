@@ -43,7 +43,7 @@ def _conv_wgrad(p, q, stride):
     """dW (cp, cq, 27) = sum over the voxels o of P of P[a][o] Q[b][s o + t - 1]."""
     cp, cq = p.shape[0], q.shape[0]
     dims = L.int_table(p.shape[1:])
-    parts = L.load().gens_conv3d_wgrad_parts(cp, cq, dims)
+    parts = L.load().gens_conv3d_wgrad_parts_strided(cp, cq, dims, stride)
     cpp, cqp = (cp + 3) // 4 * 4, (cq + 7) // 8 * 8
     ws = torch.empty(parts, cpp, cqp, 27, device=p.device, dtype=_f32)
     L.call("gens_conv3d_wgrad", L.ptr(p), L.ptr(q), cp, cq, dims, stride, L.ptr(ws), L.stream(),

@@ -589,6 +589,9 @@ int gens_conv3d_gather(const float* q, const float* w, const float* bias, int cp
                        float* p, void* stream);
 int gens_conv3d_scatter2(const float* p, const float* w, int cp, int cq, const int* dims_p, float* q, void* stream);
 int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p);
+/* the number of parts gens_conv3d_wgrad writes for THIS stride (the stride-1 matrix-core kernel cuts the volume its own way); the workspace
+ * of a call must hold gens_conv3d_wgrad_parts_strided(cp, cq, dims_p, stride) parts */
+int gens_conv3d_wgrad_parts_strided(int cp, int cq, const int* dims_p, int stride);
 int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int* dims_p, int stride, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
