@@ -130,6 +130,8 @@ SIGNATURES = {
     "gens_depthwise_conv2d_dgrad": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "gens_depthwise_conv2d_wgrad_parts": [_i, _i, _i, _i, _i, _i],
     "gens_depthwise_conv2d_wgrad": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "gens_batchnorm2d_train_fwd": [_p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gens_batchnorm2d_train_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "gens_grid_sample_fwd": [_p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p],
     "gens_grid_sample_bwd": [_p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p],
     "gens_grid_sample_bwd2": [_p, _p, _p, _p, _p, _i, _i, _i, _ip, _l, _i, _i, _p, _p, _p, _p],
@@ -181,6 +183,8 @@ def load():
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
     lib.gens_scene_cams_floats.restype = _l
     lib.gens_scene_cams_floats.argtypes = [_i]
+    lib.gens_batchnorm2d_scratch_doubles.restype = _l
+    lib.gens_batchnorm2d_scratch_doubles.argtypes = [_i, _i, _i]
     lib.gens_compact_points_scratch.restype = _l
     lib.gens_compact_points_scratch.argtypes = [_l]
     for name, args in SIGNATURES.items():

@@ -36,6 +36,31 @@ class DepthwiseConv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class BatchNorm2dReLU(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) that also applies the ReLU which follows it in the trunk when `relu` is set
+    (the nn.ReLU slot of the Sequential then holds an nn.Identity: no parameters, the indices of the state dict stay).  In training mode on
+    the device the pair is K22 (gens_batchnorm2d_train_*, csrc/k22_batchnorm.hip: two launches forward, two backward, the running statistics
+    and the batch counter updated by the kernel); otherwise nn.BatchNorm2d's own forward followed by the ReLU."""
+
+    use_k22 = os.environ.get("GENS_NO_K22") is None
+
+    def __init__(self, num_features, relu=False, **kw):
+        super().__init__(num_features, **kw)
+        self.fused_relu = relu
+
+    def forward(self, x):
+        from ... import ops
+        if self.use_k22 and ops.batchnorm_supported(x, self):
+            return ops.batchnorm2d_train(x, self, self.fused_relu)
+        y = super().forward(x)
+        return nn.functional.relu(y) if self.fused_relu else y
+
+
+def _bn_relu(c):
+    """BatchNorm2d + ReLU as two Sequential slots (torchvision's layout: `... .1` the norm, `... .2` the activation)."""
+    return BatchNorm2dReLU(c, relu=True, momentum=_BN_MOMENTUM), nn.Identity()
+
+
 class _InvertedResidual(nn.Module):
     """1x1 expand -> k x k depthwise (stride) -> 1x1 project, BatchNorm after each, ReLU after the first two; identity skip when the
     shape is kept.  `layers` is torchvision's attribute name (state-dict keys `....layers.{0,1,3,4,6,7}.*`)."""
@@ -45,10 +70,9 @@ class _InvertedResidual(nn.Module):
         mid = cin * expansion
         self.apply_residual = cin == cout and stride == 1
         self.layers = nn.Sequential(
-            nn.Conv2d(cin, mid, 1, bias=False), nn.BatchNorm2d(mid, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-            DepthwiseConv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False),
-            nn.BatchNorm2d(mid, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-            nn.Conv2d(mid, cout, 1, bias=False), nn.BatchNorm2d(cout, momentum=_BN_MOMENTUM))
+            nn.Conv2d(cin, mid, 1, bias=False), *_bn_relu(mid),
+            DepthwiseConv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False), *_bn_relu(mid),
+            nn.Conv2d(mid, cout, 1, bias=False), BatchNorm2dReLU(cout, momentum=_BN_MOMENTUM))
 
     def forward(self, x):
         return self.layers(x) + x if self.apply_residual else self.layers(x)
@@ -62,9 +86,9 @@ def _stack(cin, cout, kernel, stride, expansion, repeats):
 def _mnasnet_trunk():
     """The first 14 children of torchvision's `MNASNet(alpha=1.0).layers` (the reference uses [0:14], :59-63)."""
     layers = [
-        nn.Conv2d(3, 32, 3, padding=1, stride=2, bias=False), nn.BatchNorm2d(32, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-        DepthwiseConv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), nn.BatchNorm2d(32, momentum=_BN_MOMENTUM), nn.ReLU(inplace=True),
-        nn.Conv2d(32, 16, 1, padding=0, stride=1, bias=False), nn.BatchNorm2d(16, momentum=_BN_MOMENTUM),
+        nn.Conv2d(3, 32, 3, padding=1, stride=2, bias=False), *_bn_relu(32),
+        DepthwiseConv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), *_bn_relu(32),
+        nn.Conv2d(32, 16, 1, padding=0, stride=1, bias=False), BatchNorm2dReLU(16, momentum=_BN_MOMENTUM),
         _stack(16, 24, 3, 2, 3, 3), _stack(24, 40, 5, 2, 3, 3), _stack(40, 80, 5, 2, 6, 3),
         _stack(80, 96, 3, 1, 6, 2), _stack(96, 192, 5, 2, 6, 4), _stack(192, 320, 3, 1, 6, 1)]
     for m in layers:

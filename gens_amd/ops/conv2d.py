@@ -1,4 +1,5 @@
-"""K21: depth-wise 2-D convolutions of the MnasNet trunk (feature_network_mnasnet.py:53-103 -> torchvision's MNASNet layers).
+"""K21 / K22: the depth-wise 2-D convolutions and the training-mode BatchNorm2d [+ ReLU] of the MnasNet trunk
+(feature_network_mnasnet.py:53-103 -> torchvision's MNASNet layers).
 
 Part of gens_amd.ops (see ops/__init__.py); citations are relative to /root/reference."""
 from .base import *  # noqa: F401,F403
@@ -53,3 +54,54 @@ class _DepthwiseConv2d(torch.autograd.Function):
 def depthwise_conv2d(x, weight, stride):
     """x (n, c, h, w), weight (c, 1, k, k), padding k // 2 -> (n, c, oh, ow); differentiable in x and weight."""
     return _DepthwiseConv2d.apply(x, weight, int(stride))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K22  BatchNorm2d in training mode [+ ReLU]
+# ------------------------------------------------------------------------------------------------------------------
+def batchnorm_supported(x, bn):
+    """Training-mode nn.BatchNorm2d on a float32 device tensor with running statistics and a fixed momentum: what K22 covers."""
+    return (x.is_cuda and x.dtype == _f32 and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] > 1 and bn.training and bn.track_running_stats
+            and bn.momentum is not None and x.shape[1] <= 65535 and x.shape[0] <= 1024)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu):
+        xc = _c(x.detach())
+        n, c, h, w = xc.shape
+        hw = h * w
+        y = torch.empty_like(xc)
+        mean_rstd = torch.empty(c, 2, device=x.device, dtype=_f32)
+        scratch = torch.empty(L.load().gens_batchnorm2d_scratch_doubles(n, c, hw), device=x.device, dtype=torch.float64)
+        wd, bd = (None if weight is None else _c(weight.detach())), (None if bias is None else _c(bias.detach()))
+        L.call("gens_batchnorm2d_train_fwd", L.ptr(xc), L.ptr(wd), L.ptr(bd), n, c, hw, float(eps), float(momentum), 1 if relu else 0, L.ptr(y),
+               L.ptr(mean_rstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), L.ptr(scratch, torch.float64),
+               L.stream(), nbytes=12 * xc.numel(), label="gens_batchnorm2d")
+        ctx.save_for_backward(xc, mean_rstd, wd, bd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_y):
+        xc, mean_rstd, wd, bd = ctx.saved_tensors
+        n, c, h, w = xc.shape
+        hw = h * w
+        gy = _c(g_y.to(_f32))
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if not (need_x or need_w or need_b):
+            return (None,) * 9
+        g_x = torch.empty_like(xc) if need_x else None
+        g_w = torch.empty(c, device=xc.device, dtype=_f32) if need_w else None
+        g_b = torch.empty(c, device=xc.device, dtype=_f32) if need_b else None
+        scratch = torch.empty(L.load().gens_batchnorm2d_scratch_doubles(n, c, hw), device=xc.device, dtype=torch.float64)
+        L.call("gens_batchnorm2d_train_bwd", L.ptr(xc), L.ptr(gy), L.ptr(mean_rstd), L.ptr(wd), L.ptr(bd), n, c, hw, 1 if ctx.relu else 0, L.ptr(g_x),
+               L.ptr(g_w), L.ptr(g_b), L.ptr(scratch, torch.float64), L.stream(), nbytes=20 * xc.numel(), label="gens_batchnorm2d")
+        return g_x, g_w, g_b, None, None, None, None, None, None
+
+
+def batchnorm2d_train(x, bn, relu):
+    """nn.BatchNorm2d `bn` in training mode on x (n, c, h, w) [followed by ReLU]: batch statistics, running statistics and num_batches_tracked
+    updated in place, differentiable in x, weight and bias."""
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, bool(relu))

@@ -341,6 +341,23 @@ int gens_depthwise_conv2d_wgrad(const float* in, const float* grad_out, int n, i
                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K22  BatchNorm2d in training mode (batch statistics) [+ the ReLU that follows it] of the MnasNet trunk (k22_batchnorm.hip): the
+ *      nn.BatchNorm2d(c, momentum = 1 - 0.9997) [+ nn.ReLU] pairs of torchvision's MNASNet used by feature_network_mnasnet.py:53-103.
+ *      NCHW float32 contiguous, x / y / grad_* (n, c, hw).  gamma / beta (c) or NULL (no affine).
+ *   fwd: y = [max](((x - mean_c) * rstd_c) * gamma_c + beta_c[, 0]) with the batch's mean and BIASED variance; mean_rstd (c, 2) receives
+ *        (mean, rstd) for the backward pass; running_mean / running_var (c) or NULL are moved by `momentum` (running_var with the unbiased
+ *        variance), num_batches_tracked (DEVICE int64 or NULL) is incremented -- nn.BatchNorm2d's bookkeeping.
+ *   bwd: grad_x (or NULL), grad_gamma, grad_beta (c, or NULL) from grad_y; relu: the decision y > 0 is recomputed from x.
+ *   scratch: DEVICE, gens_batchnorm2d_scratch_doubles(n, c, hw) doubles, contents irrelevant before and after.
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t gens_batchnorm2d_scratch_doubles(int n, int c, int hw);
+int gens_batchnorm2d_train_fwd(const float* x, const float* gamma, const float* beta, int n, int c, int hw, float eps, float momentum, int relu,
+                               float* y, float* mean_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               double* scratch, void* stream);
+int gens_batchnorm2d_train_bwd(const float* x, const float* grad_y, const float* mean_rstd, const float* gamma, const float* beta, int n, int c,
+                               int hw, int relu, float* grad_x, float* grad_gamma, float* grad_beta, double* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K20  the reference's sampler boundary in full generality (k20_grid_sample.hip): what cuda_gridsample.py:7-14 exports and K2 does not
  *      cover -- grid_sample_2d, padding_mode 'border', align_corners=False, batches, channel counts that are not multiples of four.
  *     forward            F.grid_sample(bilinear) = aten::grid_sampler_2d / _3d        (cuda_gridsample.py:28, 79)
