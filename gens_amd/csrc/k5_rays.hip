@@ -51,33 +51,13 @@ __device__ __forceinline__ int upper_bound_lds(const float* row, int n, float u)
 // ---------------------------------------------------------------------------------------------------------------
 // K5 + K6
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                                  const float* __restrict__ z, const float* __restrict__ sdf,
-                                                                  int64_t n_rays, int n, int n_new, float inv_s, LevelSet ms,
-                                                                  const uint8_t* __restrict__ valid_in, float* __restrict__ z_new,
-                                                                  float* __restrict__ pts_new, uint8_t* __restrict__ valid_new) {
-    __shared__ float s_cdf[RAYS_PER_BLOCK][MAX_SAMPLES];
-    __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
-    const bool active = r < n_rays;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-    if (active) {
-        ox = rays_o[3 * r]; oy = rays_o[3 * r + 1]; oz = rays_o[3 * r + 2];
-        dx = rays_d[3 * r]; dy = rays_d[3 * r + 1]; dz = rays_d[3 * r + 2];
-    }
-    float zj[2], sj[2], rad[2], vm[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        int j = lane + 64 * s;
-        bool have = active && j < n;
-        zj[s] = have ? z[r * n + j] : 0.0f;
-        sj[s] = have ? sdf[r * n + j] : 0.0f;
-        float px = ox + dx * zj[s], py = oy + dy * zj[s], pz = oz + dz * zj[s];
-        rad[s] = sqrtf(px * px + py * py + pz * pz);
-        // validity of the existing samples: carried from the launches that created them (valid_in) or looked up again
-        vm[s] = (have && (valid_in ? valid_in[r * n + j] != 0 : any_mask(ms, px, py, pz))) ? 1.0f : 0.0f;
-    }
+// up_sample + sample_pdf for one ray held in registers (lane l owns samples l and l + 64): everything of implicit_surface.py:60-109, 14-44 after
+// the samples, their SDF, radii and mask decisions are known.  Shared by gens_upsample and by the fused merge + up-sample kernel, so that the two
+// produce the same bits.  s_cdf / s_z: this wave's LDS rows (s_z receives the z values; it may already hold them).
+__device__ __forceinline__ void upsample_core(bool active, int lane, int64_t r, int n, int n_new, float inv_s, const LevelSet& ms, float ox, float oy,
+                                              float oz, float dx, float dy, float dz, const float zj[2], const float sj[2], const float rad[2],
+                                              const float vm[2], float* __restrict__ s_cdf_row, float* __restrict__ s_z_row, float* __restrict__ z_new,
+                                              float* __restrict__ pts_new, uint8_t* __restrict__ valid_new) {
     float zn[2], sn[2], rn[2], vn[2];
     next2(zj[0], zj[1], lane, zn[0], zn[1]);
     next2(sj[0], sj[1], lane, sn[0], sn[1]);
@@ -116,19 +96,19 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* _
     float c0 = wave_scan_add(wp[0] / total, lane);
     float c1 = wave_scan_add(wp[1] / total, lane) + lane_value(c0, 63);
     if (active) {
-        if (lane == 0) s_cdf[wave][0] = 0.0f;
-        if (lane < n - 1) s_cdf[wave][lane + 1] = c0;
-        if (lane + 64 < n - 1) s_cdf[wave][lane + 65] = c1;
-        if (lane < n) s_z[wave][lane] = zj[0];
-        if (lane + 64 < n) s_z[wave][lane + 64] = zj[1];
+        if (lane == 0) s_cdf_row[0] = 0.0f;
+        if (lane < n - 1) s_cdf_row[lane + 1] = c0;
+        if (lane + 64 < n - 1) s_cdf_row[lane + 65] = c1;
+        if (lane < n) s_z_row[lane] = zj[0];
+        if (lane + 64 < n) s_z_row[lane + 64] = zj[1];
     }
     __syncthreads();
     if (active && lane < n_new) {
         float u = linspace_at(0.5f / (float)n_new, 1.0f - 0.5f / (float)n_new, n_new, lane);
-        int cnt = upper_bound_lds(s_cdf[wave], n, u);
+        int cnt = upper_bound_lds(s_cdf_row, n, u);
         int lo = max(cnt - 1, 0), hi = min(cnt, n - 1);
-        float c_lo = s_cdf[wave][lo], c_hi = s_cdf[wave][hi];
-        float b_lo = s_z[wave][lo], b_hi = s_z[wave][hi];
+        float c_lo = s_cdf_row[lo], c_hi = s_cdf_row[hi];
+        float b_lo = s_z_row[lo], b_hi = s_z_row[hi];
         float den = c_hi - c_lo;
         if (den < 1e-5f) den = 1.0f;
         float t = (u - c_lo) / den;
@@ -143,6 +123,37 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* _
         }
         if (valid_new) valid_new[o] = any_mask(ms, px, py, pz) ? 1 : 0;
     }
+}
+
+
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void upsample_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                  const float* __restrict__ z, const float* __restrict__ sdf,
+                                                                  int64_t n_rays, int n, int n_new, float inv_s, LevelSet ms,
+                                                                  const uint8_t* __restrict__ valid_in, float* __restrict__ z_new,
+                                                                  float* __restrict__ pts_new, uint8_t* __restrict__ valid_new) {
+    __shared__ float s_cdf[RAYS_PER_BLOCK][MAX_SAMPLES];
+    __shared__ float s_z[RAYS_PER_BLOCK][MAX_SAMPLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    const bool active = r < n_rays;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    if (active) {
+        ox = rays_o[3 * r]; oy = rays_o[3 * r + 1]; oz = rays_o[3 * r + 2];
+        dx = rays_d[3 * r]; dy = rays_d[3 * r + 1]; dz = rays_d[3 * r + 2];
+    }
+    float zj[2], sj[2], rad[2], vm[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int j = lane + 64 * s;
+        bool have = active && j < n;
+        zj[s] = have ? z[r * n + j] : 0.0f;
+        sj[s] = have ? sdf[r * n + j] : 0.0f;
+        float px = ox + dx * zj[s], py = oy + dy * zj[s], pz = oz + dz * zj[s];
+        rad[s] = sqrtf(px * px + py * py + pz * pz);
+        // validity of the existing samples: carried from the launches that created them (valid_in) or looked up again
+        vm[s] = (have && (valid_in ? valid_in[r * n + j] != 0 : any_mask(ms, px, py, pz))) ? 1.0f : 0.0f;
+    }
+    upsample_core(active, lane, r, n, n_new, inv_s, ms, ox, oy, oz, dx, dy, dz, zj, sj, rad, vm, s_cdf[wave], s_z[wave], z_new, pts_new, valid_new);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -190,6 +201,129 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_k(const float* __re
         z_out[o] = zk;
         if (sdf_out) sdf_out[o] = sdf_new[r * n_new + lane];
         if (valid_out) valid_out[o] = valid_new[r * n_new + lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7 + K5/K6 (+ K3) fused: one launch per sampling round.  cat_z_vals of round i (implicit_surface.py:111-133) and up_sample + sample_pdf of
+// round i + 1 (:60-109) work on the same ray: the merged samples stay in the wave's LDS rows and registers instead of going to HBM and back
+// (the merge's (n + 16) x 9 bytes per ray are still written -- the next round reads them -- but not re-read by a second kernel), and a round is
+// one launch instead of two.  MODE 0: merge + up-sample -> merged (z, sdf, valid) and the next 16 samples with their points and mask decisions.
+// MODE 1 (the last round, :129-131 merges z only): merge + render_core's section mid-points and their mask decisions (:163-168, 170-173; what
+// gens_ray_points(mid) computes).  Same arithmetic as merge_k / upsample_k / ray_points_k: the results are theirs bit for bit (tests).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void merge_upsample_k(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                        const float* __restrict__ z, const float* __restrict__ sdf,
+                                                                        const uint8_t* __restrict__ valid, const float* __restrict__ z_add,
+                                                                        const float* __restrict__ sdf_add, const uint8_t* __restrict__ valid_add,
+                                                                        int64_t n_rays, int n, int n_add, int n_new, float inv_s, float sample_dist,
+                                                                        LevelSet ms, float* __restrict__ z_out, float* __restrict__ sdf_out,
+                                                                        uint8_t* __restrict__ valid_out, float* __restrict__ z_new,
+                                                                        float* __restrict__ pts_out, uint8_t* __restrict__ valid_new) {
+    __shared__ float s_old[RAYS_PER_BLOCK][MAX_SAMPLES];      // the old samples' z (the new ones' upper bounds are searched in it)
+    __shared__ float m_z[RAYS_PER_BLOCK][MAX_SAMPLES];        // merged z: also the bin edges of the up-sampling
+    __shared__ float m_s[RAYS_PER_BLOCK][MAX_SAMPLES];
+    __shared__ float s_cdf[RAYS_PER_BLOCK][MAX_SAMPLES];
+    __shared__ uint8_t m_v[RAYS_PER_BLOCK][MAX_SAMPLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wave;
+    const bool active = r < n_rays;
+    const int m = n + n_add;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    if (active) {
+        ox = rays_o[3 * r]; oy = rays_o[3 * r + 1]; oz = rays_o[3 * r + 2];
+        dx = rays_d[3 * r]; dy = rays_d[3 * r + 1]; dz = rays_d[3 * r + 2];
+    }
+    // ---- merge by rank (merge_k)
+    float zo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        zo[s] = (active && j < n) ? z[r * n + j] : 0.0f;
+        if (active && j < n) s_old[wave][j] = zo[s];
+    }
+    const float zk = (active && lane < n_add) ? z_add[r * n_add + lane] : 0.0f;
+    __syncthreads();
+    if (active) {
+        int less[2] = {0, 0}, before = 0;
+        for (int k = 0; k < n_add; ++k) {
+            const float v = lane_value(zk, k);
+            less[0] += (v < zo[0]) ? 1 : 0;
+            less[1] += (v < zo[1]) ? 1 : 0;
+            before += (v < zk || (v == zk && k < lane)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            if (j < n) {
+                const int pos = j + less[s];
+                const int64_t o = r * m + pos;
+                m_z[wave][pos] = zo[s];
+                z_out[o] = zo[s];
+                if (MODE == 0) {
+                    const float sv = sdf[r * n + j];
+                    const uint8_t vv = valid[r * n + j];
+                    m_s[wave][pos] = sv;
+                    m_v[wave][pos] = vv;
+                    sdf_out[o] = sv;
+                    valid_out[o] = vv;
+                }
+            }
+        }
+        if (lane < n_add) {
+            const int pos = upper_bound_lds(s_old[wave], n, zk) + before;
+            const int64_t o = r * m + pos;
+            m_z[wave][pos] = zk;
+            z_out[o] = zk;
+            if (MODE == 0) {
+                const float sv = sdf_add[r * n_add + lane];
+                const uint8_t vv = valid_add[r * n_add + lane];
+                m_s[wave][pos] = sv;
+                m_v[wave][pos] = vv;
+                sdf_out[o] = sv;
+                valid_out[o] = vv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the merged ray, lane l owns samples l and l + 64
+    float zj[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        zj[s] = (active && j < m) ? m_z[wave][j] : 0.0f;
+    }
+    if (MODE == 0) {
+        float sj[2], rad[2], vm[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            const bool have = active && j < m;
+            sj[s] = have ? m_s[wave][j] : 0.0f;
+            const float px = ox + dx * zj[s], py = oy + dy * zj[s], pz = oz + dz * zj[s];
+            rad[s] = sqrtf(px * px + py * py + pz * pz);
+            vm[s] = (have && m_v[wave][j] != 0) ? 1.0f : 0.0f;
+        }
+        upsample_core(active, lane, r, m, n_new, inv_s, ms, ox, oy, oz, dx, dy, dz, zj, sj, rad, vm, s_cdf[wave], m_z[wave], z_new, pts_out, valid_new);
+    } else {
+        // section mid-points (ray_points_k with mid = 1): t = z + dist / 2, dist = the gap to the next sample or sample_dist behind the last (Q10)
+        float zn[2];
+        next2(zj[0], zj[1], lane, zn[0], zn[1]);
+        if (!active) return;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            if (j >= m) continue;
+            const float dist = (j + 1 < m) ? zn[s] - zj[s] : sample_dist;
+            const float t = zj[s] + dist * 0.5f;
+            const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;
+            const int64_t o = r * m + j;
+            pts_out[3 * o] = px;
+            pts_out[3 * o + 1] = py;
+            pts_out[3 * o + 2] = pz;
+            valid_new[o] = any_mask(ms, px, py, pz) ? 1 : 0;
+        }
     }
 }
 
@@ -492,6 +626,35 @@ extern "C" int gens_merge_samples(const float* z, const float* sdf, const float*
     merge_k<<<gens_blocks(n_rays, RAYS_PER_BLOCK), 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(z, sdf, z_new, sdf_new, valid, valid_new,
                                                                                               n_rays, n, n_new, z_out, sdf_out, valid_out);
     return gens_launch_status("gens_merge_samples");
+}
+
+// merge (z, sdf, valid) with the previous round's (z_add, sdf_add, valid_add) and, in the same launch,
+//   mode 0: up-sample the merged ray: -> merged arrays (n + n_add) and z_new (n_new), pts_out (n_rays n_new, 3), valid_new;
+//   mode 1: section mid-points of the merged ray (sdf / valid arrays unused, may be NULL): -> z_out, pts_out (n_rays (n + n_add), 3), valid_new.
+extern "C" int gens_merge_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const uint8_t* valid,
+                                   const float* z_add, const float* sdf_add, const uint8_t* valid_add, int64_t n_rays, int n, int n_add, int n_new,
+                                   float inv_s, float sample_dist, const float* const* masks, const int* dims, int n_levels, int mask_bits, int mode,
+                                   float* z_out, float* sdf_out, uint8_t* valid_out, float* z_new, float* pts_out, uint8_t* valid_new, void* stream) {
+    LevelSet ms;
+    if (int e = gens_fill_levels("gens_merge_upsample", &ms, masks, dims, n_levels)) return e;
+    ms.bits = mask_bits ? 1 : 0;
+    GENS_CHECK_ARG(mode == 0 || mode == 1, GENS_EINVAL, "gens_merge_upsample: mode %d (0 = merge + up-sample, 1 = merge + mid-points)", mode);
+    GENS_CHECK_ARG(n >= 1 && n_add >= 1 && n_add <= 64 && n + n_add <= MAX_SAMPLES && n + n_add >= 2, GENS_ELIMIT,
+                   "gens_merge_upsample: n=%d n_add=%d (n_add <= 64, 2 <= n + n_add <= 128)", n, n_add);
+    GENS_CHECK_ARG(mode == 1 || (n_new >= 1 && n_new <= 64), GENS_ELIMIT, "gens_merge_upsample: n_new=%d (1..64)", n_new);
+    GENS_CHECK_ARG(n_rays >= 0 && (n_rays == 0 || (rays_o && rays_d && z && z_add && z_out && pts_out && valid_new)), GENS_EINVAL,
+                   "gens_merge_upsample: null pointer");
+    GENS_CHECK_ARG(mode == 1 || n_rays == 0 || (sdf && valid && sdf_add && valid_add && sdf_out && valid_out && z_new), GENS_EINVAL,
+                   "gens_merge_upsample: mode 0 needs the sdf / valid arrays and z_new");
+    if (n_rays == 0) return 0;
+    const dim3 grid(gens_blocks(n_rays, RAYS_PER_BLOCK));
+    if (mode == 0)
+        merge_upsample_k<0><<<grid, 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(rays_o, rays_d, z, sdf, valid, z_add, sdf_add, valid_add, n_rays, n, n_add,
+                                                                                 n_new, inv_s, sample_dist, ms, z_out, sdf_out, valid_out, z_new, pts_out, valid_new);
+    else
+        merge_upsample_k<1><<<grid, 64 * RAYS_PER_BLOCK, 0, (hipStream_t)stream>>>(rays_o, rays_d, z, sdf, valid, z_add, sdf_add, valid_add, n_rays, n, n_add,
+                                                                                 n_new, inv_s, sample_dist, ms, z_out, sdf_out, valid_out, z_new, pts_out, valid_new);
+    return gens_launch_status("gens_merge_upsample");
 }
 
 static int check_composite_in(const char* who, const gens_composite_in* in) {

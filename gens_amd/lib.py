@@ -81,6 +81,7 @@ SIGNATURES = {
     "gens_lookup_feature_bwd": [_ip, _i, _p, _p, _i, _p, _p, _l, _pp, _p, _p],
     "gens_upsample": [_p, _p, _p, _p, _l, _i, _i, _f, _pp, _ip, _i, _i, _p, _p, _p, _p, _p],
     "gens_merge_samples": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p],
+    "gens_merge_upsample": [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _f, _f, _pp, _ip, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "gens_composite_fwd": [C.POINTER(CompositeIn), C.POINTER(CompositeOut), _p],
     "gens_composite_bwd": [C.POINTER(CompositeIn), C.POINTER(CompositeGrad), _p],
     "gens_patch_sample_fwd": [_p, _i, _i, _i, _p, _l, _p, _p],

@@ -138,6 +138,7 @@ class ImplicitSurface(nn.Module):
         self.fused_blend = True        # inference: source-view look-up + colour network in one kernel (gens_blend_views)
         self._blend_plan = None
         self.fused_train = True        # training: SDF value / gradient / smooth and their backward in the K17 kernels (gens_sdf_train_*)
+        self.fused_sampling = True     # one launch per sampling round (gens_merge_upsample) instead of merge + up-sample (+ mid-points) launches
 
     # ----------------------------------------------------------------------------------------------------------
     # masked SDF evaluation (Q7, Q8)
@@ -240,20 +241,38 @@ class ImplicitSurface(nn.Module):
         return ops.tv_regularization(list(volume_feat_cas), list(volume_mask_cas))
 
     @torch.no_grad()
-    def _sample_rays(self, rays_o, rays_d, z_vals, scene, net=None):
+    def _sample_rays(self, rays_o, rays_d, z_vals, scene, net=None, mid_points=None):
+        """The hierarchical sampling of render() (:364-393).  One launch per round between two evaluations of the network: the merge of round i
+        (cat_z_vals, :111-133) and the up-sampling of round i + 1 (:60-109) are one kernel (gens_merge_upsample); with `mid_points` =
+        sample_dist the last merge also produces render_core's section mid-points and their mask decisions (:163-173), left in
+        self._mid_points for the render_core call that follows with the returned z_vals.  `fused_sampling = False` runs the operators one by
+        one (gens_upsample / gens_merge_samples: the same bits)."""
         masks, vols = scene.masks, scene.volumes_nograd()
         b = rays_o.shape[0]
+        self._mid_points = None
         pts, valid = ops.ray_points(rays_o, rays_d, z_vals, masks)
         sdf = self._masked_sdf(pts, valid, vols, net).reshape(b, -1)
         n_new = self.n_importance // self.up_sample_steps
         valid = valid.reshape(b, -1)                       # mask decisions travel with the samples through the merges
-        for i in range(self.up_sample_steps):
-            z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64 * 2 ** i, valid_in=valid)
-            if i + 1 == self.up_sample_steps:
-                z_vals, _ = ops.merge_samples(z_vals, z_new)
-            else:
-                sdf_new = self._masked_sdf(pts_new, valid_new, vols, net).reshape(b, n_new)
-                z_vals, sdf, valid = ops.merge_samples(z_vals, z_new, sdf, sdf_new, valid, valid_new)
+        if not getattr(self, "fused_sampling", True) or self.up_sample_steps < 1:
+            for i in range(self.up_sample_steps):
+                z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64 * 2 ** i, valid_in=valid)
+                if i + 1 == self.up_sample_steps:
+                    z_vals, _ = ops.merge_samples(z_vals, z_new)
+                else:
+                    sdf_new = self._masked_sdf(pts_new, valid_new, vols, net).reshape(b, n_new)
+                    z_vals, sdf, valid = ops.merge_samples(z_vals, z_new, sdf, sdf_new, valid, valid_new)
+            return z_vals
+        z_new, pts_new, valid_new = ops.upsample(rays_o, rays_d, z_vals, sdf, n_new, masks, 64, valid_in=valid)
+        for i in range(1, self.up_sample_steps):
+            sdf_new = self._masked_sdf(pts_new, valid_new, vols, net).reshape(b, n_new)
+            z_vals, sdf, valid, z_new, pts_new, valid_new = ops.merge_upsample(rays_o, rays_d, z_vals, sdf, valid, z_new, sdf_new, valid_new, n_new, masks,
+                                                                               64 * 2 ** i)
+        if mid_points is None:
+            z_vals, _ = ops.merge_samples(z_vals, z_new)
+        else:
+            z_vals, pts_mid, valid_mid = ops.merge_mid_points(rays_o, rays_d, z_vals, z_new, masks, mid_points)
+            self._mid_points = (z_vals, float(mid_points), pts_mid, valid_mid)
         return z_vals
 
     # ----------------------------------------------------------------------------------------------------------
@@ -377,7 +396,12 @@ class ImplicitSurface(nn.Module):
         need_vol_grad = torch.is_grad_enabled() and any(v.requires_grad for v in scene.volumes)
         vols = scene.volumes if need_vol_grad else scene.volumes_nograd()
 
-        pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
+        cached = getattr(self, "_mid_points", None)
+        self._mid_points = None
+        if cached is not None and cached[0] is z_vals and cached[1] == float(sample_dist):      # _sample_rays' last launch already made them
+            pts, valid = cached[2], cached[3]
+        else:
+            pts, valid = ops.ray_points(rays_o, rays_d, z_vals, scene.masks, mid=True, sample_dist=sample_dist)
         plan = self._fused_plan(vols) if lean else None
         bplan = self._fused_blend_plan(scene.views) if lean else self._fused_blend_plan(scene.views, features, imgs)
         sdf_random = extra_sdf = None
@@ -513,7 +537,8 @@ class ImplicitSurface(nn.Module):
             t_rand = torch.rand([b, 1])                                                     # CPU generator, :362
         z_vals = ops.coarse_z(near, far, steps, t_rand.to(dev, non_blocking=True) if self.perturb > 0 else None, b)      # (:356-363, one launch)
         if self.n_importance > 0:
-            z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene, net)
+            # (the fused TRAINING path writes its mid-points into slices of the step's point array itself)
+            z_vals = self._sample_rays(rays_o, rays_d, z_vals, scene, net, mid_points=None if self._train_fused_ok(scene, net, lean) else sample_dist)
         return self.render_core(rays_o, rays_d, z_vals, sample_dist, volumes, mask_volumes, features, match_features, imgs, intrs, c2ws,
                                 cos_anneal_ratio, step, scene=scene, lean=lean, pts_random=pts_random, extra_pts=extra_pts, net=net,
                                 extra_valid=extra_valid)

@@ -41,6 +41,47 @@ def merge_samples(z, z_new, sdf=None, sdf_new=None, valid=None, valid_new=None):
     return z_out, sdf_out, v_out.view(torch.bool)
 
 
+def merge_upsample(rays_o, rays_d, z, sdf, valid, z_add, sdf_add, valid_add, n_new, masks, inv_s):
+    """One launch per sampling round: merge_samples(z, z_add, sdf, sdf_add, valid, valid_add) followed by upsample(...) of the merged ray
+    (implicit_surface.py:111-133 then :60-109).  -> (z, sdf, valid) merged (B, n + n_add) and (z_new (B, n_new), pts_new (B n_new, 3),
+    valid_new); bit for bit what the two separate operators return."""
+    table, dims, nl, bits = _mask_args(masks)
+    b, n = z.shape
+    n_add = z_add.shape[1]
+    u8 = torch.uint8
+    dev = z.device
+    z_out = torch.empty(b, n + n_add, device=dev, dtype=_f32)
+    sdf_out = torch.empty_like(z_out)
+    v_out = torch.empty(b, n + n_add, device=dev, dtype=u8)
+    z_new = torch.empty(b, n_new, device=dev, dtype=_f32)
+    pts_new = torch.empty(b * n_new, 3, device=dev, dtype=_f32)
+    v_new = torch.empty(b * n_new, device=dev, dtype=u8)
+    m = n + n_add
+    L.call("gens_merge_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), L.ptr(_c(sdf)), L.ptr(_c(valid.reshape(b, n).view(u8)), u8),
+           L.ptr(_c(z_add)), L.ptr(_c(sdf_add)), L.ptr(_c(valid_add.reshape(b, n_add).view(u8)), u8), b, n, n_add, n_new, float(inv_s), 0.0, table, dims,
+           nl, bits, 0, L.ptr(z_out), L.ptr(sdf_out), L.ptr(v_out, u8), L.ptr(z_new), L.ptr(pts_new), L.ptr(v_new, u8), L.stream(),
+           nbytes=b * (9 * (n + n_add) + 9 * m + 17 * n_new + 24), label="gens_merge_upsample")
+    return z_out, sdf_out, v_out.view(torch.bool), z_new, pts_new, v_new.view(torch.bool)
+
+
+def merge_mid_points(rays_o, rays_d, z, z_add, masks, sample_dist):
+    """The last sampling round and render_core's first step in one launch: merge_samples(z, z_add) (z only, implicit_surface.py:129-131) and
+    ray_points(..., mid=True, sample_dist) of the merged ray (:163-173).  -> z (B, n + n_add), pts (B (n + n_add), 3), valid; bit for bit
+    what the two separate operators return."""
+    table, dims, nl, bits = _mask_args(masks)
+    b, n = z.shape
+    n_add = z_add.shape[1]
+    m = n + n_add
+    dev = z.device
+    z_out = torch.empty(b, m, device=dev, dtype=_f32)
+    pts = torch.empty(b * m, 3, device=dev, dtype=_f32)
+    valid = torch.empty(b * m, device=dev, dtype=torch.uint8)
+    L.call("gens_merge_upsample", L.ptr(_c(rays_o)), L.ptr(_c(rays_d)), L.ptr(_c(z)), None, None, L.ptr(_c(z_add)), None, None, b, n, n_add, 0, 0.0,
+           float(sample_dist), table, dims, nl, bits, 1, L.ptr(z_out), None, None, None, L.ptr(pts), L.ptr(valid, torch.uint8), L.stream(),
+           nbytes=b * (4 * (n + n_add) + 17 * m + 24), label="gens_merge_mid_points")
+    return z_out, pts, valid.view(torch.bool)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # K8  compositing (implicit_surface.py:160-168, 202-303)
 # ------------------------------------------------------------------------------------------------------------------

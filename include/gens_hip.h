@@ -170,6 +170,16 @@ int gens_upsample(const float* rays_o, const float* rays_d, const float* z, cons
 int gens_merge_samples(const float* z, const float* sdf, const float* z_new, const float* sdf_new, const uint8_t* valid,
                        const uint8_t* valid_new, int64_t n_rays, int n, int n_new, float* z_out, float* sdf_out,
                        uint8_t* valid_out, void* stream);
+/* One launch per sampling round: cat_z_vals of round i (implicit_surface.py:111-133) fused with up_sample + sample_pdf of round i + 1 (:60-109,
+ * mode 0) or, after the last round, with render_core's section mid-points and their mask decisions (:163-173, mode 1 = gens_ray_points(mid)).
+ * (z, sdf, valid) (n_rays, n) + (z_add, sdf_add, valid_add) (n_rays, n_add) -> merged (n_rays, n + n_add) in z_out / sdf_out / valid_out;
+ * mode 0: z_new (n_rays, n_new), pts_out (n_rays n_new, 3), valid_new (n_rays n_new);  mode 1: pts_out (n_rays (n + n_add), 3), valid_new likewise
+ * (sdf, valid, sdf_add, valid_add, sdf_out, valid_out, z_new may be NULL).  Results equal gens_merge_samples followed by gens_upsample (mode 0,
+ * with the merged mask decisions as valid_in) / by gens_ray_points with mid = 1 (mode 1), bit for bit. */
+int gens_merge_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const uint8_t* valid,
+                        const float* z_add, const float* sdf_add, const uint8_t* valid_add, int64_t n_rays, int n, int n_add, int n_new,
+                        float inv_s, float sample_dist, const float* const* masks, const int* dims, int n_levels, int mask_bits, int mode,
+                        float* z_out, float* sdf_out, uint8_t* valid_out, float* z_new, float* pts_out, uint8_t* valid_new, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K8  render_core compositing                                     (implicit_surface.py:160-168, 202-303)

@@ -84,6 +84,52 @@ def test_sampling_full_image_sorted_bounded_and_new_samples_inside_their_bins(sc
     assert torch.equal(torch.gather(z, 1, pos.clamp(max=127)), z0)
 
 
+def test_fused_sampling_rounds_equal_the_separate_operators_bit_for_bit(scene):
+    """One launch per sampling round (gens_merge_upsample: cat_z_vals of round i + up_sample / sample_pdf of round i + 1, and after the last
+    round the merge + render_core's section mid-points) against the separate operators (gens_merge_samples, gens_upsample, gens_ray_points):
+    the same samples, points and mask decisions, bit for bit, on a full ray chunk with jitter (ties and rays without any valid sample included)."""
+    from gens_amd import ops
+    from gens_amd.config import gens_model_conf
+    from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene
+    torch.manual_seed(0)
+    dims = scene["dims"][:3]
+    surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).cuda().eval()
+    sc = Scene(scene["vols"][:3], scene["masks"][:3], scene["imgs"], scene["features"], scene["features"], scene["intrs"], scene["c2ws"])
+    n = 32768 + 3                                                            # (a last block of three rays)
+    ro, rd = scene["rays_o"][90000:90000 + n].contiguous(), scene["rays_d"][90000:90000 + n].contiguous()
+    z0 = (scene["near"] + (scene["far"] - scene["near"]) * torch.linspace(0, 1, 64, device="cuda")[None]).expand(n, 64)
+    z0 = (z0 + (torch.rand(n, 1, generator=torch.Generator().manual_seed(3)).cuda() - 0.5) * 2.0 / 64).contiguous()
+    with torch.no_grad():
+        surf.fused_sampling = False
+        z_sep = surf._sample_rays(ro, rd, z0, sc)
+        pts_sep, valid_sep = ops.ray_points(ro, rd, z_sep, sc.masks, mid=True, sample_dist=2.0 / 64)
+        surf.fused_sampling = True
+        z_fused = surf._sample_rays(ro, rd, z0, sc)
+        assert surf._mid_points is None
+        z_fused2 = surf._sample_rays(ro, rd, z0, sc, mid_points=2.0 / 64)
+        cached = surf._mid_points
+    assert torch.equal(z_sep, z_fused) and torch.equal(z_sep, z_fused2)
+    assert cached is not None and cached[0] is z_fused2 and torch.equal(cached[2], pts_sep) and torch.equal(cached[3], valid_sep)
+    # a single round through the operators themselves, with mask decisions and duplicate z values (ties keep the older sample first)
+    g = torch.Generator().manual_seed(5)
+    b, m = 1000, 80
+    z = torch.sort(torch.rand(b, m, generator=g) * 2 + 1, dim=1)[0].cuda()
+    z_add = torch.sort(torch.rand(b, 16, generator=g) * 2 + 1, dim=1)[0].cuda()
+    z_add[:, 3] = z[:, 40]                                                   # ties between an old and a new sample, and between two new ones
+    z_add[:, 4] = z_add[:, 3]
+    z_add = torch.sort(z_add, dim=1)[0].contiguous()
+    sdf, sdf_add = torch.randn(b, m, generator=g).cuda() * 0.1, torch.randn(b, 16, generator=g).cuda() * 0.1
+    valid, valid_add = (torch.rand(b, m, generator=g) < 0.7).cuda(), (torch.rand(b, 16, generator=g) < 0.7).cuda()
+    valid[:7] = False
+    valid_add[:7] = False
+    rays_o, rays_d = ro[:b].contiguous(), rd[:b].contiguous()
+    zm, sm, vm = ops.merge_samples(z, z_add, sdf, sdf_add, valid, valid_add)
+    zn, pn, vn = ops.upsample(rays_o, rays_d, zm, sm, 16, sc.masks, 256.0, valid_in=vm)
+    fz, fs, fv, fzn, fpn, fvn = ops.merge_upsample(rays_o, rays_d, z, sdf, valid, z_add, sdf_add, valid_add, 16, sc.masks, 256.0)
+    for a, c in ((zm, fz), (sm, fs), (vm, fv), (zn, fzn), (pn, fpn), (vn, fvn)):
+        assert torch.equal(a, c)
+
+
 def test_render_full_chunk_weights_are_a_sub_probability_and_partition_invariant(scene):
     from gens_amd.config import gens_model_conf
     from gens_amd.models.modules.implicit_surface import ImplicitSurface, Scene
