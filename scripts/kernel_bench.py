@@ -166,6 +166,17 @@ def main():
         snew = ss[:, :16].contiguous()
         per = measure(lambda: ops.merge_samples(zz, znew, ss, snew), args.iters)
         add(f"K7 merge B={b} n=112+16", "gens_merge_samples", per, b * 128 * 16)
+        # ---- round 4: one launch per sampling round (merge of round i + up-sampling of round i + 1; last round: merge + mid-points)
+        for rnd, n in enumerate((64, 80, 96)):
+            zz3, ss3 = z128[:, :n].contiguous(), sdf[:, :n].contiguous()
+            _, vin3 = ops.ray_points(ro, rd, zz3, mset)
+            za = (zz3[:, :16] + 1e-3).contiguous()
+            sa, va = ss3[:, :16].contiguous(), vin3.reshape(b, n)[:, :16].contiguous()
+            per = measure(lambda: ops.merge_upsample(ro, rd, zz3, ss3, vin3.reshape(b, n), za, sa, va, 16, mset, 128.0 * 2 ** rnd), args.iters)
+            add(f"K7+K5/K6 merge_upsample B={b} n={n}+16->16", "gens_merge_upsample", per, b * (9 * (n + 16) + 9 * (n + 16) + 17 * 16 + 24),
+                "merge of round i and up-sampling of round i + 1 in one launch")
+        per = measure(lambda: ops.merge_mid_points(ro, rd, zz, znew, mset, 1 / 32), args.iters)
+        add(f"K7+K3 merge_mid_points B={b} n=112+16", "gens_merge_mid_points", per, b * (4 * 128 + 17 * 128 + 24), "the last merge + render_core's mid-points and masks")
 
         # ---- K8 compositing forward (inference: no smooth vector)
         n = 128
