@@ -96,6 +96,32 @@ __device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, c
     return acc;
 }
 
+// The same product as 16 x 16 tiles of v_mfma_f32_16x16x4_f32 (round 4): a layer's 32 x n_out outputs are 2 x ceil(n_out / 16) tiles dealt to
+// the four waves, each a chain of ceil(K / 4) dependent 32-cycle MFMAs -- a quarter of the 32 x 32 x 2 chain's cycles, and every wave works in the
+// 16- and 32-column layers that one wave used to serve alone (this kernel is latency-bound per workgroup: 22 dependent products with a barrier each).
+//   tile rows [r0, r0 + 16), columns [n0, n0 + 16);  lane l: A[row l & 15][k = l >> 4], B[k = l >> 4][column l & 15], D rows 4 (l >> 4) + r
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+template <bool TRANS, int K>
+__device__ __forceinline__ f32x4t bt_gemm16(const float* __restrict__ A, int rs, const float* __restrict__ W, int w_out, int w_in, int r0, int n0, int lane) {
+    f32x4t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int i = lane & 15, kq = lane >> 4, n = n0 + i;
+    const int N = TRANS ? w_in : w_out;
+    constexpr int KQ = (K + 3) / 4;
+    float bv[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k = 4 * j + kq;
+        bv[j] = (k < K && n < N) ? (TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k = 4 * j + kq;
+        const float a = k < K ? A[(r0 + i) * rs + k] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[j], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 template <int NLEV, bool BWD>
 __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {
     constexpr int F = 3 + 4 * NLEV, F3 = 3 * F;
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     float* GH = GX + 32 * BT_S_DFE;        // [32][33]  cotangent of h / h + res
     float* PP = GH + 32 * BT_S_H;          // [32][4]   per point: 0 sum of raw weights, 1 arg-min view, 2 spare, 3 spare
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid & 31, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid & 31;
     const int S = io.nv - 1, PPW = 32 / S;
     const int64_t first = (int64_t)blockIdx.x * PPW;
     const int64_t n = io.n_dev ? min(io.n, (int64_t)io.n_dev[0]) : io.n;
@@ -195,14 +221,15 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out
 #define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT)                                             \
-    for (int n0_ = 32 * wave; n0_ < (n_out); n0_ += 32 * BT_WAVES) {                                         \
-        f32x16 acc_ = bt_gemm<false, k_in>(IN, s_in, Wm, n_out, k_in, n0_, lane);                            \
-        const int c_ = n0_ + col;                                                                            \
+    for (int t_ = wave; t_ < 2 * (((n_out) + 15) / 16); t_ += BT_WAVES) {                                    \
+        const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                                 \
+        const f32x4t acc_ = bt_gemm16<false, k_in>(IN, s_in, Wm, n_out, k_in, r0_, n0_, lane);               \
+        const int c_ = n0_ + (lane & 15);                                                                    \
         if (c_ < (n_out)) {                                                                                  \
             const float bias_ = (Bv)[c_];                                                                    \
-            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                               \
                 const float v_ = acc_[r_] + bias_;                                                           \
-                (OUT)[bt_crow(r_, lane) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;                             \
+                (OUT)[(r0_ + 4 * (lane >> 4) + r_) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;                  \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -352,12 +379,13 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
 #define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY)                                              \
-    for (int n0_ = 32 * wave; n0_ < (n_in); n0_ += 32 * BT_WAVES) {                                          \
-        f32x16 acc_ = bt_gemm<true, k_out>(IN, s_in, Wm, k_out, n_in, n0_, lane);                            \
-        const int c_ = n0_ + col;                                                                            \
+    for (int t_ = wave; t_ < 2 * (((n_in) + 15) / 16); t_ += BT_WAVES) {                                     \
+        const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                                 \
+        const f32x4t acc_ = bt_gemm16<true, k_out>(IN, s_in, Wm, k_out, n_in, r0_, n0_, lane);               \
+        const int c_ = n0_ + (lane & 15);                                                                    \
         if (c_ < (n_in)) {                                                                                   \
-            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \
-                const int rr_ = bt_crow(r_, lane);                                                           \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                               \
+                const int rr_ = r0_ + 4 * (lane >> 4) + r_;                                                  \
                 const float xb_ = acc_[r_];                                                                  \
                 BODY                                                                                         \
             }                                                                                                \
