@@ -150,3 +150,53 @@ def test_general_sampler_agrees_with_the_fast_lookup_on_the_hot_paths_call():
         cug.grid_sample_2d(img, weird, padding_mode="reflection")
     with pytest.raises(RuntimeError, match="device"):
         cug.grid_sample_2d(img.cpu(), weird.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,pad,ac", [(2, "border", True), (3, "zeros", True), (3, "border", False)])
+def test_reference_function_pair_on_the_ctypes_extension(dim, pad, ac):
+    """The route INTEGRATION.md section 3 describes for a host that keeps the reference's OWN cuda_gridsample.py: its Function pair -- forward =
+    F.grid_sample, backward = aten::grid_sampler_{2,3}d_backward, backward of the backward = gridsample_grad2.grad2_{2,3}d -- with only the
+    extension replaced by gens_amd/compat/gridsample_grad2.py (ctypes on libgens_hip.so).  The pair below follows cuda_gridsample.py:21-123."""
+    from gens_amd.compat import gridsample_grad2
+
+    class Backward(torch.autograd.Function):                                       # _GridSample{2,3}dBackward (:45-66, :94-123)
+        @staticmethod
+        def forward(ctx, grad_output, input, grid, padding_mode, align_corners):
+            op = torch.ops.aten.grid_sampler_2d_backward if dim == 2 else torch.ops.aten.grid_sampler_3d_backward
+            grad_input, grad_grid = op(grad_output, input, grid, 0, padding_mode, align_corners, (ctx.needs_input_grad[1], ctx.needs_input_grad[2]))
+            ctx.save_for_backward(grad_output, input, grid)
+            ctx.padding_mode, ctx.align_corners = padding_mode, align_corners
+            return grad_input, grad_grid
+
+        @staticmethod
+        def backward(ctx, grad2_grad_input, grad2_grad_grid):
+            grad_output, input, grid = ctx.saved_tensors
+            fn = gridsample_grad2.grad2_2d if dim == 2 else gridsample_grad2.grad2_3d
+            out = fn(grad2_grad_input, grad2_grad_grid, grad_output, input, grid, ctx.padding_mode, ctx.align_corners)
+            return out[0], out[1], out[2], None, None
+
+    class Forward(torch.autograd.Function):                                        # _GridSample{2,3}dForward (:21-43, :71-91)
+        @staticmethod
+        def forward(ctx, input, grid, padding_mode, align_corners):
+            output = F.grid_sample(input=input, grid=grid, mode="bilinear", padding_mode=padding_mode, align_corners=align_corners)
+            ctx.save_for_backward(input, grid)
+            ctx.padding_mode, ctx.align_corners = ["zeros", "border"].index(padding_mode), align_corners
+            return output
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            input, grid = ctx.saved_tensors
+            grad_input, grad_grid = Backward.apply(grad_output, input, grid, ctx.padding_mode, ctx.align_corners)
+            return grad_input, grad_grid, None, None
+
+    x, grid, go, ggi, ggg = _case(dim, 40 * dim + ac)
+    _, _, (ref_ggo, ref_gi2, ref_gg2) = _oracle_all_orders(x.double(), grid.double(), go.double(), ggi.double(), ggg.double(), pad, ac)
+    xd, gd, god = x.cuda().requires_grad_(True), grid.cuda().requires_grad_(True), go.cuda().requires_grad_(True)
+    out = Forward.apply(xd, gd, pad, ac)
+    g_in, g_grid = torch.autograd.grad(out, [xd, gd], god, create_graph=True)
+    s = (g_in * ggi.cuda()).sum() + (g_grid * ggg.cuda()).sum()
+    gg_out, g_in2, g_grid2 = torch.autograd.grad(s, [god, xd, gd])
+    _close(gg_out, ref_ggo, 1e-4, "grad_grad_output")
+    _close(g_in2, ref_gi2, 1e-4, "second grad_input")
+    _close(g_grid2, ref_gg2, 5e-4, "second grad_grid")
