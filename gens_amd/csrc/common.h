@@ -253,6 +253,44 @@ __device__ __forceinline__ float4 sample_texel(const float4* __restrict__ img, i
     return acc;
 }
 
+// The same bilinear read by the two lanes of a pair (2k, 2k + 1) TOGETHER.  The vector L1 looks up one 128-byte line per clock whatever the
+// lanes want from it (scripts/probe/gather_rate_probe.py: 0.97 sixteen-byte loads per clock and CU with a line per lane, 1.87 with two adjacent
+// lanes on one line), and the two taps of an image row are 32 contiguous bytes: so every load instruction serves ONE item of the pair -- lane 2k
+// reads its x0 tap, lane 2k + 1 the x1 tap next to it -- and the halves are swapped back with quad_perm DPP moves.  Same number of loads per
+// lane as sample_texel, half the line look-ups; same weights and order of accumulation: bit-identical.  ALL lanes of the wave must call it
+// (a lane without an item passes any in-range taps); `row_off` = texel index of the item's image inside `tab` (view * h * w).
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }   // quad_perm:[1,0,3,2] (every lane has a source; bound_ctrl lets the compiler fold the move into its consumer)
+__device__ __forceinline__ float pair_swap(float v) { return __builtin_bit_cast(float, pair_swap(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float4 pair_swap(float4 v) { return make_float4(pair_swap(v.x), pair_swap(v.y), pair_swap(v.z), pair_swap(v.w)); }
+
+struct PairTaps {         // texel indices of the four loads of one lane: rows of the even lane's item (a0, a1), of the odd lane's (b0, b1)
+    int a0, a1, b0, b1;
+};
+__device__ __forceinline__ PairTaps pair_taps(int row_off, int h, int w, const Taps2& t, int odd) {
+    const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
+    const int r0 = row_off + min(max(t.y0, 0), h - 1) * w, r1 = row_off + min(max(t.y0 + 1, 0), h - 1) * w;
+    const int p_r0 = pair_swap(r0), p_r1 = pair_swap(r1), p_x0 = pair_swap(x0), p_x1 = pair_swap(x1);
+    const int ca = odd ? p_x1 : x0, cb = odd ? x1 : p_x0;
+    PairTaps q;
+    q.a0 = (odd ? p_r0 : r0) + ca;
+    q.a1 = (odd ? p_r1 : r1) + ca;
+    q.b0 = (odd ? r0 : p_r0) + cb;
+    q.b1 = (odd ? r1 : p_r1) + cb;
+    return q;
+}
+__device__ __forceinline__ float4 sample_texel_pair(const float4* __restrict__ tab, const PairTaps& q, const Taps2& t, int odd) {
+    const float4 a0 = tab[q.a0], a1 = tab[q.a1], b0 = tab[q.b0], b1 = tab[q.b1];
+    const float4 sa0 = pair_swap(a0), sa1 = pair_swap(a1), sb0 = pair_swap(b0), sb1 = pair_swap(b1);
+    // even lane: its x0 taps are a0 / a1, its x1 taps the partner's a0 / a1; odd lane: x1 = b0 / b1, x0 = the partner's b0 / b1
+    const float4 v00 = odd ? sb0 : a0, v01 = odd ? b0 : sa0, v10 = odd ? sb1 : a1, v11 = odd ? b1 : sa1;
+    float4 acc = f4_zero();
+    acc = f4_madd(acc, v00, t.ok00 ? t.w00 : 0.0f);
+    acc = f4_madd(acc, v01, t.ok01 ? t.w01 : 0.0f);
+    acc = f4_madd(acc, v10, t.ok10 ? t.w10 : 0.0f);
+    acc = f4_madd(acc, v11, t.ok11 ? t.w11 : 0.0f);
+    return acc;
+}
+
 __device__ __forceinline__ void atomic_add4(float* p, float4 v, float s) {
     atomicAdd(p + 0, v.x * s);
     atomicAdd(p + 1, v.y * s);

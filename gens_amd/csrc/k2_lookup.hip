@@ -103,6 +103,68 @@ __global__ __launch_bounds__(256) void lookup_fwd_k(LevelSet vs, const float* __
     out[gid] = acc;
 }
 
+// The same look-up with the lanes of a wave PAIRED (packed layout only).  The vector L1 looks up one 128-byte line per clock whatever the
+// lanes want from it (scripts/probe/gather_rate_probe.py: 0.97 loads per clock and CU with a line per lane, 1.87 with two adjacent lanes on
+// one line, 3.4 with four): the forward above issues 8 loads per lane on 8 different lines although the two z-taps of a corner are 32
+// contiguous bytes, and runs at that look-up ceiling.  Here lane 2k reads the z0 taps and lane 2k+1 the z1 taps of BOTH items of the pair
+// -- eight loads each as before, every instruction now two lanes to a line -- and the halves are swapped back with quad_perm DPP moves; each
+// lane then accumulates its own item's eight taps in the order of the kernel above: bit-identical results (pair_swap: common.h).
+__global__ __launch_bounds__(256) void lookup_fwd_paired_k(LevelSet vs, const float* __restrict__ pts, int64_t n, float4* __restrict__ out, int xcd_remap) {
+    uint32_t blk = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t per = gridDim.x >> 3;
+        if (blk < 8u * per) blk = (blk & 7u) * per + (blk >> 3);
+    }
+    const int64_t gid = (int64_t)blk * 256 + threadIdx.x;
+    const int L = vs.n;
+    const int64_t total = n * L;
+    const bool active = gid < total;
+    const int64_t g = active ? gid : total - 1;               // (a lane past the end still serves its partner: it works on the last item)
+    const int l = (int)(g % L);
+    const int64_t i = g / L;
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
+    const Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
+    const int odd = threadIdx.x & 1;
+    // texel indices of this lane's item (clamped, as above), then the partner's
+    int rowb[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) rowb[2 * a + b] = (min(max(cx.i0 + a, 0), X - 1) * Y + min(max(cy.i0 + b, 0), Y - 1)) * Z;
+    // every instruction serves ONE item of the pair: the first four loads the even lane's item, the last four the odd lane's; this lane
+    // reads z-slice `odd` of both
+    const int qz0 = min(max(cz.i0, 0), Z - 1), qz1 = min(max(cz.i0 + 1, 0), Z - 1);
+    const int p_qz0 = pair_swap(qz0), p_qz1 = pair_swap(qz1);
+    const uint64_t base = (uint64_t)vs.data[l];
+    const uint64_t p_base = ((uint64_t)(uint32_t)pair_swap((int)(base >> 32)) << 32) | (uint32_t)pair_swap((int)(uint32_t)base);
+    const float4* tab_a = (const float4*)(odd ? p_base : base);          // the even lane's item, seen from both lanes
+    const float4* tab_b = (const float4*)(odd ? base : p_base);          // the odd lane's item
+    const int q_a = odd ? p_qz1 : qz0, q_b = odd ? qz1 : p_qz0;
+    float4 first[4], second[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p_row = pair_swap(rowb[k]);
+        first[k] = tab_a[(odd ? p_row : rowb[k]) + q_a];
+        second[k] = tab_b[(odd ? rowb[k] : p_row) + q_b];
+    }
+    float4 acc = f4_zero();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // even lane: its z0 tap is first[k], its z1 tap the partner's first[k]; odd lane: z1 = second[k], z0 = the partner's second[k]
+        const float4 sf = pair_swap(first[k]), ss = pair_swap(second[k]);
+        const int a = k >> 1, b = k & 1;
+        const bool okab = (a ? cx.in1 : cx.in0) && (b ? cy.in1 : cy.in0);
+        const float wab = (a ? cx.w1 : cx.w0) * (b ? cy.w1 : cy.w0);
+        float4 v0 = odd ? ss : first[k], v1 = odd ? second[k] : sf;
+        if (!(okab && cz.in0)) v0 = f4_zero();
+        if (!(okab && cz.in1)) v1 = f4_zero();
+        acc = f4_madd(acc, v0, wab * cz.w0);
+        acc = f4_madd(acc, v1, wab * cz.w1);
+    }
+    if (active) out[gid] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // backward: one thread per point, loops levels.  g_pts always written; volume scatter only if vs.grad[l] != NULL.
 // ---------------------------------------------------------------------------------------------------------------
@@ -462,7 +524,13 @@ extern "C" int gens_lookup_volume_fwd(const float* const* vols, const int* dims,
     GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_fwd: bad layout %d", layout);
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out)), GENS_EINVAL, "gens_lookup_volume_fwd: null pts/out");
     if (n == 0) return 0;
-    DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out, (int)(getenv("GENS_NO_XCD_REMAP") == nullptr));
+    const int remap = getenv("GENS_NO_XCD_REMAP") == nullptr;
+    bool paired = layout == GENS_LAYOUT_PACKED && getenv("GENS_K2_NO_PAIRS") == nullptr;      // (texel indices in 32 bits there)
+    for (int l = 0; l < n_levels; ++l) paired = paired && (int64_t)vs.dx[l] * vs.dy[l] * vs.dz[l] < (1ll << 31);
+    if (paired)
+        lookup_fwd_paired_k<<<gens_blocks(n * n_levels, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, n, (float4*)out, remap);
+    else
+        DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out, remap);
     return gens_launch_status("gens_lookup_volume_fwd");
 }
 

@@ -19,14 +19,16 @@
 #define K4_BLOCK 256
 #define K4_MAX_ROW (3 + 4 * GENS_MAX_LEVELS)
 
+template <int NLEV>   // number of pyramid levels when known at compile time (the loads of all levels are then in flight together), 0 = fs.n
 __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, const float4* __restrict__ imgs,
                                                                  const float* __restrict__ w2c, const float* __restrict__ intr,
                                                                  const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
                                                                  int64_t n, float* __restrict__ out, float4* __restrict__ ray_diff,
-                                                                 uint8_t* __restrict__ vis, int plain_copy, int xcd_remap) {
+                                                                 uint8_t* __restrict__ vis, int plain_copy, int xcd_remap, int paired) {
     extern __shared__ __attribute__((aligned(16))) float row_lds[];  // K4_BLOCK rows of `row` floats, row stride padded to an odd count
     const int S = nv - 1;
-    const int row = 3 + 4 * fs.n;
+    const int n_lev = NLEV ? NLEV : fs.n;
+    const int row = 3 + 4 * n_lev;
     const int stride = row | 1;
     // Workgroups are dealt to the eight XCDs round robin: with block b = its launch index, neighbouring points (consecutive samples of a ray,
     // neighbouring rays) read their shared texel lines through eight different L2s.  xcd_remap (probe switch GENS_K4_XCD_REMAP): XCD x takes
@@ -40,32 +42,50 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
         const uint32_t per = nb >> 3;                      // blocks [0, 8 per) are remapped, the remainder keeps its place
         if (blk < 8u * per) blk = (blk & 7u) * per + (blk >> 3);
     }
-    int64_t gid = (int64_t)blk * K4_BLOCK + threadIdx.x;
-    int64_t total = n * S;
+    const int64_t gid = (int64_t)blk * K4_BLOCK + threadIdx.x;
+    const int64_t total = n * S;
     float* mine = row_lds + threadIdx.x * stride;
-    if (gid < total) {
-        int sv = (int)(gid % S) + 1;  // source view index in [1, nv)
-        int64_t i = gid / S;
+    // Lanes work in pairs (sample_texel_pair, common.h: two lanes to a 128-byte line in every load), so a lane past the end still serves its
+    // partner: it works on the last item and writes nothing to global memory.
+    const bool active = gid < total;
+    const int64_t g = active ? gid : total - 1;
+    const int odd = threadIdx.x & 1;
+    {
+        int sv = (int)(g % S) + 1;  // source view index in [1, nv)
+        int64_t i = g / S;
         float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
         bool inside = true;
-        for (int l = 0; l < fs.n; ++l) {
+        const SrcBase pb = project_src_base(w2c + 16 * sv, intr + 16 * sv, x, y, z);     // once per (point, view): see k4_common.h
+        auto level = [&](int l) {
             int h = fs.h[l], w = fs.w[l];
-            SrcProj p = project_src(w2c + 16 * sv, intr + 16 * sv, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l], x, y, z);
+            SrcProj p = project_src_level(pb, exp2f(-(float)l), h, w, fs.cw[l], fs.ch[l], fs.rcw[l], fs.rch[l]);
             inside = inside && p.inside;
             Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-            float4 f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+            float4 f;
+            PairTaps q;
+            if (paired) {
+                q = pair_taps(sv * h * w, h, w, t, odd);
+                f = sample_texel_pair(fs.data[l], q, t, odd);
+            } else {
+                f = sample_texel(fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
+            }
             mine[3 + 4 * l] = f.x;
             mine[4 + 4 * l] = f.y;
             mine[5 + 4 * l] = f.z;
             mine[6 + 4 * l] = f.w;
             if (l == 0) {
-                float4 c = sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+                float4 c = paired ? sample_texel_pair(imgs, q, t, odd) : sample_texel(imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
                 mine[0] = c.x;
                 mine[1] = c.y;
                 mine[2] = c.z;
             }
+        };
+        if constexpr (NLEV > 0) {
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) level(l);
+        } else {
+            for (int l = 0; l < fs.n; ++l) level(l);
         }
-        vis[gid] = inside ? 1 : 0;
         // compute_angle (projector.py:278-291)
         float rx = c2w[3] - x, ry = c2w[7] - y, rz = c2w[11] - z;
         float rn = sqrtf(rx * rx + ry * ry + rz * rz) + 1e-6f;
@@ -76,7 +96,10 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
         sx /= sn; sy /= sn; sz /= sn;
         float dx = rx - sx, dy = ry - sy, dz = rz - sz;
         float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
-        ray_diff[gid] = make_float4(dx / dn, dy / dn, dz / dn, rx * sx + ry * sy + rz * sz);
+        if (active) {
+            vis[gid] = inside ? 1 : 0;
+            ray_diff[gid] = make_float4(dx / dn, dy / dn, dz / dn, rx * sx + ry * sy + rz * sz);
+        }
     }
     __syncthreads();
     // cooperative, coalesced write of this block's rows.  3 + 4 L is odd, so the padded stride IS the row length: the block's rows are one
@@ -174,10 +197,16 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && out && ray_diff && vis)), GENS_EINVAL, "gens_lookup_feature_fwd: null pts / output");
     if (n == 0) return 0;
     int row = 3 + 4 * n_levels;
+    // (texel indices in 32 bits in the paired read; GENS_K4_NO_PAIRS: the lane-per-item read, for A/B runs)
+    const int paired = getenv("GENS_K4_NO_PAIRS") == nullptr && (int64_t)nv * hw[0] * hw[1] < (1ll << 31);
     size_t lds = (size_t)K4_BLOCK * (row | 1) * sizeof(float);
-    lookup_feature_fwd_k<<<gens_blocks(n * (nv - 1), K4_BLOCK), K4_BLOCK, lds, (hipStream_t)stream>>>(
-        fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, getenv("GENS_K4_PLAIN_COPY") != nullptr,
-        getenv("GENS_K4_XCD_REMAP") != nullptr);
+    const dim3 grid = gens_blocks(n * (nv - 1), K4_BLOCK);
+    const int plain = getenv("GENS_K4_PLAIN_COPY") != nullptr, remap = getenv("GENS_K4_XCD_REMAP") != nullptr;
+#define K4_LAUNCH(NLEV) lookup_feature_fwd_k<NLEV><<<grid, K4_BLOCK, lds, (hipStream_t)stream>>>(fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, plain, remap, paired)
+    if (n_levels == 5 && !getenv("GENS_K4_NO_UNROLL")) K4_LAUNCH(5);
+    else if (n_levels == 3 && !getenv("GENS_K4_NO_UNROLL")) K4_LAUNCH(3);
+    else K4_LAUNCH(0);
+#undef K4_LAUNCH
     return gens_launch_status("gens_lookup_feature_fwd");
 }
 

@@ -31,7 +31,12 @@ ENTRY = {"sdf_mlp_k": "gens_sdf_mlp", "sdf_value_t_k": "gens_sdf_value", "sdf_gr
          "volume_bwd_tiles_k": "gens_volume_build_bwd_levels", "sdf_train_wgrad_k": "gens_sdf_train_wgrad", "sdf_train_norm_k": "gens_sdf_train_pack_wn",
          "blend_wgrad_k": "gens_blend_train_wgrad", "tv_levels_fwd_k": "gens_tv_levels_fwd", "tv_levels_bwd_k": "gens_tv_levels_bwd",
          "patch_warp_fwd_k": "gens_patch_warp_fwd", "patch_warp_bwd_k": "gens_patch_warp_bwd", "loss_fwd_k": "gens_loss_fwd", "loss_bwd_k": "gens_loss_bwd",
-         "lncc_fwd_k": "gens_lncc_fwd", "lncc_bwd_k": "gens_lncc_bwd", "composite_bwd_k": "gens_composite_bwd"}
+         "lncc_fwd_k": "gens_lncc_fwd", "lncc_bwd_k": "gens_lncc_bwd", "composite_bwd_k": "gens_composite_bwd",
+         # round 4
+         "merge_upsample_k": "gens_merge_upsample", "lookup_fwd_k": "gens_lookup_volume_fwd", "lookup_feature_fwd_k": "gens_lookup_feature_fwd",
+         "lookup_bwd_k": "gens_lookup_volume_bwd", "lookup_bwd2_k": "gens_lookup_volume_bwd2", "lookup_scatter_k": "gens_lookup_volume_scatter",
+         "conv3d_wgrad_mfma_k": "gens_conv3d_wgrad", "dw_tile_k": "gens_depthwise_conv2d", "dw_wgrad_tile_k": "gens_depthwise_conv2d", "dw_dgrad_k": "gens_depthwise_conv2d",
+         "bn_stats_k": "gens_batchnorm2d", "bn_apply_k": "gens_batchnorm2d", "bn_bwd_stats_k": "gens_batchnorm2d", "bn_bwd_apply_k": "gens_batchnorm2d"}
 # entry points made of several device kernels: the launches of this one are the entry point's
 ONE_PER_ENTRY = {"gens_volume_build_bwd_levels": "volume_bwd_tiles_k"}
 

@@ -66,9 +66,29 @@ with torch.no_grad():
     pts, valid = ops.ray_points(ro, rd, z128, mset, mid=True, sample_dist=1 / 32)
     npts = pts.shape[0]
     ab(f"K2 lookup fwd packed N={npts} L=3", lambda: ops.lookup_volume(pts, vpack), "GENS_NO_XCD_REMAP", npts * (12 + 16 * 3))
+    ab(f"K2 lookup fwd packed N={npts} L=3 (pairs)", lambda: ops.lookup_volume(pts, vpack), "GENS_K2_NO_PAIRS", npts * (12 + 16 * 3))
+    os.environ["GENS_K2_NO_PAIRS"] = "1"
+    ref = ops.lookup_volume(pts, vpack)
+    os.environ.pop("GENS_K2_NO_PAIRS")
+    print("K2 paired forward bit-identical to the lane-per-item kernel:", bool(torch.equal(ref, ops.lookup_volume(pts, vpack))))
     views = ops.SceneViews(imgs, intrs, c2ws, feats)
     pv = pts[valid.bool()].contiguous()
     nvp, s = pv.shape[0], 4
     nb4 = nvp * 12 + nvp * s * (4 * (3 + 4 * 5) + 17)
     ab(f"K4 lookup_feature N={nvp} S=4 L_f=5 (remap)", lambda: ops.lookup_feature(pv, views), "GENS_NO_XCD_REMAP", nb4)
     ab(f"K4 lookup_feature N={nvp} S=4 L_f=5 (copy)", lambda: ops.lookup_feature(pv, views), "GENS_K4_PLAIN_COPY", nb4)
+    ab(f"K4 lookup_feature N={nvp} S=4 L_f=5 (pairs)", lambda: ops.lookup_feature(pv, views), "GENS_K4_NO_PAIRS", nb4)
+    ab(f"K4 lookup_feature N={nvp} S=4 L_f=5 (unroll)", lambda: ops.lookup_feature(pv, views), "GENS_K4_NO_UNROLL", nb4)
+    os.environ["GENS_K4_NO_PAIRS"] = "1"
+    ref = ops.lookup_feature(pv, views)
+    os.environ.pop("GENS_K4_NO_PAIRS")
+    new = ops.lookup_feature(pv, views)
+    print("K4 paired forward bit-identical to the lane-per-item kernel:", all(bool(torch.equal(a, b)) for a, b in zip(ref, new)))
+    for s3 in (3, 2):
+        v3 = ops.SceneViews(imgs[:s3 + 1], intrs[:s3 + 1], c2ws[:s3 + 1], [f[:s3 + 1].contiguous() for f in feats])
+        pv3 = pv[:1000003]
+        os.environ["GENS_K4_NO_PAIRS"] = "1"
+        ref = ops.lookup_feature(pv3, v3)
+        os.environ.pop("GENS_K4_NO_PAIRS")
+        new = ops.lookup_feature(pv3, v3)
+        print(f"  S={s3}, odd point count:", all(bool(torch.equal(a, b)) for a, b in zip(ref, new)))
