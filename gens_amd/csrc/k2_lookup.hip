@@ -109,19 +109,20 @@ __global__ __launch_bounds__(256) void lookup_fwd_k(LevelSet vs, const float* __
 // contiguous bytes, and runs at that look-up ceiling.  Here lane 2k reads the z0 taps and lane 2k+1 the z1 taps of BOTH items of the pair
 // -- eight loads each as before, every instruction now two lanes to a line -- and the halves are swapped back with quad_perm DPP moves; each
 // lane then accumulates its own item's eight taps in the order of the kernel above: bit-identical results (pair_swap: common.h).
-__global__ __launch_bounds__(256) void lookup_fwd_paired_k(LevelSet vs, const float* __restrict__ pts, int64_t n, float4* __restrict__ out, int xcd_remap) {
+__global__ __launch_bounds__(256) void lookup_fwd_paired_k(LevelSet vs, const float* __restrict__ pts, uint32_t total, uint32_t magic,
+                                                           float4* __restrict__ out, int xcd_remap) {
     uint32_t blk = blockIdx.x;
     if (xcd_remap) {
         const uint32_t per = gridDim.x >> 3;
         if (blk < 8u * per) blk = (blk & 7u) * per + (blk >> 3);
     }
-    const int64_t gid = (int64_t)blk * 256 + threadIdx.x;
-    const int L = vs.n;
-    const int64_t total = n * L;
+    // (the host takes this kernel for fewer than 2^29 items: 32-bit indices, and item / L as one multiply-high by magic = ceil(2^32 / L))
+    const uint32_t gid = blk * 256u + threadIdx.x;
+    const uint32_t L = (uint32_t)vs.n;
     const bool active = gid < total;
-    const int64_t g = active ? gid : total - 1;               // (a lane past the end still serves its partner: it works on the last item)
-    const int l = (int)(g % L);
-    const int64_t i = g / L;
+    const uint32_t g = active ? gid : total - 1u;             // (a lane past the end still serves its partner: it works on the last item)
+    const uint32_t i = L == 1u ? g : __umulhi(g, magic);
+    const int l = (int)(g - i * L);
     const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     const int X = vs.dx[l], Y = vs.dy[l], Z = vs.dz[l];
     const Cell cx = axis_cell(px, X), cy = axis_cell(py, Y), cz = axis_cell(pz, Z);
@@ -527,8 +528,10 @@ extern "C" int gens_lookup_volume_fwd(const float* const* vols, const int* dims,
     const int remap = getenv("GENS_NO_XCD_REMAP") == nullptr;
     bool paired = layout == GENS_LAYOUT_PACKED && getenv("GENS_K2_NO_PAIRS") == nullptr;      // (texel indices in 32 bits there)
     for (int l = 0; l < n_levels; ++l) paired = paired && (int64_t)vs.dx[l] * vs.dy[l] * vs.dz[l] < (1ll << 31);
+    paired = paired && n * n_levels < (1ll << 29);
     if (paired)
-        lookup_fwd_paired_k<<<gens_blocks(n * n_levels, 256), 256, 0, (hipStream_t)stream>>>(vs, pts, n, (float4*)out, remap);
+        lookup_fwd_paired_k<<<gens_blocks(n * n_levels, 256), 256, 0, (hipStream_t)stream>>>(
+            vs, pts, (uint32_t)(n * n_levels), (uint32_t)(((1ull << 32) + (uint32_t)n_levels - 1u) / (uint32_t)n_levels), (float4*)out, remap);
     else
         DISPATCH_LAYOUT(layout, lookup_fwd_k, gens_blocks(n * n_levels, 256), stream, vs, pts, n, (float4*)out, remap);
     return gens_launch_status("gens_lookup_volume_fwd");

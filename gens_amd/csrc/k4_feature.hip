@@ -24,7 +24,7 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
                                                                  const float* __restrict__ w2c, const float* __restrict__ intr,
                                                                  const float* __restrict__ c2w, int nv, const float* __restrict__ pts,
                                                                  int64_t n, float* __restrict__ out, float4* __restrict__ ray_diff,
-                                                                 uint8_t* __restrict__ vis, int plain_copy, int xcd_remap, int paired) {
+                                                                 uint8_t* __restrict__ vis, int plain_copy, int xcd_remap, int paired, uint32_t magic) {
     extern __shared__ __attribute__((aligned(16))) float row_lds[];  // K4_BLOCK rows of `row` floats, row stride padded to an odd count
     const int S = nv - 1;
     const int n_lev = NLEV ? NLEV : fs.n;
@@ -51,8 +51,16 @@ __global__ __launch_bounds__(K4_BLOCK) void lookup_feature_fwd_k(MapSet fs, cons
     const int64_t g = active ? gid : total - 1;
     const int odd = threadIdx.x & 1;
     {
-        int sv = (int)(g % S) + 1;  // source view index in [1, nv)
-        int64_t i = g / S;
+        int sv;                     // source view index in [1, nv)
+        int64_t i;
+        if (magic) {                // fewer than 2^29 items: item / S as one multiply-high by magic = ceil(2^32 / S)
+            const uint32_t g32 = (uint32_t)g, i32 = __umulhi(g32, magic);
+            sv = (int)(g32 - i32 * (uint32_t)S) + 1;
+            i = i32;
+        } else {
+            sv = (int)(g % S) + 1;
+            i = g / S;
+        }
         float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
         bool inside = true;
         const SrcBase pb = project_src_base(w2c + 16 * sv, intr + 16 * sv, x, y, z);     // once per (point, view): see k4_common.h
@@ -201,8 +209,9 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
     const int paired = getenv("GENS_K4_NO_PAIRS") == nullptr && (int64_t)nv * hw[0] * hw[1] < (1ll << 31);
     size_t lds = (size_t)K4_BLOCK * (row | 1) * sizeof(float);
     const dim3 grid = gens_blocks(n * (nv - 1), K4_BLOCK);
+    const uint32_t magic = (nv > 2 && n * (nv - 1) < (1ll << 29)) ? (uint32_t)(((1ull << 32) + (uint32_t)(nv - 2)) / (uint32_t)(nv - 1)) : 0u;   // (S = 1: no magic)
     const int plain = getenv("GENS_K4_PLAIN_COPY") != nullptr, remap = getenv("GENS_K4_XCD_REMAP") != nullptr;
-#define K4_LAUNCH(NLEV) lookup_feature_fwd_k<NLEV><<<grid, K4_BLOCK, lds, (hipStream_t)stream>>>(fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, plain, remap, paired)
+#define K4_LAUNCH(NLEV) lookup_feature_fwd_k<NLEV><<<grid, K4_BLOCK, lds, (hipStream_t)stream>>>(fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, plain, remap, paired, magic)
     if (n_levels == 5 && !getenv("GENS_K4_NO_UNROLL")) K4_LAUNCH(5);
     else if (n_levels == 3 && !getenv("GENS_K4_NO_UNROLL")) K4_LAUNCH(3);
     else K4_LAUNCH(0);
