@@ -53,7 +53,9 @@ __device__ __forceinline__ Cell axis_cell(float p, int size) {
     c.w1 = pos - f;
     c.in0 = c.i0 >= 0 && c.i0 < size;
     c.in1 = c.i0 + 1 >= 0 && c.i0 + 1 < size;
-    if (!(pos == pos)) { c.in0 = c.in1 = false; c.w0 = c.w1 = 0.0f; }  // NaN point
+    // NaN point, or one so far outside that no tap is inside: zero WEIGHTS as well -- (f + 1) - pos of a point at 1e12 overflows in the product of
+    // three weights, and 0 * inf would put a NaN where F.grid_sample (which skips out-of-bounds taps) returns exactly 0
+    if (!(pos > -2.0f && pos < (float)size + 1.0f)) { c.in0 = c.in1 = false; c.w0 = c.w1 = 0.0f; }
     return c;
 }
 

@@ -697,3 +697,51 @@ def test_split_half_kernels_at_full_chunk_size_agree_with_float32_and_with_each_
     untouched[live] = False
     assert bool((s_out[untouched] == 100.0).all()) and bool((g_out[untouched] == -7.0).all())
     assert not plan.overflowed()
+
+
+@pytest.mark.parametrize("n_levels,n_points", [(1, 1001), (2, 4097), (3, 65537), (4, 333), (5, 20001)])
+def test_k2_forward_lane_pairs_equal_the_lane_per_item_kernel(scene, n_levels, n_points, monkeypatch):
+    """The packed forward reads with two lanes to a texel line (lookup_fwd_paired_k); the lane-per-item kernel (GENS_K2_NO_PAIRS) is the
+    reference of the goldens g2: bit-identical for every level count, odd item counts (a pair straddles two points / the end of the
+    launch), points on and outside the faces of the volume, and not-a-number points."""
+    from gens_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n_points)
+    pts = (torch.rand(n_points, 3, generator=g) * 2.6 - 1.3).cuda()                 # a fifth of them outside [-1, 1]^3
+    pts[::97] = torch.tensor([1.0, -1.0, 1.0], device="cuda")                      # corners
+    pts[5::89, 1] = 1.0                                                              # on a face
+    pts[7::101, 2] = float("nan")
+    pts[11::103] = 1e30
+    vset = ops.VolumeSet.packed(scene["vols"][:n_levels])
+    new = ops.lookup_volume(pts, vset)
+    monkeypatch.setenv("GENS_K2_NO_PAIRS", "1")
+    old = ops.lookup_volume(pts, vset)
+    assert new.shape == (n_points, 4 * n_levels)
+    assert torch.equal(new.view(torch.int32), old.view(torch.int32))
+    assert bool(torch.isfinite(new[torch.isfinite(pts).all(1)]).all())          # incl. the points at 1e30: no 0 * inf from overflowing weights
+    assert float(new[11::103].abs().max()) == 0.0                               # F.grid_sample skips out-of-bounds taps: exactly zero
+
+
+@pytest.mark.parametrize("n_src,n_feat,n_points", [(4, 5, 30011), (3, 5, 7777), (2, 3, 12345), (1, 3, 501), (4, 2, 999)])
+def test_k4_forward_lane_pairs_equal_the_lane_per_item_kernel(scene, n_src, n_feat, n_points, monkeypatch):
+    """lookup_feature's forward with the bilinear taps read by lane pairs (sample_texel_pair) against the lane-per-item read
+    (GENS_K4_NO_PAIRS): bit-identical rows, ray differences and visibility flags for 1 - 4 source views (pairs straddle points for odd
+    counts), 2 / 3 / 5 feature levels, points behind the cameras and far outside every frustum."""
+    from gens_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n_points)
+    pts = (torch.rand(n_points, 3, generator=g) * 2.4 - 1.2).cuda()
+    pts[::53] *= 40.0                                                                # far outside / behind some cameras
+    nv = n_src + 1
+    views = ops.SceneViews(scene["imgs"][:nv].contiguous(), scene["intrs"][:nv].contiguous(), scene["c2ws"][:nv].contiguous(),
+                           [f[:nv].contiguous() for f in scene["features"][:n_feat]])
+    new = ops.lookup_feature(pts, views)
+    monkeypatch.setenv("GENS_K4_NO_PAIRS", "1")
+    old = ops.lookup_feature(pts, views)
+    monkeypatch.setenv("GENS_K4_NO_UNROLL", "1")
+    rolled = ops.lookup_feature(pts, views)
+    for a, b, c in zip(new, old, rolled):
+        assert a.shape == b.shape
+        if a.dtype == torch.bool:
+            assert torch.equal(a, b) and torch.equal(a, c)
+        else:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
+    assert 0 < int(new[2].sum()) < new[2].numel()
