@@ -146,6 +146,13 @@ def test_general_sampler_agrees_with_the_fast_lookup_on_the_hot_paths_call():
     for pad in ("zeros", "border"):
         got = cug.grid_sample_2d(img, weird, padding_mode=pad)
         assert torch.isfinite(got).all()
+    # finite but absurdly far points: ATen skips out-of-bounds taps (zeros: exactly 0; border: the clamped texel) -- no 0 * inf from weights
+    far2 = torch.tensor([[1e30, 0.0], [-3e38, 1e20], [0.2, -1e15], [1e12, 1e12]]).reshape(1, 1, 4, 2).cuda()
+    far3 = torch.tensor([[1e30, 0.0, 0.1], [-3e38, 1e20, 0.0], [0.2, -1e15, 0.3], [1e12, 1e12, 1e12]]).reshape(1, 1, 1, 4, 3).cuda()
+    for pad in ("zeros", "border"):
+        for ac in (True, False):
+            _close(cug.grid_sample_2d(img, far2, padding_mode=pad, align_corners=ac), F.grid_sample(img, far2, padding_mode=pad, align_corners=ac), 1e-6, f"far 2-D {pad} {ac}")
+            _close(cug.grid_sample_3d(vol, far3, padding_mode=pad, align_corners=ac), F.grid_sample(vol, far3, padding_mode=pad, align_corners=ac), 1e-6, f"far 3-D {pad} {ac}")
     with pytest.raises(RuntimeError, match="padding_mode"):
         cug.grid_sample_2d(img, weird, padding_mode="reflection")
     with pytest.raises(RuntimeError, match="device"):
