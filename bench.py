@@ -234,6 +234,7 @@ def main():
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher's --nproc-per-node and --gpus must agree" % (args.gpus, env_world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                    # dmabuf IPC: what RCCL needs on this driver (also under torch.distributed.run)
     import torch
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner through the C stdio buffer, which is flushed
     # at exit, i.e. after the line): everything else that goes to file descriptor 1 is sent to stderr, the line is written to the real stdout.

@@ -157,6 +157,36 @@ extern "C" int gens_instnorm_stats(const float* x, int c, int64_t n, double* par
     return gens_launch_status("gens_instnorm_stats");
 }
 
+// partials (c, blocks, 2) of either statistics kernel -> out (c, 2) floats in ONE launch (the PyTorch glue this replaces was nine tiny launches per
+// layer forward and three backward): mode 0 = (mean, 1 / sqrt(max(E[x^2] - mean^2, 0) + eps)), mode 1 = (sum_0 / n, sum_1 / n); float64 inside.
+__global__ __launch_bounds__(64) void instnorm_finish_k(const double* __restrict__ part, int c, int blocks, double inv_n, double eps, int mode,
+                                                        float* __restrict__ out) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < blocks; ++b) {                      // in block order: the sum does not depend on scheduling
+        s0 += part[((int64_t)ch * blocks + b) * 2];
+        s1 += part[((int64_t)ch * blocks + b) * 2 + 1];
+    }
+    s0 *= inv_n;
+    s1 *= inv_n;
+    if (mode == 0) {
+        const double var = fmax(s1 - s0 * s0, 0.0) + eps;
+        out[2 * ch] = (float)s0;
+        out[2 * ch + 1] = (float)(1.0 / sqrt(var));
+    } else {
+        out[2 * ch] = (float)s0;
+        out[2 * ch + 1] = (float)s1;
+    }
+}
+
+extern "C" int gens_instnorm_finish(const double* partials, int c, int64_t n, double eps, int mode, float* out, void* stream) {
+    GENS_CHECK_ARG(partials && out && c > 0 && n > 0 && c <= 65535 && (mode == 0 || mode == 1), GENS_EINVAL, "gens_instnorm_finish: bad argument");
+    hipLaunchKernelGGL(instnorm_finish_k, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, c, gens_instnorm_blocks(c, n), 1.0 / (double)n,
+                       eps, mode, out);
+    return gens_launch_status("gens_instnorm_finish");
+}
+
 extern "C" int gens_instnorm_relu_fwd(const float* x, const float* mean_rstd, int c, int64_t n, float* y, void* stream) {
     GENS_CHECK_ARG(x && mean_rstd && y && c > 0 && n > 0 && c <= 65535, GENS_EINVAL, "gens_instnorm_relu_fwd: bad argument");
     INSTNORM_LAUNCH(instnorm_relu_fwd_k, x, mean_rstd, (const float*)nullptr, n, y);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "gens_conv3d_wgrad": [_p, _p, _i, _i, _ip, _i, _p, _p],
     "gens_instnorm_blocks": [_i, _l],
     "gens_instnorm_stats": [_p, _i, _l, _p, _p],
+    "gens_instnorm_finish": [_p, _i, _l, C.c_double, _i, _p, _p],
     "gens_instnorm_relu_fwd": [_p, _p, _i, _l, _p, _p],
     "gens_instnorm_relu_add_fwd": [_p, _p, _p, _i, _l, _p, _p],
     "gens_instnorm_relu_bwd_stats": [_p, _p, _p, _i, _l, _p, _p],

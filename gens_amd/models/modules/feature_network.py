@@ -19,6 +19,7 @@ K21 (gens_depthwise_conv2d_*, csrc/k21_depthwise.hip) whenever the call is one K
 {1, 2}, padding k // 2 -- and to nn.Conv2d's own forward otherwise (CPU tensors, other dtypes: PyTorch's convolution, as before)."""
 import os
 
+import torch
 import torch.nn as nn
 
 _BN_MOMENTUM = 1 - 0.9997
@@ -107,8 +108,17 @@ class _Deconv2d(nn.Module):
         self.bn = nn.InstanceNorm2d(cout)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x):
-        return self.relu(self.bn(self.conv(x)))
+    use_k16 = os.environ.get("GENS_NO_K16_2D") is None
+
+    def forward(self, x, skip=None):
+        """relu(instance_norm(deconv(x))) [+ skip]: on the device the norm, the ReLU and the decoder's skip addition are K16 (gens_instnorm_*, the
+        kernels of the 3-D U-Net's blocks: a batch of n * c planes), two streaming passes each way instead of aten's batch-norm route + ReLU + add."""
+        y = self.conv(x)
+        if self.use_k16 and y.is_cuda and y.dtype == torch.float32 and not self.bn.affine and not self.bn.track_running_stats:
+            from ... import ops
+            return ops.instnorm_relu(y, self.bn.eps, skip)
+        y = self.relu(self.bn(y))
+        return y if skip is None else y + skip
 
 
 class FeatureNetwork(nn.Module):
@@ -141,9 +151,9 @@ class FeatureNetwork(nn.Module):
         e3 = self.layer3(e2)
         e4 = self.layer4(e3)
         e5 = self.layer5(e4)
-        d5 = self.decod_layer5(e5) + e4
-        d4 = self.decod_layer4(d5) + e3
-        d3 = self.decod_layer3(d4) + e2
-        d2 = self.decod_layer2(d3) + e1
+        d5 = self.decod_layer5(e5, e4)
+        d4 = self.decod_layer4(d5, e3)
+        d3 = self.decod_layer3(d4, e2)
+        d2 = self.decod_layer2(d3, e1)
         d1 = self.decod_layer1(d2)
         return [self.out_layer1(d1), self.out_layer2(d2), self.out_layer3(d3), self.out_layer4(d4), self.out_layer5(d5)]

@@ -131,9 +131,8 @@ class _InstNormRelu(torch.autograd.Function):
         blocks = L.load().gens_instnorm_blocks(c, n)
         part = torch.empty(c, blocks, 2, device=x.device, dtype=_f64)
         L.call("gens_instnorm_stats", L.ptr(x2, align=16), c, n, L.ptr(part, _f64), L.stream(), nbytes=4 * c * n)
-        s = part.sum(1) / n                                                        # float64: mean, mean of squares
-        mean = s[:, 0]
-        mr = torch.stack([mean, torch.rsqrt((s[:, 1] - mean * mean).clamp_min(0.0) + eps)], 1).to(_f32)
+        mr = torch.empty(c, 2, device=x.device, dtype=_f32)                       # (mean, 1 / sqrt(biased variance + eps)), from float64 sums
+        L.call("gens_instnorm_finish", L.ptr(part, _f64), c, n, float(eps), 0, L.ptr(mr), L.stream())
         y = torch.empty_like(x2)
         if skip is None:
             L.call("gens_instnorm_relu_fwd", L.ptr(x2), L.ptr(mr), c, n, L.ptr(y), L.stream(), nbytes=8 * c * n)
@@ -152,15 +151,21 @@ class _InstNormRelu(torch.autograd.Function):
         g2 = _c(gy.to(_f32)).reshape(c, n)
         part = torch.empty(c, ctx.blocks, 2, device=x2.device, dtype=_f64)
         L.call("gens_instnorm_relu_bwd_stats", L.ptr(x2), L.ptr(g2), L.ptr(mr), c, n, L.ptr(part, _f64), L.stream(), nbytes=8 * c * n)
-        m12 = (part.sum(1) / n).to(_f32)
+        m12 = torch.empty(c, 2, device=x2.device, dtype=_f32)
+        L.call("gens_instnorm_finish", L.ptr(part, _f64), c, n, 0.0, 1, L.ptr(m12), L.stream())
         gx = torch.empty_like(x2)
         L.call("gens_instnorm_relu_bwd", L.ptr(x2), L.ptr(g2), L.ptr(mr), L.ptr(m12), c, n, L.ptr(gx), L.stream(), nbytes=12 * c * n)
         return gx.reshape(gy.shape), None, (gy if ctx.needs_input_grad[2] else None)
 
 
 def instnorm_relu(x, eps=1e-5, skip=None):
-    """relu(instance_norm(x)) [+ skip] for x (1, c, ...): per-channel statistics over the plane, biased variance, no affine parameters."""
-    assert x.shape[0] == 1 and x.dim() >= 3
+    """relu(instance_norm(x)) [+ skip] for x (n, c, ...): statistics per (sample, channel) plane, biased variance, no affine parameters
+    (nn.InstanceNorm3d / nn.InstanceNorm2d in their default form followed by nn.ReLU).  A batch is n * c planes of one sample."""
+    assert x.dim() >= 3
+    if x.shape[0] != 1:
+        shape = x.shape
+        flat = (1, shape[0] * shape[1]) + tuple(shape[2:])
+        return _InstNormRelu.apply(x.reshape(flat), float(eps), None if skip is None else skip.reshape(flat)).reshape(shape)
     return _InstNormRelu.apply(x, float(eps), skip)
 
 

@@ -628,10 +628,13 @@ int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq, const int*
  *        gens_instnorm_relu_fwd        y = max((x - mean) * rstd, 0), mean_rstd (c, 2) float32
  *        gens_instnorm_relu_bwd_stats  partials (c, blocks, 2) float64: sums of g and g xhat, g = gy [xhat > 0], xhat = (x - mean) * rstd
  *        gens_instnorm_relu_bwd        gx = rstd (g - m1 - xhat m2), g_means (c, 2) float32 = {m1 = mean(g), m2 = mean(g xhat)}
- *      The caller adds the partials (float64) and forms mean / rstd / m1 / m2.
+ *        gens_instnorm_finish          partials -> (c, 2) float32 in one launch, float64 inside: mode 0 = (mean, 1 / sqrt(max(E[x^2] - mean^2, 0) + eps))
+ *                                      from gens_instnorm_stats' partials, mode 1 = (m1, m2) from gens_instnorm_relu_bwd_stats' (eps ignored)
+ *      A batch (nn.InstanceNorm2d of the feature decoder, feature_network_mnasnet.py:29-50) is n * c planes: pass c = n * c.
  * ---------------------------------------------------------------------------------------------------------- */
 int gens_instnorm_blocks(int c, int64_t n);
 int gens_instnorm_stats(const float* x, int c, int64_t n, double* partials, void* stream);
+int gens_instnorm_finish(const double* partials, int c, int64_t n, double eps, int mode, float* out, void* stream);
 int gens_instnorm_relu_fwd(const float* x, const float* mean_rstd, int c, int64_t n, float* y, void* stream);
 /* the same + skip (c, n): the decoder blocks add the encoder's tensor right after norm + ReLU (reg_network.py:158) */
 int gens_instnorm_relu_add_fwd(const float* x, const float* mean_rstd, const float* skip, int c, int64_t n, float* y, void* stream);

@@ -42,4 +42,19 @@ with open(out, "w", newline="") as f:
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         w.writerow([name, a[0], a[1], round(a[1] / a[0], 1), round(100.0 * a[1] / total, 3), a[2], a[3], window])
 print("kernels in the last %.2f s: %d launches, %.1f ms busy" % (window, sum(a[0] for a in agg.values()), total / 1e6))
+# where the device waits for the host: idle time between consecutive kernels of the window, by the kernel that ENDS the gap
+win = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if int(r["Start_Timestamp"]) >= t0))
+gaps = defaultdict(lambda: [0, 0])
+busy_end, idle = win[0][1], 0
+for s, e, name in win[1:]:
+    if s > busy_end:
+        g = gaps[name]
+        g[0] += 1
+        g[1] += s - busy_end
+        idle += s - busy_end
+    busy_end = max(busy_end, e)
+with open(out.replace("_kernel_stats.csv", "_gaps.txt"), "w") as f:
+    f.write("idle %.1f ms of the last %.2f s (%.1f %%); by the kernel that follows the gap:\n" % (idle / 1e6, window, idle / (window * 1e7)))
+    for name, g in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
+        f.write("%9.3f ms %6d gaps  %s\n" % (g[1] / 1e6, g[0], name[:110]))
 PY

@@ -126,3 +126,46 @@ def test_instnorm_relu_with_the_fused_skip_addition():
     assert torch.equal(gsd.cpu(), cot)                                               # the skip branch passes the gradient through
     keep = F.instance_norm(x.detach().double(), eps=1e-5).abs() > 1e-5
     assert ((gxd.cpu().double() - gx) * keep).abs().max().item() / gx.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(5, 8, 48, 64), (3, 96, 3, 5), (2, 16, 15, 20), (1, 24, 7, 9)])
+def test_instnorm_relu_on_a_batch_of_planes_is_instance_norm_2d(shape):
+    """nn.InstanceNorm2d (default form) + ReLU + the decoder's skip addition of the feature pyramid (feature_network_mnasnet.py:29-50, :97-100)
+    on K16 as n * c planes, value and both gradients against float64 torch; sizes not a multiple of four take the scalar kernels."""
+    from gens_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).requires_grad_(True)
+    skip = torch.randn(*shape, generator=g).requires_grad_(True)
+    cot = torch.randn(*shape, generator=g)
+    for with_skip in (True, False):
+        y = torch.relu(F.instance_norm(x.double(), eps=1e-5)) + (skip.double() if with_skip else 0.0)
+        gx = torch.autograd.grad(y, x, cot.double())[0]
+        xd, sd = x.detach().cuda().requires_grad_(True), skip.detach().cuda().requires_grad_(True)
+        yd = ops.instnorm_relu(xd, 1e-5, sd if with_skip else None)
+        assert yd.shape == x.shape
+        _close("value", yd, y, 1e-5)
+        if with_skip:
+            gxd, gsd = torch.autograd.grad(yd, [xd, sd], cot.cuda())
+            assert torch.equal(gsd.cpu(), cot)
+        else:
+            gxd = torch.autograd.grad(yd, xd, cot.cuda())[0]
+        keep = F.instance_norm(x.detach().double(), eps=1e-5).abs() > 1e-5
+        assert ((gxd.cpu().double() - gx) * keep).abs().max().item() / gx.abs().max().item() < 5e-5
+
+
+def test_feature_decoder_blocks_on_k16_match_the_torch_route(monkeypatch):
+    """_Deconv2d (ConvTranspose2d -> InstanceNorm2d -> ReLU, + the encoder's map) with the norm on K16 against the same module on aten's
+    instance-norm route (GENS_NO_K16_2D), forward and all gradients."""
+    from gens_amd.models.modules import feature_network as fn
+    torch.manual_seed(3)
+    blk = fn._Deconv2d(24, 16).cuda()
+    x = torch.randn(5, 24, 30, 40, device="cuda", requires_grad=True)
+    skip = torch.randn(5, 16, 60, 80, device="cuda", requires_grad=True)
+    cot = torch.randn(5, 16, 60, 80, device="cuda")
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(fn._Deconv2d, "use_k16", on)
+        y = blk(x, skip)
+        res[on] = (y.detach(),) + torch.autograd.grad(y, [x, skip, blk.conv.weight], cot)
+    for name, a, b in zip(("value", "grad x", "grad skip", "grad weight"), res[True], res[False]):
+        _close(name, a, b.cpu(), 2e-4 if name == "grad weight" else 5e-5)
