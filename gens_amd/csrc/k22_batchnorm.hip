@@ -14,6 +14,8 @@
 //   backward   g = gy [y > 0] (y recomputed with the forward's expression: the same decision);  pass 1: sums of g and g xhat;
 //              pass 2: gx = (g - mean(g) - xhat mean(g xhat)) rstd gamma;  d gamma = sum g xhat, d beta = sum g.
 // A part = (image, chunk of the plane): the loops walk contiguous memory (16-byte accesses when the plane size is a multiple of four).
+#include <stdlib.h>
+
 #include "common.h"
 
 struct BnGeom {
@@ -188,6 +190,109 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnGeom g, const float* __r
     }
 }
 
+// Small maps (the deep stages of the trunk: at most BN_ONE_MAX elements per channel; with more, a channel per workgroup leaves most of the chip idle): ONE launch each way, a workgroup per channel reads its n
+// planes once -- sums, then values from the registers.  Two thirds of the trunk's normalisations are of this kind and
+// cost a launch's latency, not traffic: half the launches.
+#define BN_ONE_MAX 8192
+// (element e of the channel's n * hw values: image e / hw, offset e % hw; a thread keeps its <= BN_ONE_MAX / 256 values in registers between the passes)
+#define BN_ONE_PER (BN_ONE_MAX / 256)
+__device__ __forceinline__ int64_t bn_one_offset(const BnGeom& g, int c, int e, float inv_hw) {
+    int img = (int)((float)e * inv_hw);                       // e / hw for e < 2^13 via one multiply, corrected by one step either way
+    int r = e - img * g.hw;
+    if (r < 0) { --img; r += g.hw; }
+    if (r >= g.hw) { ++img; r -= g.hw; }
+    return ((int64_t)img * g.c + c) * g.hw + r;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_fwd_one_k(BnGeom g, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                    float momentum, float* __restrict__ y, float* __restrict__ mean_rstd, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var, int64_t* __restrict__ num_batches) {
+    const int c = blockIdx.x, total = g.n * g.hw;
+    const float inv_hw = 1.0f / (float)g.hw;
+    float v[BN_ONE_PER];
+    int64_t off[BN_ONE_PER];
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int j = 0; j < BN_ONE_PER; ++j) {
+        const int e = (int)threadIdx.x + 256 * j;
+        v[j] = 0.0f;
+        off[j] = 0;
+        if (e < total) {
+            off[j] = bn_one_offset(g, c, e, inv_hw);
+            v[j] = x[off[j]];
+            const double a = v[j];
+            s += a;
+            ss += a * a;
+        }
+    }
+    bn_block_sum2(s, ss);
+    const double m = (double)total;
+    const double mean_d = s / m;
+    double var_d = ss / m - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    if (threadIdx.x == 0) {
+        mean_rstd[2 * c] = mean;
+        mean_rstd[2 * c + 1] = rstd;
+        if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(m > 1.0 ? var_d * m / (m - 1.0) : var_d);
+        if (c == 0 && num_batches) num_batches[0] += 1;
+    }
+#pragma unroll
+    for (int j = 0; j < BN_ONE_PER; ++j) {
+        const int e = (int)threadIdx.x + 256 * j;
+        if (e < total) {
+            const float o = bn_value(v[j], mean, rstd, ga, be);
+            y[off[j]] = RELU ? fmaxf(o, 0.0f) : o;
+        }
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_one_k(BnGeom g, const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ mean_rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gx,
+                                                    float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    const int c = blockIdx.x, total = g.n * g.hw;
+    const float inv_hw = 1.0f / (float)g.hw;
+    const float mean = mean_rstd[2 * c], rstd = mean_rstd[2 * c + 1];
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    float xh[BN_ONE_PER], gv[BN_ONE_PER];
+    int64_t off[BN_ONE_PER];
+    double s = 0.0, sx = 0.0;
+#pragma unroll
+    for (int j = 0; j < BN_ONE_PER; ++j) {
+        const int e = (int)threadIdx.x + 256 * j;
+        xh[j] = 0.0f;
+        gv[j] = 0.0f;
+        off[j] = 0;
+        if (e < total) {
+            off[j] = bn_one_offset(g, c, e, inv_hw);
+            xh[j] = (x[off[j]] - mean) * rstd;
+            gv[j] = gy[off[j]];
+            if (RELU && !(xh[j] * ga + be > 0.0f)) gv[j] = 0.0f;
+            s += (double)gv[j];
+            sx += (double)gv[j] * (double)xh[j];
+        }
+    }
+    bn_block_sum2(s, sx);
+    const double m = (double)total;
+    const float mg = (float)(s / m), mgx = (float)(sx / m);
+    if (threadIdx.x == 0) {
+        if (g_gamma) g_gamma[c] = (float)sx;
+        if (g_beta) g_beta[c] = (float)s;
+    }
+    if (!gx) return;
+    const float k = rstd * ga;
+#pragma unroll
+    for (int j = 0; j < BN_ONE_PER; ++j) {
+        const int e = (int)threadIdx.x + 256 * j;
+        if (e < total) gx[off[j]] = ((gv[j] - mg) - xh[j] * mgx) * k;
+    }
+}
+static bool bn_one_launch(int n, int hw) { return (int64_t)n * hw <= BN_ONE_MAX && getenv("GENS_K22_TWO_LAUNCHES") == nullptr; }
+
 static int bn_geom(const char* who, int n, int c, int hw, BnGeom& g) {
     GENS_CHECK_ARG(n > 0 && c > 0 && hw > 0, GENS_EINVAL, "%s: bad shape (%d, %d, %d)", who, n, c, hw);
     GENS_CHECK_ARG(c <= 65535, GENS_ELIMIT, "%s: %d channels", who, c);
@@ -219,6 +324,11 @@ extern "C" int gens_batchnorm2d_train_fwd(const float* x, const float* gamma, co
     GENS_CHECK_ARG(x && y && mean_rstd && scratch, GENS_EINVAL, "gens_batchnorm2d_train_fwd: null pointer");
     const dim3 grid((unsigned)(n * g.chunks), (unsigned)c);
     hipStream_t s = (hipStream_t)stream;
+    if (bn_one_launch(n, hw)) {
+        if (relu) bn_fwd_one_k<true><<<c, 256, 0, s>>>(g, x, gamma, beta, eps, momentum, y, mean_rstd, running_mean, running_var, num_batches_tracked);
+        else bn_fwd_one_k<false><<<c, 256, 0, s>>>(g, x, gamma, beta, eps, momentum, y, mean_rstd, running_mean, running_var, num_batches_tracked);
+        return gens_launch_status("gens_batchnorm2d_train_fwd");
+    }
     bn_stats_k<<<grid, 256, 0, s>>>(g, x, scratch);
     if (relu) bn_apply_k<true><<<grid, 256, 0, s>>>(g, x, scratch, gamma, beta, eps, momentum, y, mean_rstd, running_mean, running_var, num_batches_tracked);
     else bn_apply_k<false><<<grid, 256, 0, s>>>(g, x, scratch, gamma, beta, eps, momentum, y, mean_rstd, running_mean, running_var, num_batches_tracked);
@@ -233,6 +343,11 @@ extern "C" int gens_batchnorm2d_train_bwd(const float* x, const float* grad_y, c
     GENS_CHECK_ARG(grad_x || grad_gamma || grad_beta, GENS_EINVAL, "gens_batchnorm2d_train_bwd: no output requested");
     const dim3 grid((unsigned)(n * g.chunks), (unsigned)c);
     hipStream_t s = (hipStream_t)stream;
+    if (bn_one_launch(n, hw)) {
+        if (relu) bn_bwd_one_k<true><<<c, 256, 0, s>>>(g, x, grad_y, mean_rstd, gamma, beta, grad_x, grad_gamma, grad_beta);
+        else bn_bwd_one_k<false><<<c, 256, 0, s>>>(g, x, grad_y, mean_rstd, gamma, beta, grad_x, grad_gamma, grad_beta);
+        return gens_launch_status("gens_batchnorm2d_train_bwd");
+    }
     if (relu) {
         bn_bwd_stats_k<true><<<grid, 256, 0, s>>>(g, x, grad_y, mean_rstd, gamma, beta, scratch);
         bn_bwd_apply_k<true><<<grid, 256, 0, s>>>(g, x, grad_y, mean_rstd, gamma, beta, scratch, grad_x, grad_gamma, grad_beta);

@@ -10,9 +10,13 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(5, 32, 24, 40), (2, 7, 5, 3), (1, 3, 1, 2), (5, 1152, 15, 20), (3, 16, 97, 131), (5, 48, 120, 160), (16, 4, 9, 9)]
 
 
+@pytest.mark.parametrize("two_launches", [False, True])
 @pytest.mark.parametrize("relu", [True, False])
-def test_batchnorm_train_matches_aten_float64(relu):
+def test_batchnorm_train_matches_aten_float64(relu, two_launches, monkeypatch):
+    """(maps of at most 8 192 elements per channel take the one-launch kernels; GENS_K22_TWO_LAUNCHES sends them through the two-pass pair too)"""
     from gens_amd.models.modules.feature_network import BatchNorm2dReLU
+    if two_launches:
+        monkeypatch.setenv("GENS_K22_TWO_LAUNCHES", "1")
     for i, (n, c, h, w) in enumerate(SHAPES):
         g = torch.Generator().manual_seed(7 * i + relu)
         x = torch.randn(n, c, h, w, generator=g) * 2.0 + 0.5
