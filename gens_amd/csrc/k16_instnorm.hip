@@ -161,13 +161,18 @@ extern "C" int gens_instnorm_stats(const float* x, int c, int64_t n, double* par
 // layer forward and three backward): mode 0 = (mean, 1 / sqrt(max(E[x^2] - mean^2, 0) + eps)), mode 1 = (sum_0 / n, sum_1 / n); float64 inside.
 __global__ __launch_bounds__(64) void instnorm_finish_k(const double* __restrict__ part, int c, int blocks, double inv_n, double eps, int mode,
                                                         float* __restrict__ out) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= c) return;
+    const int ch = blockIdx.x, lane = threadIdx.x;          // a wavefront per channel: lane l adds partials l, l + 64, ... (a fixed order), then the lanes meet
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < blocks; ++b) {                      // in block order: the sum does not depend on scheduling
+    for (int b = lane; b < blocks; b += 64) {
         s0 += part[((int64_t)ch * blocks + b) * 2];
         s1 += part[((int64_t)ch * blocks + b) * 2 + 1];
     }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        s0 += __shfl_down(s0, s, 64);
+        s1 += __shfl_down(s1, s, 64);
+    }
+    if (lane != 0) return;
     s0 *= inv_n;
     s1 *= inv_n;
     if (mode == 0) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64) void instnorm_finish_k(const double* __restrict
 
 extern "C" int gens_instnorm_finish(const double* partials, int c, int64_t n, double eps, int mode, float* out, void* stream) {
     GENS_CHECK_ARG(partials && out && c > 0 && n > 0 && c <= 65535 && (mode == 0 || mode == 1), GENS_EINVAL, "gens_instnorm_finish: bad argument");
-    hipLaunchKernelGGL(instnorm_finish_k, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, c, gens_instnorm_blocks(c, n), 1.0 / (double)n,
+    hipLaunchKernelGGL(instnorm_finish_k, dim3(c), dim3(64), 0, (hipStream_t)stream, partials, c, gens_instnorm_blocks(c, n), 1.0 / (double)n,
                        eps, mode, out);
     return gens_launch_status("gens_instnorm_finish");
 }
