@@ -527,7 +527,7 @@ def main():
                               "HIP graph and do not depend on the host's pace")}
             for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
                                ("hot_path_graph", ["--graph", "--fused-adam"]), ("finetune_graph", ["--finetune", "--graph", "--fused-adam"]),
-                               ("finetune_fused_adam", ["--finetune", "--fused-adam"])):
+                               ("full_graph", ["--full", "--graph", "--fused-adam"]), ("finetune_fused_adam", ["--finetune", "--fused-adam"])):
                 try:
                     ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
                 except Exception as e:                                 # (a secondary of the secondaries: report, do not lose the others)
@@ -550,7 +550,7 @@ def main():
             train["ms_per_step"] = train["full"].get("ms_per_step")
             if "error" not in train["finetune_fused_adam"]:
                 train["finetune_fused_adam"]["note"] = "the fine-tune step with torch.optim.Adam(fused=True): one pass over the 307 MB of volumes instead of ten (INTEGRATION.md)"
-            for key in ("hot_path_graph", "finetune_graph"):
+            for key in ("hot_path_graph", "finetune_graph", "full_graph"):
                 if "error" not in train[key]:
                     train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; torch.optim.Adam(fused=True, "
                                           "capturable=True): one pass over the parameters): one launch per step, independent of the host's pace")

@@ -14,8 +14,10 @@ once, replay it with ONE launch per step.
         float(loss)                       # the read-back synchronises; step.check() then raises what the reference would have raised
 
 Warm-up: torch.cuda.graph needs a few eager runs of body() first.  They would apply real optimiser steps and consume host generator draws, so
-a graphed run would start from other parameters and another draw sequence than an eager one: the parameters, the optimiser state and the CPU
-generator state are saved before the warm-up and put back after it -- replay k is step k.
+a graphed run would start from other parameters and another draw sequence than an eager one: the parameters, the optimiser state, the CPU
+generator state and the buffers of the modules named in `modules` (BatchNorm statistics) are saved before the warm-up and put back after
+it -- replay k is step k.  The whole GenS.forward training step -- MIOpen's 2-D convolutions, the 3-D U-Net, the render, the loss, backward,
+Adam: ~1 000 launches -- replays in 29.6 ms against 32 - 54 ms eager, depending on the host (scripts/train_step_bench.py --full --graph).
 
 What must hold (checked where it can be): the optimiser is capturable (torch.optim.Adam(..., capturable=True)), shapes and the set of
 tensors body() touches do not change between replays, inputs are updated IN PLACE, and body() does not synchronise with the host.  The eager
@@ -25,15 +27,19 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, body, surfaces, optimizer, warmup=3):
+    def __init__(self, body, surfaces, optimizer, warmup=3, modules=()):
         """body: callable -> scalar loss tensor, running forward + loss + backward + optimizer.step() on the current stream.  surfaces: the
-        ImplicitSurface modules whose host draws the step uses.  optimizer: zero_grad(set_to_none=True) is called around the capture."""
+        ImplicitSurface modules whose host draws the step uses.  optimizer: zero_grad(set_to_none=True) is called around the capture.
+        modules: modules whose BUFFERS a step moves (BatchNorm running statistics and batch counters of a trunk in training mode): saved
+        before the warm-up and put back after it like the parameters."""
         self.surfaces = list(surfaces)
         for group in optimizer.param_groups:
             assert group.get("capturable", False) or group.get("fused", False), "build the optimiser with capturable=True (its step counter must live on the device)"
         import copy
         params = [p for group in optimizer.param_groups for p in group["params"]]
         saved_params = [p.detach().clone() for p in params]
+        buffers = [b for m in modules for b in m.buffers()]
+        saved_buffers = [b.detach().clone() for b in buffers]
         saved_opt = copy.deepcopy(optimizer.state_dict())
         saved_rng = torch.get_rng_state()
         side = torch.cuda.Stream()
@@ -49,6 +55,8 @@ class GraphedStep:
         with torch.no_grad():                                  # the warm-up never happened: parameters, Adam moments / step counters, generator
             for p, q in zip(params, saved_params):
                 p.copy_(q)
+            for b, q in zip(buffers, saved_buffers):
+                b.copy_(q)
         state_before = optimizer.state_dict()["state"]
         if saved_opt["state"]:
             optimizer.load_state_dict(saved_opt)

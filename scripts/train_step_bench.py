@@ -109,13 +109,23 @@ def _measure(quiet, kernels=False):
         model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
         full_opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), **adam)
 
-        def step():  # noqa: F811
+        def full_body():
             out = model("train", ipts, cos_anneal_ratio=0.5, step=1)
             loss = train_loss(out, targets)["loss"]
-            full_opt.zero_grad(set_to_none=True)
             loss.backward()
             full_opt.step()
             return loss.detach()
+
+        def step():  # noqa: F811
+            full_opt.zero_grad(set_to_none=True)
+            return full_body()
+
+        if graph:                                # the whole GenS.forward step -- MIOpen's convolutions included -- captured once and replayed
+            from gens_amd.graph import GraphedStep
+            graphed = GraphedStep(full_body, [model.implicit_surface], full_opt, modules=[model])
+
+            def step():  # noqa: F811
+                return graphed()
 
     for _ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
         float(step())
