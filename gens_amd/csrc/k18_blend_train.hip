@@ -101,20 +101,25 @@ __device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, c
 // 16- and 32-column layers that one wave used to serve alone (this kernel is latency-bound per workgroup: 22 dependent products with a barrier each).
 //   tile rows [r0, r0 + 16), columns [n0, n0 + 16);  lane l: A[row l & 15][k = l >> 4], B[k = l >> 4][column l & 15], D rows 4 (l >> 4) + r
 typedef float f32x4t __attribute__((ext_vector_type(4)));
+typedef float bt_f2 __attribute__((ext_vector_type(2)));
+// the weights of one tile (columns [n0, n0 + 16) of the product) into registers ...
 template <bool TRANS, int K>
-__device__ __forceinline__ f32x4t bt_gemm16(const float* __restrict__ A, int rs, const float* __restrict__ W, int w_out, int w_in, int r0, int n0, int lane) {
-    f32x4t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+__device__ __forceinline__ void bt_load16(const float* __restrict__ W, int w_out, int w_in, int n0, int lane, float (&bv)[(K + 3) / 4]) {
     const int i = lane & 15, kq = lane >> 4, n = n0 + i;
     const int N = TRANS ? w_in : w_out;
-    constexpr int KQ = (K + 3) / 4;
-    float bv[KQ];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) {
+    for (int j = 0; j < (K + 3) / 4; ++j) {
         const int k = 4 * j + kq;
         bv[j] = (k < K && n < N) ? (TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k]) : 0.0f;
     }
+}
+// ... and the product of rows [r0, r0 + 16) of the LDS tile A with them
+template <int K>
+__device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, int r0, int lane, const float (&bv)[(K + 3) / 4]) {
+    f32x4t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) {
+    for (int j = 0; j < (K + 3) / 4; ++j) {
         const int k = 4 * j + kq;
         const float a = k < K ? A[(r0 + i) * rs + k] : 0.0f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[j], acc, 0, 0, 0);
@@ -214,32 +219,48 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 #define BT_STORE_R(l, SRC, stride, in)                                                                       \
     if (BWD) {                                                                                               \
         constexpr int rw_ = ((in) + 2) & ~1;          /* [input | 1 | 0]: even width (8-byte loads of the batched product) */ \
-        BT_FOR(i_, 32 * rw_) {                                                                               \
-            const int r_ = i_ / rw_, c_ = i_ % rw_;                                                          \
-            io.R[l][(grow0 + r_) * rw_ + c_] = c_ < (in) ? (SRC)[r_ * (stride) + c_] : (c_ == (in) ? 1.0f : 0.0f); \
+        constexpr int hw_ = rw_ / 2;                  /* ... and 8-byte stores here: the operand rows are 45 % of this kernel's time as 4-byte stores */ \
+        BT_FOR(i_, 32 * hw_) {                                                                               \
+            const int r_ = i_ / hw_, c_ = 2 * (i_ % hw_);                                                    \
+            float2 v_;                                                                                       \
+            v_.x = c_ < (in) ? (SRC)[r_ * (stride) + c_] : (c_ == (in) ? 1.0f : 0.0f);                       \
+            v_.y = c_ + 1 < (in) ? (SRC)[r_ * (stride) + c_ + 1] : (c_ + 1 == (in) ? 1.0f : 0.0f);           \
+            __builtin_nontemporal_store((bt_f2){v_.x, v_.y}, (bt_f2*)(io.R[l] + (grow0 + r_) * rw_ + c_));                                              \
         }                                                                                                    \
     }
-    // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out
-#define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT)                                             \
-    for (int t_ = wave; t_ < 2 * (((n_out) + 15) / 16); t_ += BT_WAVES) {                                    \
-        const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                                 \
-        const f32x4t acc_ = bt_gemm16<false, k_in>(IN, s_in, Wm, n_out, k_in, r0_, n0_, lane);               \
-        const int c_ = n0_ + (lane & 15);                                                                    \
-        if (c_ < (n_out)) {                                                                                  \
-            const float bias_ = (Bv)[c_];                                                                    \
-            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                               \
-                const float v_ = acc_[r_] + bias_;                                                           \
-                (OUT)[(r0_ + 4 * (lane >> 4) + r_) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;                  \
+    // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out.  Order inside a step: the WEIGHT LOADS of this wave's tiles, then STORE_
+    // (the operand rows of this layer, 8-byte stores), then the products.  Loads and stores complete in issue order (one vmcnt counter on gfx9):
+    // with the stores first, every layer's wait for its weights also waited for ~2 KB of stores to reach L2 -- 45 % of the backward kernel's time.
+#define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT, STORE_)                                     \
+    {                                                                                                        \
+        constexpr int nt_ = 2 * (((n_out) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;               \
+        float bw_[tpw_][((k_in) + 3) / 4];                                                                   \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+            const int t_ = wave + BT_WAVES * ti_;                                                            \
+            if (t_ < nt_) bt_load16<false, k_in>(Wm, n_out, k_in, 16 * (t_ >> 1), lane, bw_[ti_]);           \
+        }                                                                                                    \
+        STORE_                                                                                               \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+            const int t_ = wave + BT_WAVES * ti_;                                                            \
+            if (t_ < nt_) {                                                                                  \
+                const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
+                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, bw_[ti_]);                           \
+                const int c_ = n0_ + (lane & 15);                                                            \
+                if (c_ < (n_out)) {                                                                          \
+                    const float bias_ = (Bv)[c_];                                                            \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
+                        const float v_ = acc_[r_] + bias_;                                                   \
+                        (OUT)[(r0_ + 4 * (lane >> 4) + r_) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;          \
+                    }                                                                                        \
+                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     }
 
     // ---------------------------------------------------------------- ray_dir_fc, x = rgb_feat + direction feature (:87-89)
-    BT_STORE_R(0, RD, BT_S_RD, 4)
-    BT_LAYER(RD, BT_S_RD, 4, W.rd1, W.rd1b, 16, D1, BT_S_D1, true)
+    BT_LAYER(RD, BT_S_RD, 4, W.rd1, W.rd1b, 16, D1, BT_S_D1, true, BT_STORE_R(0, RD, BT_S_RD, 4))
     __syncthreads();
-    BT_STORE_R(1, D1, BT_S_D1, 16)
-    BT_LAYER(D1, BT_S_D1, 16, W.rd2, W.rd2b, F, DFE, BT_S_DFE, true)
+    BT_LAYER(D1, BT_S_D1, 16, W.rd2, W.rd2b, F, DFE, BT_S_DFE, true, BT_STORE_R(1, D1, BT_S_D1, 16))
     __syncthreads();
     BT_FOR(i, 32 * F) {
         const int r = i / F, c = i % F;
@@ -284,11 +305,9 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     __syncthreads();
     // ---------------------------------------------------------------- base_fc (:103-104)
-    BT_STORE_R(2, H0, BT_S_H0, F3)
-    BT_LAYER(H0, BT_S_H0, F3, W.b1, W.b1b, 64, TB, BT_S_TB, true)
+    BT_LAYER(H0, BT_S_H0, F3, W.b1, W.b1b, 64, TB, BT_S_TB, true, BT_STORE_R(2, H0, BT_S_H0, F3))
     __syncthreads();
-    BT_STORE_R(3, TB, BT_S_TB, 64)
-    BT_LAYER(TB, BT_S_TB, 64, W.b2, W.b2b, 32, H, BT_S_H, true)
+    BT_LAYER(TB, BT_S_TB, 64, W.b2, W.b2b, 32, H, BT_S_H, true, BT_STORE_R(3, TB, BT_S_TB, 64))
     __syncthreads();
     // ---------------------------------------------------------------- vis_fc on h * w (:106-109)
     BT_FOR(i, 32 * 32) {
@@ -296,11 +315,9 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = H[r * BT_S_H + c] * SC[r * BT_S_SC + 2];
     }
     __syncthreads();
-    BT_STORE_R(4, A0, BT_S_A, 32)
-    BT_LAYER(A0, BT_S_A, 32, W.v1, W.v1b, 32, TV, BT_S_TV, true)
+    BT_LAYER(A0, BT_S_A, 32, W.v1, W.v1b, 32, TV, BT_S_TV, true, BT_STORE_R(4, A0, BT_S_A, 32))
     __syncthreads();
-    BT_STORE_R(5, TV, BT_S_TV, 32)
-    BT_LAYER(TV, BT_S_TV, 32, W.v2, W.v2b, 33, HV, BT_S_HV, true)
+    BT_LAYER(TV, BT_S_TV, 32, W.v2, W.v2b, 33, HV, BT_S_HV, true, BT_STORE_R(5, TV, BT_S_TV, 32))
     __syncthreads();
     if (owner) SC[row * BT_S_SC + 3] = (1.0f / (1.0f + expf(-HV[row * BT_S_HV + 32]))) * SC[row * BT_S_SC];      // vis
     BT_FOR(i, 32 * 32) {
@@ -314,8 +331,7 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = HH[r * BT_S_HH + c] * SC[r * BT_S_SC + 3];
     }
     __syncthreads();
-    BT_STORE_R(6, A0, BT_S_A, 32)
-    BT_LAYER(A0, BT_S_A, 32, W.u1, W.u1b, 32, TU, BT_S_TU, true)
+    BT_LAYER(A0, BT_S_A, 32, W.u1, W.u1b, 32, TU, BT_S_TU, true, BT_STORE_R(6, A0, BT_S_A, 32))
     __syncthreads();
     BT_STORE_R(7, TU, BT_S_TU, 32)
     if (owner) {
@@ -329,11 +345,9 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     __syncthreads();
     // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
-    BT_STORE_R(8, HH, BT_S_HH, 37)
-    BT_LAYER(HH, BT_S_HH, 37, W.r1, W.r1b, 16, T1, BT_S_T1, true)
+    BT_LAYER(HH, BT_S_HH, 37, W.r1, W.r1b, 16, T1, BT_S_T1, true, BT_STORE_R(8, HH, BT_S_HH, 37))
     __syncthreads();
-    BT_STORE_R(9, T1, BT_S_T1, 16)
-    BT_LAYER(T1, BT_S_T1, 16, W.r2, W.r2b, 8, T2, BT_S_T2, true)
+    BT_LAYER(T1, BT_S_T1, 16, W.r2, W.r2b, 8, T2, BT_S_T2, true, BT_STORE_R(9, T1, BT_S_T1, 16))
     __syncthreads();
     BT_STORE_R(10, T2, BT_S_T2, 8)
     if (owner) {
@@ -371,23 +385,38 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     // store the cotangent rows of layer l's pre-activation (width out) from an LDS tile
 #define BT_STORE_L(l, SRC, stride, out)                                                                      \
     {                                                                                                        \
-        constexpr int lw_ = ((out) + 1) & ~1;                                                                \
-        BT_FOR(i_, 32 * lw_) {                                                                               \
-            const int r_ = i_ / lw_, c_ = i_ % lw_;                                                          \
-            io.L[l][(grow0 + r_) * lw_ + c_] = c_ < (out) ? (SRC)[r_ * (stride) + c_] : 0.0f;                \
+        constexpr int lw_ = ((out) + 1) & ~1, hl_ = lw_ / 2;                                                 \
+        BT_FOR(i_, 32 * hl_) {                                                                               \
+            const int r_ = i_ / hl_, c_ = 2 * (i_ % hl_);                                                    \
+            float2 v_;                                                                                       \
+            v_.x = c_ < (out) ? (SRC)[r_ * (stride) + c_] : 0.0f;                                            \
+            v_.y = c_ + 1 < (out) ? (SRC)[r_ * (stride) + c_ + 1] : 0.0f;                                    \
+            __builtin_nontemporal_store((bt_f2){v_.x, v_.y}, (bt_f2*)(io.L[l] + (grow0 + r_) * lw_ + c_));                                              \
         }                                                                                                    \
     }
-    // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
-#define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY)                                              \
-    for (int t_ = wave; t_ < 2 * (((n_in) + 15) / 16); t_ += BT_WAVES) {                                     \
-        const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                                 \
-        const f32x4t acc_ = bt_gemm16<true, k_out>(IN, s_in, Wm, k_out, n_in, r0_, n0_, lane);               \
-        const int c_ = n0_ + (lane & 15);                                                                    \
-        if (c_ < (n_in)) {                                                                                   \
-            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                               \
-                const int rr_ = r0_ + 4 * (lane >> 4) + r_;                                                  \
-                const float xb_ = acc_[r_];                                                                  \
-                BODY                                                                                         \
+    // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in; weight loads, STORE_, products (see BT_LAYER)
+#define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY, STORE_)                                      \
+    {                                                                                                        \
+        constexpr int nt_ = 2 * (((n_in) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;                \
+        float bw_[tpw_][((k_out) + 3) / 4];                                                                  \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+            const int t_ = wave + BT_WAVES * ti_;                                                            \
+            if (t_ < nt_) bt_load16<true, k_out>(Wm, k_out, n_in, 16 * (t_ >> 1), lane, bw_[ti_]);           \
+        }                                                                                                    \
+        STORE_                                                                                               \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+            const int t_ = wave + BT_WAVES * ti_;                                                            \
+            if (t_ < nt_) {                                                                                  \
+                const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
+                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, bw_[ti_]);                          \
+                const int c_ = n0_ + (lane & 15);                                                            \
+                if (c_ < (n_in)) {                                                                           \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
+                        const int rr_ = r0_ + 4 * (lane >> 4) + r_;                                          \
+                        const float xb_ = acc_[r_];                                                          \
+                        BODY                                                                                 \
+                    }                                                                                        \
+                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -419,13 +448,11 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.r3[c] * bt_elu_d(T2[r * BT_S_T2 + c]);
     }
     __syncthreads();
-    BT_STORE_L(9, A0, BT_S_A, 8)
-    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);)
+    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);, BT_STORE_L(9, A0, BT_S_A, 8))
     __syncthreads();
-    BT_STORE_L(8, A1, BT_S_A, 16)
     // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]: cotangent of h2 -> GH, of vis2 -> SC[8]
     BT_REVERSE(A1, BT_S_A, 16, W.r1, 37, GH, BT_S_H,
-               if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;)
+               if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;, BT_STORE_L(8, A1, BT_S_A, 16))
     __syncthreads();
     // vis2 = sigmoid(q) mask ; q = u2 . tu + b
     if (owner) {
@@ -439,9 +466,8 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.u2[c] * bt_elu_d(TU[r * BT_S_TU + c]);
     }
     __syncthreads();
-    BT_STORE_L(6, A0, BT_S_A, 32)
     // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
-    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;)
+    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(6, A0, BT_S_A, 32))
     __syncthreads();
     if (owner) {
         float vb = 0.0f;
@@ -461,12 +487,10 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = g * bt_elu_d(HV[r * BT_S_HV + c]);
     }
     __syncthreads();
-    BT_STORE_L(5, A0, BT_S_A, 33)
-    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);)
+    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);, BT_STORE_L(5, A0, BT_S_A, 33))
     __syncthreads();
-    BT_STORE_L(4, A1, BT_S_A, 32)
     // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
-    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;)
+    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(4, A1, BT_S_A, 32))
     __syncthreads();
     if (owner) {
         float wb = 0.0f;
@@ -479,11 +503,9 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A1[r * BT_S_A + c] = hb * bt_elu_d(H[r * BT_S_H + c]);                                   // base_fc.2 pre-activation
     }
     __syncthreads();
-    BT_STORE_L(3, A1, BT_S_A, 32)
-    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);)
+    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);, BT_STORE_L(3, A1, BT_S_A, 32))
     __syncthreads();
-    BT_STORE_L(2, A0, BT_S_A, 64)
-    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;)                // cotangent of [mean | var | x]
+    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(2, A0, BT_S_A, 64))                // cotangent of [mean | var | x]
     __syncthreads();
     // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
     BT_FOR(it, PPW * F) {
@@ -531,8 +553,7 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         s_bar = wave_sum(s_bar);
         if (lane == 0) io.s_part[blockIdx.x] = s_bar;
     }
-    BT_STORE_L(1, A0, BT_S_A, F)
-    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);)
+    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);, BT_STORE_L(1, A0, BT_S_A, F))
     __syncthreads();
     BT_STORE_L(0, A1, BT_S_A, 16)
     if (io.g_feat) {
