@@ -62,7 +62,24 @@ struct BlendTrainIO {
     float* L[BT_NLAYER];   // (rows_pad, out_l rounded up to even)
     float* g_feat;         // (n, S, F) cotangent of the looked-up [rgb | features] rows, or NULL
     float* s_part;         // (waves) partial sums of d loss / d |s|
+    float* acc_parts;      // ACC launches: (workgroups, csz) the workgroups' sums of L^T [R | 1] over their row tiles, layout of gens_gemm_tn_batch's result
+    int n_tiles;           // ACC launches: row tiles of the launch (a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...)
 };
+
+// The weight gradients INSIDE the backward launch (ACC): the eleven [dW | db] blocks are 11 K floats -- 65 (NLEV = 5) 16 x 16 tiles that fit the
+// registers of a workgroup's four waves (tile j of a layer belongs to wave j % 4: 21 accumulators of four registers per lane).  The workgroups
+// are persistent; where the other form stores a layer's cotangent rows L and input rows [R | 1] for gens_gemm_tn_batch (619 MB written per launch
+// and read again: 0.29 ms of this kernel and 0.35 ms of that one), this form multiplies them out of LDS -- 8 MFMAs per tile and row tile -- and
+// leaves ONE block of sums per workgroup.
+__host__ __device__ constexpr int bt_ev(int x) { return (x + 1) & ~1; }
+__host__ __device__ constexpr int bt_in(int l, int F) { return l == 0 ? 4 : l == 1 ? 16 : l == 2 ? 3 * F : l == 3 ? 64 : l == 8 ? 37 : l == 9 ? 16 : l == 10 ? 8 : 32; }
+__host__ __device__ constexpr int bt_out(int l, int F) { return l == 0 ? 16 : l == 1 ? F : l == 2 ? 64 : l == 5 ? 33 : l == 7 ? 1 : l == 8 ? 16 : l == 9 ? 8 : l == 10 ? 1 : 32; }
+__host__ __device__ constexpr int bt_ms(int l, int F) { return bt_ev(bt_out(l, F)); }            // rows of block l (gens_gemm_tn_batch's m)
+__host__ __device__ constexpr int bt_ns(int l, int F) { return bt_ev(bt_in(l, F) + 1); }         // columns (n): [input | 1 | 0]
+__host__ __device__ constexpr int bt_tiles(int l, int F) { return ((bt_ms(l, F) + 15) / 16) * ((bt_ns(l, F) + 15) / 16); }
+__host__ __device__ constexpr int bt_acc_base(int l, int F) { return l == 0 ? 0 : bt_acc_base(l - 1, F) + (bt_tiles(l - 1, F) + BT_WAVES - 1) / BT_WAVES; }
+__host__ __device__ constexpr int bt_cc_off(int l, int F) { return l == 0 ? 0 : bt_cc_off(l - 1, F) + bt_ms(l - 1, F) * bt_ns(l - 1, F); }
+#define BT_NACC(F) bt_acc_base(BT_NLAYER, F)
 
 __device__ __forceinline__ float bt_elu(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
 __device__ __forceinline__ float bt_elu_d(float out) { return out > 0.0f ? 1.0f : out + 1.0f; }    // d elu / d a from the OUTPUT
@@ -127,8 +144,9 @@ __device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, 
     return acc;
 }
 
-template <int NLEV, bool BWD>
-__global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {
+template <int NLEV, bool BWD, bool ACC>
+__device__ __forceinline__ void blend_train_tile(const BlendRaw& W, const MapSet& fs, const BlendTrainIO& io, const unsigned tile,
+                                                 f32x4t (&wacc)[BT_NACC(3 + 4 * NLEV)]) {
     constexpr int F = 3 + 4 * NLEV, F3 = 3 * F;
     static_assert(F3 + 1 <= BT_S_A && F3 <= BT_S_H0, "tile too narrow");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -152,18 +170,24 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     float* GH = GX + 32 * BT_S_DFE;        // [32][33]  cotangent of h / h + res
     float* PP = GH + 32 * BT_S_H;          // [32][4]   per point: 0 sum of raw weights, 1 arg-min view, 2 spare, 3 spare
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid & 31;
+    int tid_ = threadIdx.x;
+    if (ACC) {                                   // the thread index OPAQUE per tile: hoisted out of the persistent loop, the LDS address arithmetic of a
+        asm volatile("" : "+v"(tid_));           // tile costs ~300 registers (402 instead of 182; at most 256 fit two workgroups per CU)
+        __builtin_assume((unsigned)tid_ < (unsigned)BT_THREADS);
+    }
+    const int tid = tid_, lane = tid & 63, wave = ACC ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, row = tid & 31;
+    const int lane_w = lane;
     const int S = io.nv - 1, PPW = 32 / S;
-    const int64_t first = (int64_t)blockIdx.x * PPW;
+    const int64_t first = (int64_t)tile * PPW;
     const int64_t n = io.n_dev ? min(io.n, (int64_t)io.n_dev[0]) : io.n;
     if (first >= n) {                                                // a workgroup past the device-side count: nothing to do
-        if (BWD && threadIdx.x == 0) io.s_part[blockIdx.x] = 0.0f;   // (its operand rows are never read: gens_gemm_tn_batch_live)
+        if (BWD && threadIdx.x == 0) io.s_part[tile] = 0.0f;   // (its operand rows are never read: gens_gemm_tn_batch_live)
         return;
     }
     const int pl = row / S, sv = row % S + 1;
     const bool live = pl < PPW && first + pl < n;
     const int64_t src = live ? (io.index ? io.index[first + pl] : first + pl) : 0;      // dense row of this (point, view) row's point
-    const int64_t grow0 = (int64_t)blockIdx.x * 32;                  // first operand row of this workgroup
+    const int64_t grow0 = (int64_t)tile * 32;                  // first operand row of this workgroup
     const bool owner = tid < 32;                                     // one thread per row for the per-row scalars
 
     // ---------------------------------------------------------------- look-up (K4): [rgb | features] of the row into H0[:, 2F..3F)
@@ -217,7 +241,7 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 #define BT_FOR(i, count) for (int i = tid; i < (count); i += BT_THREADS)
     // write the operand rows [input | 1] of layer l (width `in`) from an LDS array
 #define BT_STORE_R(l, SRC, stride, in)                                                                       \
-    if (BWD) {                                                                                               \
+    if (BWD && !ACC) {                                                                                               \
         constexpr int rw_ = ((in) + 2) & ~1;          /* [input | 1 | 0]: even width (8-byte loads of the batched product) */ \
         constexpr int hw_ = rw_ / 2;                  /* ... and 8-byte stores here: the operand rows are 45 % of this kernel's time as 4-byte stores */ \
         BT_FOR(i_, 32 * hw_) {                                                                               \
@@ -234,17 +258,20 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 #define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT, STORE_)                                     \
     {                                                                                                        \
         constexpr int nt_ = 2 * (((n_out) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;               \
-        float bw_[tpw_][((k_in) + 3) / 4];                                                                   \
-        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
-            const int t_ = wave + BT_WAVES * ti_;                                                            \
-            if (t_ < nt_) bt_load16<false, k_in>(Wm, n_out, k_in, 16 * (t_ >> 1), lane, bw_[ti_]);           \
+        float bw_[ACC ? 1 : tpw_][((k_in) + 3) / 4];  /* ACC: one tile's weights at a time (the registers hold the weight-gradient sums) */ \
+        if (!ACC) {                                                                                          \
+            _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                         \
+                const int t_ = wave + BT_WAVES * ti_;                                                        \
+                if (t_ < nt_) bt_load16<false, k_in>(Wm, n_out, k_in, 16 * (t_ >> 1), lane, bw_[ACC ? 0 : ti_]); \
+            }                                                                                                \
         }                                                                                                    \
         STORE_                                                                                               \
         _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
             const int t_ = wave + BT_WAVES * ti_;                                                            \
             if (t_ < nt_) {                                                                                  \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, bw_[ti_]);                           \
+                if (ACC) bt_load16<false, k_in>(Wm, n_out, k_in, n0_, lane, bw_[0]);                         \
+                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, bw_[ACC ? 0 : ti_]);                 \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_out)) {                                                                          \
                     const float bias_ = (Bv)[c_];                                                            \
@@ -383,8 +410,30 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 
     // ================================================================ reverse
     // store the cotangent rows of layer l's pre-activation (width out) from an LDS tile
+    // ACC: block l += L^T [R | 1] of this row tile.  L = (LS)[row][c < out], R = (RS)[row][c < in] (times column SCOL of SC when SCOL >= 0: the two
+    // layers whose input is h * weight / x * visibility).  D[m = out index][n = in index]: lane supplies A[m = lane & 15][k = row 4 q + lane / 16] and
+    // B[k][n = lane & 15]
+#define BT_WACC(l, LS, ls, RS, rs, SCOL)                                                                     \
+    if (ACC) {                                                                                               \
+        constexpr int out_ = bt_out(l, F), in_ = bt_in(l, F), tn_ = (bt_ns(l, F) + 15) / 16, t_all_ = bt_tiles(l, F), base_ = bt_acc_base(l, F); \
+        _Pragma("unroll") for (int j_ = 0; j_ < t_all_; ++j_) {                                              \
+            if (wave == (j_ & (BT_WAVES - 1))) {                                                             \
+                const int oc_ = 16 * (j_ / tn_) + (lane_w & 15), ic_ = 16 * (j_ % tn_) + (lane_w & 15);          \
+                f32x4t a_ = wacc[base_ + j_ / BT_WAVES];                                                     \
+                _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                           \
+                    const int r_ = 4 * q_ + (lane_w >> 4);                                                     \
+                    const float av_ = oc_ < out_ ? (LS)[r_ * (ls) + oc_] : 0.0f;                             \
+                    float bv_ = ic_ < in_ ? (RS)[r_ * (rs) + ic_] : (ic_ == in_ ? 1.0f : 0.0f);              \
+                    if ((SCOL) >= 0 && ic_ < in_) bv_ *= SC[r_ * BT_S_SC + ((SCOL) >= 0 ? (SCOL) : 0)];     \
+                    a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv_, a_, 0, 0, 0);                        \
+                }                                                                                            \
+                wacc[base_ + j_ / BT_WAVES] = a_;                                                            \
+                __builtin_amdgcn_sched_barrier(0);        /* (one tile's 16 LDS reads in flight, not every tile's) */ \
+            }                                                                                                \
+        }                                                                                                    \
+    }
 #define BT_STORE_L(l, SRC, stride, out)                                                                      \
-    {                                                                                                        \
+    if (!ACC) {                                                                                                        \
         constexpr int lw_ = ((out) + 1) & ~1, hl_ = lw_ / 2;                                                 \
         BT_FOR(i_, 32 * hl_) {                                                                               \
             const int r_ = i_ / hl_, c_ = 2 * (i_ % hl_);                                                    \
@@ -398,17 +447,20 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 #define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY, STORE_)                                      \
     {                                                                                                        \
         constexpr int nt_ = 2 * (((n_in) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;                \
-        float bw_[tpw_][((k_out) + 3) / 4];                                                                  \
-        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
-            const int t_ = wave + BT_WAVES * ti_;                                                            \
-            if (t_ < nt_) bt_load16<true, k_out>(Wm, k_out, n_in, 16 * (t_ >> 1), lane, bw_[ti_]);           \
+        float bw_[ACC ? 1 : tpw_][((k_out) + 3) / 4];                                                        \
+        if (!ACC) {                                                                                          \
+            _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                         \
+                const int t_ = wave + BT_WAVES * ti_;                                                        \
+                if (t_ < nt_) bt_load16<true, k_out>(Wm, k_out, n_in, 16 * (t_ >> 1), lane, bw_[ACC ? 0 : ti_]); \
+            }                                                                                                \
         }                                                                                                    \
         STORE_                                                                                               \
         _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
             const int t_ = wave + BT_WAVES * ti_;                                                            \
             if (t_ < nt_) {                                                                                  \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, bw_[ti_]);                          \
+                if (ACC) bt_load16<true, k_out>(Wm, k_out, n_in, n0_, lane, bw_[0]);                         \
+                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, bw_[ACC ? 0 : ti_]);                \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_in)) {                                                                           \
                     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
@@ -442,17 +494,18 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     __syncthreads();
     BT_STORE_L(10, A1, BT_S_A, 1)
+    BT_WACC(10, A1, BT_S_A, T2, BT_S_T2, -1)
     // rgb_fc.4 -> rgb_fc.2 pre-activation
     BT_FOR(i, 32 * 8) {
         const int r = i >> 3, c = i & 7;
         A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.r3[c] * bt_elu_d(T2[r * BT_S_T2 + c]);
     }
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);, BT_STORE_L(9, A0, BT_S_A, 8))
+    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);, BT_STORE_L(9, A0, BT_S_A, 8) BT_WACC(9, A0, BT_S_A, T1, BT_S_T1, -1))
     __syncthreads();
     // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]: cotangent of h2 -> GH, of vis2 -> SC[8]
     BT_REVERSE(A1, BT_S_A, 16, W.r1, 37, GH, BT_S_H,
-               if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;, BT_STORE_L(8, A1, BT_S_A, 16))
+               if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;, BT_STORE_L(8, A1, BT_S_A, 16) BT_WACC(8, A1, BT_S_A, HH, BT_S_HH, -1))
     __syncthreads();
     // vis2 = sigmoid(q) mask ; q = u2 . tu + b
     if (owner) {
@@ -461,13 +514,14 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     __syncthreads();
     BT_STORE_L(7, A1, BT_S_A, 1)
+    BT_WACC(7, A1, BT_S_A, TU, BT_S_TU, -1)
     BT_FOR(i, 32 * 32) {
         const int r = i >> 5, c = i & 31;
         A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.u2[c] * bt_elu_d(TU[r * BT_S_TU + c]);
     }
     __syncthreads();
     // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
-    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(6, A0, BT_S_A, 32))
+    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(6, A0, BT_S_A, 32) BT_WACC(6, A0, BT_S_A, HH, BT_S_HH, 3))
     __syncthreads();
     if (owner) {
         float vb = 0.0f;
@@ -487,10 +541,10 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A0[r * BT_S_A + c] = g * bt_elu_d(HV[r * BT_S_HV + c]);
     }
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);, BT_STORE_L(5, A0, BT_S_A, 33))
+    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);, BT_STORE_L(5, A0, BT_S_A, 33) BT_WACC(5, A0, BT_S_A, TV, BT_S_TV, -1))
     __syncthreads();
     // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
-    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(4, A1, BT_S_A, 32))
+    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(4, A1, BT_S_A, 32) BT_WACC(4, A1, BT_S_A, H, BT_S_H, 2))
     __syncthreads();
     if (owner) {
         float wb = 0.0f;
@@ -503,9 +557,9 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
         A1[r * BT_S_A + c] = hb * bt_elu_d(H[r * BT_S_H + c]);                                   // base_fc.2 pre-activation
     }
     __syncthreads();
-    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);, BT_STORE_L(3, A1, BT_S_A, 32))
+    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);, BT_STORE_L(3, A1, BT_S_A, 32) BT_WACC(3, A1, BT_S_A, TB, BT_S_TB, -1))
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(2, A0, BT_S_A, 64))                // cotangent of [mean | var | x]
+    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(2, A0, BT_S_A, 64) BT_WACC(2, A0, BT_S_A, H0, BT_S_H0, -1))                // cotangent of [mean | var | x]
     __syncthreads();
     // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
     BT_FOR(it, PPW * F) {
@@ -551,11 +605,12 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
     }
     if (wave == 0) {                                               // (the owners all sit in wave 0)
         s_bar = wave_sum(s_bar);
-        if (lane == 0) io.s_part[blockIdx.x] = s_bar;
+        if (lane == 0) io.s_part[tile] = s_bar;
     }
-    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);, BT_STORE_L(1, A0, BT_S_A, F))
+    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);, BT_STORE_L(1, A0, BT_S_A, F) BT_WACC(1, A0, BT_S_A, D1, BT_S_D1, -1))
     __syncthreads();
     BT_STORE_L(0, A1, BT_S_A, 16)
+    BT_WACC(0, A1, BT_S_A, RD, BT_S_RD, -1)
     if (io.g_feat) {
         BT_FOR(i, PPW * S * F) {
             const int r = i / F, c = i % F;
@@ -566,8 +621,56 @@ __global__ __launch_bounds__(BT_THREADS) void blend_train_k(BlendRaw W, MapSet f
 #undef BT_FOR
 #undef BT_STORE_R
 #undef BT_STORE_L
+#undef BT_WACC
 #undef BT_LAYER
 #undef BT_REVERSE
+}
+
+template <int NLEV, bool BWD, bool ACC>
+__global__ __launch_bounds__(BT_THREADS, 2) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {      // (two workgroups per CU: at most 256 registers)
+    constexpr int F = 3 + 4 * NLEV, NACC = BT_NACC(F), CSZ = bt_cc_off(BT_NLAYER, F);   // (constexpr VARIABLES: a constexpr function in a loop bound is a run-time call)
+    f32x4t wacc[NACC];
+    if constexpr (!ACC) {
+        blend_train_tile<NLEV, BWD, false>(W, fs, io, blockIdx.x, wacc);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) wacc[k] = (f32x4t){0.0f, 0.0f, 0.0f, 0.0f};
+        for (unsigned tile = blockIdx.x; tile < (unsigned)io.n_tiles; tile += gridDim.x) {
+            blend_train_tile<NLEV, true, true>(W, fs, io, tile, wacc);
+            __syncthreads();                                   // the next tile overwrites the LDS arrays this one's last products read
+        }
+        // this workgroup's block of sums: accumulator register r of lane l = D[m = 4 (l / 16) + r][n = l & 15] of its tile
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float* out = io.acc_parts + (size_t)blockIdx.x * CSZ;
+#define BT_FLUSH(l)                                                                                          \
+        {                                                                                                    \
+            constexpr int ms_ = bt_ms(l, F), ns_ = bt_ns(l, F), tn_ = (ns_ + 15) / 16, nt_ = bt_tiles(l, F), off_ = bt_cc_off(l, F), ab_ = bt_acc_base(l, F); \
+            _Pragma("unroll") for (int j_ = 0; j_ < nt_; ++j_) {                                             \
+                if (wave == (j_ & (BT_WAVES - 1))) {                                                         \
+                    const int n_ = 16 * (j_ % tn_) + (lane & 15);                                            \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
+                        const int m_ = 16 * (j_ / tn_) + 4 * (lane >> 4) + r_;                               \
+                        if (m_ < ms_ && n_ < ns_) out[off_ + m_ * ns_ + n_] = wacc[ab_ + j_ / BT_WAVES][r_];     \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+        }
+        BT_FLUSH(0) BT_FLUSH(1) BT_FLUSH(2) BT_FLUSH(3) BT_FLUSH(4) BT_FLUSH(5) BT_FLUSH(6) BT_FLUSH(7) BT_FLUSH(8) BT_FLUSH(9) BT_FLUSH(10)
+#undef BT_FLUSH
+    }
+}
+
+// out[e] = sum over the parts in a FIXED order (the result does not depend on scheduling): a workgroup = 32 elements x 8 groups of parts, a thread
+// adds the parts p = g, g + 8, ... of its element, the eight sums are added in group order
+__global__ __launch_bounds__(256) void blend_train_reduce_k(const float* __restrict__ parts, int n_parts, int csz, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5, e = blockIdx.x * 32 + el;
+    float s = 0.0f;
+    if (e < csz)
+        for (int p = g; p < n_parts; p += 8) s += parts[(size_t)p * csz + e];
+    red[g][el] = s;
+    __syncthreads();
+    if (g == 0 && e < csz) out[e] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
 // ====================================================================================================================
@@ -590,7 +693,8 @@ static int bt_fill(const char* who, BlendRaw* W, const float* const* w) {
     return 0;
 }
 
-template <bool BWD>
+extern "C" int gens_blend_train_acc_parts(int64_t n, int nv);
+template <int MODE>      // 0 forward, 1 backward leaving operand rows, 2 backward with the weight-gradient sums inside (persistent workgroups)
 static int bt_launch(const char* who, const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
                      const float* c2w, int nv, const float* const* weights, BlendTrainIO io, void* stream) {
     MapSet fs;
@@ -604,13 +708,17 @@ static int bt_launch(const char* who, const float* const* feats, const int* hw, 
     io.imgs = (const float4*)imgs;
     io.w2c = w2c; io.intr = intr; io.c2w = c2w; io.nv = nv;
     const int ppw = 32 / (nv - 1);
-    const unsigned grid = gens_blocks(io.n, ppw);
+    unsigned grid = gens_blocks(io.n, ppw);
+    if (MODE == 2) {
+        io.n_tiles = (int)grid;
+        grid = (unsigned)gens_blend_train_acc_parts(io.n, nv);
+    }
     hipStream_t st = (hipStream_t)stream;
-    static GensLdsOptIn once[6][2];
+    static GensLdsOptIn once[6][3];
 #define BT_LAUNCH(NL)                                                                                                              \
     {                                                                                                                              \
-        if (int e_ = gens_lds_opt_in(once[NL][BWD], (const void*)blend_train_k<NL, BWD>, (int)bt_lds_bytes(), "gens_blend_train")) return e_; \
-        blend_train_k<NL, BWD><<<grid, BT_THREADS, bt_lds_bytes(), st>>>(W, fs, io);                                                       \
+        if (int e_ = gens_lds_opt_in(once[NL][MODE], (const void*)blend_train_k<NL, MODE != 0, MODE == 2>, (int)bt_lds_bytes(), "gens_blend_train")) return e_; \
+        blend_train_k<NL, MODE != 0, MODE == 2><<<grid, BT_THREADS, bt_lds_bytes(), st>>>(W, fs, io);                              \
     }
     switch (n_levels) {
         case 1: BT_LAUNCH(1) break;
@@ -635,7 +743,7 @@ extern "C" int gens_blend_train_fwd(const float* const* feats, const int* hw, in
     if (n == 0) return 0;
     BlendTrainIO io = {};
     io.pts = pts; io.index = index; io.n_dev = n_device; io.n = n; io.rgb_out = rgb_out; io.vis_out = vis_out;
-    return bt_launch<false>("gens_blend_train_fwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
+    return bt_launch<0>("gens_blend_train_fwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
 }
 
 extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
@@ -651,5 +759,36 @@ extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, in
         io.R[l] = r_ops[l];
         io.L[l] = l_ops[l];
     }
-    return bt_launch<true>("gens_blend_train_bwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
+    return bt_launch<1>("gens_blend_train_bwd", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream);
+}
+
+// The backward launch with the weight-gradient sums inside (no operand rows): workgroups = gens_blend_train_acc_parts(n, nv), each leaves one
+// block of gens_blend_train_acc_floats(n_levels) floats in `parts`; `cc` = their sum = what gens_gemm_tn_batch would have returned for the
+// eleven products (the input of gens_blend_train_wgrad).
+extern "C" int gens_blend_train_acc_parts(int64_t n, int nv) {
+    if (n <= 0 || nv < 2) return 0;
+    const int64_t tiles = gens_blocks(n, 32 / (nv - 1));
+    return (int)(tiles < 512 ? tiles : 512);                  // two workgroups per CU (78 KB of LDS each)
+}
+extern "C" int gens_blend_train_acc_floats(int n_levels) {
+    switch (n_levels) {
+        case 1: return bt_cc_off(BT_NLAYER, 7);
+        case 2: return bt_cc_off(BT_NLAYER, 11);
+        case 3: return bt_cc_off(BT_NLAYER, 15);
+        case 4: return bt_cc_off(BT_NLAYER, 19);
+        case 5: return bt_cc_off(BT_NLAYER, 23);
+        default: return 0;
+    }
+}
+extern "C" int gens_blend_train_bwd_acc(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                        const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                                        const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc, void* stream) {
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_rgb && s_part && parts && cc)), GENS_EINVAL, "gens_blend_train_bwd_acc: null pointer");
+    if (n == 0) return 0;
+    BlendTrainIO io = {};
+    io.pts = pts; io.index = index; io.n_dev = n_device; io.n = n; io.g_rgb = g_rgb; io.g_feat = g_feat; io.s_part = s_part; io.acc_parts = parts;
+    if (int e = bt_launch<2>("gens_blend_train_bwd_acc", feats, hw, n_levels, imgs, w2c, intr, c2w, nv, weights, io, stream)) return e;
+    const int csz = gens_blend_train_acc_floats(n_levels);
+    blend_train_reduce_k<<<gens_blocks(csz, 32), 256, 0, (hipStream_t)stream>>>(parts, gens_blend_train_acc_parts(n, nv), csz, cc);
+    return gens_launch_status("gens_blend_train_bwd_acc");
 }

@@ -22,6 +22,7 @@ class KernelChoice:
         sdf_value / sdf_grad   "transposed" (k6t / k6g: register-chained, the default) | "rowmajor" (k6_sdfmlp.hip: cross-check, other shapes)
         blend                  "transposed" (k7t, two to four source views) | "rowmajor" (k7_blend.hip)
         blend_train_fwd        "transposed" (the training step's forward through k7t + gens_blend_pack_t) | "rowmajor" (k18's own forward)
+        blend_train_wgrad      "inside" (the weight-gradient sums inside the backward launch, gens_blend_train_bwd_acc) | "rows" (operand rows + K14)
         sdf_grad_f16           True: under sdf_precision "f16x2" the value + gradient pass runs on the split-half kernel too (k6gh) | False: float32
         k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
         tex_cache              texel copies kept on the map tensors (pack_maps)"""
@@ -32,6 +33,7 @@ class KernelChoice:
         self.sdf_grad_f16 = not env.get("GENS_SDF_GRAD_F32_ONLY")
         self.blend = "rowmajor" if env.get("GENS_BLEND_ROWMAJOR") else "transposed"
         self.blend_train_fwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_ROWMAJOR") else "transposed"
+        self.blend_train_wgrad = "rows" if env.get("GENS_K18_OPERAND_ROWS") else "inside"
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
 

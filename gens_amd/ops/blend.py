@@ -216,11 +216,21 @@ class _BlendTrain(torch.autograd.Function):
         outs = [16, f, 64, 32, 32, 33, 32, 1, 16, 8, 1]
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
         ev = lambda x: (x + 1) // 2 * 2  # noqa: E731      (even widths: the batched product then reads 8 bytes per lane)
-        r_ops = [e(rows, ev(k + 1)) for k in ins]
-        l_ops = [e(rows, ev(m)) for m in outs]
         want_maps = any(ctx.needs_input_grad[3 + 23:])
         g_feat = e(n, s, f) if want_maps else None
         s_part = e(rows // 32)
+        if kernels.blend_train_wgrad == "inside":
+            # the eleven [dW_l | db_l] blocks summed INSIDE the backward launch (persistent workgroups, sums in registers): no operand rows
+            lib = L.load()
+            csz = lib.gens_blend_train_acc_floats(nl)
+            assert csz == sum(ev(m) * ev(k + 1) for m, k in zip(outs, ins))
+            parts, cc = e(lib.gens_blend_train_acc_parts(n, views.nv), csz), e(csz)
+            L.call("gens_blend_train_bwd_acc", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr(g_feat), L.ptr(s_part), L.ptr(parts), L.ptr(cc), L.stream(),
+                   nbytes=4 * n * (3 + s * f), flops=(3 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n, live=ctx.live,
+                   label="gens_blend_train_bwd")
+            return _BlendTrain._finish(ctx, cc, s_part, g_feat, w, f, nl, pshapes, fshapes, ishape, want_maps, views, pts, hw, idx, cnt, n, dev)
+        r_ops = [e(rows, ev(k + 1)) for k in ins]
+        l_ops = [e(rows, ev(m)) for m in outs]
         L.call("gens_blend_train_bwd", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr_table(r_ops), L.ptr_table(l_ops), L.ptr(g_feat), L.ptr(s_part),
                L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops, live=ctx.live)
         # [dW_l | db_l] = l_ops[l]^T r_ops[l]: eleven products over the same rows in one launch
@@ -235,6 +245,11 @@ class _BlendTrain(torch.autograd.Function):
             L.call("gens_gemm_tn_batch_live", 11, L.ptr_table(l_ops), mi, L.ptr_table(r_ops), ni, mi, ni, rows, L.ptr(cnt, torch.int32), 32 // s, 32,
                    L.ptr(ws), L.ptr(cc), L.stream(), nbytes=4 * rows * (sum(ms) + sum(ns)), flops=2 * rows * sum(m * k for m, k in zip(ms, ns)),
                    live=ctx.live, label="gens_gemm_tn_batch")
+        return _BlendTrain._finish(ctx, cc, s_part, g_feat, w, f, nl, pshapes, fshapes, ishape, want_maps, views, pts, hw, idx, cnt, n, dev)
+
+    @staticmethod
+    def _finish(ctx, cc, s_part, g_feat, w, f, nl, pshapes, fshapes, ishape, want_maps, views, pts, hw, idx, cnt, n, dev):
+        e = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
         # the 23 parameter gradients out of the product blocks in one launch, as views of one flat buffer (contiguous each)
         sizes = [math.prod(sh) if len(sh) else 1 for sh in pshapes]
         flat = e(sum(sizes))

@@ -511,6 +511,16 @@ int gens_blend_train_bwd(const float* const* feats, const int* hw, int n_levels,
                          const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
                          const int32_t* n_device, const float* g_rgb, float* const* r_ops, float* const* l_ops, float* g_feat,
                          float* s_part, void* stream);
+/* The same backward with the weight-gradient sums INSIDE the launch (round 4): persistent workgroups -- gens_blend_train_acc_parts(n, nv) of them --
+ * multiply L^T [R | 1] of their row tiles out of LDS on the matrix cores, the sums in registers, and leave one block of
+ * gens_blend_train_acc_floats(n_levels) floats each in `parts` (parts x floats); `cc` (floats) = their sum in part order = the eleven blocks
+ * even(out_l) x even(in_l + 1), concatenated, that gens_gemm_tn_batch returns for l_ops / r_ops above (the input of gens_blend_train_wgrad).  No
+ * operand rows: 619 MB per launch neither written nor read again. */
+int gens_blend_train_acc_parts(int64_t n, int nv);
+int gens_blend_train_acc_floats(int n_levels);
+int gens_blend_train_bwd_acc(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                             const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                             const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)

@@ -212,3 +212,30 @@ def test_device_side_stream_packing_equals_the_host_packing(nv, n_levels):
     finally:
         ops.kernels.blend_train_fwd = "transposed"
     assert torch.equal(vis, vis_r) and (rgb - rgb_r).abs().max() < 3e-5      # (hardware exp / rcp in the transposed kernel; two views: ill-conditioned weights)
+
+
+@pytest.mark.parametrize("nv,n_levels,n", [(5, 5, 20011), (3, 5, 777), (4, 3, 4099), (5, 1, 33)])
+def test_weight_gradient_sums_inside_the_backward_launch_equal_operand_rows_plus_k14(nv, n_levels, n):
+    """gens_blend_train_bwd_acc (persistent workgroups, the eleven [dW | db] blocks summed on the matrix cores out of LDS, one block per workgroup,
+    a fixed-order reduction) against the operand-row form (gens_blend_train_bwd + gens_gemm_tn_batch): every parameter gradient of the network,
+    with more row tiles than workgroups (20 011 points: 2 502 tiles on 512 workgroups) and a last tile that is partly empty."""
+    from gens_amd.ops import base
+    res = {}
+    saved = base.kernels.blend_train_wgrad
+    try:
+        for mode in ("rows", "inside"):
+            ops, net, views, pts = _setup(nv, n_levels, seed=70 + nv, n=n)
+            base.kernels.blend_train_wgrad = mode
+            cot = torch.randn(n, 3, generator=torch.Generator().manual_seed(4)).cuda()
+            rgb, _ = ops.blend_train(net, views, pts)
+            (rgb * cot).sum().backward()
+            res[mode] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    finally:
+        base.kernels.blend_train_wgrad = saved
+    top = max(float(g.abs().max()) for g in res["rows"].values())
+    for k, a in res["rows"].items():
+        b = res["inside"][k]
+        assert bool(torch.isfinite(b).all()), k
+        # (the anti-alias temperature's gradient is a sum of cancelling per-sample terms -- the other test judges it against the other gradients' scale)
+        tol = 5e-4 if k == "s" else 2e-5
+        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-3 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
