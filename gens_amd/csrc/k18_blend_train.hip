@@ -144,8 +144,20 @@ __device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, 
     return acc;
 }
 
+// The kernel's arguments as the tile function sees them: IN the kernarg segment (constant address space, scalar loads on demand).  A persistent
+// launch that takes them as by-value parameters keeps ~240 scalar registers of pointers and map geometry live across its tile loop (their loads are
+// loop-invariant): 135 of them spilled to vector lanes, 65 v_readlane per layer and the wait states behind each -- the tile body ran at HALF speed.
+// The loop re-derives the pointer per tile (an opaque scalar), so a tile loads what it needs where it needs it.
+struct BlendTrainArgs {
+    BlendRaw W;
+    MapSet fs;
+    BlendTrainIO io;
+};
+typedef const __attribute__((address_space(4))) BlendTrainArgs* BlendTrainArgsPtr;
+
 template <int NLEV, bool BWD, bool ACC>
-__device__ __forceinline__ void blend_train_tile(const BlendRaw& W, const MapSet& fs, const BlendTrainIO& io, const unsigned tile,
+__device__ __forceinline__ void blend_train_tile(const __attribute__((address_space(4))) BlendRaw& W, const __attribute__((address_space(4))) MapSet& fs,
+                                                 const __attribute__((address_space(4))) BlendTrainIO& io, const unsigned tile,
                                                  f32x4t (&wacc)[BT_NACC(3 + 4 * NLEV)]) {
     constexpr int F = 3 + 4 * NLEV, F3 = 3 * F;
     static_assert(F3 + 1 <= BT_S_A && F3 <= BT_S_H0, "tile too narrow");
@@ -630,13 +642,15 @@ template <int NLEV, bool BWD, bool ACC>
 __global__ __launch_bounds__(BT_THREADS, 2) void blend_train_k(BlendRaw W, MapSet fs, BlendTrainIO io) {      // (two workgroups per CU: at most 256 registers)
     constexpr int F = 3 + 4 * NLEV, NACC = BT_NACC(F), CSZ = bt_cc_off(BT_NLAYER, F);   // (constexpr VARIABLES: a constexpr function in a loop bound is a run-time call)
     f32x4t wacc[NACC];
+    BlendTrainArgsPtr kp = (BlendTrainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();       // (W, fs, io) in declaration order
     if constexpr (!ACC) {
-        blend_train_tile<NLEV, BWD, false>(W, fs, io, blockIdx.x, wacc);
+        blend_train_tile<NLEV, BWD, false>(kp->W, kp->fs, kp->io, blockIdx.x, wacc);
     } else {
 #pragma unroll
         for (int k = 0; k < NACC; ++k) wacc[k] = (f32x4t){0.0f, 0.0f, 0.0f, 0.0f};
         for (unsigned tile = blockIdx.x; tile < (unsigned)io.n_tiles; tile += gridDim.x) {
-            blend_train_tile<NLEV, true, true>(W, fs, io, tile, wacc);
+            asm volatile("" : "+s"(kp));
+            blend_train_tile<NLEV, true, true>(kp->W, kp->fs, kp->io, tile, wacc);
             __syncthreads();                                   // the next tile overwrites the LDS arrays this one's last products read
         }
         // this workgroup's block of sums: accumulator register r of lane l = D[m = 4 (l / 16) + r][n = l & 15] of its tile
@@ -768,7 +782,8 @@ extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, in
 extern "C" int gens_blend_train_acc_parts(int64_t n, int nv) {
     if (n <= 0 || nv < 2) return 0;
     const int64_t tiles = gens_blocks(n, 32 / (nv - 1));
-    return (int)(tiles < 512 ? tiles : 512);                  // two workgroups per CU (78 KB of LDS each)
+    const int64_t cap = getenv("GENS_K18_PARTS") ? atoi(getenv("GENS_K18_PARTS")) : 512;   // two workgroups per CU (78 KB of LDS each); the switch: occupancy probes
+    return (int)(tiles < cap ? tiles : cap);
 }
 extern "C" int gens_blend_train_acc_floats(int n_levels) {
     switch (n_levels) {
