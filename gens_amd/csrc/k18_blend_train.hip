@@ -69,7 +69,7 @@ struct BlendTrainIO {
 // The weight gradients INSIDE the backward launch (ACC): the eleven [dW | db] blocks are 11 K floats -- 65 (NLEV = 5) 16 x 16 tiles that fit the
 // registers of a workgroup's four waves (tile j of a layer belongs to wave j % 4: 21 accumulators of four registers per lane).  The workgroups
 // are persistent; where the other form stores a layer's cotangent rows L and input rows [R | 1] for gens_gemm_tn_batch (619 MB written per launch
-// and read again: 0.29 ms of this kernel and 0.35 ms of that one), this form multiplies them out of LDS -- 8 MFMAs per tile and row tile -- and
+// and read again: ~0.1 ms of this kernel and 0.45 ms of that one), this form multiplies them out of LDS -- 8 MFMAs per tile and row tile -- and
 // leaves ONE block of sums per workgroup.
 __host__ __device__ constexpr int bt_ev(int x) { return (x + 1) & ~1; }
 __host__ __device__ constexpr int bt_in(int l, int F) { return l == 0 ? 4 : l == 1 ? 16 : l == 2 ? 3 * F : l == 3 ? 64 : l == 8 ? 37 : l == 9 ? 16 : l == 10 ? 8 : 32; }
@@ -146,7 +146,7 @@ __device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, 
 
 // The kernel's arguments as the tile function sees them: IN the kernarg segment (constant address space, scalar loads on demand).  A persistent
 // launch that takes them as by-value parameters keeps ~240 scalar registers of pointers and map geometry live across its tile loop (their loads are
-// loop-invariant): 135 of them spilled to vector lanes, 65 v_readlane per layer and the wait states behind each -- the tile body ran at HALF speed.
+// loop-invariant): 135 of them spilled to vector lanes, 65 v_readlane per layer and the wait states behind each (3 % of the kernel).
 // The loop re-derives the pointer per tile (an opaque scalar), so a tile loads what it needs where it needs it.
 struct BlendTrainArgs {
     BlendRaw W;
@@ -265,8 +265,8 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         }                                                                                                    \
     }
     // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out.  Order inside a step: the WEIGHT LOADS of this wave's tiles, then STORE_
-    // (the operand rows of this layer, 8-byte stores), then the products.  Loads and stores complete in issue order (one vmcnt counter on gfx9):
-    // with the stores first, every layer's wait for its weights also waited for ~2 KB of stores to reach L2 -- 45 % of the backward kernel's time.
+    // (the operand rows of this layer, 8-byte stores, or the weight-gradient products of the ACC form), then the products.  Loads and stores
+    // complete in issue order (one vmcnt counter on gfx9): a layer's wait for its weights should not also wait for ~2 KB of stores issued before them.
 #define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT, STORE_)                                     \
     {                                                                                                        \
         constexpr int nt_ = 2 * (((n_out) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;               \
