@@ -155,6 +155,29 @@ struct BlendTrainArgs {
 };
 typedef const __attribute__((address_space(4))) BlendTrainArgs* BlendTrainArgsPtr;
 
+    // The weights (and the bias) of a product are loaded ONE PRODUCT AHEAD into registers (BT_PRE_F / BT_PRE_R, placed in front of the previous
+    // product): a global load takes 0.7 - 1.9 us here even when it hits L1 / L2 (s_memtime stamps inside a layer: 3 500 cycles for a 32 x 32
+    // weight tile, the same when repeated; 1 700 for a bias) -- with a load -> product -> barrier chain per layer that latency WAS the kernel
+    // (22 products x ~4 000 cycles of a 100 000-cycle tile).  Loads and stores complete in issue order (one vmcnt counter on gfx9): the
+    // operand-row stores of a layer (STORE_) are issued after the loads of the NEXT product, so nobody waits for them.
+#define BT_PRE_F(TAG, k_in, Wm, Bv, n_out)                                                                   \
+    constexpr int nt_##TAG = 2 * (((n_out) + 15) / 16), tpw_##TAG = (nt_##TAG + BT_WAVES - 1) / BT_WAVES;    \
+    float pw_##TAG[tpw_##TAG][((k_in) + 3) / 4], pb_##TAG[tpw_##TAG];                                        \
+    _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                            \
+        const int t_ = wave + BT_WAVES * ti_;                                                                \
+        const int cb_ = 16 * (t_ >> 1) + (lane & 15);                                                        \
+        pb_##TAG[ti_] = (t_ < nt_##TAG && cb_ < (n_out)) ? (Bv)[cb_] : 0.0f;                                 \
+        if (t_ < nt_##TAG) bt_load16<false, k_in>(Wm, n_out, k_in, 16 * (t_ >> 1), lane, pw_##TAG[ti_]);     \
+    }
+#define BT_PRE_R(TAG, k_out, Wm, n_in)                                                                       \
+    constexpr int nt_##TAG = 2 * (((n_in) + 15) / 16), tpw_##TAG = (nt_##TAG + BT_WAVES - 1) / BT_WAVES;     \
+    float pw_##TAG[tpw_##TAG][((k_out) + 3) / 4];                                                            \
+    if (BWD) {                                                                                               \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                        \
+            const int t_ = wave + BT_WAVES * ti_;                                                            \
+            if (t_ < nt_##TAG) bt_load16<true, k_out>(Wm, k_out, n_in, 16 * (t_ >> 1), lane, pw_##TAG[ti_]); \
+        }                                                                                                    \
+    }
 template <int NLEV, bool BWD, bool ACC>
 __device__ __forceinline__ void blend_train_tile(const __attribute__((address_space(4))) BlendRaw& W, const __attribute__((address_space(4))) MapSet& fs,
                                                  const __attribute__((address_space(4))) BlendTrainIO& io, const unsigned tile,
@@ -202,6 +225,7 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
     const int64_t grow0 = (int64_t)tile * 32;                  // first operand row of this workgroup
     const bool owner = tid < 32;                                     // one thread per row for the per-row scalars
 
+    BT_PRE_F(rd1, 4, W.rd1, W.rd1b, 16)
     // ---------------------------------------------------------------- look-up (K4): [rgb | features] of the row into H0[:, 2F..3F)
     {   // thread (row, part): part l < NLEV reads feature level l (level 0 also the image); the in-frustum flags meet in GH (free here)
         const int part = tid >> 5;
@@ -264,29 +288,18 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
             __builtin_nontemporal_store((bt_f2){v_.x, v_.y}, (bt_f2*)(io.R[l] + (grow0 + r_) * rw_ + c_));                                              \
         }                                                                                                    \
     }
-    // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out.  Order inside a step: the WEIGHT LOADS of this wave's tiles, then STORE_
-    // (the operand rows of this layer, 8-byte stores, or the weight-gradient products of the ACC form), then the products.  Loads and stores
-    // complete in issue order (one vmcnt counter on gfx9): a layer's wait for its weights should not also wait for ~2 KB of stores issued before them.
-#define BT_LAYER(IN, s_in, k_in, Wm, Bv, n_out, OUT, s_out, ACT, STORE_)                                     \
+    // one forward layer: OUT[row][c] = elu(bias + IN W^T) for c < n_out, from the registers BT_PRE_F(TAG) filled
+#define BT_LAYER(TAG, IN, s_in, k_in, n_out, OUT, s_out, ACT, STORE_)                                        \
     {                                                                                                        \
-        constexpr int nt_ = 2 * (((n_out) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;               \
-        float bw_[ACC ? 1 : tpw_][((k_in) + 3) / 4];  /* ACC: one tile's weights at a time (the registers hold the weight-gradient sums) */ \
-        if (!ACC) {                                                                                          \
-            _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                         \
-                const int t_ = wave + BT_WAVES * ti_;                                                        \
-                if (t_ < nt_) bt_load16<false, k_in>(Wm, n_out, k_in, 16 * (t_ >> 1), lane, bw_[ACC ? 0 : ti_]); \
-            }                                                                                                \
-        }                                                                                                    \
         STORE_                                                                                               \
-        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                        \
             const int t_ = wave + BT_WAVES * ti_;                                                            \
-            if (t_ < nt_) {                                                                                  \
+            if (t_ < nt_##TAG) {                                                                             \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                if (ACC) bt_load16<false, k_in>(Wm, n_out, k_in, n0_, lane, bw_[0]);                         \
-                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, bw_[ACC ? 0 : ti_]);                 \
+                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                      \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_out)) {                                                                          \
-                    const float bias_ = (Bv)[c_];                                                            \
+                    const float bias_ = pb_##TAG[ti_];                                                       \
                     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
                         const float v_ = acc_[r_] + bias_;                                                   \
                         (OUT)[(r0_ + 4 * (lane >> 4) + r_) * (s_out) + c_] = ACT ? bt_elu(v_) : v_;          \
@@ -297,9 +310,11 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
     }
 
     // ---------------------------------------------------------------- ray_dir_fc, x = rgb_feat + direction feature (:87-89)
-    BT_LAYER(RD, BT_S_RD, 4, W.rd1, W.rd1b, 16, D1, BT_S_D1, true, BT_STORE_R(0, RD, BT_S_RD, 4))
+    BT_PRE_F(rd2, 16, W.rd2, W.rd2b, F)
+    BT_LAYER(rd1, RD, BT_S_RD, 4, 16, D1, BT_S_D1, true, BT_STORE_R(0, RD, BT_S_RD, 4))
     __syncthreads();
-    BT_LAYER(D1, BT_S_D1, 16, W.rd2, W.rd2b, F, DFE, BT_S_DFE, true, BT_STORE_R(1, D1, BT_S_D1, 16))
+    BT_PRE_F(b1, F3, W.b1, W.b1b, 64)
+    BT_LAYER(rd2, D1, BT_S_D1, 16, F, DFE, BT_S_DFE, true, BT_STORE_R(1, D1, BT_S_D1, 16))
     __syncthreads();
     BT_FOR(i, 32 * F) {
         const int r = i / F, c = i % F;
@@ -344,9 +359,11 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
     }
     __syncthreads();
     // ---------------------------------------------------------------- base_fc (:103-104)
-    BT_LAYER(H0, BT_S_H0, F3, W.b1, W.b1b, 64, TB, BT_S_TB, true, BT_STORE_R(2, H0, BT_S_H0, F3))
+    BT_PRE_F(b2, 64, W.b2, W.b2b, 32)
+    BT_LAYER(b1, H0, BT_S_H0, F3, 64, TB, BT_S_TB, true, BT_STORE_R(2, H0, BT_S_H0, F3))
     __syncthreads();
-    BT_LAYER(TB, BT_S_TB, 64, W.b2, W.b2b, 32, H, BT_S_H, true, BT_STORE_R(3, TB, BT_S_TB, 64))
+    BT_PRE_F(v1, 32, W.v1, W.v1b, 32)
+    BT_LAYER(b2, TB, BT_S_TB, 64, 32, H, BT_S_H, true, BT_STORE_R(3, TB, BT_S_TB, 64))
     __syncthreads();
     // ---------------------------------------------------------------- vis_fc on h * w (:106-109)
     BT_FOR(i, 32 * 32) {
@@ -354,9 +371,11 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         A0[r * BT_S_A + c] = H[r * BT_S_H + c] * SC[r * BT_S_SC + 2];
     }
     __syncthreads();
-    BT_LAYER(A0, BT_S_A, 32, W.v1, W.v1b, 32, TV, BT_S_TV, true, BT_STORE_R(4, A0, BT_S_A, 32))
+    BT_PRE_F(v2, 32, W.v2, W.v2b, 33)
+    BT_LAYER(v1, A0, BT_S_A, 32, 32, TV, BT_S_TV, true, BT_STORE_R(4, A0, BT_S_A, 32))
     __syncthreads();
-    BT_LAYER(TV, BT_S_TV, 32, W.v2, W.v2b, 33, HV, BT_S_HV, true, BT_STORE_R(5, TV, BT_S_TV, 32))
+    BT_PRE_F(u1, 32, W.u1, W.u1b, 32)
+    BT_LAYER(v2, TV, BT_S_TV, 32, 33, HV, BT_S_HV, true, BT_STORE_R(5, TV, BT_S_TV, 32))
     __syncthreads();
     if (owner) SC[row * BT_S_SC + 3] = (1.0f / (1.0f + expf(-HV[row * BT_S_HV + 32]))) * SC[row * BT_S_SC];      // vis
     BT_FOR(i, 32 * 32) {
@@ -370,7 +389,8 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         A0[r * BT_S_A + c] = HH[r * BT_S_HH + c] * SC[r * BT_S_SC + 3];
     }
     __syncthreads();
-    BT_LAYER(A0, BT_S_A, 32, W.u1, W.u1b, 32, TU, BT_S_TU, true, BT_STORE_R(6, A0, BT_S_A, 32))
+    BT_PRE_F(r1, 37, W.r1, W.r1b, 16)
+    BT_LAYER(u1, A0, BT_S_A, 32, 32, TU, BT_S_TU, true, BT_STORE_R(6, A0, BT_S_A, 32))
     __syncthreads();
     BT_STORE_R(7, TU, BT_S_TU, 32)
     if (owner) {
@@ -384,9 +404,11 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
     }
     __syncthreads();
     // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-114)
-    BT_LAYER(HH, BT_S_HH, 37, W.r1, W.r1b, 16, T1, BT_S_T1, true, BT_STORE_R(8, HH, BT_S_HH, 37))
+    BT_PRE_F(r2, 16, W.r2, W.r2b, 8)
+    BT_LAYER(r1, HH, BT_S_HH, 37, 16, T1, BT_S_T1, true, BT_STORE_R(8, HH, BT_S_HH, 37))
     __syncthreads();
-    BT_LAYER(T1, BT_S_T1, 16, W.r2, W.r2b, 8, T2, BT_S_T2, true, BT_STORE_R(9, T1, BT_S_T1, 16))
+    BT_PRE_R(xr2, 8, W.r2, 16)
+    BT_LAYER(r2, T1, BT_S_T1, 16, 8, T2, BT_S_T2, true, BT_STORE_R(9, T1, BT_S_T1, 16))
     __syncthreads();
     BT_STORE_R(10, T2, BT_S_T2, 8)
     if (owner) {
@@ -455,24 +477,15 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
             __builtin_nontemporal_store((bt_f2){v_.x, v_.y}, (bt_f2*)(io.L[l] + (grow0 + r_) * lw_ + c_));                                              \
         }                                                                                                    \
     }
-    // X_bar tile(s) = A W (reverse product), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in; weight loads, STORE_, products (see BT_LAYER)
-#define BT_REVERSE(IN, s_in, k_out, Wm, n_in, DST, s_dst, BODY, STORE_)                                      \
+    // X_bar tile(s) = A W (reverse product, weights from BT_PRE_R(TAG)), then DST[row][c] (=|+=) X_bar * elu'(OUT_ACT) for c < n_in
+#define BT_REVERSE(TAG, IN, s_in, k_out, n_in, DST, s_dst, BODY, STORE_)                                     \
     {                                                                                                        \
-        constexpr int nt_ = 2 * (((n_in) + 15) / 16), tpw_ = (nt_ + BT_WAVES - 1) / BT_WAVES;                \
-        float bw_[ACC ? 1 : tpw_][((k_out) + 3) / 4];                                                        \
-        if (!ACC) {                                                                                          \
-            _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                         \
-                const int t_ = wave + BT_WAVES * ti_;                                                        \
-                if (t_ < nt_) bt_load16<true, k_out>(Wm, k_out, n_in, 16 * (t_ >> 1), lane, bw_[ACC ? 0 : ti_]); \
-            }                                                                                                \
-        }                                                                                                    \
         STORE_                                                                                               \
-        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_; ++ti_) {                                             \
+        _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                        \
             const int t_ = wave + BT_WAVES * ti_;                                                            \
-            if (t_ < nt_) {                                                                                  \
+            if (t_ < nt_##TAG) {                                                                             \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                if (ACC) bt_load16<true, k_out>(Wm, k_out, n_in, n0_, lane, bw_[0]);                         \
-                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, bw_[ACC ? 0 : ti_]);                \
+                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                     \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_in)) {                                                                           \
                     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
@@ -513,10 +526,12 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         A0[r * BT_S_A + c] = A1[r * BT_S_A] * W.r3[c] * bt_elu_d(T2[r * BT_S_T2 + c]);
     }
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 8, W.r2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);, BT_STORE_L(9, A0, BT_S_A, 8) BT_WACC(9, A0, BT_S_A, T1, BT_S_T1, -1))
+    BT_PRE_R(xr1, 16, W.r1, 37)
+    BT_REVERSE(xr2, A0, BT_S_A, 8, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(T1[rr_ * BT_S_T1 + c_]);, BT_STORE_L(9, A0, BT_S_A, 8) BT_WACC(9, A0, BT_S_A, T1, BT_S_T1, -1))
     __syncthreads();
     // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]: cotangent of h2 -> GH, of vis2 -> SC[8]
-    BT_REVERSE(A1, BT_S_A, 16, W.r1, 37, GH, BT_S_H,
+    BT_PRE_R(xu1, 32, W.u1, 32)
+    BT_REVERSE(xr1, A1, BT_S_A, 16, 37, GH, BT_S_H,
                if (c_ < 32) GH[rr_ * BT_S_H + c_] = xb_; else if (c_ == 32) SC[rr_ * BT_S_SC + 8] = xb_;, BT_STORE_L(8, A1, BT_S_A, 16) BT_WACC(8, A1, BT_S_A, HH, BT_S_HH, -1))
     __syncthreads();
     // vis2 = sigmoid(q) mask ; q = u2 . tu + b
@@ -533,7 +548,8 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
     }
     __syncthreads();
     // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
-    BT_REVERSE(A0, BT_S_A, 32, W.u1, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(6, A0, BT_S_A, 32) BT_WACC(6, A0, BT_S_A, HH, BT_S_HH, 3))
+    BT_PRE_R(xv2, 33, W.v2, 32)
+    BT_REVERSE(xu1, A0, BT_S_A, 32, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(6, A0, BT_S_A, 32) BT_WACC(6, A0, BT_S_A, HH, BT_S_HH, 3))
     __syncthreads();
     if (owner) {
         float vb = 0.0f;
@@ -553,10 +569,12 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         A0[r * BT_S_A + c] = g * bt_elu_d(HV[r * BT_S_HV + c]);
     }
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 33, W.v2, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);, BT_STORE_L(5, A0, BT_S_A, 33) BT_WACC(5, A0, BT_S_A, TV, BT_S_TV, -1))
+    BT_PRE_R(xv1, 32, W.v1, 32)
+    BT_REVERSE(xv2, A0, BT_S_A, 33, 32, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TV[rr_ * BT_S_TV + c_]);, BT_STORE_L(5, A0, BT_S_A, 33) BT_WACC(5, A0, BT_S_A, TV, BT_S_TV, -1))
     __syncthreads();
     // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
-    BT_REVERSE(A1, BT_S_A, 32, W.v1, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(4, A1, BT_S_A, 32) BT_WACC(4, A1, BT_S_A, H, BT_S_H, 2))
+    BT_PRE_R(xb2, 32, W.b2, 64)
+    BT_REVERSE(xv1, A1, BT_S_A, 32, 32, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(4, A1, BT_S_A, 32) BT_WACC(4, A1, BT_S_A, H, BT_S_H, 2))
     __syncthreads();
     if (owner) {
         float wb = 0.0f;
@@ -569,9 +587,11 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         A1[r * BT_S_A + c] = hb * bt_elu_d(H[r * BT_S_H + c]);                                   // base_fc.2 pre-activation
     }
     __syncthreads();
-    BT_REVERSE(A1, BT_S_A, 32, W.b2, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);, BT_STORE_L(3, A1, BT_S_A, 32) BT_WACC(3, A1, BT_S_A, TB, BT_S_TB, -1))
+    BT_PRE_R(xb1, 64, W.b1, F3)
+    BT_REVERSE(xb2, A1, BT_S_A, 32, 64, A0, BT_S_A, A0[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(TB[rr_ * BT_S_TB + c_]);, BT_STORE_L(3, A1, BT_S_A, 32) BT_WACC(3, A1, BT_S_A, TB, BT_S_TB, -1))
     __syncthreads();
-    BT_REVERSE(A0, BT_S_A, 64, W.b1, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(2, A0, BT_S_A, 64) BT_WACC(2, A0, BT_S_A, H0, BT_S_H0, -1))                // cotangent of [mean | var | x]
+    BT_PRE_R(xrd2, F, W.rd2, 16)
+    BT_REVERSE(xb1, A0, BT_S_A, 64, F3, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_;, BT_STORE_L(2, A0, BT_S_A, 64) BT_WACC(2, A0, BT_S_A, H0, BT_S_H0, -1))                // cotangent of [mean | var | x]
     __syncthreads();
     // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
     BT_FOR(it, PPW * F) {
@@ -619,7 +639,7 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
         s_bar = wave_sum(s_bar);
         if (lane == 0) io.s_part[tile] = s_bar;
     }
-    BT_REVERSE(A0, BT_S_A, F, W.rd2, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);, BT_STORE_L(1, A0, BT_S_A, F) BT_WACC(1, A0, BT_S_A, D1, BT_S_D1, -1))
+    BT_REVERSE(xrd2, A0, BT_S_A, F, 16, A1, BT_S_A, A1[rr_ * BT_S_A + c_] = xb_ * bt_elu_d(D1[rr_ * BT_S_D1 + c_]);, BT_STORE_L(1, A0, BT_S_A, F) BT_WACC(1, A0, BT_S_A, D1, BT_S_D1, -1))
     __syncthreads();
     BT_STORE_L(0, A1, BT_S_A, 16)
     BT_WACC(0, A1, BT_S_A, RD, BT_S_RD, -1)
@@ -634,6 +654,8 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
 #undef BT_STORE_R
 #undef BT_STORE_L
 #undef BT_WACC
+#undef BT_PRE_F
+#undef BT_PRE_R
 #undef BT_LAYER
 #undef BT_REVERSE
 }
