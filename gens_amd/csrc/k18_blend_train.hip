@@ -119,25 +119,54 @@ __device__ __forceinline__ f32x16 bt_gemm(const float* __restrict__ A, int rs, c
 //   tile rows [r0, r0 + 16), columns [n0, n0 + 16);  lane l: A[row l & 15][k = l >> 4], B[k = l >> 4][column l & 15], D rows 4 (l >> 4) + r
 typedef float f32x4t __attribute__((ext_vector_type(4)));
 typedef float bt_f2 __attribute__((ext_vector_type(2)));
-// the weights of one tile (columns [n0, n0 + 16) of the product) into registers ...
+// The weights of one tile (columns [n0, n0 + 16) of the product) into registers, and the product of rows [r0, r0 + 16) of the LDS tile A with them.
+// Operand slot j of lane (i = lane & 15, kq = lane >> 4) is reduction index k(j, kq):
+//   reverse products (TRANS: W[k][n], consecutive lanes on consecutive n -- 64-byte runs):   k = 4 j + kq;
+//   forward products (W[n][k], a lane walks along ITS row):  k = 16 (j / 4) + 4 kq + j % 4 -- four consecutive floats per lane, ONE 16-byte load
+//   instead of four 4-byte loads that each touch 16 different 128-byte lines: the vector L1 looks up one line per clock (gather_rate_probe), and
+//   after every barrier all eight waves of a CU queue their weight loads there -- that queue, not the memory latency (90 ns when the pipe is
+//   quiet), is what a layer waits for.  The reduction is over ceil(K / 16) * 16 slots then (the products are sums: any order of k is the same sum
+//   up to float32 rounding; slots with k >= K carry zeros).
 template <bool TRANS, int K>
-__device__ __forceinline__ void bt_load16(const float* __restrict__ W, int w_out, int w_in, int n0, int lane, float (&bv)[(K + 3) / 4]) {
+struct BtSlots {
+    static constexpr int n = TRANS ? (K + 3) / 4 : 4 * ((K + 15) / 16);
+    static __device__ __forceinline__ int k(int j, int kq) { return TRANS ? 4 * j + kq : 16 * (j >> 2) + 4 * kq + (j & 3); }
+};
+struct __attribute__((packed, aligned(4))) bt_f4u { float x, y, z, w; };      // four floats at a 4-byte aligned address (rows of 69 / 37 floats)
+
+template <bool TRANS, int K>
+__device__ __forceinline__ void bt_load16(const float* __restrict__ W, int w_out, int w_in, int n0, int lane, float (&bv)[BtSlots<TRANS, K>::n]) {
     const int i = lane & 15, kq = lane >> 4, n = n0 + i;
     const int N = TRANS ? w_in : w_out;
+    if constexpr (TRANS) {
 #pragma unroll
-    for (int j = 0; j < (K + 3) / 4; ++j) {
-        const int k = 4 * j + kq;
-        bv[j] = (k < K && n < N) ? (TRANS ? W[(size_t)k * w_in + n] : W[(size_t)n * w_in + k]) : 0.0f;
+        for (int j = 0; j < BtSlots<TRANS, K>::n; ++j) {
+            const int k = 4 * j + kq;
+            bv[j] = (k < K && n < N) ? W[(size_t)k * w_in + n] : 0.0f;
+        }
+    } else {
+        const float* row = W + (size_t)(n < N ? n : 0) * w_in;
+#pragma unroll
+        for (int m = 0; m < (K + 15) / 16; ++m) {
+            const int k0 = 16 * m + 4 * kq;
+            if (k0 + 3 < K) {
+                const bt_f4u v = *(const bt_f4u*)(row + k0);
+                bv[4 * m] = v.x; bv[4 * m + 1] = v.y; bv[4 * m + 2] = v.z; bv[4 * m + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[4 * m + r] = k0 + r < K ? row[k0 + r] : 0.0f;
+            }
+            if (!(n < N)) { bv[4 * m] = 0.0f; bv[4 * m + 1] = 0.0f; bv[4 * m + 2] = 0.0f; bv[4 * m + 3] = 0.0f; }
+        }
     }
 }
-// ... and the product of rows [r0, r0 + 16) of the LDS tile A with them
-template <int K>
-__device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, int r0, int lane, const float (&bv)[(K + 3) / 4]) {
+template <bool TRANS, int K>
+__device__ __forceinline__ f32x4t bt_mma16(const float* __restrict__ A, int rs, int r0, int lane, const float (&bv)[BtSlots<TRANS, K>::n]) {
     f32x4t acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < (K + 3) / 4; ++j) {
-        const int k = 4 * j + kq;
+    for (int j = 0; j < BtSlots<TRANS, K>::n; ++j) {
+        const int k = BtSlots<TRANS, K>::k(j, kq);
         const float a = k < K ? A[(r0 + i) * rs + k] : 0.0f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[j], acc, 0, 0, 0);
     }
@@ -162,7 +191,7 @@ typedef const __attribute__((address_space(4))) BlendTrainArgs* BlendTrainArgsPt
     // operand-row stores of a layer (STORE_) are issued after the loads of the NEXT product, so nobody waits for them.
 #define BT_PRE_F(TAG, k_in, Wm, Bv, n_out)                                                                   \
     constexpr int nt_##TAG = 2 * (((n_out) + 15) / 16), tpw_##TAG = (nt_##TAG + BT_WAVES - 1) / BT_WAVES;    \
-    float pw_##TAG[tpw_##TAG][((k_in) + 3) / 4], pb_##TAG[tpw_##TAG];                                        \
+    float pw_##TAG[tpw_##TAG][BtSlots<false, k_in>::n], pb_##TAG[tpw_##TAG];                                        \
     _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                            \
         const int t_ = wave + BT_WAVES * ti_;                                                                \
         const int cb_ = 16 * (t_ >> 1) + (lane & 15);                                                        \
@@ -171,7 +200,7 @@ typedef const __attribute__((address_space(4))) BlendTrainArgs* BlendTrainArgsPt
     }
 #define BT_PRE_R(TAG, k_out, Wm, n_in)                                                                       \
     constexpr int nt_##TAG = 2 * (((n_in) + 15) / 16), tpw_##TAG = (nt_##TAG + BT_WAVES - 1) / BT_WAVES;     \
-    float pw_##TAG[tpw_##TAG][((k_out) + 3) / 4];                                                            \
+    float pw_##TAG[tpw_##TAG][BtSlots<true, k_out>::n];                                                            \
     if (BWD) {                                                                                               \
         _Pragma("unroll") for (int ti_ = 0; ti_ < tpw_##TAG; ++ti_) {                                        \
             const int t_ = wave + BT_WAVES * ti_;                                                            \
@@ -296,7 +325,7 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
             const int t_ = wave + BT_WAVES * ti_;                                                            \
             if (t_ < nt_##TAG) {                                                                             \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                const f32x4t acc_ = bt_mma16<k_in>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                      \
+                const f32x4t acc_ = bt_mma16<false, k_in>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                      \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_out)) {                                                                          \
                     const float bias_ = pb_##TAG[ti_];                                                       \
@@ -485,7 +514,7 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
             const int t_ = wave + BT_WAVES * ti_;                                                            \
             if (t_ < nt_##TAG) {                                                                             \
                 const int r0_ = 16 * (t_ & 1), n0_ = 16 * (t_ >> 1);                                         \
-                const f32x4t acc_ = bt_mma16<k_out>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                     \
+                const f32x4t acc_ = bt_mma16<true, k_out>(IN, s_in, r0_, lane, pw_##TAG[ti_]);                     \
                 const int c_ = n0_ + (lane & 15);                                                            \
                 if (c_ < (n_in)) {                                                                           \
                     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \

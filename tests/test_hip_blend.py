@@ -238,4 +238,5 @@ def test_weight_gradient_sums_inside_the_backward_launch_equal_operand_rows_plus
         assert bool(torch.isfinite(b).all()), k
         # (the anti-alias temperature's gradient is a sum of cancelling per-sample terms -- the other test judges it against the other gradients' scale)
         tol = 5e-4 if k == "s" else 2e-5
-        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-3 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
+        # (floor: the bias in front of the soft-max has an analytically zero gradient -- 1e-8 of round-off in either form)
+        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-2 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
