@@ -182,41 +182,82 @@ def launch_ranks(n, argv, env=None, child=None, poll_s=0.05):
     down with it (they would otherwise wait in a collective for ever): the exact child processes are terminated, nothing is retried.
 
     child: the command of a rank process (tests substitute a stub); default: this interpreter on this file with the same arguments."""
+    import shutil
+    import signal
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:        # a free port for the rendezvous
+    import tempfile
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:        # a free port for MASTER_PORT (what the environment contract names) ...
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    # ... but the rendezvous itself goes through a FILE store in a directory of our own: between closing the socket above and rank 0's bind
+    # another process could take the port, a file nobody else knows cannot be taken
+    store_dir = tempfile.mkdtemp(prefix="gens_bench_rdzv_")
     cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
     base = dict(os.environ if env is None else env)
-    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "GENS_BENCH_INIT": "file://" + os.path.join(store_dir, "store")})
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                      # dmabuf IPC: what RCCL needs on this driver
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     procs = []
-    for r in range(n):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
-    # rank 0 writes its line once, at the end: reading its pipe on a helper thread keeps a chatty library from filling it
+
+    def stop_children(grace_s=5.0):
+        """terminate(), then kill() what is still alive: these exact children, never a pattern."""
+        alive = [p_ for p_ in procs if p_.poll() is None]
+        for p_ in alive:
+            p_.terminate()
+        deadline = time.time() + grace_s
+        for p_ in alive:
+            try:
+                p_.wait(max(0.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                p_.wait()
+
+    class _Stopped(Exception):
+        pass
+
+    def on_term(signum, frame):                                             # a harness timeout sends SIGTERM: leave through the finally below
+        raise _Stopped(signum)
+
+    previous = None
+    try:
+        previous = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                                                      # (not the main thread: tests call this from wherever they like)
+        previous = None
     import threading
     chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
     rc = 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
-                for o in sorted(live):
-                    procs[o].terminate()                                    # these exact children; never a pattern
-        if live:
-            time.sleep(poll_s)
-    reader.join(10)
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+        # rank 0 writes its line once, at the end: reading its pipe on a helper thread keeps a chatty library from filling it
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                    stop_children()                                         # (they would wait in a collective for ever)
+            if live:
+                time.sleep(poll_s)
+    except (KeyboardInterrupt, _Stopped) as stop:                           # the PARENT was interrupted: nothing may stay behind holding a GPU
+        sys.stderr.write("bench.py: launcher interrupted (%r); stopping %d rank processes\n" % (stop, sum(p_.poll() is None for p_ in procs)))
+        rc = 130 if isinstance(stop, KeyboardInterrupt) else 143
+    finally:
+        stop_children()
+        if previous is not None:
+            signal.signal(signal.SIGTERM, previous)
+        shutil.rmtree(store_dir, ignore_errors=True)
+    if procs and procs[0].stdout is not None:
+        reader.join(10)
     out = b"".join(chunks)
     if rc == 0:
         os.write(1, out)
@@ -257,7 +298,10 @@ def main():
     dist = None
     if world > 1 or os.environ.get("GENS_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
-        dist.init_process_group(backend=os.environ.get("GENS_BENCH_BACKEND", "nccl"), init_method="env://")      # 'nccl' is RCCL on ROCm
+        # 'nccl' is RCCL on ROCm.  Under our own launcher the rendezvous is a file store (GENS_BENCH_INIT, see launch_ranks); under
+        # torch.distributed.run it is the launcher's env:// contract
+        init = os.environ.get("GENS_BENCH_INIT", "env://")
+        dist.init_process_group(backend=os.environ.get("GENS_BENCH_BACKEND", "nccl"), init_method=init, world_size=world, rank=rank)
 
     from gens_amd import lib as L
     from gens_amd import synthetic

@@ -833,7 +833,8 @@ extern "C" int gens_blend_train_bwd(const float* const* feats, const int* hw, in
 extern "C" int gens_blend_train_acc_parts(int64_t n, int nv) {
     if (n <= 0 || nv < 2) return 0;
     const int64_t tiles = gens_blocks(n, 32 / (nv - 1));
-    const int64_t cap = getenv("GENS_K18_PARTS") ? atoi(getenv("GENS_K18_PARTS")) : 512;   // two workgroups per CU (78 KB of LDS each); the switch: occupancy probes
+    int64_t cap = getenv("GENS_K18_PARTS") ? atoi(getenv("GENS_K18_PARTS")) : 512;   // two workgroups per CU (78 KB of LDS each); the switch: occupancy probes
+    if (cap < 1) cap = 1;                                                            // ("0" or a non-number would be a grid of no workgroups: a failed launch)
     return (int)(tiles < cap ? tiles : cap);
 }
 extern "C" int gens_blend_train_acc_floats(int n_levels) {

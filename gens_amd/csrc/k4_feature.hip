@@ -209,7 +209,13 @@ extern "C" int gens_lookup_feature_fwd(const float* const* feats, const int* hw,
     const int paired = getenv("GENS_K4_NO_PAIRS") == nullptr && (int64_t)nv * hw[0] * hw[1] < (1ll << 31);
     size_t lds = (size_t)K4_BLOCK * (row | 1) * sizeof(float);
     const dim3 grid = gens_blocks(n * (nv - 1), K4_BLOCK);
-    const uint32_t magic = (nv > 2 && n * (nv - 1) < (1ll << 29)) ? (uint32_t)(((1ull << 32) + (uint32_t)(nv - 2)) / (uint32_t)(nv - 1)) : 0u;   // (S = 1: no magic)
+    // item / S as one multiply-high by m = ceil(2^32 / S) is exact while item * (m S - 2^32) < 2^32 (S up to 15: m S - 2^32 reaches S - 1, so a fixed
+    // 2^29 bound on the items is not enough -- S = 15 goes wrong from item 306 783 389); otherwise the kernel divides in 64 bits (magic = 0)
+    uint32_t magic = 0u;                                                                                                                     // (S = 1: no magic)
+    if (nv > 2) {
+        const uint64_t s = (uint64_t)(nv - 1), m = ((1ull << 32) + s - 1) / s, excess = m * s - (1ull << 32), items = (uint64_t)n * s;
+        if (items < (1ull << 31) && items * excess < (1ull << 32)) magic = (uint32_t)m;
+    }
     const int plain = getenv("GENS_K4_PLAIN_COPY") != nullptr, remap = getenv("GENS_K4_XCD_REMAP") != nullptr;
 #define K4_LAUNCH(NLEV) lookup_feature_fwd_k<NLEV><<<grid, K4_BLOCK, lds, (hipStream_t)stream>>>(fs, (const float4*)imgs, w2c, intr, c2w, nv, pts, n, out, (float4*)ray_diff, vis, plain, remap, paired, magic)
     if (n_levels == 5 && !getenv("GENS_K4_NO_UNROLL")) K4_LAUNCH(5);

@@ -370,7 +370,7 @@ __device__ __forceinline__ void ray_setup(const gens_composite_in& in, int64_t r
         p.gz = have ? in.grad[3 * e + 2] : 0.0f;
         p.gn = sqrtf(p.gx * p.gx + p.gy * p.gy + p.gz * p.gz);
         p.tc = d[0] * p.gx + d[1] * p.gy + d[2] * p.gz;
-        float a = in.cos_anneal;
+        const float a = in.cos_anneal_dev ? *in.cos_anneal_dev : in.cos_anneal;   // (uniform: a scalar load)
         p.ic = -(fmaxf(-p.tc * 0.5f + 0.5f, 0.0f) * (1.0f - a) + fmaxf(-p.tc, 0.0f) * a);
         p.ic *= p.vm;
         float icc = fminf(fmaxf(p.ic, -10.0f), 10.0f);
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_bwd_k(gens_comp
         float gsdf = gep + gen;
         float gicc = (gen - gep) * p.dist * 0.5f;
         float gic = (p.ic >= -10.0f && p.ic <= 10.0f) ? gicc * p.vm : 0.0f;
-        float a = in.cos_anneal;
+        const float a = in.cos_anneal_dev ? *in.cos_anneal_dev : in.cos_anneal;   // (uniform: a scalar load)
         float dic = ((-p.tc * 0.5f + 0.5f) > 0.0f ? 0.5f * (1.0f - a) : 0.0f) + ((-p.tc) > 0.0f ? a : 0.0f);
         float gtc = gic * dic;
         float ek = (p.gn > 0.0f) ? geik * p.relax * 2.0f * (p.gn - 1.0f) / p.gn : 0.0f;

@@ -27,7 +27,7 @@ _fp = C.POINTER(C.c_float)
 
 class CompositeIn(C.Structure):
     _fields_ = [(n, _p) for n in ("rays_o", "rays_d", "z", "sdf", "grad", "color", "smooth", "voxel_mask", "src_vis", "inv_s", "z_max")] + [
-        ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9), ("rot_dev", _p)]
+        ("n_rays", _l), ("n", _i), ("n_src", _i), ("sample_dist", _f), ("cos_anneal", _f), ("rot", _f * 9), ("rot_dev", _p), ("cos_anneal_dev", _p)]
 
 
 class LossArgs(C.Structure):

@@ -38,28 +38,51 @@ class DepthwiseConv2d(nn.Conv2d):
 
 
 class BatchNorm2dReLU(nn.BatchNorm2d):
-    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) that also applies the ReLU which follows it in the trunk when `relu` is set
-    (the nn.ReLU slot of the Sequential then holds an nn.Identity: no parameters, the indices of the state dict stay).  In training mode on
-    the device the pair is K22 (gens_batchnorm2d_train_*, csrc/k22_batchnorm.hip: two launches forward, two backward, the running statistics
-    and the batch counter updated by the kernel); otherwise nn.BatchNorm2d's own forward followed by the ReLU."""
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) that also applies the ReLU which follows it in the trunk when `relu` is set.
+    In training mode on the device the pair is K22 (gens_batchnorm2d_train_*, csrc/k22_batchnorm.hip: two launches forward, two backward,
+    the running statistics and the batch counter updated by the kernel); otherwise nn.BatchNorm2d's own forward, and the activation is
+    left to the module that follows.
+
+    The nn.ReLU slot of the Sequential keeps a REAL activation (`ReLUAfterNorm`): a forward of this class that applied the ReLU itself says so
+    through `_relu_done`, which the activation consumes and then passes its input through.  A utility that replaces `_BatchNorm` modules
+    (nn.SyncBatchNorm.convert_sync_batchnorm for multi-GPU training, batch-norm folding, quantisation preparation) installs a plain norm that
+    never raises the flag -- the activation then simply runs; ReLU is idempotent, so no combination of the two can drop or double it."""
 
     use_k22 = os.environ.get("GENS_NO_K22") is None
 
     def __init__(self, num_features, relu=False, **kw):
         super().__init__(num_features, **kw)
         self.fused_relu = relu
+        self._relu_done = False
 
     def forward(self, x):
         from ... import ops
         if self.use_k22 and ops.batchnorm_supported(x, self):
+            self._relu_done = bool(self.fused_relu)
             return ops.batchnorm2d_train(x, self, self.fused_relu)
-        y = super().forward(x)
-        return nn.functional.relu(y) if self.fused_relu else y
+        self._relu_done = False
+        return super().forward(x)
+
+
+class ReLUAfterNorm(nn.ReLU):
+    """The trunk's nn.ReLU behind a BatchNorm2dReLU: skips itself exactly when that norm's forward has just applied the activation."""
+
+    def __init__(self, norm):
+        super().__init__(inplace=True)                       # (torchvision's trunk: nn.ReLU(inplace=True))
+        object.__setattr__(self, "_norm", norm)             # not a sub-module: the norm stays registered once, under its own key
+
+    def forward(self, x):
+        norm = self._norm
+        if getattr(norm, "_relu_done", False):
+            norm._relu_done = False
+            return x
+        return super().forward(x)
 
 
 def _bn_relu(c):
     """BatchNorm2d + ReLU as two Sequential slots (torchvision's layout: `... .1` the norm, `... .2` the activation)."""
-    return BatchNorm2dReLU(c, relu=True, momentum=_BN_MOMENTUM), nn.Identity()
+    norm = BatchNorm2dReLU(c, relu=True, momentum=_BN_MOMENTUM)
+    return norm, ReLUAfterNorm(norm)
 
 
 class _InvertedResidual(nn.Module):

@@ -218,13 +218,15 @@ class _BlendTrain(torch.autograd.Function):
         ev = lambda x: (x + 1) // 2 * 2  # noqa: E731      (even widths: the batched product then reads 8 bytes per lane)
         want_maps = any(ctx.needs_input_grad[3 + 23:])
         g_feat = e(n, s, f) if want_maps else None
-        s_part = e(rows // 32)
+        s_part = e(rows // 32) if n else torch.zeros(rows // 32, device=dev, dtype=_f32)
         if kernels.blend_train_wgrad == "inside":
             # the eleven [dW_l | db_l] blocks summed INSIDE the backward launch (persistent workgroups, sums in registers): no operand rows
             lib = L.load()
             csz = lib.gens_blend_train_acc_floats(nl)
             assert csz == sum(ev(m) * ev(k + 1) for m, k in zip(outs, ins))
-            parts, cc = e(lib.gens_blend_train_acc_parts(n, views.nv), csz), e(csz)
+            parts = e(lib.gens_blend_train_acc_parts(n, views.nv), csz)
+            # (zeros, not empty: with n == 0 the entry point returns before either of its launches and _finish reads cc as it is)
+            cc = torch.zeros(csz, device=dev, dtype=_f32) if n == 0 else e(csz)
             L.call("gens_blend_train_bwd_acc", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr(g_feat), L.ptr(s_part), L.ptr(parts), L.ptr(cc), L.stream(),
                    nbytes=4 * n * (3 + s * f), flops=(3 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n, live=ctx.live,
                    label="gens_blend_train_bwd")

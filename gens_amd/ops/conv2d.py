@@ -78,6 +78,10 @@ class _BatchNormTrain(torch.autograd.Function):
         L.call("gens_batchnorm2d_train_fwd", L.ptr(xc), L.ptr(wd), L.ptr(bd), n, c, hw, float(eps), float(momentum), 1 if relu else 0, L.ptr(y),
                L.ptr(mean_rstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), L.ptr(scratch, torch.float64),
                L.stream(), nbytes=12 * xc.numel(), label="gens_batchnorm2d")
+        # the kernel moved the three buffers in place: tell autograd's version counters (anything that saved them for a backward then
+        # raises instead of reading the new values silently) -- ctx.mark_dirty would force them to be returned as outputs
+        for buf in (running_mean, running_var, num_batches_tracked):
+            torch.autograd.graph.increment_version(buf)
         ctx.save_for_backward(xc, mean_rstd, wd, bd)
         ctx.relu = relu
         return y

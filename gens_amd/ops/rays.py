@@ -85,6 +85,14 @@ def merge_mid_points(rays_o, rays_d, z, z_add, masks, sample_dist):
 # ------------------------------------------------------------------------------------------------------------------
 # K8  compositing (implicit_surface.py:160-168, 202-303)
 # ------------------------------------------------------------------------------------------------------------------
+def _anneal(cos_anneal):
+    """The annealing ratio as the launch takes it: a Python float by value, or a one-element float32 device tensor by address."""
+    if torch.is_tensor(cos_anneal):
+        assert cos_anneal.is_cuda and cos_anneal.dtype == _f32 and cos_anneal.numel() == 1
+        return cos_anneal.detach()
+    return float(cos_anneal)
+
+
 def _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_vis, inv_s, z_max, sample_dist, cos_anneal, rot):
     ci = L.CompositeIn()
     ci.rays_o, ci.rays_d, ci.z = L.ptr(rays_o), L.ptr(rays_d), L.ptr(z)
@@ -94,7 +102,11 @@ def _composite_in(rays_o, rays_d, z, sdf, grad, color, smooth, voxel_mask, src_v
     ci.inv_s, ci.z_max = L.ptr(inv_s), L.ptr(z_max)
     ci.n_rays, ci.n = z.shape
     ci.n_src = src_vis.shape[-1] if src_vis is not None else 0
-    ci.sample_dist, ci.cos_anneal = float(sample_dist), float(cos_anneal)
+    ci.sample_dist = float(sample_dist)
+    if torch.is_tensor(cos_anneal):          # one float ON THE DEVICE: a captured step is replayed with whatever ratio the caller left there
+        ci.cos_anneal, ci.cos_anneal_dev = 0.0, L.ptr(cos_anneal)
+    else:
+        ci.cos_anneal, ci.cos_anneal_dev = float(cos_anneal), None
     if torch.is_tensor(rot):                 # nine floats on the device (SceneCams.rot_inv): no host read
         ci.rot_dev = L.ptr(rot)
     else:
@@ -269,7 +281,7 @@ def composite_train(sel, rays_o, rays_d, z, sample_dist, y_all, g_all, s_all, co
     sv = src_vis.reshape(b * n, -1)
     sv = _c(sv.view(u8) if sv.dtype == torch.bool else sv.to(u8))
     outs = _CompositeTrain.apply(y_all, g_all, s_all, color, variance, sel, _c(rays_o.to(_f32)), _c(rays_d.to(_f32)), _c(z.detach().to(_f32)), vm, sv,
-                                 float(sample_dist), float(cos_anneal), rot)
+                                 float(sample_dist), _anneal(cos_anneal), rot)
     return dict(zip(COMPOSITE_TRAIN_KEYS, outs))
 
 
@@ -299,7 +311,7 @@ def composite(rays_o, rays_d, z, sample_dist, sdf, gradients, smooth, color, vox
         sv = _c(sv.view(u8) if sv.dtype == torch.bool else sv.to(u8))
     outs = _Composite.apply(sdf.reshape(b, n), gradients.reshape(b, n, 3), color.reshape(b, n, 3),
                             smooth.reshape(b, n, 3) if smooth is not None else None, inv_s.reshape(1), _c(rays_o.to(_f32)),
-                            _c(rays_d.to(_f32)), z, vm, sv, z_max, float(sample_dist), float(cos_anneal), rot)
+                            _c(rays_d.to(_f32)), z, vm, sv, z_max, float(sample_dist), _anneal(cos_anneal), rot)
     return dict(zip(COMPOSITE_KEYS, outs))
 
 

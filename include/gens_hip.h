@@ -41,7 +41,14 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-int gens_abi_version(void);   /* 7 (6 + gens_sdf_grad_f16: the split-half value + gradient kernel) */
+/* 9.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
+ *   8 = round 4's additions, which shipped under the stale number 7: gens_grid_sample_{fwd,bwd,bwd2} (K20), gens_depthwise_conv2d_{fwd,dgrad,wgrad}
+ *       + gens_depthwise_conv2d_wgrad_parts (K21), gens_batchnorm2d_train_{fwd,bwd} + gens_batchnorm2d_scratch_doubles (K22),
+ *       gens_blend_train_bwd_acc + gens_blend_train_acc_{parts,floats}, gens_merge_upsample, gens_conv3d_wgrad_parts_strided, gens_instnorm_finish,
+ *       gens_sdf_grad_stash_reset, gens_sdf_grad_f16_stash_reset, and gens_ray_points' `mid` / `sample_dist` arguments.
+ *   9 = round 5: gens_composite_in gained `cos_anneal_dev` (the annealing ratio read from the device, so that a captured step can be replayed
+ *       with another ratio) -- a struct-layout change: callers built against 8 must be rebuilt. */
+int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layout helpers (no reference counterpart: the reference keeps NCHW / NCDHW everywhere).
@@ -204,6 +211,8 @@ typedef struct {
     float sample_dist, cos_anneal;
     float rot[9];
     const float* rot_dev;
+    const float* cos_anneal_dev;   /* NULL, or a device float that REPLACES cos_anneal (read at launch: a HIP graph of the step can be replayed
+                                    * with this step's ratio, runner.py:156-157,394-398) */
 } gens_composite_in;
 
 typedef struct {

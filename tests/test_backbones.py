@@ -79,3 +79,38 @@ def test_gens_builds_stand_alone_with_its_own_backbones():
     assert isinstance(model.match_feature_network, FeatureNetwork) and not any(p.requires_grad for p in model.match_feature_network.parameters())
     groups = model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3})
     assert len(groups) == 2 and len(groups[1]["params"]) == len(list(model.feature_network.parameters())) + len(list(model.reg_network.parameters()))
+
+
+def test_trunk_keeps_its_activations_when_a_utility_replaces_the_norm_modules():
+    """The ReLU that K22 folds into the trunk's BatchNorm stays a real module in the Sequential's slot: replacing every `_BatchNorm` with a
+    plain one (what nn.SyncBatchNorm.convert_sync_batchnorm, batch-norm folding or quantisation preparation do) must not drop an activation,
+    and the untouched trunk must equal the plain-module trunk (no activation applied twice with a different result either)."""
+    import copy
+
+    import torch.nn as nn
+    from gens_amd.models.modules import feature_network as fn
+    torch.manual_seed(0)
+    trunk = nn.Sequential(*fn._mnasnet_trunk()).train()
+    plain = copy.deepcopy(trunk)
+
+    def swap(mod):
+        for name, child in mod.named_children():
+            if isinstance(child, nn.modules.batchnorm._BatchNorm):
+                new = nn.BatchNorm2d(child.num_features, eps=child.eps, momentum=child.momentum)
+                new.load_state_dict(child.state_dict())
+                setattr(mod, name, new)
+            else:
+                swap(child)
+    swap(plain)
+    assert not any(isinstance(m, fn.BatchNorm2dReLU) for m in plain.modules())
+    assert sum(isinstance(m, nn.ReLU) for m in plain.modules()) == sum(isinstance(m, nn.ReLU) for m in trunk.modules()) > 30
+    assert list(plain.state_dict()) == list(trunk.state_dict())
+    x = torch.rand(2, 3, 64, 96)
+    a, b = trunk(x), plain(x)
+    assert torch.equal(a, b)
+    # the activations are really there: without them the output differs
+    bare = copy.deepcopy(plain)
+    for m in bare.modules():
+        if isinstance(m, nn.ReLU):
+            m.forward = lambda t: t
+    assert not torch.allclose(bare(x), b)

@@ -13,9 +13,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DIMS5 = [256, 128, 64, 32, 16]
-# parameters with <= 4 elements (the variance, the blending network's temperature) are sums of cancelling per-sample terms: relative to their
-# own magnitude they carry more float32 round-off than a weight matrix.  Bound = 3 x the worst value measured over both full-size steps below.
-SCALAR_GRAD_TOL = 0.15
 
 
 def _surface(seed=0, perturb_weights=0.04, dims=DIMS5, radius=0.5):

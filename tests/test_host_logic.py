@@ -113,6 +113,42 @@ sys.exit(bench.launch_ranks(2, [], child=stub))
     assert "rank 1 exited with status 7" in r.stderr
 
 
+def test_bench_launcher_interrupted_by_sigterm_leaves_no_rank_behind(tmp_path):
+    """A harness timeout SIGTERMs the PARENT: the rank processes (each writes its pid, then would sleep for ten minutes -- in a real run: wait
+    in an RCCL collective holding its GPU) must be gone when the parent exits, and the rendezvous directory with them."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+    code = r'''
+import sys
+import bench
+stub = [sys.executable, "-c", "import os, time; open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid())); time.sleep(600)"]
+sys.exit(bench.launch_ranks(3, [], child=stub))
+''' % str(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    parent = subprocess.Popen([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 60
+    while time.time() < deadline and len(list(tmp_path.glob("pid*"))) < 3:
+        time.sleep(0.05)
+    pids = [int(f.read_text()) for f in tmp_path.glob("pid*") if f.read_text()]
+    assert len(pids) == 3
+    parent.send_signal(signal.SIGTERM)
+    out, err = parent.communicate(timeout=60)
+    assert parent.returncode == 143, (parent.returncode, err)
+    assert b"launcher interrupted" in err
+    for pid in pids:
+        for _ in range(100):                                      # (reaped by the parent's wait(); give the kernel a moment)
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.05)
+        else:
+            raise AssertionError("rank process %d survived its launcher" % pid)
+
+
 def test_bench_main_becomes_the_launcher_only_without_a_launcher_around_it():
     """--gpus 2 with no WORLD_SIZE: main() hands over to launch_ranks before torch is imported.  Under a launcher (WORLD_SIZE set) --gpus must
     equal the world size or the run aborts."""
