@@ -103,6 +103,7 @@ class GenS(nn.Module):
         self.features = model["features"].to(device)
         self.implicit_surface.load_state_dict(model["implicit_surface"])
         self.has_vol = True
+        self._mode_version = getattr(self, "_mode_version", 0) + 1
 
     def get_params_vol(self):
         return {"volumes": self.volumes, "mask_volmes": self.mask_volmes, "features": self.features,
@@ -118,17 +119,120 @@ class GenS(nn.Module):
         self.mask_volmes = nn.ParameterList([nn.Parameter(v.detach(), requires_grad=False) for v in mask_volmes])
         self.features = nn.ParameterList([nn.Parameter(f.detach(), requires_grad=False) for f in features])
         self.has_vol = True
+        self._mode_version = getattr(self, "_mode_version", 0) + 1
 
     # -- forward (gens.py:124-157) ------------------------------------------------------------------------------
+    def get_optim_params_fused(self, lr_confs):
+        """get_optim_params with `fused=True` in every group: torch.optim.Adam(groups) -- built exactly as runner.py:96-97 builds it -- then
+        updates all parameters of a group in ONE launch instead of ~10 passes of the multi-tensor form (the fine-tune volumes are 307 MB:
+        1.3 ms per step).  Same update rule; an opt-in because the rounding order inside the update differs from the multi-tensor form."""
+        groups = self.get_optim_params(lr_confs)
+        for g in groups:
+            g["fused"] = True
+        return groups
+
+    def _reload_match(self, step):
+        """gens.py:131-135: every fifth epoch's first step copies the feature network into its frozen matching twin."""
+        if step is not None and step % 5 == 0:
+            print("load image feature ckpt")
+            self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
+            for p in self.match_feature_network.parameters():
+                p.requires_grad = False
+
+    def _view_index_of(self, view_ids):
+        """(gens.py:151-153: `self.features[i][view_ids]` with a Python list builds an index tensor on the host and copies it over -- every step, a
+        pageable host-to-device copy, and not capturable into a graph: the index tensor is kept per list of ids; one gather serves both uses,
+        the reference's two copies hold the same values)"""
+        if torch.is_tensor(view_ids):
+            return view_ids
+        ids = tuple(int(v) for v in view_ids)
+        cache = getattr(self, "_view_index", None)
+        if cache is None or cache[0] != ids or cache[1].device != self.features[0].device:
+            cache = self._view_index = (ids, torch.tensor(ids, dtype=torch.long, device=self.features[0].device))
+        return cache[1]
+
+    def train(self, mode=True):
+        self._mode_version = getattr(self, "_mode_version", 0) + 1      # (a captured step belongs to one train / eval setting of the module tree)
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._mode_version = getattr(self, "_mode_version", 0) + 1      # .to() / .cuda() / .float(): the parameters move
+        return super()._apply(fn, *args, **kwargs)
+
+    def _step_refs(self):
+        """Every parameter and buffer of the model, listed once per module-tree version (walking ~500 modules costs a millisecond per call)."""
+        version = (getattr(self, "_mode_version", 0), self.has_vol, len(getattr(self, "volumes", ())) if self.has_vol else 0)
+        cache = getattr(self, "_refs_cache", None)
+        if cache is None or cache[0] != version:
+            cache = self._refs_cache = (version, list(self.parameters()) + list(self.buffers()))
+        return cache[1]
+
+    def _auto_graph_ok(self, mode, ipts, step):
+        """May this call run as a captured step (gens_amd.graph.AutoGraph)?  Training / fine-tune calls on the device whose render takes the fused
+        path; the one step in five epochs that refreshes the matching network stays eager (its copy sits between the two CNN passes)."""
+        from .. import graph
+        if mode == "val" or not getattr(self, "auto_graph", True) or not graph.auto_graph_enabled() or not torch.is_grad_enabled():
+            return False
+        if not self.has_vol and step is not None and step % 5 == 0:
+            return False
+        if self.has_vol:
+            volumes, n_feat = list(self.volumes), len(self.features)
+        else:
+            dims = getattr(self.volume, "volume_dims", None)
+            if dims is None:
+                return False
+            volumes, n_feat = None, len(dims)
+        surf = self.implicit_surface
+        if volumes is None:           # the U-Net's outputs do not exist yet: the same test on what they will be (four channels, one volume per level)
+            if not surf.fused_train or not torch.is_tensor(ipts["rays_o"]) or not ipts["rays_o"].is_cuda or torch.cuda.is_current_stream_capturing():
+                return False
+            from .. import ops
+            return (ops.SdfTrainStep.supported(surf.sdf_network, n_feat) and ops.BlendPlan.supported(surf.color_network) and ipts["imgs"].shape[0] >= 2
+                    and surf.n_importance > 0)
+        return surf._auto_graph_ok(mode, ipts, volumes, list(self.features))
+
     def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None):
+        """gens.py:124-157.  Training / fine-tune calls run as a CAPTURED step after two eager ones (forward = one HIP graph replay, the backward
+        of the caller's loss = a second one; gens_amd.graph.AutoGraph) -- the loop of runner.py:157-166 / 300-308 stays as it is.
+        `model.auto_graph = False` or GENS_AUTO_GRAPH=0: every call eager."""
+        if not self._auto_graph_ok(mode, ipts, step):
+            if getattr(self, "auto_graph", True):
+                return self._forward_impl(mode, ipts, cos_anneal_ratio, step)
+            self.implicit_surface._auto_suppressed = True       # switched off on the model: off for the render inside it too
+            try:
+                return self._forward_impl(mode, ipts, cos_anneal_ratio, step)
+            finally:
+                self.implicit_surface._auto_suppressed = False
+        from .. import graph
+        surf = self.implicit_surface
+        auto = getattr(self, "_auto", None)
+        if auto is None:
+            auto = self._auto = graph.AutoGraph()
+        copied = {k: ipts[k] for k in surf.STEP_INPUTS if k in ipts}
+        if self.has_vol:
+            copied["view_index"] = self._view_index_of(ipts["view_ids"])
+        refs = self._step_refs()
+        use_match = not (step is None or step < 5)
+
+        def body(cp, sc, alias):
+            ip = dict(ipts)
+            ip.update({k: v for k, v in cp.items() if k != "view_index"})
+            if "view_index" in cp:
+                ip["view_ids"] = cp["view_index"]
+            surf._auto_suppressed = True              # the render is part of THIS step's graph (or warm-up), not a captured step of its own
+            try:
+                return self._forward_impl(mode, ip, sc["cos_anneal_ratio"], 5.0 if use_match else 1.0, reload_match=False)
+            finally:
+                surf._auto_suppressed = False
+        key = ("GenS", mode, self.has_vol, use_match, getattr(self, "_mode_version", 0), self.training, len(refs))
+        return auto.run(key, copied, refs, {"cos_anneal_ratio": float(cos_anneal_ratio)}, body, [surf], module=self)
+
+    def _forward_impl(self, mode, ipts, cos_anneal_ratio=1.0, step=None, reload_match=True):
         if not self.has_vol:
             imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
             features = self.feature_network(imgs)
-            if step is not None and step % 5 == 0:
-                print("load image feature ckpt")
-                self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
-                for p in self.match_feature_network.parameters():
-                    p.requires_grad = False
+            if reload_match:
+                self._reload_match(step)
             with torch.no_grad():
                 match_features = self.match_feature_network(imgs)
             volumes, mask_volmes = self.volume.agg_mean_var(features, intrs, c2ws)
@@ -136,17 +240,7 @@ class GenS(nn.Module):
         else:
             view_ids = ipts["view_ids"] if mode != "val" else list(range(ipts["imgs"].shape[0]))
             volumes, mask_volmes = list(self.volumes), list(self.mask_volmes)
-            # (gens.py:151-153: `self.features[i][view_ids]` with a Python list builds an index tensor on the host and copies it over -- every
-            # step, a pageable host-to-device copy, and not capturable into a graph: the index tensor is kept per list of ids; one gather serves
-            # both uses, the reference's two copies hold the same values)
-            ids = tuple(int(v) for v in view_ids) if not torch.is_tensor(view_ids) else None
-            if ids is None:
-                index = view_ids
-            else:
-                cache = getattr(self, "_view_index", None)
-                if cache is None or cache[0] != ids or cache[1].device != self.features[0].device:
-                    cache = self._view_index = (ids, torch.tensor(ids, dtype=torch.long, device=self.features[0].device))
-                index = cache[1]
+            index = self._view_index_of(view_ids)
             features = [f.index_select(0, index) for f in self.features]
             match_features = features
         return self.implicit_surface(mode, ipts, volumes, mask_volmes, features, match_features, cos_anneal_ratio, step)

@@ -300,15 +300,36 @@ class ImplicitSurface(nn.Module):
             self._pinned_draws_event.record()
         return (on_dev[:n_t].view(b, 1) if n_t else None), on_dev[n_t:].view(N_RANDOM_PTS, 3)
 
-    def refresh_host_draws(self):
+    def refresh_host_draws(self, buf=None, layout=None):
         """Draw the step's host random numbers into the page-locked staging buffer (the reference's generator, its order and shapes).  A step
-        replayed from a captured graph (gens_amd.graph.GraphedStep) calls this before every replay: the graph's copy node then carries the new
-        draws to the device.  The previous replay must have finished (the loss read-back of a training loop guarantees it)."""
-        n_t, b = self._pinned_draws_layout
-        buf = self._pinned_draws
+        replayed from a captured graph (gens_amd.graph.GraphedStep / AutoGraph) calls this before every replay: the graph's copy node then
+        carries the new draws to the device.  The previous replay must have finished reading the buffer.  buf / layout: the buffer a captured
+        step owns (AutoGraph keeps one per captured signature); default: this module's own."""
+        n_t, b = self._pinned_draws_layout if layout is None else layout
+        buf = self._pinned_draws if buf is None else buf
         if n_t:
             buf[:n_t] = torch.rand([b, 1]).reshape(-1)
         buf[n_t:] = (torch.rand([N_RANDOM_PTS, 3]) * 2 - 1).reshape(-1)
+
+    def begin_capture(self):
+        """Before a step is captured into a HIP graph: fresh page-locked buffers for the host draws and the deferred checks, allocated NOW (a
+        page-locked allocation is not a capturable operation) in the sizes the eager calls before this one used; the captured copy nodes will
+        read / write these, and end_capture() hands them to the graph's owner."""
+        old = getattr(self, "_pinned_draws", None)
+        self._pinned_draws = None if old is None else torch.empty(old.numel(), dtype=torch.float32, pin_memory=True)
+        self._pinned_draws_event = None
+        self._deferred_host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        self._deferred = None
+
+    def end_capture(self):
+        """-> (draw buffer, its layout, deferred-check words) of the capture that has just ended; this module forgets them, so that an eager call
+        allocates its own and never refills or reallocates what a graph's copy nodes point at."""
+        got = (getattr(self, "_pinned_draws", None), getattr(self, "_pinned_draws_layout", None), getattr(self, "_deferred_host", None))
+        self._pinned_draws = None
+        self._pinned_draws_event = None
+        self._deferred_host = None
+        self._deferred = None
+        return got
 
     def _train_fused_ok(self, scene, net, lean):
         """The fused TRAINING path of render_core: K17 (net) + K18 on a device-side selection (ops.StepPoints), no host synchronisation."""
@@ -747,7 +768,81 @@ class ImplicitSurface(nn.Module):
         if int(host[2]) < 1:
             raise RuntimeError("No valid pseudo pts!")
 
+    # inputs of a training step that change from call to call (copied into a captured step's static tensors); everything else in `ipts` is
+    # either consumed by the caller's loss (colour, depths, masks) or describes the item (scene, file names)
+    STEP_INPUTS = ("imgs", "intrs", "c2ws", "rays_o", "rays_d", "near", "far", "pseudo_pts")
+
+    def _auto_graph_ok(self, mode, ipts, volumes, features):
+        """May this call run as a captured step (gens_amd.graph.AutoGraph)?  Training / fine-tune steps on the device that take the fused path
+        (K17 + K18 on a device-side selection: nothing in them is read back by the host)."""
+        from ... import graph
+        if mode == "val" or not getattr(self, "auto_graph", True) or not graph.auto_graph_enabled() or not torch.is_grad_enabled():
+            return False
+        if getattr(self, "_auto_suppressed", False):          # an enclosing GenS.forward manages this step
+            return False
+        rays = ipts["rays_o"]
+        if not (torch.is_tensor(rays) and rays.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return False
+        if not self.fused_train or self.n_importance <= 0 or features is None or ipts["imgs"].shape[0] < 2:
+            return False
+        if not any(p.requires_grad for p in self.sdf_network.parameters()) and not any(v.requires_grad for v in volumes):
+            return False
+        nf = len(features)
+        if not (ops.BlendPlan.supported(self.color_network) and nf <= 5 and self.color_network.ray_dir_fc[2].weight.shape[0] == 3 + 4 * nf):
+            return False
+        return ops.SdfTrainStep.supported(self.sdf_network, len(volumes)) and all(v.dim() == 5 and v.shape[1] == 4 for v in volumes)
+
     def forward(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):
+        """implicit_surface.py:472-499.  A training / fine-tune call that qualifies (_auto_graph_ok) runs as a CAPTURED step after two eager
+        ones: forward and backward are one HIP graph replay each (gens_amd.graph.AutoGraph), behind this unchanged signature -- the loop of
+        runner.py:157-166 stays as it is.  `self.auto_graph = False` or GENS_AUTO_GRAPH=0: every call eager."""
+        if not self._auto_graph_ok(mode, ipts, volumes, features):
+            return self._forward_impl(mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio, step)
+        from ... import graph
+        auto = getattr(self, "_auto", None)
+        if auto is None:
+            auto = self._auto = graph.AutoGraph()
+        copied, refs, layout = {}, [], []
+
+        def take(name, t):
+            """persistent tensors (parameters, leaves the caller optimises) are used where they are; the rest is copied per call"""
+            if isinstance(t, nn.Parameter) or (t.is_leaf and t.requires_grad):
+                refs.append(t)
+                layout.append((name, len(refs) - 1))
+            else:
+                copied[name] = t
+                layout.append((name, None))
+        for k in self.STEP_INPUTS:
+            if k in ipts:
+                take(k, ipts[k])
+        same_match = all(a is b for a, b in zip(features, match_features)) and len(features) == len(match_features)
+        groups = [("volumes", volumes), ("mask_volumes", mask_volumes), ("features", features)] + ([] if same_match else [("match_features", match_features)])
+        for gname, group in groups:
+            for i, t in enumerate(group):
+                take(f"{gname}.{i}", t)
+        params = [p for p in self.parameters()]
+        n_in = len(refs)
+        refs = refs + params
+        use_match = not (step is None or step < 5)
+        counts = tuple(len(g) for _, g in groups)
+
+        where = dict(layout)
+
+        def body(cp, sc, alias):
+            def get(name):
+                return cp[name] if name in cp else alias(refs[where[name]])
+            ip = dict(ipts)
+            for k in self.STEP_INPUTS:
+                if k in ipts:
+                    ip[k] = get(k)
+            lists = {gname: [get(f"{gname}.{i}") for i in range(len(group))] for gname, group in groups}
+            feats = lists["features"]
+            return self._forward_impl(mode, ip, lists["volumes"], lists["mask_volumes"], feats, feats if same_match else lists["match_features"],
+                                      sc["cos_anneal_ratio"], 5.0 if use_match else 0.0)
+        key = ("ImplicitSurface", mode, use_match, same_match, counts, tuple(n for n, _ in layout), n_in, self.training)
+        return auto.run(key, copied, refs, {"cos_anneal_ratio": float(cos_anneal_ratio)}, body, [self], module=self)
+
+    def _forward_impl(self, mode, ipts, volumes, mask_volumes, features, match_features, cos_anneal_ratio=1.0, step=None):
         imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
         rays_o, rays_d, near, far = ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"]
         scene = Scene(volumes, mask_volumes, imgs, features, match_features, intrs, c2ws)

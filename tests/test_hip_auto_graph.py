@@ -1,0 +1,203 @@
+"""The captured training step BEHIND the reference's unchanged boundary (gens_amd.graph.AutoGraph inside GenS.forward / ImplicitSurface.forward).
+
+The loops below are runner.py:157-166 / 300-308 as written -- `outputs = model(mode, inputs, ...)`, the caller's loss, `optimizer.zero_grad()`,
+`loss.backward()`, `optimizer.step()`, the loss read back -- with a plain torch.optim.Adam and NO graph object in the caller.  After two eager calls
+the model captures forward and backward into two HIP graphs and replays them; the run must walk the trajectory of the same loop with the
+capture switched off (model.auto_graph = False), within the tolerances tests/test_hip_graph.py uses for GraphedStep."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _finetune_model(auto):
+    from tests.test_hip_ddp import _inputs, _model
+    model = _model()
+    ipts = _inputs(7, nv=3)
+    model.init_volumes({k: ipts[k] for k in ("imgs", "intrs", "c2ws")})
+    model.auto_graph = auto
+    return model
+
+
+def _step_inputs(k, n_rays=48, nv=3):
+    """A different ray batch, pseudo-point set and view order per step (what the fine-tune loop's dataset hands over, runner.py:296-297)."""
+    from tests.test_hip_ddp import _inputs
+    ipts = _inputs(100 + k, n_rays=n_rays, nv=nv)
+    ipts["view_ids"] = [[0, 1, 2], [1, 0, 2], [2, 1, 0]][k % 3]
+    ipts["color"] = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(k)).cuda()
+    return ipts
+
+
+def _runner_loop(model, opt, n, loss_fn, anneal=lambda k: 1.0, mode="train", step_of=lambda k: None, inputs=_step_inputs, zero=None):
+    """runner.py:295-308 (fine-tune) / 154-166 (train): nothing here knows about graphs."""
+    losses = []
+    for k in range(n):
+        ipts = inputs(k)
+        outputs = model(mode, ipts, cos_anneal_ratio=anneal(k), step=step_of(k))
+        loss = loss_fn(outputs, ipts)
+        if zero is None:
+            opt.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=zero)
+        loss.backward()
+        opt.step()
+        psnr = 20.0 * torch.log10(1.0 / (((outputs["color_fine"] - ipts["color"]) ** 2).mean()).sqrt())       # runner.py:311 reads the outputs after the update
+        losses.append((float(loss), float(psnr)))
+        del outputs
+    torch.cuda.synchronize()
+    return losses
+
+
+def _compare(model_a, model_b, la, lb, rel=2e-5, prel=2e-4):
+    assert len(la) == len(lb)
+    for (a, pa), (b, pb) in zip(la, lb):
+        assert abs(a - b) <= rel * abs(a), (la, lb)
+        assert abs(pa - pb) <= 1e-3, (la, lb)
+    assert len({a for a, _ in lb}) == len(lb)                 # different steps, not one step replayed
+    pa = dict(model_a.named_parameters())
+    for k, v in model_b.named_parameters():
+        if v.requires_grad:
+            ref = pa[k]
+            assert float((v - ref).abs().max()) <= prel * max(float(ref.abs().max()), 1e-2), k      # (floor: parameters whose gradient is round-off, e.g. a bias in front of a softmax, move by Adam steps of noise)
+
+
+def test_finetune_loop_is_captured_behind_the_unchanged_boundary():
+    from tests.test_hip_ddp import _loss
+    lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
+    n = 7
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        opt = torch.optim.Adam(model.get_optim_params(lrs))       # runner.py:96-97, as written
+        torch.manual_seed(21)
+        runs[auto] = (model, _runner_loop(model, opt, n, _loss, anneal=lambda k: min(1.0, 0.2 * k)))
+    model, graphed = runs[True]
+    assert model._auto.stats["captured"] == 1 and model._auto.stats["replayed"] == n - 2 and model._auto.stats["superset_backward"] == 0, model._auto.stats
+    assert not hasattr(model.implicit_surface, "_auto")           # the render did not capture a step of its own inside the model's
+    _compare(runs[False][0], model, runs[False][1], graphed)
+
+
+def test_captured_loop_follows_in_place_zeroing_and_gradient_accumulation():
+    """optimizer.zero_grad(set_to_none=False) (torch 1.13's default, the version the reference pins) keeps .grad alive across steps: it must never
+    alias a static gradient buffer that the next replay overwrites (the gradient would be added to itself)."""
+    from tests.test_hip_ddp import _loss
+    lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        opt = torch.optim.Adam(model.get_optim_params(lrs))
+        torch.manual_seed(5)
+        runs[auto] = (model, _runner_loop(model, opt, 6, _loss, zero=False))
+    assert runs[True][0]._auto.stats["replayed"] == 4
+    _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1])
+
+
+def test_a_new_shape_is_a_new_capture_and_an_old_one_is_found_again():
+    from tests.test_hip_ddp import _loss
+    lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
+    sizes = [48, 48, 48, 48, 32, 32, 32, 32, 48, 32]
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        opt = torch.optim.Adam(model.get_optim_params(lrs))
+        torch.manual_seed(9)
+        runs[auto] = (model, _runner_loop(model, opt, len(sizes), _loss, inputs=lambda k: _step_inputs(k, n_rays=sizes[k])))
+    st = runs[True][0]._auto.stats
+    assert st["captured"] == 2 and st["replayed"] == 2 + 2 + 2, st
+    _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1])
+
+
+def test_the_reference_errors_of_a_captured_step_are_raised_before_the_update():
+    """No valid pseudo point (implicit_surface.py:494-495): the reference raises inside forward.  A captured step learns it from a device flag;
+    it must surface inside loss.backward() -- before optimizer.step() -- without any help from the loop."""
+    from tests.test_hip_ddp import _loss
+    model = _finetune_model(True)
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}))
+    torch.manual_seed(3)
+    _runner_loop(model, opt, 4, _loss)
+    assert model._auto.stats["replayed"] == 2
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    ipts = _step_inputs(4)
+    ipts["pseudo_pts"] = torch.full_like(ipts["pseudo_pts"], 5.0)          # far outside every mask volume
+    outputs = model("train", ipts, cos_anneal_ratio=1.0)
+    loss = _loss(outputs, ipts)
+    opt.zero_grad()
+    with pytest.raises(RuntimeError, match="No valid pseudo pts"):
+        loss.backward()
+    for k, v in model.named_parameters():
+        assert torch.equal(v, before[k]), k
+    # the loop goes on with good inputs
+    more = _runner_loop(model, opt, 2, _loss, inputs=lambda k: _step_inputs(k + 5))
+    assert all(torch.isfinite(torch.tensor(a)) for a, _ in more)
+
+
+def test_a_loss_that_starts_to_use_another_output_is_served_by_the_superset_backward_then_recaptured():
+    from tests.test_hip_ddp import _loss
+
+    def loss_b(out, ipts):
+        return _loss(out, ipts) + 0.3 * (out["normal"] ** 2).sum() + 0.1 * out["weight_sum"].sum()
+    lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        opt = torch.optim.Adam(model.get_optim_params(lrs))
+        torch.manual_seed(13)
+        first = _runner_loop(model, opt, 4, _loss)
+        second = _runner_loop(model, opt, 4, loss_b, inputs=lambda k: _step_inputs(k + 4))
+        runs[auto] = (model, first + second)
+    st = runs[True][0]._auto.stats
+    assert st["superset_backward"] == 1 and st["captured"] == 2 and st["replayed"] == 2 + 4, st
+    _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1])
+
+
+def test_train_mode_with_the_cnns_is_captured_and_the_match_refresh_step_stays_eager():
+    """GenS.forward("train") with the 2-D CNN, K1 and the U-Net inside the captured step; `step` as runner.py:157 passes it (epoch + batch / len):
+    the step with step % 5 == 0 copies the feature network into its matching twin between the two CNN passes and is never captured; steps >= 5
+    warp with the matching features (another launch sequence: another capture)."""
+    from tests.test_hip_ddp import _loss, _model
+    steps = [0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 5.0, 5.125, 5.25, 5.375, 5.5]
+    runs = {}
+    for auto in (False, True):
+        model = _model()
+        model.auto_graph = auto
+        opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+        torch.manual_seed(17)
+        runs[auto] = (model, _runner_loop(model, opt, len(steps), _loss, anneal=lambda k: min(1.0, steps[k] / 2.0), step_of=lambda k: steps[k],
+                                          inputs=lambda k: _step_inputs(k, nv=4) | {"view_ids": None}))
+    st = runs[True][0]._auto.stats
+    # steps[0] and steps[6] refresh the matching network (eager, outside the cache); 0.125, 0.25 warm up, 0.375 .. 0.625 replay; 5.125, 5.25 warm up, 5.375, 5.5 replay
+    assert st["captured"] == 2 and st["replayed"] == 3 + 2, st
+    _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1], rel=1e-4, prel=2e-3)
+
+
+def test_render_alone_is_captured_when_it_is_called_directly():
+    """ImplicitSurface.forward is a boundary of its own (implicit_surface.py:472-499): called directly with leaf volumes / feature maps the caller
+    optimises (used where they are) and per-step mask volumes (copied), it captures its own step."""
+    from gens_amd import ops
+    from tests.test_hip_ddp import _loss
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        surf = model.implicit_surface
+        surf.auto_graph = auto
+        vols = [v.detach().clone().requires_grad_(True) for v in model.volumes]
+        feats = [f.detach().clone().requires_grad_(True) for f in model.features]
+        masks = [m.detach().clone() for m in model.mask_volmes]
+        opt = torch.optim.Adam(list(surf.parameters()) + vols + feats, lr=1e-3)
+        torch.manual_seed(2)
+        losses = []
+        for k in range(6):
+            ipts = _step_inputs(k)
+            out = surf("train", ipts, vols, [m.clone() for m in masks], feats, feats, min(1.0, 0.3 * k), 1.0)
+            loss = _loss(out, ipts)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append((float(loss), 0.0))
+        runs[auto] = (surf, losses, vols, feats)
+    surf = runs[True][0]
+    assert surf._auto.stats["captured"] == 1 and surf._auto.stats["replayed"] == 4, surf._auto.stats
+    _compare(runs[False][0], surf, runs[False][1], runs[True][1])
+    for a, b in zip(runs[False][2] + runs[False][3], runs[True][2] + runs[True][3]):
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(a.abs().max()), 1e-3)
+    assert ops is not None
