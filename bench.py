@@ -563,41 +563,54 @@ def main():
         try:
             from scripts.train_step_bench import measure
             train = {"workload": "BASELINE config[2]: DTU-shaped training step, 5 views 480x640, volume_dims [256, 128, 64], 512 rays + 2048 pseudo "
-                                 "points, the reference's Loss (gens_amd.losses.Loss, shipped weights) + backward + Adam (torch.optim.Adam as "
-                                 "runner.py:97 builds it); 30 timed steps after 5 warm-up each, the loss read back every step as runner.py does; "
+                                 "points, the reference's Loss (gens_amd.losses.Loss, shipped weights) + backward + torch.optim.Adam(model.get_optim_params(...)) "
+                                 "as runner.py:96-97 builds it; 30 timed steps after 5 warm-up each, the loss read back every step as runner.py does; "
                                  "ms_per_step = the MEDIAN step (mean_ms_per_step beside it)",
-                     "note": ("secondary figures; not the headline.  The eager keys enqueue ~140 launches per step from Python, about as long as the GPU needs "
-                              "to run them (see ms_per_step_stats: on a busy or cold host the median leaves p10); the *_graph keys replay the same step from a "
-                              "HIP graph and do not depend on the host's pace")}
-            for key, flags in (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
-                               ("hot_path_graph", ["--graph", "--fused-adam"]), ("finetune_graph", ["--finetune", "--graph", "--fused-adam"]),
-                               ("full_graph", ["--full", "--graph", "--fused-adam"]), ("finetune_fused_adam", ["--finetune", "--fused-adam"])):
+                     "note": ("secondary figures; not the headline.  hot_path / finetune / finetune_conf / full: the loop of runner.py:157-166 / 300-308 AS "
+                              "WRITTEN -- model(...), loss, zero_grad, backward, optimizer.step, loss read back -- with no graph object in the caller: behind "
+                              "GenS.forward / ImplicitSurface.forward the step's forward and backward replay from two HIP graphs captured after two eager "
+                              "calls (gens_amd.graph.AutoGraph).  *_graph: the caller captures the WHOLE step incl. loss and optimiser itself "
+                              "(gens_amd.graph.GraphedStep): the lower bound.  *_nograph: every call eager (GENS_AUTO_GRAPH=0; rounds 1 - 4's eager "
+                              "figures: ~140 - 1 070 launches per step enqueued from Python, host-paced)")}
+            runs = (("hot_path", []), ("finetune", ["--finetune"]), ("finetune_conf", ["--finetune", "--conf-shape"]), ("full", ["--full"]),
+                    ("hot_path_graph", ["--graph"]), ("finetune_graph", ["--finetune", "--graph"]),
+                    ("finetune_conf_graph", ["--finetune", "--conf-shape", "--graph"]), ("full_graph", ["--full", "--graph"]),
+                    ("finetune_nograph", ["--finetune", "--no-auto"]), ("full_nograph", ["--full", "--no-auto"]),
+                    ("finetune_foreach_adam", ["--finetune", "--foreach-adam"]))
+            for key, flags in runs:
                 try:
-                    ms, _, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=True)
+                    ms, label, kt = measure(flags + ["--steps", "30", "--warm", "5"], quiet=True, kernels=key in ("hot_path", "finetune", "finetune_conf", "full"))
                 except Exception as e:                                 # (a secondary of the secondaries: report, do not lose the others)
                     train[key] = {"error": f"{type(e).__name__}: {e}"}
                     continue
                 from scripts.train_step_bench import _measure as _m
                 stats = dict(getattr(_m, "stats", {}))
+                auto_stats = stats.pop("auto_graph", None)
                 med = stats.get("median_ms", ms)                      # the median; the mean of an eager step carries the host's hiccups (both are reported)
-                train[key] = {"ms_per_step": round(med, 2), "mean_ms_per_step": round(ms, 2), "ms_per_step_stats": stats,
-                              "ray_samples_per_s": round(512 * 128 / med * 1e3, 1), "launches_per_step_c_abi": sum(k["launches"] for k in kt.values()),
-                              "hip_kernels": kernel_rows(kt, 8)}
+                train[key] = {"what": label, "ms_per_step": round(med, 2), "mean_ms_per_step": round(ms, 2), "ms_per_step_stats": stats,
+                              "ray_samples_per_s": round(512 * 128 / med * 1e3, 1)}
+                if auto_stats is not None:
+                    train[key]["auto_graph"] = auto_stats             # eager warm-up calls / captures / replays behind forward()
                 if kt:
+                    train[key]["launches_per_step_c_abi"] = sum(k["launches"] for k in kt.values())
+                    train[key]["hip_kernels"] = kernel_rows(kt, 8)
                     train[key]["roofline"] = kernel_roofline(kt)
-                else:                                                  # (a graph replay: the kernels are the eager key's)
-                    del train[key]["hip_kernels"], train[key]["launches_per_step_c_abi"]
                 torch.cuda.empty_cache()
             train["finetune_conf"].setdefault("workload", None)
             train["finetune_conf"]["workload"] = ("confs/gens_finetune.conf as shipped (BASELINE config[4] on one GPU): img_hw 1152 x 1600, num_views 3, "
                                                   "volume_dims 256/128/64/32/16 as parameters, 512 rays + 2048 pseudo points")
             train["ms_per_step"] = train["full"].get("ms_per_step")
-            if "error" not in train["finetune_fused_adam"]:
-                train["finetune_fused_adam"]["note"] = "the fine-tune step with torch.optim.Adam(fused=True): one pass over the 307 MB of volumes instead of ten (INTEGRATION.md)"
-            for key in ("hot_path_graph", "finetune_graph", "full_graph"):
-                if "error" not in train[key]:
-                    train[key]["note"] = ("the same step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep; torch.optim.Adam(fused=True, "
-                                          "capturable=True): one pass over the parameters): one launch per step, independent of the host's pace")
+            if "error" not in train["finetune_foreach_adam"]:
+                train["finetune_foreach_adam"]["note"] = ("the fine-tune loop with GENS_FUSED_ADAM=0: torch's multi-tensor Adam makes ~10 passes over the 307 MB of "
+                                                          "volumes where the fused update get_optim_params asks for makes one")
+            # the boundary promise in one place: the unchanged loop against the caller-captured whole step
+            ratios = {}
+            for key in ("hot_path", "finetune", "finetune_conf", "full"):
+                a, b = train.get(key, {}), train.get(key + "_graph", {})
+                if "ms_per_step" in a and "ms_per_step" in b:
+                    ratios[key] = {"unchanged_loop_over_whole_step_graph": round(a["ms_per_step"] / b["ms_per_step"], 3),
+                                   "p90_over_median": round(a["ms_per_step_stats"]["p90_ms"] / a["ms_per_step"], 3)}
+            train["unchanged_loop_vs_graph"] = ratios
         except Exception as e:                                             # never let a secondary figure take the headline down
             train = {"error": f"{type(e).__name__}: {e}"}
         # secondary figure: one whole `--mode val` item (volume build, 512^3 SDF lattice, marching cubes on the device, 480x640 render)
@@ -625,6 +638,12 @@ def main():
                    "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
                                    if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
+        "value_note": (None if world == 1 else "ray-sharded (strong scaling): ONE scene's rays split across the ranks" if by_rays else
+                       "weak scaling: `value` is %d INDEPENDENT scenes, one per GPU (what the reference's DistributedSampler does, datasets/__init__.py:33) -- "
+                       "N x one GPU by construction; the figure that answers north_star's '>= 6 x ray-throughput at 8 GPUs' is `strong_scaling` "
+                       "(one scene, its rays split across the ranks, gather inside the timed region)" % world),
+        "strong_scaling": (None if ray_sharded is None or "error" in ray_sharded else
+                           {k: ray_sharded[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_by_rank", "n_gpus", "rays_per_rank", "ray_chunk")}),
         "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "views3": views3, "train_step": train, "val_item": val_item,
         "ray_sharded": ray_sharded, "ray_sharded_projection": projection,
         "hip_kernels": table,
@@ -707,10 +726,13 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync, projection
                 "what": "ONE GPU renders rank %d's share of a %d-way ray-sharded image alone: K1 (replicated on every rank) + rays [%d, %d) of %d, "
                         "no gather; a projection of the ray-sharded step, NOT a multi-GPU measurement" % (projection[0], projection[1], r0, r1, n_rays)}
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)                                   # each rank's own time: min / max beside the figure (the slowest rank is the step)
+    per_rank = [float(x) * 1e3 for x in every]
+    dt = max(per_rank) / 1e3
     return {"scaling": "strong", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
-            "n_gpus": dist.get_world_size(), "ray_chunk": balanced_chunk(r1 - r0, args.chunk),
+            "ms_per_step_by_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)},
+            "n_gpus": dist.get_world_size(), "ray_chunk": balanced_chunk(r1 - r0, args.chunk), "rays_per_rank": r1 - r0,
             "workload": "one scene, %d rays split across the ranks, all_gather of the (P, 8) buffers in the timed region" % n_rays,
             "note": "secondary figure of the same run; `python bench.py --gpus N --shard rays` reports it as the headline"}
 

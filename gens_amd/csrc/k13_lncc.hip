@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * LN_RAYS) void lncc_bwd_k(const float* __restri
 
 static int lncc_check(const char* who, const void* ref, const void* src, int64_t n_rays, int s, int p, int c) {
     GENS_CHECK_ARG(n_rays >= 0 && s >= 1 && p >= 1 && c >= 1, GENS_EINVAL, "%s: bad shape rays=%lld S=%d P=%d C=%d", who, (long long)n_rays, s, p, c);
-    GENS_CHECK_ARG(s * c <= LN_MAX_SC, GENS_ELIMIT, "%s: S*C = %d exceeds %d (one wavefront per ray)", who, s * c, LN_MAX_SC);
+    GENS_CHECK_ARG(s <= LN_MAX_SC && c <= LN_MAX_SC && s * c <= LN_MAX_SC, GENS_ELIMIT, "%s: S = %d, C = %d: S*C exceeds %d (one wavefront per ray)", who, s, c, LN_MAX_SC);
     GENS_CHECK_ARG(n_rays == 0 || (ref && src), GENS_EINVAL, "%s: null input", who);
     return 0;
 }

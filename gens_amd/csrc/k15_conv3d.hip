@@ -586,6 +586,9 @@ static WgradMfmaPlan wgrad_mfma_plan(int cp, int cq, const int* dims_p, int stri
 static int conv_geom(const int* dims_p, int cp, int cq, int stride, ConvGeom& g, const char* what) {
     GENS_CHECK_ARG(dims_p && dims_p[0] > 0 && dims_p[1] > 0 && dims_p[2] > 0 && cp > 0 && cq > 0, GENS_EINVAL, "%s: bad shape", what);
     GENS_CHECK_ARG(stride == 1 || stride == 2, GENS_EINVAL, "%s: stride %d (1 or 2)", what, stride);
+    // (every factor bounded before the products are formed: a 2 GiB tensor has no side longer than 2^29 and no 2^16 channels)
+    GENS_CHECK_ARG(dims_p[0] < (1 << 11) && dims_p[1] < (1 << 11) && dims_p[2] < (1 << 11) && cp < (1 << 16) && cq < (1 << 16), GENS_EINVAL,
+                   "%s: a side of 2048 voxels or more, or 65536 channels or more (32-bit buffer offsets)", what);
     const int64_t pn = (int64_t)dims_p[0] * dims_p[1] * dims_p[2], qn = pn * stride * stride * stride;
     GENS_CHECK_ARG(pn * (cp + 8) * 4 < (int64_t)CONV_OOB && qn * (cq + 8) * 4 < (int64_t)CONV_OOB, GENS_EINVAL,
                    "%s: a tensor of 2 GiB or more (32-bit buffer offsets)", what);
@@ -653,8 +656,13 @@ static void wgrad_shape(int cp, int cq, int64_t pn, int& cpp, int& cqp, int& ny,
     n_ranges = (int)((chunks + chunks_per_range - 1) / chunks_per_range);
 }
 
+static bool conv_shape_in_range(int cp, int cq, const int* dims_p) {      // conv_geom's bounds, for the helpers that are asked before any launch
+    return dims_p && cp > 0 && cq > 0 && cp < (1 << 16) && cq < (1 << 16) && dims_p[0] > 0 && dims_p[1] > 0 && dims_p[2] > 0 && dims_p[0] < (1 << 11) &&
+           dims_p[1] < (1 << 11) && dims_p[2] < (1 << 11);
+}
+
 extern "C" int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p) {
-    if (!dims_p || cp <= 0 || cq <= 0) return 0;
+    if (!conv_shape_in_range(cp, cq, dims_p)) return 0;
     int cpp, cqp, ny, n_ranges, cpr;
     wgrad_shape(cp, cq, (int64_t)dims_p[0] * dims_p[1] * dims_p[2], cpp, cqp, ny, n_ranges, cpr);
     return n_ranges * 4;
@@ -662,7 +670,7 @@ extern "C" int gens_conv3d_wgrad_parts(int cp, int cq, const int* dims_p) {
 
 // the same for a given stride: the stride-1 matrix-core kernel (z a multiple of 64) cuts the volume into its own parts
 extern "C" int gens_conv3d_wgrad_parts_strided(int cp, int cq, const int* dims_p, int stride) {
-    if (!dims_p || cp <= 0 || cq <= 0) return 0;
+    if (!conv_shape_in_range(cp, cq, dims_p)) return 0;
     const WgradMfmaPlan pl = wgrad_mfma_plan(cp, cq, dims_p, stride);
     if (pl.use) return pl.x_chunks * pl.y_blocks * pl.z_segs;
     return gens_conv3d_wgrad_parts(cp, cq, dims_p);

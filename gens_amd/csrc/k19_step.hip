@@ -546,6 +546,7 @@ static int fill_tv_levels(const char* who, TvLevels* L, const float* const* vols
 }
 
 extern "C" int gens_tv_levels_blocks(const int* dims, int n_levels) {
+    if (!dims) return 0;
     int b = 0;
     for (int l = 0; l < n_levels && l < GENS_MAX_LEVELS; ++l) b += (int)gens_blocks((int64_t)dims[3 * l] * dims[3 * l + 1] * dims[3 * l + 2] / 4, TVL_BLOCK);
     return b;

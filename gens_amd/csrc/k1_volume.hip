@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void unpack_nhwc_k(const float* __restrict__ s
 
 extern "C" int gens_pack_nchw(const float* src, float* dst, int n, int c, int h, int w, void* stream) {
     GENS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, GENS_EINVAL, "gens_pack_nchw: bad argument");
+    GENS_CHECK_ARG(n < (1 << 15) && c < (1 << 15) && h < (1 << 15) && w < (1 << 15), GENS_EINVAL, "gens_pack_nchw: a dimension of 32768 or more");
     int q4 = (c + 3) / 4;
     int64_t total = (int64_t)n * h * w * q4;
     pack_nchw_k<<<gens_blocks(total, 256), 256, 0, (hipStream_t)stream>>>(src, (float4*)dst, c, (int64_t)h * w, q4, total);
@@ -54,6 +55,7 @@ extern "C" int gens_pack_nchw(const float* src, float* dst, int n, int c, int h,
 
 extern "C" int gens_unpack_nhwc(const float* src, float* dst, int n, int c, int h, int w, void* stream) {
     GENS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, GENS_EINVAL, "gens_unpack_nhwc: bad argument");
+    GENS_CHECK_ARG(n < (1 << 15) && c < (1 << 15) && h < (1 << 15) && w < (1 << 15), GENS_EINVAL, "gens_unpack_nhwc: a dimension of 32768 or more");
     int64_t total = (int64_t)n * c * h * w;
     unpack_nhwc_k<<<gens_blocks(total, 256), 256, 0, (hipStream_t)stream>>>(src, dst, c, (int64_t)h * w, 4 * ((c + 3) / 4), total);
     return gens_launch_status("gens_unpack_nhwc");

@@ -88,12 +88,23 @@ class GenS(nn.Module):
 
     # -- optimiser / checkpoint plumbing (gens.py:32-61) --------------------------------------------------------
     def get_optim_params(self, lr_confs):
+        """gens.py:32-45: the parameter groups runner.py:96-97 hands to torch.optim.Adam.  On the device every group also carries `fused=True`
+        (a per-group option torch's Adam honours in step()): the same update rule in ONE launch per group instead of the multi-tensor form's ~10
+        passes over the parameters -- the fine-tune volumes are 307 MB, 1.3 ms per step.  GENS_FUSED_ADAM=0: the reference's groups as they are."""
+        import os
         groups = [{"params": list(self.implicit_surface.parameters()), "lr": lr_confs["mlp_lr"]}]
         if not self.has_vol:
             groups.append({"params": list(self.feature_network.parameters()) + list(self.reg_network.parameters()), "lr": lr_confs["feat_lr"]})
         else:
             for vol, lr in zip(self.volumes, lr_confs["vol_lr"]):
                 groups.append({"params": vol, "lr": lr})
+        if os.environ.get("GENS_FUSED_ADAM", "1") not in ("0", "off", "false", "no"):
+            def on_device(ps):
+                ps = [ps] if torch.is_tensor(ps) else ps
+                return all(p.is_cuda and p.is_floating_point() for p in ps)
+            if all(on_device(g["params"]) for g in groups):
+                for g in groups:
+                    g["fused"] = True
         return groups
 
     def load_params_vol(self, path, device):
@@ -122,15 +133,6 @@ class GenS(nn.Module):
         self._mode_version = getattr(self, "_mode_version", 0) + 1
 
     # -- forward (gens.py:124-157) ------------------------------------------------------------------------------
-    def get_optim_params_fused(self, lr_confs):
-        """get_optim_params with `fused=True` in every group: torch.optim.Adam(groups) -- built exactly as runner.py:96-97 builds it -- then
-        updates all parameters of a group in ONE launch instead of ~10 passes of the multi-tensor form (the fine-tune volumes are 307 MB:
-        1.3 ms per step).  Same update rule; an opt-in because the rounding order inside the update differs from the multi-tensor form."""
-        groups = self.get_optim_params(lr_confs)
-        for g in groups:
-            g["fused"] = True
-        return groups
-
     def _reload_match(self, step):
         """gens.py:131-135: every fifth epoch's first step copies the feature network into its frozen matching twin."""
         if step is not None and step % 5 == 0:

@@ -1,7 +1,19 @@
 #!/usr/bin/env python3
-"""Timing of one training step of the hot path (BASELINE config 3 shape): 5 views 480x640, volume_dims 256/128/64,
-512 rays + 2048 pseudo points, forward through ImplicitSurface (all 18 keys) + a reference-like loss + backward into
-the SDF/colour MLPs, the volumes and the feature pyramid.  CNNs are out of scope: features / volumes are leaf tensors."""
+"""Timing of one training step of the hot path (BASELINE config 3 / 5 shape): 5 views 480x640, volume_dims 256/128/64, 512 rays + 2048 pseudo
+points, the reference's Loss, backward into the SDF / colour MLPs, the volumes and the feature pyramid, Adam.
+
+The loop is runner.py's (157-166 / 300-308): `outputs = model(...)`, the loss, `optimizer.zero_grad()`, `loss.backward()`, `optimizer.step()`, the
+loss read back -- nothing in it knows about graphs.  What runs behind `model(...)`:
+    (default)    the captured step of gens_amd.graph.AutoGraph: after two eager calls, forward and backward are one HIP graph replay each
+    --no-auto    every call eager (GENS_AUTO_GRAPH=0: rounds 1 - 4's "eager" figures)
+    --graph      the WHOLE step -- forward, loss, backward, optimiser -- captured by the caller (gens_amd.graph.GraphedStep): the lower bound
+Workloads:
+    (default)    "hot path": K1 + ImplicitSurface.forward("train") on leaf feature maps / regularised volumes (the CNNs' outputs stand-ins)
+    --finetune   GenS(has_vol).forward("train") as runner.py:300 calls it: the volumes are the parameters (config 5); --conf-shape: 1152 x 1600,
+                 three views, five levels (confs/gens_finetune.conf as shipped)
+    --full       GenS.forward("train") with the 2-D CNN (twice), K1 and the 3-D U-Net inside (config 3 as runner.py runs it)
+The optimiser of the GenS workloads is torch.optim.Adam(model.get_optim_params(lrs)) exactly as runner.py:96-97 builds it (get_optim_params asks for
+the fused update in its groups; GENS_FUSED_ADAM=0 / --foreach-adam: the multi-tensor default)."""
 import os
 import sys
 import time
@@ -56,76 +68,87 @@ def _measure(quiet, kernels=False):
     train_loss, ft_loss = Loss(gens_loss_conf()).to(dev), Loss(gens_loss_conf(finetune=True)).to(dev)
     if "--freeze-color" in sys.argv:             # probe: what the colour network's PyTorch-layer training costs (fine-tune: the feature maps are frozen too)
         surf.color_network.requires_grad_(False)
-    adam = {"fused": True} if "--fused-adam" in sys.argv else {}      # (runner.py:97 builds the default, multi-tensor Adam: measured as such; the flag: one fused kernel)
-    graph = "--graph" in sys.argv               # the step captured once into a HIP graph and replayed (gens_amd.graph.GraphedStep): one launch per step
-    if graph:
-        adam["capturable"] = True
-    opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4, **adam)
-
+    graph = "--graph" in sys.argv               # the WHOLE step captured by the caller into one HIP graph (gens_amd.graph.GraphedStep): the lower bound
+    no_auto = "--no-auto" in sys.argv           # every model call eager: what rounds 1 - 4 called the eager step
+    foreach = "--foreach-adam" in sys.argv      # torch's multi-tensor Adam instead of the fused update get_optim_params asks for
+    adam = {"capturable": True} if graph else {}
     finetune = "--finetune" in sys.argv          # BASELINE config 5 shape: volumes are the parameters, no volume build in the step
+    full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen matching copy
+    #                                              too) and the 3-D U-Net inside the step
+    saved_env = os.environ.get("GENS_FUSED_ADAM")
+    if foreach:
+        os.environ["GENS_FUSED_ADAM"] = "0"
+    model = None
     if finetune:
+        # GenS with its per-scene parameters in place (what runner.py:87-93 builds with init_volumes / load_params_vol), forward("train", ...) with
+        # view_ids (runner.py:296-300)
+        from gens_amd.models import gens
+        torch.manual_seed(0)
+        model = gens.GenS(gens_model_conf(volume_dims=tuple(dims), has_vol=True)).to(dev).train()
         with torch.no_grad():
             _, ft_masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], intrs, c2ws, dims)
-        ft_feats = [f.detach() for f in feats]
-        ft_opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad] + vols, lr=5e-4, **adam)
+        model.volumes = torch.nn.ParameterList([torch.nn.Parameter(v.detach(), requires_grad=True) for v in vols])
+        model.mask_volmes = torch.nn.ParameterList([torch.nn.Parameter(m, requires_grad=False) for m in ft_masks])
+        model.features = torch.nn.ParameterList([torch.nn.Parameter(f.detach(), requires_grad=False) for f in feats])
+        model._mode_version = getattr(model, "_mode_version", 0) + 1
+        surf = model.implicit_surface
+        if "--freeze-color" in sys.argv:
+            surf.color_network.requires_grad_(False)
+        ipts["view_ids"] = list(range(nv))
+        loss_fn = ft_loss
+        opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [5e-4] * len(dims)}), **adam)        # runner.py:96-97
 
-    def ft_body():
-        out = surf("finetune", ipts, vols, ft_masks, ft_feats, ft_feats, 0.5, 1.0)
-        loss = ft_loss(out, targets)["loss"]                                        # runner.py:304-305 with confs/gens_finetune.conf's weights
-        loss.backward()
-        ft_opt.step()
-        return loss.detach()
+        def forward():
+            return model("train", ipts, cos_anneal_ratio=0.5), None
+    elif full:
+        from gens_amd.models import gens
+        torch.manual_seed(0)
+        model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
+        surf = model.implicit_surface
+        loss_fn = train_loss
+        opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), **adam)
 
-    def hot_body():
-        cost, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)        # K1 with autograd to the features, once per step (gens.py:139)
-        out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
-        loss = train_loss(out, targets)["loss"] + 1e-6 * sum(c.mean() for c in cost)  # runner.py:161-162; the cost volumes stand in for the U-Net's use of them
+        def forward():
+            return model("train", ipts, cos_anneal_ratio=0.5, step=1), None
+    else:
+        loss_fn = train_loss
+        opt = torch.optim.Adam([p for p in surf.parameters() if p.requires_grad], lr=5e-4, **({"fused": True} if not foreach else {}), **adam)
+
+        def forward():
+            cost, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)        # K1 with autograd to the features, once per step (gens.py:139)
+            out = surf("train", ipts, vols, masks, feats, [f.detach() for f in feats], 0.5, 1.0)
+            return out, 1e-6 * sum(c.mean() for c in cost)                               # the cost volumes stand in for the U-Net's use of them
+    if saved_env is None:
+        os.environ.pop("GENS_FUSED_ADAM", None)
+    else:
+        os.environ["GENS_FUSED_ADAM"] = saved_env
+    if no_auto or graph:
+        (model if model is not None else surf).auto_graph = False
+
+    def body():
+        out, extra = forward()
+        loss = loss_fn(out, targets)["loss"]                                             # runner.py:161-162 / 304-305
+        if extra is not None:
+            loss = loss + extra
         loss.backward()
         opt.step()
         return loss.detach()
 
     def step():
-        (ft_opt if finetune else opt).zero_grad(set_to_none=True)
-        if not finetune:
+        opt.zero_grad(set_to_none=True)
+        if model is None:
             for t in feats + vols:               # leaves that stand in for the CNNs' outputs: a fresh gradient per step, as for a non-leaf
                 t.grad = None
-        return ft_body() if finetune else hot_body()
+        return body()
 
     if graph:
         from gens_amd.graph import GraphedStep
-        for f in feats:                          # (leaves outside the optimiser: their gradients are assigned by every replay too)
-            f.grad = None
-        for v in vols:
-            v.grad = None
-        graphed = GraphedStep(ft_body if finetune else hot_body, [surf], ft_opt if finetune else opt)
+        for t in feats + vols:                   # (leaves outside the optimiser: their gradients are assigned by every replay too)
+            t.grad = None
+        graphed = GraphedStep(body, [surf], opt, modules=[model] if full else ())
 
         def step():  # noqa: F811
             return graphed()
-
-    full = "--full" in sys.argv                  # BASELINE config 3 as runner.py runs it: GenS.forward with the 2-D CNN (twice: the frozen
-    if full:                                     # matching copy too) and the 3-D U-Net inside the step
-        from gens_amd.models import gens
-        torch.manual_seed(0)
-        model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
-        full_opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), **adam)
-
-        def full_body():
-            out = model("train", ipts, cos_anneal_ratio=0.5, step=1)
-            loss = train_loss(out, targets)["loss"]
-            loss.backward()
-            full_opt.step()
-            return loss.detach()
-
-        def step():  # noqa: F811
-            full_opt.zero_grad(set_to_none=True)
-            return full_body()
-
-        if graph:                                # the whole GenS.forward step -- MIOpen's convolutions included -- captured once and replayed
-            from gens_amd.graph import GraphedStep
-            graphed = GraphedStep(full_body, [model.implicit_surface], full_opt, modules=[model])
-
-            def step():  # noqa: F811
-                return graphed()
 
     for _ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
         float(step())
@@ -146,7 +169,7 @@ def _measure(quiet, kernels=False):
         loss = step()
         host += time.perf_counter() - t1                                 # the host's share: every launch of the step enqueued
         float(loss)                                                      # (runner.py reads the loss every step: one synchronisation per step)
-        (model.implicit_surface if full else surf).check_deferred()                                         # the reference's mid-step errors, raised at the step they belong to (the read-back synchronised)
+        surf.check_deferred()                                            # the reference's mid-step errors (already raised inside backward for a captured step)
         per_step.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
@@ -156,7 +179,9 @@ def _measure(quiet, kernels=False):
     gc.unfreeze()
     if graph:
         graphed.check()
-    label = ("full (CNNs + hot path)" if full else "fine-tune" if finetune else "train") + (", HIP graph replay" if graph else "")
+    label = ("full (CNNs + hot path)" if full else "fine-tune" if finetune else "train") + (", whole step as one HIP graph" if graph else ", every call eager" if no_auto else ", captured behind forward()")
+    auto = getattr(model if model is not None else surf, "_auto", None)
+    _measure.stats["auto_graph"] = dict(auto.stats) if auto is not None else None
     if not quiet:
         print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step)")
     if os.environ.get("GENS_TRAIN_OPS"):         # which torch operators make up the step's launches (torch.profiler over one step)
@@ -173,9 +198,15 @@ def _measure(quiet, kernels=False):
         from gens_amd import lib as L
         if graph:                                # (a replay launches nothing through the C ABI's host side)
             return dt * 1e3, label, {}
-        L.profile_begin()
-        step()
-        return dt * 1e3, label, L.profile_end()
+        owner = model if model is not None else surf
+        was = getattr(owner, "auto_graph", True)
+        owner.auto_graph = False                 # the kernel table: one extra step with every launch made from the host (the same kernels)
+        try:
+            L.profile_begin()
+            step()
+            return dt * 1e3, label, L.profile_end()
+        finally:
+            owner.auto_graph = was
     return dt * 1e3, label
 
 

@@ -158,3 +158,69 @@ def test_single_process_shard_stand_in_collects_in_rank_order():
         sh = D.Shard.single(r, 3, sink)
         got = sh.gather_chunks(torch.stack([torch.full((2,), float(c)) for c in sh.chunks(7)]), 7)
     assert torch.equal(got, torch.arange(7.0)[:, None].expand(7, 2))
+
+
+def _worker_eight(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shards = D.Shard()
+        n_rays = 24 * 32 + 5                                                  # not a multiple of the world size: shard lengths differ by one
+        s, e = shards.rays(n_rays)
+        # every rank draws the jitter of EVERY ray from the same generator state and renders its own slice (validate's contract); the "render"
+        # here is a function of (ray index, jitter) only, so the gathered image must not depend on the partition
+        torch.manual_seed(77)
+        jitter = torch.rand(n_rays, 1)
+        local = torch.cat([torch.arange(s, e, dtype=torch.float32)[:, None], jitter[s:e], (jitter[s:e] * 3.0).sin()], 1)
+        image = shards.gather_rows(local, n_rays)
+        own = shards.chunks(19)                                               # 19 lattice chunks over 8 ranks: three ranks own three, five own two
+        lattice = shards.gather_chunks(torch.stack([torch.full((4,), float(c)) for c in own]), 19)
+        flag = shards.any(rank == 5)                                          # one rank's overflow flag reaches everybody
+        none = shards.any(False)
+        p = torch.nn.Parameter(torch.zeros(1, 4, 5, 5, 5))                    # 500 floats: the flat buffer is padded to a multiple of 8
+        flat = D.FlatGradients([p])
+        (p * float(rank + 1)).sum().backward()
+        flat.sync()
+        q.put((rank, (s, e), image.numpy().copy(), lattice.numpy().copy(), flag, none, float(p.grad.mean()), flat.padded % world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_gather_the_same_image_lattice_and_gradients_gloo():
+    """World size EIGHT (the node BASELINE names) on gloo: contiguous ray ranges that differ by at most one ray, the gathered (P, C) buffer
+    identical on every rank and equal to the unsharded one, lattice chunks `index mod 8`, the one-flag all-reduce, the flat gradient exchange."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_eight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=400) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_rays = 24 * 32 + 5
+    torch.manual_seed(77)
+    jitter = torch.rand(n_rays, 1)
+    whole = torch.cat([torch.arange(n_rays, dtype=torch.float32)[:, None], jitter, (jitter * 3.0).sin()], 1)
+    spans = [g[1] for g in got]
+    assert spans[0][0] == 0 and spans[-1][1] == n_rays and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(e - s for s, e in spans) - min(e - s for s, e in spans) == 1
+    for rank, _, image, lattice, flag, none, gmean, pad in got:
+        assert torch.equal(torch.from_numpy(image), whole), rank              # bit for bit, on every rank
+        assert torch.equal(torch.from_numpy(lattice), torch.arange(19.0)[:, None].expand(19, 4)), rank
+        assert flag is True and none is False
+        assert abs(gmean - 4.5) < 1e-6 and pad == 0                           # mean of 1 .. 8
+
+
+def test_bench_ray_shards_of_the_headline_image_are_balanced_at_eight_ranks():
+    """bench.py --gpus 8 --shard rays: every rank renders 38 400 of the 307 200 rays in two chunks of 19 200 (not 32 768 + 5 632)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    for rank in range(8):
+        s, e = D.ray_shard(480 * 640, rank, 8)
+        assert e - s == 38400
+        chunk = bench.balanced_chunk(e - s, 32768)
+        assert [min(chunk, e - s - o) for o in range(0, e - s, chunk)] == [19200, 19200]

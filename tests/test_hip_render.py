@@ -264,7 +264,7 @@ def test_render_config0_coarsest_volume_only(golden):
         close(out[k], g["out." + k], atol=1e-4, rtol=2e-3, what=k)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ray_and_lattice_shards_reproduce_the_single_gpu_result_bit_for_bit(golden, world):
     """BASELINE config 4 on the HIP kernels: validate() with the rays split into `world` contiguous ranges and the lattice into chunks
     `index mod world` -- each shard rendered by the device kernels, gathered by the collective-free stand-in of the RCCL all_gather

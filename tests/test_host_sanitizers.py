@@ -1,0 +1,136 @@
+"""The HOST side of libgens_hip.so under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only; GPU ASan is not available on this pool).
+
+`make -C gens_amd/csrc san` compiles every entry point's host code -- argument validation, level / map tables, launch geometry, scratch-size and
+plan helpers -- with -fsanitize=address,undefined (undefined behaviour fatal); the device code is compiled as usual and never runs here.  A child
+interpreter (the sanitizer runtime must be loaded first: LD_PRELOAD) then calls EVERY function the header declares, several times, with argument
+sets built from the ctypes signatures: null pointers, zero and huge sizes, level counts 0 .. 9, and plausible values with made-up device addresses
+(the host never dereferences a device pointer; host tables are real arrays).  Without a GPU a call that gets as far as a launch returns a HIP
+error -- every return code is fine, a sanitizer report or a crash is not."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gens_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+DRIVER = r'''
+import ctypes as C, itertools, os, sys
+sys.path.insert(0, %(root)r)
+from gens_amd import lib as L
+lib = C.CDLL(%(so)r)
+lib.gens_last_error.restype = C.c_char_p
+_p, _pp, _ip, _fp = C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float)
+keep = []
+def fake(k):                       # a made-up, 256-byte aligned "device" address: never dereferenced by host code
+    return C.c_void_p(0x7e0000000000 + 4096 * k)
+def table(n=32, null=False):
+    arr = (C.c_void_p * n)(*[None if null else fake(100 + i).value for i in range(n)])
+    keep.append(arr); return C.cast(arr, _pp)
+def ints(v, n=64):
+    arr = (C.c_int * n)(*([v] * n)); keep.append(arr); return arr
+def floats(v, n=64):
+    arr = (C.c_float * n)(*([v] * n)); keep.append(arr); return arr
+def struct(cls, null):
+    s = cls()
+    for name, typ in cls._fields_:
+        if typ is C.c_void_p: setattr(s, name, None if null else fake(300).value)
+        elif typ in (C.c_int, C.c_int64): setattr(s, name, 0 if null else 8)
+        elif typ is C.c_float: setattr(s, name, 1.0)
+    keep.append(s); return C.byref(s)
+def value(typ, mode, k):
+    small, big = mode["small"], mode["big"]
+    if typ is C.c_void_p: return None if mode["null"] else fake(k)
+    if typ is _pp: return None if mode["null_tables"] else table(null=mode["null"])
+    if typ is _ip: return None if mode["null_tables"] else ints(small)
+    if typ is _fp: return None if mode["null_tables"] else floats(1.0)
+    if typ is C.c_int: return small
+    if typ is C.c_int64: return big
+    if typ is C.c_float: return mode["f"]
+    if typ is C.c_double: return float(mode["f"])
+    if isinstance(typ, type) and issubclass(typ, C._Pointer): return struct(typ._type_, mode["null"])
+    raise TypeError(typ)
+modes = []
+for small in (0, 1, 2, 3, 4, 5, 8, 9, 16, 64, -1, 1 << 20):
+    for big in (0, 1, 1000, (1 << 31) + 5):
+        modes.append(dict(small=small, big=big, null=False, null_tables=False, f=1.0))
+modes += [dict(small=3, big=64, null=True, null_tables=False, f=1.0), dict(small=3, big=64, null=False, null_tables=True, f=0.0),
+          dict(small=5, big=64, null=True, null_tables=True, f=float("nan"))]
+calls = 0
+names = sorted(L.SIGNATURES)
+for name in names:
+    fn = getattr(lib, name)
+    fn.restype = C.c_int
+    sig = list(L.SIGNATURES[name])
+    if name in ("gens_loss_fwd", "gens_loss_bwd"):          # (their first argument is a HOST struct that gens_amd.lib passes as a plain pointer)
+        sig[0] = C.POINTER(L.LossArgs)
+    fn.argtypes = sig
+    for mode in modes:
+        args = [value(t, mode, k) for k, t in enumerate(sig)]
+        rc = fn(*args)
+        calls += 1
+# the size / plan helpers (plain integers in, integers out)
+for name, restype, argsets in (
+        ("gens_abi_version", C.c_int, [()]),
+        ("gens_tv_blocks", C.c_int, [(C.c_int64(n),) for n in (0, 1, 1 << 24, 1 << 40)]),
+        ("gens_sdf_train_stash_bytes", C.c_int64, [(C.c_int64(n), C.c_int(k)) for n in (0, 1, 70000, 1 << 33) for k in (0, 1)]),
+        ("gens_sdf_grad_stash_bytes", C.c_int64, [()]),
+        ("gens_sdf_grad_f16_stash_bytes", C.c_int64, [()]),
+        ("gens_blend_train_rows", C.c_int64, [(C.c_int64(n), C.c_int(v)) for n in (0, 1, 65536, 1 << 33) for v in (0, 1, 2, 5, 16, 17)]),
+        ("gens_blend_train_acc_parts", C.c_int, [(C.c_int64(n), C.c_int(v)) for n in (0, 1, 65536, 1 << 33) for v in (0, 1, 2, 5, 16, 17)]),
+        ("gens_blend_train_acc_floats", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_scene_cams_floats", C.c_int64, [(C.c_int(v),) for v in (0, 1, 5, 16, 17)]),
+        ("gens_batchnorm2d_scratch_doubles", C.c_int64, [(C.c_int(a), C.c_int(b), C.c_int(c)) for a in (0, 1, 5) for b in (0, 3, 1152) for c in (0, 1, 300, 76800)]),
+        ("gens_compact_points_scratch", C.c_int64, [(C.c_int64(n),) for n in (0, 1, 70000, 1 << 33)]),
+        ("gens_sdf_value_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_sdf_grad_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_sdf_grad_f16_pieces", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_sdf_value_f16_units", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_blend_views4_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
+        ("gens_blend_views_t_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)])):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    for a in argsets:
+        fn(*a)
+        calls += 1
+hw = ints(48); dims = ints(16)
+lib.gens_volume_build_bwd_levels_scratch_bytes.restype = C.c_int64
+for nl in range(0, 10):
+    for nv in (0, 1, 5, 16, 17):
+        lib.gens_volume_build_bwd_levels_scratch_bytes(hw, dims, C.c_int(nl), C.c_int(nv)); calls += 1
+lib.gens_gemm_tn_batch_workspace.restype = C.c_int64
+for n in (0, 1, 11, 12, 13):
+    lib.gens_gemm_tn_batch_workspace(C.c_int(n), ints(128), ints(188), C.c_int64(250000)); calls += 1
+print("SANITIZED_CALLS", calls, len(names), lib.gens_last_error() is not None)
+'''
+
+
+def _asan_runtime():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = out.stdout.strip()
+    return path if out.returncode == 0 and os.path.isabs(path) and os.path.exists(path) else None
+
+
+@pytest.mark.timeout(900)
+def test_every_entry_point_survives_hostile_arguments_under_asan_and_ubsan():
+    if not os.path.exists(HIPCC) or shutil.which("make") is None:
+        pytest.skip("no hipcc: the sanitizer build cannot be made here")
+    runtime = _asan_runtime()
+    if runtime is None:
+        pytest.skip("clang's AddressSanitizer runtime is not installed")
+    build = subprocess.run(["make", "-C", CSRC, "-j8", "san", "ARCH=gfx950"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-4000:]
+    so = os.path.join(CSRC, "san", "libgens_hip_san.so")
+    env = dict(os.environ, LD_PRELOAD=runtime, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               PYTHONDONTWRITEBYTECODE="1")
+    run = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "so": so}], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    report = run.stdout[-3000:] + run.stderr[-6000:]
+    assert "ERROR: AddressSanitizer" not in report and "runtime error:" not in report, report
+    assert run.returncode == 0, report
+    line = [ln for ln in run.stdout.splitlines() if ln.startswith("SANITIZED_CALLS")]
+    assert line, report
+    calls, names = int(line[0].split()[1]), int(line[0].split()[2])
+    assert names >= 100 and calls >= 50 * names                      # every signature of gens_amd.lib, ~50 argument sets each
