@@ -539,6 +539,10 @@ __device__ __forceinline__ void blend_train_tile(const __attribute__((address_sp
                 dot += SC[(base + v) * BT_S_SC + 6] * (g0 * C[(base + v) * 3] + g1 * C[(base + v) * 3 + 1] + g2 * C[(base + v) * 3 + 2]);
             const float p = SC[row * BT_S_SC + 6];
             sb = p * ((g0 * C[row * 3] + g1 * C[row * 3 + 1] + g2 * C[row * 3 + 2]) - dot);
+            // masked_fill(mask == 0, -1e9) (blending_network.py:115) passes no gradient to the score it replaced.  With a visible view beside it p is
+            // 0 there anyway; a point NO source view sees has p = 1 / S on every (masked) view -- a mid-point inside the mask volumes but outside
+            // both source images, an image-corner ray of a three-view set -- and its softmax gradient must not reach the network
+            if (SC[row * BT_S_SC] == 0.0f) sb = 0.0f;
             gx0 = g0 * p; gx1 = g1 * p; gx2 = g2 * p;
         }
         A1[row * BT_S_A] = sb;                                   // cotangent of the score = L of rgb_fc.4

@@ -247,6 +247,10 @@ def _judge_gradients(rows, tol=2e-3):
             print("%-44s %10.1e %12.1e %12.1e %s" % (name, e_do, e_d64, e_o, "" if ok else "  <-- FAIL"))
         if not ok:
             bad[name] = (e_do, e_d64, e_o)
+            worst = torch.topk((dev_g - o64).abs().reshape(-1), min(5, dev_g.numel())).indices      # where: one entry (a decision that fell the other way) or everywhere (round-off)?
+            print("    worst entries of %s (flat index: device / float32 oracle / float64 oracle): %s; entries beyond tol * scale: %d of %d" % (
+                name, [(int(i), float(dev_g.reshape(-1)[i]), float(o32.reshape(-1)[i]), float(o64.reshape(-1)[i])) for i in worst],
+                int(((dev_g - o64).abs() > tol * scale).sum()), dev_g.numel()))
     return bad
 
 
@@ -438,31 +442,51 @@ def test_training_step_config2_shape_five_views_480x640_volumes_256_128_64():
 
     # ---- leg 3: a 96-ray sub-batch of that step against the oracle (samples pinned to the device's)
     nb = 96
-    sub = slice(0, nb)
-    t_rand = torch.rand(nb, 1, generator=g)
+    t_rand_all = torch.rand(nb, 1, generator=g)
     pts_rand = torch.rand(1024, 3, generator=g) * 2 - 1
     masks_c = [m.cpu() for m in masks]
     ok_c = K.point_valid(masks_c, pseudo).reshape(-1)
     pseudo_ok = pseudo[ok_c]
     assert 0 < pseudo_ok.shape[0] < 2048 or pseudo_ok.shape[0] == 2048
-    with torch.no_grad():
-        scene = Scene([v.detach() for v in vols], masks, imgs, [f.detach() for f in feats], [f.detach() for f in feats], intrs, c2ws)
-        z0 = ops.coarse_z(near, far, surf._coarse_steps(dev), t_rand.to(dev), nb)
-        z = surf._sample_rays(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z0, scene)
-    for p in surf.parameters():
-        p.grad = None
-    vols_d = [v.detach().clone().requires_grad_(True) for v in vols]
-    feats_d = [f.detach().clone().requires_grad_(True) for f in feats]
-    cost, masks_d = ops.volume_build(feats_d[:3], intrs, c2ws, dims)
-    flags = torch.empty(2048, device=dev, dtype=torch.uint8)
-    ops.lookup_mask(pseudo.to(dev), ops.VolumeSet.masks(masks_d), out=flags)              # as ImplicitSurface.forward hands the pseudo points over
-    assert torch.equal(flags.cpu().bool(), ok_c)
-    out = surf.render_core(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z, 2.0 / 64, vols_d, masks_d, feats_d, [f.detach() for f in feats_d],
-                           imgs, intrs, c2ws, 0.5, 1.0, pts_random=pts_rand.to(dev), extra_pts=pseudo.to(dev), extra_valid=flags)
-    out["pseudo_sdf"] = out.pop("_extra_sdf_dense")
-    sub_targets = {k: v[sub] for k, v in targets.items()}
-    terms = loss_fn(out, sub_targets)
-    (terms["loss"] + sum((a * b).sum() for a, b in zip(cost, cots))).backward()
+    scene = Scene([v.detach() for v in vols], masks, imgs, [f.detach() for f in feats], [f.detach() for f in feats], intrs, c2ws)
+
+    def device_step(sub):
+        n_sub = sub.shape[0]
+        with torch.no_grad():
+            z0 = ops.coarse_z(near, far, surf._coarse_steps(dev), t_rand_all[sub].to(dev), n_sub)
+            z = surf._sample_rays(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z0, scene)
+        for p in surf.parameters():
+            p.grad = None
+        vols_d = [v.detach().clone().requires_grad_(True) for v in vols]
+        feats_d = [f.detach().clone().requires_grad_(True) for f in feats]
+        cost, masks_d = ops.volume_build(feats_d[:3], intrs, c2ws, dims)
+        flags = torch.empty(2048, device=dev, dtype=torch.uint8)
+        ops.lookup_mask(pseudo.to(dev), ops.VolumeSet.masks(masks_d), out=flags)          # as ImplicitSurface.forward hands the pseudo points over
+        assert torch.equal(flags.cpu().bool(), ok_c)
+        out = surf.render_core(ro[sub].to(dev).contiguous(), rd[sub].to(dev).contiguous(), z, 2.0 / 64, vols_d, masks_d, feats_d,
+                               [f.detach() for f in feats_d], imgs, intrs, c2ws, 0.5, 1.0, pts_random=pts_rand.to(dev), extra_pts=pseudo.to(dev),
+                               extra_valid=flags)
+        out["pseudo_sdf"] = out.pop("_extra_sdf_dense")
+        terms = loss_fn(out, {k: v[sub.to(dev)] for k, v in targets.items()})
+        (terms["loss"] + sum((a * b).sum() for a, b in zip(cost, cots))).backward()
+        return z, vols_d, feats_d, out, terms
+
+    # The reference's sparse term is exp(-100 |sdf|) (loss.py:30): |.| has a kink at the surface, and the hierarchical sampler puts samples ON it --
+    # a sample whose SDF is within float32 round-off of zero gets the opposite sign(sdf) on the device and in the oracle (both right), i.e. a
+    # gradient contribution of 2 x 100 x weight / N with either sign (found at 96 rays: one such sample moved one level-2 voxel by 4e-6 of a 2e-3
+    # tolerance).  Rays that carry such a sample are left out of the comparison -- decided on the device's own values, before the oracle runs.
+    sub = torch.arange(nb)
+    z, vols_d, feats_d, out, terms = device_step(sub)
+    ray_sdf = out["sparse_sdf"].detach()[1024:, 0].reshape(nb, -1)
+    on_kink = (ray_sdf.abs() < 1e-5).any(dim=1).cpu()
+    if bool(on_kink.any()):
+        print("rays with a sample within 1e-5 of the surface (left out):", torch.nonzero(on_kink)[:, 0].tolist())
+        assert int(on_kink.sum()) <= nb // 8
+        sub = sub[~on_kink]
+        z, vols_d, feats_d, out, terms = device_step(sub)
+    nb = sub.shape[0]
+    t_rand = t_rand_all[sub]
+    sub_targets = {k: v[sub.to(dev)] for k, v in targets.items()}
 
     conf = gens_loss_conf()
     names = ("color_weight", "igr_weight", "sparse_weight", "mfc_weight", "smooth_weight", "tv_weight", "pseudo_sdf_weight", "pseudo_depth_weight",
