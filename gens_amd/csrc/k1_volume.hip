@@ -259,6 +259,10 @@ __device__ __forceinline__ void row_constraint(float g0, float g1, float scale, 
     if (g0 < g1) lo = fmaxf(lo, t); else hi = fminf(hi, t);
 }
 
+typedef const __attribute__((address_space(4))) float* k1_cfloat_p;
+typedef const __attribute__((address_space(4))) uint32_t* k1_cuint_p;
+__device__ __forceinline__ k1_cfloat_p k1_const(const float* p) { return (k1_cfloat_p)(uintptr_t)p; }
+
 __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
                                                    float* __restrict__ vol, float* __restrict__ mask, uint8_t* __restrict__ count) {
@@ -359,14 +363,18 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     for (int v = 0; v < nv; ++v) {
         const int2 span = row_span[my_row][v];
         if (kz < span.x || kz > span.y) continue;                                 // outside the view's frustum for sure
-        const float* m = w2c + 16 * v;
-        const float* k = intr + 16 * v;
+        // The camera matrices are read through the CONSTANT address space: wave-uniform addresses of memory nothing in this launch writes, i.e.
+        // scalar loads whatever the compiler can prove about aliasing.  As plain global pointers they were scalar loads in the one-level kernel
+        // (__restrict__ kernel arguments) but per-lane global_load_dword in the all-levels kernel (pointers out of the level table: every store
+        // might alias them) -- a vector-memory round trip per view and wave, 60 us of that launch's 280 (profiles/r05_k1_levels_ab.txt).
+        const k1_cfloat_p m = (k1_cfloat_p)(uintptr_t)(w2c + 16 * v);
+        const k1_cfloat_p k = (k1_cfloat_p)(uintptr_t)(intr + 16 * v);
         const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
         const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
         const float cz = m[8] * x + m[9] * y + m[10] * z + m[11];
         // integer tests on the scalar unit (a float compare would be a VALU instruction + vcc branch per matrix entry)
-        const uint32_t* mb = (const uint32_t*)m;
-        const uint32_t* kb = (const uint32_t*)k;
+        const k1_cuint_p mb = (k1_cuint_p)m;
+        const k1_cuint_p kb = (k1_cuint_p)k;
         const uint32_t must_be_zero = (mb[12] | mb[13] | mb[14] | kb[1] | kb[3] | kb[4] | kb[7] | kb[8] | kb[9] | kb[11]) << 1;   // +-0
         const uint32_t must_be_one = (mb[15] ^ 0x3f800000u) | (kb[10] ^ 0x3f800000u);
         float u, vv, dd;
@@ -798,7 +806,7 @@ struct LeanProj {
     bool vis;
 };
 // volume_build_chunk's projection (same operations in the same order: the visibility and the taps of the backward pass are the forward's)
-__device__ __forceinline__ LeanProj project_lean(const float* __restrict__ m, const float* __restrict__ k, bool pinhole, const LevelConst& lc,
+__device__ __forceinline__ LeanProj project_lean(k1_cfloat_p m, k1_cfloat_p k, bool pinhole, const LevelConst& lc,
                                                  float wm1, float hm1, float x, float y, float z) {
     const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
     const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
@@ -824,9 +832,9 @@ __device__ __forceinline__ LeanProj project_lean(const float* __restrict__ m, co
     o.fy = (ny + 1.0f) / 2.0f * hm1;
     return o;
 }
-__device__ __forceinline__ bool is_pinhole(const float* __restrict__ m, const float* __restrict__ k) {
-    const uint32_t* mb = (const uint32_t*)m;
-    const uint32_t* kb = (const uint32_t*)k;
+__device__ __forceinline__ bool is_pinhole(k1_cfloat_p m, k1_cfloat_p k) {
+    const k1_cuint_p mb = (k1_cuint_p)m;
+    const k1_cuint_p kb = (k1_cuint_p)k;
     const uint32_t must_be_zero = (mb[12] | mb[13] | mb[14] | kb[1] | kb[3] | kb[4] | kb[7] | kb[8] | kb[9] | kb[11]) << 1;   // +-0
     const uint32_t must_be_one = (mb[15] ^ 0x3f800000u) | (kb[10] ^ 0x3f800000u);
     return (must_be_zero | must_be_one) == 0u;
@@ -837,7 +845,7 @@ __device__ __forceinline__ float lattice_at(const LevelConst& lc, int d, int i) 
 
 // Range of image tiles of one (wave tile, view) pair: 0 = no voxel of the wave tile is visible in the view for sure; bit 31 = some may be,
 // bit 30 = more than 2 x 2 tiles (the pair goes to the direct bin), else tx_lo | ty_lo << 12 | (nx - 1) << 24 | (ny - 1) << 25.
-__device__ uint32_t bwd_pair_code(const BwdLevel& L, const float* __restrict__ m, const float* __restrict__ k, uint32_t wave_code) {
+__device__ uint32_t bwd_pair_code(const BwdLevel& L, k1_cfloat_p m, k1_cfloat_p k, uint32_t wave_code) {
     const int d = L.d, w = L.w, h = L.h;
     constexpr int zlen = 16, rows = 4;
     const int kz0 = (int)(wave_code & 0xFFu) * zlen, jy = (int)((wave_code >> 8) & 0xFFFu), ix0 = (int)(wave_code >> 20) * rows;
@@ -846,7 +854,11 @@ __device__ uint32_t bwd_pair_code(const BwdLevel& L, const float* __restrict__ m
     bool sure = true;
     for (int c = 0; c < 4; ++c) {
         const float x = lattice_at(L.lc, d, ix0 + ((c & 1) ? rows - 1 : 0)), z = lattice_at(L.lc, d, kz0 + ((c & 2) ? zlen - 1 : 0));
-        const float4 cam = mat4_point(m, x, y, z);
+        float4 cam;                                                                // (= mat4_point, on the constant-address-space matrix)
+        cam.x = m[0] * x + m[1] * y + m[2] * z + m[3];
+        cam.y = m[4] * x + m[5] * y + m[6] * z + m[7];
+        cam.z = m[8] * x + m[9] * y + m[10] * z + m[11];
+        cam.w = m[12] * x + m[13] * y + m[14] * z + m[15];
         const float u = k[0] * cam.x + k[1] * cam.y + k[2] * cam.z + k[3] * cam.w;
         const float vv = k[4] * cam.x + k[5] * cam.y + k[6] * cam.z + k[7] * cam.w;
         const float dd = k[8] * cam.x + k[9] * cam.y + k[10] * cam.z + k[11] * cam.w;
@@ -948,7 +960,7 @@ __global__ __launch_bounds__(256) void volume_bwd_plan_k(BwdLevels a, const floa
     const uint32_t q = (b - (uint32_t)v * per_view) * 256u + (uint32_t)threadIdx.x;
     uint32_t code = 0;
     if (q < L.n_waves) {
-        code = bwd_pair_code(L, w2c + 16 * v, L.intr + 16 * v, bwd_tile_code(q, L.d));
+        code = bwd_pair_code(L, k1_const(w2c + 16 * v), k1_const(L.intr + 16 * v), bwd_tile_code(q, L.d));
         L.codes[(uint32_t)v * L.n_waves + q] = code;
     }
     bwd_bin_pairs<false>(a, L, code, v, 0u, 0u);
@@ -1047,8 +1059,8 @@ __device__ __forceinline__ BwdBuffers bwd_buffers(const BwdLevel& L, int nv) {
 __device__ __forceinline__ float buffer_f32(const __amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
 }
-__device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, const float* __restrict__ m,
-                                              const float* __restrict__ k, bool pinhole, const TileVoxel& tv) {
+__device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, k1_cfloat_p m, k1_cfloat_p k, bool pinhole,
+                                              const TileVoxel& tv) {
     const int d = L.d, w = L.w, h = L.h;
     const uint32_t at = tv.vox * 4u, pb = b.plane_bytes;
     BwdLoads o;
@@ -1156,7 +1168,7 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
             const uint32_t pair = a.list[e];
             const int v = (int)(pair / L.n_waves);
             const TileVoxel tv = bwd_tile_voxel(bwd_tile_code(pair - (uint32_t)v * L.n_waves, d), lane, d);
-            const float *m = w2c + 16 * v, *k = L.intr + 16 * v;
+            const k1_cfloat_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);
             direct_voxel(L, v, bwd_finish(L, bwd_issue(L, buf, (uint32_t)v * buf.view_bytes, m, k, is_pinhole(m, k), tv)));
         }
         continue;
@@ -1165,7 +1177,7 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
     const int x_org = tx * BL_W, y_org = ty * BL_H;
     for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) win[i] = 0.0;
     __syncthreads();
-    const float *m = w2c + 16 * v, *k = L.intr + 16 * v;
+    const k1_cfloat_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);      // (constant address space: see volume_build_chunk)
     const bool pinhole = is_pinhole(m, k);
     const uint32_t view_off = (uint32_t)v * buf.view_bytes;
     RotatedLane rl;
