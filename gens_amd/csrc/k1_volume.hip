@@ -261,7 +261,17 @@ __device__ __forceinline__ void row_constraint(float g0, float g1, float scale, 
 
 typedef const __attribute__((address_space(4))) float* k1_cfloat_p;
 typedef const __attribute__((address_space(4))) uint32_t* k1_cuint_p;
-__device__ __forceinline__ k1_cfloat_p k1_const(const float* p) { return (k1_cfloat_p)(uintptr_t)p; }
+// the backward kernels' matrix pointers: plain global pointers (K1_BWD_CONST_AS: the constant address space there too -- measured: no gain, and a
+// captured training step then faulted on its second replay, profiles/r05_k1_bwd_const_as_fault.txt)
+#ifdef K1_BWD_CONST_AS
+typedef k1_cfloat_p k1b_float_p;
+typedef k1_cuint_p k1b_uint_p;
+__device__ __forceinline__ k1b_float_p k1_const(const float* p) { return (k1b_float_p)(uintptr_t)p; }
+#else
+typedef const float* k1b_float_p;
+typedef const uint32_t* k1b_uint_p;
+__device__ __forceinline__ k1b_float_p k1_const(const float* p) { return p; }
+#endif
 
 __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
@@ -806,7 +816,7 @@ struct LeanProj {
     bool vis;
 };
 // volume_build_chunk's projection (same operations in the same order: the visibility and the taps of the backward pass are the forward's)
-__device__ __forceinline__ LeanProj project_lean(k1_cfloat_p m, k1_cfloat_p k, bool pinhole, const LevelConst& lc,
+__device__ __forceinline__ LeanProj project_lean(k1b_float_p m, k1b_float_p k, bool pinhole, const LevelConst& lc,
                                                  float wm1, float hm1, float x, float y, float z) {
     const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
     const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
@@ -832,9 +842,9 @@ __device__ __forceinline__ LeanProj project_lean(k1_cfloat_p m, k1_cfloat_p k, b
     o.fy = (ny + 1.0f) / 2.0f * hm1;
     return o;
 }
-__device__ __forceinline__ bool is_pinhole(k1_cfloat_p m, k1_cfloat_p k) {
-    const k1_cuint_p mb = (k1_cuint_p)m;
-    const k1_cuint_p kb = (k1_cuint_p)k;
+__device__ __forceinline__ bool is_pinhole(k1b_float_p m, k1b_float_p k) {
+    const k1b_uint_p mb = (k1b_uint_p)m;
+    const k1b_uint_p kb = (k1b_uint_p)k;
     const uint32_t must_be_zero = (mb[12] | mb[13] | mb[14] | kb[1] | kb[3] | kb[4] | kb[7] | kb[8] | kb[9] | kb[11]) << 1;   // +-0
     const uint32_t must_be_one = (mb[15] ^ 0x3f800000u) | (kb[10] ^ 0x3f800000u);
     return (must_be_zero | must_be_one) == 0u;
@@ -845,7 +855,7 @@ __device__ __forceinline__ float lattice_at(const LevelConst& lc, int d, int i) 
 
 // Range of image tiles of one (wave tile, view) pair: 0 = no voxel of the wave tile is visible in the view for sure; bit 31 = some may be,
 // bit 30 = more than 2 x 2 tiles (the pair goes to the direct bin), else tx_lo | ty_lo << 12 | (nx - 1) << 24 | (ny - 1) << 25.
-__device__ uint32_t bwd_pair_code(const BwdLevel& L, k1_cfloat_p m, k1_cfloat_p k, uint32_t wave_code) {
+__device__ uint32_t bwd_pair_code(const BwdLevel& L, k1b_float_p m, k1b_float_p k, uint32_t wave_code) {
     const int d = L.d, w = L.w, h = L.h;
     constexpr int zlen = 16, rows = 4;
     const int kz0 = (int)(wave_code & 0xFFu) * zlen, jy = (int)((wave_code >> 8) & 0xFFFu), ix0 = (int)(wave_code >> 20) * rows;
@@ -948,6 +958,11 @@ __device__ __forceinline__ void bwd_bin_pairs(const BwdLevels& a, const BwdLevel
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (bin[k] >= 0) a.list[base[bin[k]] + rank[k]] = direct ? pair : entry;
+}
+
+__global__ __launch_bounds__(256) void volume_bwd_zero_k(uint32_t* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void volume_bwd_plan_k(BwdLevels a, const float* __restrict__ w2c) {
@@ -1059,7 +1074,7 @@ __device__ __forceinline__ BwdBuffers bwd_buffers(const BwdLevel& L, int nv) {
 __device__ __forceinline__ float buffer_f32(const __amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
 }
-__device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, k1_cfloat_p m, k1_cfloat_p k, bool pinhole,
+__device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, k1b_float_p m, k1b_float_p k, bool pinhole,
                                               const TileVoxel& tv) {
     const int d = L.d, w = L.w, h = L.h;
     const uint32_t at = tv.vox * 4u, pb = b.plane_bytes;
@@ -1168,7 +1183,7 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
             const uint32_t pair = a.list[e];
             const int v = (int)(pair / L.n_waves);
             const TileVoxel tv = bwd_tile_voxel(bwd_tile_code(pair - (uint32_t)v * L.n_waves, d), lane, d);
-            const k1_cfloat_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);
+            const k1b_float_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);
             direct_voxel(L, v, bwd_finish(L, bwd_issue(L, buf, (uint32_t)v * buf.view_bytes, m, k, is_pinhole(m, k), tv)));
         }
         continue;
@@ -1177,7 +1192,7 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
     const int x_org = tx * BL_W, y_org = ty * BL_H;
     for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) win[i] = 0.0;
     __syncthreads();
-    const k1_cfloat_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);      // (constant address space: see volume_build_chunk)
+    const k1b_float_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);      // (constant address space: see volume_build_chunk)
     const bool pinhole = is_pinhole(m, k);
     const uint32_t view_off = (uint32_t)v * buf.view_bytes;
     RotatedLane rl;
@@ -1205,7 +1220,11 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
         const float s = (float)win[c * BL_WIN + texel];
         if (s != 0.0f) {
             const int r = texel / (BL_W + 1), cc = texel - r * (BL_W + 1);
-            atomicAdd(out + ((int64_t)(y_org + r) * w + x_org + cc) * 4 + c, s);      // (only in-image taps were added: the texel exists)
+            // Taps on row h / column w (the +1 neighbours of the last row / column) carry weight exactly 0, so their sums are 0 and stay in LDS --
+            // unless the cotangent is NaN or infinite: 0 x NaN = NaN != 0 then reached this add, and for the last row of the last view that is
+            // a write PAST THE END of the gradient buffer (a captured training step whose parameters went non-finite faulted there on its second
+            // replay; eagerly the write landed in whatever the allocator had put behind the buffer).  Only texels of the image are written.
+            if (y_org + r < h && x_org + cc < w) atomicAdd(out + ((int64_t)(y_org + r) * w + x_org + cc) * 4 + c, s);
         }
     }
     __syncthreads();                                                               // (the window is zeroed again by the next item)
@@ -1311,7 +1330,13 @@ extern "C" int gens_volume_build_bwd_levels(const float* const* feat, const int*
     static GensLdsOptIn lds_set;                                                    // (the window is more than the 64 KB a kernel gets by default)
     if (int e = gens_lds_opt_in(lds_set, (const void*)volume_bwd_tiles_k, BL_LDS_BYTES, "gens_volume_build_bwd_levels")) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.count, 0, (char*)a.offset - (char*)a.count, st) != hipSuccess) return gens_launch_status("gens_volume_build_bwd_levels");
+    // A kernel, not hipMemsetAsync: captured into a HIP graph (ROCm 7.0 runtime of the GPU boxes) the memset NODE did not order against the kernel
+    // nodes behind it -- the plan kernel counted on top of what the previous replay had left, the offsets ran past the end of the lists, and the
+    // fill kernel of a captured training step's SECOND replay wrote into unmapped memory (profiles/r05_k1_bwd_graph_fault.txt).
+    {
+        const uint32_t words = (uint32_t)(((char*)a.offset - (char*)a.count) / 4);
+        volume_bwd_zero_k<<<(words + 255u) / 256u, 256, 0, st>>>(a.count, words);
+    }
     volume_bwd_plan_k<<<a.plan_blocks, 256, 0, st>>>(a, w2c);
     volume_bwd_scan_k<<<1, 256, 0, st>>>(a);
     volume_bwd_fill_k<<<a.plan_blocks, 256, 0, st>>>(a);

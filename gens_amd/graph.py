@@ -119,6 +119,16 @@ def _same(t):
     return t
 
 
+def _phase(what):
+    """GENS_AG_SYNC=1 (a debugging aid): wait for the device after every phase of a captured step and say so -- a GPU memory fault is reported
+    asynchronously, the last phase printed before it is the one that faulted."""
+    if os.environ.get("GENS_AG_SYNC"):
+        import sys
+        torch.cuda.synchronize()
+        sys.stderr.write("      [auto-graph] %s\n" % what)
+        sys.stderr.flush()
+
+
 def _swapped_parameters(module, alias_of):
     """Context: the parameters of `module` that require a gradient are replaced by their aliases (torch's own functional-call machinery)."""
     import contextlib
@@ -146,6 +156,7 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, owner, *grad_inputs):
         entry.fwd.replay()
+        _phase("forward graph replayed")
         ctx.entry, ctx.owner = entry, owner
         outs = tuple(o.detach() for o in entry.out_static)
         ctx.mark_non_differentiable(*[o for o, d in zip(outs, entry.out_diff) if not d])
@@ -182,8 +193,10 @@ class _Replay(torch.autograd.Function):
             g = t.grad if t.is_leaf else None
             if g is not None and s is not None and g.data_ptr() == s.data_ptr():
                 t.grad = g.clone()
+        _phase("cotangents copied")
         if plan.graph is not None:
             plan.graph.replay()
+        _phase("backward graph replayed")
         return (None, None, *[None if s is None else s.detach() for s in plan.grad_in])
 
 
@@ -270,7 +283,8 @@ class AutoGraph:
         """An eager warm-up step: note which outputs receive a gradient from the caller's loss (the captured backward differentiates those)."""
         for name, t in out.items():
             if torch.is_tensor(t) and t.requires_grad:
-                t.register_hook(lambda g, name=name, entry=entry: entry.used.add(name))
+                # (the hook holds the SET, not the entry: whatever keeps an eager step's autograd graph alive must not keep captured graphs alive)
+                t.register_hook(lambda g, name=name, used=entry.used: used.add(name))
         return out
 
     # -- capture -------------------------------------------------------------------------------------------------------
@@ -373,6 +387,7 @@ class AutoGraph:
         for s, buf, layout in entry.draws:
             if buf is not None:
                 s.refresh_host_draws(buf, layout)              # the reference's generator, its order (implicit_surface.py:362, then :256)
+        _phase("inputs copied, host draws refreshed")
         outs = _Replay.apply(entry, self, *entry.grad_inputs)
         entry.fwd_done = torch.cuda.Event()
         entry.fwd_done.record()

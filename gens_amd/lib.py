@@ -216,25 +216,27 @@ def profile_begin(only=None):
     _profile_only = set(only) if only else None
 
 
-def profile_end(raw=False):
+def profile_end(raw=False, per_launch=False):
     """Stop recording; -> {kernel: {"launches", "ms", "bytes"}} (synchronises).  raw=True: the per-launch list
-    [(kernel, ms, algorithmic bytes, flops)] in launch order instead."""
+    [(kernel, ms, algorithmic bytes, flops)] in launch order instead.  per_launch=True: (the table, {kernel: [ms of every launch]})."""
     global _profile
     rec, _profile = _profile or [], None
     torch.cuda.synchronize()
     if raw:
         return [(name, s.elapsed_time(e), nbytes, flops) for name, s, e, nbytes, flops, _live in rec]
-    out = {}
+    out, each = {}, {}
     for name, s, e, nbytes, flops, live in rec:
         d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
         frac = 1.0
         if live is not None:        # (device count tensor, launched points): algorithmic work is that of the points really evaluated
             frac = min(1.0, float(live[0].item()) / max(1, live[1]))
+        ms = s.elapsed_time(e)
         d["launches"] += 1
-        d["ms"] += s.elapsed_time(e)
+        d["ms"] += ms
         d["bytes"] += int(nbytes * frac)
         d["flops"] += int(flops * frac)
-    return out
+        each.setdefault(name, []).append(ms)
+    return (out, each) if per_launch else out
 
 
 def call(name, *args, nbytes=0, flops=0, live=None, label=None):

@@ -586,7 +586,11 @@ class SdfTrainStep:
 class _SdfTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, step, sel, tv, *tensors):
-        ctx.step, ctx.sel = step, sel
+        # (NOT ctx.sel = sel: sel.y / sel.g / sel.s are this Function's OUTPUTS -- node -> sel -> output tensor -> grad_fn -> node is a cycle the
+        # collector cannot break (the last edge lives in C++), so every training step would leave this node, the blending node behind sel.rgb and
+        # everything they hold on the device for ever: 1.9 MB per step on the small test model, scripts/probe/eager_leak_probe.py)
+        ctx.step = step
+        ctx.sel_index = None if sel is None else (sel.idx, sel.counts[0:1])
         ctx.shapes = [t.shape for t in tensors]
         ctx.n_par = len(step.tensors)
         y, g, s = step._forward(pts, sel)
@@ -608,10 +612,10 @@ class _SdfTrain(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, y_bar, g_bar, s_bar, tv_bar):
-        step, sel = ctx.step, ctx.sel
+        step = ctx.step
         pts, *tv_saved = ctx.saved_tensors
         n, dev = pts.shape[0], pts.device
-        idx, cnt = (None, None) if sel is None else (sel.idx, sel.counts[0:1])
+        idx, cnt = (None, None) if ctx.sel_index is None else ctx.sel_index
         nl = step.n_levels
         cf, fe, kin = 4 * nl, 20 * nl, 128 + 20 * nl
         fep = step.kp - 128

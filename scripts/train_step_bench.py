@@ -28,12 +28,13 @@ from gens_amd.models.modules.implicit_surface import ImplicitSurface  # noqa: E4
 
 
 def measure(argv=(), quiet=False, kernels=False):
-    """One measurement; argv: the command-line flags below.  -> (milliseconds per step, label), or with kernels=True
-    (milliseconds per step, label, {C-ABI entry: {"launches", "ms", "bytes", "flops"}} of ONE extra, untimed step)."""
+    """One measurement; argv: the command-line flags below.  -> (milliseconds per step, label, table); table: with kernels=True
+    {C-ABI entry: {"launches", "ms", "bytes", "flops"}} of ONE extra, untimed step, else {}."""
     saved = sys.argv
     sys.argv = [saved[0], *argv]
     try:
-        return _measure(quiet, kernels)
+        got = _measure(quiet, kernels)
+        return got if kernels else (*got, {})
     finally:
         sys.argv = saved
 
@@ -102,6 +103,11 @@ def _measure(quiet, kernels=False):
             return model("train", ipts, cos_anneal_ratio=0.5), None
     elif full:
         from gens_amd.models import gens
+        if os.environ.get("GENS_TRAIN_TINY"):        # probe: stand-in backbones ("feature", "reg" or "feature,reg")
+            from tests.test_hip_ddp import TinyFeatureNet, TinyRegNet
+            gens._BACKBONES.clear()
+            which = os.environ["GENS_TRAIN_TINY"].split(",")
+            gens.register_backbones(TinyFeatureNet if "feature" in which else None, TinyRegNet if "reg" in which else None)
         torch.manual_seed(0)
         model = gens.GenS(gens_model_conf(volume_dims=tuple(dims))).to(dev).train()
         surf = model.implicit_surface
@@ -130,8 +136,17 @@ def _measure(quiet, kernels=False):
         loss = loss_fn(out, targets)["loss"]                                             # runner.py:161-162 / 304-305
         if extra is not None:
             loss = loss + extra
+        if os.environ.get("GENS_AG_SYNC"):
+            torch.cuda.synchronize()
+            sys.stderr.write("      [loop] loss computed\n")
         loss.backward()
+        if os.environ.get("GENS_AG_SYNC"):
+            torch.cuda.synchronize()
+            sys.stderr.write("      [loop] backward returned\n")
         opt.step()
+        if os.environ.get("GENS_AG_SYNC"):
+            torch.cuda.synchronize()
+            sys.stderr.write("      [loop] optimizer stepped\n")
         return loss.detach()
 
     def step():
@@ -150,16 +165,37 @@ def _measure(quiet, kernels=False):
         def step():  # noqa: F811
             return graphed()
 
-    for _ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
-        float(step())
+    trace = os.environ.get("GENS_TRAIN_TRACE")
+    for i_ in range(int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 2):
+        lv_ = float(step())
+        if trace:
+            sys.stderr.write("   loss %r\n" % lv_)
+            torch.cuda.synchronize()
+            sys.stderr.write("   warm-up step %d done\n" % i_)
+            sys.stderr.flush()
     torch.cuda.synchronize()
     # What the process built so far (modules, plans, cached tensors -- and, inside bench.py, everything the earlier workloads left) goes out of the
     # cyclic collector's way, as bench.py does for the headline: a step creates tens of thousands of short-lived Python objects, i.e. a full
     # collection every few steps, and each of those walks every long-lived object of the process (~20 - 35 ms here).  Measured in bench.py's
     # process: the full step's median 52 - 54 ms with p10 32.4 before, against 32.8 ms in a process of its own.
     import gc
-    gc.collect()
-    gc.freeze()
+    if trace:
+        graphs = [o for o in gc.get_objects() if isinstance(o, torch.cuda.CUDAGraph)]
+        sys.stderr.write("   live CUDAGraph objects before the collection: %d\n" % len(graphs))
+        del graphs
+    n_coll = 0 if os.environ.get("GENS_TRAIN_NO_COLLECT") else gc.collect()
+    if trace:
+        graphs = [o for o in gc.get_objects() if isinstance(o, torch.cuda.CUDAGraph)]
+        sys.stderr.write("   collected %d objects; live CUDAGraph objects after: %d\n" % (n_coll, len(graphs)))
+        del graphs
+    if not os.environ.get("GENS_TRAIN_NO_COLLECT"):
+        gc.freeze()
+    if trace:
+        torch.cuda.synchronize()
+        sys.stderr.write("   collected; timed loop starts\n")
+        sys.stderr.flush()
+        if trace == "2" and full:
+            torch.cuda.memory._dump_snapshot("gpurun_out/snap_full.pickle")
     t0 = time.perf_counter()
     n = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
     host = 0.0

@@ -201,3 +201,42 @@ def test_render_alone_is_captured_when_it_is_called_directly():
     for a, b in zip(runs[False][2] + runs[False][3], runs[True][2] + runs[True][3]):
         assert float((a - b).abs().max()) <= 2e-4 * max(float(a.abs().max()), 1e-3)
     assert ops is not None
+
+
+@pytest.mark.parametrize("auto", [False, True])
+def test_training_steps_leave_nothing_behind(auto):
+    """Device memory and live autograd nodes after every step of the runner's loop: constant from the first step on (eager) / from the first
+    replay on (captured).  Until round 5 every eager step leaked its `_SdfTrain` node -- ctx.sel held the Function's own outputs, a reference cycle
+    through C++ that Python's collector cannot break -- and, through it, the blending node and everything both held on the device."""
+    import gc
+
+    from tests.test_hip_ddp import _loss
+    model = _finetune_model(auto)
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}))
+    torch.manual_seed(4)
+    seen = []
+    for k in range(9):
+        _runner_loop(model, opt, 1, _loss, inputs=lambda _k, k=k: _step_inputs(k))
+        gc.collect()
+        nodes = sum(1 for o in gc.get_objects() if type(o).__name__.endswith("Backward") and isinstance(o, torch.autograd.function.BackwardCFunction))
+        seen.append((torch.cuda.memory_allocated(), nodes))
+    settled = seen[4:]                                         # (captured: steps 0, 1 eager, step 2 captures; from then on replays)
+    assert len({m for m, _ in settled}) == 1, seen
+    assert all(n == 0 for _, n in seen), seen
+
+
+def test_two_models_trained_one_after_the_other_in_one_process():
+    """bench.py trains one model after the other in ONE process; the second captured step used to die with a GPU memory fault on its second
+    replay (a memset node inside K1's backward, profiles/r05_k1_bwd_graph_fault.txt).  Train mode (K1 forward + backward inside the captured
+    graphs) after a fine-tune model, enough replays for the pool to have been reused."""
+    from tests.test_hip_ddp import _loss, _model
+    first = _finetune_model(True)
+    opt = torch.optim.Adam(first.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}))
+    torch.manual_seed(8)
+    _runner_loop(first, opt, 5, _loss)
+    del first, opt
+    second = _model()
+    opt2 = torch.optim.Adam(second.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+    out = _runner_loop(second, opt2, 8, _loss, step_of=lambda k: 1.0 + k / 16, inputs=lambda k: _step_inputs(k, nv=4) | {"view_ids": None})
+    assert second._auto.stats["replayed"] == 6
+    assert all(torch.isfinite(torch.tensor(a)) for a, _ in out)
