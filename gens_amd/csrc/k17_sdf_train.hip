@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
                                                        const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                        float2* __restrict__ stash, float* __restrict__ y_out, float* __restrict__ g_out,
                                                        float* __restrict__ s_out) {
-    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4;
+    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 8) / 8 * 8, GIN = KP / 8, RS = KP + 4;
     static_assert(KP > KIN, "a pad column carries the bias");
-    constexpr int NT_B = (KIN + 31) / 32;
+    constexpr int NT_B = 4 + ((FE + 31) / 32 <= 2 ? 2 : 4);      // 4 hidden tiles + the conditioning tiles, padded to 2 or 4 (zero columns: gens_sdf_train_pack)
     constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                       // [2][XT]: value tile [h | e | 1 | 0], tangent tile [h' | e' | 0]; h part reused by the reverse sweeps
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
                                                        const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
                                                        const float* __restrict__ y_bar, const float* __restrict__ g_bar,
                                                        const float* __restrict__ s_bar, float4* __restrict__ stash, SdfTrainBwdOut O) {
-    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 7) / 8 * 8, GIN = KP / 8, RS = KP + 4, FEP = KP - TR_H;
-    constexpr int NT_B = (KIN + 31) / 32;
+    constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 8) / 8 * 8, GIN = KP / 8, RS = KP + 4, FEP = KP - TR_H;
+    constexpr int NT_B = 4 + ((FE + 31) / 32 <= 2 ? 2 : 4);      // 4 hidden tiles + the conditioning tiles, padded to 2 or 4 (zero columns: gens_sdf_train_pack)
     constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;              // [4][XT]
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
     const int64_t m0 = (int64_t)blockIdx.x * TR_M;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;      // (as the forward launch; operand rows past the count are never read)
     if (m0 >= n) {
-        if (threadIdx.x < (TR_H + FE + 7) / 8 * 8) O.w6_part[(int64_t)blockIdx.x * ((TR_H + FE + 7) / 8 * 8) + threadIdx.x] = 0.0f;
+        if (threadIdx.x < KP) O.w6_part[(int64_t)blockIdx.x * KP + threadIdx.x] = 0.0f;
         return;
     }
     const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
@@ -923,12 +923,12 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
 
 template <int FE>
 static constexpr size_t fwd_lds_bytes() {
-    constexpr int CF = FE / 5, KP = (TR_H + FE + 7) / 8 * 8, RS = KP + 4;
+    constexpr int CF = FE / 5, KP = (TR_H + FE + 8) / 8 * 8, RS = KP + 4;
     return sizeof(float) * (2 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + 2 * TR_M * CF * 3 + 2 * TR_M * CF + TR_M * 8);
 }
 template <int FE>
 static constexpr size_t bwd_lds_bytes() {
-    constexpr int KP = (TR_H + FE + 7) / 8 * 8, RS = KP + 4;
+    constexpr int KP = (TR_H + FE + 8) / 8 * 8, RS = KP + 4;
     return sizeof(float) * (4 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + TR_M);
 }
 
@@ -951,7 +951,7 @@ extern "C" int64_t gens_sdf_train_stash_bytes(int64_t n, int backward) {
 
 extern "C" int gens_sdf_train_pack(const float* const* w, const float* const* b, int n_levels, float* const* wf, float* const* wb,
                                    void* stream) {
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_pack: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_train_pack: built for 1 to 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(w && b && wf && wb, GENS_EINVAL, "gens_sdf_train_pack: null table");
     SdfPackArgs A;
     const int kin = TR_H + 20 * n_levels;
@@ -966,7 +966,7 @@ extern "C" int gens_sdf_train_pack(const float* const* w, const float* const* b,
         A.rows[l] = l == 2 ? TR_SKIP_H : TR_H;
         A.cols[l] = l == 0 ? TR_PE : kin;
         A.gf[l] = (A.cols[l] + 1 + 7) / 8;
-        A.ntb[l] = (A.cols[l] + 31) / 32;
+        A.ntb[l] = l == 0 ? 1 : 4 + ((20 * n_levels + 31) / 32 <= 2 ? 2 : 4);      // (the kernels' NT_B: conditioning tiles padded to two or four)
         most = max(most, 4 * A.gf[l] * 64 + A.ntb[l] * 16 * 64);
     }
     sdf_train_pack_k<<<dim3(gens_blocks(most, 256), TR_NLAYER), 256, 0, (hipStream_t)stream>>>(A);
@@ -978,7 +978,7 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
                                   int64_t n, const int32_t* n_device, void* stash, float* y_out, float* g_out, float* s_out, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_train_fwd", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_fwd: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_train_fwd: built for 1 to 5 volume levels, got %d", n_levels);
     SdfTrainWeights W;
     if (int e = fill_train_weights("gens_sdf_train_fwd", &W, wf, wb, w_last, b_last)) return e;
     GENS_CHECK_ARG(b_last, GENS_EINVAL, "gens_sdf_train_fwd: null b_last");
@@ -986,15 +986,20 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, TR_M);
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels == 3) {
-        static GensLdsOptIn lds;
-        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_fwd_k<60>, (int)fwd_lds_bytes<60>(), "gens_sdf_train_fwd")) return e;
-        sdf_train_fwd_k<60><<<grid, 256, fwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
-    } else {
-        static GensLdsOptIn lds;
-        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_fwd_k<100>, (int)fwd_lds_bytes<100>(), "gens_sdf_train_fwd")) return e;
-        sdf_train_fwd_k<100><<<grid, 256, fwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out);
+#define TR_FWD(FE_)                                                                                                                         \
+    {                                                                                                                                      \
+        static GensLdsOptIn lds;                                                                                                           \
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_fwd_k<FE_>, (int)fwd_lds_bytes<FE_>(), "gens_sdf_train_fwd")) return e;    \
+        sdf_train_fwd_k<FE_><<<grid, 256, fwd_lds_bytes<FE_>(), s>>>(W, vs, pts, index, n, n_device, (float2*)stash, y_out, g_out, s_out); \
     }
+    switch (n_levels) {
+        case 1: TR_FWD(20) break;
+        case 2: TR_FWD(40) break;
+        case 3: TR_FWD(60) break;
+        case 4: TR_FWD(80) break;
+        default: TR_FWD(100) break;
+    }
+#undef TR_FWD
     return gens_launch_status("gens_sdf_train_fwd");
 }
 
@@ -1004,7 +1009,7 @@ extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* di
                                   float* rh, float* re, float* r0, float* f_hat, float* mu_f, float* lam_f, float* w6_part, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_train_bwd", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_bwd: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_train_bwd: built for 1 to 5 volume levels, got %d", n_levels);
     SdfTrainWeights W;
     if (int e = fill_train_weights("gens_sdf_train_bwd", &W, wf, wb, w_last, nullptr)) return e;
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && lop && rh && re && r0 && f_hat && mu_f && lam_f && w6_part)), GENS_EINVAL,
@@ -1013,15 +1018,20 @@ extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* di
     const unsigned grid = gens_blocks(n, TR_M);
     SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, w6_part, (int64_t)grid * TR_M};
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels == 3) {
-        static GensLdsOptIn lds;
-        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_bwd_k<60>, (int)bwd_lds_bytes<60>(), "gens_sdf_train_bwd")) return e;
-        sdf_train_bwd_k<60><<<grid, 256, bwd_lds_bytes<60>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
-    } else {
-        static GensLdsOptIn lds;
-        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_bwd_k<100>, (int)bwd_lds_bytes<100>(), "gens_sdf_train_bwd")) return e;
-        sdf_train_bwd_k<100><<<grid, 256, bwd_lds_bytes<100>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);
+#define TR_BWD(FE_)                                                                                                                                  \
+    {                                                                                                                                               \
+        static GensLdsOptIn lds;                                                                                                                    \
+        if (int e = gens_lds_opt_in(lds, (const void*)sdf_train_bwd_k<FE_>, (int)bwd_lds_bytes<FE_>(), "gens_sdf_train_bwd")) return e;             \
+        sdf_train_bwd_k<FE_><<<grid, 256, bwd_lds_bytes<FE_>(), s>>>(W, vs, pts, index, n, n_device, y_bar, g_bar, s_bar, (float4*)stash, O);       \
     }
+    switch (n_levels) {
+        case 1: TR_BWD(20) break;
+        case 2: TR_BWD(40) break;
+        case 3: TR_BWD(60) break;
+        case 4: TR_BWD(80) break;
+        default: TR_BWD(100) break;
+    }
+#undef TR_BWD
     return gens_launch_status("gens_sdf_train_bwd");
 }
 
@@ -1062,7 +1072,7 @@ static void sdf_layer_shapes(int n_levels, int* rows, int* cols) {
 // arrays of rows_l floats, kept for gens_sdf_train_wgrad.
 extern "C" int gens_sdf_train_pack_wn(const float* const* v, const float* const* g, const float* const* b, int n_levels, float* const* scale,
                                       float* const* wf, float* const* wb, float* w_last, float* b_last, void* stream) {
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_pack_wn: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_train_pack_wn: built for 1 to 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(v && g && b && scale && wf && wb && w_last && b_last, GENS_EINVAL, "gens_sdf_train_pack_wn: null table");
     SdfNormArgs N;
     sdf_layer_shapes(n_levels, N.rows, N.cols);
@@ -1089,7 +1099,7 @@ extern "C" int gens_sdf_train_pack_wn(const float* const* v, const float* const*
         A.rows[l] = N.rows[l];
         A.cols[l] = N.cols[l];
         A.gf[l] = (A.cols[l] + 1 + 7) / 8;
-        A.ntb[l] = (A.cols[l] + 31) / 32;
+        A.ntb[l] = l == 0 ? 1 : 4 + ((20 * n_levels + 31) / 32 <= 2 ? 2 : 4);      // (the kernels' NT_B: conditioning tiles padded to two or four)
         most = max(most, 4 * A.gf[l] * 64 + A.ntb[l] * 16 * 64);
     }
     sdf_train_pack_k<<<dim3(gens_blocks(most, 256), TR_NLAYER), 256, 0, s>>>(A);
@@ -1101,7 +1111,7 @@ extern "C" int gens_sdf_train_pack_wn(const float* const* v, const float* const*
 // = the column sums of w6_part.  dv[l] (rows_l, cols_l), dg[l] (rows_l), db[l] (rows_l) for lin0..lin6: weight norm's backward included.
 extern "C" int gens_sdf_train_wgrad(const float* const* v, const float* const* g, int n_levels, const float* cc, const float* w6_sum,
                                     float* const* dv, float* const* dg, float* const* db, void* stream) {
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_train_wgrad: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_train_wgrad: built for 1 to 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(v && g && cc && w6_sum && dv && dg && db, GENS_EINVAL, "gens_sdf_train_wgrad: null pointer");
     SdfWgradArgs A;
     sdf_layer_shapes(n_levels, A.rows, A.cols);

@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void sdf_mlp_k(SdfMlpWeights W, 
     constexpr int CF = FE / 5;            // raw volume channels (4 per level)
     constexpr int MLP_PF = 4;             // B prefetch depth in groups (6 and 8 measured no faster)
     constexpr int KIN = MLP_H + FE;       // input width of layers 1..6
-    constexpr int KP = (KIN + 7) / 8 * 8; // ... padded to whole groups (pad columns are zero)
+    constexpr int KP = (KIN + 8) / 8 * 8; // ... + the bias column, padded to whole groups (the other pad columns are zero)
     constexpr int GIN = KP / 8;           // groups per forward product of layers 1..5
     constexpr int RS = KP + 4;            // row stride: 16-B aligned, = 4 (mod 8) words
-    constexpr int NT_B = (KIN + 31) / 32; // backward n-tiles (h part: 4, conditioning part: the rest)
+    constexpr int NT_B = 4 + ((FE + 31) / 32 <= 2 ? 2 : 4);   // backward n-tiles: 4 of the h part + the conditioning tiles, padded to 2 or 4 (zero columns)
     __shared__ __attribute__((aligned(16))) float X[MLP_M * RS];              // [h | fe | 0] tile; reused as the G buffer in the reverse pass
     __shared__ __attribute__((aligned(16))) float PE[MLP_M * MLP_PE_STRIDE];  // point encoding (27, cols 27..31 = 0)
     __shared__ float GPE[GRAD ? MLP_M * MLP_PE_STRIDE : 1];   // d/d(point encoding) from the skip connection
@@ -418,7 +418,9 @@ static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int 
                           void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_mlp", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_mlp: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_mlp: built for 1 to 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(!grad_out || n_levels == 3 || n_levels == 5, GENS_ELIMIT,
+                   "gens_sdf_mlp: the row-major value + gradient kernel is built for 3 or 5 levels (gens_sdf_grad serves 1 to 5), got %d", n_levels);
     GENS_CHECK_ARG(wf && w_last && (wb || !grad_out), GENS_EINVAL, "gens_sdf_mlp: null weight table");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out)), GENS_EINVAL, "gens_sdf_mlp: null pts / output");
     GENS_CHECK_ARG(scale != 0.0f, GENS_EINVAL, "gens_sdf_mlp: scale must be non-zero");
@@ -442,10 +444,12 @@ static int sdf_mlp_launch(const float* const* vols_packed, const int* dims, int 
         if (w_last_scaled) sdf_mlp_k<FE_, GRAD_, true><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out); \
         else sdf_mlp_k<FE_, GRAD_, false><<<grid, 256, 0, s>>>(W, vs, pts, index, n, n_device, sdf_out, grad_out);          \
     }
-    if (n_levels == 3) {
-        if (grad_out) SDF_LAUNCH(60, true) else SDF_LAUNCH(60, false)
-    } else {
-        if (grad_out) SDF_LAUNCH(100, true) else SDF_LAUNCH(100, false)
+    switch (n_levels) {
+        case 1: SDF_LAUNCH(20, false) break;
+        case 2: SDF_LAUNCH(40, false) break;
+        case 3: if (grad_out) SDF_LAUNCH(60, true) else SDF_LAUNCH(60, false) break;
+        case 4: SDF_LAUNCH(80, false) break;
+        default: if (grad_out) SDF_LAUNCH(100, true) else SDF_LAUNCH(100, false) break;
     }
 #undef SDF_LAUNCH
     return gens_launch_status("gens_sdf_mlp");

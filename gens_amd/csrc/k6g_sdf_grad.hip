@@ -72,7 +72,7 @@ struct GradShapeT {
     static constexpr int NCH = CF / 2;                 // channels per lane half
     static constexpr int NCS = 5 * NCH + 1;            // conditioning slots per half (5 encodings per channel + the constant one)
     static constexpr int GC = (NCS + 3) / 4;           // ... in groups of four pairs (forward)
-    static constexpr int TC = (5 * NCH + 15) / 16;     // accumulator tiles of the conditioning gradient (16 slots of a half per tile)
+    static constexpr int TC = ((5 * NCH + 15) / 16 + 1) / 2 * 2;   // accumulator tiles of the conditioning gradient (16 slots of a half per tile), in PAIRS (an odd count is padded with a tile of zero rows)
     static constexpr int GP = 4;
     static constexpr int NG_FWD = GP + 4 * (16 + GC) + (13 + GP + GC);
     // reverse pass: layers 5, 4, 3, 1: 16 groups of hidden products + 8 per pair of conditioning tiles; layer 2 (101 units): 13 + 7;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
                                                       int64_t n_max, const int32_t* __restrict__ n_dev, float* __restrict__ sdf_out,
                                                       float* __restrict__ grad_out, float4* __restrict__ stash_all) {
     typedef GradShapeT<NLEV> S;
-    constexpr int NCH = S::NCH, NCS = S::NCS, GC = S::GC, GP = S::GP, TC = S::TC, MID = NLEV / 2;
+    constexpr int NCH = S::NCH, NCS = S::NCS, GC = S::GC, GP = S::GP, TC = S::TC, MID = NLEV / 2, ODD = NLEV & 1;      // (the split of the levels between the lane halves: k6t_sdf_value.hip)
     static_assert(TC % 2 == 0, "the conditioning gradient is accumulated two tiles at a time");
     __shared__ float4 DS[2][16][64];        // softplus' of layers 0 and 1: [layer][accumulator register / 4][lane]
     __shared__ float JL[3 * NCH][64];       // trilinear Jacobians of this lane's channels
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     // Three levels: buffer loads -- descriptor + 16 lane in a VGPR + the group's byte offset in an SGPR + an immediate per tile: no vector
     // address arithmetic (with flat global loads hipcc spent ~540 VALU instructions and 300 wait states per tile on 64-bit addresses).
     // Five levels keep the scalar pointer + 16 lane form: with buffer loads the allocator spills the weight registers there.
-    constexpr bool WBUF = NLEV == 3;
+    constexpr bool WBUF = NLEV <= 3;
     typedef float f32x4b __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, (int)((S::NG_FWD + S::NG_BWD + 2) * 4096), 0x00020000);
     const uint32_t wlane = (uint32_t)lane * 16u;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 #define TG_WNEXT()      \
     woff += 4096u;      \
     wp += 256;
-    constexpr int NB = NLEV == 3 ? 3 : 2;      // (five levels: the conditioning operands take the third set's registers; one group ahead. Three sets there: 11 instead of 36 spilled registers and TWICE the time, 626 against 301 ms per step)
+    constexpr int NB = NLEV <= 3 ? 3 : 2;      // (five levels: the conditioning operands take the third set's registers; one group ahead. Three sets there: 11 instead of 36 spilled registers and TWICE the time, 626 against 301 ms per step)
     float4 wbuf[NB][4];
     int par = 0;
 #pragma unroll
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
     float f[NCH];          // the raw features: the chain rule at the end re-derives the encodings from them (46 registers less to carry)
     {
 #pragma unroll
-        for (int j = 0; j <= MID; ++j) {     // whole levels of this half (j < MID); level MID is shared, two channels each
-            const int l = j < MID ? (half ? MID + 1 + j : j) : MID;
+        for (int j = 0; j < MID + ODD; ++j) {     // whole levels of this half (j < MID); with an odd count level MID is shared, two channels each
+            const int l = j < MID ? (half ? MID + ODD + j : j) : MID;
             float4 jx, jy, jz;
             const float4 t = sample_volume4g((const float4*)vols.data[l], vols.dx[l], vols.dy[l], vols.dz[l], x, live, jx, jy, jz);
             if (j < MID) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
                     f[4 * j + c] = tv[c];
                     JL[3 * (4 * j + c)][lane] = ax[c]; JL[3 * (4 * j + c) + 1][lane] = ay[c]; JL[3 * (4 * j + c) + 2][lane] = az[c];
                 }
-            } else {
+            } else if constexpr (ODD != 0) {
                 f[4 * MID] = half ? t.z : t.x;
                 f[4 * MID + 1] = half ? t.w : t.y;
                 JL[3 * (4 * MID)][lane] = half ? jx.z : jx.x; JL[3 * (4 * MID) + 1][lane] = half ? jy.z : jy.x; JL[3 * (4 * MID) + 2][lane] = half ? jz.z : jz.x;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) (HT_)[r_] = __builtin_amdgcn_fmed3f((T_)[r_], u__[r_], 3.0e38f); \
     }
 
-    static_assert(4 * GC - NCS <= 1 && 4 * GC >= NCS, "the conditioning block ends with a group of three or four pairs");
+    static_assert(4 * GC >= NCS && 4 * GC - NCS <= 3, "the conditioning block ends with a partly filled group (its empty pairs carry zeros on both sides)");
     // ------------------------------------------------------------------ forward
     TG_ZERO();
     TG_PE();
@@ -483,7 +483,14 @@ __global__ __launch_bounds__(64, 1) void sdf_grad_t_k(LevelSet vols, const float
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
 extern "C" int gens_sdf_grad_groups(int n_levels) {
-    return n_levels == 3 ? GradShapeT<3>::NG_FWD + GradShapeT<3>::NG_BWD : n_levels == 5 ? GradShapeT<5>::NG_FWD + GradShapeT<5>::NG_BWD : 0;
+    switch (n_levels) {
+        case 1: return GradShapeT<1>::NG_FWD + GradShapeT<1>::NG_BWD;
+        case 2: return GradShapeT<2>::NG_FWD + GradShapeT<2>::NG_BWD;
+        case 3: return GradShapeT<3>::NG_FWD + GradShapeT<3>::NG_BWD;
+        case 4: return GradShapeT<4>::NG_FWD + GradShapeT<4>::NG_BWD;
+        case 5: return GradShapeT<5>::NG_FWD + GradShapeT<5>::NG_BWD;
+        default: return 0;
+    }
 }
 
 extern "C" int64_t gens_sdf_grad_stash_bytes(void) { return (int64_t)TG_SLOTS * TG_SLOT_F4 * 16; }
@@ -499,7 +506,7 @@ extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, i
                              float* sdf_out, float* grad_out, void* stash, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_grad", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_grad: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_grad: built for 1 to 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(wstream && w_out, GENS_EINVAL, "gens_sdf_grad: null weight stream");
     GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_sdf_grad: the weight stream must be 16-byte aligned");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out && grad_out)), GENS_EINVAL, "gens_sdf_grad: null pts / output");
@@ -507,11 +514,14 @@ extern "C" int gens_sdf_grad(const float* const* vols_packed, const int* dims, i
     GENS_CHECK_ARG(stash && ((uintptr_t)stash & 15) == 0, GENS_EINVAL, "gens_sdf_grad: null or misaligned stash (gens_sdf_grad_stash_bytes() bytes, zeroed once)");
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, 32);
-    if (n_levels == 3)
-        sdf_grad_t_k<3><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
-                                                             sdf_out, grad_out, (float4*)stash);
-    else
-        sdf_grad_t_k<5><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device,
-                                                             sdf_out, grad_out, (float4*)stash);
+#define TG_LAUNCH(NL) sdf_grad_t_k<NL><<<grid, 64, 0, (hipStream_t)stream>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device, sdf_out, grad_out, (float4*)stash)
+    switch (n_levels) {
+        case 1: TG_LAUNCH(1); break;
+        case 2: TG_LAUNCH(2); break;
+        case 3: TG_LAUNCH(3); break;
+        case 4: TG_LAUNCH(4); break;
+        default: TG_LAUNCH(5); break;
+    }
+#undef TG_LAUNCH
     return gens_launch_status("gens_sdf_grad");
 }

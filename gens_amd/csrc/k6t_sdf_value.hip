@@ -71,7 +71,9 @@ __global__ __launch_bounds__(64 * TV_WAVES, 2) void sdf_value_t_k(LevelSet vols,
                                                                   const int64_t* __restrict__ index, int64_t n_max,
                                                                   const int32_t* __restrict__ n_dev, float* __restrict__ sdf_out) {
     typedef ValueShapeT<NLEV> S;
-    constexpr int NCH = S::NCH, NCS = S::NCS, GC = S::GC, GP = S::GP, MID = NLEV / 2;
+    // the channels of a point are split between the two lane halves: half 0 takes the first NLEV / 2 levels, half 1 the last NLEV / 2, and with an
+    // odd level count the middle level is shared, two channels each (gens_amd.ops._value_pairs packs the weights in the same order)
+    constexpr int NCH = S::NCH, NCS = S::NCS, GC = S::GC, GP = S::GP, MID = NLEV / 2, ODD = NLEV & 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_pt = lane & 31, half = lane >> 5;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
@@ -115,12 +117,12 @@ __global__ __launch_bounds__(64 * TV_WAVES, 2) void sdf_value_t_k(LevelSet vols,
     {
         float f[NCH];
 #pragma unroll
-        for (int j = 0; j < MID; ++j) {     // whole levels of this half; level MID is shared, two channels each
-            const int l = half ? MID + 1 + j : j;
+        for (int j = 0; j < MID; ++j) {     // whole levels of this half; with an odd count level MID is shared, two channels each
+            const int l = half ? MID + ODD + j : j;
             const float4 t = sample_volume4t((const float4*)vols.data[l], vols.dx[l], vols.dy[l], vols.dz[l], x, live);
             f[4 * j] = t.x; f[4 * j + 1] = t.y; f[4 * j + 2] = t.z; f[4 * j + 3] = t.w;
         }
-        {
+        if constexpr (ODD) {
             const float4 t = sample_volume4t((const float4*)vols.data[MID], vols.dx[MID], vols.dy[MID], vols.dz[MID], x, live);
             f[4 * MID] = half ? t.z : t.x;
             f[4 * MID + 1] = half ? t.w : t.y;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64 * TV_WAVES, 2) void sdf_value_t_k(LevelSet vols,
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)          \
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) H[t_][r_] = softplus_ct(acc[t_][r_]);
 
-    static_assert(4 * GC - NCS <= 1 && 4 * GC >= NCS, "the conditioning block ends with a group of three or four pairs");
+    static_assert(4 * GC >= NCS && 4 * GC - NCS <= 3, "the conditioning block ends with a partly filled group (its empty pairs carry zeros on both sides)");
     TV_ZERO();
     TV_PE();
     TV_ACTIVATE();
@@ -225,14 +227,23 @@ __global__ __launch_bounds__(64 * TV_WAVES, 2) void sdf_value_t_k(LevelSet vols,
 
 int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, const int* dims, int n_levels);
 
-extern "C" int gens_sdf_value_groups(int n_levels) { return n_levels == 3 ? ValueShapeT<3>::NG : n_levels == 5 ? ValueShapeT<5>::NG : 0; }
+extern "C" int gens_sdf_value_groups(int n_levels) {
+    switch (n_levels) {
+        case 1: return ValueShapeT<1>::NG;
+        case 2: return ValueShapeT<2>::NG;
+        case 3: return ValueShapeT<3>::NG;
+        case 4: return ValueShapeT<4>::NG;
+        case 5: return ValueShapeT<5>::NG;
+        default: return 0;
+    }
+}
 
 extern "C" int gens_sdf_value(const float* const* vols_packed, const int* dims, int n_levels, const float* wstream, const float* w_out,
                               float b_last, float scale, const float* pts, const int64_t* index, int64_t n, const int32_t* n_device,
                               float* sdf_out, void* stream) {
     LevelSet vs;
     if (int e = gens_fill_levels("gens_sdf_value", &vs, vols_packed, dims, n_levels)) return e;
-    GENS_CHECK_ARG(n_levels == 3 || n_levels == 5, GENS_ELIMIT, "gens_sdf_value: built for 3 or 5 volume levels, got %d", n_levels);
+    GENS_CHECK_ARG(n_levels >= 1 && n_levels <= 5, GENS_ELIMIT, "gens_sdf_value: built for 1 to 5 volume levels, got %d", n_levels);
     GENS_CHECK_ARG(wstream && w_out, GENS_EINVAL, "gens_sdf_value: null weight stream");
     GENS_CHECK_ARG(((uintptr_t)wstream & 15) == 0, GENS_EINVAL, "gens_sdf_value: the weight stream must be 16-byte aligned");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && sdf_out)), GENS_EINVAL, "gens_sdf_value: null pts / output");
@@ -240,9 +251,14 @@ extern "C" int gens_sdf_value(const float* const* vols_packed, const int* dims, 
     if (n == 0) return 0;
     const unsigned grid = gens_blocks(n, 32 * TV_WAVES);
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels == 3)
-        sdf_value_t_k<3><<<grid, 64 * TV_WAVES, 0, s>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device, sdf_out);
-    else
-        sdf_value_t_k<5><<<grid, 64 * TV_WAVES, 0, s>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device, sdf_out);
+#define TV_LAUNCH(NL) sdf_value_t_k<NL><<<grid, 64 * TV_WAVES, 0, s>>>(vs, (const float4*)wstream, w_out, b_last, scale, 1.0f / scale, pts, index, n, n_device, sdf_out)
+    switch (n_levels) {
+        case 1: TV_LAUNCH(1); break;
+        case 2: TV_LAUNCH(2); break;
+        case 3: TV_LAUNCH(3); break;
+        case 4: TV_LAUNCH(4); break;
+        default: TV_LAUNCH(5); break;
+    }
+#undef TV_LAUNCH
     return gens_launch_status("gens_sdf_value");
 }

@@ -63,9 +63,9 @@ def _check_limits(confs):
                              "must have 4 channels and feat_channels must equal 4 x the number of levels (the kernels' texel layout)")
         if any(c != 4 for c in confs["feature_network"]["d_out"]) or len(confs["feature_network"]["d_out"]) > 5:
             raise ValueError("feature_network.d_out: at most 5 feature levels of 4 channels each (K1 / K4 / K7 read 4-channel texels)")
-    if feat_ch // 4 not in (3, 5):
-        warnings.warn(f"gens_amd: {feat_ch // 4} volume levels: the fused SDF kernels (gens_sdf_mlp, gens_sdf_train_*) are built for 3 or 5 levels; "
-                      "this configuration runs the PyTorch layers on the K2 look-up kernels (correct, several times slower)", RuntimeWarning, stacklevel=3)
+    if feat_ch // 4 > 5:
+        warnings.warn(f"gens_amd: {feat_ch // 4} volume levels: the fused SDF kernels (gens_sdf_value / gens_sdf_grad / gens_sdf_train_*) are built for 1 to 5 "
+                      "levels; this configuration runs the PyTorch layers on the K2 look-up kernels (correct, several times slower)", RuntimeWarning, stacklevel=3)
 
 
 class GenS(nn.Module):

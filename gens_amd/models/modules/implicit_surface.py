@@ -156,7 +156,7 @@ class ImplicitSurface(nn.Module):
         planar volumes, or a non-shipped architecture) -- then the PyTorch layers run on top of the K2 kernels."""
         if not self.fused_sdf or torch.is_grad_enabled():
             return None
-        if not (isinstance(volumes, ops.VolumeSet) and volumes.layout == 1 and volumes.n in (3, 5)):
+        if not (isinstance(volumes, ops.VolumeSet) and volumes.layout == 1 and 1 <= volumes.n <= 5):
             return None
         net = self.sdf_network
         if not ops.SdfMlpPlan.supported(net) or net.init_feat_channels != 4 * volumes.n:

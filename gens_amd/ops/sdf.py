@@ -57,10 +57,11 @@ def _value_slots(n_levels):
         if q < 12:
             pe[q >> 3, 1, q & 7] = 15 + q
     cond = torch.full((nc, 2, 8), -2, dtype=torch.long)
+    odd = n_levels % 2
     for h in range(2):
-        nfull = 4 * mid if h == 0 else 4 * (n_levels - 1 - mid)
+        nfull = 4 * mid                                       # whole levels of a half: the first / the last n_levels // 2
         for lc in range(nch):
-            ch = (lc if h == 0 else 4 * (mid + 1) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
+            ch = (lc if h == 0 else 4 * (mid + odd) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
             for e in range(5):
                 q = 5 * lc + e
                 cond[q >> 3, h, q & 7] = e * cf + ch
@@ -137,10 +138,11 @@ def _value_pairs(n_levels):
         pe[q >> 2, 0, q & 3] = q
         pe[q >> 2, 1, q & 3] = 15 + q if q < 12 else (-1 if q == 12 else -2)
     cond = torch.full((gc, 2, 4), -2, dtype=torch.long)
+    odd = n_levels % 2                                        # an odd level count: the middle level is shared, two channels per lane half
     for h in range(2):
-        nfull = 4 * mid if h == 0 else 4 * (n_levels - 1 - mid)
+        nfull = 4 * mid                                       # whole levels of a half: the first / the last n_levels // 2 (k6t_sdf_value.hip)
         for lc in range(nch):
-            ch = (lc if h == 0 else 4 * (mid + 1) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
+            ch = (lc if h == 0 else 4 * (mid + odd) + lc) if lc < nfull else 4 * mid + 2 * h + (lc - nfull)
             for e in range(5):
                 q = 5 * lc + e
                 cond[q >> 2, h, q & 3] = e * cf + ch
@@ -208,7 +210,7 @@ def _pack_grad_stream(ws, bs, n_levels):
     c = 100.0 / math.log(2.0)
     hid, pe, cond = (t.to(dev) for t in _value_pairs(n_levels))
     nch = 2 * n_levels
-    tc = (5 * nch + 15) // 16
+    tc = ((5 * nch + 15) // 16 + 1) // 2 * 2                 # conditioning-gradient tiles, in pairs (k6g_sdf_grad.hip: GradShapeT::TC)
     fwd, _ = _pack_value_stream(ws, bs, n_levels)
     out = [fwd[:-1]]
 
@@ -365,7 +367,7 @@ class SdfMlpPlan:
     @staticmethod
     def supported(net):
         return (net.num_layers == 8 and tuple(net.skip_in) == (3,) and net.embed_fn_fine is not None and net.embed_fn_feat is not None
-                and net.lin0.weight_v.shape == (128, 27) and net.init_feat_channels in (12, 20)
+                and net.lin0.weight_v.shape == (128, 27) and net.init_feat_channels in (4, 8, 12, 16, 20)
                 and net.lin6.weight_v.shape[1] == 128 + 5 * net.init_feat_channels and net.lin2.weight_v.shape[0] == 101)
 
     @staticmethod
@@ -406,10 +408,14 @@ class SdfMlpPlan:
             self.value_stream, self.value_row = _pack_value_stream(ws, bs, self.n_levels)
             self.grad_stream, self.grad_row = _pack_grad_stream(ws, bs, self.n_levels)
             assert self.grad_stream.shape[0] == L.load().gens_sdf_grad_groups(self.n_levels) + 2
-            self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
-            self.value_ok = vmax < 6.0e4
+            # the split-half kernels (k6v / k6gh, the opt-in sdf_precision="f16x2") are built for 3 and 5 levels: other counts stay in float32
+            self.value_units = self.value_w_out = None
+            self.value_ok = False
+            if self.n_levels in (3, 5):
+                self.value_units, self.value_w_out, vmax = _pack_value_units(ws, bs, self.n_levels)
+                self.value_ok = vmax < 6.0e4
             self.grad_pieces = None                        # the split-half value + gradient kernel: None if a weight leaves the half range
-            n_pieces = L.load().gens_sdf_grad_f16_pieces(self.n_levels)
+            n_pieces = L.load().gens_sdf_grad_f16_pieces(self.n_levels) if self.n_levels in (3, 5) else 0
             if n_pieces:
                 self.grad_pieces, gvmax = _pack_grad_pieces(ws, bs, self.n_levels, n_pieces)
                 assert self.grad_pieces.shape[0] == n_pieces
@@ -511,7 +517,7 @@ class SdfTrainStep:
 
     @staticmethod
     def supported(net, n_levels):
-        return SdfMlpPlan.supported(net) and float(net.scale) == 1.0 and n_levels in (3, 5) and net.init_feat_channels == 4 * n_levels
+        return SdfMlpPlan.supported(net) and float(net.scale) == 1.0 and 1 <= n_levels <= 5 and net.init_feat_channels == 4 * n_levels
 
     def __init__(self, weights, biases, volumes, packed, raw=None, tv_masks=None):
         """weights / biases: the EFFECTIVE matrices with autograd history (torch._weight_norm's outputs) -- or, with raw = (weight_v list,
@@ -519,7 +525,7 @@ class SdfTrainStep:
         gradient launch (gens_sdf_train_pack_wn / gens_sdf_train_wgrad), and the raw parameters are the autograd inputs.
         tv_masks: the mask pyramid; with it `step(pts, sel, tv=True)` also returns tv_regularization(volumes, masks) (implicit_surface.py:
         135-150) so that the dense TV gradient and the scattered look-up gradient of the volumes are formed in ONE buffer."""
-        assert isinstance(packed, VolumeSet) and packed.layout == L.LAYOUT_PACKED and packed.n in (3, 5)
+        assert isinstance(packed, VolumeSet) and packed.layout == L.LAYOUT_PACKED and 1 <= packed.n <= 5
         self.volumes, self.packed = list(volumes), packed
         self.n_levels = packed.n
         self.raw = raw
@@ -528,7 +534,10 @@ class SdfTrainStep:
         kin = 128 + 20 * self.n_levels
         self.kp = (kin + 1 + 7) // 8 * 8
         gf = [(27 + 1 + 7) // 8] + [self.kp // 8] * 5
-        ntb = [1] + [(kin + 31) // 32] * 5
+        # backward n-tiles of layers 1..5: four hidden tiles + the conditioning tiles, padded to two or four (zero columns): the four waves of a
+        # workgroup take one tile each or two share one (k17_sdf_train.hip: NT_B)
+        n_cond = (20 * self.n_levels + 31) // 32
+        ntb = [1] + [4 + (2 if n_cond <= 2 else 4)] * 5
         self.wf = [torch.empty(4 * g * 64 * 4, device=dev, dtype=_f32) for g in gf]
         self.wb = [torch.empty(nt * 16 * 64 * 4, device=dev, dtype=_f32) for nt in ntb]
         self.wf_table, self.wb_table = L.ptr_table(self.wf), L.ptr_table(self.wb)

@@ -130,8 +130,13 @@ def test_limits_are_checked_where_the_model_is_built():
     nine = gens_model_conf(volume_dims=tuple([8] * 9))
     with pytest.raises(ValueError, match="GENS_MAX_LEVELS"):
         _check_limits(nine)
-    with pytest.warns(RuntimeWarning, match="3 or 5 levels"):
-        _check_limits(gens_model_conf(volume_dims=(16, 8)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                                  # one to five levels: fused kernels, no warning
+        for n in range(1, 6):
+            _check_limits(gens_model_conf(volume_dims=tuple([8] * n)))
+    with pytest.warns(RuntimeWarning, match="1 to 5"):
+        _check_limits(gens_model_conf(volume_dims=tuple([8] * 6), n_feature_levels=5))
 
 
 def test_offset_views_are_refused_by_float4_consumers():

@@ -229,8 +229,9 @@ def test_split_half_overflow_renders_the_image_again_in_float32_with_the_same_ji
 
 def test_render_config0_coarsest_volume_only(golden):
     """BASELINE config[0] as written (golden g9d: 3 views 480 x 640, ONE 16^3 volume built from the level-4 map with intrinsics * 2^-4,
-    512 rays): K1 on the device (mask bit-exact), then render() on the single-level pyramid -- a level count the fused kernels do not
-    cover, so this is the PyTorch-layer path on K2 / K4 / K8 -- against the reference's outputs."""
+    512 rays): K1 on the device (mask bit-exact), then render() on the single-level pyramid against the reference's outputs -- through the FUSED
+    kernels (round 5: gens_sdf_value / gens_sdf_grad / gens_sdf_train_* are built for one to five levels; until then a single level ran the
+    PyTorch layers on the stand-alone K2 / K2'' kernels): the test asserts which entry points were launched, not only the numbers."""
     from gens_amd import ops
     from gens_amd.config import gens_model_conf
     from gens_amd.models.modules.implicit_surface import ImplicitSurface
@@ -246,12 +247,28 @@ def test_render_config0_coarsest_volume_only(golden):
     surf.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, strict=True)
     surf = surf.cuda()
     feats = [c(f) for f in sc["features"]]
+    from gens_amd import lib as L
     torch.manual_seed(int(g["rng_seed"]))
+    L.profile_begin()
     out = surf.render(c(g["rays_o"]), c(g["rays_d"]), c(sc["near"]), c(sc["far"]), [c(g["vol0"])], masks, c(sc["imgs"]), feats, feats,
                       c(sc["intrs"]), c(sc["c2ws"]), 1.0, None)
+    launched = set(L.profile_end())
+    assert {"gens_sdf_train_fwd", "gens_blend_train_fwd", "gens_composite_fwd"} <= launched, launched          # the fused training-mode path
+    assert not ({"gens_lookup_volume_fwd", "gens_lookup_volume_bwd", "gens_lookup_volume_bwd2"} & launched), launched      # ... not the layers on K2 / K2''
     for k in ("color_fine", "render_depth", "sdf_depth"):
         assert (out[k].cpu() - g["out." + k]).abs().mean() < 1e-4, k
     assert (out["valid_mask"].cpu() != g["out.valid_mask"]).float().mean() < 0.005
+    # the inference path of the same scene (validate's lean render): gens_sdf_value in the sampling rounds, gens_sdf_grad in render_core
+    with torch.no_grad():
+        torch.manual_seed(int(g["rng_seed"]))
+        L.profile_begin()
+        lean = surf.render(c(g["rays_o"]), c(g["rays_d"]), c(sc["near"]), c(sc["far"]), [c(g["vol0"])], masks, c(sc["imgs"]), feats, feats,
+                           c(sc["intrs"]), c(sc["c2ws"]), 1.0, None, lean=True)
+        launched = set(L.profile_end())
+    assert {"gens_sdf_value", "gens_sdf_grad"} <= launched and any(k.startswith("gens_blend_views") for k in launched), launched
+    assert "gens_lookup_volume_fwd" not in launched and "gens_lookup_feature_fwd" not in launched, launched
+    for k in ("color_fine", "render_depth", "sdf_depth"):
+        assert (lean[k].cpu() - g["out." + k]).abs().mean() < 1e-4, k
     out = surf.render_core(c(g["rays_o"]), c(g["rays_d"]), c(g["z_final"]), 2.0 / 64, [c(g["vol0"])], masks, feats, feats, c(sc["imgs"]),
                            c(sc["intrs"]), c(sc["c2ws"]), 1.0, None, pts_random=c(g["draw_ptsrand"]) * 2 - 1)
     assert torch.equal(out["valid_mask"].cpu(), g["out.valid_mask"])

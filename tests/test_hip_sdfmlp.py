@@ -18,7 +18,7 @@ def _net(n_levels, seed):
     return net.cuda(), dims
 
 
-@pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 31), (3, 1)])
+@pytest.mark.parametrize("n_levels,n", [(3, 1000), (5, 777), (3, 31), (3, 1), (1, 500), (2, 333), (4, 650), (1, 1), (4, 33)])
 def test_fused_sdf_and_gradient_match_torch_layers(n_levels, n):
     from gens_amd import ops, synthetic
     net, dims = _net(n_levels, seed=n_levels)
@@ -202,8 +202,9 @@ def test_new_sdf_kernels_reject_bad_arguments():
     with pytest.raises(RuntimeError, match="scale must be non-zero"):
         L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 0.0, L.ptr(pts), None, 8,
                None, L.ptr(out), L.ptr(pts), L.ptr(ops.sdf_grad_stash("cuda"), torch.uint8), L.stream())
-    with pytest.raises(RuntimeError, match="3 or 5 volume levels"):
-        L.call("gens_sdf_grad", packed.table, packed.dim_table, 2, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
+    six = ops.VolumeSet.packed([v.cuda() for v in synthetic.make_volumes((8, 6, 4, 4, 4, 4), seed=4)])
+    with pytest.raises(RuntimeError, match="1 to 5 volume levels"):
+        L.call("gens_sdf_grad", six.table, six.dim_table, 6, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
                None, L.ptr(out), L.ptr(pts), L.ptr(ops.sdf_grad_stash("cuda"), torch.uint8), L.stream())
     with pytest.raises(RuntimeError, match="stash"):
         L.call("gens_sdf_grad", packed.table, packed.dim_table, 3, L.ptr(plan.grad_stream), L.ptr(plan.grad_row), 0.0, 1.0, L.ptr(pts), None, 8,
@@ -272,3 +273,32 @@ def test_non_finite_weights_give_not_a_number_outputs():
     assert torch.isnan(sdf[idx[:30]]).all() and torch.isnan(grad[idx[:30]]).all()
     assert (sdf[idx[30:]] == 100).all() and (sdf[1::2] == 100).all()
     assert torch.isnan(ops.sdf_mlp(plan, packed, pts)).all()
+
+
+@pytest.mark.parametrize("n_levels", [1, 2, 4])
+def test_other_level_counts_match_the_cpu_oracle(n_levels):
+    """Level counts other than the shipped 3 / 5 (BASELINE config[0] is ONE volume): value and gradient of the fused kernels against the oracle's
+    functional network (oracle/render_oracle.py::sdf_mlp, sdf_gradient) in float64, points inside and outside the cube, and the value-only kernel
+    (gens_sdf_value) bit-identical to the value of the value + gradient kernel (gens_sdf_grad) -- the sampling passes and render_core see ONE SDF."""
+    from gens_amd import ops, synthetic
+    from oracle import render_oracle as R
+    net, dims = _net(n_levels, seed=30 + n_levels)
+    vols = synthetic.make_volumes(dims, seed=11)
+    sd = {"sdf_network." + k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(n_levels)
+    pts = torch.rand(700, 3, generator=g) * 2.3 - 1.15
+    vols64 = [v.double() * 2 for v in vols]
+    ref = R.sdf_mlp(sd, pts.double(), vols64)[:, :1]
+    ref_g, _ = R.sdf_gradient(sd, pts.double(), vols64, second=False)
+    plan = ops.SdfMlpPlan(net)
+    assert plan.n_levels == n_levels and plan.value_units is None and plan.grad_pieces is None      # (split-half kernels: 3 and 5 levels only)
+    packed = ops.VolumeSet.packed([(v * 2).cuda() for v in vols])
+    s, gr = ops.sdf_mlp(plan, packed, pts.cuda(), want_grad=True)
+    only = ops.sdf_mlp(plan, packed, pts.cuda())
+    assert float((s.cpu().double() - ref).abs().max()) < 2e-5
+    assert float((gr.cpu().double() - ref_g.detach()).abs().max()) < 2e-4 * max(1.0, float(ref_g.abs().max()))
+    assert torch.equal(only, s)
+    # the opt-in split-half precision falls back to float32 for these level counts: same numbers, no error
+    s16, g16 = ops.sdf_mlp(plan, packed, pts.cuda(), want_grad=True, precision="f16x2")
+    assert torch.equal(s16, s) and torch.equal(g16, gr)
+    assert torch.equal(ops.sdf_mlp(plan, packed, pts.cuda(), precision="f16x2"), only)

@@ -18,7 +18,7 @@ def _case(n_levels, n=40, seed=0, dtype=torch.float64):
     return W, b, vols, pts, cot
 
 
-@pytest.mark.parametrize("n_levels", [3, 5])
+@pytest.mark.parametrize("n_levels", [1, 2, 3, 4, 5])
 def test_sweeps_equal_autograd(n_levels):
     W, b, vols, pts, (yb, gb, sb) = _case(n_levels)
     ref = T.by_autograd(W, b, vols, pts, yb, gb, sb)
