@@ -131,15 +131,27 @@ __device__ __forceinline__ int64_t gemm_tn_live_rows(const GemmTnBatch& B, int64
     return min(kk, max((int64_t)0, groups) * B.k_rows);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+// Workgroup -> (slab, four tiles of it), XCD-aware.  The tiles of ONE slab read the same K rows of the same operands (the seven products of the SDF
+// network's weight gradients share `lop`: every row is read by up to six tiles), and workgroup b runs on XCD b % 8, each with its own L2: numbered
+// slab after slab, a slab's eight workgroups sat on eight different XCDs and every L2 fetched the rows for itself -- 3.9 GB over the fabric for
+// 1.6 GB of operands, the launch's whole 0.94 ms.  Here the workgroups of a slab are eight apart: one XCD, one fetch.
+// n_wg workgroups per slab; slabs in octets (one slab per XCD); -> false when this workgroup / wave has no unit.
+__device__ __forceinline__ bool gemm_tn_batch_unit(int n_wg, int64_t n_slabs, int tiles, int64_t& s, int& t) {
+    const int64_t per_octet = 8 * (int64_t)n_wg, octet = blockIdx.x / per_octet;
+    const int in_octet = (int)(blockIdx.x - octet * per_octet);
+    s = 8 * octet + (in_octet & 7);
+    t = 4 * (in_octet >> 3) + (int)(threadIdx.x >> 6);
+    return s < n_slabs && t < tiles;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_slabs, int n_wg, float* __restrict__ ws) {
     kk = gemm_tn_live_rows(B, kk);
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= n_units) return;
     const int tiles = B.tile0[B.count];
-    const int64_t s = unit / tiles;
-    int t = (int)(unit % tiles);
+    int64_t s;
+    int t;
+    if (!gemm_tn_batch_unit(n_wg, n_slabs, tiles, s, t)) return;
     int p = 0;
     while (p + 1 < B.count && t >= B.tile0[p + 1]) ++p;
     t -= B.tile0[p];
@@ -186,15 +198,14 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_partial_k(GemmTnBatch B, in
 // Register-blocked form of the batched kernel for EVEN m, n, lda, ldb (8-byte aligned operands): a unit is a 64 x 64 block of C = 2 x 2
 // MFMA tiles whose rows / columns INTERLEAVE (tile a holds rows m0 + 2 i + a), so one 8-byte load per operand and lane feeds four
 // v_mfma_f32_32x32x2_f32 -- 0.5 load instructions per MFMA instead of 2 (the 32 x 32 kernel is bound by load issue: 1.7 TB/s).
-__global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_units, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, int64_t kk, int64_t slab, int64_t n_slabs, int n_wg, float* __restrict__ ws) {
     kk = gemm_tn_live_rows(B, kk);
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= n_units) return;
     const int tiles = B.tile0[B.count];
-    const int64_t s = unit / tiles;
-    int t = (int)(unit % tiles);
+    int64_t s;
+    int t;
+    if (!gemm_tn_batch_unit(n_wg, n_slabs, tiles, s, t)) return;
     int p = 0;
     while (p + 1 < B.count && t >= B.tile0[p + 1]) ++p;
     t -= B.tile0[p];
@@ -372,13 +383,13 @@ static int gemm_tn_batch_run(int count, const float* const* a, const int* lda, c
         }
         const int64_t slab = gemm_tn_batch_slab(k, tiles64);
         n_slabs = (int)((k + slab - 1) / slab);
-        const int64_t units = (int64_t)n_slabs * tiles64;
-        gemm_tn_batch2_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+        const int n_wg = (int)((tiles64 + 3) / 4);
+        gemm_tn_batch2_partial_k<<<(unsigned)(((n_slabs + 7) / 8) * 8 * n_wg), 256, 0, s>>>(B, k, slab, n_slabs, n_wg, workspace);
     } else {
         const int64_t slab = gemm_tn_batch_slab(k, tiles);
         n_slabs = (int)((k + slab - 1) / slab);
-        const int64_t units = (int64_t)n_slabs * tiles;
-        gemm_tn_batch_partial_k<<<gens_blocks(units, 4), 256, 0, s>>>(B, k, slab, units, workspace);
+        const int n_wg = (int)((tiles + 3) / 4);
+        gemm_tn_batch_partial_k<<<(unsigned)(((n_slabs + 7) / 8) * 8 * n_wg), 256, 0, s>>>(B, k, slab, n_slabs, n_wg, workspace);
     }
     if (n_slabs <= GEMM_TN_GROUPS) {
         gemm_tn_reduce_k<<<dim3(gens_blocks(csz, 256), 1), 256, 0, s>>>(workspace, n_slabs, n_slabs, csz, c);
