@@ -10,7 +10,7 @@ rm -rf /tmp/pmc_$TAG
 BENCH="$ROOT/bench.py --steps 1 --warmup 1 --cpu-rays 0 --no-kernel-timing --headline-only"
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_$TAG/fetch --output-format csv -- python3 $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_$TAG/write --output-format csv -- python3 $BENCH > /dev/null 2>&1
-TRAIN="$ROOT/scripts/train_step_bench.py --steps 2 --warm 1"
+TRAIN="$ROOT/scripts/train_step_bench.py --steps 2 --warm 1 --no-auto"
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_$TAG/tfetch --output-format csv -- python3 $TRAIN > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_$TAG/twrite --output-format csv -- python3 $TRAIN > /dev/null 2>&1
 cd "$ROOT"
