@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TR_SKIP_H 101
 #define TR_NLAYER 6
 #define TR_SQ2 0.70710678118654752440f
+#ifndef TR_PF_B
+#define TR_PF_B 8            // weight groups in flight per wave in the backward launch's products (one wave per SIMD: nothing else hides a load)
+#endif
 #define TR_DEAD (-1.0e30f)   // pre-activation stored for the 27 pass-through columns of layer 2: softplus' = '' = ''' = 0
 
 struct SdfTrainWeights {
@@ -46,6 +49,7 @@ struct SdfTrainWeights {
 // softplus(beta = 100, threshold 20) with its first three derivatives, branch-free (hardware exp2 / log2 / rcp).  Above the
 // threshold torch's softplus is the identity: derivatives 1, 0, 0 (v_cndmask discards the inf / NaN of the other branch).
 __device__ __forceinline__ void softplus_d3(float a, float& h, float& d1, float& d2, float& d3) {
+#pragma clang fp contract(fast)      // (no index or mask decision hangs on these values: fused multiply-adds are as good as the separate roundings)
     const float e = __builtin_amdgcn_exp2f(a * 144.269504088896340736f);   // e^{100 a}
     const float u = 1.0f + e;
     const float r = __builtin_amdgcn_rcpf(u);                              // 1 - sigmoid(100 a)
@@ -60,9 +64,8 @@ __device__ __forceinline__ void softplus_d3(float a, float& h, float& d1, float&
 
 // acc[t] += A_t (32 x 8G, rows of stride given by the caller's pointer arithmetic; tile t starts `tstride` floats after tile 0)
 // * B (G packed groups).  `a` points at this lane's row + 4 * half of tile 0, `b` at this lane's float4 of group 0.
-template <int G, int T>
+template <int G, int T, int PF = 4>
 __device__ __forceinline__ void mfma_tiles(const float* __restrict__ a, const int tstride, const float4* __restrict__ b, f32x16 (&acc)[T]) {
-    constexpr int PF = 4;
     float4 pre[PF];
 #pragma unroll
     for (int j = 0; j < PF; ++j)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
     float* GPE = PE + 2 * PT;              // [2][PT]: lambda / mu with respect to the point encoding
     float* JAC = GPE + 2 * PT;             // [32][CF][3] df/dx ; then [32][CF][3] sum_b d2f/dx dx_b
     float* LF = JAC + 2 * TR_M * CF * 3;   // [2][32][CF]: lambda_f, mu_f
-    float* RED = LF + 2 * TR_M * CF;       // [32][8]
+    float* RED = GPE;                      // [32][8]: the output row's partial sums, dead before the reverse sweeps write GPE (80 KB -> 79 KB: two workgroups per CU at three levels)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * TR_M;
@@ -452,6 +455,17 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
 // ====================================================================================================================
 // (operand rows are POINT-major, the four sweeps of a point adjacent: the rows of the live points are then one contiguous range
 // [0, 4 * 32 ceil(n / 32)) whatever the launch's upper bound was, and the weight-gradient products stop there -- gens_gemm_tn_batch's k_live)
+// Cycle stamps of one workgroup's phases (build with -DGENS_K17_STAMPS; scripts/probe/k17_stamps_probe.py reads them): never in the shipped library.
+#ifdef GENS_K17_STAMPS
+__device__ unsigned long long k17_stamps[4][128];
+#define TR_STAMP()                                                                                            \
+    do {                                                                                                      \
+        if (blockIdx.x == 300 && lane == 0 && n_stamp < 128) k17_stamps[wave][n_stamp++] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TR_STAMP() do { } while (0)
+#endif
+
 struct SdfTrainBwdOut {
     float* lop;     // [npad][4][6][128]   omega_a, rho_a, lambda_a, mu_a of layers 0..5
     float* rh;      // [5][npad][4][128]   h parts of the inputs of layers 1..5: z, z', kappa_z, nu_z
@@ -460,37 +474,52 @@ struct SdfTrainBwdOut {
     float* f_hat;   // [npad][CF]          cotangent of the looked-up features
     float* mu_f;    // [npad][CF]
     float* lam_f;   // [npad][CF]
-    float* w6_part; // [blocks][KP]        this workgroup's share of d loss / d w_last (column K = its bias)
+    float* w6_part; // [npad / 16][KP]     this workgroup's share of d loss / d w_last (column K = its bias)
     int64_t npad;
 };
 
+// Layout of the backward launch (round 5): a workgroup owns SIXTEEN points and its four sweeps are STACKED two to a 32-row tile -- tile t, row R
+// holds sweep 2 t + (R >> 4) of point R & 15 -- so every v_mfma_f32_32x32x2_f32 still multiplies 32 full rows, the four sweeps of a (point, column)
+// still meet in ONE lane (accumulator registers i and i + 8 of the two tiles), and the workgroup needs 59 KB of LDS (three levels; 70 KB at five)
+// and < 256 registers instead of 118 KB and 360: TWO workgroups per CU, one wave of each per SIMD.  With one workgroup per CU nothing overlapped a
+// layer's element-wise pass, its operand-row stores or the prologue's gathers with the matrix pipe: 439 k cycles per 32 points of which 250 k were
+// MFMA issue (scripts/probe/k17_stamps_probe.py); now the other workgroup's products run under them.
+#define TR_MB 16
 template <int FE>
-__global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
-                                                       const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
-                                                       const float* __restrict__ y_bar, const float* __restrict__ g_bar,
-                                                       const float* __restrict__ s_bar, float4* __restrict__ stash, SdfTrainBwdOut O) {
+__global__ __launch_bounds__(256, 2) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
+                                                          const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                          const float* __restrict__ y_bar, const float* __restrict__ g_bar,
+                                                          const float* __restrict__ s_bar, float4* __restrict__ stash, SdfTrainBwdOut O) {
     constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 8) / 8 * 8, GIN = KP / 8, RS = KP + 4, FEP = KP - TR_H;
     constexpr int NT_B = 4 + ((FE + 31) / 32 <= 2 ? 2 : 4);      // 4 hidden tiles + the conditioning tiles, padded to 2 or 4 (zero columns: gens_sdf_train_pack)
-    constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
+    constexpr int XT = 32 * RS, PT = 32 * TR_PE_STRIDE;          // one stacked tile
+    constexpr int XS = TR_MB * RS, PS = TR_MB * TR_PE_STRIDE;    // from a sweep to the other sweep of its tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;              // [4][XT]
-    float* PE = X + 4 * XT;       // [4][PT]
-    float* YB = PE + 4 * PT;      // [32]
+    float* X = smem;              // [2][32][RS]
+    float* PE = X + 2 * XT;       // [2][32][TR_PE_STRIDE]
+    float* YB = PE + 2 * PT;      // [16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    const int64_t m0 = (int64_t)blockIdx.x * TR_MB;
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;      // (as the forward launch; operand rows past the count are never read)
-    if (m0 >= n) {
+    // the weight-gradient products read whole groups of 32 points (128 operand rows): the second half of the last group is computed (dead points:
+    // zero rows on one side of every product) even when none of its points exists
+    if (m0 >= (n + 31) / 32 * 32) {
         if (threadIdx.x < KP) O.w6_part[(int64_t)blockIdx.x * KP + threadIdx.x] = 0.0f;
         return;
     }
     const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
     const int col = 32 * wave + (lane & 31);
     const int64_t npad = O.npad;
+#ifdef GENS_K17_STAMPS
+    int n_stamp = 0;
+#endif
+    TR_STAMP();
 
-    // ------------------------------------------------------------------ prologue
+    // ------------------------------------------------------------------ prologue: threads 0..127 gather the levels, 128..255 encode the point
     {
-        const int p = tid >> 3, sub = tid & 7;
+        const int p = (tid & 127) >> 3, sub = tid & 7;
+        const bool enc = tid >= 128;
         const int64_t row = m0 + p;
         const bool live = row < n;
         float x[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
@@ -503,11 +532,11 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
                 gb[a] = g_bar ? g_bar[3 * src + a] : 0.0f;
             }
         }
-        if (sub == 6) YB[p] = (live && y_bar) ? y_bar[src] : 0.0f;
-        if (sub < 3) {
+        if (enc && sub == 6) YB[p] = (live && y_bar) ? y_bar[src] : 0.0f;
+        if (enc && sub < 3) {
             const int a = sub;
             float* p0 = PE + p * TR_PE_STRIDE;
-            float *p1 = p0 + PT, *p2 = p0 + 2 * PT, *p3 = p0 + 3 * PT;
+            float *p1 = p0 + PS, *p2 = p0 + PT, *p3 = p0 + PT + PS;
             p0[a] = x[a];
             p1[a] = 1.0f;
             p2[a] = gb[a];
@@ -534,21 +563,22 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
                 for (int k = TR_PE + 1; k < TR_PE_K; ++k) p0[k] = p1[k] = p2[k] = p3[k] = 0.0f;
             }
         }
-        if (sub == 7) {
+        if (enc && sub == 7) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                X[t * XT + p * RS + KIN] = t == 0 ? 1.0f : 0.0f;
+                float* xr = X + (t >> 1) * XT + (t & 1) * XS + p * RS;
+                xr[KIN] = t == 0 ? 1.0f : 0.0f;
 #pragma unroll
-                for (int k = KIN + 1; k < KP; ++k) X[t * XT + p * RS + k] = 0.0f;
+                for (int k = KIN + 1; k < KP; ++k) xr[k] = 0.0f;
             }
         }
-        if (sub < vols.n) {
+        if (!enc && sub < vols.n) {
             const int l = sub;
             const float dir[3][3] = {{1.0f, 1.0f, 1.0f}, {gb[0], gb[1], gb[2]}, {sb[0], sb[1], sb[2]}};
             float4 o[4], jac[3], mix[3];
             corner_sums<3, false>(vols, l, x, live, dir, o, jac, mix);
             float* x0 = X + p * RS + TR_H;
-            float *x1 = x0 + XT, *x2 = x0 + 2 * XT, *x3 = x0 + 3 * XT;
+            float *x1 = x0 + XS, *x2 = x0 + XT, *x3 = x0 + XT + XS;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ch = 4 * l + c;
@@ -569,32 +599,36 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
         }
     }
     __syncthreads();
-    // operand rows that are already complete: the conditioning parts and the inputs of layer 0
-    for (int i = tid; i < 4 * TR_M * FEP; i += 256) {
-        const int t = i / (TR_M * FEP), rem = i % (TR_M * FEP), row = rem / FEP, c = rem % FEP;
-        O.re[((m0 + row) * 4 + t) * FEP + c] = X[t * XT + row * RS + TR_H + c];
+    // operand rows that are already complete: the conditioning parts and the inputs of layer 0  (sweep t of point `row` = tile t >> 1, row 16 (t & 1) + row)
+    for (int i = tid; i < 4 * TR_MB * FEP; i += 256) {
+        const int t = i / (TR_MB * FEP), rem = i % (TR_MB * FEP), row = rem / FEP, c = rem % FEP;
+        O.re[((m0 + row) * 4 + t) * FEP + c] = X[(t >> 1) * XT + (t & 1) * XS + row * RS + TR_H + c];
     }
-    for (int i = tid; i < 4 * TR_M * 32; i += 256) {
-        const int t = i >> 10, row = (i >> 5) & 31, c = i & 31;
-        O.r0[((m0 + row) * 4 + t) * 32 + c] = PE[t * PT + row * TR_PE_STRIDE + c];
+    for (int i = tid; i < 4 * TR_MB * 32; i += 256) {
+        const int t = i >> 9, row = (i >> 5) & 15, c = i & 31;
+        O.r0[((m0 + row) * 4 + t) * 32 + c] = PE[(t >> 1) * PT + (t & 1) * PS + row * TR_PE_STRIDE + c];
     }
 
     // ------------------------------------------------------------------ forward sweeps: a, a', kappa_a, nu_a
     const int64_t sbase = (int64_t)blockIdx.x * TR_NLAYER;
     for (int l = 0; l < TR_NLAYER; ++l) {
-        f32x16 acc[4];
+        f32x16 acc[2];
         zero_acc(acc);
+        TR_STAMP();
         if (l == 0)
-            mfma_tiles<TR_PE_K / 8, 4>(PE + a_lane * TR_PE_STRIDE + a_half, PT, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
+            mfma_tiles<TR_PE_K / 8, 2>(PE + a_lane * TR_PE_STRIDE + a_half, PT, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
         else
-            mfma_tiles<GIN, 4>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
+            mfma_tiles<GIN, 2, TR_PF_B>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
+        TR_STAMP();
         __syncthreads();
-        float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+        TR_STAMP();
+        float4* st = stash + (((sbase + l) * 4 + wave) * 8) * 64 + lane;
         float* rh = O.rh + (((int64_t)l * npad + m0) * 4) * TR_H + col;       // inputs of layer l + 1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tr_acc_row(r, lane);
-            const float a = acc[0][r], ad = acc[1][r], ak = acc[2][r], an = acc[3][r];
+        for (int i = 0; i < 8; ++i) {
+#pragma clang fp contract(fast)
+            const int row = tr_acc_row(i, lane);                              // 0..15: the point; its other sweeps sit 16 rows / one tile further
+            const float a = acc[0][i], ad = acc[0][i + 8], ak = acc[1][i], an = acc[1][i + 8];
             float h, d1, d2, d3;
             softplus_d3(a, h, d1, d2, d3);
             (void)d3;
@@ -605,25 +639,27 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
                     h *= TR_SQ2; hd *= TR_SQ2; hk *= TR_SQ2; hn *= TR_SQ2;
                 } else {
                     const float* pe = PE + row * TR_PE_STRIDE + (col - TR_SKIP_H);
-                    h = pe[0] * TR_SQ2; hd = pe[PT] * TR_SQ2; hk = pe[2 * PT] * TR_SQ2; hn = pe[3 * PT] * TR_SQ2;
+                    h = pe[0] * TR_SQ2; hd = pe[PS] * TR_SQ2; hk = pe[PT] * TR_SQ2; hn = pe[PT + PS] * TR_SQ2;
                     keep = make_float4(TR_DEAD, 0.0f, 0.0f, 0.0f);
                 }
             }
             float* xr = X + row * RS + col;
-            xr[0] = h; xr[XT] = hd; xr[2 * XT] = hk; xr[3 * XT] = hn;
+            xr[0] = h; xr[XS] = hd; xr[XT] = hk; xr[XT + XS] = hn;
             if (l < 5) {   // (the inputs of the output row stay in LDS: its weight gradient is summed below)
                 float* gr = rh + (int64_t)row * 4 * TR_H;
                 gr[0] = h; gr[TR_H] = hd; gr[2 * TR_H] = hk; gr[3 * TR_H] = hn;
             }
-            st[r * 64] = keep;
+            st[i * 64] = keep;
         }
+        TR_STAMP();
         __syncthreads();
     }
+    TR_STAMP();
 
-    // d loss / d w_last = sum_points y_bar z_6 + kappa_z6 (the constant-1 column gives the bias): this workgroup's 32 points in row order
+    // d loss / d w_last = sum_points y_bar z_6 + kappa_z6 (the constant-1 column gives the bias): this workgroup's 16 points in row order
     if (tid < KP) {
         float s = 0.0f;
-        for (int row = 0; row < TR_M; ++row) s += YB[row] * X[row * RS + tid] + X[2 * XT + row * RS + tid];
+        for (int row = 0; row < TR_MB; ++row) s += YB[row] * X[row * RS + tid] + X[XT + row * RS + tid];
         O.w6_part[(int64_t)blockIdx.x * KP + tid] = s;
     }
 
@@ -632,31 +668,39 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
     const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
     const int fe_g0 = SPLIT_K ? 8 * (wave >> 1) : 0;
     constexpr int FE_G = SPLIT_K ? 8 : 16;
-    f32x16 gfe[4];
+    f32x16 gfe[2];
     zero_acc(gfe);
     const float wl_col = W.w_last[col];
     for (int l = 5; l >= 0; --l) {
         // cotangents of h_l: from the output row (l = 5) or from the reverse products of layer l + 1
-        f32x16 gh[4];
+        f32x16 gh[2];
         zero_acc(gh);
+        // this layer's parked state (a, a', nu_a, kappa_a), asked for BEFORE the products so that it arrives under them
+        const float4* st = stash + (((sbase + l) * 4 + wave) * 8) * 64 + lane;
+        float4 parked[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) parked[i] = st[i * 64];
+        TR_STAMP();
         if (l < 5) {
-            mfma_tiles<16, 4>(X + a_lane * RS + a_half, XT, W.wb[l + 1] + (size_t)wave * 16 * 64 + lane, gh);
-            mfma_tiles<FE_G, 4>(X + a_lane * RS + a_half + 8 * fe_g0, XT, W.wb[l + 1] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
+            mfma_tiles<16, 2, TR_PF_B>(X + a_lane * RS + a_half, XT, W.wb[l + 1] + (size_t)wave * 16 * 64 + lane, gh);
+            mfma_tiles<FE_G, 2, TR_PF_B>(X + a_lane * RS + a_half + 8 * fe_g0, XT, W.wb[l + 1] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
         }
+        TR_STAMP();
         __syncthreads();
-        const float4* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+        TR_STAMP();
         float* lop = O.lop + ((int64_t)m0 * 4 * TR_NLAYER + l) * TR_H + col;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tr_acc_row(r, lane);
+        for (int i = 0; i < 8; ++i) {
+#pragma clang fp contract(fast)
+            const int row = tr_acc_row(i, lane);
             float oh, rho_h, lh, mh;
             if (l == 5) {
                 oh = YB[row] * wl_col; rho_h = 0.0f; lh = wl_col; mh = 0.0f;
             } else {
-                oh = gh[0][r]; rho_h = gh[1][r]; lh = gh[2][r]; mh = gh[3][r];
+                oh = gh[0][i]; rho_h = gh[0][i + 8]; lh = gh[1][i]; mh = gh[1][i + 8];
                 if (l == 2) { oh *= TR_SQ2; rho_h *= TR_SQ2; lh *= TR_SQ2; mh *= TR_SQ2; }
             }
-            const float4 k = st[r * 64];                       // a, a', nu_a, kappa_a
+            const float4 k = parked[i];                        // a, a', nu_a, kappa_a
             float h, d1, d2, d3;
             softplus_d3(k.x, h, d1, d2, d3);
             (void)h;
@@ -665,48 +709,50 @@ __global__ __launch_bounds__(256) void sdf_train_bwd_k(SdfTrainWeights W, LevelS
             const float rho_a = d2 * k.z * lh + d1 * rho_h;
             const float om_a = d1 * oh + d3 * k.y * k.z * lh + d2 * (mh * k.z + k.y * rho_h + lh * k.w);
             float* xr = X + row * RS + col;
-            xr[0] = om_a; xr[XT] = rho_a; xr[2 * XT] = lam_a; xr[3 * XT] = mu_a;
+            xr[0] = om_a; xr[XS] = rho_a; xr[XT] = lam_a; xr[XT + XS] = mu_a;
             float* gr = lop + (int64_t)row * 4 * TR_NLAYER * TR_H;
             constexpr int qs = TR_NLAYER * TR_H;
             gr[0] = om_a; gr[qs] = rho_a; gr[2 * qs] = lam_a; gr[3 * qs] = mu_a;
         }
+        TR_STAMP();
         __syncthreads();
     }
-    // conditioning cotangents -> the (dead) h part of the four tiles
+    TR_STAMP();
+    // conditioning cotangents -> the (dead) h part of the four sweeps
     {
         const int c = 32 * (fe_tile - 4) + (lane & 31);
         if (c < FE && (!SPLIT_K || wave < 2)) {
             const float wl = W.w_last[TR_H + c];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = tr_acc_row(r, lane);
+            for (int i = 0; i < 8; ++i) {
+                const int row = tr_acc_row(i, lane);
                 float* xr = X + row * RS + c;
-                xr[0] = gfe[0][r] + YB[row] * wl;
-                xr[XT] = gfe[1][r];
-                xr[2 * XT] = gfe[2][r] + wl;
-                xr[3 * XT] = gfe[3][r];
+                xr[0] = gfe[0][i] + YB[row] * wl;
+                xr[XS] = gfe[0][i + 8];
+                xr[XT] = gfe[1][i] + wl;
+                xr[XT + XS] = gfe[1][i + 8];
             }
         }
         if (SPLIT_K) {
             __syncthreads();
             if (c < FE && wave >= 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* xr = X + tr_acc_row(r, lane) * RS + c;
-                    xr[0] += gfe[0][r]; xr[XT] += gfe[1][r]; xr[2 * XT] += gfe[2][r]; xr[3 * XT] += gfe[3][r];
+                for (int i = 0; i < 8; ++i) {
+                    float* xr = X + tr_acc_row(i, lane) * RS + c;
+                    xr[0] += gfe[0][i]; xr[XS] += gfe[0][i + 8]; xr[XT] += gfe[1][i]; xr[XT + XS] += gfe[1][i + 8];
                 }
             }
         }
     }
     __syncthreads();
-    {
+    if (tid < 128) {
         const int p = tid >> 3, sub = tid & 7;
         if (sub < vols.n) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ch = 4 * sub + c;
                 const float* x0 = X + p * RS;
-                const float *x1 = x0 + XT, *x2 = x0 + 2 * XT, *x3 = x0 + 3 * XT;
+                const float *x1 = x0 + XS, *x2 = x0 + XT, *x3 = x0 + XT + XS;
                 const float s1 = x0[TR_H + CF + ch], c1 = x0[TR_H + 2 * CF + ch], s2 = x0[TR_H + 3 * CF + ch], c2 = x0[TR_H + 4 * CF + ch];
                 const float fd = x1[TR_H + ch], kf = x2[TR_H + ch], nf = x3[TR_H + ch];
                 // E' = [1, c1, -s1, 2 c2, -2 s2], E'' = [0, -s1, -c1, -4 s2, -4 c2], E''' = [0, -c1, s1, -8 c2, 8 s2]
@@ -924,12 +970,12 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
 template <int FE>
 static constexpr size_t fwd_lds_bytes() {
     constexpr int CF = FE / 5, KP = (TR_H + FE + 8) / 8 * 8, RS = KP + 4;
-    return sizeof(float) * (2 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + 2 * TR_M * CF * 3 + 2 * TR_M * CF + TR_M * 8);
+    return sizeof(float) * (2 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + 2 * TR_M * CF * 3 + 2 * TR_M * CF);
 }
 template <int FE>
 static constexpr size_t bwd_lds_bytes() {
     constexpr int KP = (TR_H + FE + 8) / 8 * 8, RS = KP + 4;
-    return sizeof(float) * (4 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + TR_M);
+    return sizeof(float) * (2 * 32 * RS + 2 * 32 * TR_PE_STRIDE + TR_MB);
 }
 
 static int fill_train_weights(const char* who, SdfTrainWeights* W, const float* const* wf, const float* const* wb, const float* w_last,
@@ -945,7 +991,7 @@ static int fill_train_weights(const char* who, SdfTrainWeights* W, const float* 
     return 0;
 }
 
-extern "C" int64_t gens_sdf_train_stash_bytes(int64_t n, int backward) {
+extern "C" int64_t gens_sdf_train_stash_bytes(int64_t n, int backward) {       // (the same bytes either way: 32 points x 6 layers x 128 columns)
     return gens_blocks(n, TR_M) * (int64_t)TR_NLAYER * 4 * 16 * 64 * (backward ? 16 : 8);
 }
 
@@ -1015,8 +1061,8 @@ extern "C" int gens_sdf_train_bwd(const float* const* vols_packed, const int* di
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && lop && rh && re && r0 && f_hat && mu_f && lam_f && w6_part)), GENS_EINVAL,
                    "gens_sdf_train_bwd: null pts / stash / output");
     if (n == 0) return 0;
-    const unsigned grid = gens_blocks(n, TR_M);
-    SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, w6_part, (int64_t)grid * TR_M};
+    const unsigned grid = gens_blocks(n, TR_M) * (TR_M / TR_MB);        // workgroups of 16 points, in whole groups of 32 (the operand rows' granularity)
+    SdfTrainBwdOut O = {lop, rh, re, r0, f_hat, mu_f, lam_f, w6_part, (int64_t)grid * TR_MB};
     hipStream_t s = (hipStream_t)stream;
 #define TR_BWD(FE_)                                                                                                                                  \
     {                                                                                                                                               \
@@ -1126,3 +1172,9 @@ extern "C" int gens_sdf_train_wgrad(const float* const* v, const float* const* g
     sdf_train_wgrad_k<<<dim3(TR_H + 1, TR_NLAYER + 1), 64, 0, (hipStream_t)stream>>>(A);
     return gens_launch_status("gens_sdf_train_wgrad");
 }
+
+#ifdef GENS_K17_STAMPS
+extern "C" int gens_debug_k17_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k17_stamps), sizeof(unsigned long long) * 4 * 128) == hipSuccess ? 0 : -1;
+}
+#endif

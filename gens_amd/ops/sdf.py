@@ -631,7 +631,7 @@ class _SdfTrain(torch.autograd.Function):
         npad = (n + 31) // 32 * 32
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=_f32)  # noqa: E731
         lop, rh, re, r0 = f(npad, 4, 6, 128), f(5, npad, 4, 128), f(npad, 4, fep), f(npad, 4, 32)      # point-major operand rows
-        f_hat, mu_f, lam_f, w6p = f(npad, cf), f(npad, cf), f(npad, cf), f(npad // 32, step.kp)
+        f_hat, mu_f, lam_f, w6p = f(npad, cf), f(npad, cf), f(npad, cf), f(npad // 16, step.kp)     # (a row per 16-point workgroup of the launch)
         stash = torch.empty(L.load().gens_sdf_train_stash_bytes(n, 1), device=dev, dtype=torch.uint8)
         cot = [None if t is None else _c(t.to(_f32)) for t in (y_bar, g_bar, s_bar)]
         flops = 8 * 2 * (27 * 128 + (128 + fe) * (4 * 128 + 101 + 1))

@@ -41,13 +41,15 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-/* 9.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
+/* 10.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
  *   8 = round 4's additions, which shipped under the stale number 7: gens_grid_sample_{fwd,bwd,bwd2} (K20), gens_depthwise_conv2d_{fwd,dgrad,wgrad}
  *       + gens_depthwise_conv2d_wgrad_parts (K21), gens_batchnorm2d_train_{fwd,bwd} + gens_batchnorm2d_scratch_doubles (K22),
  *       gens_blend_train_bwd_acc + gens_blend_train_acc_{parts,floats}, gens_merge_upsample, gens_conv3d_wgrad_parts_strided, gens_instnorm_finish,
  *       gens_sdf_grad_stash_reset, gens_sdf_grad_f16_stash_reset, and gens_ray_points' `mid` / `sample_dist` arguments.
  *   9 = round 5: gens_composite_in gained `cos_anneal_dev` (the annealing ratio read from the device, so that a captured step can be replayed
- *       with another ratio) -- a struct-layout change: callers built against 8 must be rebuilt. */
+ *       with another ratio) -- a struct-layout change: callers built against 8 must be rebuilt.
+ *   10 = round 5: gens_sdf_train_bwd's w6_part has a row per SIXTEEN points (npad / 16 rows, was npad / 32): its workgroups own 16 points
+ *       now, two of them to a compute unit. */
 int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -420,7 +422,7 @@ int gens_grid_sample_bwd2(const float* gg_input, const float* gg_grid, const flo
  *       dL/dW_l[:, :128]  = lop[:, :, l, :]^T rh[l - 1]                  (l = 1..5; layer 3's columns are [h_2 | pe] / sqrt 2)
  *       dL/dW_l[:, 128:K] , dL/db_l = lop[:, :, l, :]^T re               (column K - 128 of re is the bias input)
  *       dL/dW_0, dL/db_0  = lop[:, :, 0, :]^T r0                         (column 27 = bias input)
- *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 32, KP): columns [0, K) and column K (zero rows for dead workgroups)
+ *       dL/dw_last, dL/db_last = column sums of w6_part (npad / 16, KP): columns [0, K) and column K (zero rows for dead workgroups)
  *     (gens_gemm_tn_batch runs the products in one launch) and f_hat, mu_f, lam_f (npad, 4 n_levels) for
  *     gens_sdf_train_scatter.  stash: gens_sdf_train_stash_bytes(n, 1) bytes.
  *   gens_sdf_train_scatter: adds dL/dvolume into g_vols[l] (planar (4, X, Y, Z), pre-zeroed or accumulating):
