@@ -163,25 +163,28 @@ __device__ __forceinline__ float f4_at(const float4& v, int c) { return c == 0 ?
 // ====================================================================================================================
 // forward launch: y, g = dy/dx, s = d(sum_k g_k)/dx
 // ====================================================================================================================
+// (round 5) SIXTEEN points per workgroup, value and tangent sweep STACKED in one 32-row tile (rows 0-15 / 16-31), as the backward launch below:
+// 40 KB of LDS (50 KB at five levels) and < 168 registers, three workgroups per CU instead of two.
+#define TR_MB 16
 template <int FE>
-__global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
-                                                       const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
-                                                       float2* __restrict__ stash, float* __restrict__ y_out, float* __restrict__ g_out,
-                                                       float* __restrict__ s_out) {
+__global__ __launch_bounds__(256, 3) void sdf_train_fwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
+                                                          const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                          float2* __restrict__ stash, float* __restrict__ y_out, float* __restrict__ g_out,
+                                                          float* __restrict__ s_out) {
     constexpr int CF = FE / 5, KIN = TR_H + FE, KP = (KIN + 8) / 8 * 8, GIN = KP / 8, RS = KP + 4;
     static_assert(KP > KIN, "a pad column carries the bias");
     constexpr int NT_B = 4 + ((FE + 31) / 32 <= 2 ? 2 : 4);      // 4 hidden tiles + the conditioning tiles, padded to 2 or 4 (zero columns: gens_sdf_train_pack)
-    constexpr int XT = TR_M * RS, PT = TR_M * TR_PE_STRIDE;
+    constexpr int XS = TR_MB * RS, PS = TR_MB * TR_PE_STRIDE;    // from a point's value row to its tangent row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;                       // [2][XT]: value tile [h | e | 1 | 0], tangent tile [h' | e' | 0]; h part reused by the reverse sweeps
-    float* PE = X + 2 * XT;                // [2][PT]: point encoding and its tangent
-    float* GPE = PE + 2 * PT;              // [2][PT]: lambda / mu with respect to the point encoding
-    float* JAC = GPE + 2 * PT;             // [32][CF][3] df/dx ; then [32][CF][3] sum_b d2f/dx dx_b
-    float* LF = JAC + 2 * TR_M * CF * 3;   // [2][32][CF]: lambda_f, mu_f
-    float* RED = GPE;                      // [32][8]: the output row's partial sums, dead before the reverse sweeps write GPE (80 KB -> 79 KB: two workgroups per CU at three levels)
+    float* X = smem;                        // [32][RS]: value rows [h | e | 1 | 0], tangent rows [h' | e' | 0]; h part reused by the reverse sweeps
+    float* PE = X + 32 * RS;                // [32][TR_PE_STRIDE]: point encoding and its tangent
+    float* GPE = PE + 32 * TR_PE_STRIDE;    // [32][TR_PE_STRIDE]: lambda / mu with respect to the point encoding
+    float* JAC = GPE + 32 * TR_PE_STRIDE;   // [16][CF][3] df/dx ; then [16][CF][3] sum_b d2f/dx dx_b
+    float* LF = JAC + 2 * TR_MB * CF * 3;   // [2][16][CF]: lambda_f, mu_f
+    float* RED = GPE;                       // [16][8]: the output row's partial sums, dead before the reverse sweeps write GPE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * TR_M;
+    const int64_t m0 = (int64_t)blockIdx.x * TR_MB;
     // point i of the launch is pts[index[i]] (NULL: i) and its results go to row index[i] of the outputs; only the first min(n_max, *n_dev)
     // points exist (the masked evaluation of implicit_surface.py:174-191 without a host-side count): later workgroups leave at once
     const int64_t n = n_dev ? min(n_max, (int64_t)n_dev[0]) : n_max;
@@ -189,9 +192,10 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
     const int a_lane = lane & 31, a_half = 4 * (lane >> 5);
     const int col = 32 * wave + (lane & 31);
 
-    // ------------------------------------------------------------------ prologue
+    // ------------------------------------------------------------------ prologue: threads 0..127 gather the levels, 128..255 encode the point
     {
-        const int p = tid >> 3, sub = tid & 7;
+        const int p = (tid & 127) >> 3, sub = tid & 7;
+        const bool enc = tid >= 128;
         const int64_t row = m0 + p;
         const bool live = row < n;
         float x[3] = {0.f, 0.f, 0.f};
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
             const int64_t src = index ? index[row] : row;
             x[0] = pts[3 * src]; x[1] = pts[3 * src + 1]; x[2] = pts[3 * src + 2];
         }
-        if (sub < 3) {
+        if (enc && sub < 3) {
             const int a = sub;
             float* pe = PE + p * TR_PE_STRIDE;
-            float* pd = pe + PT;
+            float* pd = pe + PS;
             pe[a] = x[a];
             pd[a] = 1.0f;
 #pragma unroll
@@ -222,19 +226,19 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
                 for (int k = TR_PE + 1; k < TR_PE_K; ++k) { pe[k] = 0.0f; pd[k] = 0.0f; }
             }
         }
-        if (sub == 7) {
+        if (enc && sub == 7) {
             X[p * RS + KIN] = 1.0f;
-            X[XT + p * RS + KIN] = 0.0f;
+            X[XS + p * RS + KIN] = 0.0f;
 #pragma unroll
-            for (int k = KIN + 1; k < KP; ++k) { X[p * RS + k] = 0.0f; X[XT + p * RS + k] = 0.0f; }
+            for (int k = KIN + 1; k < KP; ++k) { X[p * RS + k] = 0.0f; X[XS + p * RS + k] = 0.0f; }
         }
-        if (sub < vols.n) {
+        if (!enc && sub < vols.n) {
             const int l = sub;
             const float dir[1][3] = {{1.0f, 1.0f, 1.0f}};
             float4 o[2], jac[3], mix[3];
             corner_sums<1, true>(vols, l, x, live, dir, o, jac, mix);
             float* xr = X + p * RS + TR_H;
-            float* xd = xr + XT;
+            float* xd = xr + XS;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ch = 4 * l + c;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
                 xr[ch] = f; xr[CF + ch] = s1; xr[2 * CF + ch] = c1; xr[3 * CF + ch] = s2; xr[4 * CF + ch] = c2;
                 xd[ch] = fd; xd[CF + ch] = c1 * fd; xd[2 * CF + ch] = -s1 * fd; xd[3 * CF + ch] = 2.0f * c2 * fd; xd[4 * CF + ch] = -2.0f * s2 * fd;
                 float* j = JAC + (p * CF + ch) * 3;
-                float* jd = j + TR_M * CF * 3;
+                float* jd = j + TR_MB * CF * 3;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { j[a] = f4_at(jac[a], c); jd[a] = f4_at(mix[a], c); }
             }
@@ -256,41 +260,41 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
     // ------------------------------------------------------------------ forward sweeps: value + tangent
     const int64_t sbase = (int64_t)blockIdx.x * TR_NLAYER;
     for (int l = 0; l < TR_NLAYER; ++l) {
-        f32x16 acc[2];
+        f32x16 acc[1];
         zero_acc(acc);
         if (l == 0)
-            mfma_tiles<TR_PE_K / 8, 2>(PE + a_lane * TR_PE_STRIDE + a_half, PT, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
+            mfma_tiles<TR_PE_K / 8, 1>(PE + a_lane * TR_PE_STRIDE + a_half, 0, W.wf[0] + (size_t)wave * (TR_PE_K / 8) * 64 + lane, acc);
         else
-            mfma_tiles<GIN, 2>(X + a_lane * RS + a_half, XT, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
+            mfma_tiles<GIN, 1>(X + a_lane * RS + a_half, 0, W.wf[l] + (size_t)wave * GIN * 64 + lane, acc);
         __syncthreads();
-        float2* st = stash + (((sbase + l) * 4 + wave) * 16) * 64 + lane;
+        float2* st = stash + (((sbase + l) * 4 + wave) * 8) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tr_acc_row(r, lane);
+        for (int i = 0; i < 8; ++i) {
+            const int row = tr_acc_row(i, lane);                 // 0..15: the point; its tangent sits 16 rows further (accumulator register i + 8)
             float h, d1, d2, d3;
-            softplus_d3(acc[0][r], h, d1, d2, d3);
+            softplus_d3(acc[0][i], h, d1, d2, d3);
             (void)d3;
-            float hd = d1 * acc[1][r];
-            float2 keep = make_float2(d1, d2 * acc[1][r]);
+            float hd = d1 * acc[0][i + 8];
+            float2 keep = make_float2(d1, d2 * acc[0][i + 8]);
             if (l == 2) {   // z_3 = [h_2 | pe] / sqrt(2)   (sdf_network.py:111-112)
                 if (col < TR_SKIP_H) {
                     h *= TR_SQ2;
                     hd *= TR_SQ2;
                 } else {
                     h = PE[row * TR_PE_STRIDE + (col - TR_SKIP_H)] * TR_SQ2;
-                    hd = PE[PT + row * TR_PE_STRIDE + (col - TR_SKIP_H)] * TR_SQ2;
+                    hd = PE[PS + row * TR_PE_STRIDE + (col - TR_SKIP_H)] * TR_SQ2;
                     keep = make_float2(0.0f, 0.0f);
                 }
             }
             X[row * RS + col] = h;
-            X[XT + row * RS + col] = hd;
-            st[r * 64] = keep;
+            X[XS + row * RS + col] = hd;
+            st[i * 64] = keep;
         }
         __syncthreads();
     }
 
     // ------------------------------------------------------------------ layer 6, sdf row only
-    {
+    if (tid < 128) {
         const int p = tid >> 3, sub = tid & 7;
         const float* xr = X + p * RS;
         float s = 0.0f;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
         RED[p * 8 + sub] = s;
     }
     __syncthreads();
-    if (tid < TR_M) {
+    if (tid < TR_MB) {
         const int64_t row = m0 + tid;
         if (row < n) {
             float s = W.b_last[0];
@@ -313,118 +317,118 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
     const int fe_tile = SPLIT_K ? 4 + (wave & 1) : 4 + wave;
     const int fe_g0 = SPLIT_K ? 8 * (wave >> 1) : 0;
     constexpr int FE_G = SPLIT_K ? 8 : 16;
-    f32x16 gfe[2];
+    f32x16 gfe[1];
     zero_acc(gfe);
     __syncthreads();
     {
         const float wl = W.w_last[col];
-        const float2* st = stash + (((sbase + 5) * 4 + wave) * 16) * 64 + lane;
+        const float2* st = stash + (((sbase + 5) * 4 + wave) * 8) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tr_acc_row(r, lane);
-            const float2 k = st[r * 64];
+        for (int i = 0; i < 8; ++i) {
+            const int row = tr_acc_row(i, lane);
+            const float2 k = st[i * 64];
             X[row * RS + col] = k.x * wl;            // lambda_a5 = softplus' w6
-            X[XT + row * RS + col] = k.y * wl;       // mu_a5 = softplus'' a' w6
+            X[XS + row * RS + col] = k.y * wl;       // mu_a5 = softplus'' a' w6
         }
     }
     __syncthreads();
     for (int l = 5; l >= 1; --l) {
-        f32x16 gh[2];
+        f32x16 gh[1];
         zero_acc(gh);
-        mfma_tiles<16, 2>(X + a_lane * RS + a_half, XT, W.wb[l] + (size_t)wave * 16 * 64 + lane, gh);
-        mfma_tiles<FE_G, 2>(X + a_lane * RS + a_half + 8 * fe_g0, XT, W.wb[l] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
+        mfma_tiles<16, 1>(X + a_lane * RS + a_half, 0, W.wb[l] + (size_t)wave * 16 * 64 + lane, gh);
+        mfma_tiles<FE_G, 1>(X + a_lane * RS + a_half + 8 * fe_g0, 0, W.wb[l] + ((size_t)fe_tile * 16 + fe_g0) * 64 + lane, gfe);
         __syncthreads();
-        const float2* st = stash + (((sbase + (l - 1)) * 4 + wave) * 16) * 64 + lane;
+        const float2* st = stash + (((sbase + (l - 1)) * 4 + wave) * 8) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tr_acc_row(r, lane);
-            float lh = gh[0][r], mh = gh[1][r];
+        for (int i = 0; i < 8; ++i) {
+            const int row = tr_acc_row(i, lane);
+            float lh = gh[0][i], mh = gh[0][i + 8];
             if (l == 3) {
                 lh *= TR_SQ2;
                 mh *= TR_SQ2;
                 if (col >= TR_SKIP_H) {
                     GPE[row * TR_PE_STRIDE + (col - TR_SKIP_H)] = lh;
-                    GPE[PT + row * TR_PE_STRIDE + (col - TR_SKIP_H)] = mh;
+                    GPE[PS + row * TR_PE_STRIDE + (col - TR_SKIP_H)] = mh;
                 }
             }
-            const float2 k = st[r * 64];
+            const float2 k = st[i * 64];
             X[row * RS + col] = k.x * lh;
-            X[XT + row * RS + col] = k.y * lh + k.x * mh;
+            X[XS + row * RS + col] = k.y * lh + k.x * mh;
         }
         __syncthreads();
     }
     // layer 0: (32 x 128) x (128 x 27); the four waves split the reduction, partial tiles summed in a fixed order
     {
-        f32x16 gp[2];
+        f32x16 gp[1];
         zero_acc(gp);
-        mfma_tiles<4, 2>(X + a_lane * RS + a_half + 32 * wave, XT, W.wb[0] + (size_t)(4 * wave) * 64 + lane, gp);
+        mfma_tiles<4, 1>(X + a_lane * RS + a_half + 32 * wave, 0, W.wb[0] + (size_t)(4 * wave) * 64 + lane, gp);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            X[tr_acc_row(r, lane) * RS + col] = gp[0][r];
-            X[XT + tr_acc_row(r, lane) * RS + col] = gp[1][r];
+        for (int i = 0; i < 8; ++i) {
+            X[tr_acc_row(i, lane) * RS + col] = gp[0][i];
+            X[XS + tr_acc_row(i, lane) * RS + col] = gp[0][i + 8];
         }
         __syncthreads();
-        for (int i = tid; i < 2 * TR_M * 32; i += 256) {
-            const int t = i >> 10, row = (i >> 5) & 31, c = i & 31;
+        for (int i = tid; i < 2 * TR_MB * 32; i += 256) {
+            const int t = i >> 9, row = (i >> 5) & 15, c = i & 31;
             if (c < TR_PE) {
-                const float* xr = X + t * XT + row * RS + c;
-                GPE[t * PT + row * TR_PE_STRIDE + c] += ((xr[0] + xr[32]) + xr[64]) + xr[96];
+                const float* xr = X + t * XS + row * RS + c;
+                GPE[t * PS + row * TR_PE_STRIDE + c] += ((xr[0] + xr[32]) + xr[64]) + xr[96];
             }
         }
     }
     __syncthreads();
-    // conditioning adjoints -> the (dead) h part of the two tiles
+    // conditioning adjoints -> the (dead) h part of the two sweeps
     {
         const int c = 32 * (fe_tile - 4) + (lane & 31);
         if (c < FE && (!SPLIT_K || wave < 2)) {
             const float wl = W.w_last[TR_H + c];      // layer 6 adds the same vector for every point; its tangent is zero
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                X[tr_acc_row(r, lane) * RS + c] = gfe[0][r] + wl;
-                X[XT + tr_acc_row(r, lane) * RS + c] = gfe[1][r];
+            for (int i = 0; i < 8; ++i) {
+                X[tr_acc_row(i, lane) * RS + c] = gfe[0][i] + wl;
+                X[XS + tr_acc_row(i, lane) * RS + c] = gfe[0][i + 8];
             }
         }
         if (SPLIT_K) {
             __syncthreads();
             if (c < FE && wave >= 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    X[tr_acc_row(r, lane) * RS + c] += gfe[0][r];
-                    X[XT + tr_acc_row(r, lane) * RS + c] += gfe[1][r];
+                for (int i = 0; i < 8; ++i) {
+                    X[tr_acc_row(i, lane) * RS + c] += gfe[0][i];
+                    X[XS + tr_acc_row(i, lane) * RS + c] += gfe[0][i + 8];
                 }
             }
         }
     }
     __syncthreads();
-    {   // lambda_f = E'^T lambda_e ; mu_f = E'^T mu_e + E''[f'] lambda_e
+    if (tid < 128) {   // lambda_f = E'^T lambda_e ; mu_f = E'^T mu_e + E''[f'] lambda_e
         const int p = tid >> 3, sub = tid & 7;
         if (sub < vols.n) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ch = 4 * sub + c;
                 const float* e = X + p * RS + TR_H;           // [f, sin f, cos f, sin 2f, cos 2f]
-                const float fd = X[XT + p * RS + TR_H + ch];
+                const float fd = X[XS + p * RS + TR_H + ch];
                 const float s1 = e[CF + ch], c1 = e[2 * CF + ch], s2 = e[3 * CF + ch], c2 = e[4 * CF + ch];
                 const float* le = X + p * RS;
-                const float* me = le + XT;
+                const float* me = le + XS;
                 const float l0 = le[ch], l1 = le[CF + ch], l2 = le[2 * CF + ch], l3 = le[3 * CF + ch], l4 = le[4 * CF + ch];
                 const float lam_f = l0 + c1 * l1 - s1 * l2 + 2.0f * (c2 * l3 - s2 * l4);
                 const float mu_f = me[ch] + c1 * me[CF + ch] - s1 * me[2 * CF + ch] + 2.0f * (c2 * me[3 * CF + ch] - s2 * me[4 * CF + ch]) -
                                    fd * (s1 * l1 + c1 * l2 + 4.0f * (s2 * l3 + c2 * l4));
                 LF[p * CF + ch] = lam_f;
-                LF[TR_M * CF + p * CF + ch] = mu_f;
+                LF[TR_MB * CF + p * CF + ch] = mu_f;
             }
         }
     }
     __syncthreads();
-    if (tid < TR_M * 3) {
+    if (tid < TR_MB * 3) {
         const int p = tid / 3, a = tid % 3;
         const int64_t row = m0 + p;
         if (row < n) {
             const float* pe = PE + p * TR_PE_STRIDE;
             const float* lp = GPE + p * TR_PE_STRIDE;
-            const float* mp = lp + PT;
+            const float* mp = lp + PS;
             float g = lp[a], s = mp[a];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -435,9 +439,9 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_k(SdfTrainWeights W, LevelS
                 s += f * (mp[3 + 6 * k + a] * C - mp[6 + 6 * k + a] * S) - f * f * (ls * S + lc * C);
             }
             const float* j = JAC + p * CF * 3;
-            const float* jd = j + TR_M * CF * 3;
+            const float* jd = j + TR_MB * CF * 3;
             const float* lf = LF + p * CF;
-            const float* mf = lf + TR_M * CF;
+            const float* mf = lf + TR_MB * CF;
             for (int c = 0; c < CF; ++c) {
                 g += j[c * 3 + a] * lf[c];
                 s += jd[c * 3 + a] * lf[c] + j[c * 3 + a] * mf[c];
@@ -484,7 +488,6 @@ struct SdfTrainBwdOut {
 // and < 256 registers instead of 118 KB and 360: TWO workgroups per CU, one wave of each per SIMD.  With one workgroup per CU nothing overlapped a
 // layer's element-wise pass, its operand-row stores or the prologue's gathers with the matrix pipe: 439 k cycles per 32 points of which 250 k were
 // MFMA issue (scripts/probe/k17_stamps_probe.py); now the other workgroup's products run under them.
-#define TR_MB 16
 template <int FE>
 __global__ __launch_bounds__(256, 2) void sdf_train_bwd_k(SdfTrainWeights W, LevelSet vols, const float* __restrict__ pts,
                                                           const int64_t* __restrict__ index, int64_t n_max, const int32_t* __restrict__ n_dev,
@@ -970,7 +973,7 @@ int gens_fill_levels(const char* who, LevelSet* ls, const float* const* data, co
 template <int FE>
 static constexpr size_t fwd_lds_bytes() {
     constexpr int CF = FE / 5, KP = (TR_H + FE + 8) / 8 * 8, RS = KP + 4;
-    return sizeof(float) * (2 * TR_M * RS + 4 * TR_M * TR_PE_STRIDE + 2 * TR_M * CF * 3 + 2 * TR_M * CF);
+    return sizeof(float) * (32 * RS + 2 * 32 * TR_PE_STRIDE + 2 * TR_MB * CF * 3 + 2 * TR_MB * CF);
 }
 template <int FE>
 static constexpr size_t bwd_lds_bytes() {
@@ -1030,7 +1033,7 @@ extern "C" int gens_sdf_train_fwd(const float* const* vols_packed, const int* di
     GENS_CHECK_ARG(b_last, GENS_EINVAL, "gens_sdf_train_fwd: null b_last");
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && stash && y_out && g_out && s_out)), GENS_EINVAL, "gens_sdf_train_fwd: null pts / stash / output");
     if (n == 0) return 0;
-    const unsigned grid = gens_blocks(n, TR_M);
+    const unsigned grid = gens_blocks(n, TR_MB);
     hipStream_t s = (hipStream_t)stream;
 #define TR_FWD(FE_)                                                                                                                         \
     {                                                                                                                                      \
