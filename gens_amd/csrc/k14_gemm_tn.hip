@@ -140,7 +140,7 @@ __device__ __forceinline__ bool gemm_tn_batch_unit(int n_wg, int64_t n_slabs, in
     const int64_t per_octet = 8 * (int64_t)n_wg, octet = blockIdx.x / per_octet;
     const int in_octet = (int)(blockIdx.x - octet * per_octet);
     s = 8 * octet + (in_octet & 7);
-    t = 4 * (in_octet >> 3) + (int)(threadIdx.x >> 6);
+    t = 4 * (in_octet >> 3) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave's number as a SCALAR: everything derived from the unit -- product, strides, descriptors -- stays in SGPRs)
     return s < n_slabs && t < tiles;
 }
 
@@ -228,45 +228,65 @@ __global__ __launch_bounds__(256) void gemm_tn_batch2_partial_k(GemmTnBatch B, i
     // four row pairs per trip, their eight loads issued together -- and ONE TRIP AHEAD of the products that use them (two register sets): a trip's
     // sixteen MFMAs are 1 024 cycles of work, a load under this traffic takes longer, and the waves of a SIMD could not cover the difference
     // (matrix pipe 57 % busy, waves waiting 76 % of their time with the loads issued at the top of their own trip).
-#define K14_LOAD(AV, BV)                                     \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {          \
-        AV[q] = ap[(int64_t)q * sa];                         \
-        BV[q] = bp[(int64_t)q * sb];                         \
-    }                                                        \
-    ap += 4 * sa;                                            \
-    bp += 4 * sb;
+    // Round 5: the loads go through buffer descriptors -- a lane's byte offset is ONE register for the whole slab, the row of a load is a scalar
+    // offset -- and the operands of rows / columns outside the matrix are no longer zeroed per product (such a lane reads column 0 and its outer-product
+    // rows / columns of the accumulators are never stored): 179 -> <= 128 registers, four waves per SIMD instead of two.
+    typedef float k14_f2 __attribute__((ext_vector_type(2)));
+    const uint32_t slab_rows = (uint32_t)(k_end - k_begin);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(B.a[p] + k_begin * lda), 0, (int)(slab_rows * (uint32_t)lda * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B.b[p] + k_begin * ldb), 0, (int)(slab_rows * (uint32_t)ldb * 4u), 0x00020000);
+    const uint32_t va = ((uint32_t)h * (uint32_t)lda + (uint32_t)(am ? m0 + 2 * i : 0)) * 4u, vb = ((uint32_t)h * (uint32_t)ldb + (uint32_t)(bn ? n0 + 2 * i : 0)) * 4u;
+    const uint32_t pa = 8u * (uint32_t)lda, pb = 8u * (uint32_t)ldb;           // bytes from a row pair to the next
+    uint32_t oa = 0u, ob = 0u;                                                  // (scalar) byte offset of the next row pair to load
+#define K14_LOAD(AV, BV)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+        AV[q] = __builtin_bit_cast(k14_f2, __builtin_amdgcn_raw_buffer_load_b64(ra, va, oa + (uint32_t)q * pa, 0));   \
+        BV[q] = __builtin_bit_cast(k14_f2, __builtin_amdgcn_raw_buffer_load_b64(rb, vb, ob + (uint32_t)q * pb, 0));   \
+    }                                                                                                          \
+    oa += 4u * pa;                                                                                             \
+    ob += 4u * pb;
 #define K14_MULT(AV, BV)                                                                                                                 \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                      \
-        const float a0 = am ? AV[q].x : 0.0f, a1 = am ? AV[q].y : 0.0f, b0 = bn ? BV[q].x : 0.0f, b1 = bn ? BV[q].y : 0.0f;              \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);                                                    \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);                                                    \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);                                                    \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);                                                    \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].x, BV[q].x, acc[0][0], 0, 0, 0);                                          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].x, BV[q].y, acc[0][1], 0, 0, 0);                                          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].y, BV[q].x, acc[1][0], 0, 0, 0);                                          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].y, BV[q].y, acc[1][1], 0, 0, 0);                                          \
     }
-    if (k + 8 <= k_end) {
-        float2 av0[4], bv0[4], av1[4], bv1[4];
-        K14_LOAD(av0, bv0)
-        for (; k + 24 <= k_end; k += 16) {                             // (this trip's set is loaded, the next two fit)
-            K14_LOAD(av1, bv1)
-            __builtin_amdgcn_sched_barrier(0);
-            K14_MULT(av0, bv0)
-            K14_LOAD(av0, bv0)
-            __builtin_amdgcn_sched_barrier(0);
-            K14_MULT(av1, bv1)
+    // Three register sets, a set loaded TWO products (32 MFMAs, 2 048 cycles) before it is multiplied; every LOAD / MULT pinned in place (the
+    // scheduler otherwise pulls the later loads to the top of the trip and the counter wait of the second product then covers them too -- an
+    // effective distance of one product, 1 024 cycles, less than an L2 round trip under this traffic).
+#define K14_STEP(LD, MU)                      \
+    K14_LOAD(a##LD, b##LD)                    \
+    __builtin_amdgcn_sched_barrier(0);        \
+    K14_MULT(a##MU, b##MU)                    \
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int n8 = (int)((k_end - k_begin) >> 3);                  // whole 8-row steps of the slab
+        k14_f2 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+        if (n8 >= 1) { K14_LOAD(a0, b0) }
+        if (n8 >= 2) { K14_LOAD(a1, b1) }
+        int step = 0;
+        for (; step + 5 <= n8; step += 3) {                            // sets 0 and 1 hold steps `step` and `step + 1`
+            K14_STEP(2, 0)
+            K14_STEP(0, 1)
+            K14_STEP(1, 2)
         }
-        if (k + 16 <= k_end) {
-            K14_LOAD(av1, bv1)
-            __builtin_amdgcn_sched_barrier(0);
-            K14_MULT(av0, bv0)
-            K14_MULT(av1, bv1)
-            k += 16;
-        } else {
-            K14_MULT(av0, bv0)
-            k += 8;
-        }
+        const int r = n8 - step;                                       // 0 .. 4 steps left, the first two of them loaded
+        if (r >= 3) { K14_LOAD(a2, b2) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r >= 1) { K14_MULT(a0, b0) }
+        if (r == 4) { K14_LOAD(a0, b0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r >= 2) { K14_MULT(a1, b1) }
+        if (r >= 3) { K14_MULT(a2, b2) }
+        if (r == 4) { K14_MULT(a0, b0) }
+        k = k_begin + 8 * (int64_t)n8;
     }
+#undef K14_STEP
 #undef K14_LOAD
 #undef K14_MULT
+    ap += (k - k_begin) / 2 * sa;                                       // (the tail walks pointers: row pairs, sa float2 = 2 rows)
+    bp += (k - k_begin) / 2 * sb;
     for (; k < k_end; k += 2) {
         const bool row = k + h < k_end;
         float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
