@@ -471,8 +471,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int yy = y0 - 1 + (q_row[it] >> 3);
-            const uint32_t off = (q_ok[it] && (unsigned)xq < (unsigned)g.x) ? (uint32_t)(((xq * g.y + yy) * g.z + z0 + 4 * q_f4[it]) * 4) : CONV_OOB;
-            qv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, off, q_soff[it], 0));
+            // (the channel's offset in the LANE offset: as the load's scalar operand it differs across the lanes -> a readfirstlane loop per load)
+            const uint32_t off = (q_ok[it] && (unsigned)xq < (unsigned)g.x) ? (uint32_t)(((xq * g.y + yy) * g.z + z0 + 4 * q_f4[it]) * 4) + q_soff[it] : CONV_OOB;
+            qv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, off, 0, 0));
         }
     };
     auto store_q = [&](int xq) {
@@ -487,11 +488,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int yy = y0 + (p_row[it] >> 3);
-            const uint32_t off = p_ok[it] ? (uint32_t)(((xp * g.y + yy) * g.z + z0 + 4 * p_f4[it]) * 4) : CONV_OOB;
-            pv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, p_soff[it], 0));
+            const uint32_t off = p_ok[it] ? (uint32_t)(((xp * g.y + yy) * g.z + z0 + 4 * p_f4[it]) * 4) + p_soff[it] : CONV_OOB;
+            pv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, 0, 0));
         }
-        const uint32_t hoff = h_ok ? (uint32_t)(((xp * g.y + y0 + (h_row >> 3)) * g.z + h_z) * 4) : CONV_OOB;
-        hv = conv_load(pr, hoff, h_soff);
+        const uint32_t hoff = h_ok ? (uint32_t)(((xp * g.y + y0 + (h_row >> 3)) * g.z + h_z) * 4) + h_soff : CONV_OOB;
+        hv = conv_load(pr, hoff, 0);
     };
     auto store_p = [&]() {
 #pragma unroll
@@ -561,20 +562,199 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// wgrad on the matrix cores, STRIDE 2 (coarse z a multiple of 64): dW[a][b][tx][ty][tz] = sum_o P[a][o] Q[b][2 o + t - 1].  Along z the three taps
+// read the EVEN fine voxels (tz = 1: Q[2 o]) and the ODD ones (tz = 2: Q[2 o + 1]; tz = 0: Q[2 o - 1] = the odd voxel of o - 1), so with the fine
+// rows stored de-interleaved in LDS -- [odd | even] per row and z segment -- the reduction index m runs over the segment's coarse z with unit stride:
+//     D_e[(a, s)][(b, par)] += sum_m  P[a][m + s]  *  Q_par[b][2 x + tx - 1][2 y + ty - 1][m]
+//         (s, par) = (0, even) -> tz = 1,  (0, odd) -> tz = 2,  (1, odd) -> tz = 0,  (1, even) -> not a tap (a quarter of the products)
+// Rows i = (a, s): SIXTEEN channels of P x {P, P shifted by one}; columns j = (b, par, u): eight channels of Q x {even, odd} x two of the nine
+// (tx, ty) combinations: five products per reduction step cover the nine (the tenth slot repeats the ninth and is dropped) -- 67 % of the
+// MFMA's products are taps, against the 29 TFLOP/s of the vector-ALU kernel.  The z sum is partitioned by the Q position (a segment owns fine z
+// [2 z0, 2 z0 + 2 ZC); the P halo P[z0 + ZC] supplies the neighbouring segment's voxel of the tz = 0 tap), x and y by the P position.
+// A workgroup = four waves = four consecutive coarse y of one z segment, marching along coarse x: the three fine x planes of a step (nine fine y
+// rows x eight channels x 2 ZC z) live in LDS as a ring by (fine x) mod 3 -- a step brings TWO new planes, loaded as 16-byte buffer reads into
+// registers while the previous step multiplies (out-of-volume rows: out-of-range offsets, the hardware returns the zero padding).
+// Measured (scripts/probe/wgrad2_ab.py, 16 x 8 channels at coarse 128^3, the U-Net's first down / last up convolution): vector-ALU kernel 0.99 ms;
+// ZC = 64, one workgroup per CU 0.44 ms; the loads' channel offset moved from the scalar operand (a readfirstlane loop per load!) into the lane
+// offset 0.375; ZC = 32, two workgroups per CU 0.29 ms = 50 TFLOP/s of taps.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// ZC = coarse z per segment: 64, or 32 -- 75 KB of LDS instead of 130: TWO workgroups per CU, so that one's loads, LDS stores and barriers run under
+// the other's products (with one workgroup a step took 26 k cycles for 10 k cycles of MFMA issue).
+// LDS row of Q: [odd ZC][1][even ZC] -- the even half ZC + 1 floats on, so that a column's two parities sit in neighbouring banks (64 on = the SAME
+// bank: a two-way conflict on every B read); pitch 2 ZC + 3 = 3 mod 64 across the rows a wave reads.
+#define W2_PP 67            // P row: ZC + the halo (67 = 3 mod 64 for either ZC)
+template <int ZC>
+__global__ __launch_bounds__(256, ZC == 32 ? 2 : 1) void conv3d_wgrad2_mfma_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int y_blocks, int z_segs,
+                                                            int xc, float* __restrict__ ws) {
+    constexpr int W2_QP = 2 * ZC + 3, NF = ZC / 2, NQ = (72 * NF + 255) / 256, NPF = ZC / 4, NP = 64 * NPF / 256;
+    extern __shared__ __attribute__((aligned(16))) float w2_lds[];
+    float* Ql = w2_lds;                                   // [3][9][8][W2_QP]
+    float* Pl = w2_lds + 3 * 9 * 8 * W2_QP;               // [4][16][W2_PP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = g.cqp / 8, n_col = ((g.cpp + 15) / 16) * nqb;
+    const int part = (int)blockIdx.x / n_col, col = (int)blockIdx.x % n_col;
+    const int pb = (col / nqb) * 16, qb = (col % nqb) * 8;
+    const int zs = part % z_segs, yb = (part / z_segs) % y_blocks, xk = part / (z_segs * y_blocks);
+    const int z0 = zs * ZC, y0 = yb * 4, x0 = xk * xc, x1 = min(x0 + xc, g.x);
+    const int qx = 2 * g.x, qy = 2 * g.y, qz = 2 * g.z;
+    const uint32_t pn_bytes = (uint32_t)g.x * g.y * g.z * 4u, qn_bytes = 8u * pn_bytes;
+    const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * qx * qy * qz);
+    const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * g.x * g.y * g.z);
+
+    // ---- this thread's share of a plane of Q (72 rows x NF float4) and of a step's P rows (64 rows x NPF float4, + a halo float)
+    uint32_t q_off[NQ];                                    // byte offset inside a fine x plane, or out of range
+    uint32_t q_soff[NQ];
+    int q_dst[NQ];                                         // LDS float index inside a ring slot: row * W2_QP + 2 * f4   (odd part; even part 64 further)
+#pragma unroll
+    for (int it = 0; it < NQ; ++it) {
+        const int idx = tid + 256 * it, row = idx / NF, f4 = idx % NF;          // row = fy row * 8 + b
+        const int fy = 2 * y0 - 1 + (row >> 3), b = row & 7;
+        const bool ok = idx < 72 * NF && (unsigned)fy < (unsigned)qy && qb + b < g.cq;
+        q_off[it] = ok ? (uint32_t)((fy * qz + 2 * z0 + 4 * f4) * 4) : CONV_OOB;
+        q_soff[it] = (uint32_t)(qb + b) * qn_bytes;
+        q_dst[it] = idx < 72 * NF ? row * W2_QP + 2 * f4 : -1;
+    }
+    uint32_t p_off[NP], p_soff[NP];
+    int p_dst[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int idx = tid + 256 * it, row = idx / NPF, f4 = idx % NPF;        // row = wave' * 16 + a
+        const int yy = y0 + (row >> 4), a = row & 15;
+        const bool ok = yy < g.y && pb + a < g.cp;
+        p_off[it] = ok ? (uint32_t)((yy * g.z + z0 + 4 * f4) * 4) : CONV_OOB;
+        p_soff[it] = (uint32_t)(pb + a) * pn_bytes;
+        p_dst[it] = row * W2_PP + 4 * f4;
+    }
+    const int h_row = tid & 63;                                                  // (threads 0..63) the halo P[z0 + ZC] of row h_row
+    const bool h_ok = tid < 64 && y0 + (h_row >> 4) < g.y && pb + (h_row & 15) < g.cp && z0 + ZC < g.z;
+    const uint32_t h_off = h_ok ? (uint32_t)(((y0 + (h_row >> 4)) * g.z + z0 + ZC) * 4) : CONV_OOB;
+    const uint32_t h_soff = (uint32_t)(pb + (h_row & 15)) * pn_bytes;
+    const uint32_t q_plane = (uint32_t)qy * qz * 4u, p_plane = (uint32_t)g.y * g.z * 4u;
+
+    wm_f32x4 qv[2][NQ], pv[NP];
+    float hv = 0.0f;
+    auto load_q = [&](int fx, wm_f32x4 (&v)[NQ]) {
+        const bool in = (unsigned)fx < (unsigned)qx;
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            // (the channel's offset rides in the LANE offset: as the scalar operand of the load it differs across the lanes and the compiler wraps
+            // every load in a readfirstlane loop over the wave's eight channels)
+            const uint32_t off = (in && q_off[it] != CONV_OOB) ? (uint32_t)fx * q_plane + q_off[it] + q_soff[it] : CONV_OOB;
+            v[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, off, 0, 0));
+        }
+    };
+    auto store_q = [&](int fx, const wm_f32x4 (&v)[NQ]) {
+        float* slot = Ql + ((fx + 3) % 3) * (9 * 8 * W2_QP);
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            if (NQ * 256 != 72 * NF && q_dst[it] < 0) continue;
+            float* dst = slot + q_dst[it];                                       // fine z 4 f4 .. 4 f4 + 3 = coarse m = 2 f4, 2 f4 + 1: (even, odd) each
+            dst[ZC + 1] = v[it].x; dst[0] = v[it].y; dst[ZC + 2] = v[it].z; dst[1] = v[it].w;
+        }
+    };
+    auto load_p = [&](int xp) {
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const uint32_t off = p_off[it] != CONV_OOB ? (uint32_t)xp * p_plane + p_off[it] + p_soff[it] : CONV_OOB;
+            pv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, 0, 0));
+        }
+        hv = conv_load(pr, h_ok ? (uint32_t)xp * p_plane + h_off + h_soff : CONV_OOB, 0);
+    };
+    auto store_p = [&]() {
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            float* dst = Pl + p_dst[it];
+            dst[0] = pv[it].x; dst[1] = pv[it].y; dst[2] = pv[it].z; dst[3] = pv[it].w;
+        }
+        if (tid < 64) Pl[h_row * W2_PP + ZC] = hv;
+    };
+
+    // ---- MFMA operands of this lane: A row i = (a, s), B column j = (b, par, u)
+    const int i32 = lane & 31, kk = lane >> 5;
+    const float* a_ptr = Pl + (wave * 16 + (i32 >> 1)) * W2_PP + (i32 & 1) + (ZC / 2) * kk;
+    const int ob = i32 & 7, opar = (i32 >> 3) & 1, ou = i32 >> 4;
+    int b_tx[5], b_row[5];                                                       // per product: the ring plane's tx and the LDS row offset inside a slot
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int e = min(2 * c + ou, 8), tx = e / 3, ty = e - 3 * tx;
+        b_tx[c] = tx;
+        b_row[c] = ((2 * wave + ty) * 8 + ob) * W2_QP + (opar ? 0 : ZC + 1) + (ZC / 2) * kk;
+    }
+    wm_f32x16 acc[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    // planes 2 x0 - 1, 2 x0, 2 x0 + 1 and the P rows of x0
+    load_q(2 * x0 - 1, qv[0]);
+    store_q(2 * x0 - 1, qv[0]);
+    load_q(2 * x0, qv[0]);
+    load_q(2 * x0 + 1, qv[1]);
+    load_p(x0);
+    for (int x = x0; x < x1; ++x) {
+        store_q(2 * x, qv[0]);
+        store_q(2 * x + 1, qv[1]);
+        store_p();
+        __syncthreads();
+        if (x + 1 < x1) {                                                        // the next step's two planes and rows fly while this one multiplies
+            load_q(2 * x + 2, qv[0]);
+            load_q(2 * x + 3, qv[1]);
+            load_p(x + 1);
+        }
+        const float* b_ptr[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) b_ptr[c] = Ql + ((2 * x - 1 + b_tx[c] + 3) % 3) * (9 * 8 * W2_QP) + b_row[c];
+#pragma unroll 4
+        for (int t = 0; t < ZC / 2; ++t) {
+            const float av = a_ptr[t];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ptr[c][t], acc[c], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- the four waves' sums, then the workgroup's block of ws[part]
+    float* R = Ql;                                                               // 5 x 16 x 64 floats
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* dst = R + (c * 16 + r) * 64 + lane;
+                    *dst = w == 0 ? acc[c][r] : *dst + acc[c][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 5 * 16 * 64; e += 256) {
+        const int c = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;         // row / column of accumulator register r in lane l
+        const int a = i >> 1, sft = i & 1, b = j & 7, par = (j >> 3) & 1, u = j >> 4;
+        const int combo = 2 * c + u;
+        if (combo > 8 || (sft == 1 && par == 0)) continue;
+        const int tx = combo / 3, ty = combo - 3 * tx, tz = sft ? 0 : (par ? 2 : 1);
+        if (pb + a < g.cpp && qb + b < g.cqp) ws[(((int64_t)part * g.cpp + pb + a) * g.cqp + qb + b) * 27 + (tx * 3 + ty) * 3 + tz] = R[e];
+    }
+}
+#define W2_LDS_BYTES(ZC) ((3 * 9 * 8 * (2 * (ZC) + 3) + 4 * 16 * W2_PP) * 4)
+
 struct WgradMfmaPlan {
     bool use;
     int y_blocks, z_segs, x_chunks, xc, n_col;
 };
 static WgradMfmaPlan wgrad_mfma_plan(int cp, int cq, const int* dims_p, int stride) {
     WgradMfmaPlan pl = {};
-    pl.use = stride == 1 && (dims_p[2] & 63) == 0 && getenv("GENS_K15_NO_MFMA_WGRAD") == nullptr;
+    pl.use = ((stride == 1 && (dims_p[2] & 63) == 0) || (stride == 2 && (dims_p[2] & 31) == 0)) && getenv("GENS_K15_NO_MFMA_WGRAD") == nullptr;
+    if (stride == 2 && getenv("GENS_K15_NO_MFMA_WGRAD2") != nullptr) pl.use = false;
     if (!pl.use) return pl;
     const int cpp = (cp + 3) / 4 * 4, cqp = (cq + 7) / 8 * 8;
-    pl.n_col = ((cpp + 7) / 8) * (cqp / 8);
+    pl.n_col = ((cpp + (stride == 2 ? 15 : 7)) / (stride == 2 ? 16 : 8)) * (cqp / 8);          // stride 2: sixteen channels of P per column
     pl.y_blocks = (dims_p[1] + 3) / 4;
-    pl.z_segs = dims_p[2] / 64;
+    pl.z_segs = dims_p[2] / (stride == 2 ? 32 : 64);                               // (stride 2: segments of 32 coarse z, two workgroups per CU)
     const int tiles = pl.y_blocks * pl.z_segs * pl.n_col;
-    int chunks = (1536 + tiles - 1) / tiles;                                      // ~1 500 workgroups: two or three per CU
+    int chunks = ((stride == 2 ? 1024 : 1536) + tiles - 1) / tiles;               // ~1 500 workgroups: two or three per CU (stride 2: two per CU)
     const int max_chunks = (dims_p[0] + 3) / 4;                                   // at least four steps per chunk (each chunk loads two extra planes)
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
@@ -687,7 +867,11 @@ extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq,
     const WgradMfmaPlan pl = wgrad_mfma_plan(cp, cq, dims_p, stride);
     if (pl.use) {          // (workspace: gens_conv3d_wgrad_parts_strided(..., stride) parts)
         const unsigned blocks = (unsigned)(pl.x_chunks * pl.y_blocks * pl.z_segs * pl.n_col);
-        hipLaunchKernelGGL(conv3d_wgrad_mfma_k, dim3(blocks), dim3(256), 0, s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        if (stride == 2) {
+            static GensLdsOptIn lds;
+            if (int e = gens_lds_opt_in(lds, (const void*)conv3d_wgrad2_mfma_k<32>, W2_LDS_BYTES(32), "gens_conv3d_wgrad")) return e;
+            hipLaunchKernelGGL(conv3d_wgrad2_mfma_k<32>, dim3(blocks), dim3(256), W2_LDS_BYTES(32), s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        } else hipLaunchKernelGGL(conv3d_wgrad_mfma_k, dim3(blocks), dim3(256), 0, s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
         return gens_launch_status("gens_conv3d_wgrad");
     }
     if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr)
