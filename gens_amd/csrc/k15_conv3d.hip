@@ -424,52 +424,60 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_k(const float* __restrict__ 
 typedef float wm_f32x16 __attribute__((ext_vector_type(16)));
 typedef float wm_f32x4 __attribute__((ext_vector_type(4)));
 
+// PAIR (four channels of P or fewer -- the U-Net's output heads, whose (a, tz) rows would fill 12 of the MFMA's 32): a wave takes TWO consecutive y
+// rows of P, rows i = (a, y row, tz) = 24, columns j = (b, fine row fy = y row + ty) = 32; both y rows' products land in the same weight (summed on the
+// way out) and a quarter of the columns (fy - y row outside 0..2) is no tap: 56 % of the products useful instead of 28 %, half the MFMAs per voxel.
+template <bool PAIR>
 __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restrict__ p, const float* __restrict__ q, ConvGeom g, int y_blocks, int z_segs,
                                                            int xc, float* __restrict__ ws) {
-    __shared__ float Ql[3][6][8][WM_QP];
-    __shared__ float Pl[4][8][WM_PP];
+    constexpr int NYQ = PAIR ? 10 : 6, RY = PAIR ? 8 : 4, PCH = PAIR ? 4 : 8, NQ = NYQ * 8 * 16 / 256;
+    extern __shared__ __attribute__((aligned(16))) float wm_lds[];
+    float (*Ql)[NYQ][8][WM_QP] = (float (*)[NYQ][8][WM_QP])wm_lds;                        // [3][NYQ][8][WM_QP]
+    float (*Pl)[WM_PP] = (float (*)[WM_PP])(wm_lds + 3 * NYQ * 8 * WM_QP);                // [32 = RY x PCH][WM_PP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nqb = g.cqp / 8, n_col = ((g.cpp + 7) / 8) * nqb;
+    const int nqb = g.cqp / 8, n_col = ((g.cpp + PCH - 1) / PCH) * nqb;
     const int part = (int)blockIdx.x / n_col, col = (int)blockIdx.x % n_col;
-    const int pb = (col / nqb) * 8, qb = (col % nqb) * 8;
+    const int pb = (col / nqb) * PCH, qb = (col % nqb) * 8;
     const int zs = part % z_segs, yb = (part / z_segs) % y_blocks, xk = part / (z_segs * y_blocks);
-    const int z0 = zs * 64, y0 = yb * 4, x0 = xk * xc, x1 = min(x0 + xc, g.x);
+    const int z0 = zs * 64, y0 = yb * RY, x0 = xk * xc, x1 = min(x0 + xc, g.x);
     const uint32_t pn_bytes = (uint32_t)g.x * g.y * g.z * 4u;
     const __amdgpu_buffer_rsrc_t qr = conv_rsrc(q, (int64_t)g.cq * g.x * g.y * g.z);
     const __amdgpu_buffer_rsrc_t pr = conv_rsrc(p, (int64_t)g.cp * g.x * g.y * g.z);
 
-    // ---- this thread's share of a step's loads: 3 float4 of the Q plane, 2 float4 of the P rows, (64 threads) one halo float
-    int q_row[3], q_f4[3], p_row[2], p_f4[2];
-    uint32_t q_soff[3], p_soff[2];
-    bool q_ok[3], p_ok[2];
+    // ---- this thread's share of a step's loads: NQ float4 of the Q plane, 2 float4 of the P rows, (64 threads) one halo float
+    int q_row[NQ], q_f4[NQ], p_row[2], p_f4[2];
+    uint32_t q_soff[NQ], p_soff[2];
+    bool q_ok[NQ], p_ok[2];
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < NQ; ++it) {
         const int idx = tid + 256 * it;
-        q_row[it] = idx >> 4;                                                       // 0..47 = yrow * 8 + b
+        q_row[it] = idx >> 4;                                                       // yrow * 8 + b
         q_f4[it] = idx & 15;
         const int yy = y0 - 1 + (q_row[it] >> 3), b = q_row[it] & 7;
         q_ok[it] = (unsigned)yy < (unsigned)g.y && qb + b < g.cq;
         q_soff[it] = (uint32_t)(qb + b) * pn_bytes;
     }
+    auto p_y = [&](int row) { return PAIR ? row >> 2 : row >> 3; };                 // flat P row (0..31) -> y row of the workgroup, channel of the block
+    auto p_a = [&](int row) { return PAIR ? row & 3 : row & 7; };
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + 256 * it;
-        p_row[it] = idx >> 4;                                                       // 0..31 = w * 8 + a
+        p_row[it] = idx >> 4;
         p_f4[it] = idx & 15;
-        const int yy = y0 + (p_row[it] >> 3), a = p_row[it] & 7;
+        const int yy = y0 + p_y(p_row[it]), a = p_a(p_row[it]);
         p_ok[it] = yy < g.y && pb + a < g.cp;
         p_soff[it] = (uint32_t)(pb + a) * pn_bytes;
     }
     const int h_row = (tid >> 1) & 31, h_side = tid & 1;                           // (threads 0..63) halo of P row h_row: z0 - 1 or z0 + 64
     const int h_z = h_side ? z0 + 64 : z0 - 1;
-    const bool h_ok = tid < 64 && y0 + (h_row >> 3) < g.y && pb + (h_row & 7) < g.cp && (unsigned)h_z < (unsigned)g.z;
-    const uint32_t h_soff = (uint32_t)(pb + (h_row & 7)) * pn_bytes;
+    const bool h_ok = tid < 64 && y0 + p_y(h_row) < g.y && pb + p_a(h_row) < g.cp && (unsigned)h_z < (unsigned)g.z;
+    const uint32_t h_soff = (uint32_t)(pb + p_a(h_row)) * pn_bytes;
 
-    wm_f32x4 qv[3], pv[2];
+    wm_f32x4 qv[NQ], pv[2];
     float hv = 0.0f;
     auto load_q = [&](int xq) {
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
+        for (int it = 0; it < NQ; ++it) {
             const int yy = y0 - 1 + (q_row[it] >> 3);
             // (the channel's offset in the LANE offset: as the load's scalar operand it differs across the lanes -> a readfirstlane loop per load)
             const uint32_t off = (q_ok[it] && (unsigned)xq < (unsigned)g.x) ? (uint32_t)(((xq * g.y + yy) * g.z + z0 + 4 * q_f4[it]) * 4) + q_soff[it] : CONV_OOB;
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
     auto store_q = [&](int xq) {
         const int slot = (xq + 3) % 3;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
+        for (int it = 0; it < NQ; ++it) {
             float* dst = &Ql[slot][q_row[it] >> 3][q_row[it] & 7][4 * q_f4[it]];
             dst[0] = qv[it].x; dst[1] = qv[it].y; dst[2] = qv[it].z; dst[3] = qv[it].w;
         }
@@ -487,27 +495,29 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
     auto load_p = [&](int xp) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int yy = y0 + (p_row[it] >> 3);
+            const int yy = y0 + p_y(p_row[it]);
             const uint32_t off = p_ok[it] ? (uint32_t)(((xp * g.y + yy) * g.z + z0 + 4 * p_f4[it]) * 4) + p_soff[it] : CONV_OOB;
             pv[it] = __builtin_bit_cast(wm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, 0, 0));
         }
-        const uint32_t hoff = h_ok ? (uint32_t)(((xp * g.y + y0 + (h_row >> 3)) * g.z + h_z) * 4) + h_soff : CONV_OOB;
+        const uint32_t hoff = h_ok ? (uint32_t)(((xp * g.y + y0 + p_y(h_row)) * g.z + h_z) * 4) + h_soff : CONV_OOB;
         hv = conv_load(pr, hoff, 0);
     };
     auto store_p = [&]() {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            float* dst = &Pl[p_row[it] >> 3][p_row[it] & 7][1 + 4 * p_f4[it]];
+            float* dst = &Pl[p_row[it]][1 + 4 * p_f4[it]];
             dst[0] = pv[it].x; dst[1] = pv[it].y; dst[2] = pv[it].z; dst[3] = pv[it].w;
         }
-        if (tid < 64) Pl[h_row >> 3][h_row & 7][h_side ? 65 : 0] = hv;
+        if (tid < 64) Pl[h_row][h_side ? 65 : 0] = hv;
     };
 
-    // ---- MFMA operand rows of this lane: A row i = (a, tz), B column j = (b, ty); lanes 24..31 of a half repeat rows 0..7 (their products are dropped)
+    // ---- MFMA operand rows of this lane.  Plain: A row i = (a, tz), B column j = (b, ty); lanes 24..31 of a half repeat rows 0..7 (their products are
+    // dropped).  PAIR: A row i = (a, y row, tz) (24 used), B column j = (b, fy) (all 32)
     const int i32 = lane & 31, kk = lane >> 5;
     const int ii = i32 < 24 ? i32 : i32 - 24;
-    const int oa = ii / 3, ot = ii - 3 * oa;                                        // a (or b), tz (or ty)
-    const float* a_ptr = &Pl[wave][oa][2 - ot + 32 * kk];
+    const int oa = ii / 3, ot = ii - 3 * oa;                                        // plain: a (or b), tz (or ty)
+    const int pa = ii / 6, pyr = (ii - 6 * pa) / 3;                                 // PAIR: a, y row; tz = ot
+    const float* a_ptr = PAIR ? &Pl[(2 * wave + pyr) * 4 + pa][2 - ot + 32 * kk] : &Pl[wave * 8 + oa][2 - ot + 32 * kk];
     wm_f32x16 acc[3];
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
@@ -530,7 +540,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
         }
         const float* b_ptr[3];
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) b_ptr[tx] = &Ql[(x - 1 + tx + 3) % 3][wave + ot][oa][32 * kk];
+        for (int tx = 0; tx < 3; ++tx)
+            b_ptr[tx] = PAIR ? &Ql[(x - 1 + tx + 3) % 3][2 * wave + (i32 & 3)][i32 >> 2][32 * kk] : &Ql[(x - 1 + tx + 3) % 3][wave + ot][oa][32 * kk];
 #pragma unroll 8
         for (int t = 0; t < 32; ++t) {
             const float av = a_ptr[t];
@@ -553,6 +564,16 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
         }
         __syncthreads();
     }
+    if (PAIR) {
+        // accumulator element of row i, column j: register r = (i & 3) + 4 (i >> 3), lane 32 ((i >> 2) & 1) + j
+        auto at = [&](int tx, int i, int j) { return R[(tx * 16 + (i & 3) + 4 * (i >> 3)) * 64 + 32 * ((i >> 2) & 1) + j]; };
+        for (int e = tid; e < 3 * 4 * 8 * 9; e += 256) {                            // (tx, a, b, ty, tz)
+            const int tz = e % 3, ty = (e / 3) % 3, b = (e / 9) % 8, a = (e / 72) % 4, tx = e / 288;
+            const float v = at(tx, a * 6 + tz, b * 4 + ty) + at(tx, a * 6 + 3 + tz, b * 4 + ty + 1);      // y row 0 (fy = ty) + y row 1 (fy = ty + 1)
+            if (pb + a < g.cpp && qb + b < g.cqp) ws[(((int64_t)part * g.cpp + pb + a) * g.cqp + qb + b) * 27 + (tx * 3 + ty) * 3 + tz] = v;
+        }
+        return;
+    }
     for (int e = tid; e < 3 * 16 * 64; e += 256) {
         const int tx = e >> 10, r = (e >> 6) & 15, l = e & 63;
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;            // row / column of accumulator register r in lane l
@@ -561,6 +582,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_k(const float* __restri
         if (pb + a < g.cpp && qb + b < g.cqp) ws[(((int64_t)part * g.cpp + pb + a) * g.cqp + qb + b) * 27 + (tx * 3 + ty) * 3 + tz] = R[e];
     }
 }
+#define WM_LDS_BYTES(PAIR) ((3 * ((PAIR) ? 10 : 6) * 8 * WM_QP + 32 * WM_PP) * 4)
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // wgrad on the matrix cores, STRIDE 2 (coarse z a multiple of 64): dW[a][b][tx][ty][tz] = sum_o P[a][o] Q[b][2 o + t - 1].  Along z the three taps
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(256, ZC == 32 ? 2 : 1) void conv3d_wgrad2_mfma_k(co
 #define W2_LDS_BYTES(ZC) ((3 * 9 * 8 * (2 * (ZC) + 3) + 4 * 16 * W2_PP) * 4)
 
 struct WgradMfmaPlan {
-    bool use;
+    bool use, pair;
     int y_blocks, z_segs, x_chunks, xc, n_col;
 };
 static WgradMfmaPlan wgrad_mfma_plan(int cp, int cq, const int* dims_p, int stride) {
@@ -750,8 +772,10 @@ static WgradMfmaPlan wgrad_mfma_plan(int cp, int cq, const int* dims_p, int stri
     if (stride == 2 && getenv("GENS_K15_NO_MFMA_WGRAD2") != nullptr) pl.use = false;
     if (!pl.use) return pl;
     const int cpp = (cp + 3) / 4 * 4, cqp = (cq + 7) / 8 * 8;
-    pl.n_col = ((cpp + (stride == 2 ? 15 : 7)) / (stride == 2 ? 16 : 8)) * (cqp / 8);          // stride 2: sixteen channels of P per column
-    pl.y_blocks = (dims_p[1] + 3) / 4;
+    pl.pair = stride == 1 && cpp <= 4 && getenv("GENS_K15_NO_WGRAD_PAIR") == nullptr;             // the output heads: two y rows per wave
+    const int pch = stride == 2 ? 16 : pl.pair ? 4 : 8;                                           // channels of P per column
+    pl.n_col = ((cpp + pch - 1) / pch) * (cqp / 8);
+    pl.y_blocks = (dims_p[1] + (pl.pair ? 7 : 3)) / (pl.pair ? 8 : 4);
     pl.z_segs = dims_p[2] / (stride == 2 ? 32 : 64);                               // (stride 2: segments of 32 coarse z, two workgroups per CU)
     const int tiles = pl.y_blocks * pl.z_segs * pl.n_col;
     int chunks = ((stride == 2 ? 1024 : 1536) + tiles - 1) / tiles;               // ~1 500 workgroups: two or three per CU (stride 2: two per CU)
@@ -871,7 +895,15 @@ extern "C" int gens_conv3d_wgrad(const float* p, const float* q, int cp, int cq,
             static GensLdsOptIn lds;
             if (int e = gens_lds_opt_in(lds, (const void*)conv3d_wgrad2_mfma_k<32>, W2_LDS_BYTES(32), "gens_conv3d_wgrad")) return e;
             hipLaunchKernelGGL(conv3d_wgrad2_mfma_k<32>, dim3(blocks), dim3(256), W2_LDS_BYTES(32), s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
-        } else hipLaunchKernelGGL(conv3d_wgrad_mfma_k, dim3(blocks), dim3(256), 0, s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        } else if (pl.pair) {
+            static GensLdsOptIn lds;
+            if (int e = gens_lds_opt_in(lds, (const void*)conv3d_wgrad_mfma_k<true>, WM_LDS_BYTES(true), "gens_conv3d_wgrad")) return e;
+            hipLaunchKernelGGL(conv3d_wgrad_mfma_k<true>, dim3(blocks), dim3(256), WM_LDS_BYTES(true), s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        } else {
+            static GensLdsOptIn lds;
+            if (int e = gens_lds_opt_in(lds, (const void*)conv3d_wgrad_mfma_k<false>, WM_LDS_BYTES(false), "gens_conv3d_wgrad")) return e;
+            hipLaunchKernelGGL(conv3d_wgrad_mfma_k<false>, dim3(blocks), dim3(256), WM_LDS_BYTES(false), s, p, q, g, pl.y_blocks, pl.z_segs, pl.xc, workspace);
+        }
         return gens_launch_status("gens_conv3d_wgrad");
     }
     if (stride == 1 && (g.z & 63) == 0 && getenv("GENS_K15_NO_ROWLDS") == nullptr)
