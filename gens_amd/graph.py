@@ -68,7 +68,7 @@ class GraphedStep:
         torch.set_rng_state(saved_rng)
         optimizer.zero_grad(set_to_none=True)                  # the captured backward then ASSIGNS the gradients (no accumulation across replays)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.loss = body()
         torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
         self._replayed = None
@@ -108,6 +108,13 @@ class GraphedStep:
 # ----------------------------------------------------------------------------------------------------------------------
 import os
 import warnings
+
+
+# Capture mode of every graph in this file.  The default ("global") makes a runtime call from ANY thread illegal while a capture is open -- and
+# torch.distributed's RCCL watchdog thread polls its events (hipEventQuery) whenever a collective is outstanding: a DDP-wrapped model that captured
+# its step right after DDP's buffer broadcast was aborted from that thread now and then (tests/test_hip_ddp.py, one run in three).  "thread_local"
+# restricts the checks to the capturing thread; kernels other threads (autograd's worker) enqueue on the capturing stream are captured either way.
+_CAPTURE_MODE = os.environ.get("GENS_CAPTURE_MODE", "thread_local")
 
 
 def auto_graph_enabled():
@@ -317,7 +324,7 @@ class AutoGraph:
                 a = aliases[id(t)] = t.detach().requires_grad_(True)
             return a
         fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd):
+        with torch.cuda.graph(fwd, capture_error_mode=_CAPTURE_MODE):
             with torch.enable_grad(), _swapped_parameters(module, alias_of):
                 out = body(static_in, scalar_dev, alias_of)
         torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
@@ -363,7 +370,7 @@ class AutoGraph:
             return plan
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=entry.fwd.pool()):
+        with torch.cuda.graph(graph, pool=entry.fwd.pool(), capture_error_mode=_CAPTURE_MODE):
             # (retain_graph: a second backward -- the one over every differentiable output -- is captured through the same autograd graph)
             grad_in = torch.autograd.grad([entry.out_static[i] for i in pattern], entry.grad_static, plan.grad_out, retain_graph=True, allow_unused=True)
         plan.graph, plan.grad_in = graph, list(grad_in)
