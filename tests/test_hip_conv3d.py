@@ -21,6 +21,7 @@ def _close(name, got, want, tol=2e-5):
     (1, 1, (2, 2, 2), 1, False), (9, 3, (2, 2, 2), 2, False),
     (8, 8, (4, 6, 64), 1, True), (12, 5, (3, 3, 128), 1, False), (4, 4, (2, 5, 192), 1, False),       # z % 64 == 0: the LDS neighbour exchange
     (8, 8, (4, 4, 128), 2, True), (5, 12, (2, 6, 256), 2, False),                                       # coarse z % 64 == 0 at stride 2
+    (8, 8, (9, 6, 64), 1, True), (6, 7, (5, 9, 128), 1, False), (3, 8, (17, 4, 64), 1, True),              # five to eight channels out, at most eight in: the matrix-core gather (forward and data gradient)
     (8, 3, (3, 11, 64), 1, True), (16, 4, (2, 17, 128), 1, False),                                      # four output channels or fewer: the weight gradient's two-rows-per-wave form (the U-Net's heads)
     (12, 24, (6, 10, 64), 2, False), (40, 20, (2, 14, 64), 2, True),                                    # coarse z = 32: one segment of the stride-2 matrix-core weight gradient, two blocks of P channels
     (72, 128, (2, 2, 2), 2, False), (128, 128, (2, 2, 2), 1, False), (64, 64, (4, 4, 4), 1, True), (40, 64, (4, 4, 4), 2, False)])   # the deep levels of the 5-stage U-Net
