@@ -68,7 +68,7 @@ class GraphedStep:
         torch.set_rng_state(saved_rng)
         optimizer.zero_grad(set_to_none=True)                  # the captured backward then ASSIGNS the gradients (no accumulation across replays)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+        with _capturing(self.graph):
             self.loss = body()
         torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
         self._replayed = None
@@ -115,6 +115,33 @@ import warnings
 # its step right after DDP's buffer broadcast was aborted from that thread now and then (tests/test_hip_ddp.py, one run in three).  "thread_local"
 # restricts the checks to the capturing thread; kernels other threads (autograd's worker) enqueue on the capturing stream are captured either way.
 _CAPTURE_MODE = os.environ.get("GENS_CAPTURE_MODE", "thread_local")
+
+
+class _capturing:
+    """`with torch.cuda.graph(...)` on a stream of its own, with a way back when the capture fails.  torch's context manager ends the capture in its
+    __exit__ BEFORE it restores the current stream: a capture that was invalidated makes that call raise, and the thread stays on the side stream --
+    which still reports "capturing", so the eager fall-through of AutoGraph ran into "operation not permitted when stream is capturing".  Here a failed
+    capture puts the caller's stream back, drops the side stream for good (a fresh one per attempt) and clears the runtime's sticky error."""
+
+    def __init__(self, graph, pool=None):
+        self.prev = torch.cuda.current_stream()
+        self.inner = torch.cuda.graph(graph, pool=pool, stream=torch.cuda.Stream(), capture_error_mode=_CAPTURE_MODE)
+
+    def __enter__(self):
+        return self.inner.__enter__()
+
+    def __exit__(self, *exc):
+        try:
+            return self.inner.__exit__(*exc)
+        except BaseException:
+            torch.cuda.set_stream(self.prev)
+            try:
+                import ctypes
+                ctypes.CDLL("libamdhip64.so").hipGetLastError()             # (returns AND clears it: the next launch check would raise it again)
+            except OSError:
+                pass
+            raise
+
 
 
 def auto_graph_enabled():
@@ -273,7 +300,10 @@ class AutoGraph:
             except Exception as e:  # noqa: BLE001   (whatever the capture trips over: this signature stays eager, in this process)
                 entry.state, entry.why_eager = "eager", f"{type(e).__name__}: {e}"
                 entry.fwd = entry.bwd_used = entry.bwd_all = None
-                torch.cuda.synchronize()
+                try:
+                    torch.cuda.current_stream().synchronize()
+                except RuntimeError:
+                    pass
                 warnings.warn(f"gens_amd.graph.AutoGraph: this step cannot be captured into a HIP graph ({entry.why_eager}); it runs eagerly",
                               RuntimeWarning, stacklevel=3)
                 self.stats["eager"] += 1
@@ -324,7 +354,7 @@ class AutoGraph:
                 a = aliases[id(t)] = t.detach().requires_grad_(True)
             return a
         fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd, capture_error_mode=_CAPTURE_MODE):
+        with _capturing(fwd):
             with torch.enable_grad(), _swapped_parameters(module, alias_of):
                 out = body(static_in, scalar_dev, alias_of)
         torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
@@ -370,7 +400,7 @@ class AutoGraph:
             return plan
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=entry.fwd.pool(), capture_error_mode=_CAPTURE_MODE):
+        with _capturing(graph, pool=entry.fwd.pool()):
             # (retain_graph: a second backward -- the one over every differentiable output -- is captured through the same autograd graph)
             grad_in = torch.autograd.grad([entry.out_static[i] for i in pattern], entry.grad_static, plan.grad_out, retain_graph=True, allow_unused=True)
         plan.graph, plan.grad_in = graph, list(grad_in)

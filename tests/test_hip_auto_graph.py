@@ -287,3 +287,34 @@ def test_capture_survives_another_thread_that_calls_the_runtime():
     stats = model._auto.stats
     assert stats["captured"] == 1 and stats["replayed"] == 4 and stats["eager"] == 2, stats
     assert all(torch.isfinite(torch.tensor(l)).all() for l in losses)
+
+
+def test_a_capture_that_fails_leaves_the_loop_on_the_eager_path_of_the_same_process():
+    """Something inside the step that a capture cannot hold (here: a stream synchronisation the first time the step is captured) must cost a warning,
+    not the run: the signature stays eager, the loop goes on in this process and walks the un-captured trajectory."""
+    import warnings
+    from tests.test_hip_ddp import _loss
+    lrs = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        opt = torch.optim.Adam(model.get_optim_params(lrs))
+        if auto:
+            inner, calls = model._forward_impl, []
+
+            def spoiled(*a, **k):
+                calls.append(torch.cuda.is_current_stream_capturing())
+                if calls[-1]:
+                    torch.cuda.current_stream().synchronize()           # illegal while capturing
+                return inner(*a, **k)
+            model._forward_impl = spoiled
+        torch.manual_seed(21)
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            runs[auto] = (model, _runner_loop(model, opt, 6, _loss))
+        if auto:
+            assert any("cannot be captured" in str(w.message) for w in seen), [str(w.message) for w in seen]
+            assert calls.count(True) == 1, calls                          # one capture attempt, then eager for good
+            stats = model._auto.stats
+            assert stats["captured"] == 0 and stats["replayed"] == 0 and stats["eager"] == 6, stats
+    _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1])
