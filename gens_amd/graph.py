@@ -140,6 +140,13 @@ class _capturing:
                 ctypes.CDLL("libamdhip64.so").hipGetLastError()             # (returns AND clears it: the next launch check would raise it again)
             except OSError:
                 pass
+            # capture_begin put the device's default generator into its capture mode and only capture_end's LAST step takes it out again: left there,
+            # the next torch.randn on the device raises "Offset increment outside graph capture".  A clone of the state is a state outside any capture.
+            try:
+                gen = torch.cuda.default_generators[torch.cuda.current_device()]
+                gen.graphsafe_set_state(gen.clone_state())
+            except (AttributeError, RuntimeError):
+                pass
             raise
 
 
