@@ -121,11 +121,17 @@ class _capturing:
     """`with torch.cuda.graph(...)` on a stream of its own, with a way back when the capture fails.  torch's context manager ends the capture in its
     __exit__ BEFORE it restores the current stream: a capture that was invalidated makes that call raise, and the thread stays on the side stream --
     which still reports "capturing", so the eager fall-through of AutoGraph ran into "operation not permitted when stream is capturing".  Here a failed
-    capture puts the caller's stream back, drops the side stream for good (a fresh one per attempt) and clears the runtime's sticky error."""
+    capture puts the caller's stream back, drops the side stream for good (the next attempt gets a fresh one) and clears the runtime's sticky error."""
+
+    side = {}          # device -> the stream captures run on (one for all captures, as torch's own default: the forward and backward graphs of an entry
+                       # share a memory pool, whose blocks are reused only within the stream that freed them); replaced after a failed capture
 
     def __init__(self, graph, pool=None):
         self.prev = torch.cuda.current_stream()
-        self.inner = torch.cuda.graph(graph, pool=pool, stream=torch.cuda.Stream(), capture_error_mode=_CAPTURE_MODE)
+        self.dev = torch.cuda.current_device()
+        if self.dev not in _capturing.side:
+            _capturing.side[self.dev] = torch.cuda.Stream()
+        self.inner = torch.cuda.graph(graph, pool=pool, stream=_capturing.side[self.dev], capture_error_mode=_CAPTURE_MODE)
 
     def __enter__(self):
         return self.inner.__enter__()
@@ -135,6 +141,7 @@ class _capturing:
             return self.inner.__exit__(*exc)
         except BaseException:
             torch.cuda.set_stream(self.prev)
+            _capturing.side.pop(self.dev, None)
             try:
                 import ctypes
                 ctypes.CDLL("libamdhip64.so").hipGetLastError()             # (returns AND clears it: the next launch check would raise it again)
