@@ -225,6 +225,7 @@ class _Replay(torch.autograd.Function):
             entry.recapture = True
             owner.stats["superset_backward"] += 1
             plan = entry.bwd_all
+        dst, src = [], []
         for k, i in enumerate(plan.pattern):
             g, buf = grads[i], plan.grad_out[k]
             if g is None:
@@ -233,8 +234,14 @@ class _Replay(torch.autograd.Function):
                     plan.zero[k] = True
             else:
                 if g.data_ptr() != buf.data_ptr():
-                    buf.copy_(g)
+                    if g.shape == buf.shape and g.dtype == buf.dtype:
+                        dst.append(buf)
+                        src.append(g)
+                    else:
+                        buf.copy_(g)
                 plan.zero[k] = False
+        if dst:
+            torch._foreach_copy_(dst, src)                      # the loss's cotangents in one launch
         # a .grad that still aliases a static gradient buffer (a loop that zeroes gradients in place instead of dropping them, or accumulates over
         # several backward passes): give it memory of its own before the replay overwrites that buffer
         for t, s in zip(entry.grad_inputs, plan.grad_in):
@@ -424,10 +431,14 @@ class AutoGraph:
     def _replay(self, entry, copied, scalars):
         for s in entry.surfaces:
             s.check_deferred()                                 # what the previous step left to verify, if its backward never ran
+        dst, src = [], []
         for n, t in copied.items():
             st = entry.static_in[n]
             if t.data_ptr() != st.data_ptr():
-                st.detach().copy_(t, non_blocking=True)
+                dst.append(st.detach())
+                src.append(t)
+        if dst:
+            torch._foreach_copy_(dst, src, non_blocking=True)   # the step's ~ ten inputs in one or two launches (per dtype), not one each
         for n, v in scalars.items():
             v = float(v)
             if v != entry.scalar_val[n]:
