@@ -172,3 +172,20 @@ def test_feature_decoder_blocks_on_k16_match_the_torch_route(monkeypatch):
         res[on] = (y.detach(),) + torch.autograd.grad(y, [x, skip, blk.conv.weight], cot)
     for name, a, b in zip(("value", "grad x", "grad skip", "grad weight"), res[True], res[False]):
         _close(name, a, b.cpu(), 2e-4 if name == "grad weight" else 5e-5)
+
+
+@pytest.mark.parametrize("cp,cq,d,stride", [(16, 8, 128, 2), (32, 16, 64, 2), (64, 32, 32, 2), (8, 8, 256, 1), (4, 8, 256, 1), (4, 16, 128, 1)])
+def test_matrix_core_weight_gradients_agree_with_the_vector_kernel_at_the_unet_shapes(cp, cq, d, stride, monkeypatch):
+    """The U-Net's own layer shapes (P = coarse / output side, Q = fine / input side; volume_dims 256 / 128 / 64): the matrix-core weight-gradient kernels --
+    stride 2 (conv3d_wgrad2_mfma_k), stride 1 (conv3d_wgrad_mfma_k) and its two-rows-per-wave form for the four-channel heads -- against the vector-ALU
+    kernel on the same tensors, to float32 summation error of 2 M - 17 M terms per weight."""
+    from gens_amd.ops.conv3d import _conv_wgrad
+    g = torch.Generator(device="cuda").manual_seed(cp * 1000 + cq + d)
+    p = torch.randn(cp, d, d, d, device="cuda", generator=g)
+    q = torch.randn(cq, stride * d, stride * d, stride * d, device="cuda", generator=g)
+    fast = _conv_wgrad(p, q, stride)
+    monkeypatch.setenv("GENS_K15_NO_MFMA_WGRAD", "1")
+    ref = _conv_wgrad(p, q, stride)
+    assert fast.shape == ref.shape == (cp, cq, 27)
+    err = float((fast - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
