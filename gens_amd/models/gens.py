@@ -153,6 +153,25 @@ class GenS(nn.Module):
             cache = self._view_index = (ids, torch.tensor(ids, dtype=torch.long, device=self.features[0].device))
         return cache[1]
 
+    def _seed_frozen_layouts(self, selected, index):
+        """Fine-tuning keeps the feature pyramid of EVERY view of the scene as frozen parameters and takes this step's views out of it
+        (gens.py:151-153).  The kernels read texel layouts of the maps (ops.pack_maps) and, for the patch warp, the three finest levels up-sampled
+        into one map (ops.build_warp_features); both are cached on the map TENSOR -- and `features[i][view_ids]` is a new tensor every step, so every
+        step re-packed and re-up-sampled what never changes (0.2 ms of a 5.5 ms step; 0.7 of 6.5 at the shipped 1152 x 1600).  Here the layouts of
+        the whole frozen pyramid are built once (cached on the parameters, for their current versions) and this step's views are taken out of
+        THEM: the selected maps carry ready layouts when the renderer asks."""
+        from .. import ops
+        from ..ops.base import kernels, pack_maps
+        if not kernels.tex_cache or any(f.requires_grad for f in self.features) or not selected or selected[0].device.type != "cuda":
+            return
+        grad_mode = torch.is_grad_enabled()
+        full = pack_maps(list(self.features))
+        for f, t in zip(selected, full):
+            f._gens_tex = (f._version, grad_mode and f.requires_grad, t.index_select(0, index))
+        if len(selected) >= 3:
+            warp_full, channels = ops.build_warp_features(list(self.features[:3]))
+            selected[0]._gens_warp = (tuple((id(f), f._version) for f in selected[:3]), list(selected[1:3]), (warp_full.index_select(0, index), channels))
+
     def train(self, mode=True):
         self._mode_version = getattr(self, "_mode_version", 0) + 1      # (a captured step belongs to one train / eval setting of the module tree)
         return super().train(mode)
@@ -226,7 +245,8 @@ class GenS(nn.Module):
                 return self._forward_impl(mode, ip, sc["cos_anneal_ratio"], 5.0 if use_match else 1.0, reload_match=False)
             finally:
                 surf._auto_suppressed = False
-        key = ("GenS", mode, self.has_vol, use_match, getattr(self, "_mode_version", 0), self.training, len(refs))
+        frozen = tuple(f._version for f in self.features) if self.has_vol else ()      # (the cached layouts of the frozen maps belong to these versions)
+        key = ("GenS", mode, self.has_vol, use_match, getattr(self, "_mode_version", 0), self.training, len(refs), frozen)
         return auto.run(key, copied, refs, {"cos_anneal_ratio": float(cos_anneal_ratio)}, body, [surf], module=self)
 
     def _forward_impl(self, mode, ipts, cos_anneal_ratio=1.0, step=None, reload_match=True):
@@ -244,5 +264,6 @@ class GenS(nn.Module):
             volumes, mask_volmes = list(self.volumes), list(self.mask_volmes)
             index = self._view_index_of(view_ids)
             features = [f.index_select(0, index) for f in self.features]
+            self._seed_frozen_layouts(features, index)
             match_features = features
         return self.implicit_surface(mode, ipts, volumes, mask_volmes, features, match_features, cos_anneal_ratio, step)
