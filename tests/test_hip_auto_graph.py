@@ -319,3 +319,38 @@ def test_a_capture_that_fails_leaves_the_loop_on_the_eager_path_of_the_same_proc
             assert stats["captured"] == 0 and stats["replayed"] == 0 and stats["eager"] == 6, stats
     _compare(runs[False][0], runs[True][0], runs[False][1], runs[True][1])
     assert torch.isfinite(torch.randn(8, device="cuda")).all()        # the device's generator is out of capture mode again (the next test's randn raised once)
+
+
+def test_frozen_feature_layouts_are_taken_from_the_cached_pyramid_bit_for_bit():
+    """GenS(has_vol): the texel / warp layouts of this step's views, index-selected out of the layouts of the whole frozen pyramid (built once), against the
+    layouts packed from `features[i][view_ids]` every step (the per-tensor cache switched off): the same outputs bit for bit, for several view orders, and
+    after the frozen maps change in place (their version moves: the cached layouts are rebuilt)."""
+    from gens_amd.ops.base import kernels
+    from tests.test_hip_ddp import _inputs
+    model = _finetune_model(False)
+    f0 = model.features[0].detach().clone()
+    runs = {}
+    for cache in (True, False):
+        kernels.tex_cache = cache
+        try:
+            outs = []
+            for k, ids in enumerate(([0, 1, 2], [2, 0, 1], [1, 2, 0], [0, 1, 2])):
+                if k == 3:
+                    with torch.no_grad():
+                        model.features[0].mul_(1.5)                       # frozen, not constant: e.g. a checkpoint loaded in place
+                ipts = _inputs(300 + k, n_rays=32, nv=3)
+                ipts["view_ids"] = ids
+                torch.manual_seed(5 + k)
+                with torch.no_grad():
+                    out = model("train", ipts, cos_anneal_ratio=0.5, step=None)
+                outs.append({n: v.clone() for n, v in out.items() if torch.is_tensor(v)})
+            runs[cache] = outs
+            with torch.no_grad():
+                model.features[0].copy_(f0)
+        finally:
+            kernels.tex_cache = True
+    for a, b in zip(runs[True], runs[False]):
+        assert sorted(a) == sorted(b)
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
+    assert not torch.equal(runs[True][0]["color_fine"], runs[True][3]["color_fine"])          # (the in-place change reached the render)
