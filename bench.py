@@ -46,7 +46,8 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--rays", type=int, default=480 * 640, help="rays per step and rank (default: the full 480x640 image)")
-    p.add_argument("--chunk", type=int, default=32768, help="rays per render() chunk")
+    p.add_argument("--chunk", type=int, default=None, help="rays per render() chunk (default: what ImplicitSurface.validate chooses itself -- equal "
+                                                           "chunks of at most 32 768 rays; the bench sets nothing on the model)")
     p.add_argument("--dims", type=int, nargs="+", default=[256, 128, 64])
     p.add_argument("--views", type=int, default=5)
     p.add_argument("--cpu-rays", type=int, default=640, help="rays of the CPU-oracle baseline sample (0 = skip); ~15 s on a 128-core host")
@@ -96,13 +97,7 @@ def gpu_clocks(card_dir):
     return out
 
 
-def balanced_chunk(n_rays, max_chunk, unit=256):
-    """Rays per render() chunk for a ray range of n_rays: the fewest chunks of at most max_chunk rays, of EQUAL length (a multiple of the
-    reference's 256-ray chunk), instead of full chunks + a short tail that runs at a fraction of the chip's occupancy (an eighth of a
-    480 x 640 image is 38 400 rays: 2 x 19 200, not 32 768 + 5 632).  The jitter is drawn in 256-ray groups whatever the chunk (JitterStream)."""
-    n_chunks = max(1, -(-n_rays // max_chunk))
-    per = -(-n_rays // n_chunks)
-    return min(max_chunk, -(-per // unit) * unit)
+from gens_amd.chunking import balanced_chunk  # noqa: E402  (torch-free; what ImplicitSurface.validate uses when val_chunk is left alone)
 
 
 class ClockSampler:
@@ -320,8 +315,10 @@ def main():
     rays_o, rays_d = rays_o[:args.rays].to(dev), rays_d[:args.rays].to(dev)
     n_rays = rays_o.shape[0]
     surf, volume = build_model(args.dims, dev)
-    surf.val_chunk = args.chunk
-    surf.sdf_precision = args.sdf_precision
+    if args.chunk:                      # (the default run leaves the model as its constructor built it: the measured configuration IS the shipped one)
+        surf.val_chunk = args.chunk
+    if args.sdf_precision != "f32":
+        surf.sdf_precision = args.sdf_precision
     n_final = surf.n_samples + surf.n_importance
     hw = (1, n_rays)
 
@@ -330,8 +327,7 @@ def main():
     if by_rays:
         from gens_amd.distributed import Shard
         shard = Shard()
-        r0, r1 = shard.rays(n_rays)
-        surf.val_chunk = balanced_chunk(r1 - r0, args.chunk)          # equal chunks over THIS rank's ray range
+        r0, r1 = shard.rays(n_rays)       # (validate() cuts THIS rank's ray range into equal chunks itself)
 
     def step():
         # the previous step's 690 MB of cost volumes and masks go back to the allocator BEFORE this step's are built (no second set of segments)
@@ -342,11 +338,8 @@ def main():
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             out = surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, hw,
                                 extract_geometry=False, scene=scene, shard=shard)       # shard: this rank's ray range + RCCL gather inside
-            # image after image, as a validation loop renders them: the NEXT image's jitter draws (13 generator draws per ray in the
-            # reference's order, 14 ms of host time per image) start now, on the helper thread, instead of at the next call -- the first ray
-            # chunk then finds its jitter ready (1.5 ms of idle GPU per image otherwise), and a rank that renders the LAST rays of a
-            # ray-sharded image does not wait for the draws of all the rays before its own.  Same draws, same order.
-            surf.prefetch_jitter(n_rays)
+            # (image after image, as a validation loop renders them: validate() itself starts the NEXT image's jitter draws on a helper thread
+            # before it waits for this image's copy -- ImplicitSurface._speculate_jitter; rounds 2 - 5 called surf.prefetch_jitter() here)
         if dist is not None and not by_rays:                                             # config 4: gather of rendered buffers
             buf = surf.last_device_image                                                 # (P, 8) rgb | normal | sdf depth | rendered depth, on the device
             gathered = torch.empty(world * buf.shape[0], buf.shape[1], device=dev, dtype=buf.dtype)
@@ -415,9 +408,7 @@ def main():
             ray_sharded = {"error": f"{type(e).__name__}: {e}"}
 
     def finish():
-        pending = getattr(surf, "_jitter_ahead", None)  # the draws for an image that will not be rendered: let the helper thread finish before the
-        if pending is not None:                         # interpreter tears down (a daemon thread killed inside torch's generator aborts the process)
-            pending[1].join()
+        surf.join_speculation()          # the draws for an image that will not be rendered: let the helper thread finish before the interpreter tears down
         if dist is not None:
             dist.destroy_process_group()
 
@@ -466,7 +457,7 @@ def main():
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             doc = json.load(open(tpath))
             t = doc["kernels"].get(dom_name.split(":")[0])
-            if t and args.chunk == 32768 and args.views == 5 and doc.get("kernel_source_hash") == kernel_source_hash():
+            if t and args.chunk in (None, 32768) and args.views == 5 and doc.get("kernel_source_hash") == kernel_source_hash():
                 traffic = t["traffic_bytes_per_launch_corrected"]      # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide)
                 traffic_source = "profiles/" + os.path.basename(tpath) + " (mean over the entry point's launches)"
                 break
@@ -634,6 +625,24 @@ def main():
                                       for k in ("lattice_ms", "render_ms", "total_ms", "total_ms_stats", "vertices", "triangles")}
         except Exception as e:
             val_item = {"error": f"{type(e).__name__}: {e}"}
+    # The measured configuration IS the shipped one: the headline above sets nothing on the model (ray chunk and jitter head start are
+    # ImplicitSurface.validate's own defaults).  Beside it, the same scene as ONE validation item through the public boundary --
+    # GenS(has_vol).forward("val", ipts), runner.py:215 -- with the item's mesh time taken out: within 2 % of the headline step.
+    default_path = None
+    if secondary and args.sdf_precision == "f32" and not args.chunk:
+        try:
+            from scripts.val_full_bench import measure_default_path
+            default_path = measure_default_path(repeats=SECONDARY_STEPS + 1, dims=tuple(args.dims))
+            headline_ms = elapsed / args.steps * 1e3
+            default_path.update({
+                "ms_per_step": default_path["render_ms"], "value": round(n_rays * n_final / default_path["render_ms"] * 1e3, 1), "unit": "ray-samples/s",
+                "ratio_to_headline_ms": round(default_path["render_ms"] / headline_ms, 4),
+                "what": "GenS(has_vol).forward('val', ipts) as runner.py:215 calls it, nothing set on the model from outside; item_ms = the whole item "
+                        "incl. the mesh the reference's validate always extracts (512^3 lattice + marching cubes = geometry_ms, wall time taken inside "
+                        "validate), render_ms = item_ms - geometry_ms = the headline's render without K1 (~0.26 ms; the volumes of a has_vol model are "
+                        "parameters)"})
+        except Exception as e:
+            default_path = {"error": f"{type(e).__name__}: {e}"}
 
     line = {
         "metric": "SDF ray-samples/sec at 480x640, 5-view, 3-scale volumes", "value": value, "unit": "ray-samples/s",
@@ -646,7 +655,7 @@ def main():
                                "(K1 volume build + hierarchical sampling + SDF/blend MLPs + compositing); one scene per GPU"
                                % (args.dims, n_rays, n_final),
                    "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
-                   "ray_chunk": args.chunk, "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
+                   "ray_chunk": getattr(surf, "last_val_chunk", args.chunk), "ray_chunk_set_by": "--chunk" if args.chunk else "ImplicitSurface.validate (default)", "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
                                    if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
         "value_note": (None if world == 1 else "ray-sharded (strong scaling): ONE scene's rays split across the ranks" if by_rays else
@@ -655,7 +664,7 @@ def main():
                        "(one scene, its rays split across the ranks, gather inside the timed region)" % world),
         "strong_scaling": (None if ray_sharded is None or "error" in ray_sharded else
                            {k: ray_sharded[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_by_rank", "n_gpus", "rays_per_rank", "ray_chunk")}),
-        "k1_in_step": k1_in_step,
+        "k1_in_step": k1_in_step, "default_path": default_path,
         "roofline": roofline, "cpu_baseline": cpu, "split_half_sdf": split, "levels5": levels5, "views3": views3, "train_step": train, "val_item": val_item,
         "ray_sharded": ray_sharded, "ray_sharded_projection": projection,
         "hip_kernels": table,
@@ -711,7 +720,7 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync, projection
     sink = {}
     shard = Shard() if projection is None else Shard.single(projection[0], projection[1], sink)
     r0, r1 = shard.rays(n_rays)
-    saved_chunk, surf.val_chunk = surf.val_chunk, balanced_chunk(r1 - r0, args.chunk)
+    ray_chunk = balanced_chunk(r1 - r0, args.chunk) if args.chunk else balanced_chunk(r1 - r0)      # what validate() chooses for this rank's range
 
     def step():
         sink.clear()
@@ -720,21 +729,17 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync, projection
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, (1, n_rays), extract_geometry=False,
                           scene=scene, shard=shard)
-            surf.prefetch_jitter(n_rays)       # (see ImplicitSurface.prefetch_jitter: the last rank would otherwise wait ~12 ms for its draws)
     torch.manual_seed(4321)                    # the same CPU generator state on every rank: identical jitter for every ray
-    try:
+    step()
+    sync()
+    steps = SECONDARY_STEPS
+    t0 = time.perf_counter()
+    for _ in range(steps):
         step()
-        sync()
-        steps = SECONDARY_STEPS
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        sync()
-        dt = (time.perf_counter() - t0) / steps
-    finally:
-        surf.val_chunk = saved_chunk
+    sync()
+    dt = (time.perf_counter() - t0) / steps
     if projection is not None:
-        return {"ms": round(dt * 1e3, 2), "steps": steps, "rank": projection[0], "world": projection[1], "rays": r1 - r0, "ray_chunk": balanced_chunk(r1 - r0, args.chunk),
+        return {"ms": round(dt * 1e3, 2), "steps": steps, "rank": projection[0], "world": projection[1], "rays": r1 - r0, "ray_chunk": ray_chunk,
                 "what": "ONE GPU renders rank %d's share of a %d-way ray-sharded image alone: K1 (replicated on every rank) + rays [%d, %d) of %d, "
                         "no gather; a projection of the ray-sharded step, NOT a multi-GPU measurement" % (projection[0], projection[1], r0, r1, n_rays)}
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -744,7 +749,7 @@ def ray_sharded_variant(args, dev, dist, surf, volume, n_final, sync, projection
     dt = max(per_rank) / 1e3
     return {"scaling": "strong", "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
             "ms_per_step_by_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)},
-            "n_gpus": dist.get_world_size(), "ray_chunk": balanced_chunk(r1 - r0, args.chunk), "rays_per_rank": r1 - r0,
+            "n_gpus": dist.get_world_size(), "ray_chunk": ray_chunk, "rays_per_rank": r1 - r0,
             "workload": "one scene, %d rays split across the ranks, all_gather of the (P, 8) buffers in the timed region" % n_rays,
             "note": "secondary figure of the same run; `python bench.py --gpus N --shard rays` reports it as the headline"}
 
@@ -756,7 +761,8 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
     from gens_amd.models.modules.implicit_surface import Scene
     dims = [256, 128, 64, 32, 16]
     surf, volume = build_model(dims, dev)
-    surf.val_chunk = args.chunk
+    if args.chunk:
+        surf.val_chunk = args.chunk
     vols = [v.to(dev) for v in synthetic.make_volumes(dims, seed=100)]
     n_rays = rays_o.shape[0]
 
@@ -766,15 +772,11 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
             scene = Scene(vols, masks, imgs, feats, feats, intrs, c2ws)
             surf.validate(rays_o, rays_d, near, far, vols, masks, imgs, feats, feats, intrs, c2ws, None, None, (1, n_rays), extract_geometry=False,
                           scene=scene)
-            surf.prefetch_jitter(n_rays)       # image after image, as in the headline loop
     step()
     torch.cuda.synchronize()
     import gc
     gc.collect()
     dt, ms = run_timed(step)
-    pending = getattr(surf, "_jitter_ahead", None)
-    if pending is not None:
-        pending[1].join()
     res = {"volume_dims": dims, "value": n_rays * n_final / dt, "unit": "ray-samples/s", "ms_per_step": round(dt * 1e3, 2), "steps": SECONDARY_STEPS,
            "ms_per_step_stats": percentiles(ms), "note": "the shipped level count of confs/gens.conf; BASELINE's metric is quoted on three levels, so this is not the headline"}
     if not kernels:      # the same steps in the opt-in split-half arithmetic (gens_sdf_value_f16 / gens_sdf_grad_f16 at five levels)
@@ -789,9 +791,7 @@ def five_level_variant(args, dev, sc, feats, imgs, intrs, c2ws, near, far, rays_
         step()
         torch.cuda.synchronize()
         res["hip_kernels"] = kernel_rows(L.profile_end(), 4)
-        pending = getattr(surf, "_jitter_ahead", None)
-        if pending is not None:
-            pending[1].join()
+    surf.join_speculation()
     return res
 
 

@@ -44,7 +44,10 @@ class GraphedStep:
         saved_rng = torch.get_rng_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                          # (warm-up off the default stream, as torch.cuda.graph requires)
+        # The body's model calls run EAGERLY in here: with the default warmup=3 the third call would otherwise start an AutoGraph capture of its own
+        # inside this warm-up, whose end_capture() takes the surface's page-locked draw / check buffers away -- the whole-step capture below would then
+        # allocate page-locked memory inside an open capture -- and an AutoGraph entry with its pools would stay alive for nothing.
+        with no_auto_graph(), torch.cuda.stream(side):         # (warm-up off the default stream, as torch.cuda.graph requires)
             for _ in range(warmup):
                 optimizer.zero_grad(set_to_none=True)
                 body()
@@ -68,9 +71,11 @@ class GraphedStep:
         torch.set_rng_state(saved_rng)
         optimizer.zero_grad(set_to_none=True)                  # the captured backward then ASSIGNS the gradients (no accumulation across replays)
         self.graph = torch.cuda.CUDAGraph()
-        with _capturing(self.graph):
-            self.loss = body()
-        torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
+        try:
+            with no_auto_graph(), _capturing(self.graph):
+                self.loss = body()
+        finally:
+            torch.set_rng_state(saved_rng)                     # (the capture pass drew one step's numbers without running a step)
         self._replayed = None
 
     def __call__(self):
@@ -142,11 +147,7 @@ class _capturing:
         except BaseException:
             torch.cuda.set_stream(self.prev)
             _capturing.side.pop(self.dev, None)
-            try:
-                import ctypes
-                ctypes.CDLL("libamdhip64.so").hipGetLastError()             # (returns AND clears it: the next launch check would raise it again)
-            except OSError:
-                pass
+            _clear_sticky_hip_error()                                       # (the next launch check would raise it again)
             # capture_begin put the device's default generator into its capture mode and only capture_end's LAST step takes it out again: left there,
             # the next torch.randn on the device raises "Offset increment outside graph capture".  A clone of the state is a state outside any capture.
             try:
@@ -158,9 +159,52 @@ class _capturing:
 
 
 
+_auto_off_depth = 0
+
+
+class no_auto_graph:
+    """Context: every GenS.forward / ImplicitSurface.forward call inside runs eagerly (no warm-up count, no capture, no replay) -- for a caller that
+    captures the step itself (GraphedStep)."""
+
+    def __enter__(self):
+        global _auto_off_depth
+        _auto_off_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _auto_off_depth
+        _auto_off_depth -= 1
+        return False
+
+
+def _loaded_hip_runtime():
+    """Path of the libamdhip64 THIS process has mapped (torch's: possibly a versioned file bundled in torch/lib).  Opening "libamdhip64.so" by
+    name could map a second runtime, whose hipGetLastError knows nothing of the first one's sticky error."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rstrip("\n").split(" ")[-1]
+                if "libamdhip64.so" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return None
+
+
+def _clear_sticky_hip_error():
+    path = _loaded_hip_runtime()
+    if path is None:
+        return
+    try:
+        import ctypes
+        ctypes.CDLL(path).hipGetLastError()                    # already mapped: dlopen hands back the same handle; returns AND clears the error
+    except OSError:
+        pass
+
+
 def auto_graph_enabled():
-    """GENS_AUTO_GRAPH=0 switches the captured path off (every call eager, as in rounds 1 - 4)."""
-    return os.environ.get("GENS_AUTO_GRAPH", "1") not in ("0", "off", "false", "no")
+    """GENS_AUTO_GRAPH=0 switches the captured path off (every call eager, as in rounds 1 - 4); so does an enclosing `no_auto_graph()`."""
+    return _auto_off_depth == 0 and os.environ.get("GENS_AUTO_GRAPH", "1") not in ("0", "off", "false", "no")
 
 
 def _same(t):
@@ -190,10 +234,10 @@ class _Entry:
     """One captured (forward, backward) pair and the static tensors around it."""
     __slots__ = ("calls", "used", "state", "fwd", "bwd", "static_in", "scalar_dev", "scalar_val", "refs", "grad_inputs", "grad_static", "out_names",
                  "out_static", "out_const", "out_diff", "diff_index", "bwd_used", "bwd_all", "recapture", "surfaces", "draws", "deferred", "fwd_done",
-                 "tick", "why_eager", "out_order")
+                 "tick", "why_eager", "out_order", "generation")
 
     def __init__(self):
-        self.calls, self.used, self.state, self.tick, self.why_eager, self.recapture = 0, set(), "warm", 0, None, False
+        self.calls, self.used, self.state, self.tick, self.why_eager, self.recapture, self.generation = 0, set(), "warm", 0, None, False, 0
 
 
 class _Replay(torch.autograd.Function):
@@ -205,7 +249,8 @@ class _Replay(torch.autograd.Function):
     def forward(ctx, entry, owner, *grad_inputs):
         entry.fwd.replay()
         _phase("forward graph replayed")
-        ctx.entry, ctx.owner = entry, owner
+        entry.generation += 1
+        ctx.entry, ctx.owner, ctx.generation = entry, owner, entry.generation
         outs = tuple(o.detach() for o in entry.out_static)
         ctx.mark_non_differentiable(*[o for o, d in zip(outs, entry.out_diff) if not d])
         ctx.set_materialize_grads(False)
@@ -215,6 +260,13 @@ class _Replay(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         entry, owner = ctx.entry, ctx.owner
+        if ctx.generation != entry.generation:
+            # the saved activations of a captured step are the graph's STATIC buffers, shared by every call of the entry: a second forward has
+            # overwritten them (gradient accumulation over micro-batches, two model(...) calls before one backward).  The reference's loop never
+            # does this; silently wrong gradients are not an option
+            raise RuntimeError("gens_amd.graph.AutoGraph: backward of a captured step whose forward has been replayed again since (its activations "
+                               "live in static graph memory).  Call backward() before the next forward of the same signature, or switch the "
+                               "captured path off for this loop: model.auto_graph = False / GENS_AUTO_GRAPH=0")
         owner._before_backward(entry)                          # the errors the reference raises inside forward: before any update
         plan = entry.bwd_used
         if any(g is not None and i not in plan.index for i, g in enumerate(grads)):
@@ -375,15 +427,21 @@ class AutoGraph:
                 a = aliases[id(t)] = t.detach().requires_grad_(True)
             return a
         fwd = torch.cuda.CUDAGraph()
-        with _capturing(fwd):
-            with torch.enable_grad(), _swapped_parameters(module, alias_of):
-                out = body(static_in, scalar_dev, alias_of)
-        torch.set_rng_state(saved_rng)                         # (the capture pass drew one step's numbers without running a step)
+        taken = []
+        try:
+            with _capturing(fwd):
+                with torch.enable_grad(), _swapped_parameters(module, alias_of):
+                    out = body(static_in, scalar_dev, alias_of)
+        finally:
+            # whether the capture went through or not: the capture pass drew one step's numbers without running a step (a failed capture falls
+            # through to the EAGER step, which must see the generator where the caller left it), and the surfaces get buffers of their own back
+            torch.set_rng_state(saved_rng)
+            for s in surfaces:
+                taken.append((s,) + tuple(s.end_capture()))
         # the page-locked buffers the captured copy nodes read from / write to now belong to this entry: an eager call of another signature
         # must not reallocate or refill them behind the graph's back
         entry.draws, entry.deferred = [], []
-        for s in surfaces:
-            buf, layout, words = s.end_capture()
+        for s, buf, layout, words in taken:
             entry.draws.append((s, buf, layout))
             entry.deferred.append((s, words))
         names, tensors, consts = [], [], {}

@@ -114,7 +114,7 @@ class GenS(nn.Module):
         self.features = model["features"].to(device)
         self.implicit_surface.load_state_dict(model["implicit_surface"])
         self.has_vol = True
-        self._mode_version = getattr(self, "_mode_version", 0) + 1
+        self._drop_captured_steps()
 
     def get_params_vol(self):
         return {"volumes": self.volumes, "mask_volmes": self.mask_volmes, "features": self.features,
@@ -130,7 +130,7 @@ class GenS(nn.Module):
         self.mask_volmes = nn.ParameterList([nn.Parameter(v.detach(), requires_grad=False) for v in mask_volmes])
         self.features = nn.ParameterList([nn.Parameter(f.detach(), requires_grad=False) for f in features])
         self.has_vol = True
-        self._mode_version = getattr(self, "_mode_version", 0) + 1
+        self._drop_captured_steps()
 
     # -- forward (gens.py:124-157) ------------------------------------------------------------------------------
     def _reload_match(self, step):
@@ -172,12 +172,29 @@ class GenS(nn.Module):
             warp_full, channels = ops.build_warp_features(list(self.features[:3]))
             selected[0]._gens_warp = (tuple((id(f), f._version) for f in selected[:3]), list(selected[1:3]), (warp_full.index_select(0, index), channels))
 
+    def _tree_modes(self):
+        return tuple(m.training for m in self.modules())
+
+    def _drop_captured_steps(self):
+        """The tensors under the captured steps changed (parameters moved, volumes frozen or loaded): they can never be replayed again, and an
+        entry keeps its private graph pool -- a whole step's activations, the 256^3 U-Net's included -- until it is dropped."""
+        self._mode_version = getattr(self, "_mode_version", 0) + 1
+        for owner in (self, getattr(self, "implicit_surface", None)):
+            auto = getattr(owner, "_auto", None) if owner is not None else None
+            if auto is not None:
+                auto.reset()
+
     def train(self, mode=True):
-        self._mode_version = getattr(self, "_mode_version", 0) + 1      # (a captured step belongs to one train / eval setting of the module tree)
-        return super().train(mode)
+        # A captured step belongs to one train / eval setting of the module tree: the setting is part of the step's signature.  runner.py:140 calls
+        # model.train() at the start of EVERY epoch and validate() switches to eval and back around an image (runner.py:201): a call that changes
+        # nothing, or that returns to a setting seen before, finds its captured step again -- no re-capture (two eager steps + a capture), no second
+        # copy of the step's activations pinned in a graph pool that runner.py's empty_cache() cannot free.
+        out = super().train(mode)
+        self._mode_sig = hash(self._tree_modes())
+        return out
 
     def _apply(self, fn, *args, **kwargs):
-        self._mode_version = getattr(self, "_mode_version", 0) + 1      # .to() / .cuda() / .float(): the parameters move
+        self._drop_captured_steps()                # .to() / .cuda() / .float(): the parameters move
         return super()._apply(fn, *args, **kwargs)
 
     def _step_refs(self):
@@ -246,7 +263,7 @@ class GenS(nn.Module):
             finally:
                 surf._auto_suppressed = False
         frozen = tuple(f._version for f in self.features) if self.has_vol else ()      # (the cached layouts of the frozen maps belong to these versions)
-        key = ("GenS", mode, self.has_vol, use_match, getattr(self, "_mode_version", 0), self.training, len(refs), frozen)
+        key = ("GenS", mode, self.has_vol, use_match, getattr(self, "_mode_version", 0), getattr(self, "_mode_sig", None), self.training, len(refs), frozen)
         return auto.run(key, copied, refs, {"cos_anneal_ratio": float(cos_anneal_ratio)}, body, [surf], module=self)
 
     def _forward_impl(self, mode, ipts, cos_anneal_ratio=1.0, step=None, reload_match=True):

@@ -65,18 +65,19 @@ class Scene:
         return self._warp[use_match]
 
 
-def _jitter_block(n_rays, chunk=REFERENCE_CHUNK):
+def _jitter_block(n_rays, chunk=REFERENCE_CHUNK, generator=None):
     """Jitter of `n_rays` rays (a whole number of reference chunks, except possibly the last) in the reference's draw order:
     per chunk `torch.rand([chunk, 1])` followed by the `torch.rand([1024, 3])` of render_core (implicit_surface.py:256,362).
-    The CPU generator produces one float per 32-bit draw, so ONE large call yields the same stream as the 2*k small ones."""
+    The CPU generator produces one float per 32-bit draw, so ONE large call yields the same stream as the 2*k small ones.
+    generator: None = the default CPU generator (the reference's), else a private one standing at the state the draws start from."""
     full, rem = divmod(n_rays, chunk)
     out = []
     if full:
         per = chunk + 3 * N_RANDOM_PTS
-        out.append(torch.rand(full * per).reshape(full, per)[:, :chunk].reshape(-1, 1))
+        out.append(torch.rand(full * per, generator=generator).reshape(full, per)[:, :chunk].reshape(-1, 1))
     if rem:
-        out.append(torch.rand([rem, 1]))
-        torch.rand([N_RANDOM_PTS, 3])
+        out.append(torch.rand([rem, 1], generator=generator))
+        torch.rand([N_RANDOM_PTS, 3], generator=generator)
     return torch.cat(out, 0) if out else torch.zeros(0, 1)
 
 
@@ -89,25 +90,25 @@ class JitterStream:
     """reference_jitter() produced group by group on a helper thread, so the ~4 M host RNG draws of a 480x640 image overlap
     with GPU work instead of preceding it.
 
-    RESTRICTION (it is what keeps the draw order equal to the reference's): while the thread runs, nothing else may draw from the default
-    CPU generator -- no torch.rand / randint on the main thread, no in-process dataset sampling (DataLoader workers are separate
-    processes and are fine).  validate() joins the thread before it returns; a driver that uses prefetch_jitter() must not interleave a
-    TRAINING render (whose pts_random / t_rand come from the same generator, implicit_surface.py:256,362) between two validations
-    without joining first -- ImplicitSurface.render() does that join itself when a prefetch is pending."""
+    generator=None draws from the default CPU generator -- then nothing else may draw from it while the thread runs (validate() joins the
+    thread before it returns).  With a PRIVATE generator (validate()'s head start on the next image, ImplicitSurface._speculate_jitter) the
+    thread touches nothing shared: the draws become the default generator's past only if they are used (its state is moved to
+    `end_state()` then)."""
 
-    def __init__(self, n_rays, group, buf=None):
+    def __init__(self, n_rays, group, buf=None, generator=None):
         """buf: optional (n_rays, 1) host buffer to fill -- a page-locked one makes the per-chunk upload asynchronous."""
         import threading
         group = max(REFERENCE_CHUNK, group // REFERENCE_CHUNK * REFERENCE_CHUNK)
         self.bounds = [(s, min(s + group, n_rays)) for s in range(0, n_rays, group)]
         self.buf = buf if buf is not None else torch.empty(n_rays, 1)
+        self.generator = generator
         self.ready = [threading.Event() for _ in self.bounds]
         self.thread = threading.Thread(target=self._run, daemon=False)    # (joined at interpreter exit: a daemon thread killed inside torch's generator aborts the process)
         self.thread.start()
 
     def _run(self):
         for k, (s, e) in enumerate(self.bounds):
-            self.buf[s:e] = _jitter_block(e - s)
+            self.buf[s:e] = _jitter_block(e - s, generator=self.generator)
             self.ready[k].set()
 
     def slice(self, s, e):
@@ -120,6 +121,10 @@ class JitterStream:
     def join(self):
         self.thread.join()
 
+    def end_state(self):
+        """(after join) the generator state behind the image's last draw"""
+        return self.generator.get_state()
+
 
 class ImplicitSurface(nn.Module):
     def __init__(self, confs):
@@ -131,7 +136,9 @@ class ImplicitSurface(nn.Module):
         self.sdf_network = SDFNetwork(**confs["sdf_network"])
         self.color_network = BlendingNetwork(**confs["color_network"])
         self.deviation_network = SingleVarianceNetwork(**confs["variance_network"])
-        self.val_chunk = 8192          # rays per chunk in validate(); rays are independent, so this is a free knob
+        self.val_chunk = None          # rays per chunk in validate(); rays are independent, so this is a free knob.  None: equal chunks of at most
+                                       # 32 768 rays over the ray range (chunking.balanced_chunk) -- the setting every committed measurement uses
+        self.speculate_jitter = True   # validate() draws the NEXT image's jitter ahead of time on a private generator (see _speculate_jitter)
         self.fused_sdf = True          # inference: evaluate the SDF network with the fused MFMA kernel (gens_sdf_mlp)
         self.sdf_precision = "f32"     # "f32": exact float32 MFMA; "f16x2": split-half operands (~1e-6 rel.), float32 fallback on overflow
         self._sdf_plan = None
@@ -544,17 +551,11 @@ class ImplicitSurface(nn.Module):
         dev = rays_o.device
         net = self._train_net(scene, lean)
         if self.perturb > 0 and t_rand is None and pts_random is None and self._train_fused_ok(scene, net, lean):
-            pending = getattr(self, "_jitter_ahead", None)
-            if pending is not None:
-                pending[1].join()
             t_rand, pts_random = self._host_draws(dev, b)          # both host draws of the step (:362, then :256) through one pinned copy
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         sample_dist = 2.0 / self.n_samples                                                  # unit-sphere assumption (:355)
         steps = self._coarse_steps(dev)
         if self.perturb > 0 and t_rand is None:
-            pending = getattr(self, "_jitter_ahead", None)
-            if pending is not None:                                                         # a prefetch for the next validate() is drawing:
-                pending[1].join()                                                           # one thread at a time on the generator
             t_rand = torch.rand([b, 1])                                                     # CPU generator, :362
         z_vals = ops.coarse_z(near, far, steps, t_rand.to(dev, non_blocking=True) if self.perturb > 0 else None, b)      # (:356-363, one launch)
         if self.n_importance > 0:
@@ -630,21 +631,26 @@ class ImplicitSurface(nn.Module):
         r0, r1 = (0, n_rays) if shard is None else shard.rays(n_rays)
         # the jitter thread starts first: its ~1.5 ms per 32 768 rays (the reference's draw order costs 13 draws per ray) then hide behind
         # the mesh extraction, which draws nothing from the generator
+        chunk = self.val_chunk_for(r1 - r0)
+        self.last_val_chunk = chunk
         jitter = None
         if self.perturb > 0:
-            jitter = self._take_prefetched_jitter(n_rays)
+            jitter = self._take_speculated_jitter(n_rays)
             if jitter is None:
-                jitter = JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter"))
+                jitter = JitterStream(n_rays, chunk, self._pinned(n_rays, 1, "_pinned_jitter"))
         if extract_geometry:
+            import time
+            t_geo = time.perf_counter()
             outputs["vertices"], outputs["triangles"] = self.extract_geometry(scene.volumes_nograd(), bound_min, bound_max, mesh_resolution,
                                                                               threshold, shard=shard)
+            self.last_geometry_s = time.perf_counter() - t_geo     # (ends with the mesh's read-back: wall time is the item's share; bench.py's default_path)
         # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
         # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
         image = torch.empty(r1 - r0, 8, device=rays_o.device, dtype=torch.float32)
 
         def render_image():
-            for s in range(r0, r1, self.val_chunk):
-                e = min(s + self.val_chunk, r1)
+            for s in range(r0, r1, chunk):
+                e = min(s + chunk, r1)
                 r = self.render(rays_o[s:e], rays_d[s:e], near, far, volumes, mask_volumes, imgs, features, match_features, intrs, c2ws,
                                 cos_anneal_ratio, step, scene=scene, lean=True, t_rand=None if jitter is None else jitter.slice(s, e))
                 image[s - r0:e - r0, 0:3] = r["color_fine"]
@@ -655,6 +661,8 @@ class ImplicitSurface(nn.Module):
         render_image()
         if jitter is not None:
             jitter.join()
+            if jitter.generator is not None:           # the head start was used: its draws are the default generator's past now
+                torch.set_rng_state(jitter.end_state())
         overflowed = self._split_half_overflowed()
         if shard is not None and self.sdf_precision == "f16x2":
             overflowed = shard.any(overflowed)         # every rank re-renders or none does: the gathered image never mixes precisions
@@ -684,6 +692,8 @@ class ImplicitSurface(nn.Module):
         post[10 * p_:11 * p_].copy_(image[:, 7])
         host = self._pinned(11 * n_rays, 1, "_pinned_post")
         host.copy_(post.view(-1, 1), non_blocking=True)
+        if self.perturb > 0 and self.speculate_jitter:
+            self._speculate_jitter(n_rays, chunk)      # image after image (runner.py:215's loop): the next image's draws start while this one drains
         status = scene.views.cams.status.cpu()         # (rides behind the image copy: a singular camera matrix raises, as torch.inverse does)
         torch.cuda.current_stream().synchronize()
         if int(status) != 0:
@@ -696,29 +706,53 @@ class ImplicitSurface(nn.Module):
         outputs["render_depth"] = flat[10 * p_:11 * p_].reshape([height, width])
         return outputs
 
-    def prefetch_jitter(self, n_rays):
-        """Start drawing the NEXT validate() call's jitter now (a driver that renders image after image calls this right after it has
-        enqueued one image): the reference's draw order costs 13 generator draws per ray -- 14 ms of host time for a 480 x 640 image,
-        and a rank that renders the LAST rays of a ray-sharded image needs the generator state behind all the others', so without the
-        head start it waits ~12 ms of a 35 ms step at eight GPUs.  Draw order is unchanged: images are drawn one after the other."""
-        if self.perturb <= 0:
-            return
+    def val_chunk_for(self, n_rays):
+        """Rays per render() chunk for a range of n_rays rays: `val_chunk` when the caller set one, else equal chunks of at most 32 768."""
+        from ...chunking import balanced_chunk
+        return int(self.val_chunk) if self.val_chunk else balanced_chunk(n_rays)
+
+    def _speculate_jitter(self, n_rays, chunk=None):
+        """Draw the NEXT validate() call's jitter now, on a helper thread with a PRIVATE generator that starts at the default CPU generator's
+        current state.  The reference's draw order costs 13 generator draws per ray -- 14 ms of host time for a 480 x 640 image -- and a rank
+        that renders the LAST rays of a ray-sharded image needs the state behind all the others': without the head start the first chunk waits
+        1.5 ms per image for its draws, the last rank of eight ~12 ms of a 35 ms step.  The next validate() uses the draws only if it asks for
+        the same number of rays AND the default generator still stands where the draws started (nobody drew in between: image after image, as
+        runner.py:215's loop renders them); it then moves the default generator behind them.  Otherwise they are dropped -- a training step
+        between two validations sees exactly the reference's stream, whatever was drawn ahead."""
         pending = getattr(self, "_jitter_ahead", None)
+        state = torch.get_rng_state()
         if pending is not None:
-            pending[1].join()                          # one image ahead at most; the generator is used by one thread at a time
+            if pending[0] == n_rays and torch.equal(pending[1], state):
+                return                                 # already drawing exactly this
+            pending[2].join()                          # (its page-locked buffer is about to be reused)
+        g = torch.Generator()
+        g.set_state(state)
         # two page-locked buffers take turns: the image being rendered reads one while the next image's draws fill the other
         self._jitter_parity = 1 - getattr(self, "_jitter_parity", 0)
-        self._jitter_ahead = (n_rays, JitterStream(n_rays, self.val_chunk, self._pinned(n_rays, 1, "_pinned_jitter_ahead%d" % self._jitter_parity)))
+        buf = self._pinned(n_rays, 1, "_pinned_jitter_ahead%d" % self._jitter_parity)
+        self._jitter_ahead = (n_rays, state, JitterStream(n_rays, chunk or self.val_chunk_for(n_rays), buf, generator=g))
 
-    def _take_prefetched_jitter(self, n_rays):
+    def prefetch_jitter(self, n_rays):
+        """Rounds 2 - 5's explicit head start for drivers that render image after image; validate() now does it itself (_speculate_jitter).
+        Kept for callers that want the draws started before the FIRST image."""
+        if self.perturb > 0:
+            self._speculate_jitter(n_rays)
+
+    def _take_speculated_jitter(self, n_rays):
         pending = getattr(self, "_jitter_ahead", None)
         self._jitter_ahead = None
         if pending is None:
             return None
-        if pending[0] != n_rays:                       # a different image size: the draws were made for nothing, but in order
-            pending[1].join()
+        if pending[0] != n_rays or not torch.equal(pending[1], torch.get_rng_state()):
+            pending[2].join()                          # drawn for nothing -- on its own generator: the default one never moved
             return None
-        return pending[1]
+        return pending[2]
+
+    def join_speculation(self):
+        """Wait for a head start that will not be used (before interpreter shutdown in scripts that time themselves)."""
+        pending = getattr(self, "_jitter_ahead", None)
+        if pending is not None:
+            pending[2].join()
 
     def _pinned(self, n_rays, cols=8, slot="_pinned_image"):
         """Page-locked (P, cols) staging buffer (rendered image / ray jitter), kept between validate() calls, which end with a

@@ -91,7 +91,7 @@ def _measure(quiet, kernels=False):
         model.volumes = torch.nn.ParameterList([torch.nn.Parameter(v.detach(), requires_grad=True) for v in vols])
         model.mask_volmes = torch.nn.ParameterList([torch.nn.Parameter(m, requires_grad=False) for m in ft_masks])
         model.features = torch.nn.ParameterList([torch.nn.Parameter(f.detach(), requires_grad=False) for f in feats])
-        model._mode_version = getattr(model, "_mode_version", 0) + 1
+        model._drop_captured_steps()
         surf = model.implicit_surface
         if "--freeze-color" in sys.argv:
             surf.color_network.requires_grad_(False)

@@ -27,8 +27,8 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True, sdf_prec
     near, far = sc["near"].to(dev), sc["far"].to(dev)
     torch.manual_seed(0)
     surf = ImplicitSurface(gens_model_conf(volume_dims=tuple(dims))["implicit_surface"]).to(dev).eval()
-    surf.val_chunk = 32768
-    surf.sdf_precision = sdf_precision
+    if sdf_precision != "f32":           # (nothing else is set on the model: validate() chooses its ray chunk and draws ahead by itself)
+        surf.sdf_precision = sdf_precision
     bmin, bmax = torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])
 
     def T():
@@ -67,6 +67,52 @@ def measure(repeats=3, dims=(256, 128, 64), resolution=512, quiet=True, sdf_prec
     return res
 
 
+def measure_default_path(repeats=4, dims=(256, 128, 64)):
+    """The benchmark scene as ONE validation item through the public boundary -- `GenS(has_vol).forward("val", ipts)`, what runner.py:215 calls --
+    with NOTHING set on the model from outside (no val_chunk, no prefetch call, no Scene handed in).  The item includes the mesh (512^3 lattice +
+    marching cubes, as the reference's validate always does); its wall time is taken inside validate() (`last_geometry_s`) and reported beside
+    the item's, so that item - geometry can be held against bench.py's headline step (K1 + render, geometry off).
+    -> {"item_ms", "geometry_ms", "render_ms"} medians over the items after the first, "items"."""
+    from gens_amd.models import gens
+    dev = torch.device("cuda:0")
+    dims = list(dims)
+    sc = synthetic.make_scene(nv=5, h=480, w=640, n_levels=5, seed=0)
+    imgs, intrs, c2ws = sc["imgs"].to(dev), sc["intrs"].to(dev), sc["c2ws"].to(dev)
+    feats = [f.to(dev) for f in sc["features"]]
+    vols = [v.to(dev) for v in synthetic.make_volumes(dims, seed=100)]
+    ro, rd = synthetic.make_rays(sc["intrs"], sc["c2ws"], 480, 640)
+    torch.manual_seed(0)
+    model = gens.GenS(gens_model_conf(volume_dims=tuple(dims), has_vol=True)).to(dev)
+    with torch.no_grad():
+        _, masks = ops.volume_build(feats[:len(dims)], intrs, c2ws, dims)
+    model.volumes = torch.nn.ParameterList([torch.nn.Parameter(v, requires_grad=True) for v in vols])
+    model.mask_volmes = torch.nn.ParameterList([torch.nn.Parameter(m, requires_grad=False) for m in masks])
+    model.features = torch.nn.ParameterList([torch.nn.Parameter(f, requires_grad=False) for f in feats])
+    model._drop_captured_steps()
+    model.eval()                                                     # runner.py:201
+    ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "rays_o": ro.to(dev), "rays_d": rd.to(dev), "near": sc["near"].to(dev), "far": sc["far"].to(dev),
+            "bound_min": torch.tensor([-1.0, -1, -1], device=dev), "bound_max": torch.tensor([1.0, 1, 1], device=dev),
+            "hw": torch.tensor([480, 640], device=dev)}
+    import gc
+    item, geo = [], []
+    for it in range(repeats):
+        gc.collect()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():                                        # runner.py:199 (@torch.no_grad())
+            out = model("val", ipts, cos_anneal_ratio=1.0)           # runner.py:215
+        torch.cuda.synchronize()
+        item.append(1e3 * (time.perf_counter() - t0))
+        geo.append(1e3 * model.implicit_surface.last_geometry_s)
+    model.implicit_surface.join_speculation()
+    assert out["img_fine"].shape == (480, 640, 3) and len(out["vertices"]) > 0
+    rest = sorted(range(1, repeats), key=lambda k: item[k]) if repeats > 1 else [0]
+    k = rest[len(rest) // 2]
+    return {"item_ms": round(item[k], 2), "geometry_ms": round(geo[k], 2), "render_ms": round(item[k] - geo[k], 2), "items": repeats,
+            "ray_chunk": model.implicit_surface.last_val_chunk}
+
+
 if __name__ == "__main__":
+    print(measure_default_path())
     measure(quiet=False)
     measure(quiet=False, sdf_precision="f16x2")

@@ -343,24 +343,39 @@ def test_split_half_overflow_recomputes_the_lattice_in_float32(golden):
     close(torch.as_tensor(out["color_fine"]), torch.as_tensor(ref_out["color_fine"]), atol=1e-6, rtol=1e-6, what="colour")
 
 
-def test_prefetched_jitter_renders_the_same_images(golden):
-    """prefetch_jitter() only moves the generator draws of the NEXT image earlier in time, not in order: two images rendered with the head
-    start equal the two rendered without it, and the generator ends in the same state."""
+def test_head_start_on_the_next_images_jitter_changes_nothing(golden):
+    """validate() starts the NEXT image's jitter draws itself (on a private generator, used only if the default generator has not moved): images
+    rendered one after the other equal the ones rendered without the head start, the generator ends in the same state, and a draw between two
+    images (a training step's) makes the head start void -- the stream everybody sees is the reference's.  prefetch_jitter() (rounds 2 - 5's
+    explicit call) is the same mechanism."""
     g = golden("g9a_render")
     surf = build_surface(g)
+    assert surf.val_chunk is None and surf.speculate_jitter          # the shipped defaults are what is tested
     feats, vols, masks, match, step = scene_inputs(g)
     c = lambda t: t.cuda()  # noqa: E731
     args = (c(g["rays_o"]), c(g["rays_d"]), c(g["near"]), c(g["far"]), vols, masks, c(g["imgs"]), feats, match, c(g["intrs"]), c(g["c2ws"]), None, None, (4, 6))
-    torch.manual_seed(11)
-    a1 = surf.validate(*args, extract_geometry=False)
-    a2 = surf.validate(*args, extract_geometry=False)
-    end_a = torch.rand(1)
-    torch.manual_seed(11)
-    b1 = surf.validate(*args, extract_geometry=False)
-    surf.prefetch_jitter(24)
-    b2 = surf.validate(*args, extract_geometry=False)
-    end_b = torch.rand(1)
-    for k in ("color_fine", "sdf_depth", "render_depth"):
-        assert torch.equal(torch.as_tensor(a1[k]), torch.as_tensor(b1[k])) and torch.equal(torch.as_tensor(a2[k]), torch.as_tensor(b2[k])), k
-    assert not torch.equal(torch.as_tensor(a1["color_fine"]), torch.as_tensor(a2["color_fine"]))      # the second image has its own jitter
-    assert torch.equal(end_a, end_b)
+
+    def sequence(explicit=False):
+        torch.manual_seed(11)
+        imgs = [surf.validate(*args, extract_geometry=False)]
+        if explicit:
+            surf.prefetch_jitter(24)
+        imgs.append(surf.validate(*args, extract_geometry=False))
+        between = torch.rand(5)                                       # somebody else draws (a training step's t_rand): the head start is void
+        imgs.append(surf.validate(*args, extract_geometry=False))
+        return imgs, between, torch.rand(1)
+
+    surf.speculate_jitter = False
+    a, a_between, end_a = sequence()
+    assert getattr(surf, "_jitter_ahead", None) is None
+    surf.speculate_jitter = True
+    b, b_between, end_b = sequence()
+    assert surf._jitter_ahead is not None                            # (a head start for a fourth image is pending: dropped below)
+    e, e_between, end_e = sequence(explicit=True)
+    surf.join_speculation()
+    for other, bt, end in ((b, b_between, end_b), (e, e_between, end_e)):
+        for k in ("color_fine", "sdf_depth", "render_depth"):
+            for x, y in zip(a, other):
+                assert torch.equal(torch.as_tensor(x[k]), torch.as_tensor(y[k])), k
+        assert torch.equal(a_between, bt) and torch.equal(end_a, end)
+    assert not torch.equal(torch.as_tensor(a[0]["color_fine"]), torch.as_tensor(a[1]["color_fine"]))      # every image has its own jitter

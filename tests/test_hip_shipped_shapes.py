@@ -106,7 +106,8 @@ def test_validate_full_image_480x640(nv, dims):
                                 sc["intrs"], sc["c2ws"], None, None, hw, extract_geometry=False, scene=scene)
         return out, surf.last_device_image.clone()
 
-    out, dev_image = image(32768)
+    out, dev_image = image(None)                                 # the shipped default: validate() cuts the image into equal chunks itself
+    assert surf.last_val_chunk == 30720                          # (307 200 rays = 10 x 30 720: what bench.py's headline runs)
     assert out["img_fine"].shape == (480, 640, 3) and out["render_depth"].shape == (480, 640)
     assert torch.isfinite(dev_image).all()
     # rays are independent: another chunking renders the same image (same jitter per ray) bit for bit
@@ -194,7 +195,7 @@ def test_validate_full_image_480x640(nv, dims):
     # within a tenth of the north-star bound of the float32 image over ALL rays, and within the bound of the oracle on the sample
     surf.sdf_precision = "f16x2"
     try:
-        _, half_image = image(32768)
+        _, half_image = image(None)
     finally:
         surf.sdf_precision = "f32"
     assert surf._sdf_plan.grad_pieces is not None and not torch.equal(half_image, dev_image)

@@ -30,6 +30,41 @@ def test_jitter_matches_the_reference_draw_order_for_any_chunking():
         assert torch.equal(after_ref, after_one) and torch.equal(after_ref, after_stream)   # generator left in the same state
 
 
+def test_jitter_head_start_is_used_only_if_the_generator_has_not_moved(monkeypatch):
+    """ImplicitSurface._speculate_jitter / _take_speculated_jitter (what validate() does between two images), without a device."""
+    surf = M.ImplicitSurface(gens_model_conf(volume_dims=(8, 4, 2))["implicit_surface"])
+    monkeypatch.setattr(surf, "_pinned", lambda n, cols=8, slot="": torch.empty(n, cols))
+    n = 700
+    # used: the draws equal the reference's from that state, and end_state() is the state behind them
+    torch.manual_seed(5)
+    start = torch.get_rng_state()
+    surf._speculate_jitter(n)
+    assert torch.equal(torch.get_rng_state(), start)                 # the default generator did not move
+    js = surf._take_speculated_jitter(n)
+    assert js is not None and surf._jitter_ahead is None
+    got = js.slice(0, n).clone()
+    js.join()
+    want = M.reference_jitter(n)
+    assert torch.equal(got, want) and torch.equal(js.end_state(), torch.get_rng_state())
+    # void: somebody drew in between, or another ray count is asked for
+    torch.manual_seed(5)
+    surf._speculate_jitter(n)
+    torch.rand(3)
+    state = torch.get_rng_state()
+    assert surf._take_speculated_jitter(n) is None and torch.equal(torch.get_rng_state(), state)
+    surf._speculate_jitter(n)
+    assert surf._take_speculated_jitter(n + 1) is None and torch.equal(torch.get_rng_state(), state)
+    # asked twice from the same state: one thread, not two
+    surf._speculate_jitter(n)
+    first = surf._jitter_ahead[2]
+    surf.prefetch_jitter(n)
+    assert surf._jitter_ahead[2] is first
+    surf.join_speculation()
+    assert surf.val_chunk is None and surf.val_chunk_for(307200) == 30720 and surf.val_chunk_for(38400) == 19200
+    surf.val_chunk = 512
+    assert surf.val_chunk_for(307200) == 512
+
+
 def test_config_stand_in_behaves_like_a_config_tree():
     c = gens_model_conf(volume_dims=(256, 128, 64))
     assert c.get_list("volume.volume_dims") == [256, 128, 64]
