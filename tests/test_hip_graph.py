@@ -17,9 +17,12 @@ def _setup():
     return model, ipts, opt, _loss
 
 
-def test_graphed_finetune_step_walks_the_eager_trajectory():
+@pytest.mark.parametrize("warm", [2, None])
+def test_graphed_finetune_step_walks_the_eager_trajectory(warm):
+    """warm=None: GraphedStep's own default (3 warm-up calls).  The model's own capture-behind-the-boundary (AutoGraph, on by default) would start
+    on exactly that third call, nested inside this warm-up: GraphedStep switches it off for its warm-up and its capture."""
     from gens_amd.graph import GraphedStep
-    warm, n = 2, 4
+    n = 4
     # eager: n steps from the seed.  The graphed run warms up `warm` times and captures once in between -- and must STILL walk this trajectory:
     # GraphedStep puts parameters, optimiser state and the CPU generator back, so replay k is step k
     model, ipts, opt, loss_fn = _setup()
@@ -46,7 +49,8 @@ def test_graphed_finetune_step_walks_the_eager_trajectory():
         assert a.shape == b.shape
     torch.manual_seed(21)
     ipts = ipts2                                     # (body_of closes over `ipts`: the second model's own tensors)
-    step = GraphedStep(body_of(model2, opt2), [model2.implicit_surface], opt2, warmup=warm)
+    step = GraphedStep(body_of(model2, opt2), [model2.implicit_surface], opt2, **({} if warm is None else {"warmup": warm}))
+    assert getattr(model2, "_auto", None) is None or model2._auto.stats["captured"] == 0      # no capture of the model's own inside the caller's
     graphed = []
     for _ in range(n):
         graphed.append(float(step()))
