@@ -381,6 +381,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     kernels, each_launch = L.profile_end(per_launch=True) if not args.no_kernel_timing else ({}, {})
+    headline_chunk = getattr(surf, "last_val_chunk", args.chunk)          # (the secondaries below render other ray counts with the same model)
     timed_steps = {k: args.steps for k in kernels}
     if not args.no_kernel_timing:
         L.profile_begin()
@@ -655,7 +656,7 @@ def main():
                                "(K1 volume build + hierarchical sampling + SDF/blend MLPs + compositing); one scene per GPU"
                                % (args.dims, n_rays, n_final),
                    "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_final, "views": args.views, "volume_dims": args.dims,
-                   "ray_chunk": getattr(surf, "last_val_chunk", args.chunk), "ray_chunk_set_by": "--chunk" if args.chunk else "ImplicitSurface.validate (default)", "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
+                   "ray_chunk": headline_chunk, "ray_chunk_set_by": "--chunk" if args.chunk else "ImplicitSurface.validate (default)", "cnn": "out of scope (synthetic feature pyramid and regularised volumes)",
                    "parallelism": ("ONE scene, contiguous ray ranges across ranks, K1 replicated, all_gather of rendered buffers in the timed region"
                                    if by_rays else "scenes sharded across ranks, all_gather of rendered buffers") if world > 1 else "single GPU"},
         "value_note": (None if world == 1 else "ray-sharded (strong scaling): ONE scene's rays split across the ranks" if by_rays else

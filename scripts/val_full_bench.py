@@ -104,11 +104,24 @@ def measure_default_path(repeats=4, dims=(256, 128, 64)):
         torch.cuda.synchronize()
         item.append(1e3 * (time.perf_counter() - t0))
         geo.append(1e3 * model.implicit_surface.last_geometry_s)
-    model.implicit_surface.join_speculation()
     assert out["img_fine"].shape == (480, 640, 3) and len(out["vertices"]) > 0
+    # the same model's render alone (validate() called directly, geometry off): what "item - geometry" should come to
+    surf, alone = model.implicit_surface, []
+    feats_sel = [f.detach() for f in model.features]
+    for it in range(repeats):
+        gc.collect()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            surf.validate(ipts["rays_o"], ipts["rays_d"], ipts["near"], ipts["far"], list(model.volumes), list(model.mask_volmes), imgs, feats_sel, feats_sel,
+                          intrs, c2ws, None, None, (480, 640), extract_geometry=False)
+        torch.cuda.synchronize()
+        alone.append(1e3 * (time.perf_counter() - t0))
+    model.implicit_surface.join_speculation()
     rest = sorted(range(1, repeats), key=lambda k: item[k]) if repeats > 1 else [0]
     k = rest[len(rest) // 2]
     return {"item_ms": round(item[k], 2), "geometry_ms": round(geo[k], 2), "render_ms": round(item[k] - geo[k], 2), "items": repeats,
+            "render_alone_ms": round(sorted(alone[1:])[len(alone[1:]) // 2] if repeats > 1 else alone[0], 2),
             "ray_chunk": model.implicit_surface.last_val_chunk}
 
 

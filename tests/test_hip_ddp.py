@@ -217,6 +217,10 @@ def test_finetune_stepper_drives_flat_gradients():
 # ----------------------------------------------------------------------------------------------------------------------
 # Round 6: the captured step (gens_amd.graph.AutoGraph) under data parallelism, for more than the one or two steps the tests above run
 # ----------------------------------------------------------------------------------------------------------------------
+# rgb_fc.4.bias shifts every view's score alike: the soft-max over views does not see it, its gradient is analytically ZERO -- 1e-8 of round-off in
+# any implementation, which Adam's normalisation turns into steps of +-lr whose signs follow the summation order (here: the order the ranks'
+# gradients are added in).  Every other parameter is compared.
+NOISE_ONLY = "color_network.rgb_fc.4.bias"
 N_LOOP = 7          # two eager warm-up steps, one capture, five replays (the capture step itself replays)
 TRAIN_LRS = {"mlp_lr": 5e-4, "feat_lr": 1e-3}
 FT_LRS = {"mlp_lr": 5e-4, "vol_lr": [1e-2, 1e-2, 1e-2]}
@@ -332,6 +336,8 @@ def _check_against_reference(got_by_rank, ref_losses, ref_params, rel, prel):
             assert abs(a - b) <= rel * abs(b), (r, losses, ref_losses[r])
         assert set(params) == set(ref_params)
         for k, v in params.items():
+            if k.endswith(NOISE_ONLY):
+                continue
             ref = ref_params[k]
             assert float(np.abs(v - ref).max()) <= prel * max(float(np.abs(ref).max()), 1e-2), (r, k)
         assert digests == got_by_rank[0][1], r                # every rank ends EVERY step with the same parameters, bit for bit
@@ -459,4 +465,5 @@ def test_a_failed_capture_under_ddp_stays_eager_in_the_same_process():
     for a, b in zip(losses, ref_losses[0]):
         assert abs(a - b) <= 1e-4 * abs(b), (losses, ref_losses[0])
     for k, v in _params_np(model).items():
-        assert float(np.abs(v - ref_params[k]).max()) <= 2e-3 * max(float(np.abs(ref_params[k]).max()), 1e-2), k
+        if not k.endswith(NOISE_ONLY):
+            assert float(np.abs(v - ref_params[k]).max()) <= 2e-3 * max(float(np.abs(ref_params[k]).max()), 1e-2), k
