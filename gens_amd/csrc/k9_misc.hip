@@ -16,7 +16,7 @@ void gens_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gens_last_error(void) { return g_err; }
-extern "C" int gens_abi_version(void) { return 10; }
+extern "C" int gens_abi_version(void) { return 11; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K9: bilinear read of a texel image at pixel coordinates (align_corners=True after the reference's own

@@ -117,6 +117,8 @@ SIGNATURES = {
     "gens_blend_train_fwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _p, _p],
     "gens_blend_train_bwd": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _pp, _pp, _p, _p, _p],
     "gens_blend_train_bwd_acc": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p],
+    "gens_blend_train_bwd_t": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p],
+    "gens_blend_train_bwd_t_dump": [_pp, _ip, _i, _p, _p, _p, _p, _i, _pp, _p, _p, _l, _p, _p, _p, _p, _p, _p, _pp, _pp, _p],
     "gens_lookup_feature_bwd_idx": [_ip, _i, _p, _p, _i, _p, _p, _p, _l, _p, _pp, _p, _p],
     "gens_gemm_tn_batch_live": [_i, _pp, _ip, _pp, _ip, _ip, _ip, _l, _p, _i, _i, _p, _p, _p],
     "gens_sdf_train_pack": [_pp, _pp, _i, _pp, _pp, _p],
@@ -186,6 +188,8 @@ def load():
     lib.gens_blend_train_acc_parts.argtypes = [_l, _i]
     lib.gens_blend_train_acc_floats.restype = _i
     lib.gens_blend_train_acc_floats.argtypes = [_i]
+    lib.gens_blend_train_t_parts.restype = _i
+    lib.gens_blend_train_t_parts.argtypes = [_l, _i]
     lib.gens_gemm_tn_batch_workspace.restype = _l
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
     lib.gens_scene_cams_floats.restype = _l

@@ -23,6 +23,8 @@ class KernelChoice:
         blend                  "transposed" (k7t, two to four source views) | "rowmajor" (k7_blend.hip)
         blend_train_fwd        "transposed" (the training step's forward through k7t + gens_blend_pack_t) | "rowmajor" (k18's own forward)
         blend_train_wgrad      "inside" (the weight-gradient sums inside the backward launch, gens_blend_train_bwd_acc) | "rows" (operand rows + K14)
+        blend_train_bwd        "transposed" (two to four source views: gens_blend_train_bwd_t, a wave per 16 rows, weights in LDS) | "rowmajor" (k18's
+                               32-row workgroups; always for other view counts)
         sdf_grad_f16           True: under sdf_precision "f16x2" the value + gradient pass runs on the split-half kernel too (k6gh) | False: float32
         k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
         tex_cache              texel copies kept on the map tensors (pack_maps)"""
@@ -34,6 +36,7 @@ class KernelChoice:
         self.blend = "rowmajor" if env.get("GENS_BLEND_ROWMAJOR") else "transposed"
         self.blend_train_fwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_ROWMAJOR") else "transposed"
         self.blend_train_wgrad = "rows" if env.get("GENS_K18_OPERAND_ROWS") else "inside"
+        self.blend_train_bwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_BWD_ROWMAJOR") or env.get("GENS_K18_OPERAND_ROWS") else "transposed"
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
 

@@ -218,6 +218,16 @@ class _BlendTrain(torch.autograd.Function):
         ev = lambda x: (x + 1) // 2 * 2  # noqa: E731      (even widths: the batched product then reads 8 bytes per lane)
         want_maps = any(ctx.needs_input_grad[3 + 23:])
         g_feat = e(n, s, f) if want_maps else None
+        true_flops = (2 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n      # the forward again, the reverse chain, [dW | db]
+        if 2 <= s <= 4 and kernels.blend_train_bwd == "transposed" and kernels.blend_train_wgrad == "inside" and n > 0:
+            # the TRANSPOSED backward (k18t_blend_train.hip): a wave per 16 rows, the weights in LDS, one block of weight-gradient sums per wave
+            lib = L.load()
+            csz = lib.gens_blend_train_acc_floats(nl)
+            n_parts = lib.gens_blend_train_t_parts(n, views.nv)
+            parts, cc, s_part = e(n_parts, csz), e(csz), e(n_parts)
+            L.call("gens_blend_train_bwd_t", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr(g_feat), L.ptr(s_part), L.ptr(parts), L.ptr(cc), L.stream(),
+                   nbytes=4 * n * (3 + s * f), flops=true_flops, live=ctx.live, label="gens_blend_train_bwd")
+            return _BlendTrain._finish(ctx, cc, s_part, g_feat, w, f, nl, pshapes, fshapes, ishape, want_maps, views, pts, hw, idx, cnt, n, dev)
         s_part = e(rows // 32) if n else torch.zeros(rows // 32, device=dev, dtype=_f32)
         if kernels.blend_train_wgrad == "inside":
             # the eleven [dW_l | db_l] blocks summed INSIDE the backward launch (persistent workgroups, sums in registers): no operand rows
@@ -228,13 +238,12 @@ class _BlendTrain(torch.autograd.Function):
             # (zeros, not empty: with n == 0 the entry point returns before either of its launches and _finish reads cc as it is)
             cc = torch.zeros(csz, device=dev, dtype=_f32) if n == 0 else e(csz)
             L.call("gens_blend_train_bwd_acc", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr(g_feat), L.ptr(s_part), L.ptr(parts), L.ptr(cc), L.stream(),
-                   nbytes=4 * n * (3 + s * f), flops=(3 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n, live=ctx.live,
-                   label="gens_blend_train_bwd")
+                   nbytes=4 * n * (3 + s * f), flops=true_flops, live=ctx.live, label="gens_blend_train_bwd")
             return _BlendTrain._finish(ctx, cc, s_part, g_feat, w, f, nl, pshapes, fshapes, ishape, want_maps, views, pts, hw, idx, cnt, n, dev)
         r_ops = [e(rows, ev(k + 1)) for k in ins]
         l_ops = [e(rows, ev(m)) for m in outs]
         L.call("gens_blend_train_bwd", *ctx.args, L.ptr(_c(g_rgb.to(_f32))), L.ptr_table(r_ops), L.ptr_table(l_ops), L.ptr(g_feat), L.ptr(s_part),
-               L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=3 * n * flops, live=ctx.live)
+               L.stream(), nbytes=4 * rows * (sum(ins) + 11 + sum(outs)), flops=2 * n * flops, live=ctx.live)      # the forward again + the reverse chain
         # [dW_l | db_l] = l_ops[l]^T r_ops[l]: eleven products over the same rows in one launch
         ms, ns = [ev(m) for m in outs], [ev(k + 1) for k in ins]
         mi, ni = L.int_table(ms), L.int_table(ns)

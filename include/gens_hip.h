@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-/* 10.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
+/* 11.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
  *   8 = round 4's additions, which shipped under the stale number 7: gens_grid_sample_{fwd,bwd,bwd2} (K20), gens_depthwise_conv2d_{fwd,dgrad,wgrad}
  *       + gens_depthwise_conv2d_wgrad_parts (K21), gens_batchnorm2d_train_{fwd,bwd} + gens_batchnorm2d_scratch_doubles (K22),
  *       gens_blend_train_bwd_acc + gens_blend_train_acc_{parts,floats}, gens_merge_upsample, gens_conv3d_wgrad_parts_strided, gens_instnorm_finish,
@@ -49,7 +49,9 @@ const char* gens_last_error(void);
  *   9 = round 5: gens_composite_in gained `cos_anneal_dev` (the annealing ratio read from the device, so that a captured step can be replayed
  *       with another ratio) -- a struct-layout change: callers built against 8 must be rebuilt.
  *   10 = round 5: gens_sdf_train_bwd's w6_part has a row per SIXTEEN points (npad / 16 rows, was npad / 32): its workgroups own 16 points
- *       now, two of them to a compute unit. */
+ *       now, two of them to a compute unit.
+ *   11 = round 6: gens_blend_train_bwd_t + gens_blend_train_t_parts + gens_blend_train_bwd_t_dump (the colour branch's backward transposed: one
+ *       wave per 16 rows, nothing shared between waves but the weights in LDS). */
 int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -532,6 +534,24 @@ int gens_blend_train_acc_floats(int n_levels);
 int gens_blend_train_bwd_acc(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
                              const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
                              const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc, void* stream);
+/* The same backward TRANSPOSED (round 6; two to four source views, nv = 3 .. 5 -- other counts: gens_blend_train_bwd_acc): a wave owns 16 (point,
+ * view) rows and all of their forward, reverse and weight-gradient work -- the weights of the eleven layers in LDS as the A operand of
+ * v_mfma_f32_16x16x4_f32, the activations in registers from layer to layer and, in [channel][row] order, in a wave-private LDS store the weight-
+ * gradient products read both operands from; four independent waves per workgroup, one persistent workgroup per compute unit, no barrier behind the
+ * weight load.  gens_blend_train_t_parts(n, nv) = the number of waves = blocks of gens_blend_train_acc_floats(n_levels) floats in `parts` AND
+ * entries of s_part (one partial of d loss / d |s| per wave; 0 = nothing to launch or a view count this kernel is not built for); cc, g_feat as in
+ * gens_blend_train_bwd_acc.  Results equal gens_blend_train_bwd_acc's up to float32 summation order.
+ * gens_blend_train_bwd_t_dump additionally leaves the operand rows r_ops / l_ops of gens_blend_train_bwd (same widths) for
+ * rows = 16 ceil(n / (16 / G)) rows, G = 2 (nv = 3) or 4 lanes per point: row 16 tile + G point + view (three source views: every fourth row is
+ * empty) -- the two kernels compared layer by layer (tests). */
+int gens_blend_train_t_parts(int64_t n, int nv);
+int gens_blend_train_bwd_t(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                           const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                           const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc, void* stream);
+int gens_blend_train_bwd_t_dump(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
+                                const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
+                                const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc,
+                                float* const* r_ops, float* const* l_ops, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K9  the two F.grid_sample(align_corners=True) reads of surface_patch_warp   (projector.py:406-416)

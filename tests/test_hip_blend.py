@@ -240,3 +240,84 @@ def test_weight_gradient_sums_inside_the_backward_launch_equal_operand_rows_plus
         tol = 5e-4 if k == "s" else 2e-5
         # (floor: the bias in front of the soft-max has an analytically zero gradient -- 1e-8 of round-off in either form)
         assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-2 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("nv,n_levels,n", [(5, 3, 1000), (5, 5, 203), (3, 5, 77), (4, 3, 130), (4, 5, 33), (5, 1, 64), (5, 2, 50), (5, 4, 41), (3, 3, 5000)])
+def test_transposed_backward_equals_the_row_major_backward_layer_by_layer(nv, n_levels, n):
+    """gens_blend_train_bwd_t (round 6: a wave per 16 rows, weights in LDS, activations from layer to layer in registers) against
+    gens_blend_train_bwd (32-row workgroups through LDS tiles) on the same points, with an index map and a device-side count as
+    implicit_surface.py:196-199 passes them: the operand rows of EVERY layer -- [input | 1] and the cotangent of the pre-activation, which is the
+    whole forward and the whole reverse chain --, the cotangent of the looked-up rows, d loss / d |s|, and the eleven [dW | db] blocks against the
+    batched products of the row-major kernel's operand rows."""
+    from gens_amd import lib as L
+    ops, net, views, pts = _setup(nv, n_levels, seed=90 + nv + n_levels, n=n)
+    dev = pts.device
+    s, f = nv - 1, 3 + 4 * n_levels
+    g = torch.Generator().manual_seed(n)
+    idx = torch.randperm(n, generator=g).cuda()
+    n_live = max(1, (3 * n) // 4)
+    count = torch.tensor([n_live], dtype=torch.int32, device=dev)
+    g_rgb = torch.randn(n, 3, generator=g).cuda()
+    w = [p.detach().reshape(-1).contiguous() if p.dim() == 0 else p.detach().contiguous() for p in ops.blend_params(net)]
+    feats = [ops.aligned16(t.detach()) for t in views.feat_tex]
+    imgs = ops.aligned16(views.imgs_tex.detach())
+    hw = [d for t in feats for d in t.shape[1:3]]
+    args = (L.ptr_table(feats, align=16), L.int_table(hw), n_levels, L.ptr(imgs, align=16), L.ptr(views.w2c), L.ptr(views.intr), L.ptr(views.c2w), nv,
+            L.ptr_table(w), L.ptr(pts), L.ptr(idx, torch.int64), n, L.ptr(count, torch.int32), L.ptr(g_rgb))
+    ins = [4, 16, 3 * f, 64, 32, 32, 32, 32, 37, 16, 8]
+    outs = [16, f, 64, 32, 32, 33, 32, 1, 16, 8, 1]
+    ev = lambda x: (x + 1) // 2 * 2  # noqa: E731
+    lib = L.load()
+    # row-major: operand rows + the batched products
+    rows_a = lib.gens_blend_train_rows(n, nv)
+    r_a = [torch.zeros(rows_a, ev(k + 1), device=dev) for k in ins]
+    l_a = [torch.zeros(rows_a, ev(m), device=dev) for m in outs]
+    gf_a, sp_a = torch.zeros(n, s, f, device=dev), torch.zeros(rows_a // 32, device=dev)
+    L.call("gens_blend_train_bwd", *args, L.ptr_table(r_a), L.ptr_table(l_a), L.ptr(gf_a), L.ptr(sp_a), L.stream())
+    # transposed, with its operand rows dumped
+    g_lanes = 2 if nv == 3 else 4
+    rows_b = 16 * (-(-n // (16 // g_lanes)))
+    r_b = [torch.zeros(rows_b, ev(k + 1), device=dev) for k in ins]
+    l_b = [torch.zeros(rows_b, ev(m), device=dev) for m in outs]
+    csz, n_parts = lib.gens_blend_train_acc_floats(n_levels), lib.gens_blend_train_t_parts(n, nv)
+    assert n_parts > 0 and n_parts % 4 == 0
+    gf_b, sp_b = torch.zeros(n, s, f, device=dev), torch.zeros(n_parts, device=dev)
+    parts, cc = torch.zeros(n_parts, csz, device=dev), torch.zeros(csz, device=dev)
+    L.call("gens_blend_train_bwd_t_dump", *args, L.ptr(gf_b), L.ptr(sp_b), L.ptr(parts), L.ptr(cc), L.ptr_table(r_b), L.ptr_table(l_b), L.stream())
+    # the same launch without the dump: the same sums
+    gf_c, sp_c = torch.zeros(n, s, f, device=dev), torch.zeros(n_parts, device=dev)
+    parts_c, cc_c = torch.zeros(n_parts, csz, device=dev), torch.zeros(csz, device=dev)
+    L.call("gens_blend_train_bwd_t", *args, L.ptr(gf_c), L.ptr(sp_c), L.ptr(parts_c), L.ptr(cc_c), L.stream())
+    torch.cuda.synchronize()
+    # (point, view) -> its row in either kernel
+    pt = torch.arange(n_live, device=dev).repeat_interleave(s)
+    vw = torch.arange(s, device=dev).repeat(n_live)
+    ppw_a = 32 // s
+    row_a = (pt // ppw_a) * 32 + (pt % ppw_a) * s + vw
+    ppw_b = 16 // g_lanes
+    row_b = (pt // ppw_b) * 16 + (pt % ppw_b) * g_lanes + vw
+    names = ["ray_dir_fc.0", "ray_dir_fc.2", "base_fc.0", "base_fc.2", "vis_fc.0", "vis_fc.2", "vis_fc2.0", "vis_fc2.2", "rgb_fc.0", "rgb_fc.2", "rgb_fc.4"]
+    worst = {}
+    for l in range(11):
+        for kind, a, b in (("R", r_a[l][row_a], r_b[l][row_b]), ("L", l_a[l][row_a], l_b[l][row_b])):
+            scale = max(float(a.abs().max()), 1e-6)
+            err = float((a - b).abs().max()) / scale
+            worst[f"{names[l]}.{kind}"] = err
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v <= 3e-5}
+    assert not bad, bad
+    assert float((gf_a[:n_live] - gf_b[:n_live]).abs().max()) <= 3e-5 * max(float(gf_a[:n_live].abs().max()), 1e-6)
+    s_a, s_b = float(sp_a.sum()), float(sp_b.sum())
+    top_l = max(float(t[row_a].abs().max()) for t in l_a)
+    assert abs(s_a - s_b) <= 1e-4 * max(abs(s_a), top_l), (s_a, s_b)
+    assert torch.equal(cc, cc_c) and torch.equal(sp_b, sp_c) and torch.equal(gf_b, gf_c)             # deterministic, dump or not
+    # the blocks: [dW_l | db_l] = L^T [R | 1] over the live rows (float64 on the row-major kernel's operand rows)
+    off = 0
+    for l in range(11):
+        m, k = ev(outs[l]), ev(ins[l] + 1)
+        ref = (l_a[l][row_a].double().T @ r_a[l][row_a].double())[:outs[l], :ins[l] + 1]
+        got = cc[off:off + m * k].view(m, k)[:outs[l], :ins[l] + 1].double()
+        err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-9)
+        assert err <= 2e-5, (names[l], err)
+        off += m * k
+    assert off == csz
