@@ -285,6 +285,21 @@ __host__ __device__ constexpr int kt_lw_total(int F) { return kt_lw(KT_NLAYER, F
 
 typedef const __attribute__((address_space(4))) KtArgs* KtArgsPtr;
 
+// Cycle stamps of one wave's phases (build with -DGENS_K18T_STAMPS: make -C gens_amd/csrc stamps; scripts/probe/k18t_stamps_probe.py reads them):
+// never in the shipped library.  A stamp waits for everything outstanding first, so that a phase is charged with its own latencies.
+#ifdef GENS_K18T_STAMPS
+__device__ unsigned long long k18t_stamps[4][64];
+#define KT_STAMP()                                                                                           \
+    do {                                                                                                     \
+        if (blockIdx.x == 7 && tile_no == 3) {                                                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+            if (lane == 0 && n_stamp < 64) k18t_stamps[wave][n_stamp++] = __builtin_readcyclecounter();      \
+        }                                                                                                    \
+    } while (0)
+#else
+#define KT_STAMP() do { } while (0)
+#endif
+
 // S source views as G lanes per point: G = 4 for three (one dead lane) or four views, G = 2 for two
 template <int NLEV, int G, bool DUMP>
 __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_train_t_k(KtArgs A_) {
@@ -333,7 +348,14 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     f32x4 sp_v2[2] = {kt_splat(0.0f), kt_splat(0.0f)}, sp_u2[2] = {kt_splat(0.0f), kt_splat(0.0f)}, sp_r3 = kt_splat(0.0f);
     float sp_v2b = 0.0f, sp_u2b = 0.0f, sp_r3b = 0.0f, s_acc = 0.0f;
 
+#ifdef GENS_K18T_STAMPS
+    int n_stamp = 0, tile_no = -1;
+#endif
     for (int64_t tile = (int64_t)blockIdx.x * KT_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * KT_WAVES) {
+#ifdef GENS_K18T_STAMPS
+        ++tile_no;
+#endif
+        KT_STAMP();                                                   // 0: tile start
         asm volatile("" : "+s"(kp));                                  // (the loads through it belong to this tile: not hoisted, not kept)
         const KtArgs __attribute__((address_space(4)))& A = *kp;
         // ---------------------------------------------------------------- the rows of this tile
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
             }
         }
+        KT_STAMP();                                                   // 1: points loaded, projected, texels gathered and stored
         const float mask = (live && inside) ? 1.0f : 0.0f;
         // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them
         float rd[4];
@@ -392,6 +415,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             KT_AT(ST::HX + 1) = rd[0]; KT_AT(ST::HX + 2) = rd[1]; KT_AT(ST::HX + 3) = rd[2]; KT_AT(ST::HX + 4) = rd[3];
             KT_AT(ST::RD) = rd[0]; KT_AT(ST::RD + 1) = rd[1]; KT_AT(ST::RD + 2) = rd[2]; KT_AT(ST::RD + 3) = rd[3];
         }
+        KT_STAMP();                                                   // 2: compute_angle
         // ================================================================ forward
         // ---------------------------------------------------------------- ray_dir_fc, x = rgb_feat + direction feature (:87-89)
         f32x4 RDt[1], D1[1], DFE[XT];
@@ -431,6 +455,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             kt_put(S, L, ST::H0, t, mean, kq, F);
             kt_put(S, L, ST::H0 + FP, t, var, kq, F);
         }
+        KT_STAMP();                                                   // 3: ray_dir_fc, view weights, mean / variance
         // ---------------------------------------------------------------- base_fc (:103-104)
         f32x4 H0t[HT], TB[4], H[2];
 #pragma unroll
@@ -449,6 +474,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int r = 0; r < 4; ++r) H[t][r] = kt_elu(H[t][r]);
             kt_put(S, L, ST::H, t, H[t], kq, 32);
         }
+        KT_STAMP();                                                   // 4: base_fc
         // ---------------------------------------------------------------- vis_fc on h * w (:106-109)
         f32x4 A0[2], TV[2], HV[2];
         A0[0] = H[0] * wn; A0[1] = H[1] * wn;
@@ -507,6 +533,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const float ex = dead ? 0.0f : expf(score - mx);
         const float p = ex / kt_gsum<G>(ex);
 
+        KT_STAMP();                                                   // 5: vis_fc, vis_fc2, rgb_fc, soft-max
         // ================================================================ reverse
         // colour = sum_v rgb_in p_v: score_bar = p (p_bar - sum_u p_u p_bar_u), rgb_in_bar = g p
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
@@ -568,6 +595,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const float hv32_bar = vis_bar * mask * vis * (1.0f - vis) * kt_elu_d(hv32);                  // cotangent of vis_fc.2's 33rd pre-activation
         sp_v2[0] += TV[0] * hv32_bar; sp_v2[1] += TV[1] * hv32_bar;
         if (kq == 0) sp_v2b += hv32_bar;
+        KT_STAMP();                                                   // 6: reverse rgb_fc, vis_fc2 (+ their weight gradients)
         // h2 = h + hv[:32]: hv_bar[:32] = h_bar = GH
         f32x4 L5[2], L4[2], M4[2];
 #pragma unroll
@@ -592,6 +620,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if (DUMP) kt_dump<4, F, 2, 3, ST::CH>(A, S, L, ST::TV, ST::H, 32, RSW, row0, i, kq);
         kt_rev<2, 2>(KT_W(4), KT_P(4), L4, M4, i, kq);
         float w_bar = kt_qsum(kt_dot(M4[0], H[0]) + kt_dot(M4[1], H[1]));
+        KT_STAMP();                                                   // 7: reverse vis_fc
         f32x4 L3[2], L2[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -611,6 +640,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         kt_dw<kt_acc_off(2, F), 4, kt_nt(2, F), NTILES, ST::CH>(wacc, S, L, ST::TB, ST::H0, 3 * FP, nullptr, i, kq, F);
         if (DUMP) kt_dump<2, F, 4, kt_nt(2, F), ST::CH>(A, S, L, ST::TB, ST::H0, 3 * FP, nullptr, row0, i, kq);
+        KT_STAMP();                                                   // 8: reverse base_fc.2, weight gradients of base_fc
         // cotangent of [mean | var | x] (padded blocks) -> through [TB | H] back to x-layout
         f32x4 H0b[HT];
         kt_rev<4, HT>(KT_W(2), KT_P(2), L2, H0b, i, kq);
@@ -656,6 +686,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         kt_put(S, L, ST::D1, 0, L0[0], kq, 16);
         kt_dw<kt_acc_off(0, F), 1, 1, NTILES, ST::CH>(wacc, S, L, ST::D1, ST::RD, 4, nullptr, i, kq);
         if (DUMP) kt_dump<0, F, 1, 1, ST::CH>(A, S, L, ST::D1, ST::RD, 4, nullptr, row0, i, kq);
+        KT_STAMP();                                                   // 9: reverse base_fc.0, mean / variance, ray_dir_fc
         // ---------------------------------------------------------------- cotangent of the looked-up [rgb | features] rows (K4's backward reads it)
         if (A.g_feat && live) {
             float* gf = A.g_feat + (pt * Sv + v) * F;
@@ -667,6 +698,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     if (c < F) gf[c] = GX[t][r] + (c == 0 ? gx0 : c == 1 ? gx1 : c == 2 ? gx2 : 0.0f);
                 }
         }
+        KT_STAMP();                                                   // 10: g_feat stored
     }
 
     // ================================================================ this wave's block of sums
@@ -837,3 +869,9 @@ extern "C" int gens_blend_train_bwd_t_dump(const float* const* feats, const int*
     blend_train_t_reduce_k<<<gens_blocks(A.csz, 32), 256, 0, (hipStream_t)stream>>>(parts, gens_blend_train_t_parts(n, nv), A.csz, cc);
     return gens_launch_status("gens_blend_train_bwd_t_dump");
 }
+
+#ifdef GENS_K18T_STAMPS
+extern "C" int gens_debug_k18t_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k18t_stamps), sizeof(unsigned long long) * 4 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
