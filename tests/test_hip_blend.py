@@ -236,10 +236,13 @@ def test_weight_gradient_sums_inside_the_backward_launch_equal_operand_rows_plus
     for k, a in res["rows"].items():
         b = res["inside"][k]
         assert bool(torch.isfinite(b).all()), k
-        # (the anti-alias temperature's gradient is a sum of cancelling per-sample terms -- the other test judges it against the other gradients' scale)
-        tol = 5e-4 if k == "s" else 2e-5
-        # (floor: the bias in front of the soft-max has an analytically zero gradient -- 1e-8 of round-off in either form)
-        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-2 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
+        # (the anti-alias temperature's gradient is a sum of cancelling per-sample terms, each divided by a sum of view weights that may be ~1e-6: it is
+        # judged against the other gradients' scale, as in the oracle test; the bias in front of the soft-max has an analytically ZERO gradient --
+        # sum_v score_bar_v = 0 per point -- 1e-7 of round-off in either form)
+        if k in ("s", "rgb_fc.4.bias"):
+            assert float((a - b).abs().max()) <= 3e-5 * top, (k, float((a - b).abs().max()), top)
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-2 * top), (k, float((a - b).abs().max()), float(a.abs().max()))
 
 
 @pytest.mark.parametrize("nv,n_levels,n", [(5, 3, 1000), (5, 5, 203), (3, 5, 77), (4, 3, 130), (4, 5, 33), (5, 1, 64), (5, 2, 50), (5, 4, 41), (3, 3, 5000)])
@@ -309,7 +312,10 @@ def test_transposed_backward_equals_the_row_major_backward_layer_by_layer(nv, n_
     assert float((gf_a[:n_live] - gf_b[:n_live]).abs().max()) <= 3e-5 * max(float(gf_a[:n_live].abs().max()), 1e-6)
     s_a, s_b = float(sp_a.sum()), float(sp_b.sum())
     top_l = max(float(t[row_a].abs().max()) for t in l_a)
-    assert abs(s_a - s_b) <= 1e-4 * max(abs(s_a), top_l), (s_a, s_b)
+    # d loss / d |s|: per point a difference of near-equal terms divided by the sum of the raw view weights -- with TWO source views that sum is ONE
+    # difference of two exponentials, ~1e-6 where the viewing angles agree, and float32 round-off in w_bar comes out multiplied by 1e6 (the oracle
+    # test's remark on two views): held to the scale of the cotangents, loosely for two views
+    assert abs(s_a - s_b) <= (1e-3 if nv == 3 else 1e-4) * max(abs(s_a), top_l), (s_a, s_b)
     assert torch.equal(cc, cc_c) and torch.equal(sp_b, sp_c) and torch.equal(gf_b, gf_c)             # deterministic, dump or not
     # the blocks: [dW_l | db_l] = L^T [R | 1] over the live rows (float64 on the row-major kernel's operand rows)
     off = 0
