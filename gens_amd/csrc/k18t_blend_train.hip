@@ -159,12 +159,28 @@ __device__ __forceinline__ float kt_gmax(float v) {
     if (G == 4) v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
     return v;
 }
+// Across the four lane groups kq of a row (lanes n, n + 16, n + 32, n + 48): gfx950's row / half swaps on the vector ALU -- a ds_bpermute pair
+// costs two LDS round trips, and one wave per SIMD has nothing to run under them.  v_permlane16_swap exchanges the odd 16-lane rows of its first
+// operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second.  (Inline assembly:
+// the builtin with the same value in both operands was compiled to x + x on this toolchain, as if its two results were one; the s_nop is the
+// VALU-write -> permlane-read hazard the compiler pads for its own instructions.)
+__device__ __forceinline__ void kt_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void kt_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ float kt_qsum(float v) {       // sum over the four lane groups kq of a row, in every lane
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    float a = v, b = v;
+    kt_swap16(a, b);                                      // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3] (rows of 16 lanes)
+    float s = a + b;
+    a = s; b = s;
+    kt_swap32(a, b);                                      // a = [s01 s01 s01 s01], b = [s23 s23 s23 s23]
+    return a + b;
 }
-__device__ __forceinline__ float kt_from_q0(float v, int lane) { return __shfl(v, lane & 15, 64); }      // the value lane group 0 holds for this row
+__device__ __forceinline__ float kt_from_q0(float v) {    // the value lane group 0 holds for this row, in every lane
+    float a = v, b = v;
+    kt_swap16(a, b);                                      // a = [v0 v0 v2 v2]
+    b = a;
+    kt_swap32(a, b);                                      // a = [v0 v0 v0 v0]
+    return a;
+}
 __device__ __forceinline__ float kt_rowsum16(float v) {   // sum over the 16 lanes of a lane group (a DPP row), valid in its LAST lane
     v += dpp_move<0x111, 0xF>(0.0f, v);                   // row_shr:1
     v += dpp_move<0x112, 0xF>(0.0f, v);                   // row_shr:2
@@ -351,24 +367,46 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #ifdef GENS_K18T_STAMPS
     int n_stamp = 0, tile_no = -1;
 #endif
-    for (int64_t tile = (int64_t)blockIdx.x * KT_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * KT_WAVES) {
+    // ---------------------------------------------------------------- the rows of a tile; the NEXT tile's points are loaded while this one is worked on
+    const int pl = n / G, v = n % G;
+    const bool dead = v >= Sv;                                        // (three views: the fourth lane of a point carries no view)
+    const int sv = dead ? Sv : v + 1;
+    const int64_t stride = (int64_t)gridDim.x * KT_WAVES;
+    // dense row of this lane's point in tile t, -1 if it has none (index -> coordinates is a chain of two loads: the index runs two tiles ahead)
+#define KT_SRC(t) ((!dead && (t) < n_tiles && (t) * PPW + pl < npts) ? (kp->index ? kp->index[(t) * PPW + pl] : (t) * PPW + pl) : (int64_t)-1)
+    struct KtPoint { float x, y, z, g0, g1, g2; };
+    auto load_point = [&](int64_t src) {
+        KtPoint P = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (src >= 0) {
+            const float* q = kp->pts + 3 * src;
+            const float* g = kp->g_rgb + 3 * src;
+            P.x = q[0]; P.y = q[1]; P.z = q[2];
+            P.g0 = g[0]; P.g1 = g[1]; P.g2 = g[2];
+        }
+        return P;
+    };
+    int64_t tile = (int64_t)blockIdx.x * KT_WAVES + wave;
+    int64_t src_cur = KT_SRC(tile), src_n1 = KT_SRC(tile + stride);
+    KtPoint P_cur = load_point(src_cur);
+    for (; tile < n_tiles; tile += stride) {
 #ifdef GENS_K18T_STAMPS
         ++tile_no;
 #endif
         KT_STAMP();                                                   // 0: tile start
         asm volatile("" : "+s"(kp));                                  // (the loads through it belong to this tile: not hoisted, not kept)
         const KtArgs __attribute__((address_space(4)))& A = *kp;
-        // ---------------------------------------------------------------- the rows of this tile
-        const int pl = n / G, v = n % G;
-        const bool dead = v >= Sv;                                    // (three views: the fourth lane of a point carries no view)
+        const KtPoint P_n1 = load_point(src_n1);                      // in flight until the next trip
+        const int64_t src_n2 = KT_SRC(tile + 2 * stride);
+        const bool live = src_cur >= 0;
         const int64_t pt = tile * PPW + pl;
-        const bool live = !dead && pt < npts;
-        const int64_t src = live ? (A.index ? A.index[pt] : pt) : 0;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (live) { x = A.pts[3 * src]; y = A.pts[3 * src + 1]; z = A.pts[3 * src + 2]; }
-        const int sv = dead ? Sv : v + 1;
-        // ---------------------------------------------------------------- look-up (K4): every lane projects its row, lane group l & 3 reads level l
+        const float x = P_cur.x, y = P_cur.y, z = P_cur.z;
+        // ---------------------------------------------------------------- look-up (K4): every lane projects its row; lane group l & 3 reads level l, lane
+        // group 1 the image besides.  The texel loads are ISSUED here and used after compute_angle and ray_dir_fc: one exposed memory latency less.
         bool inside = true;
+        f32x4 qa[4], qb[4];                                              // slot A: the lane group's own level 0..3; slot B: level 4 (group 0) / the image (group 1)
+        float wa[4], wb[4];                                           // bilinear weights, zero where a tap is outside the map
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qa[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; qb[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; wa[k] = 0.0f; wb[k] = 0.0f; }
         {
             const SrcBase pb = project_src_base(A.w2c + 16 * sv, A.intr + 16 * sv, x, y, z);
 #pragma unroll
@@ -376,25 +414,28 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const int h = A.fs.h[l], w = A.fs.w[l];
                 const SrcProj p = project_src_level(pb, exp2f(-(float)l), h, w, A.fs.cw[l], A.fs.ch[l], A.fs.rcw[l], A.fs.rch[l]);
                 inside = inside && p.inside;
-                if (kq == (l & 3)) {
-                    float4 f = f4_zero(), c = f4_zero();
-                    if (live) {
-                        const Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-                        f = sample_texel(A.fs.data[l] + (int64_t)sv * h * w, h, w, 1, 0, t);
-                        if (l == 0) c = sample_texel(A.imgs + (int64_t)sv * h * w, h, w, 1, 0, t);
+                const bool img = l == 0 && kq == 1;
+                if ((kq == (l & 3) || img) && live) {
+                    const Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
+                    const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
+                    const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
+                    const float w00 = t.ok00 ? t.w00 : 0.0f, w01 = t.ok01 ? t.w01 : 0.0f, w10 = t.ok10 ? t.w10 : 0.0f, w11 = t.ok11 ? t.w11 : 0.0f;
+                    if (kq == (l & 3)) {
+                        const f32x4* r0 = (const f32x4*)A.fs.data[l] + ((int64_t)sv * h + y0) * w, * r1 = (const f32x4*)A.fs.data[l] + ((int64_t)sv * h + y1) * w;
+                        if (l < 4) { qa[0] = r0[x0]; qa[1] = r0[x1]; qa[2] = r1[x0]; qa[3] = r1[x1]; wa[0] = w00; wa[1] = w01; wa[2] = w10; wa[3] = w11; }
+                        else { qb[0] = r0[x0]; qb[1] = r0[x1]; qb[2] = r1[x0]; qb[3] = r1[x1]; wb[0] = w00; wb[1] = w01; wb[2] = w10; wb[3] = w11; }
                     }
-                    KT_AT(ST::H0 + 2 * FP + 3 + 4 * l) = f.x; KT_AT(ST::H0 + 2 * FP + 4 + 4 * l) = f.y;
-                    KT_AT(ST::H0 + 2 * FP + 5 + 4 * l) = f.z; KT_AT(ST::H0 + 2 * FP + 6 + 4 * l) = f.w;
-                    if (l == 0) {
-                        KT_AT(ST::H0 + 2 * FP) = c.x; KT_AT(ST::H0 + 2 * FP + 1) = c.y; KT_AT(ST::H0 + 2 * FP + 2) = c.z;
-                        RC0[n] = c.x; RC1[n] = c.y; RC2[n] = c.z;
+                    if (img) {
+                        const f32x4* r0 = (const f32x4*)A.imgs + ((int64_t)sv * h + y0) * w, * r1 = (const f32x4*)A.imgs + ((int64_t)sv * h + y1) * w;
+                        qb[0] = r0[x0]; qb[1] = r0[x1]; qb[2] = r1[x0]; qb[3] = r1[x1]; wb[0] = w00; wb[1] = w01; wb[2] = w10; wb[3] = w11;
                     }
                 }
             }
         }
-        KT_STAMP();                                                   // 1: points loaded, projected, texels gathered and stored
         const float mask = (live && inside) ? 1.0f : 0.0f;
-        // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them
+        // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them: the view weights below are differences of
+        // exponentials of rd[3] - 1 -- with two source views ONE difference, ~1e-6 where the viewing angles agree -- and 1 ulp here is per cent there
+        // (hardware sqrt / rcp / exp in these few lines: operand rows 3e-5 .. 2e-4 away from the row-major kernel's instead of 1e-6, for 3 % of a tile)
         float rd[4];
         {
             float rx = A.c2w[3] - x, ry = A.c2w[7] - y, rz = A.c2w[11] - z;
@@ -415,23 +456,57 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             KT_AT(ST::HX + 1) = rd[0]; KT_AT(ST::HX + 2) = rd[1]; KT_AT(ST::HX + 3) = rd[2]; KT_AT(ST::HX + 4) = rd[3];
             KT_AT(ST::RD) = rd[0]; KT_AT(ST::RD + 1) = rd[1]; KT_AT(ST::RD + 2) = rd[2]; KT_AT(ST::RD + 3) = rd[3];
         }
-        KT_STAMP();                                                   // 2: compute_angle
+        KT_STAMP();                                                   // 1: projection, texel loads issued, compute_angle
         // ================================================================ forward
-        // ---------------------------------------------------------------- ray_dir_fc, x = rgb_feat + direction feature (:87-89)
-        f32x4 RDt[1], D1[1], DFE[XT];
-        RDt[0] = kq == 0 ? (f32x4){rd[0], rd[1], rd[2], rd[3]} : kt_splat(0.0f);
-        kt_fwd<1, 1>(KT_W(0), KT_P(0), KT_B(0), RDt, D1, i, kq);
+        // ---------------------------------------------------------------- ray_dir_fc (:87-88)
+        f32x4 DFE[XT];
+        {
+            f32x4 RDt[1], D1[1];
+            RDt[0] = kq == 0 ? (f32x4){rd[0], rd[1], rd[2], rd[3]} : kt_splat(0.0f);
+            kt_fwd<1, 1>(KT_W(0), KT_P(0), KT_B(0), RDt, D1, i, kq);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) D1[0][r] = kt_elu(D1[0][r]);
-        kt_put(S, L, ST::D1, 0, D1[0], kq, 16);
-        kt_fwd<1, XT>(KT_W(1), KT_P(1), KT_B(1), D1, DFE, i, kq);
+            for (int r = 0; r < 4; ++r) D1[0][r] = kt_elu(D1[0][r]);
+            kt_put(S, L, ST::D1, 0, D1[0], kq, 16);
+            kt_fwd<1, XT>(KT_W(1), KT_P(1), KT_B(1), D1, DFE, i, kq);
+#pragma unroll
+            for (int t = 0; t < XT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) DFE[t][r] = kt_elu(DFE[t][r]);
+                DFE[t] = kt_mask(DFE[t], t, kq, F);
+                kt_put(S, L, ST::DFE, t, DFE[t], kq, F);
+            }
+        }
+        KT_STAMP();                                                   // 2: ray_dir_fc
+        // ---------------------------------------------------------------- the texels have arrived: [rgb | features] of the row into H0's x block
+        {
+            f32x4 fa = (f32x4){0.f, 0.f, 0.f, 0.f}, fb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                fa.x = __builtin_fmaf(qa[k].x, wa[k], fa.x); fa.y = __builtin_fmaf(qa[k].y, wa[k], fa.y);
+                fa.z = __builtin_fmaf(qa[k].z, wa[k], fa.z); fa.w = __builtin_fmaf(qa[k].w, wa[k], fa.w);
+                fb.x = __builtin_fmaf(qb[k].x, wb[k], fb.x); fb.y = __builtin_fmaf(qb[k].y, wb[k], fb.y);
+                fb.z = __builtin_fmaf(qb[k].z, wb[k], fb.z); fb.w = __builtin_fmaf(qb[k].w, wb[k], fb.w);
+            }
+            // level kq's four channels sit at x-block channels 3 + 4 kq ..: channel c = base + 4 kq + j with base = H0 + 2 FP + 3 (+ j)
+            if (kq < NLEV) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = ST::H0 + 2 * FP + 3 + j + 4 * kq;
+                    S[kt_row(c) * 16 + L.co[(ST::H0 + 2 * FP + 3 + j) & 3]] = j == 0 ? fa.x : j == 1 ? fa.y : j == 2 ? fa.z : fa.w;
+                }
+            }
+            if (NLEV == 5 && kq == 0) {
+                KT_AT(ST::H0 + 2 * FP + 19) = fb.x; KT_AT(ST::H0 + 2 * FP + 20) = fb.y; KT_AT(ST::H0 + 2 * FP + 21) = fb.z; KT_AT(ST::H0 + 2 * FP + 22) = fb.w;
+            }
+            if (kq == 1) {
+                KT_AT(ST::H0 + 2 * FP) = fb.x; KT_AT(ST::H0 + 2 * FP + 1) = fb.y; KT_AT(ST::H0 + 2 * FP + 2) = fb.z;
+                RC0[n] = fb.x; RC1[n] = fb.y; RC2[n] = fb.z;
+            }
+        }
+        // ---------------------------------------------------------------- x = rgb_feat + direction feature (:89)
         f32x4 xq[XT];
 #pragma unroll
         for (int t = 0; t < XT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) DFE[t][r] = kt_elu(DFE[t][r]);
-            DFE[t] = kt_mask(DFE[t], t, kq, F);
-            kt_put(S, L, ST::DFE, t, DFE[t], kq, F);
             xq[t] = kt_get(S, L, ST::H0 + 2 * FP, t, kq, F) + DFE[t];
             kt_put(S, L, ST::H0 + 2 * FP, t, xq[t], kq, F);
         }
@@ -455,89 +530,98 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             kt_put(S, L, ST::H0, t, mean, kq, F);
             kt_put(S, L, ST::H0 + FP, t, var, kq, F);
         }
-        KT_STAMP();                                                   // 3: ray_dir_fc, view weights, mean / variance
+        KT_STAMP();                                                   // 3: texels interpolated, view weights, mean / variance
         // ---------------------------------------------------------------- base_fc (:103-104)
-        f32x4 H0t[HT], TB[4], H[2];
+        f32x4 H[2];
+        {
+            f32x4 H0t[HT], TB[4];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) H0t[t] = kt_get(S, L, ST::H0, t, kq, 3 * FP);          // (the pad channels of the three blocks hold zeros)
-        kt_fwd<HT, 4>(KT_W(2), KT_P(2), KT_B(2), H0t, TB, i, kq);
+            for (int t = 0; t < HT; ++t) H0t[t] = kt_get(S, L, ST::H0, t, kq, 3 * FP);      // (the pad channels of the three blocks hold zeros)
+            kt_fwd<HT, 4>(KT_W(2), KT_P(2), KT_B(2), H0t, TB, i, kq);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) TB[t][r] = kt_elu(TB[t][r]);
-            kt_put(S, L, ST::TB, t, TB[t], kq, 64);
-        }
-        kt_fwd<4, 2>(KT_W(3), KT_P(3), KT_B(3), TB, H, i, kq);
+                for (int r = 0; r < 4; ++r) TB[t][r] = kt_elu(TB[t][r]);
+                kt_put(S, L, ST::TB, t, TB[t], kq, 64);
+            }
+            kt_fwd<4, 2>(KT_W(3), KT_P(3), KT_B(3), TB, H, i, kq);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) H[t][r] = kt_elu(H[t][r]);
-            kt_put(S, L, ST::H, t, H[t], kq, 32);
+                for (int r = 0; r < 4; ++r) H[t][r] = kt_elu(H[t][r]);
+                kt_put(S, L, ST::H, t, H[t], kq, 32);
+            }
         }
         KT_STAMP();                                                   // 4: base_fc
         // ---------------------------------------------------------------- vis_fc on h * w (:106-109)
-        f32x4 A0[2], TV[2], HV[2];
-        A0[0] = H[0] * wn; A0[1] = H[1] * wn;
-        kt_fwd<2, 2>(KT_W(4), KT_P(4), KT_B(4), A0, TV, i, kq);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) TV[t][r] = kt_elu(TV[t][r]);
-            kt_put(S, L, ST::TV, t, TV[t], kq, 32);
-        }
-        kt_fwd<2, 2>(KT_W(5), KT_P(5), KT_B(5), TV, HV, i, kq);
-        const f32x4 v2w0 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 4 * kq), v2w1 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 16 + 4 * kq);
-        const float hv32 = kt_elu(kt_qsum(kt_dot(v2w0, TV[0]) + kt_dot(v2w1, TV[1])) + KT_B(5)[32]);    // the 33rd output reads the same hidden layer
         f32x4 H2[2];
+        float hv32, vis;
+        {
+            f32x4 A0[2], TV[2], HV[2];
+            A0[0] = H[0] * wn; A0[1] = H[1] * wn;
+            kt_fwd<2, 2>(KT_W(4), KT_P(4), KT_B(4), A0, TV, i, kq);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) HV[t][r] = kt_elu(HV[t][r]);
-            kt_put(S, L, ST::HV, t, HV[t], kq, 32);
-            H2[t] = H[t] + HV[t];                                                                     // x = x + x_res
-            kt_put(S, L, ST::H2, t, H2[t], kq, 32);
+                for (int r = 0; r < 4; ++r) TV[t][r] = kt_elu(TV[t][r]);
+                kt_put(S, L, ST::TV, t, TV[t], kq, 32);
+            }
+            kt_fwd<2, 2>(KT_W(5), KT_P(5), KT_B(5), TV, HV, i, kq);
+            const f32x4 v2w0 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 4 * kq), v2w1 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 16 + 4 * kq);
+            hv32 = kt_elu(kt_qsum(kt_dot(v2w0, TV[0]) + kt_dot(v2w1, TV[1])) + KT_B(5)[32]);          // the 33rd output reads the same hidden layer
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) HV[t][r] = kt_elu(HV[t][r]);
+                kt_put(S, L, ST::HV, t, HV[t], kq, 32);
+                H2[t] = H[t] + HV[t];                                                                 // x = x + x_res
+                kt_put(S, L, ST::H2, t, H2[t], kq, 32);
+            }
+            vis = hw_sigmoid(hv32) * mask;
+            if (kq == 0) RSV[n] = vis;
         }
-        const float vis = (1.0f / (1.0f + expf(-hv32))) * mask;
-        if (kq == 0) RSV[n] = vis;
-        // ---------------------------------------------------------------- vis_fc2 on x * vis (:110)
-        f32x4 TU[2];
-        A0[0] = H2[0] * vis; A0[1] = H2[1] * vis;
-        kt_fwd<2, 2>(KT_W(6), KT_P(6), KT_B(6), A0, TU, i, kq);
+        // ---------------------------------------------------------------- vis_fc2 on x * vis (:110), rgb_fc on cat([x, vis, ray_diff]) (:113-115)
+        float vis2, score;
+        {
+            f32x4 A0[2], TU[2];
+            A0[0] = H2[0] * vis; A0[1] = H2[1] * vis;
+            kt_fwd<2, 2>(KT_W(6), KT_P(6), KT_B(6), A0, TU, i, kq);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) TU[t][r] = kt_elu(TU[t][r]);
-            kt_put(S, L, ST::TU, t, TU[t], kq, 32);
+                for (int r = 0; r < 4; ++r) TU[t][r] = kt_elu(TU[t][r]);
+                kt_put(S, L, ST::TU, t, TU[t], kq, 32);
+            }
+            const f32x4 u2w0 = *(const f32x4*)(KT_W(7) + 4 * kq), u2w1 = *(const f32x4*)(KT_W(7) + 16 + 4 * kq);
+            vis2 = hw_sigmoid(kt_qsum(kt_dot(u2w0, TU[0]) + kt_dot(u2w1, TU[1])) + KT_B(7)[0]) * mask;
+            if (kq == 0) KT_AT(ST::HX) = vis2;
+            f32x4 HH[3], T1[1], T2[1];
+            HH[0] = H2[0]; HH[1] = H2[1];
+            HH[2] = kq == 0 ? (f32x4){vis2, rd[0], rd[1], rd[2]} : (kq == 1 ? (f32x4){rd[3], 0.0f, 0.0f, 0.0f} : kt_splat(0.0f));
+            kt_fwd<3, 1>(KT_W(8), KT_P(8), KT_B(8), HH, T1, i, kq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T1[0][r] = kt_elu(T1[0][r]);
+            kt_put(S, L, ST::T1, 0, T1[0], kq, 16);
+            kt_fwd<1, 1>(KT_W(9), KT_P(9), KT_B(9), T1, T2, i, kq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T2[0][r] = kt_elu(T2[0][r]);
+            T2[0] = kt_mask(T2[0], 0, kq, 8);
+            kt_put(S, L, ST::T2, 0, T2[0], kq, 8);
+            const f32x4 r3w = kt_mask(*(const f32x4*)(KT_W(10) + 4 * kq), 0, kq, 8);
+            const float sc = kt_qsum(kt_dot(r3w, T2[0])) + KT_B(10)[0];
+            score = dead ? -__builtin_inff() : (mask == 0.0f ? -1e9f : sc);                         // masked_fill(mask == 0, -1e9)  (:115)
         }
-        const f32x4 u2w0 = *(const f32x4*)(KT_W(7) + 4 * kq), u2w1 = *(const f32x4*)(KT_W(7) + 16 + 4 * kq);
-        const float vis2 = (1.0f / (1.0f + expf(-(kt_qsum(kt_dot(u2w0, TU[0]) + kt_dot(u2w1, TU[1])) + KT_B(7)[0])))) * mask;
-        if (kq == 0) KT_AT(ST::HX) = vis2;
-        // ---------------------------------------------------------------- rgb_fc on cat([x, vis, ray_diff]) (:113-115)
-        f32x4 HH[3], T1[1], T2[1];
-        HH[0] = H2[0]; HH[1] = H2[1];
-        HH[2] = kq == 0 ? (f32x4){vis2, rd[0], rd[1], rd[2]} : (kq == 1 ? (f32x4){rd[3], 0.0f, 0.0f, 0.0f} : kt_splat(0.0f));
-        kt_fwd<3, 1>(KT_W(8), KT_P(8), KT_B(8), HH, T1, i, kq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T1[0][r] = kt_elu(T1[0][r]);
-        kt_put(S, L, ST::T1, 0, T1[0], kq, 16);
-        kt_fwd<1, 1>(KT_W(9), KT_P(9), KT_B(9), T1, T2, i, kq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T2[0][r] = kt_elu(T2[0][r]);
-        T2[0] = kt_mask(T2[0], 0, kq, 8);
-        kt_put(S, L, ST::T2, 0, T2[0], kq, 8);
-        const f32x4 r3w = kt_mask(*(const f32x4*)(KT_W(10) + 4 * kq), 0, kq, 8);
-        const float sc = kt_qsum(kt_dot(r3w, T2[0])) + KT_B(10)[0];
-        const float score = dead ? -__builtin_inff() : (mask == 0.0f ? -1e9f : sc);                 // masked_fill(mask == 0, -1e9)  (:115)
         // ---------------------------------------------------------------- softmax over views (:116-117)
         const float mx = kt_gmax<G>(score);
-        const float ex = dead ? 0.0f : expf(score - mx);
-        const float p = ex / kt_gsum<G>(ex);
-
+        const float ex = dead ? 0.0f : hw_exp(score - mx);
+        const float p = ex * hw_rcp(kt_gsum<G>(ex));
         KT_STAMP();                                                   // 5: vis_fc, vis_fc2, rgb_fc, soft-max
+
         // ================================================================ reverse
+        // (Nothing of the forward is kept in registers but the per-row scalars: every activation is read back from the store where its derivative or
+        // a per-lane sum needs it -- four ds_read_b32 per tile against ~100 registers held through the whole reverse pass.)
         // colour = sum_v rgb_in p_v: score_bar = p (p_bar - sum_u p_u p_bar_u), rgb_in_bar = g p
-        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-        if (live) { g0 = A.g_rgb[3 * src]; g1 = A.g_rgb[3 * src + 1]; g2 = A.g_rgb[3 * src + 2]; }
+        const float g0 = P_cur.g0, g1 = P_cur.g1, g2 = P_cur.g2;
         const float dotv = (g0 * RC0[n] + g1 * RC1[n]) + g2 * RC2[n];
         const float pdot = kt_gsum<G>(p * dotv);
         // masked_fill passes no gradient to the score it replaced: with a visible view beside it p is 0 there anyway, a point NO source view sees
@@ -545,147 +629,171 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const float sb = (live && mask != 0.0f) ? p * (dotv - pdot) : 0.0f;
         const float gx0 = live ? g0 * p : 0.0f, gx1 = live ? g1 * p : 0.0f, gx2 = live ? g2 * p : 0.0f;
         const int64_t row0 = tile * 16;
-        // rgb_fc.4 (one output): per-lane sums of sb [T2 | 1]; its input's cotangent
-        sp_r3 += T2[0] * sb;
-        if (kq == 0) sp_r3b += sb;
-        f32x4 L9[1], L8[1], HHb[3];
+        f32x4 GH[2];
+        float vis2_bar;
+        {
+            // rgb_fc.4 (one output): per-lane sums of sb [T2 | 1]; its input's cotangent
+            const f32x4 T2 = kt_get(S, L, ST::T2, 0, kq, 8);
+            const f32x4 r3w = kt_mask(*(const f32x4*)(KT_W(10) + 4 * kq), 0, kq, 8);
+            sp_r3 += T2 * sb;
+            if (kq == 0) sp_r3b += sb;
+            f32x4 L9[1], L8[1], HHb[3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L9[0][r] = sb * r3w[r] * kt_elu_d(T2[0][r]);
-        L9[0] = kt_mask(L9[0], 0, kq, 8);
-        if (DUMP) {                                                  // rgb_fc.4: L = [sb | 0], R = [T2 | 1 | 0]
-            if (kq == 0) { A.dbg_l[10][2 * (row0 + n)] = sb; A.dbg_l[10][2 * (row0 + n) + 1] = 0.0f; A.dbg_r[10][10 * (row0 + n) + 8] = 1.0f; A.dbg_r[10][10 * (row0 + n) + 9] = 0.0f; }
-            for (int r = 0; r < 4; ++r)
-                if (4 * kq + r < 8) A.dbg_r[10][10 * (row0 + n) + 4 * kq + r] = T2[0][r];
-        }
-        kt_put(S, L, ST::T2, 0, L9[0], kq, 8);
-        kt_dw<kt_acc_off(9, F), 1, 2, NTILES, ST::CH>(wacc, S, L, ST::T2, ST::T1, 16, nullptr, i, kq);
-        if (DUMP) kt_dump<9, F, 1, 2, ST::CH>(A, S, L, ST::T2, ST::T1, 16, nullptr, row0, i, kq);
-        kt_rev<1, 1>(KT_W(9), KT_P(9), L9, L8, i, kq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) L8[0][r] = L8[0][r] * kt_elu_d(T1[0][r]);
-        kt_put(S, L, ST::T1, 0, L8[0], kq, 16);
-        // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]
-        kt_dw<kt_acc_off(8, F), 1, 3, NTILES, ST::CH>(wacc, S, L, ST::T1, ST::H2, 37, nullptr, i, kq);
-        if (DUMP) kt_dump<8, F, 1, 3, ST::CH>(A, S, L, ST::T1, ST::H2, 37, nullptr, row0, i, kq);
-        kt_rev<1, 3>(KT_W(8), KT_P(8), L8, HHb, i, kq);
-        f32x4 GH[2] = {HHb[0], HHb[1]};
-        const float vis2_bar = kt_from_q0(HHb[2][0], lane);
-        // vis2 = sigmoid(q) mask ; q = u2 . tu + b (one output)
-        const float q_bar = vis2_bar * mask * vis2 * (1.0f - vis2);
-        sp_u2[0] += TU[0] * q_bar; sp_u2[1] += TU[1] * q_bar;
-        if (kq == 0) sp_u2b += q_bar;
-        f32x4 L6[2], M6[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { L6[0][r] = q_bar * u2w0[r] * kt_elu_d(TU[0][r]); L6[1][r] = q_bar * u2w1[r] * kt_elu_d(TU[1][r]); }
-        if (DUMP) {                                                  // vis_fc2.2: L = [q_bar | 0], R = [TU | 1 | 0]
-            if (kq == 0) {
-                A.dbg_l[7][2 * (row0 + n)] = q_bar; A.dbg_l[7][2 * (row0 + n) + 1] = 0.0f;
-                A.dbg_r[7][34 * (row0 + n) + 32] = 1.0f; A.dbg_r[7][34 * (row0 + n) + 33] = 0.0f;
+            for (int r = 0; r < 4; ++r) L9[0][r] = sb * r3w[r] * kt_elu_d(T2[r]);
+            L9[0] = kt_mask(L9[0], 0, kq, 8);
+            if (DUMP) {                                                  // rgb_fc.4: L = [sb | 0], R = [T2 | 1 | 0]
+                if (kq == 0) { A.dbg_l[10][2 * (row0 + n)] = sb; A.dbg_l[10][2 * (row0 + n) + 1] = 0.0f; A.dbg_r[10][10 * (row0 + n) + 8] = 1.0f; A.dbg_r[10][10 * (row0 + n) + 9] = 0.0f; }
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kq + r < 8) A.dbg_r[10][10 * (row0 + n) + 4 * kq + r] = T2[r];
             }
-            for (int t = 0; t < 2; ++t)
-                for (int r = 0; r < 4; ++r) A.dbg_r[7][34 * (row0 + n) + 16 * t + 4 * kq + r] = TU[t][r];
+            kt_put(S, L, ST::T2, 0, L9[0], kq, 8);
+            kt_dw<kt_acc_off(9, F), 1, 2, NTILES, ST::CH>(wacc, S, L, ST::T2, ST::T1, 16, nullptr, i, kq);
+            if (DUMP) kt_dump<9, F, 1, 2, ST::CH>(A, S, L, ST::T2, ST::T1, 16, nullptr, row0, i, kq);
+            kt_rev<1, 1>(KT_W(9), KT_P(9), L9, L8, i, kq);
+            const f32x4 T1 = kt_get(S, L, ST::T1, 0, kq, 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L8[0][r] = L8[0][r] * kt_elu_d(T1[r]);
+            kt_put(S, L, ST::T1, 0, L8[0], kq, 16);
+            // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]
+            kt_dw<kt_acc_off(8, F), 1, 3, NTILES, ST::CH>(wacc, S, L, ST::T1, ST::H2, 37, nullptr, i, kq);
+            if (DUMP) kt_dump<8, F, 1, 3, ST::CH>(A, S, L, ST::T1, ST::H2, 37, nullptr, row0, i, kq);
+            kt_rev<1, 3>(KT_W(8), KT_P(8), L8, HHb, i, kq);
+            GH[0] = HHb[0]; GH[1] = HHb[1];
+            vis2_bar = kt_from_q0(HHb[2][0]);
         }
-        kt_put(S, L, ST::TU, 0, L6[0], kq, 32); kt_put(S, L, ST::TU, 1, L6[1], kq, 32);
-        // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
-        kt_dw<kt_acc_off(6, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TU, ST::H2, 32, RSV, i, kq);
-        if (DUMP) kt_dump<6, F, 2, 3, ST::CH>(A, S, L, ST::TU, ST::H2, 32, RSV, row0, i, kq);
-        kt_rev<2, 2>(KT_W(6), KT_P(6), L6, M6, i, kq);
-        const float vis_bar = kt_qsum(kt_dot(M6[0], H2[0]) + kt_dot(M6[1], H2[1]));
-        GH[0] += M6[0] * vis; GH[1] += M6[1] * vis;
-        const float hv32_bar = vis_bar * mask * vis * (1.0f - vis) * kt_elu_d(hv32);                  // cotangent of vis_fc.2's 33rd pre-activation
-        sp_v2[0] += TV[0] * hv32_bar; sp_v2[1] += TV[1] * hv32_bar;
-        if (kq == 0) sp_v2b += hv32_bar;
+        float hv32_bar;
+        {
+            // vis2 = sigmoid(q) mask ; q = u2 . tu + b (one output)
+            const float q_bar = vis2_bar * mask * vis2 * (1.0f - vis2);
+            const f32x4 TU0 = kt_get(S, L, ST::TU, 0, kq, 32), TU1 = kt_get(S, L, ST::TU, 1, kq, 32);
+            const f32x4 u2w0 = *(const f32x4*)(KT_W(7) + 4 * kq), u2w1 = *(const f32x4*)(KT_W(7) + 16 + 4 * kq);
+            sp_u2[0] += TU0 * q_bar; sp_u2[1] += TU1 * q_bar;
+            if (kq == 0) sp_u2b += q_bar;
+            f32x4 L6[2], M6[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { L6[0][r] = q_bar * u2w0[r] * kt_elu_d(TU0[r]); L6[1][r] = q_bar * u2w1[r] * kt_elu_d(TU1[r]); }
+            if (DUMP) {                                                  // vis_fc2.2: L = [q_bar | 0], R = [TU | 1 | 0]
+                if (kq == 0) {
+                    A.dbg_l[7][2 * (row0 + n)] = q_bar; A.dbg_l[7][2 * (row0 + n) + 1] = 0.0f;
+                    A.dbg_r[7][34 * (row0 + n) + 32] = 1.0f; A.dbg_r[7][34 * (row0 + n) + 33] = 0.0f;
+                }
+                for (int r = 0; r < 4; ++r) { A.dbg_r[7][34 * (row0 + n) + 4 * kq + r] = TU0[r]; A.dbg_r[7][34 * (row0 + n) + 16 + 4 * kq + r] = TU1[r]; }
+            }
+            kt_put(S, L, ST::TU, 0, L6[0], kq, 32); kt_put(S, L, ST::TU, 1, L6[1], kq, 32);
+            // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
+            kt_dw<kt_acc_off(6, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TU, ST::H2, 32, RSV, i, kq);
+            if (DUMP) kt_dump<6, F, 2, 3, ST::CH>(A, S, L, ST::TU, ST::H2, 32, RSV, row0, i, kq);
+            kt_rev<2, 2>(KT_W(6), KT_P(6), L6, M6, i, kq);
+            const f32x4 H20 = kt_get(S, L, ST::H2, 0, kq, 32), H21 = kt_get(S, L, ST::H2, 1, kq, 32);
+            const float vis_bar = kt_qsum(kt_dot(M6[0], H20) + kt_dot(M6[1], H21));
+            GH[0] += M6[0] * vis; GH[1] += M6[1] * vis;
+            hv32_bar = vis_bar * mask * vis * (1.0f - vis) * kt_elu_d(hv32);                            // cotangent of vis_fc.2's 33rd pre-activation
+        }
         KT_STAMP();                                                   // 6: reverse rgb_fc, vis_fc2 (+ their weight gradients)
-        // h2 = h + hv[:32]: hv_bar[:32] = h_bar = GH
-        f32x4 L5[2], L4[2], M4[2];
+        float w_bar;
+        {
+            // h2 = h + hv[:32]: hv_bar[:32] = h_bar = GH
+            const f32x4 TV0 = kt_get(S, L, ST::TV, 0, kq, 32), TV1 = kt_get(S, L, ST::TV, 1, kq, 32);
+            sp_v2[0] += TV0 * hv32_bar; sp_v2[1] += TV1 * hv32_bar;
+            if (kq == 0) sp_v2b += hv32_bar;
+            f32x4 L5[2], L4[2], M4[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 HV = kt_get(S, L, ST::HV, t, kq, 32);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) L5[t][r] = GH[t][r] * kt_elu_d(HV[t][r]);
-            kt_put(S, L, ST::HV, t, L5[t], kq, 32);
-        }
-        if (DUMP && kq == 0) { A.dbg_l[5][34 * (row0 + n) + 32] = hv32_bar; A.dbg_l[5][34 * (row0 + n) + 33] = 0.0f; }
-        kt_dw<kt_acc_off(5, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::HV, ST::TV, 32, nullptr, i, kq);
-        if (DUMP) kt_dump<5, F, 2, 3, ST::CH>(A, S, L, ST::HV, ST::TV, 32, nullptr, row0, i, kq);
-        kt_rev<2, 2>(KT_W(5), KT_P(5), L5, L4, i, kq);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 w32 = t == 0 ? v2w0 : v2w1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L4[t][r] = (L4[t][r] + hv32_bar * w32[r]) * kt_elu_d(TV[t][r]);
-            kt_put(S, L, ST::TV, t, L4[t], kq, 32);
-        }
-        // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
-        kt_dw<kt_acc_off(4, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TV, ST::H, 32, RSW, i, kq);
-        if (DUMP) kt_dump<4, F, 2, 3, ST::CH>(A, S, L, ST::TV, ST::H, 32, RSW, row0, i, kq);
-        kt_rev<2, 2>(KT_W(4), KT_P(4), L4, M4, i, kq);
-        float w_bar = kt_qsum(kt_dot(M4[0], H[0]) + kt_dot(M4[1], H[1]));
-        KT_STAMP();                                                   // 7: reverse vis_fc
-        f32x4 L3[2], L2[4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L3[t][r] = (GH[t][r] + M4[t][r] * wn) * kt_elu_d(H[t][r]);       // base_fc.2 pre-activation
-        }
-        // (H's store still fed the weight gradient of vis_fc.0 above: L3 goes in after it)
-        kt_put(S, L, ST::H, 0, L3[0], kq, 32); kt_put(S, L, ST::H, 1, L3[1], kq, 32);
-        kt_dw<kt_acc_off(3, F), 2, 5, NTILES, ST::CH>(wacc, S, L, ST::H, ST::TB, 64, nullptr, i, kq);
-        if (DUMP) kt_dump<3, F, 2, 5, ST::CH>(A, S, L, ST::H, ST::TB, 64, nullptr, row0, i, kq);
-        kt_rev<2, 4>(KT_W(3), KT_P(3), L3, L2, i, kq);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L2[t][r] = L2[t][r] * kt_elu_d(TB[t][r]);
-            kt_put(S, L, ST::TB, t, L2[t], kq, 64);
-        }
-        kt_dw<kt_acc_off(2, F), 4, kt_nt(2, F), NTILES, ST::CH>(wacc, S, L, ST::TB, ST::H0, 3 * FP, nullptr, i, kq, F);
-        if (DUMP) kt_dump<2, F, 4, kt_nt(2, F), ST::CH>(A, S, L, ST::TB, ST::H0, 3 * FP, nullptr, row0, i, kq);
-        KT_STAMP();                                                   // 8: reverse base_fc.2, weight gradients of base_fc
-        // cotangent of [mean | var | x] (padded blocks) -> through [TB | H] back to x-layout
-        f32x4 H0b[HT];
-        kt_rev<4, HT>(KT_W(2), KT_P(2), L2, H0b, i, kq);
-#pragma unroll
-        for (int t = 0; t < HT; ++t) kt_put(S, L, ST::TB, t, H0b[t], kq, 3 * FP);
-        // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
-        f32x4 GX[XT], L1[XT], L0[1];
-        float wb_part = 0.0f;
-#pragma unroll
-        for (int t = 0; t < XT; ++t) {
-            const f32x4 mean_b = kt_get(S, L, ST::TB, t, kq, F), var_b = kt_get(S, L, ST::TB + FP, t, kq, F), x_b = kt_get(S, L, ST::TB + 2 * FP, t, kq, F);
-            const f32x4 mean = kt_get(S, L, ST::H0, t, kq, F);
+                for (int r = 0; r < 4; ++r) L5[t][r] = GH[t][r] * kt_elu_d(HV[r]);
+                kt_put(S, L, ST::HV, t, L5[t], kq, 32);
+            }
+            if (DUMP && kq == 0) { A.dbg_l[5][34 * (row0 + n) + 32] = hv32_bar; A.dbg_l[5][34 * (row0 + n) + 33] = 0.0f; }
+            kt_dw<kt_acc_off(5, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::HV, ST::TV, 32, nullptr, i, kq);
+            if (DUMP) kt_dump<5, F, 2, 3, ST::CH>(A, S, L, ST::HV, ST::TV, 32, nullptr, row0, i, kq);
+            kt_rev<2, 2>(KT_W(5), KT_P(5), L5, L4, i, kq);
+            const f32x4 v2w0 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 4 * kq), v2w1 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 16 + 4 * kq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float mb = kt_gsum<G>(mean_b[r]);
-                const float vb = kt_gsum<G>(var_b[r]);
-                const float d = xq[t][r] - mean[r];
-                const float cross = kt_gsum<G>(wn * d);
-                mb -= 2.0f * vb * cross;                                                                 // var depends on mean too
-                const float xb = x_b[r] + wn * mb + 2.0f * wn * d * vb;
-                GX[t][r] = xb;
-                L1[t][r] = xb * kt_elu_d(DFE[t][r]);                                                     // ray_dir_fc.2 pre-activation
-                wb_part += (16 * t + 4 * kq + r < F) ? mb * xq[t][r] + vb * d * d : 0.0f;
+                L4[0][r] = (L4[0][r] + hv32_bar * v2w0[r]) * kt_elu_d(TV0[r]);
+                L4[1][r] = (L4[1][r] + hv32_bar * v2w1[r]) * kt_elu_d(TV1[r]);
             }
-            L1[t] = kt_mask(L1[t], t, kq, F);
-            kt_put(S, L, ST::DFE, t, L1[t], kq, F);
-        }
-        w_bar += kt_qsum(wb_part);
-        // w = wr / (sum wr + 1e-8), wr = (e - min e) mask, e = exp(|s| (dot - 1))
-        {
-            const float sum = wsum + 1e-8f;
-            const float ww = kt_gsum<G>(w_bar * wn);
-            float wrb = (w_bar - ww) / sum * mask;
-            const float tot = kt_gsum<G>(wrb);
-            if (!dead && (float)v == arg) wrb -= tot;                                                    // the minimum's share
-            if (kq == 0 && live) s_acc += wrb * e * (rd[3] - 1.0f);
-        }
-        kt_dw<kt_acc_off(1, F), XT, 2, NTILES, ST::CH>(wacc, S, L, ST::DFE, ST::D1, 16, nullptr, i, kq);
-        if (DUMP) kt_dump<1, F, XT, 2, ST::CH>(A, S, L, ST::DFE, ST::D1, 16, nullptr, row0, i, kq);
-        kt_rev<XT, 1>(KT_W(1), KT_P(1), L1, L0, i, kq);
+            kt_put(S, L, ST::TV, 0, L4[0], kq, 32); kt_put(S, L, ST::TV, 1, L4[1], kq, 32);
+            // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
+            kt_dw<kt_acc_off(4, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TV, ST::H, 32, RSW, i, kq);
+            if (DUMP) kt_dump<4, F, 2, 3, ST::CH>(A, S, L, ST::TV, ST::H, 32, RSW, row0, i, kq);
+            kt_rev<2, 2>(KT_W(4), KT_P(4), L4, M4, i, kq);
+            const f32x4 H0_ = kt_get(S, L, ST::H, 0, kq, 32), H1_ = kt_get(S, L, ST::H, 1, kq, 32);
+            w_bar = kt_qsum(kt_dot(M4[0], H0_) + kt_dot(M4[1], H1_));
+            f32x4 L3[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L0[0][r] = L0[0][r] * kt_elu_d(D1[0][r]);
-        kt_put(S, L, ST::D1, 0, L0[0], kq, 16);
-        kt_dw<kt_acc_off(0, F), 1, 1, NTILES, ST::CH>(wacc, S, L, ST::D1, ST::RD, 4, nullptr, i, kq);
-        if (DUMP) kt_dump<0, F, 1, 1, ST::CH>(A, S, L, ST::D1, ST::RD, 4, nullptr, row0, i, kq);
+            for (int r = 0; r < 4; ++r) {                                                                  // base_fc.2 pre-activation
+                L3[0][r] = (GH[0][r] + M4[0][r] * wn) * kt_elu_d(H0_[r]);
+                L3[1][r] = (GH[1][r] + M4[1][r] * wn) * kt_elu_d(H1_[r]);
+            }
+            KT_STAMP();                                               // 7: reverse vis_fc
+            // (H's store still fed the weight gradient of vis_fc.0 above: L3 goes in after it)
+            kt_put(S, L, ST::H, 0, L3[0], kq, 32); kt_put(S, L, ST::H, 1, L3[1], kq, 32);
+            kt_dw<kt_acc_off(3, F), 2, 5, NTILES, ST::CH>(wacc, S, L, ST::H, ST::TB, 64, nullptr, i, kq);
+            if (DUMP) kt_dump<3, F, 2, 5, ST::CH>(A, S, L, ST::H, ST::TB, 64, nullptr, row0, i, kq);
+            f32x4 L2[4];
+            kt_rev<2, 4>(KT_W(3), KT_P(3), L3, L2, i, kq);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 TB = kt_get(S, L, ST::TB, t, kq, 64);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L2[t][r] = L2[t][r] * kt_elu_d(TB[r]);
+                kt_put(S, L, ST::TB, t, L2[t], kq, 64);
+            }
+            kt_dw<kt_acc_off(2, F), 4, kt_nt(2, F), NTILES, ST::CH>(wacc, S, L, ST::TB, ST::H0, 3 * FP, nullptr, i, kq, F);
+            if (DUMP) kt_dump<2, F, 4, kt_nt(2, F), ST::CH>(A, S, L, ST::TB, ST::H0, 3 * FP, nullptr, row0, i, kq);
+            KT_STAMP();                                               // 8: reverse base_fc.2, weight gradients of base_fc
+            // cotangent of [mean | var | x] (padded blocks) -> through [TB | H] back to x-layout
+            f32x4 H0b[HT];
+            kt_rev<4, HT>(KT_W(2), KT_P(2), L2, H0b, i, kq);
+#pragma unroll
+            for (int t = 0; t < HT; ++t) kt_put(S, L, ST::TB, t, H0b[t], kq, 3 * FP);
+        }
+        // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
+        f32x4 GX[XT];
+        {
+            f32x4 L1[XT], L0[1];
+            float wb_part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < XT; ++t) {
+                const f32x4 mean_b = kt_get(S, L, ST::TB, t, kq, F), var_b = kt_get(S, L, ST::TB + FP, t, kq, F), x_b = kt_get(S, L, ST::TB + 2 * FP, t, kq, F);
+                const f32x4 mean = kt_get(S, L, ST::H0, t, kq, F), xv = kt_get(S, L, ST::H0 + 2 * FP, t, kq, F), dfe = kt_get(S, L, ST::DFE, t, kq, F);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mb = kt_gsum<G>(mean_b[r]);
+                    const float vb = kt_gsum<G>(var_b[r]);
+                    const float d = xv[r] - mean[r];
+                    const float cross = kt_gsum<G>(wn * d);
+                    mb -= 2.0f * vb * cross;                                                             // var depends on mean too
+                    const float xb = x_b[r] + wn * mb + 2.0f * wn * d * vb;
+                    GX[t][r] = xb;
+                    L1[t][r] = xb * kt_elu_d(dfe[r]);                                                    // ray_dir_fc.2 pre-activation
+                    wb_part += (16 * t + 4 * kq + r < F) ? mb * xv[r] + vb * d * d : 0.0f;
+                }
+                L1[t] = kt_mask(L1[t], t, kq, F);
+                kt_put(S, L, ST::DFE, t, L1[t], kq, F);
+            }
+            w_bar += kt_qsum(wb_part);
+            // w = wr / (sum wr + 1e-8), wr = (e - min e) mask, e = exp(|s| (dot - 1))
+            {
+                const float sum = wsum + 1e-8f;
+                const float ww = kt_gsum<G>(w_bar * wn);
+                float wrb = (w_bar - ww) / sum * mask;
+                const float tot = kt_gsum<G>(wrb);
+                if (!dead && (float)v == arg) wrb -= tot;                                                // the minimum's share
+                if (kq == 0 && live) s_acc += wrb * e * (rd[3] - 1.0f);
+            }
+            kt_dw<kt_acc_off(1, F), XT, 2, NTILES, ST::CH>(wacc, S, L, ST::DFE, ST::D1, 16, nullptr, i, kq);
+            if (DUMP) kt_dump<1, F, XT, 2, ST::CH>(A, S, L, ST::DFE, ST::D1, 16, nullptr, row0, i, kq);
+            kt_rev<XT, 1>(KT_W(1), KT_P(1), L1, L0, i, kq);
+            const f32x4 D1 = kt_get(S, L, ST::D1, 0, kq, 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L0[0][r] = L0[0][r] * kt_elu_d(D1[r]);
+            kt_put(S, L, ST::D1, 0, L0[0], kq, 16);
+            kt_dw<kt_acc_off(0, F), 1, 1, NTILES, ST::CH>(wacc, S, L, ST::D1, ST::RD, 4, nullptr, i, kq);
+            if (DUMP) kt_dump<0, F, 1, 1, ST::CH>(A, S, L, ST::D1, ST::RD, 4, nullptr, row0, i, kq);
+        }
         KT_STAMP();                                                   // 9: reverse base_fc.0, mean / variance, ray_dir_fc
         // ---------------------------------------------------------------- cotangent of the looked-up [rgb | features] rows (K4's backward reads it)
         if (A.g_feat && live) {
@@ -699,7 +807,11 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
         }
         KT_STAMP();                                                   // 10: g_feat stored
+        P_cur = P_n1;
+        src_cur = src_n1;
+        src_n1 = src_n2;
     }
+#undef KT_SRC
 
     // ================================================================ this wave's block of sums
     {

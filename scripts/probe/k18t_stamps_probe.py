@@ -13,8 +13,9 @@ from gens_amd import lib as L  # noqa: E402
 k18t_probe.main()
 buf = (ctypes.c_ulonglong * (4 * 64))()
 assert L.load().gens_debug_k18t_stamps(buf) == 0
-names = ["points, projection, texel gather -> store", "compute_angle", "ray_dir_fc, view weights, mean / variance", "base_fc", "vis_fc, vis_fc2, rgb_fc, soft-max",
-         "reverse rgb_fc, vis_fc2", "reverse vis_fc", "reverse base_fc.2 + dW base_fc", "reverse base_fc.0, mean / var, ray_dir_fc", "g_feat stores"]
+names = ["points (prefetched), projection, texel loads issued, compute_angle", "ray_dir_fc", "texels interpolated, view weights, mean / variance", "base_fc",
+         "vis_fc, vis_fc2, rgb_fc, soft-max", "reverse rgb_fc, vis_fc2", "reverse vis_fc", "dW base_fc.2, reverse base_fc.2, dW base_fc.0",
+         "reverse base_fc.0, mean / var, ray_dir_fc", "g_feat stores"]
 for w in range(4):
     st = [buf[w * 64 + i] for i in range(64)]
     st = [v for v in st if v]
@@ -22,6 +23,6 @@ for w in range(4):
         print(f"wave {w}: no stamps")
         continue
     d = [st[i + 1] - st[i] for i in range(len(st) - 1)]
-    print(f"wave {w}: {len(st)} stamps, tile total {st[-1] - st[0]} ticks (s_memtime: 100 MHz -> x 24 = shader cycles at 2.4 GHz)")
+    print(f"wave {w}: {len(st)} stamps, tile total {st[-1] - st[0]} shader cycles (s_memtime)")
     for i, v in enumerate(d):
         print(f"   {names[i] if i < len(names) else '?':48s} {v:8d}")
