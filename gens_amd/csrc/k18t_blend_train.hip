@@ -23,8 +23,9 @@
 //   * the eleven [dW | db] blocks are 48 (three levels) ... 58 (five) accumulator tiles = 192 ... 232 registers of the wave, for the whole launch:
 //     one wave per SIMD owns the SIMD's 512 registers.  The single-output rows (vis_fc.2's 33rd, vis_fc2.2, rgb_fc.4) are per-lane dot products
 //     and per-lane partial sums, reduced over the 16 row lanes once, at the end.
-//   * at the end a wave leaves ONE block of sums (layout of gens_gemm_tn_batch's result, as gens_blend_train_bwd_acc does) and one partial of
-//     d loss / d |s|; blend_train_reduce_k adds the blocks in a fixed order (deterministic).
+//   * at the end the four waves' accumulators are added through LDS in wave order and the workgroup leaves ONE block of sums (layout of
+//     gens_gemm_tn_batch's result, as gens_blend_train_bwd_acc does) and one partial of d loss / d |s|; blend_train_t_reduce_k adds the blocks
+//     in a fixed order (deterministic).
 //
 // Per 16 rows at three levels: 152 forward + 148 reverse + 192 weight-gradient MFMAs (15.7 k matrix-pipe cycles) for 0.88 MFLOP of useful work.
 #include "k4_common.h"
@@ -85,15 +86,20 @@ struct KtArgs {
     int64_t n;
     const float* g_rgb;           // (N, 3) cotangent of the colours
     float* g_feat;                // (n, S, F) cotangent of the looked-up [rgb | features] rows, or NULL
-    float* s_part;                // (waves) partial sums of d loss / d |s|
-    float* parts;                 // (waves, csz) the waves' sums of L^T [R | 1]
+    float* s_part;                // (workgroups) partial sums of d loss / d |s|
+    float* parts;                 // (workgroups, csz) the workgroups' sums of L^T [R | 1]
     int csz;
     float* dbg_r[KT_NLAYER];      // DUMP launches: the operand rows of every layer as gens_blend_train_bwd leaves them, in THIS kernel's row order
     float* dbg_l[KT_NLAYER];
 };
 
-__device__ __forceinline__ float kt_elu(float x) { return x > 0.0f ? x : hw_exp(x) - 1.0f; }
-__device__ __forceinline__ float kt_elu_d(float out) { return out > 0.0f ? 1.0f : out + 1.0f; }       // d elu / d a from the OUTPUT
+// elu(x) = x for x > 0, exp(x) - 1 below: the MEDIAN of (x, exp(x) - 1, 0) -- exp(x) - 1 > x > 0 above, x < exp(x) - 1 < 0 below (k7_blend.hip::elu1).
+// (A NaN input comes out as the median of two NaNs and 0, which is not NaN: the forward launch of the step carries the poison in the row mask; this
+// launch's inputs are the step's own forward values -- finite, or the loss is NaN already.)
+__device__ __forceinline__ float kt_elu(float x) { return __builtin_amdgcn_fmed3f(x, hw_exp(x) - 1.0f, 0.0f); }
+// y * elu'(a) from the OUTPUT out = elu(a): elu' = 1 above 0, out + 1 below -> y + y * min(out, 0)
+__device__ __forceinline__ float kt_elu_dy(float y, float out) { return __builtin_fmaf(y, fminf(out, 0.0f), y); }
+__device__ __forceinline__ float kt_elu_d(float out) { return fminf(out, 0.0f) + 1.0f; }              // d elu / d a from the OUTPUT
 __device__ __forceinline__ f32x4 kt_splat(float v) { return (f32x4){v, v, v, v}; }
 
 // The store: channel rows of 16 floats.  Inside every aligned group of 8 channels bits 0 and 2 of the channel index trade places (so that the lanes
@@ -385,9 +391,44 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         return P;
     };
+    // ---------------------------------------------------------------- look-up (K4), ISSUE half: every lane projects its row; lane group l & 3 reads level l,
+    // lane group 1 the image besides.  The texel loads of tile t + 1 are issued in the middle of tile t's reverse pass and used one phase into tile
+    // t + 1: a global load takes 2 - 3 us here, 5 000 - 7 000 cycles of a 45 000-cycle tile when it is waited for.
+    // slot A: the lane group's own level 0..3; slot B: level 4 (group 0) / the image (group 1); weights zero where a tap is outside the map
+#define KT_GATHER(P_, LIVE_, qa_, qb_, wa_, wb_, inside_)                                                                          \
+    {                                                                                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { qa_[k_] = kt_splat(0.0f); qb_[k_] = kt_splat(0.0f); wa_[k_] = 0.0f; wb_[k_] = 0.0f; } \
+        inside_ = true;                                                                                                            \
+        const SrcBase pb_ = project_src_base(kp->w2c + 16 * sv, kp->intr + 16 * sv, (P_).x, (P_).y, (P_).z);                      \
+        _Pragma("unroll") for (int l_ = 0; l_ < NLEV; ++l_) {                                                                      \
+            const int h_ = kp->fs.h[l_], w_ = kp->fs.w[l_];                                                                        \
+            const SrcProj p_ = project_src_level(pb_, exp2f(-(float)l_), h_, w_, kp->fs.cw[l_], kp->fs.ch[l_], kp->fs.rcw[l_], kp->fs.rch[l_]); \
+            inside_ = inside_ && p_.inside;                                                                                        \
+            const bool img_ = l_ == 0 && kq == 1;                                                                                  \
+            if ((kq == (l_ & 3) || img_) && (LIVE_)) {                                                                             \
+                const Taps2 t_ = bilinear_taps(p_.ix, p_.iy, h_, w_);                                                              \
+                const int x0_ = min(max(t_.x0, 0), w_ - 1), x1_ = min(max(t_.x0 + 1, 0), w_ - 1);                                  \
+                const int y0_ = min(max(t_.y0, 0), h_ - 1), y1_ = min(max(t_.y0 + 1, 0), h_ - 1);                                  \
+                const float w00_ = t_.ok00 ? t_.w00 : 0.0f, w01_ = t_.ok01 ? t_.w01 : 0.0f, w10_ = t_.ok10 ? t_.w10 : 0.0f, w11_ = t_.ok11 ? t_.w11 : 0.0f; \
+                if (kq == (l_ & 3)) {                                                                                              \
+                    const f32x4* r0_ = (const f32x4*)kp->fs.data[l_] + ((int64_t)sv * h_ + y0_) * w_, * r1_ = (const f32x4*)kp->fs.data[l_] + ((int64_t)sv * h_ + y1_) * w_; \
+                    if (l_ < 4) { qa_[0] = r0_[x0_]; qa_[1] = r0_[x1_]; qa_[2] = r1_[x0_]; qa_[3] = r1_[x1_]; wa_[0] = w00_; wa_[1] = w01_; wa_[2] = w10_; wa_[3] = w11_; } \
+                    else { qb_[0] = r0_[x0_]; qb_[1] = r0_[x1_]; qb_[2] = r1_[x0_]; qb_[3] = r1_[x1_]; wb_[0] = w00_; wb_[1] = w01_; wb_[2] = w10_; wb_[3] = w11_; } \
+                }                                                                                                                  \
+                if (img_) {                                                                                                        \
+                    const f32x4* r0_ = (const f32x4*)kp->imgs + ((int64_t)sv * h_ + y0_) * w_, * r1_ = (const f32x4*)kp->imgs + ((int64_t)sv * h_ + y1_) * w_; \
+                    qb_[0] = r0_[x0_]; qb_[1] = r0_[x1_]; qb_[2] = r1_[x0_]; qb_[3] = r1_[x1_]; wb_[0] = w00_; wb_[1] = w01_; wb_[2] = w10_; wb_[3] = w11_; \
+                }                                                                                                                  \
+            }                                                                                                                      \
+        }                                                                                                                          \
+    }
     int64_t tile = (int64_t)blockIdx.x * KT_WAVES + wave;
     int64_t src_cur = KT_SRC(tile), src_n1 = KT_SRC(tile + stride);
     KtPoint P_cur = load_point(src_cur);
+    f32x4 qa[4], qb[4];
+    float wa[4], wb[4];
+    bool inside;
+    KT_GATHER(P_cur, src_cur >= 0, qa, qb, wa, wb, inside)
     for (; tile < n_tiles; tile += stride) {
 #ifdef GENS_K18T_STAMPS
         ++tile_no;
@@ -400,38 +441,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const bool live = src_cur >= 0;
         const int64_t pt = tile * PPW + pl;
         const float x = P_cur.x, y = P_cur.y, z = P_cur.z;
-        // ---------------------------------------------------------------- look-up (K4): every lane projects its row; lane group l & 3 reads level l, lane
-        // group 1 the image besides.  The texel loads are ISSUED here and used after compute_angle and ray_dir_fc: one exposed memory latency less.
-        bool inside = true;
-        f32x4 qa[4], qb[4];                                              // slot A: the lane group's own level 0..3; slot B: level 4 (group 0) / the image (group 1)
-        float wa[4], wb[4];                                           // bilinear weights, zero where a tap is outside the map
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { qa[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; qb[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; wa[k] = 0.0f; wb[k] = 0.0f; }
-        {
-            const SrcBase pb = project_src_base(A.w2c + 16 * sv, A.intr + 16 * sv, x, y, z);
-#pragma unroll
-            for (int l = 0; l < NLEV; ++l) {
-                const int h = A.fs.h[l], w = A.fs.w[l];
-                const SrcProj p = project_src_level(pb, exp2f(-(float)l), h, w, A.fs.cw[l], A.fs.ch[l], A.fs.rcw[l], A.fs.rch[l]);
-                inside = inside && p.inside;
-                const bool img = l == 0 && kq == 1;
-                if ((kq == (l & 3) || img) && live) {
-                    const Taps2 t = bilinear_taps(p.ix, p.iy, h, w);
-                    const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
-                    const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
-                    const float w00 = t.ok00 ? t.w00 : 0.0f, w01 = t.ok01 ? t.w01 : 0.0f, w10 = t.ok10 ? t.w10 : 0.0f, w11 = t.ok11 ? t.w11 : 0.0f;
-                    if (kq == (l & 3)) {
-                        const f32x4* r0 = (const f32x4*)A.fs.data[l] + ((int64_t)sv * h + y0) * w, * r1 = (const f32x4*)A.fs.data[l] + ((int64_t)sv * h + y1) * w;
-                        if (l < 4) { qa[0] = r0[x0]; qa[1] = r0[x1]; qa[2] = r1[x0]; qa[3] = r1[x1]; wa[0] = w00; wa[1] = w01; wa[2] = w10; wa[3] = w11; }
-                        else { qb[0] = r0[x0]; qb[1] = r0[x1]; qb[2] = r1[x0]; qb[3] = r1[x1]; wb[0] = w00; wb[1] = w01; wb[2] = w10; wb[3] = w11; }
-                    }
-                    if (img) {
-                        const f32x4* r0 = (const f32x4*)A.imgs + ((int64_t)sv * h + y0) * w, * r1 = (const f32x4*)A.imgs + ((int64_t)sv * h + y1) * w;
-                        qb[0] = r0[x0]; qb[1] = r0[x1]; qb[2] = r1[x0]; qb[3] = r1[x1]; wb[0] = w00; wb[1] = w01; wb[2] = w10; wb[3] = w11;
-                    }
-                }
-            }
-        }
+        // (the look-up of THIS tile was issued one tile ago -- KT_GATHER in the reverse pass below, or ahead of the loop: qa / qb / wa / wb / inside)
         const float mask = (live && inside) ? 1.0f : 0.0f;
         // compute_angle (projector.py:278-291), IEEE square roots / divisions as the PyTorch path takes them: the view weights below are differences of
         // exponentials of rd[3] - 1 -- with two source views ONE difference, ~1e-6 where the viewing angles agree -- and 1 ulp here is per cent there
@@ -647,17 +657,17 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     if (4 * kq + r < 8) A.dbg_r[10][10 * (row0 + n) + 4 * kq + r] = T2[r];
             }
             kt_put(S, L, ST::T2, 0, L9[0], kq, 8);
+            kt_rev<1, 1>(KT_W(9), KT_P(9), L9, L8, i, kq);
             kt_dw<kt_acc_off(9, F), 1, 2, NTILES, ST::CH>(wacc, S, L, ST::T2, ST::T1, 16, nullptr, i, kq);
             if (DUMP) kt_dump<9, F, 1, 2, ST::CH>(A, S, L, ST::T2, ST::T1, 16, nullptr, row0, i, kq);
-            kt_rev<1, 1>(KT_W(9), KT_P(9), L9, L8, i, kq);
             const f32x4 T1 = kt_get(S, L, ST::T1, 0, kq, 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) L8[0][r] = L8[0][r] * kt_elu_d(T1[r]);
+            for (int r = 0; r < 4; ++r) L8[0][r] = kt_elu_dy(L8[0][r], T1[r]);
             kt_put(S, L, ST::T1, 0, L8[0], kq, 16);
             // rgb_fc.0 input = [h2 (32) | vis2 | ray difference]
+            kt_rev<1, 3>(KT_W(8), KT_P(8), L8, HHb, i, kq);
             kt_dw<kt_acc_off(8, F), 1, 3, NTILES, ST::CH>(wacc, S, L, ST::T1, ST::H2, 37, nullptr, i, kq);
             if (DUMP) kt_dump<8, F, 1, 3, ST::CH>(A, S, L, ST::T1, ST::H2, 37, nullptr, row0, i, kq);
-            kt_rev<1, 3>(KT_W(8), KT_P(8), L8, HHb, i, kq);
             GH[0] = HHb[0]; GH[1] = HHb[1];
             vis2_bar = kt_from_q0(HHb[2][0]);
         }
@@ -681,9 +691,9 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             }
             kt_put(S, L, ST::TU, 0, L6[0], kq, 32); kt_put(S, L, ST::TU, 1, L6[1], kq, 32);
             // vis_fc2.0 input = h2 * vis: h2_bar += m vis ; vis_bar = sum_k m_k h2_k
+            kt_rev<2, 2>(KT_W(6), KT_P(6), L6, M6, i, kq);
             kt_dw<kt_acc_off(6, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TU, ST::H2, 32, RSV, i, kq);
             if (DUMP) kt_dump<6, F, 2, 3, ST::CH>(A, S, L, ST::TU, ST::H2, 32, RSV, row0, i, kq);
-            kt_rev<2, 2>(KT_W(6), KT_P(6), L6, M6, i, kq);
             const f32x4 H20 = kt_get(S, L, ST::H2, 0, kq, 32), H21 = kt_get(S, L, ST::H2, 1, kq, 32);
             const float vis_bar = kt_qsum(kt_dot(M6[0], H20) + kt_dot(M6[1], H21));
             GH[0] += M6[0] * vis; GH[1] += M6[1] * vis;
@@ -701,55 +711,60 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int t = 0; t < 2; ++t) {
                 const f32x4 HV = kt_get(S, L, ST::HV, t, kq, 32);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L5[t][r] = GH[t][r] * kt_elu_d(HV[r]);
+                for (int r = 0; r < 4; ++r) L5[t][r] = kt_elu_dy(GH[t][r], HV[r]);
                 kt_put(S, L, ST::HV, t, L5[t], kq, 32);
             }
             if (DUMP && kq == 0) { A.dbg_l[5][34 * (row0 + n) + 32] = hv32_bar; A.dbg_l[5][34 * (row0 + n) + 33] = 0.0f; }
+            kt_rev<2, 2>(KT_W(5), KT_P(5), L5, L4, i, kq);
             kt_dw<kt_acc_off(5, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::HV, ST::TV, 32, nullptr, i, kq);
             if (DUMP) kt_dump<5, F, 2, 3, ST::CH>(A, S, L, ST::HV, ST::TV, 32, nullptr, row0, i, kq);
-            kt_rev<2, 2>(KT_W(5), KT_P(5), L5, L4, i, kq);
             const f32x4 v2w0 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 4 * kq), v2w1 = *(const f32x4*)(KT_W(5) + 32 * KT_P(5) + 16 + 4 * kq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                L4[0][r] = (L4[0][r] + hv32_bar * v2w0[r]) * kt_elu_d(TV0[r]);
-                L4[1][r] = (L4[1][r] + hv32_bar * v2w1[r]) * kt_elu_d(TV1[r]);
+                L4[0][r] = kt_elu_dy(L4[0][r] + hv32_bar * v2w0[r], TV0[r]);
+                L4[1][r] = kt_elu_dy(L4[1][r] + hv32_bar * v2w1[r], TV1[r]);
             }
             kt_put(S, L, ST::TV, 0, L4[0], kq, 32); kt_put(S, L, ST::TV, 1, L4[1], kq, 32);
             // vis_fc.0 input = h * w: h_bar += m w ; w_bar += sum_k m_k h_k
+            kt_rev<2, 2>(KT_W(4), KT_P(4), L4, M4, i, kq);
             kt_dw<kt_acc_off(4, F), 2, 3, NTILES, ST::CH>(wacc, S, L, ST::TV, ST::H, 32, RSW, i, kq);
             if (DUMP) kt_dump<4, F, 2, 3, ST::CH>(A, S, L, ST::TV, ST::H, 32, RSW, row0, i, kq);
-            kt_rev<2, 2>(KT_W(4), KT_P(4), L4, M4, i, kq);
             const f32x4 H0_ = kt_get(S, L, ST::H, 0, kq, 32), H1_ = kt_get(S, L, ST::H, 1, kq, 32);
             w_bar = kt_qsum(kt_dot(M4[0], H0_) + kt_dot(M4[1], H1_));
             f32x4 L3[2];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                                                  // base_fc.2 pre-activation
-                L3[0][r] = (GH[0][r] + M4[0][r] * wn) * kt_elu_d(H0_[r]);
-                L3[1][r] = (GH[1][r] + M4[1][r] * wn) * kt_elu_d(H1_[r]);
+                L3[0][r] = kt_elu_dy(GH[0][r] + M4[0][r] * wn, H0_[r]);
+                L3[1][r] = kt_elu_dy(GH[1][r] + M4[1][r] * wn, H1_[r]);
             }
             KT_STAMP();                                               // 7: reverse vis_fc
             // (H's store still fed the weight gradient of vis_fc.0 above: L3 goes in after it)
             kt_put(S, L, ST::H, 0, L3[0], kq, 32); kt_put(S, L, ST::H, 1, L3[1], kq, 32);
-            kt_dw<kt_acc_off(3, F), 2, 5, NTILES, ST::CH>(wacc, S, L, ST::H, ST::TB, 64, nullptr, i, kq);
-            if (DUMP) kt_dump<3, F, 2, 5, ST::CH>(A, S, L, ST::H, ST::TB, 64, nullptr, row0, i, kq);
             f32x4 L2[4];
             kt_rev<2, 4>(KT_W(3), KT_P(3), L3, L2, i, kq);
+            kt_dw<kt_acc_off(3, F), 2, 5, NTILES, ST::CH>(wacc, S, L, ST::H, ST::TB, 64, nullptr, i, kq);
+            if (DUMP) kt_dump<3, F, 2, 5, ST::CH>(A, S, L, ST::H, ST::TB, 64, nullptr, row0, i, kq);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x4 TB = kt_get(S, L, ST::TB, t, kq, 64);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L2[t][r] = L2[t][r] * kt_elu_d(TB[r]);
+                for (int r = 0; r < 4; ++r) L2[t][r] = kt_elu_dy(L2[t][r], TB[r]);
                 kt_put(S, L, ST::TB, t, L2[t], kq, 64);
             }
-            kt_dw<kt_acc_off(2, F), 4, kt_nt(2, F), NTILES, ST::CH>(wacc, S, L, ST::TB, ST::H0, 3 * FP, nullptr, i, kq, F);
-            if (DUMP) kt_dump<2, F, 4, kt_nt(2, F), ST::CH>(A, S, L, ST::TB, ST::H0, 3 * FP, nullptr, row0, i, kq);
-            KT_STAMP();                                               // 8: reverse base_fc.2, weight gradients of base_fc
             // cotangent of [mean | var | x] (padded blocks) -> through [TB | H] back to x-layout
             f32x4 H0b[HT];
             kt_rev<4, HT>(KT_W(2), KT_P(2), L2, H0b, i, kq);
+            kt_dw<kt_acc_off(2, F), 4, kt_nt(2, F), NTILES, ST::CH>(wacc, S, L, ST::TB, ST::H0, 3 * FP, nullptr, i, kq, F);
+            if (DUMP) kt_dump<2, F, 4, kt_nt(2, F), ST::CH>(A, S, L, ST::TB, ST::H0, 3 * FP, nullptr, row0, i, kq);
+            KT_STAMP();                                               // 8: reverse base_fc, weight gradients of base_fc
 #pragma unroll
             for (int t = 0; t < HT; ++t) kt_put(S, L, ST::TB, t, H0b[t], kq, 3 * FP);
         }
+        // ---------------------------------------------------------------- the NEXT tile's look-up goes out now (its points arrived long ago)
+        f32x4 qa_n[4], qb_n[4];
+        float wa_n[4], wb_n[4];
+        bool inside_n;
+        KT_GATHER(P_n1, src_n1 >= 0, qa_n, qb_n, wa_n, wb_n, inside_n)
         // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
         f32x4 GX[XT];
         {
@@ -768,7 +783,7 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     mb -= 2.0f * vb * cross;                                                             // var depends on mean too
                     const float xb = x_b[r] + wn * mb + 2.0f * wn * d * vb;
                     GX[t][r] = xb;
-                    L1[t][r] = xb * kt_elu_d(dfe[r]);                                                    // ray_dir_fc.2 pre-activation
+                    L1[t][r] = kt_elu_dy(xb, dfe[r]);                                                    // ray_dir_fc.2 pre-activation
                     wb_part += (16 * t + 4 * kq + r < F) ? mb * xv[r] + vb * d * d : 0.0f;
                 }
                 L1[t] = kt_mask(L1[t], t, kq, F);
@@ -784,12 +799,12 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 if (!dead && (float)v == arg) wrb -= tot;                                                // the minimum's share
                 if (kq == 0 && live) s_acc += wrb * e * (rd[3] - 1.0f);
             }
+            kt_rev<XT, 1>(KT_W(1), KT_P(1), L1, L0, i, kq);
             kt_dw<kt_acc_off(1, F), XT, 2, NTILES, ST::CH>(wacc, S, L, ST::DFE, ST::D1, 16, nullptr, i, kq);
             if (DUMP) kt_dump<1, F, XT, 2, ST::CH>(A, S, L, ST::DFE, ST::D1, 16, nullptr, row0, i, kq);
-            kt_rev<XT, 1>(KT_W(1), KT_P(1), L1, L0, i, kq);
             const f32x4 D1 = kt_get(S, L, ST::D1, 0, kq, 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) L0[0][r] = L0[0][r] * kt_elu_d(D1[r]);
+            for (int r = 0; r < 4; ++r) L0[0][r] = kt_elu_dy(L0[0][r], D1[r]);
             kt_put(S, L, ST::D1, 0, L0[0], kq, 16);
             kt_dw<kt_acc_off(0, F), 1, 1, NTILES, ST::CH>(wacc, S, L, ST::D1, ST::RD, 4, nullptr, i, kq);
             if (DUMP) kt_dump<0, F, 1, 1, ST::CH>(A, S, L, ST::D1, ST::RD, 4, nullptr, row0, i, kq);
@@ -810,64 +825,93 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         P_cur = P_n1;
         src_cur = src_n1;
         src_n1 = src_n2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qa[k] = qa_n[k]; qb[k] = qb_n[k]; wa[k] = wa_n[k]; wb[k] = wb_n[k]; }
+        inside = inside_n;
     }
 #undef KT_SRC
+#undef KT_GATHER
 
-    // ================================================================ this wave's block of sums
+    // ================================================================ the workgroup's block of sums
+    // The four waves' accumulators meet in LDS (the stores and the weights are dead now): in rounds of CAP tiles every wave parks its registers,
+    // then wave (t & 3) adds the four copies of tile t in wave order -- a fixed order -- and writes the sums into the workgroup's block of `parts`
+    // (layout of gens_gemm_tn_batch's result).  The per-lane sums of the single-output rows and of d loss / d |s| ride along as six more tiles.
     {
-        float* out = kp->parts + (size_t)(blockIdx.x * KT_WAVES + wave) * kp->csz;
-        // accumulator register r of lane (kq, i) = D[m = 4 kq + r][n = i] of its tile
+        constexpr int NEXT = 6, NALL = NTILES + NEXT;
+        constexpr int CAP = (int)((kt_lw_total(F) + kt_b_total(F) + KT_WAVES * ST::FLOATS) / (KT_WAVES * 256));
+        constexpr int ROUNDS = (NALL + CAP - 1) / CAP;
+        static_assert(CAP >= 8, "LDS too small for the final reduction");
+        float* out = kp->parts + (size_t)blockIdx.x * kp->csz;
+        const f32x4 ext[NEXT] = {sp_v2[0], sp_v2[1], sp_u2[0], sp_u2[1], sp_r3, (f32x4){sp_v2b, sp_u2b, sp_r3b, s_acc}};
+        // the sum of tile t (compile-time t of the current round) over the four waves
+#define KT_SUM(t_) (((*(const f32x4*)(smem + ((0 * CAP + (t_) % CAP) * 64 + lane) * 4) + *(const f32x4*)(smem + ((1 * CAP + (t_) % CAP) * 64 + lane) * 4)) + \
+                     (*(const f32x4*)(smem + ((2 * CAP + (t_) % CAP) * 64 + lane) * 4) + *(const f32x4*)(smem + ((3 * CAP + (t_) % CAP) * 64 + lane) * 4))))
+#define KT_MINE(t_) ((t_) / CAP == round && ((t_) & 3) == wave)
+#pragma unroll
+        for (int round = 0; round < ROUNDS; ++round) {
+            __syncthreads();                                            // (round 0: every wave has left the tile loop; later: the previous round was read)
+#pragma unroll
+            for (int t = 0; t < NALL; ++t)
+                if (t / CAP == round) *(f32x4*)(smem + ((wave * CAP + t % CAP) * 64 + lane) * 4) = t < NTILES ? wacc[t < NTILES ? t : 0] : ext[t < NTILES ? 0 : t - NTILES];
+            __syncthreads();
+            // accumulator register r of lane (kq, i) = D[m = 4 kq + r][n = i] of its tile
 #define KT_FLUSH(l)                                                                                          \
-        {                                                                                                    \
-            constexpr int ms_ = (l) == 5 ? 32 : kt_out(l, F), ns_ = kt_in(l, F) + 1, ld_ = kt_ev(kt_in(l, F) + 1); \
-            constexpr int mt_ = kt_mt(l, F), nt_ = kt_nt(l, F), off_ = kt_cc_off(l, F), ab_ = kt_acc_off(l, F); \
-            _Pragma("unroll") for (int mo_ = 0; mo_ < mt_; ++mo_)                                            \
-                _Pragma("unroll") for (int no_ = 0; no_ < nt_; ++no_)                                        \
-                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                       \
-                        const int m_ = 16 * mo_ + 4 * kq + r_, n_ = 16 * no_ + i;                            \
-                        if (m_ < ms_ && n_ < ns_) out[off_ + m_ * ld_ + n_] = wacc[ab_ + mo_ * nt_ + no_][r_]; \
-                    }                                                                                        \
-        }
-        KT_FLUSH(0) KT_FLUSH(1) KT_FLUSH(3) KT_FLUSH(4) KT_FLUSH(5) KT_FLUSH(6) KT_FLUSH(8) KT_FLUSH(9)
-#undef KT_FLUSH
-        {   // base_fc.0: its columns were the padded [mean | var | x] blocks; column F (the first pad slot) = the bias
-            constexpr int nt_ = kt_nt(2, F), off_ = kt_cc_off(2, F), ab_ = kt_acc_off(2, F), ld_ = kt_ev(3 * F + 1);
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-                for (int no = 0; no < nt_; ++no) {
-                    const int q = 16 * no + i, blk = q / FP, c = q - blk * FP;
-                    const int col = q == F ? 3 * F : ((blk < 3 && c < F) ? blk * F + c : -1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col >= 0) out[off_ + (16 * mo + 4 * kq + r) * ld_ + col] = wacc[ab_ + mo * nt_ + no][r];
-                }
-        }
-        // the single-output rows: per-lane sums over this lane's row -> over the 16 rows of the lane group (valid in lane 15 of the group)
-#define KT_ROW(VEC, t_, r_, l, row_)                                                                         \
-        {                                                                                                    \
-            const float v_ = kt_rowsum16(VEC);                                                               \
-            const int c_ = 16 * (t_) + 4 * kq + (r_);                                                        \
-            if (i == 15 && c_ < KT_C(kt_in(l, F))) out[KT_C(kt_cc_off(l, F)) + (row_) * KT_C(kt_ev(kt_in(l, F) + 1)) + c_] = v_; \
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                KT_ROW(sp_v2[t][r], t, r, 5, 32)
-                KT_ROW(sp_u2[t][r], t, r, 7, 0)
+            {                                                                                                \
+                constexpr int ms_ = (l) == 5 ? 32 : kt_out(l, F), ns_ = kt_in(l, F) + 1, ld_ = kt_ev(kt_in(l, F) + 1); \
+                constexpr int mt_ = kt_mt(l, F), nt_ = kt_nt(l, F), off_ = kt_cc_off(l, F), ab_ = kt_acc_off(l, F); \
+                _Pragma("unroll") for (int mo_ = 0; mo_ < mt_; ++mo_)                                        \
+                    _Pragma("unroll") for (int no_ = 0; no_ < nt_; ++no_)                                    \
+                        if (KT_MINE(ab_ + mo_ * nt_ + no_)) {                                                \
+                            const f32x4 v_ = KT_SUM(ab_ + mo_ * nt_ + no_);                                  \
+                            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                               \
+                                const int m_ = 16 * mo_ + 4 * kq + r_, n_ = 16 * no_ + i;                    \
+                                if (m_ < ms_ && n_ < ns_) out[off_ + m_ * ld_ + n_] = v_[r_];                \
+                            }                                                                                \
+                        }                                                                                    \
             }
+            KT_FLUSH(0) KT_FLUSH(1) KT_FLUSH(3) KT_FLUSH(4) KT_FLUSH(5) KT_FLUSH(6) KT_FLUSH(8) KT_FLUSH(9)
+#undef KT_FLUSH
+            {   // base_fc.0: its columns were the padded [mean | var | x] blocks; column F (the first pad slot) = the bias
+                constexpr int nt_ = kt_nt(2, F), off_ = kt_cc_off(2, F), ab_ = kt_acc_off(2, F), ld_ = kt_ev(3 * F + 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) KT_ROW(sp_r3[r], 0, r, 10, 0)
-#undef KT_ROW
-        const float b5 = kt_rowsum16(sp_v2b), b7 = kt_rowsum16(sp_u2b), b10 = kt_rowsum16(sp_r3b);
-        if (lane == 15) {
-            out[KT_C(kt_cc_off(5, F)) + 32 * 34 + 32] = b5;
-            out[KT_C(kt_cc_off(7, F)) + 32] = b7;
-            out[KT_C(kt_cc_off(10, F)) + 8] = b10;
+                for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+                    for (int no = 0; no < nt_; ++no)
+                        if (KT_MINE(ab_ + mo * nt_ + no)) {
+                            const f32x4 v_ = KT_SUM(ab_ + mo * nt_ + no);
+                            const int q = 16 * no + i, blk = q / FP, c = q - blk * FP;
+                            const int col = q == F ? 3 * F : ((blk < 3 && c < F) ? blk * F + c : -1);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col >= 0) out[off_ + (16 * mo + 4 * kq + r) * ld_ + col] = v_[r];
+                        }
+            }
+            // the single-output rows: per-lane sums over this lane's row -> over the 16 rows of the lane group (valid in lane 15 of the group)
+#define KT_ROWS(e_, t_, l, row_)                                                                             \
+            if (KT_MINE(NTILES + (e_))) {                                                                    \
+                const f32x4 v_ = KT_SUM(NTILES + (e_));                                                      \
+                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                           \
+                    const float w_ = kt_rowsum16(v_[r_]);                                                    \
+                    const int c_ = 16 * (t_) + 4 * kq + r_;                                                  \
+                    if (i == 15 && c_ < KT_C(kt_in(l, F))) out[KT_C(kt_cc_off(l, F)) + (row_) * KT_C(kt_ev(kt_in(l, F) + 1)) + c_] = w_; \
+                }                                                                                            \
+            }
+            KT_ROWS(0, 0, 5, 32) KT_ROWS(1, 1, 5, 32) KT_ROWS(2, 0, 7, 0) KT_ROWS(3, 1, 7, 0) KT_ROWS(4, 0, 10, 0)
+#undef KT_ROWS
+            if (KT_MINE(NTILES + 5)) {
+                const f32x4 v_ = KT_SUM(NTILES + 5);
+                const float b5 = kt_rowsum16(v_[0]), b7 = kt_rowsum16(v_[1]), b10 = kt_rowsum16(v_[2]);
+                if (lane == 15) {                                       // (the three bias sums were kept by lane group 0 only)
+                    out[KT_C(kt_cc_off(5, F)) + 32 * 34 + 32] = b5;
+                    out[KT_C(kt_cc_off(7, F)) + 32] = b7;
+                    out[KT_C(kt_cc_off(10, F)) + 8] = b10;
+                }
+                const float ss = wave_sum(v_[3]);
+                if (lane == 0) kp->s_part[blockIdx.x] = ss;
+            }
         }
-        const float ss = wave_sum(s_acc);
-        if (lane == 0) kp->s_part[blockIdx.x * KT_WAVES + wave] = ss;
+#undef KT_SUM
+#undef KT_MINE
     }
 #undef KT_W
 #undef KT_P
@@ -894,7 +938,7 @@ __global__ __launch_bounds__(256) void blend_train_t_reduce_k(const float* __res
 int gens_fill_maps(const char* who, MapSet* ms, const float* const* feats, const int* hw, int n_levels);
 extern "C" int gens_blend_train_acc_floats(int n_levels);
 
-// Number of partial blocks (= waves) of a gens_blend_train_bwd_t launch over n points of nv views: four waves per workgroup, one persistent
+// Number of partial blocks (= workgroups) of a gens_blend_train_bwd_t launch over n points of nv views: four waves per workgroup, one persistent
 // workgroup per CU at most (GENS_K18T_WGS overrides the cap: occupancy probes).  0: nothing to launch, or a view count this kernel is not built for.
 extern "C" int gens_blend_train_t_parts(int64_t n, int nv) {
     if (n <= 0 || nv < 3 || nv > 5) return 0;
@@ -903,7 +947,7 @@ extern "C" int gens_blend_train_t_parts(int64_t n, int nv) {
     int64_t cap = getenv("GENS_K18T_WGS") ? atoi(getenv("GENS_K18T_WGS")) : 256;
     if (cap < 1) cap = 1;
     const int64_t wgs = (tiles + KT_WAVES - 1) / KT_WAVES;
-    return (int)((wgs < cap ? wgs : cap) * KT_WAVES);
+    return (int)(wgs < cap ? wgs : cap);
 }
 
 static int kt_launch(const char* who, bool dump, const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
@@ -920,7 +964,7 @@ static int kt_launch(const char* who, bool dump, const float* const* feats, cons
     A.imgs = (const float4*)imgs;
     A.w2c = w2c; A.intr = intr; A.c2w = c2w; A.nv = nv;
     A.csz = gens_blend_train_acc_floats(n_levels);
-    const unsigned grid = (unsigned)(gens_blend_train_t_parts(A.n, nv) / KT_WAVES);
+    const unsigned grid = (unsigned)gens_blend_train_t_parts(A.n, nv);
     hipStream_t st = (hipStream_t)stream;
     static GensLdsOptIn once[6][2][2];
 #define KT_GO(NL, G_, D_)                                                                                                              \
@@ -947,8 +991,8 @@ static int kt_launch(const char* who, bool dump, const float* const* feats, cons
 }
 
 // The backward launch of the colour branch, transposed: `parts` = gens_blend_train_t_parts(n, nv) blocks of gens_blend_train_acc_floats(n_levels)
-// floats (one per wave), `cc` = their fixed-order sum = what gens_gemm_tn_batch returns for the eleven products (the input of
-// gens_blend_train_wgrad); s_part: one partial of d loss / d |s| per wave (gens_blend_train_t_parts of them).
+// floats (one per workgroup), `cc` = their fixed-order sum = what gens_gemm_tn_batch returns for the eleven products (the input of
+// gens_blend_train_wgrad); s_part: one partial of d loss / d |s| per workgroup (gens_blend_train_t_parts of them).
 extern "C" int gens_blend_train_bwd_t(const float* const* feats, const int* hw, int n_levels, const float* imgs, const float* w2c, const float* intr,
                                       const float* c2w, int nv, const float* const* weights, const float* pts, const int64_t* index, int64_t n,
                                       const int32_t* n_device, const float* g_rgb, float* g_feat, float* s_part, float* parts, float* cc, void* stream) {

@@ -538,8 +538,8 @@ int gens_blend_train_bwd_acc(const float* const* feats, const int* hw, int n_lev
  * view) rows and all of their forward, reverse and weight-gradient work -- the weights of the eleven layers in LDS as the A operand of
  * v_mfma_f32_16x16x4_f32, the activations in registers from layer to layer and, in [channel][row] order, in a wave-private LDS store the weight-
  * gradient products read both operands from; four independent waves per workgroup, one persistent workgroup per compute unit, no barrier behind the
- * weight load.  gens_blend_train_t_parts(n, nv) = the number of waves = blocks of gens_blend_train_acc_floats(n_levels) floats in `parts` AND
- * entries of s_part (one partial of d loss / d |s| per wave; 0 = nothing to launch or a view count this kernel is not built for); cc, g_feat as in
+ * weight load.  gens_blend_train_t_parts(n, nv) = the number of workgroups = blocks of gens_blend_train_acc_floats(n_levels) floats in `parts` AND
+ * entries of s_part (one partial of d loss / d |s| per workgroup; 0 = nothing to launch or a view count this kernel is not built for); cc, g_feat as in
  * gens_blend_train_bwd_acc.  Results equal gens_blend_train_bwd_acc's up to float32 summation order.
  * gens_blend_train_bwd_t_dump additionally leaves the operand rows r_ops / l_ops of gens_blend_train_bwd (same widths) for
  * rows = 16 ceil(n / (16 / G)) rows, G = 2 (nv = 3) or 4 lanes per point: row 16 tile + G point + view (three source views: every fourth row is

@@ -283,7 +283,7 @@ def test_transposed_backward_equals_the_row_major_backward_layer_by_layer(nv, n_
     r_b = [torch.zeros(rows_b, ev(k + 1), device=dev) for k in ins]
     l_b = [torch.zeros(rows_b, ev(m), device=dev) for m in outs]
     csz, n_parts = lib.gens_blend_train_acc_floats(n_levels), lib.gens_blend_train_t_parts(n, nv)
-    assert n_parts > 0 and n_parts % 4 == 0
+    assert n_parts > 0
     gf_b, sp_b = torch.zeros(n, s, f, device=dev), torch.zeros(n_parts, device=dev)
     parts, cc = torch.zeros(n_parts, csz, device=dev), torch.zeros(csz, device=dev)
     L.call("gens_blend_train_bwd_t_dump", *args, L.ptr(gf_b), L.ptr(sp_b), L.ptr(parts), L.ptr(cc), L.ptr_table(r_b), L.ptr_table(l_b), L.stream())
