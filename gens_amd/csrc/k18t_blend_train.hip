@@ -196,36 +196,59 @@ __device__ __forceinline__ float kt_rowsum16(float v) {   // sum over the 16 lan
 }
 __device__ __forceinline__ float kt_dot(const f32x4& a, const f32x4& b) { return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]; }
 
+// The operands of the NEXT group of products are asked for before the current group is multiplied (hipcc otherwise sinks every ds_read next to its
+// use -- one exposed LDS round trip per pair of products, and with one wave per SIMD nothing else runs under it; `sched_barrier(0)` pins the order,
+// as k6_sdfmlp.hip does for its weight stream).
+#define KT_PIN() __builtin_amdgcn_sched_barrier(0)
+
 // Y (MT tiles of the layer's outputs) = bias + W X: the weights' rows are the A operand (one ds_read_b128 = the four reduction slots of a tile)
 template <int KT, int MT>
 __device__ __forceinline__ void kt_fwd(const float* W, int P, const float* bias, const f32x4 (&X)[KT], f32x4 (&Y)[MT], int i, int kq) {
+    f32x4 a[2][MT];
+#pragma unroll
+    for (int to = 0; to < MT; ++to) a[0][to] = *(const f32x4*)(W + (16 * to + i) * P + 4 * kq);
 #pragma unroll
     for (int to = 0; to < MT; ++to) Y[to] = *(const f32x4*)(bias + 16 * to + 4 * kq);
 #pragma unroll
     for (int ti = 0; ti < KT; ++ti) {
-        f32x4 a[MT];
+        if (ti + 1 < KT) {
 #pragma unroll
-        for (int to = 0; to < MT; ++to) a[to] = *(const f32x4*)(W + (16 * to + i) * P + 16 * ti + 4 * kq);
+            for (int to = 0; to < MT; ++to) a[(ti + 1) & 1][to] = *(const f32x4*)(W + (16 * to + i) * P + 16 * (ti + 1) + 4 * kq);
+        }
+        KT_PIN();
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int to = 0; to < MT; ++to) Y[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], X[ti][r], Y[to], 0, 0, 0);
+            for (int to = 0; to < MT; ++to) Y[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti & 1][to][r], X[ti][r], Y[to], 0, 0, 0);
+        KT_PIN();
     }
 }
 // Y (MT tiles of the layer's INPUTS) = W^T G over KT tiles of its outputs: column reads of the same LDS matrix.  Channels of Y beyond the layer's
 // input count are garbage (the caller masks them); channels of G beyond its output count must be zero.
 template <int KT, int MT>
 __device__ __forceinline__ void kt_rev(const float* W, int P, const f32x4 (&G)[KT], f32x4 (&Y)[MT], int i, int kq) {
+    float a[2][4][MT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ti = 0; ti < MT; ++ti) a[0][r][ti] = W[(4 * kq + r) * P + i + 16 * ti];
 #pragma unroll
     for (int ti = 0; ti < MT; ++ti) Y[ti] = kt_splat(0.0f);
 #pragma unroll
-    for (int to = 0; to < KT; ++to)
+    for (int to = 0; to < KT; ++to) {
+        if (to + 1 < KT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* row = W + (16 * to + 4 * kq + r) * P + i;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ti = 0; ti < MT; ++ti) Y[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16 * ti], G[to][r], Y[ti], 0, 0, 0);
+                for (int ti = 0; ti < MT; ++ti) a[(to + 1) & 1][r][ti] = W[(16 * (to + 1) + 4 * kq + r) * P + i + 16 * ti];
         }
+        KT_PIN();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ti = 0; ti < MT; ++ti) Y[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to & 1][r][ti], G[to][r], Y[ti], 0, 0, 0);
+        KT_PIN();
+    }
 }
 // block += L^T [R | 1] over this wave's 16 rows: L = MT tiles of channels from store channel cL, R = `in` channels from cR (times the per-row
 // scalars `scale` when given: the two layers whose input is h * weight / x * visibility); D[m = out][n = in], reduction slot j of lane group kq = row 4 kq + j
@@ -233,21 +256,26 @@ __device__ __forceinline__ void kt_rev(const float* W, int P, const f32x4 (&G)[K
 template <int OFF, int MT, int NT, int NTILES, int CH>
 __device__ __forceinline__ void kt_dw(f32x4 (&wacc)[NTILES], const float* S, const KtLane& L, int cL, int cR, int in, const float* scale, int i, int kq, int one = -1) {
     if (one < 0) one = in;
-    f32x4 a[MT];
+    f32x4 a[MT], b[2];
 #pragma unroll
     for (int mo = 0; mo < MT; ++mo) a[mo] = kt_op(S, L, cL + 16 * mo);
     f32x4 sc = kt_splat(1.0f);
     if (scale) sc = *(const f32x4*)(scale + 4 * kq);
+    // (a tile that lies behind the inputs altogether -- the bias column of a 32- or 64-wide layer -- is not read at all)
+    b[0] = kt_op(S, L, cR);
 #pragma unroll
     for (int no = 0; no < NT; ++no) {
+        if (no + 1 < NT && 16 * (no + 1) < in) b[(no + 1) & 1] = kt_op(S, L, cR + 16 * (no + 1));
+        KT_PIN();
         const int col = 16 * no + i;
-        f32x4 b = kt_op(S, L, cR + 16 * no);          // (columns behind `in` are replaced below: a tile may reach past the operand, never past the wave's LDS)
-        if (scale) b *= sc;
-        b = col == one ? kt_splat(1.0f) : (col < in ? b : kt_splat(0.0f));
+        f32x4 bb = 16 * no < in ? b[no & 1] : kt_splat(0.0f);
+        if (scale) bb *= sc;
+        bb = col == one ? kt_splat(1.0f) : (col < in ? bb : kt_splat(0.0f));
 #pragma unroll
         for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wacc[OFF + mo * NT + no] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][j], b[j], wacc[OFF + mo * NT + no], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) wacc[OFF + mo * NT + no] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][j], bb[j], wacc[OFF + mo * NT + no], 0, 0, 0);
+        KT_PIN();
     }
 }
 

@@ -55,6 +55,14 @@ def thrash():
     trash.fill_(1.0)
 
 
+def thrash_then_touch_texels():
+    """cold caches, then ONE pass over the packed texels K1 reads (33 MB: ~8 us): is the cold penalty the texel reads?"""
+    trash.fill_(1.0)
+    from gens_amd.ops.base import pack_maps
+    for t in pack_maps(feats[:len(dims)]):
+        t.view(-1)[::16].sum()                       # (one float per 64-byte line)
+
+
 def thrash_then_idle():
     trash.fill_(1.0)
     torch.cuda.synchronize()
@@ -66,7 +74,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 algo = 5 * 480 * 640 * 16 * (1 + 0.25 + 0.0625) + 36 * sum(d ** 3 for d in dims)
 for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), ("after 2 ms idle", idle(2)), ("after 20 ms idle", idle(20)),
-                   ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash), ("after the fill and 2 ms idle", thrash_then_idle)):
+                   ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash), ("after the fill and 2 ms idle", thrash_then_idle),
+                   ("after the fill and a pass over the texels", thrash_then_touch_texels)):
     med, p10, p90 = timed(prep)
     print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / med / 1e6 / 8e6 * 100 * 1e0))
 

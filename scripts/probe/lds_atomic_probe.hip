@@ -17,6 +17,7 @@ __device__ __forceinline__ int slot(int lane, int pattern, int k) {
 }
 
 // type 0: float atomic | 1: uint32 atomic | 2: uint64 atomic | 3: float load + add + store (NOT a sum: timing only) | 4: double atomic
+// | 5: float atomic, relaxed at workgroup scope (__hip_atomic_fetch_add: the native ds_add_f32)
 template <int TYPE>
 __global__ __launch_bounds__(256) void lds_k(int pattern, int iters, float* out) {
     __shared__ unsigned long long buf[2048];
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void lds_k(int pattern, int iters, float* out)
         else if (TYPE == 1) atomicAdd(u + s, 1u);
         else if (TYPE == 2) atomicAdd(buf + (s & 2047), 1ull);
         else if (TYPE == 4) atomicAdd((double*)buf + (s & 2047), 1.0);
+        else if (TYPE == 5) __hip_atomic_fetch_add(f + s, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else f[s] = f[s] + 1.0f;
     }
     __syncthreads();
@@ -44,6 +46,7 @@ extern "C" void lds_probe(int type, int pattern, int iters, int blocks, float* o
         case 1: lds_k<1><<<blocks, 256, 0, s>>>(pattern, iters, out); break;
         case 2: lds_k<2><<<blocks, 256, 0, s>>>(pattern, iters, out); break;
         case 4: lds_k<4><<<blocks, 256, 0, s>>>(pattern, iters, out); break;
+        case 5: lds_k<5><<<blocks, 256, 0, s>>>(pattern, iters, out); break;
         default: lds_k<3><<<blocks, 256, 0, s>>>(pattern, iters, out); break;
     }
 }

@@ -17,7 +17,7 @@ lib.lds_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_vo
 out = torch.zeros(4, device="cuda:0")
 blocks, iters = 256 * 8, 4096              # 8 workgroups of 4 waves per CU
 clock_ghz = 2.4
-for tname, t in (("f32 atomic", 0), ("u32 atomic", 1), ("u64 atomic", 2), ("f32 load+add+store", 3), ("f64 atomic", 4)):
+for tname, t in (("f32 atomic", 0), ("u32 atomic", 1), ("u64 atomic", 2), ("f32 load+add+store", 3), ("f64 atomic", 4), ("f32 native (wg scope)", 5)):
     for pname, p in (("64 distinct words", 0), ("one word", 1), ("runs of 4 lanes", 2), ("runs of 16 lanes", 3), ("distinct, stride 4", 4)):
         fn = lambda: lib.lds_probe(t, p, iters, blocks, out.data_ptr(), torch.cuda.current_stream().cuda_stream)  # noqa: E731
         fn()
