@@ -98,8 +98,10 @@ struct KtArgs {
 // launch's inputs are the step's own forward values -- finite, or the loss is NaN already.)
 __device__ __forceinline__ float kt_elu(float x) { return __builtin_amdgcn_fmed3f(x, hw_exp(x) - 1.0f, 0.0f); }
 // y * elu'(a) from the OUTPUT out = elu(a): elu' = 1 above 0, out + 1 below -> y + y * min(out, 0)
-__device__ __forceinline__ float kt_elu_dy(float y, float out) { return __builtin_fmaf(y, fminf(out, 0.0f), y); }
-__device__ __forceinline__ float kt_elu_d(float out) { return fminf(out, 0.0f) + 1.0f; }              // d elu / d a from the OUTPUT
+// (min(out, 0) as the median of (out, 0, -inf): one instruction, where fminf costs a canonicalising max besides)
+__device__ __forceinline__ float kt_min0(float out) { return __builtin_amdgcn_fmed3f(out, 0.0f, -__builtin_inff()); }
+__device__ __forceinline__ float kt_elu_dy(float y, float out) { return __builtin_fmaf(y, kt_min0(out), y); }
+__device__ __forceinline__ float kt_elu_d(float out) { return kt_min0(out) + 1.0f; }                  // d elu / d a from the OUTPUT
 __device__ __forceinline__ f32x4 kt_splat(float v) { return (f32x4){v, v, v, v}; }
 
 // The store: channel rows of 16 floats.  Inside every aligned group of 8 channels bits 0 and 2 of the channel index trade places (so that the lanes
@@ -146,23 +148,27 @@ __device__ __forceinline__ f32x4 kt_mask(f32x4 v, int t, int kq, int limit) {
     return v;
 }
 
-// sums / extrema over the G adjacent lanes of a point (= its views), in every lane
+// sums / extrema over the G adjacent lanes of a point (= its views), in every lane.  (update_dpp with bound_ctrl and no `old` value: the compiler
+// folds the lane permutation into the add / min / max as its DPP operand -- with `old` = the value itself it emitted a copy, the hazard nop and a
+// separate v_mov_dpp per butterfly step.)
+template <int CTRL>
+__device__ __forceinline__ float kt_dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
 template <int G>
 __device__ __forceinline__ float kt_gsum(float v) {
-    v += dpp_move<0xB1, 0xF>(v, v);                       // quad_perm:[1,0,3,2]
-    if (G == 4) v += dpp_move<0x4E, 0xF>(v, v);           // quad_perm:[2,3,0,1]
+    v += kt_dpp<0xB1>(v);                                 // quad_perm:[1,0,3,2]
+    if (G == 4) v += kt_dpp<0x4E>(v);                     // quad_perm:[2,3,0,1]
     return v;
 }
 template <int G>
 __device__ __forceinline__ float kt_gmin(float v) {
-    v = fminf(v, dpp_move<0xB1, 0xF>(v, v));
-    if (G == 4) v = fminf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fminf(v, kt_dpp<0xB1>(v));
+    if (G == 4) v = fminf(v, kt_dpp<0x4E>(v));
     return v;
 }
 template <int G>
 __device__ __forceinline__ float kt_gmax(float v) {
-    v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
-    if (G == 4) v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fmaxf(v, kt_dpp<0xB1>(v));
+    if (G == 4) v = fmaxf(v, kt_dpp<0x4E>(v));
     return v;
 }
 // Across the four lane groups kq of a row (lanes n, n + 16, n + 32, n + 48): gfx950's row / half swaps on the vector ALU -- a ds_bpermute pair
