@@ -287,7 +287,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // within the tile a wave takes 16 z of all four rows (lane = 16 row + z): its footprints in a view then span ~30 pixels instead of ~90
     const uint32_t t_row = lane >> 4, t_z = (wv << 4) | (lane & 15u);
     const uint32_t idx = tiled ? (((t_ix0 + t_row) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + t_z)) : chunk * 256u + threadIdx.x;
-    const int kz = (int)(idx & dm), jy = (int)((idx >> lc.log2d) & dm), ix = (int)(idx >> (2 * lc.log2d));
+    const int kz = (int)(idx & dm);                                             // (ix, jy: through row_pre)
     const int half = d >> 1;
     // ---- frustum culling per (z-row, view).  Along a z-row the homogeneous image coordinates (u, v, depth) are affine in z, so the
     // voxels of the row a view can see form ONE interval of kz.  Thread (row r, view v) of the workgroup intersects the five half-lines
@@ -297,6 +297,11 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // The exact per-voxel test below still decides visibility; the intervals only have to be supersets, and the bit-for-bit
     // comparisons with the unculled kernels check that they are.
     __shared__ int2 row_span[32][K1_FAST_VIEWS];
+    // ... and the part of the camera-space coordinates that is the same along a z-row: m[4 q] x + m[4 q + 1] y, the first two terms of
+    // m[4 q] x + m[4 q + 1] y + m[4 q + 2] z + m[4 q + 3] as the reference's left-to-right float32 sums form them (two products, one addition:
+    // the same three roundings here as there, so the voxel's  (p + m[4 q + 2] z) + m[4 q + 3]  is bit for bit the four-term expression).  Nine vector
+    // instructions per (voxel, view) become one broadcast 16-byte LDS read: the kernel is bound by its instruction stream (78 % VALU-busy).
+    __shared__ float4 row_pre[32][K1_FAST_VIEWS];
     int seen = 0;                                                                 // this thread's (row, view) pair has a span
     {
         const int rows = tiled ? 4 : 256 >> lc.log2d;                             // z-rows the workgroup touches (d <= 256)
@@ -308,6 +313,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
             const float ry = rj < half ? -1.0f + lc.step * (float)rj : 1.0f - lc.step * (float)(d - 1 - rj);
             const float* m = w2c + 16 * v;
             const float* k = intr + 16 * v;
+            row_pre[r][v] = make_float4(m[0] * rx + m[1] * ry, m[4] * rx + m[5] * ry, m[8] * rx + m[9] * ry, m[12] * rx + m[13] * ry);
             float c0[4], c1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -362,8 +368,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     }
     const int my_row = tiled ? (int)t_row : (int)(threadIdx.x >> lc.log2d);
     // torch.linspace(-1, 1, d)[i]: lower half counts up from the start, upper half down from the end
-    const float x = ix < half ? -1.0f + lc.step * (float)ix : 1.0f - lc.step * (float)(d - 1 - ix);
-    const float y = jy < half ? -1.0f + lc.step * (float)jy : 1.0f - lc.step * (float)(d - 1 - jy);
+    // (x and y of the voxel enter through row_pre: they are the same along the z-row)
     const float z = kz < half ? -1.0f + lc.step * (float)kz : 1.0f - lc.step * (float)(d - 1 - kz);
     const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
     const uint32_t row_bytes = (uint32_t)w * 16u, view_bytes = (uint32_t)h * row_bytes;
@@ -379,9 +384,10 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
         // might alias them) -- a vector-memory round trip per view and wave, 60 us of that launch's 280 (profiles/r05_k1_levels_ab.txt).
         const k1_cfloat_p m = (k1_cfloat_p)(uintptr_t)(w2c + 16 * v);
         const k1_cfloat_p k = (k1_cfloat_p)(uintptr_t)(intr + 16 * v);
-        const float cx = m[0] * x + m[1] * y + m[2] * z + m[3];
-        const float cy = m[4] * x + m[5] * y + m[6] * z + m[7];
-        const float cz = m[8] * x + m[9] * y + m[10] * z + m[11];
+        const float4 pre = row_pre[my_row][v];                                    // (m[4 q] x + m[4 q + 1] y)_q of this lane's z-row
+        const float cx = pre.x + m[2] * z + m[3];
+        const float cy = pre.y + m[6] * z + m[7];
+        const float cz = pre.z + m[10] * z + m[11];
         // integer tests on the scalar unit (a float compare would be a VALU instruction + vcc branch per matrix entry)
         const k1_cuint_p mb = (k1_cuint_p)m;
         const k1_cuint_p kb = (k1_cuint_p)k;
@@ -393,7 +399,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
             vv = k[5] * cy + k[6] * cz;
             dd = cz;
         } else {
-            const float cw = m[12] * x + m[13] * y + m[14] * z + m[15];
+            const float cw = pre.w + m[14] * z + m[15];
             u = k[0] * cx + k[1] * cy + k[2] * cz + k[3] * cw;
             vv = k[4] * cx + k[5] * cy + k[6] * cz + k[7] * cw;
             dd = k[8] * cx + k[9] * cy + k[10] * cz + k[11] * cw;
@@ -481,10 +487,52 @@ struct VolumeLevels {
     int n;
 };
 
-__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis) {
+// Texel warm-up.  Inside a step this launch follows a render (or a backward pass) that left L2 and the Infinity Cache full of volume data: every
+// first touch of a texel line then goes to HBM, ~2 us each, paid wave by wave all through the launch -- 255 - 275 us where the same launch takes 217 - 222
+// with the 33 MB of texels resident (scripts/probe/k1_instep_probe.py: a 1 GiB fill before the launch costs + 55 us, one pass over the texels
+// between the fill and the launch takes it back).  So the FIRST workgroups of the launch ask for every 128-byte line of the tables -- one dword per
+// line, two lines per thread, ~500 workgroups of the ~2 000 that start together -- before they turn to their own voxels; the loads are waited for
+// only at the very end of those workgroups (their values feed a store that never happens), HBM streams the tables in ~6 us under everybody's
+// first projections.  Nothing is computed differently.
+#define K1_WARM_LINES_PER_BLOCK 512
+__device__ __forceinline__ float k1_warm_texels(const VolumeLevels& lv, int nv) {
+    float acc = 0.0f;
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < K1_WARM_LINES_PER_BLOCK / 256; ++k) {
+        uint32_t line = blockIdx.x * K1_WARM_LINES_PER_BLOCK + (uint32_t)k * 256u + threadIdx.x;      // over the tables of all levels, one after the other
+        base = 0;
+        for (int l = 0; l < lv.n; ++l) {
+            const uint32_t lines = ((uint32_t)nv * (uint32_t)lv.h[l] * (uint32_t)lv.w[l] * 16u + 127u) >> 7;
+            if (line >= base && line < base + lines) {
+                const uint32_t bytes = (uint32_t)nv * (uint32_t)lv.h[l] * (uint32_t)lv.w[l] * 16u, at = min((line - base) << 7, bytes - 4u);
+                acc += *(const float*)((const char*)lv.feat[l] + at);
+            }
+            base += lines;
+        }
+    }
+    return acc;
+}
+
+// ... or as a launch of its own in front (GENS_K1_WARM=2): one thread per line
+__global__ __launch_bounds__(256) void volume_warm_texels_k(VolumeLevels lv, int nv) {
+    uint32_t line = blockIdx.x * 256u + threadIdx.x, base = 0;
+    float acc = 0.0f;
+    for (int l = 0; l < lv.n; ++l) {
+        const uint32_t bytes = (uint32_t)nv * (uint32_t)lv.h[l] * (uint32_t)lv.w[l] * 16u, lines = (bytes + 127u) >> 7;
+        if (line >= base && line < base + lines) acc += *(const float*)((const char*)lv.feat[l] + min((line - base) << 7, bytes - 4u));
+        base += lines;
+    }
+    if (acc == 1.2345678e-31f) lv.mask[0][0] = acc;                                 // (never)
+}
+
+__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis, uint32_t warm_blocks) {
+    float warm = 0.0f;
+    if (blockIdx.x < warm_blocks) warm = k1_warm_texels(lv, nv);
     int l = 0;
     while (l + 1 < lv.n && blockIdx.x >= lv.first[l + 1]) ++l;                     // scalar: blockIdx and the table are uniform
     volume_build_chunk(blockIdx.x - lv.first[l], lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l]);
+    if (warm == 1.2345678e-31f) lv.mask[0][0] = warm;                              // (never: the warm-up loads have to be loads of something)
 }
 
 __global__ __launch_bounds__(256) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
@@ -727,7 +775,17 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
         lv.lc[l] = level_const(hw[2 * l], hw[2 * l + 1], d);
         lv.first[l + 1] = lv.first[l] + (uint32_t)(((int64_t)d * d * d) / 256);
     }
-    volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view);
+    // the texel warm-up (k1_warm_texels): enough leading workgroups to ask for every 128-byte line of the tables once; GENS_K1_WARM=0 switches it off
+    // (A/B runs: scripts/probe/k1_instep_probe.py)
+    int64_t lines = 0;
+    for (int l = 0; l < n_levels; ++l) lines += ((int64_t)nv * hw[2 * l] * hw[2 * l + 1] * 16 + 127) >> 7;
+    uint32_t warm_blocks = (uint32_t)std::min<int64_t>((lines + K1_WARM_LINES_PER_BLOCK - 1) / K1_WARM_LINES_PER_BLOCK, lv.first[n_levels]);
+    // Measured (scripts/probe/k1_instep_probe.py, profiles/r06_k1_warm_ab.txt): cold 266 us; warm-up inside the launch 244; as a launch of its own 229 --
+    // it costs 6 us when the texels are resident already (214 -> 221)
+    const int warm_mode = getenv("GENS_K1_WARM") ? atoi(getenv("GENS_K1_WARM")) : 2;
+    if (lines >= (1ll << 31) || warm_mode != 1) warm_blocks = 0;
+    if (warm_mode == 2 && lines < (1ll << 31)) volume_warm_texels_k<<<(unsigned)((lines + 255) / 256), 256, 0, (hipStream_t)stream>>>(lv, nv);
+    volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view, warm_blocks);
     return gens_launch_status("gens_volume_build_levels");
 }
 
@@ -1134,10 +1192,21 @@ __device__ __forceinline__ float4 rotate4(const RotatedLane& rl, float4 g) {    
     return make_float4(rl.b1 ? t2 : t0, rl.b1 ? t3 : t1, rl.b1 ? t0 : t2, rl.b1 ? t1 : t3);
 }
 __device__ __forceinline__ void window_add4(double* win, const RotatedLane& rl, int at, float4 g_rot, float w) {
+#if defined(GENS_K1_BWD_PROBE) && GENS_K1_BWD_PROBE == 1
+    // (timing probe, WRONG sums: plain stores instead of the LDS atomics -- what do the 16 ds_add_f64 per voxel cost?  scripts/probe/k1_bwd_floor_probe.sh)
+    win[rl.plane[0] + at] = (double)(g_rot.x * w);
+    win[rl.plane[1] + at] = (double)(g_rot.y * w);
+    win[rl.plane[2] + at] = (double)(g_rot.z * w);
+    win[rl.plane[3] + at] = (double)(g_rot.w * w);
+#elif defined(GENS_K1_BWD_PROBE) && GENS_K1_BWD_PROBE == 2
+    // (timing probe, WRONG sums: one atomic per tap instead of four)
+    atomicAdd(win + rl.plane[0] + at, (double)((g_rot.x + g_rot.y + g_rot.z + g_rot.w) * w));
+#else
     atomicAdd(win + rl.plane[0] + at, (double)(g_rot.x * w));
     atomicAdd(win + rl.plane[1] + at, (double)(g_rot.y * w));
     atomicAdd(win + rl.plane[2] + at, (double)(g_rot.z * w));
     atomicAdd(win + rl.plane[3] + at, (double)(g_rot.w * w));
+#endif
 }
 __device__ __forceinline__ void window_voxel(double* win, const RotatedLane& rl, const BwdVoxel& o, int x_org, int y_org) {
     const int cx = o.x0 - x_org, cy = o.y0 - y_org;

@@ -77,8 +77,21 @@ for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), 
                    ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash), ("after the fill and 2 ms idle", thrash_then_idle),
                    ("after the fill and a pass over the texels", thrash_then_touch_texels)):
     med, p10, p90 = timed(prep)
-    print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / med / 1e6 / 8e6 * 100 * 1e0))
+    print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / (med * 1e-6) / 8e12 * 100))
 
+os.environ["GENS_K1_WARM"] = "0"
+print("--- the same with the launch's own texel warm-up switched off (GENS_K1_WARM=0)")
+for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash),
+                   ("after the fill and a pass over the texels", thrash_then_touch_texels)):
+    med, p10, p90 = timed(prep)
+    print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / (med * 1e-6) / 8e12 * 100))
+os.environ["GENS_K1_WARM"] = "2"
+print("--- the warm-up as a launch of its own in front (GENS_K1_WARM=2; both launches inside the timed entry point)")
+for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash),
+                   ("after the fill and a pass over the texels", thrash_then_touch_texels)):
+    med, p10, p90 = timed(prep)
+    print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / (med * 1e-6) / 8e12 * 100))
+os.environ.pop("GENS_K1_WARM")
 print("--- one launch for all levels against level by level (GENS_K1_PER_LEVEL), outputs kept, 0.2 ms idle before each")
 for env in (None, "1"):
     if env is None:
