@@ -162,7 +162,9 @@ def test_validate_full_image_480x640(nv, dims):
     dz = (z_dev.cpu() - z_ref).abs().max(1)[0]
     print("hierarchical samples, worst |device - oracle| per ray: median %.1e, p99 %.1e, max %.1e; rays with a sample off by > 1e-4: %d of %d"
           % (float(dz.median()), float(dz.quantile(0.99)), float(dz.max()), int((dz > 1e-4).sum()), dz.numel()))
-    assert float(dz.median()) <= 2e-6 and int((dz > 1e-4).sum()) <= max(2, n_oracle // 16)      # the discontinuity is rare, the rest is round-off
+    # the discontinuity is rare, the rest is round-off.  Observed (profiles/r06_parity_numbers.txt): 1 of 512 rays at three levels / four source views,
+    # 8 of 512 at five levels / two source views (border rays most); the bound is twice the worst observed count (round 5: n / 16 = 32)
+    assert float(dz.median()) <= 2e-6 and int((dz > 1e-4).sum()) <= max(2, n_oracle // 32)
 
     def per_ray(r):
         nrm = (r["gradients"] * r["weights"][..., None] * r["inside_sphere"][..., None]).sum(1)
