@@ -348,7 +348,7 @@ __device__ unsigned long long k18t_stamps[4][64];
 #define KT_STAMP()                                                                                           \
     do {                                                                                                     \
         if (blockIdx.x == 7 && tile_no == 3) {                                                               \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+            if (GENS_K18T_STAMPS == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
             if (lane == 0 && n_stamp < 64) k18t_stamps[wave][n_stamp++] = __builtin_readcyclecounter();      \
         }                                                                                                    \
     } while (0)
