@@ -1133,20 +1133,39 @@ __device__ __forceinline__ float buffer_f32(const __amdgpu_buffer_rsrc_t r, uint
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
 }
 __device__ __forceinline__ BwdLoads bwd_issue(const BwdLevel& L, const BwdBuffers& b, uint32_t view_off, k1b_float_p m, k1b_float_p k, bool pinhole,
-                                              const TileVoxel& tv) {
+                                              const int4 box, const TileVoxel& tv) {
     const int d = L.d, w = L.w, h = L.h;
     const uint32_t at = tv.vox * 4u, pb = b.plane_bytes;
-    BwdLoads o;
-    o.cnt = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(b.count, tv.vox, 0, 0);
-    o.gm0 = buffer_f32(b.gvol, at, 0), o.gm1 = buffer_f32(b.gvol, at, pb), o.gm2 = buffer_f32(b.gvol, at, 2u * pb), o.gm3 = buffer_f32(b.gvol, at, 3u * pb);
-    o.gv0 = buffer_f32(b.gvol, at, 4u * pb), o.gv1 = buffer_f32(b.gvol, at, 5u * pb), o.gv2 = buffer_f32(b.gvol, at, 6u * pb), o.gv3 = buffer_f32(b.gvol, at, 7u * pb);
-    o.m0 = buffer_f32(b.vol, at, 0), o.m1 = buffer_f32(b.vol, at, pb), o.m2 = buffer_f32(b.vol, at, 2u * pb), o.m3 = buffer_f32(b.vol, at, 3u * pb);
+    BwdLoads o = {};
+#if defined(GENS_K1_BWD_PROBE) && GENS_K1_BWD_PROBE == 4
+    // (timing probe, WRONG sums: no loads at all -- lane-dependent constants in their place: what do the projection, the taps and the window adds cost alone?)
+    {
+        const float c0 = (float)(tv.vox & 1023u) * 1e-3f;
+        o.cnt = 1u + (tv.vox & 3u);
+        o.gm0 = c0, o.gm1 = c0 + 1.0f, o.gm2 = c0 + 2.0f, o.gm3 = c0 + 3.0f, o.gv0 = c0 * 2.0f, o.gv1 = c0 * 3.0f, o.gv2 = c0 * 4.0f, o.gv3 = c0 * 5.0f;
+        o.m0 = c0 - 1.0f, o.m1 = c0 - 2.0f, o.m2 = c0 - 3.0f, o.m3 = c0 - 4.0f;
+        const LeanProj p = project_lean(m, k, pinhole, L.lc, (float)(w - 1), (float)(h - 1), lattice_at(L.lc, d, tv.ix), lattice_at(L.lc, d, tv.jy), lattice_at(L.lc, d, tv.kz));
+        o.vis = p.vis;
+        o.fx = p.vis ? p.fx : 0.0f;
+        o.fy = p.vis ? p.fy : 0.0f;
+        o.v00 = (f4){c0, c0, c0, c0}, o.v01 = o.v00 + 1.0f, o.v10 = o.v00 + 2.0f, o.v11 = o.v00 + 3.0f;
+        return o;
+    }
+#endif
     const LeanProj p = project_lean(m, k, pinhole, L.lc, (float)(w - 1), (float)(h - 1), lattice_at(L.lc, d, tv.ix), lattice_at(L.lc, d, tv.jy), lattice_at(L.lc, d, tv.kz));
     // a visible voxel reads inside the image: fx in [0, w - 1], fy in [0, h - 1]; the +1 taps may sit on column w / row h with weight exactly 0
     o.vis = p.vis;
     o.fx = p.vis ? p.fx : 0.0f;
     o.fy = p.vis ? p.fy : 0.0f;
     const int x0 = (int)floorf(o.fx), y0 = (int)floorf(o.fy);
+    // Only the lanes whose voxel is visible in this view AND owned by this item's image tile load anything (box = x_org, y_org, width, height of the
+    // tile): the kernel is bound by the bytes it fetches, not by its arithmetic or its LDS atomics (profiles/r06_k1_bwd_floor.txt: no loads 0.43 ms,
+    // no window adds 0.66, all of it 0.69), and a third of the lanes of a visit belong to a neighbouring tile's visit of the same pair or to no view.
+    if (!(p.vis && (uint32_t)(x0 - box.x) < (uint32_t)box.z && (uint32_t)(y0 - box.y) < (uint32_t)box.w)) return o;
+    o.cnt = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(b.count, tv.vox, 0, 0);
+    o.gm0 = buffer_f32(b.gvol, at, 0), o.gm1 = buffer_f32(b.gvol, at, pb), o.gm2 = buffer_f32(b.gvol, at, 2u * pb), o.gm3 = buffer_f32(b.gvol, at, 3u * pb);
+    o.gv0 = buffer_f32(b.gvol, at, 4u * pb), o.gv1 = buffer_f32(b.gvol, at, 5u * pb), o.gv2 = buffer_f32(b.gvol, at, 6u * pb), o.gv3 = buffer_f32(b.gvol, at, 7u * pb);
+    o.m0 = buffer_f32(b.vol, at, 0), o.m1 = buffer_f32(b.vol, at, pb), o.m2 = buffer_f32(b.vol, at, 2u * pb), o.m3 = buffer_f32(b.vol, at, 3u * pb);
     const uint32_t xo0 = (uint32_t)x0 << 4, xo1 = (uint32_t)min(x0 + 1, w - 1) << 4, y1 = (uint32_t)min(y0 + 1, h - 1);
     o.v00 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24((uint32_t)y0, b.row_bytes) + xo0, view_off, 0));
     o.v01 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(b.texels, __umul24((uint32_t)y0, b.row_bytes) + xo1, view_off, 0));
@@ -1210,6 +1229,11 @@ __device__ __forceinline__ void window_add4(double* win, const RotatedLane& rl, 
 }
 __device__ __forceinline__ void window_voxel(double* win, const RotatedLane& rl, const BwdVoxel& o, int x_org, int y_org) {
     const int cx = o.x0 - x_org, cy = o.y0 - y_org;
+#if defined(GENS_K1_BWD_PROBE) && GENS_K1_BWD_PROBE == 3
+    // (timing probe, WRONG sums: the loads and the arithmetic stay alive, no window adds -- what do the loads cost alone?)
+    if (o.on && o.g.x + o.g.y + o.g.z + o.g.w + o.w00 == 1.2345e33f) win[cx] = 1.0;
+    return;
+#endif
     if (o.on && cx >= 0 && cx < BL_W && cy >= 0 && cy < BL_H) {                     // the voxel belongs to this image tile
         const int at = cy * (BL_W + 1) + cx;
         const float4 gr = rotate4(rl, o.g);
@@ -1228,6 +1252,25 @@ __device__ __forceinline__ void direct_voxel(const BwdLevel& L, int v, const Bwd
     if (o.ok_x1 && o.ok_y1) atomic_add4(base + (int64_t)L.w * 4 + 4, o.g, o.w11);
 }
 
+#ifdef GENS_K1_BWD_STAMPS
+// (dev build: cycles of wave 0 per phase, summed over the launch -- 0 take an item, 1 zero the window, 2 the pairs, 3 the flush, 4 direct items, 5 items)
+__device__ unsigned long long k1_bwd_stamps[8];
+extern "C" int gens_debug_k1_bwd_stamps(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(k1_bwd_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k1_bwd_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#define K1B_STAMP(i)                                                                   \
+    do {                                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter();                  \
+        if (tid == 0) atomicAdd(&k1_bwd_stamps[i], now_ - stamp_);                     \
+        stamp_ = now_;                                                                 \
+    } while (0)
+#else
+#define K1B_STAMP(i)
+#endif
 __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, const float* __restrict__ w2c) {
     extern __shared__ double win[];                    // 4 channel planes of BL_WIN sums: the lanes of one add spread over all banks
     __shared__ uint32_t taken;
@@ -1235,12 +1278,16 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
     // One workgroup per CU takes work items off a counter until none is left: the items differ in length (a bin's last piece, the short pieces
     // of the direct bins), and a grid of one workgroup per POSSIBLE item was mostly empty workgroups (10 000 launched for 1 700 items at 256^3).
     const uint32_t n_items = *a.n_items;
+#ifdef GENS_K1_BWD_STAMPS
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
     if (tid == 0) taken = atomicAdd(a.next_item, 1u);
     __syncthreads();
     const uint32_t mine_item = taken;
     __syncthreads();
     if (mine_item >= n_items) return;
+    K1B_STAMP(0);
     const uint4 item = a.items[mine_item];
     const BwdLevel& L = a.lv[__builtin_amdgcn_readfirstlane((int)item.w)];
     const int d = L.d, w = L.w, h = L.h;
@@ -1253,14 +1300,20 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
             const int v = (int)(pair / L.n_waves);
             const TileVoxel tv = bwd_tile_voxel(bwd_tile_code(pair - (uint32_t)v * L.n_waves, d), lane, d);
             const k1b_float_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);
-            direct_voxel(L, v, bwd_finish(L, bwd_issue(L, buf, (uint32_t)v * buf.view_bytes, m, k, is_pinhole(m, k), tv)));
+            direct_voxel(L, v, bwd_finish(L, bwd_issue(L, buf, (uint32_t)v * buf.view_bytes, m, k, is_pinhole(m, k), make_int4(0, 0, 1 << 30, 1 << 30), tv)));
         }
+#ifdef GENS_K1_BWD_STAMPS
+        __syncthreads();
+        K1B_STAMP(4);
+#endif
         continue;
     }
     const int tx = (int)(local % (uint32_t)L.tiles_x), ty = (int)((local / (uint32_t)L.tiles_x) % (uint32_t)L.tiles_y), v = (int)(local / (uint32_t)(L.tiles_x * L.tiles_y));
     const int x_org = tx * BL_W, y_org = ty * BL_H;
+    const int4 box = make_int4(x_org, y_org, BL_W, BL_H);
     for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) win[i] = 0.0;
     __syncthreads();
+    K1B_STAMP(1);
     const k1b_float_p m = k1_const(w2c + 16 * v), k = k1_const(L.intr + 16 * v);      // (constant address space: see volume_build_chunk)
     const bool pinhole = is_pinhole(m, k);
     const uint32_t view_off = (uint32_t)v * buf.view_bytes;
@@ -1270,19 +1323,24 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
 #pragma unroll
     for (int c = 0; c < 4; ++c) rl.plane[c] = ((c + lane) & 3) * BL_WIN;
     // the waves take interleaved entries (wave w: e0 + w, e0 + w + 16, ...): neighbours in the list are neighbours in the volume and read the same texels
+    // and the two halves of the same 128-byte lines of the planes at the same moment (64 consecutive entries per wave: 0.60 -> 0.70 ms; a streaming
+    // hint on the planar loads: 0.76; work items ordered by slab of the volume so that the views meet in the memory-side cache: 0.62 -- r06_k1_bwd_floor.txt)
     for (uint32_t e0 = item.y; e0 + (uint32_t)wave < item.z; e0 += 64u * NW) {
         const uint32_t mine_at = e0 + (uint32_t)wave + NW * (uint32_t)lane;
         const uint32_t mine = mine_at < item.z ? a.list[mine_at] : 0u;            // the wave's next 64 tiles, one per lane
         const int cnt = (int)min(64u, (item.z - e0 - (uint32_t)wave + NW - 1u) / NW);
-        BwdLoads cur = bwd_issue(L, buf, view_off, m, k, pinhole, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, 0), lane, d));
-        for (int j = 0; j < cnt; ++j) {
-            // (the last trip loads its own tile again: no branch around the loads, and the lines are in L1)
-            const BwdLoads nxt = bwd_issue(L, buf, view_off, m, k, pinhole, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, min(j + 1, cnt - 1)), lane, d));
-            window_voxel(win, rl, bwd_finish(L, cur), x_org, y_org);
-            cur = nxt;
+        // two tiles per trip, their loads in two named sets of registers (one set copied into the other per tile was 39 moves of ~230 instructions)
+        BwdLoads even = bwd_issue(L, buf, view_off, m, k, pinhole, box, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, 0), lane, d));
+        for (int j = 0; j < cnt; j += 2) {
+            // (past the end a trip loads the last tile again: no branch around the loads, and the lines are in L1)
+            const BwdLoads odd = bwd_issue(L, buf, view_off, m, k, pinhole, box, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, min(j + 1, cnt - 1)), lane, d));
+            window_voxel(win, rl, bwd_finish(L, even), x_org, y_org);
+            even = bwd_issue(L, buf, view_off, m, k, pinhole, box, bwd_tile_voxel((uint32_t)__builtin_amdgcn_readlane((int)mine, min(j + 2, cnt - 1)), lane, d));
+            if (j + 1 < cnt) window_voxel(win, rl, bwd_finish(L, odd), x_org, y_org);
         }
     }
     __syncthreads();
+    K1B_STAMP(2);
     float* out = L.gfeat + (int64_t)v * h * w * 4;
     for (int i = tid; i < 4 * BL_WIN; i += BL_THREADS) {      // a lane per FLOAT: the lanes of an atomic instruction on consecutive addresses (L2 serves requests, not lanes)
         const int texel = i >> 2, c = i & 3;
@@ -1297,6 +1355,10 @@ __global__ __launch_bounds__(BL_THREADS) void volume_bwd_tiles_k(BwdLevels a, co
         }
     }
     __syncthreads();                                                               // (the window is zeroed again by the next item)
+    K1B_STAMP(3);
+#ifdef GENS_K1_BWD_STAMPS
+    if (tid == 0) atomicAdd(&k1_bwd_stamps[5], 1ull);
+#endif
     }
 }
 
