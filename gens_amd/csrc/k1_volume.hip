@@ -526,12 +526,21 @@ __global__ __launch_bounds__(256) void volume_warm_texels_k(VolumeLevels lv, int
     if (acc == 1.2345678e-31f) lv.mask[0][0] = acc;                                 // (never)
 }
 
-__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis, uint32_t warm_blocks) {
+__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis, uint32_t warm_blocks,
+                                                                 uint32_t groups) {
     float warm = 0.0f;
     if (blockIdx.x < warm_blocks) warm = k1_warm_texels(lv, nv);
     int l = 0;
     while (l + 1 < lv.n && blockIdx.x >= lv.first[l + 1]) ++l;                     // scalar: blockIdx and the table are uniform
-    volume_build_chunk(blockIdx.x - lv.first[l], lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l]);
+    // Chunk order (A/B switch GENS_K1_INTERLEAVE=<parts>, off by default).  In index order the launch walks the volume slab by slab, and the tiles no view
+    // reaches (stores only: two thirds of the volume at the benchmark geometry) and the tiles with work (instruction-bound) come in long runs of one
+    // kind; with the switch consecutive workgroups take their chunks from <parts> different parts of the volume (chunk i of part g runs as workgroup
+    // i * parts + g).  Isolated and cold, 128 parts at 256^3 (two per x-slab) measured 230 -> 221 us and -2.5 .. -6 % on four of five camera set-ups
+    // (16, 32, 256 parts: 260 - 277 us: not monotonic) -- but inside the bench step nothing: 223.4 against 221.6 us (profiles/r06_k1_interleave_ab.txt).
+    uint32_t chunk = blockIdx.x - lv.first[l];
+    const uint32_t n_chunks = lv.first[l + 1] - lv.first[l];
+    if (groups > 1u && n_chunks % groups == 0u) chunk = (chunk % groups) * (n_chunks / groups) + chunk / groups;
+    volume_build_chunk(chunk, lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l]);
     if (warm == 1.2345678e-31f) lv.mask[0][0] = warm;                              // (never: the warm-up loads have to be loads of something)
 }
 
@@ -785,7 +794,8 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
     const int warm_mode = getenv("GENS_K1_WARM") ? atoi(getenv("GENS_K1_WARM")) : 2;
     if (lines >= (1ll << 31) || warm_mode != 1) warm_blocks = 0;
     if (warm_mode == 2 && lines < (1ll << 31)) volume_warm_texels_k<<<(unsigned)((lines + 255) / 256), 256, 0, (hipStream_t)stream>>>(lv, nv);
-    volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view, warm_blocks);
+    const uint32_t groups = getenv("GENS_K1_INTERLEAVE") ? (uint32_t)atoi(getenv("GENS_K1_INTERLEAVE")) : 0u;
+    volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view, warm_blocks, groups);
     return gens_launch_status("gens_volume_build_levels");
 }
 

@@ -79,6 +79,13 @@ for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), 
     med, p10, p90 = timed(prep)
     print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / (med * 1e-6) / 8e12 * 100))
 
+for g in (8, 64, 512, 4096):
+    os.environ["GENS_K1_INTERLEAVE"] = str(g)
+    print(f"--- consecutive workgroups from {g} different parts of the volume (GENS_K1_INTERLEAVE={g})")
+    for name, prep in (("back to back", nothing), ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash)):
+        med, p10, p90 = timed(prep)
+        print("%-48s median %6.1f us  p10 %6.1f  p90 %6.1f   %.1f %% of 8 TB/s" % (name, med, p10, p90, algo / (med * 1e-6) / 8e12 * 100))
+os.environ.pop("GENS_K1_INTERLEAVE")
 os.environ["GENS_K1_WARM"] = "0"
 print("--- the same with the launch's own texel warm-up switched off (GENS_K1_WARM=0)")
 for name, prep in (("back to back", nothing), ("after 0.2 ms idle", idle(0.2)), ("after a 1 GiB fill (cold L2 / MALL), no idle", thrash),

@@ -13,6 +13,7 @@ STEPS=40
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG --output-format csv -- python3 "$ROOT/scripts/train_step_bench.py" "$@" --steps $STEPS --warm 5 > "$ROOT/gpurun_out/${TAG}_run.log" 2>&1 || true
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} "$ROOT/gpurun_out/${TAG}_kernel_stats.csv" \;
 python3 "$ROOT/scripts/gap_report.py" /tmp/prof_$TAG 30 > "$ROOT/gpurun_out/${TAG}_gaps.txt" 2>&1 || true
+python3 "$ROOT/scripts/step_gaps.py" /tmp/prof_$TAG ${MARKER:-scene_setup_k} 20 10 > "$ROOT/gpurun_out/${TAG}_step_gaps.txt" 2>&1 || true
 python3 - "$ROOT/gpurun_out/${TAG}_kernel_stats.csv" $STEPS >> "$ROOT/gpurun_out/${TAG}_gaps.txt" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
