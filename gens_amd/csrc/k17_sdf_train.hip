@@ -648,10 +648,12 @@ __global__ __launch_bounds__(256, 2) void sdf_train_bwd_k(SdfTrainWeights W, Lev
             }
             float* xr = X + row * RS + col;
             xr[0] = h; xr[XS] = hd; xr[XT] = hk; xr[XT + XS] = hn;
+#ifndef GENS_K17_NO_RH      // (timing probe scripts/probe/k17_rh_probe.py: what do these 0.64 GB of stores cost the launch?  WRONG weight gradients without them)
             if (l < 5) {   // (the inputs of the output row stay in LDS: its weight gradient is summed below)
                 float* gr = rh + (int64_t)row * 4 * TR_H;
                 gr[0] = h; gr[TR_H] = hd; gr[2 * TR_H] = hk; gr[3 * TR_H] = hn;
             }
+#endif
             st[i * 64] = keep;
         }
         TR_STAMP();
