@@ -275,7 +275,8 @@ __device__ __forceinline__ k1b_float_p k1_const(const float* p) { return p; }
 
 __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
-                                                   float* __restrict__ vol, float* __restrict__ mask, uint8_t* __restrict__ count) {
+                                                   float* __restrict__ vol, float* __restrict__ mask, uint8_t* __restrict__ count,
+                                                   uint32_t* __restrict__ bits = nullptr) {
     // Chunk -> voxels.  d >= 64: the four waves take the SAME 64 z of four x-adjacent rows (ix = 4 g + wave), whose image footprints
     // overlap, so most of a wave's texel lines are already in the CU's L1 (the z-contiguous 256-voxel chunk sent 3-4x as many requests
     // to L2); smaller volumes: 256 consecutive voxels = 256 / d whole rows.
@@ -364,6 +365,8 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
             const uint32_t at = tiled ? (((t_ix0 + (q >> 2)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 3u) << 4))) : chunk * 256u + q * 16u;
             *(u4*)(count + at) = zero;
         }
+        if (bits && wave == 2 && q < 8u)                                           // (the mask as bits, see below: this tile's eight words)
+            bits[tiled ? (((((t_ix0 + (q >> 1)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | t_kz0) >> 5) + (q & 1u)) : chunk * 8u + q] = 0u;
         return;
     }
     const int my_row = tiled ? (int)t_row : (int)(threadIdx.x >> lc.log2d);
@@ -433,6 +436,18 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
         s2 = make_float4(__builtin_fmaf(f.x, f.x, s2.x), __builtin_fmaf(f.y, f.y, s2.y), __builtin_fmaf(f.z, f.z, s2.z), __builtin_fmaf(f.w, f.w, s2.w));
         cnt += 1.0f;
     }
+    if (bits) {
+        // The mask once more as BITS (bit i & 31 of word i >> 5 = mask[i] > 0), the form the ray-point and nearest look-up kernels read: a training
+        // step packed them from the float planes in a launch per level (gens_pack_mask_bits: 75 MB read again, 50 us per step).  A wave's ballot
+        // holds 16 z of four rows (tiled: half a word per row) or 64 consecutive voxels (two words).
+        const unsigned long long b = __ballot(cnt > (float)min_vis);
+        if (tiled) {
+            if (lane < 4u)
+                ((uint16_t*)bits)[((((t_ix0 + lane) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + (wv << 4))) >> 4)] = (uint16_t)(b >> (16u * lane));
+        } else if ((lane & 31u) == 0u) {
+            bits[((chunk * 256u + (wv << 6)) >> 5) + (lane >> 5)] = (uint32_t)(b >> lane);
+        }
+    }
     const float den = cnt <= 0.0f ? 1e-8f : cnt;                                  // (Q5)
     const float yn = rcp_rn(den);
     const float4 mm = make_float4(div_rn(s1.x, den, yn), div_rn(s1.y, den, yn), div_rn(s1.z, den, yn), div_rn(s1.w, den, yn));
@@ -481,6 +496,7 @@ struct VolumeLevels {
     float* vol[GENS_MAX_LEVELS];
     float* mask[GENS_MAX_LEVELS];
     uint8_t* count[GENS_MAX_LEVELS];             // visible views per voxel (may be null)
+    uint32_t* bits[GENS_MAX_LEVELS];             // the mask as bits (may be null)
     int h[GENS_MAX_LEVELS], w[GENS_MAX_LEVELS], d[GENS_MAX_LEVELS];
     LevelConst lc[GENS_MAX_LEVELS];
     uint32_t first[GENS_MAX_LEVELS + 1];
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv
     uint32_t chunk = blockIdx.x - lv.first[l];
     const uint32_t n_chunks = lv.first[l + 1] - lv.first[l];
     if (groups > 1u && n_chunks % groups == 0u) chunk = (chunk % groups) * (n_chunks / groups) + chunk / groups;
-    volume_build_chunk(chunk, lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l]);
+    volume_build_chunk(chunk, lv.feat[l], w2c, lv.intr[l], nv, lv.h[l], lv.w[l], lv.d[l], lv.lc[l], min_vis, lv.vol[l], lv.mask[l], lv.count[l], lv.bits[l]);
     if (warm == 1.2345678e-31f) lv.mask[0][0] = warm;                              // (never: the warm-up loads have to be loads of something)
 }
 
@@ -748,9 +764,11 @@ extern "C" int gens_volume_build_fwd(const float* feat, const float* w2c, const 
     return volume_build_fwd_level(feat, w2c, intr, intr_scale, nv, h, w, d, min_vis_view, volume, mask, nullptr, stream);
 }
 
-extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
-                                        const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
-                                        uint8_t* const* counts, void* stream) {
+extern "C" int gens_pack_mask_bits(const float* mask, int64_t n, uint32_t* bits, void* stream);
+
+extern "C" int gens_volume_build_levels_bits(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                             const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
+                                             uint8_t* const* counts, uint32_t* const* mask_bits, void* stream) {
     GENS_CHECK_ARG(feat && hw && dims && w2c && intr && volumes && masks, GENS_EINVAL, "gens_volume_build_levels: null table");
     GENS_CHECK_ARG(n_levels >= 1 && n_levels <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_volume_build_levels: %d levels (1..%d)", n_levels, GENS_MAX_LEVELS);
     bool one_launch = nv <= K1_FAST_VIEWS && !getenv("GENS_K1_GENERIC") && !getenv("GENS_K1_SINGLE") && !getenv("GENS_K1_PER_LEVEL");
@@ -766,6 +784,9 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
             if (int e = volume_build_fwd_level(feat[l], w2c, intr[l], 1.0f, nv, hw[2 * l], hw[2 * l + 1], dims[l], min_vis_view, volumes[l], masks[l],
                                                counts ? counts[l] : nullptr, stream))
                 return e;
+        for (int l = 0; mask_bits && l < n_levels; ++l)
+            if (mask_bits[l])
+                if (int e = gens_pack_mask_bits(masks[l], (int64_t)dims[l] * dims[l] * dims[l], mask_bits[l], stream)) return e;
         return 0;
     }
     VolumeLevels lv;
@@ -778,6 +799,7 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
         lv.vol[l] = volumes[l];
         lv.mask[l] = masks[l];
         lv.count[l] = counts ? counts[l] : nullptr;
+        lv.bits[l] = mask_bits ? mask_bits[l] : nullptr;
         lv.h[l] = hw[2 * l];
         lv.w[l] = hw[2 * l + 1];
         lv.d[l] = d;
@@ -797,6 +819,12 @@ extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw,
     const uint32_t groups = getenv("GENS_K1_INTERLEAVE") ? (uint32_t)atoi(getenv("GENS_K1_INTERLEAVE")) : 0u;
     volume_build_fwd_levels_k<<<lv.first[n_levels], 256, 0, (hipStream_t)stream>>>(lv, w2c, nv, min_vis_view, warm_blocks, groups);
     return gens_launch_status("gens_volume_build_levels");
+}
+
+extern "C" int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                        const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
+                                        uint8_t* const* counts, void* stream) {
+    return gens_volume_build_levels_bits(feat, hw, dims, n_levels, w2c, intr, nv, min_vis_view, volumes, masks, counts, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ void gens_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gens_last_error(void) { return g_err; }
-extern "C" int gens_abi_version(void) { return 11; }
+extern "C" int gens_abi_version(void) { return 12; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K9: bilinear read of a texel image at pixel coordinates (align_corners=True after the reference's own
@@ -118,6 +118,79 @@ extern "C" int gens_upsample2d_into(const float* src, int n, int c, int hs, int 
     int64_t total = (int64_t)n * h * w * c;
     upsample2d_into_k<<<gens_blocks(total, 256), 256, 0, (hipStream_t)stream>>>(src, c, hs, ws, dst, h, w, c_pad_dst, c_off, total);
     return gens_launch_status("gens_upsample2d_into");
+}
+
+// cat([f0, up(f1), up(f2), ...], 1) as texels in ONE pass: a thread per pixel writes all its channels (whole 16-byte pieces of a contiguous
+// C_pad x 4-byte texel), where a launch of upsample2d_into_k per level wrote a quarter of every texel each time, behind a zero fill of the whole
+// tensor (three launches + fill: 135 us per training step at 5 x 480 x 640 x 12; this one: see DESIGN.md).  Per value the arithmetic of
+// upsample2d_into_k, operation for operation.
+struct UpsampleCat {
+    const float* src[GENS_MAX_LEVELS];
+    int c[GENS_MAX_LEVELS], hs[GENS_MAX_LEVELS], ws[GENS_MAX_LEVELS];
+    int n;
+};
+template <bool FOUR>
+__global__ __launch_bounds__(256) void upsample2d_cat_k(UpsampleCat A, float* __restrict__ dst, int h, int w, int cpad, int64_t pixels) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= pixels) return;
+    const int x = (int)(gid % w), y = (int)((gid / w) % h);
+    const int64_t img = gid / ((int64_t)w * h);
+    float* out = dst + gid * cpad;
+    int off = 0;
+    for (int l = 0; l < A.n; ++l) {
+        const int c = A.c[l], hs = A.hs[l], ws = A.ws[l];
+        const float sy = fmaxf(((float)y + 0.5f) * ((float)hs / (float)h) - 0.5f, 0.0f);
+        const float sx = fmaxf(((float)x + 0.5f) * ((float)ws / (float)w) - 0.5f, 0.0f);
+        const int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
+        const int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+        const float ty = sy - (float)y0, tx = sx - (float)x0;
+        const int64_t plane = (int64_t)hs * ws;
+        const float* s = A.src[l] + img * c * plane;
+        const int64_t i00 = (int64_t)y0 * ws + x0, i01 = (int64_t)y0 * ws + x1, i10 = (int64_t)y1 * ws + x0, i11 = (int64_t)y1 * ws + x1;
+        if (FOUR) {      // (every level has four channels: one 16-byte store per level)
+            float v[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float* sc = s + ch * plane;
+                const float top = sc[i00] * (1.0f - tx) + sc[i01] * tx;
+                const float bot = sc[i10] * (1.0f - tx) + sc[i11] * tx;
+                v[ch] = top * (1.0f - ty) + bot * ty;
+            }
+            *(float4*)(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int ch = 0; ch < c; ++ch) {
+                const float* sc = s + ch * plane;
+                const float top = sc[i00] * (1.0f - tx) + sc[i01] * tx;
+                const float bot = sc[i10] * (1.0f - tx) + sc[i11] * tx;
+                out[off + ch] = top * (1.0f - ty) + bot * ty;
+            }
+        }
+        off += c;
+    }
+    for (int ch = off; ch < cpad; ++ch) out[ch] = 0.0f;                             // the pad channels (what the zero fill left there)
+}
+
+extern "C" int gens_upsample2d_cat(const float* const* srcs, const int* chw, int n_maps, int n, float* dst, int h, int w, int c_pad_dst, void* stream) {
+    GENS_CHECK_ARG(srcs && chw && dst && n > 0 && h > 0 && w > 0, GENS_EINVAL, "gens_upsample2d_cat: bad argument");
+    GENS_CHECK_ARG(n_maps >= 1 && n_maps <= GENS_MAX_LEVELS, GENS_ELIMIT, "gens_upsample2d_cat: %d maps (at most %d)", n_maps, GENS_MAX_LEVELS);
+    UpsampleCat A = {};
+    A.n = n_maps;
+    int ctot = 0;
+    bool four = (c_pad_dst & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+    for (int l = 0; l < n_maps; ++l) {
+        A.src[l] = srcs[l];
+        A.c[l] = chw[3 * l], A.hs[l] = chw[3 * l + 1], A.ws[l] = chw[3 * l + 2];
+        GENS_CHECK_ARG(A.src[l] && A.c[l] > 0 && A.hs[l] > 0 && A.ws[l] > 0, GENS_EINVAL, "gens_upsample2d_cat: bad map %d", l);
+        four = four && A.c[l] == 4;
+        ctot += A.c[l];
+    }
+    GENS_CHECK_ARG(ctot <= c_pad_dst, GENS_EINVAL, "gens_upsample2d_cat: %d channels into texels of %d", ctot, c_pad_dst);
+    const int64_t pixels = (int64_t)n * h * w;
+    if (four)
+        upsample2d_cat_k<true><<<gens_blocks(pixels, 256), 256, 0, (hipStream_t)stream>>>(A, dst, h, w, c_pad_dst, pixels);
+    else
+        upsample2d_cat_k<false><<<gens_blocks(pixels, 256), 256, 0, (hipStream_t)stream>>>(A, dst, h, w, c_pad_dst, pixels);
+    return gens_launch_status("gens_upsample2d_cat");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gens_volume_build_bwd": [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
     "gens_selftest_division": [_p, _p],
     "gens_volume_build_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _pp, _p],
+    "gens_volume_build_levels_bits": [_pp, _ip, _ip, _i, _p, _pp, _i, _i, _pp, _pp, _pp, _pp, _p],
     "gens_volume_build_bwd_levels": [_pp, _ip, _ip, _i, _p, _pp, _i, _pp, _pp, _pp, _pp, _p, _l, _p],
     "gens_gemm_tn_slabs": [_l, _i, _i],
     "gens_gemm_tn": [_p, _p, _l, _i, _i, _p, _p, _p],
@@ -88,6 +89,7 @@ SIGNATURES = {
     "gens_patch_sample_fwd": [_p, _i, _i, _i, _p, _l, _p, _p],
     "gens_patch_sample_bwd": [_p, _i, _i, _i, _p, _p, _l, _p, _p],
     "gens_upsample2d_into": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
+    "gens_upsample2d_cat": [_p, _p, _i, _i, _p, _i, _i, _i, _p],
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_tv_bwd_scaled": [_p, _p, _i, _i, _i, _f, _p, _p, _p],

@@ -399,10 +399,15 @@ def _build_warp_features(levels):
     nv, c, h, w = f0.shape
     ctot = sum(f.shape[1] for f in levels)
     cpad = 4 * ((ctot + 3) // 4)
+    maps = [_c(f.detach().to(_f32)) for f in levels]
+    if len(maps) <= 8:                      # one launch, every texel written whole (gens_upsample2d_cat)
+        dst = torch.empty(nv, h, w, cpad, device=f0.device, dtype=_f32)
+        chw = [d for f in maps for d in f.shape[1:]]
+        L.call("gens_upsample2d_cat", L.ptr_table(maps), L.int_table(chw), len(maps), nv, L.ptr(dst), h, w, cpad, L.stream())
+        return dst, ctot
     dst = torch.zeros(nv, h, w, cpad, device=f0.device, dtype=_f32)
     off = 0
-    for f in levels:
-        f = _c(f.detach().to(_f32))
+    for f in maps:
         L.call("gens_upsample2d_into", L.ptr(f), nv, f.shape[1], f.shape[2], f.shape[3], L.ptr(dst), h, w, cpad, off, L.stream())
         off += f.shape[1]
     return dst, ctot

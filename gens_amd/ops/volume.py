@@ -59,14 +59,17 @@ class _VolumeBuildLevels(torch.autograd.Function):
         want = any(ctx.needs_input_grad[3:3 + n])
         levels_bwd = want and kernels.k1_bwd == "auto" and L.load().gens_volume_build_bwd_levels_scratch_bytes(L.int_table(hw), L.int_table(dims), n, nv) > 0
         counts = [torch.empty(d ** 3, device=dev, dtype=torch.uint8) for d in dims] if levels_bwd else None
-        L.call("gens_volume_build_levels", L.ptr_table(texs_c), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv, min_vis,
-               L.ptr_table(vols), L.ptr_table(masks), L.ptr_table(counts, torch.uint8), L.stream(),
-               nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)))
+        # the masks as bits too (what the ray-point / nearest look-up kernels read): written by the same launch, not packed from the float planes
+        # by a launch per level and step (VolumeSet.bit_table finds them on the mask tensors)
+        bits = [torch.empty((d ** 3 + 31) // 32, device=dev, dtype=torch.int32) for d in dims]
+        L.call("gens_volume_build_levels_bits", L.ptr_table(texs_c), L.int_table(hw), L.int_table(dims), n, L.ptr(w2c), L.ptr_table(list(intrs)), nv, min_vis,
+               L.ptr_table(vols), L.ptr_table(masks), L.ptr_table(counts, torch.uint8), L.ptr_table(bits, torch.int32), L.stream(),
+               nbytes=sum(nv * t.shape[1] * t.shape[2] * 16 + 36 * d ** 3 for t, d in zip(texs, dims)), label="gens_volume_build_levels")
         ctx.save_for_backward(w2c, *texs, *intrs, *(vols + counts if levels_bwd else []))
         ctx.dims = list(dims)
         ctx.levels_bwd = levels_bwd
-        ctx.mark_non_differentiable(*masks)
-        return (*vols, *masks)
+        ctx.mark_non_differentiable(*masks, *bits)
+        return (*vols, *masks, *bits)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -108,7 +111,13 @@ def volume_build(features, intrs, c2ws, dims, min_vis_view=1):
     texs = pack_maps([features[lvl] for lvl in range(len(dims))])
     out = _VolumeBuildLevels.apply(cams.w2c, [int(d) for d in dims], int(min_vis_view), *texs, *cams.ks[:len(dims)])
     n = len(dims)
-    return list(out[:n]), list(out[n:])
+    masks = list(out[n:2 * n])
+    for m, words in zip(masks, out[2 * n:]):
+        try:
+            m._gens_bits = (m._version, words)                      # (VolumeSet.bit_table)
+        except (AttributeError, RuntimeError):
+            pass
+    return list(out[:n]), masks
 
 
 __all__ = [n_ for n_ in dir() if not n_.startswith("__")]      # private helpers travel too: the package namespace is the old module's

@@ -41,7 +41,7 @@ extern "C" {
 #define GENS_LAYOUT_PACKED 1
 
 const char* gens_last_error(void);
-/* 11.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
+/* 12.  History: 7 = 6 + gens_sdf_grad_f16 (the split-half value + gradient kernel).
  *   8 = round 4's additions, which shipped under the stale number 7: gens_grid_sample_{fwd,bwd,bwd2} (K20), gens_depthwise_conv2d_{fwd,dgrad,wgrad}
  *       + gens_depthwise_conv2d_wgrad_parts (K21), gens_batchnorm2d_train_{fwd,bwd} + gens_batchnorm2d_scratch_doubles (K22),
  *       gens_blend_train_bwd_acc + gens_blend_train_acc_{parts,floats}, gens_merge_upsample, gens_conv3d_wgrad_parts_strided, gens_instnorm_finish,
@@ -51,7 +51,9 @@ const char* gens_last_error(void);
  *   10 = round 5: gens_sdf_train_bwd's w6_part has a row per SIXTEEN points (npad / 16 rows, was npad / 32): its workgroups own 16 points
  *       now, two of them to a compute unit.
  *   11 = round 6: gens_blend_train_bwd_t + gens_blend_train_t_parts + gens_blend_train_bwd_t_dump (the colour branch's backward transposed: one
- *       wave per 16 rows, nothing shared between waves but the weights in LDS). */
+ *       wave per 16 rows, nothing shared between waves but the weights in LDS).
+ *   12 = round 6: gens_upsample2d_cat (the warp features in one launch), gens_volume_build_levels_bits (the volume build leaves the masks as bits
+ *       too). */
 int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -85,6 +87,12 @@ int gens_volume_build_bwd(const float* feat, const float* w2c, const float* intr
 int gens_volume_build_levels(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
                              const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
                              uint8_t* const* counts, void* stream);
+/* The same launch, leaving the masks as BITS too (ABI 12): mask_bits: NULL, or a HOST array of device pointers (an entry may be NULL) to
+ * ceil(D_l^3 / 32) uint32 words, bit (i & 31) of word (i >> 5) = masks[l][i] > 0 -- what gens_pack_mask_bits makes of the float plane and the
+ * ray-point / nearest look-up kernels read with mask_bits = 1; a training step then has no packing pass over the masks. */
+int gens_volume_build_levels_bits(const float* const* feat, const int* hw, const int* dims, int n_levels, const float* w2c,
+                                  const float* const* intr, int nv, int min_vis_view, float* const* volumes, float* const* masks,
+                                  uint8_t* const* counts, uint32_t* const* mask_bits, void* stream);
 /* d(volumes)/d(texels) of ALL levels in one launch set (five launches whatever n_levels is) with the sum owned by the IMAGE: the (64-voxel tile,
  * view) pairs are sorted by the 64 x 60-texel image tile they project into, a workgroup per tile keeps that tile's gradient in LDS (double
  * sums) and writes every touched texel once (gens_volume_build_bwd, the wave-window kernel, is bound by its ~0.3 G global atomics at 256^3).
@@ -566,6 +574,11 @@ int gens_patch_sample_bwd(const float* image, int h, int w, int c, const float* 
                           float* g_xy, void* stream);
 int gens_upsample2d_into(const float* src, int n, int c, int hs, int ws, float* dst, int h, int w, int c_pad_dst,
                          int c_off, void* stream);
+/* ... and the whole cat([f0, up(f1), up(f2), ...], 1) of implicit_surface.py:313-326 in ONE launch (ABI 12): srcs[i] is map i, (n, C_i, hs_i, ws_i)
+ * NCHW with chw[3 i .. 3 i + 2] = (C_i, hs_i, ws_i); every texel of dst (n, H, W, C_pad_dst) is written whole, its pad channels with zeros (no
+ * fill beforehand); the values are gens_upsample2d_into's bit for bit. */
+int gens_upsample2d_cat(const float* const* srcs, const int* chw, int n_maps, int n, float* dst, int h, int w, int c_pad_dst,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K13  compute_LNCC, the photometric patch statistic of the loss     (models/losses/ncc.py:7-55, loss.py:36)

@@ -219,7 +219,8 @@ def _measure(quiet, kernels=False):
     auto = getattr(model if model is not None else surf, "_auto", None)
     _measure.stats["auto_graph"] = dict(auto.stats) if auto is not None else None
     if not quiet:
-        print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step)")
+        print(f"{label} step: {dt * 1e3:.1f} ms  ({512 * 128 / dt / 1e6:.2f} M ray-samples/s, 512 rays; host enqueue {host / n * 1e3:.1f} ms of it, incl. the waits inside the step); "
+              f"median {_measure.stats['median_ms']:.2f} ms, p10 {_measure.stats['p10_ms']:.2f}, p90 {_measure.stats['p90_ms']:.2f}")
     if os.environ.get("GENS_TRAIN_OPS"):         # which torch operators make up the step's launches (torch.profiler over one step)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(libpath):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in gens_hip.h but not exported"
     lib.gens_abi_version.restype = ctypes.c_int
-    assert lib.gens_abi_version() == 11
+    assert lib.gens_abi_version() == 12
 
 
 def test_ctypes_table_covers_header(libpath):

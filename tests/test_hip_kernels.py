@@ -388,6 +388,28 @@ def test_k9_warp_feature_upsampling_vs_oracle(ops):
     close(tex.permute(0, 3, 1, 2)[:, 8:12], torch_ref, atol=1e-6, what="vs F.interpolate")
 
 
+@pytest.mark.parametrize("chans", [(4, 4, 4), (3, 5, 2), (4, 4)])
+def test_k9_one_launch_upsampling_equals_the_launch_per_level(ops, chans):
+    """gens_upsample2d_cat against gens_upsample2d_into level by level, bit for bit; the pad channels are written (zeros), not left to a fill."""
+    from gens_amd import lib as L
+    g = torch.Generator().manual_seed(21)
+    nv, h, w = 2, 44, 60
+    maps = [torch.randn(nv, c, max(h >> i, 1), max(w >> i, 1), generator=g).cuda() for i, c in enumerate(chans)]
+    ctot = sum(chans)
+    cpad = 4 * ((ctot + 3) // 4)
+    ref = torch.zeros(nv, h, w, cpad, device="cuda")
+    off = 0
+    for f in maps:
+        L.call("gens_upsample2d_into", L.ptr(f), nv, f.shape[1], f.shape[2], f.shape[3], L.ptr(ref), h, w, cpad, off, L.stream())
+        off += f.shape[1]
+    out = torch.full((nv, h, w, cpad), float("nan"), device="cuda")
+    chw = [d for f in maps for d in f.shape[1:]]
+    L.call("gens_upsample2d_cat", L.ptr_table(maps), L.int_table(chw), len(maps), nv, L.ptr(out), h, w, cpad, L.stream())
+    assert torch.equal(out, ref)
+    tex, c = ops.build_warp_features(maps)
+    assert c == ctot and torch.equal(tex, ref)
+
+
 # --------------------------------------------------------------------------------------------------- K10 / K11
 def test_k10_tv_golden(ops, golden):
     g = golden("g8_tv")

@@ -281,6 +281,30 @@ def _k1_bwd(L, tex, w2c, intrs, scale, d, gvol, how):
     return gf
 
 
+@pytest.mark.parametrize("dims", [[128, 64, 32], [32, 16, 8], [24, 16]])
+def test_k1_leaves_the_masks_as_bits_too(dims):
+    """gens_volume_build_levels_bits: the words the volume build writes are gens_pack_mask_bits of its float masks (tiled levels, small levels, the
+    level-by-level fallback of a side that is not a power of two; tiles no view reaches included), and VolumeSet.bit_table takes them from the mask
+    tensors instead of packing again."""
+    from gens_amd import lib as L, ops, synthetic
+    from gens_amd.ops.base import VolumeSet
+    sc = synthetic.make_scene(nv=3, h=96, w=128, n_levels=len(dims), seed=5)
+    feats = [f.cuda() for f in sc["features"][:len(dims)]]
+    with torch.no_grad():
+        vols, masks = ops.volume_build(feats, sc["intrs"].cuda(), sc["c2ws"].cuda(), dims)
+    for m, d in zip(masks, dims):
+        n = d ** 3
+        want = torch.empty((n + 31) // 32, device="cuda", dtype=torch.int32)
+        L.call("gens_pack_mask_bits", L.ptr(m.reshape(-1).contiguous()), n, L.ptr(want, torch.int32), L.stream())
+        ver, got = m._gens_bits
+        assert ver == m._version and torch.equal(got, want), d
+        assert 0 < int((m > 0).sum()) < n                       # (both kinds of tiles are in the test)
+    vs = VolumeSet.masks(masks)
+    L.profile_begin()
+    vs.bit_table()
+    assert not any(name == "gens_pack_mask_bits" for name, _, _, _ in L.profile_end(raw=True))
+
+
 def test_k1_backward_window_kernel_equals_direct_atomics(scene):
     """The LDS-window scatter (one global atomic per touched texel and channel of a wave's 4 x 16 voxel tile) against one global atomic per tap, at full
     size (19 M voxels x 5 views): the same sums in a different order."""
