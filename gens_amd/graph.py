@@ -234,7 +234,7 @@ class _Entry:
     """One captured (forward, backward) pair and the static tensors around it."""
     __slots__ = ("calls", "used", "state", "fwd", "bwd", "static_in", "scalar_dev", "scalar_val", "refs", "grad_inputs", "grad_static", "out_names",
                  "out_static", "out_const", "out_diff", "diff_index", "bwd_used", "bwd_all", "recapture", "surfaces", "draws", "deferred", "fwd_done",
-                 "tick", "why_eager", "out_order", "generation")
+                 "tick", "why_eager", "out_order", "generation", "mask_words")
 
     def __init__(self):
         self.calls, self.used, self.state, self.tick, self.why_eager, self.recapture, self.generation = 0, set(), "warm", 0, None, False, 0
@@ -404,11 +404,18 @@ class AutoGraph:
             s.check_deferred()
         torch.cuda.synchronize()
         static_in = {}
+        mask_words = {}
         for n, t in copied.items():
             st = t.detach().clone()
             if t.requires_grad:
                 st.requires_grad_(True)
             static_in[n] = st
+            # a mask volume that arrives with its bit-packed copy (the volume build writes both: ops.volume_build) keeps one on its static twin, so the
+            # captured step holds no packing launch; every replay refreshes the words with the tensor (_replay)
+            hit = getattr(t, "_gens_bits", None)
+            if hit is not None and hit[0] == t._version and hit[1].device == t.device:
+                mask_words[n] = hit[1].clone()
+                st._gens_bits = (st._version, mask_words[n])
         scalar_dev = {n: torch.full((1,), float(v), device=dev, dtype=torch.float32) for n, v in scalars.items()}
         saved_rng = torch.get_rng_state()
         for s in surfaces:                                     # page-locked buffers of this capture's own (see below)
@@ -462,6 +469,7 @@ class AutoGraph:
         entry.out_names, entry.out_static, entry.out_const, entry.out_diff = names, tensors, consts, diff
         entry.diff_index = [i for i, d in enumerate(diff) if d]
         entry.surfaces = list(surfaces)
+        entry.mask_words = mask_words
         entry.fwd_done = None
         every = tuple(entry.diff_index)
         entry.bwd_used = self._capture_backward(entry, pattern)
@@ -489,14 +497,26 @@ class AutoGraph:
     def _replay(self, entry, copied, scalars):
         for s in entry.surfaces:
             s.check_deferred()                                 # what the previous step left to verify, if its backward never ran
-        dst, src = [], []
+        dst, src, wdst, wsrc = [], [], [], []
         for n, t in copied.items():
             st = entry.static_in[n]
             if t.data_ptr() != st.data_ptr():
                 dst.append(st.detach())
                 src.append(t)
+            words = entry.mask_words.get(n)
+            if words is not None:
+                hit = getattr(t, "_gens_bits", None)
+                if hit is not None and hit[0] == t._version and hit[1].shape == words.shape and hit[1].device == words.device:
+                    wdst.append(words)
+                    wsrc.append(hit[1])
+                else:                                          # (this step's mask came without its words: pack them now)
+                    from . import lib as L
+                    tc = t.detach().reshape(-1).contiguous()
+                    L.call("gens_pack_mask_bits", L.ptr(tc), tc.numel(), L.ptr(words, torch.int32), L.stream())
         if dst:
             torch._foreach_copy_(dst, src, non_blocking=True)   # the step's ~ ten inputs in one or two launches (per dtype), not one each
+        if wdst:
+            torch._foreach_copy_(wdst, wsrc, non_blocking=True)
         for n, v in scalars.items():
             v = float(v)
             if v != entry.scalar_val[n]:

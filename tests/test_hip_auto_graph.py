@@ -203,6 +203,48 @@ def test_render_alone_is_captured_when_it_is_called_directly():
     assert ops is not None
 
 
+def test_masks_that_arrive_with_their_bits_keep_them_through_a_captured_step():
+    """The volume build hands out its masks with their bit-packed copies (ops.volume_build -> `_gens_bits`): the captured step holds no packing launch,
+    every replay copies the step's words beside the step's masks -- or packs them when a step's masks come bare.  The masks CHANGE from step to step
+    here (another visibility threshold), so stale words would show in the trajectory."""
+    from gens_amd import ops
+    from tests.test_hip_ddp import _loss
+    runs = {}
+    for auto in (False, True):
+        model = _finetune_model(auto)
+        surf = model.implicit_surface
+        surf.auto_graph = auto
+        vols = [v.detach().clone().requires_grad_(True) for v in model.volumes]
+        feats = [f.detach().clone().requires_grad_(True) for f in model.features]
+        dims = [int(v.shape[-1]) for v in vols]
+        opt = torch.optim.Adam(list(surf.parameters()) + vols, lr=1e-3)
+        torch.manual_seed(2)
+        losses, seen = [], set()
+        for k in range(7):
+            ipts = _step_inputs(k)
+            with torch.no_grad():
+                _, masks = ops.volume_build([f.detach() for f in feats[:len(dims)]], ipts["intrs"], ipts["c2ws"], dims, min_vis_view=k % 3)
+            assert all(hasattr(m, "_gens_bits") for m in masks)
+            seen.add(tuple(int((m > 0).sum()) for m in masks))
+            if k == 4:
+                masks = [m.clone() for m in masks]             # a step whose masks come without their words
+            out = surf("train", ipts, vols, masks, feats, feats, 0.5, 1.0)
+            loss = _loss(out, ipts)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append((float(loss), 0.0))
+        assert len(seen) == 3
+        runs[auto] = (surf, losses, vols)
+    surf = runs[True][0]
+    assert surf._auto.stats["captured"] == 1 and surf._auto.stats["replayed"] == 5, surf._auto.stats
+    entry = next(e for e in surf._auto.entries.values() if e.state == "captured")
+    assert len(entry.mask_words) == len(runs[True][2])
+    _compare(runs[False][0], surf, runs[False][1], runs[True][1])
+    for a, b in zip(runs[False][2], runs[True][2]):
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(a.abs().max()), 1e-3)
+
+
 @pytest.mark.parametrize("auto", [False, True])
 def test_training_steps_leave_nothing_behind(auto):
     """Device memory and live autograd nodes after every step of the runner's loop: constant from the first step on (eager) / from the first
