@@ -683,6 +683,13 @@ def kernel_rows(table, top):
             rows[name]["algo_GBs"] = round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1)
         if k["ms"] > 0 and k.get("flops"):
             rows[name]["TFLOPs"] = round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1)
+        if name == "gens_blend_train_bwd" and "TFLOPs" in rows[name]:
+            from gens_amd.ops.base import kernels
+            ratio = getattr(kernels, "blend_bwd_round5_count_ratio", None)
+            if ratio:
+                rows[name]["TFLOPs_by_round5_count"] = round(rows[name]["TFLOPs"] * ratio, 1)
+                rows[name]["flops_note"] = ("TFLOPs counts the forward again + the reverse chain + [dW | db] = (2 F + 2 S sum m (k + 1)) per point; rounds 4 - 5 "
+                                            "counted 3 F for the chain (a third too much): TFLOPs_by_round5_count is the figure comparable with their 32 - 34")
     return rows
 
 

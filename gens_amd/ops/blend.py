@@ -219,6 +219,9 @@ class _BlendTrain(torch.autograd.Function):
         want_maps = any(ctx.needs_input_grad[3 + 23:])
         g_feat = e(n, s, f) if want_maps else None
         true_flops = (2 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n      # the forward again, the reverse chain, [dW | db]
+        # (round 5 counted 3 x the forward's products here -- the reverse chain is as long as the forward, not twice: its rate read 4/3 too high.
+        #  bench.py prints both; the ratio of the two counts for this shape:)
+        kernels.blend_bwd_round5_count_ratio = (3 * flops + 2 * s * sum(m * (k + 1) for m, k in zip(outs, ins))) * n / max(true_flops, 1)
         if 2 <= s <= 4 and kernels.blend_train_bwd == "transposed" and kernels.blend_train_wgrad == "inside" and n > 0:
             # the TRANSPOSED backward (k18t_blend_train.hip): a wave per 16 rows, the weights in LDS, one block of weight-gradient sums per wave
             lib = L.load()
