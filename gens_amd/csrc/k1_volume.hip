@@ -149,6 +149,7 @@ struct LevelConst {
     float rcw, rch;      // RN(1 / cw), RN(1 / ch)
     int log2d;
     int no_shortcut;     // (A/B switch GENS_K1_NO_EMPTY_SHORTCUT: tiles no view reaches take the general path too)
+    int pieces;          // 64-voxel pieces of its rows a workgroup of the frustum-culled kernel takes (1, 2 or 4; GENS_K1_PIECES: A/B)
 };
 
 template <bool PRESCALED>
@@ -273,7 +274,7 @@ typedef const uint32_t* k1b_uint_p;
 __device__ __forceinline__ k1b_float_p k1_const(const float* p) { return p; }
 #endif
 
-__device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4* __restrict__ feat, const float* __restrict__ w2c,
+__device__ __forceinline__ void volume_build_chunk(uint32_t group, const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                    const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc, int min_vis,
                                                    float* __restrict__ vol, float* __restrict__ mask, uint8_t* __restrict__ count,
                                                    uint32_t* __restrict__ bits = nullptr) {
@@ -284,11 +285,14 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     const bool tiled = lc.log2d >= 6;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t zq_bits = (uint32_t)lc.log2d - 6u;                              // (tiled) a row is 2^zq_bits pieces of 64 voxels
-    const uint32_t t_kz0 = (chunk & ((1u << zq_bits) - 1u)) << 6, t_jy = (chunk >> zq_bits) & dm, t_ix0 = (chunk >> (zq_bits + lc.log2d)) << 2;
+    // A workgroup takes lc.pieces CONSECUTIVE pieces of its four rows (all of them up to d = 256), one after the other: the frustum spans and the
+    // z-row-invariant halves of the projection below belong to the ROWS -- a workgroup per piece computed them once per piece (~170 dependent vector
+    // instructions and 28 loads on one wave in front of everything else: most of what a tile no view reaches costs, an eighth of the launch's
+    // instructions), and there are a quarter as many workgroups to start.
+    const uint32_t np = tiled ? (uint32_t)lc.pieces : 1u, chunk = group * np;       // (np is a power of two <= 2^zq_bits: the pieces share ix, jy)
+    const uint32_t t_jy = (chunk >> zq_bits) & dm, t_ix0 = (chunk >> (zq_bits + lc.log2d)) << 2;
     // within the tile a wave takes 16 z of all four rows (lane = 16 row + z): its footprints in a view then span ~30 pixels instead of ~90
     const uint32_t t_row = lane >> 4, t_z = (wv << 4) | (lane & 15u);
-    const uint32_t idx = tiled ? (((t_ix0 + t_row) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + t_z)) : chunk * 256u + threadIdx.x;
-    const int kz = (int)(idx & dm);                                             // (ix, jy: through row_pre)
     const int half = d >> 1;
     // ---- frustum culling per (z-row, view).  Along a z-row the homogeneous image coordinates (u, v, depth) are affine in z, so the
     // voxels of the row a view can see form ONE interval of kz.  Thread (row r, view v) of the workgroup intersects the five half-lines
@@ -303,7 +307,9 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // the same three roundings here as there, so the voxel's  (p + m[4 q + 2] z) + m[4 q + 3]  is bit for bit the four-term expression).  Nine vector
     // instructions per (voxel, view) become one broadcast 16-byte LDS read: the kernel is bound by its instruction stream (78 % VALU-busy).
     __shared__ float4 row_pre[32][K1_FAST_VIEWS];
-    int seen = 0;                                                                 // this thread's (row, view) pair has a span
+    __shared__ uint32_t piece_seen;                                               // bit p: some (row, view) span of the tile reaches piece p
+    if (threadIdx.x == 0) piece_seen = lc.no_shortcut ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
     {
         const int rows = tiled ? 4 : 256 >> lc.log2d;                             // z-rows the workgroup touches (d <= 256)
         const int r = threadIdx.x >> 3, v = threadIdx.x & 7;
@@ -340,11 +346,27 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
             span.y = min((int)ceilf(hi * (float)(d - 1)) + 2, d - 1);
             if (empty) span = make_int2(1, 0);
             row_span[r][v] = span;
-            seen = span.x <= span.y;
+            if (span.x <= span.y) {
+                const int kz_first = tiled ? (int)((chunk & ((1u << zq_bits) - 1u)) << 6) : 0;
+                uint32_t bits = 0u;
+                for (uint32_t p = 0; p < np; ++p) {
+                    const int lo_p = tiled ? kz_first + (int)(p << 6) : 0, hi_p = tiled ? lo_p + 63 : d - 1;
+                    bits |= (span.x <= hi_p && span.y >= lo_p) ? 1u << p : 0u;
+                }
+                if (bits) atomicOr(&piece_seen, bits);
+            }
         }
     }
-    // (the barrier that publishes the spans also tells every wave whether ANY (row, view) pair of the workgroup's tile has one)
-    if (!__syncthreads_or(seen | lc.no_shortcut)) {
+    __syncthreads();
+    const uint32_t seen_bits = piece_seen;
+    __shared__ float stage[9][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_count[256];
+#pragma unroll 1
+    for (uint32_t piece = 0; piece < np; ++piece) {
+    const uint32_t t_kz0 = ((chunk + piece) & ((1u << zq_bits) - 1u)) << 6;
+    const uint32_t idx = tiled ? (((t_ix0 + t_row) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + t_z)) : chunk * 256u + threadIdx.x;
+    const int kz = (int)(idx & dm);                                             // (ix, jy: through row_pre)
+    if (!((seen_bits >> piece) & 1u)) {
         // No view reaches any voxel of the tile -- more than half of the tiles at the benchmark geometry (five 31 x 23 degree frusta
         // cover a third of the cube): mean = var = mask = count = +0, exactly what the general path computes for cnt = 0
         // (div_rn(0, 1e-8, y) = +0, 0 - 0 * 0 = +0), stored straight from registers: no view loop, no divisions, no staging,
@@ -367,7 +389,7 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
         }
         if (bits && wave == 2 && q < 8u)                                           // (the mask as bits, see below: this tile's eight words)
             bits[tiled ? (((((t_ix0 + (q >> 1)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | t_kz0) >> 5) + (q & 1u)) : chunk * 8u + q] = 0u;
-        return;
+        continue;
     }
     const int my_row = tiled ? (int)t_row : (int)(threadIdx.x >> lc.log2d);
     // torch.linspace(-1, 1, d)[i]: lower half counts up from the start, upper half down from the end
@@ -455,8 +477,6 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
     // instruction carries 16 B per lane (one plane's 1 KiB per wave-store: 9 store instructions per workgroup instead of 36 -- the
     // texture path of a CU was busy 72 % of the kernel with 4-byte stores); streaming (non-temporal), so that the 36 B / voxel do not
     // sweep the texels out of L2; through buffer descriptors (lane offset in 32 bits; d^3 <= 2^24 voxels: 8 planes are 512 MiB).
-    __shared__ float stage[9][256];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_count[256];
     const int tid = threadIdx.x;
     const int slot = tiled ? (int)(t_row * 64u + t_z) : tid;                        // position in the workgroup's tile: row-piece, then z
     stage[0][slot] = mm.x;
@@ -486,7 +506,10 @@ __device__ __forceinline__ void volume_build_chunk(uint32_t chunk, const float4*
         const uint32_t at = tiled ? (((t_ix0 + (q >> 2)) << (2 * lc.log2d)) | (t_jy << lc.log2d) | (t_kz0 + ((q & 3u) << 4))) : chunk * 256u + q * 16u;
         *(u4*)(count + at) = *(const u4*)&stage_count[16u * q];
     }
+    if (piece + 1u < np) __syncthreads();                                         // (the staging rows are written again by the next piece with work)
+    }
 }
+
 
 // All levels of a scene in ONE launch: the small levels (a few hundred workgroups, latency-bound on their own: 28 + 10 us for
 // 128^3 + 64^3) run in the shadow of the large one.  Blocks [first[l], first[l + 1]) belong to level l.
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(256) void volume_warm_texels_k(VolumeLevels lv, int
     if (acc == 1.2345678e-31f) lv.mask[0][0] = acc;                                 // (never)
 }
 
-__global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis, uint32_t warm_blocks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void volume_build_fwd_levels_k(VolumeLevels lv, const float* __restrict__ w2c, int nv, int min_vis, uint32_t warm_blocks,
                                                                  uint32_t groups) {
     float warm = 0.0f;
     if (blockIdx.x < warm_blocks) warm = k1_warm_texels(lv, nv);
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(256) void volume_build_fwd_levels_k(VolumeLevels lv
     if (warm == 1.2345678e-31f) lv.mask[0][0] = warm;                              // (never: the warm-up loads have to be loads of something)
 }
 
-__global__ __launch_bounds__(256) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void volume_build_fwd_lean_k(const float4* __restrict__ feat, const float* __restrict__ w2c,
                                                                const float* __restrict__ intr, int nv, int h, int w, int d, LevelConst lc,
                                                                int min_vis, float* __restrict__ vol, float* __restrict__ mask,
                                                                uint8_t* __restrict__ count) {
@@ -728,6 +751,8 @@ static LevelConst level_const(int h, int w, int d) {      // the float32 operati
     lc.log2d = 0;
     while ((1 << lc.log2d) < d) ++lc.log2d;
     lc.no_shortcut = getenv("GENS_K1_NO_EMPTY_SHORTCUT") != nullptr;
+    const int want = getenv("GENS_K1_PIECES") ? atoi(getenv("GENS_K1_PIECES")) : 4;
+    lc.pieces = d >= 256 && want >= 4 ? 4 : d >= 128 && want >= 2 ? 2 : 1;
     return lc;
 }
 
@@ -740,7 +765,7 @@ static int volume_build_fwd_level(const float* feat, const float* w2c, const flo
     if (pow2 && !getenv("GENS_K1_GENERIC")) {                 // (the environment switch keeps the generic kernel reachable for A/B tests)
         const LevelConst lc = level_const(h, w, d);
         if (d >= 8 && nv <= K1_FAST_VIEWS && intr_scale == 1.0f && !getenv("GENS_K1_SINGLE")) {   // production path (the switch keeps the previous kernel reachable for A/B runs)
-            volume_build_fwd_lean_k<<<(unsigned)(n / 256), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
+            volume_build_fwd_lean_k<<<(unsigned)(n / 256 / lc.pieces), 256, 0, (hipStream_t)stream>>>((const float4*)feat, w2c, intr, nv, h, w, d, lc,
                                                                                      min_vis_view, volume, mask, count);
             return gens_launch_status("gens_volume_build_fwd");
         }
@@ -804,7 +829,7 @@ extern "C" int gens_volume_build_levels_bits(const float* const* feat, const int
         lv.w[l] = hw[2 * l + 1];
         lv.d[l] = d;
         lv.lc[l] = level_const(hw[2 * l], hw[2 * l + 1], d);
-        lv.first[l + 1] = lv.first[l] + (uint32_t)(((int64_t)d * d * d) / 256);
+        lv.first[l + 1] = lv.first[l] + (uint32_t)(((int64_t)d * d * d) / 256 / lv.lc[l].pieces);
     }
     // the texel warm-up (k1_warm_texels): enough leading workgroups to ask for every 128-byte line of the tables once; GENS_K1_WARM=0 switches it off
     // (A/B runs: scripts/probe/k1_instep_probe.py)
