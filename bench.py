@@ -642,8 +642,10 @@ def main():
                 "ratio_to_headline_ms": round(default_path["render_ms"] / headline_ms, 4),
                 "what": "GenS(has_vol).forward('val', ipts) as runner.py:215 calls it, nothing set on the model from outside; item_ms = the whole item "
                         "incl. the mesh the reference's validate always extracts (512^3 lattice + marching cubes = geometry_ms, wall time taken inside "
-                        "validate), render_ms = item_ms - geometry_ms = the headline's render without K1 (~0.26 ms; the volumes of a has_vol model are "
-                        "parameters)"})
+                        "validate), render_ms = the image's part of the same call, timed inside validate from the end of the mesh's read-back to the image "
+                        "on the host = the headline's step without K1 (~0.2 ms; the volumes of a has_vol model are parameters), rest_ms = what "
+                        "GenS.forward does around validate on the host (scene set-up, the mesh into world space, the outputs); render_alone_ms = "
+                        "validate() called directly with the geometry off"})
         except Exception as e:
             default_path = {"error": f"{type(e).__name__}: {e}"}
 

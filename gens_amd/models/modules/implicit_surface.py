@@ -646,6 +646,8 @@ class ImplicitSurface(nn.Module):
             self.last_geometry_s = time.perf_counter() - t_geo     # (ends with the mesh's read-back: wall time is the item's share; bench.py's default_path)
         # one (P, 8) device buffer [rgb | normal | sdf_depth | render_depth] filled chunk by chunk: ONE D2H copy per image
         # into a pinned host buffer (the reference copies 4 tensors per 256-ray chunk, implicit_surface.py:446-453)
+        import time as _time
+        t_render = _time.perf_counter()                 # (the image's share of the call, as last_geometry_s is the mesh's: bench.py's default_path)
         image = torch.empty(r1 - r0, 8, device=rays_o.device, dtype=torch.float32)
 
         def render_image():
@@ -704,6 +706,7 @@ class ImplicitSurface(nn.Module):
         outputs["normal_img"] = flat[6 * p_:9 * p_].reshape([height, width, 3])
         outputs["sdf_depth"] = flat[9 * p_:10 * p_].reshape([height, width])
         outputs["render_depth"] = flat[10 * p_:11 * p_].reshape([height, width])
+        self.last_render_s = _time.perf_counter() - t_render
         return outputs
 
     def val_chunk_for(self, n_rays):
