@@ -429,32 +429,47 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // lane group 1 the image besides.  The texel loads of tile t + 1 are issued in the middle of tile t's reverse pass and used one phase into tile
     // t + 1: a global load takes 2 - 3 us here, 5 000 - 7 000 cycles of a 45 000-cycle tile when it is waited for.
     // slot A: the lane group's own level 0..3; slot B: level 4 (group 0) / the image (group 1); weights zero where a tap is outside the map
+// The look-up of one tile, WITHOUT a branch: lane (kq, n) reads feature level kq of row n into qa (levels 0 .. 3) and, kq = 0, level 4 / kq = 1, the image
+// into qb.  Every lane projects into ITS level only -- the level's constants picked per lane out of the scalar table -- and the mask term "inside every
+// level" is the four lanes' terms combined by one lane-group sum.  (The first form walked the levels one after the other with every lane projecting into
+// all of them and the quarter of the lanes that owns a level reading under an exec mask: six divergent regions of ~60 instructions in the middle of
+// the reverse pass, 42 of the launch's 347 us.)  Lanes without a level (kq >= NLEV; kq >= 2 for qb) read level 0 at weight 0.
+#define KT_SEL4(a0, a1, a2, a3) (kqg_ == 0 ? (a0) : kqg_ == 1 ? (a1) : kqg_ == 2 ? (a2) : (a3))
+#define KT_LV(field, l) (kp->fs.field[(l) < NLEV ? (l) : 0])
+#define KT_TAPS(q_, w_out_, p_, h_, w_, base_, on_)                                                                                \
+    {                                                                                                                              \
+        const Taps2 t_ = bilinear_taps((p_).ix, (p_).iy, h_, w_);                                                                  \
+        const int x0_ = min(max(t_.x0, 0), (w_) - 1), x1_ = min(max(t_.x0 + 1, 0), (w_) - 1);                                      \
+        const int y0_ = min(max(t_.y0, 0), (h_) - 1), y1_ = min(max(t_.y0 + 1, 0), (h_) - 1);                                      \
+        const f32x4* r0_ = (base_) + ((int64_t)sv * (h_) + y0_) * (w_), * r1_ = (base_) + ((int64_t)sv * (h_) + y1_) * (w_);       \
+        q_[0] = r0_[x0_]; q_[1] = r0_[x1_]; q_[2] = r1_[x0_]; q_[3] = r1_[x1_];                                                    \
+        w_out_[0] = (on_) && t_.ok00 ? t_.w00 : 0.0f; w_out_[1] = (on_) && t_.ok01 ? t_.w01 : 0.0f;                                \
+        w_out_[2] = (on_) && t_.ok10 ? t_.w10 : 0.0f; w_out_[3] = (on_) && t_.ok11 ? t_.w11 : 0.0f;                                \
+    }
 #define KT_GATHER(P_, LIVE_, qa_, qb_, wa_, wb_, inside_)                                                                          \
     {                                                                                                                              \
-        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { qa_[k_] = kt_splat(0.0f); qb_[k_] = kt_splat(0.0f); wa_[k_] = 0.0f; wb_[k_] = 0.0f; } \
-        inside_ = true;                                                                                                            \
+        /* (the level constants a lane picks do not change from tile to tile: an opaque copy of kq keeps them from being hoisted out of the    \
+            tile loop, where they would hold twenty of the wave's registers for the whole launch) */                                      \
+        int kqg_ = kq;                                                                                                             \
+        asm volatile("" : "+v"(kqg_));                                                                                             \
         const SrcBase pb_ = project_src_base(kp->w2c + 16 * sv, kp->intr + 16 * sv, (P_).x, (P_).y, (P_).z);                      \
-        _Pragma("unroll") for (int l_ = 0; l_ < NLEV; ++l_) {                                                                      \
-            const int h_ = kp->fs.h[l_], w_ = kp->fs.w[l_];                                                                        \
-            const SrcProj p_ = project_src_level(pb_, exp2f(-(float)l_), h_, w_, kp->fs.cw[l_], kp->fs.ch[l_], kp->fs.rcw[l_], kp->fs.rch[l_]); \
-            inside_ = inside_ && p_.inside;                                                                                        \
-            const bool img_ = l_ == 0 && kq == 1;                                                                                  \
-            if ((kq == (l_ & 3) || img_) && (LIVE_)) {                                                                             \
-                const Taps2 t_ = bilinear_taps(p_.ix, p_.iy, h_, w_);                                                              \
-                const int x0_ = min(max(t_.x0, 0), w_ - 1), x1_ = min(max(t_.x0 + 1, 0), w_ - 1);                                  \
-                const int y0_ = min(max(t_.y0, 0), h_ - 1), y1_ = min(max(t_.y0 + 1, 0), h_ - 1);                                  \
-                const float w00_ = t_.ok00 ? t_.w00 : 0.0f, w01_ = t_.ok01 ? t_.w01 : 0.0f, w10_ = t_.ok10 ? t_.w10 : 0.0f, w11_ = t_.ok11 ? t_.w11 : 0.0f; \
-                if (kq == (l_ & 3)) {                                                                                              \
-                    const f32x4* r0_ = (const f32x4*)kp->fs.data[l_] + ((int64_t)sv * h_ + y0_) * w_, * r1_ = (const f32x4*)kp->fs.data[l_] + ((int64_t)sv * h_ + y1_) * w_; \
-                    if (l_ < 4) { qa_[0] = r0_[x0_]; qa_[1] = r0_[x1_]; qa_[2] = r1_[x0_]; qa_[3] = r1_[x1_]; wa_[0] = w00_; wa_[1] = w01_; wa_[2] = w10_; wa_[3] = w11_; } \
-                    else { qb_[0] = r0_[x0_]; qb_[1] = r0_[x1_]; qb_[2] = r1_[x0_]; qb_[3] = r1_[x1_]; wb_[0] = w00_; wb_[1] = w01_; wb_[2] = w10_; wb_[3] = w11_; } \
-                }                                                                                                                  \
-                if (img_) {                                                                                                        \
-                    const f32x4* r0_ = (const f32x4*)kp->imgs + ((int64_t)sv * h_ + y0_) * w_, * r1_ = (const f32x4*)kp->imgs + ((int64_t)sv * h_ + y1_) * w_; \
-                    qb_[0] = r0_[x0_]; qb_[1] = r0_[x1_]; qb_[2] = r1_[x0_]; qb_[3] = r1_[x1_]; wb_[0] = w00_; wb_[1] = w01_; wb_[2] = w10_; wb_[3] = w11_; \
-                }                                                                                                                  \
-            }                                                                                                                      \
-        }                                                                                                                          \
+        const int ha_ = KT_SEL4(KT_LV(h, 0), KT_LV(h, 1), KT_LV(h, 2), KT_LV(h, 3)), wd_a_ = KT_SEL4(KT_LV(w, 0), KT_LV(w, 1), KT_LV(w, 2), KT_LV(w, 3)); \
+        const float cwa_ = KT_SEL4(KT_LV(cw, 0), KT_LV(cw, 1), KT_LV(cw, 2), KT_LV(cw, 3)), cha_ = KT_SEL4(KT_LV(ch, 0), KT_LV(ch, 1), KT_LV(ch, 2), KT_LV(ch, 3)); \
+        const float rcwa_ = KT_SEL4(KT_LV(rcw, 0), KT_LV(rcw, 1), KT_LV(rcw, 2), KT_LV(rcw, 3)), rcha_ = KT_SEL4(KT_LV(rch, 0), KT_LV(rch, 1), KT_LV(rch, 2), KT_LV(rch, 3)); \
+        const f32x4* da_ = (const f32x4*)KT_SEL4(KT_LV(data, 0), KT_LV(data, 1), KT_LV(data, 2), KT_LV(data, 3));                  \
+        const bool has_a_ = kqg_ < NLEV;                                                                                           \
+        const SrcProj pa_ = project_src_level(pb_, KT_SEL4(1.0f, 0.5f, 0.25f, 0.125f), ha_, wd_a_, cwa_, cha_, rcwa_, rcha_);      \
+        KT_TAPS(qa_, wa_, pa_, ha_, wd_a_, da_, has_a_ && (LIVE_))                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        const bool b4_ = NLEV > 4 && kqg_ == 0;                                                                                    \
+        const int hb_ = b4_ ? KT_LV(h, 4) : KT_LV(h, 0), wd_b_ = b4_ ? KT_LV(w, 4) : KT_LV(w, 0);                                   \
+        const float cwb_ = b4_ ? KT_LV(cw, 4) : KT_LV(cw, 0), chb_ = b4_ ? KT_LV(ch, 4) : KT_LV(ch, 0);                             \
+        const float rcwb_ = b4_ ? KT_LV(rcw, 4) : KT_LV(rcw, 0), rchb_ = b4_ ? KT_LV(rch, 4) : KT_LV(rch, 0);                       \
+        const f32x4* db_ = b4_ ? (const f32x4*)KT_LV(data, 4) : (const f32x4*)kp->imgs;                                            \
+        const SrcProj pq_ = project_src_level(pb_, b4_ ? 0.0625f : 1.0f, hb_, wd_b_, cwb_, chb_, rcwb_, rchb_);                    \
+        KT_TAPS(qb_, wb_, pq_, hb_, wd_b_, db_, (b4_ || kqg_ == 1) && (LIVE_))                                                     \
+        const float out_ = ((has_a_ && !pa_.inside) ? 1.0f : 0.0f) + ((b4_ && !pq_.inside) ? 1.0f : 0.0f);                         \
+        inside_ = kt_qsum(out_) == 0.0f;                                                                                           \
     }
     int64_t tile = (int64_t)blockIdx.x * KT_WAVES + wave;
     int64_t src_cur = KT_SRC(tile), src_n1 = KT_SRC(tile + stride);
@@ -798,7 +813,12 @@ __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         f32x4 qa_n[4], qb_n[4];
         float wa_n[4], wb_n[4];
         bool inside_n;
+#ifdef GENS_K18T_NO_GATHER      // (timing probe, WRONG results: what does the next tile's look-up cost inside the reverse pass?)
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { qa_n[k_] = qa[k_]; qb_n[k_] = qb[k_]; wa_n[k_] = wa[k_]; wb_n[k_] = wb[k_]; }
+        inside_n = inside;
+#else
         KT_GATHER(P_n1, src_n1 >= 0, qa_n, qb_n, wa_n, wb_n, inside_n)
+#endif
         // mean = sum_v w x, var = sum_v w (x - mean)^2 (shared by the views of a point)
         f32x4 GX[XT];
         {
