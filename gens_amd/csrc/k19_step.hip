@@ -337,6 +337,58 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_points_write_k(const uint8_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// views taken out of several per-scene maps in ONE launch (fine-tuning: `self.features[i][view_ids]`, gens.py:151-153, and the same selection of the
+// maps' texel / warp layouts): dst[k][j] = src[k][index[j]] for every map k, a map's view being `floats[k]` contiguous floats (a multiple of 4,
+// 16-byte aligned).  torch.index_select per map was eleven launches at ~1 TB/s.
+// ---------------------------------------------------------------------------------------------------------------
+#define GENS_MAX_SELECT 16
+struct ViewSelect {
+    const float4* src[GENS_MAX_SELECT];
+    float4* dst[GENS_MAX_SELECT];
+    int64_t quads[GENS_MAX_SELECT];          // float4s per view
+    int n_views[GENS_MAX_SELECT];            // views the source holds (index range check)
+    int n_maps, n_sel;
+};
+__global__ __launch_bounds__(256) void select_views_k(ViewSelect S, const int64_t* __restrict__ index) {
+    const int k = blockIdx.y;
+    if (k >= S.n_maps) return;
+    const int64_t q = S.quads[k], total = q * S.n_sel;
+    const float4* __restrict__ src = S.src[k];
+    float4* __restrict__ dst = S.dst[k];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t j = i / q, r = i - j * q;
+        int64_t v = index[j];
+        v = v < 0 ? v + S.n_views[k] : v;                                             // (torch's negative indices)
+        if (v < 0 || v >= S.n_views[k]) continue;                                     // (an index torch would have refused: the view is left as it is)
+        dst[i] = src[v * q + r];
+    }
+}
+
+extern "C" int gens_select_views(const float* const* src, float* const* dst, const int* floats_per_view, const int* views_in_src, int n_maps,
+                                 const int64_t* index, int n_sel, void* stream) {
+    GENS_CHECK_ARG(src && dst && floats_per_view && views_in_src && index, GENS_EINVAL, "gens_select_views: null pointer");
+    GENS_CHECK_ARG(n_maps >= 1 && n_maps <= GENS_MAX_SELECT && n_sel >= 0, GENS_ELIMIT, "gens_select_views: %d maps (1..%d), %d views", n_maps, GENS_MAX_SELECT, n_sel);
+    if (n_sel == 0) return 0;
+    ViewSelect S = {};
+    S.n_maps = n_maps;
+    S.n_sel = n_sel;
+    int64_t most = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        GENS_CHECK_ARG(src[k] && dst[k] && floats_per_view[k] > 0 && (floats_per_view[k] & 3) == 0 && views_in_src[k] > 0, GENS_EINVAL,
+                       "gens_select_views: map %d: null, empty or a view that is not a multiple of four floats", k);
+        GENS_CHECK_ARG((((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15) == 0, GENS_EINVAL, "gens_select_views: map %d is not 16-byte aligned", k);
+        S.src[k] = (const float4*)src[k];
+        S.dst[k] = (float4*)dst[k];
+        S.quads[k] = floats_per_view[k] >> 2;
+        S.n_views[k] = views_in_src[k];
+        most = std::max<int64_t>(most, S.quads[k] * n_sel);
+    }
+    const dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 4096), (unsigned)n_maps);
+    select_views_k<<<grid, 256, 0, (hipStream_t)stream>>>(S, index);
+    return gens_launch_status("gens_select_views");
+}
+
 extern "C" int64_t gens_compact_points_scratch(int64_t n) { return 4 * ((n + CP_ROWS - 1) / CP_ROWS + 1); }      // int32 / float words
 
 extern "C" int gens_compact_points(const uint8_t* valid, int64_t n_rays_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,

@@ -90,6 +90,7 @@ SIGNATURES = {
     "gens_patch_sample_bwd": [_p, _i, _i, _i, _p, _p, _l, _p, _p],
     "gens_upsample2d_into": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "gens_upsample2d_cat": [_pp, _ip, _i, _i, _p, _i, _i, _i, _p],
+    "gens_select_views": [_pp, _pp, _ip, _ip, _i, _p, _i, _p],
     "gens_tv_fwd": [_p, _p, _i, _i, _i, _p, _p],
     "gens_tv_bwd": [_p, _p, _i, _i, _i, _f, _p, _p],
     "gens_tv_bwd_scaled": [_p, _p, _i, _i, _i, _f, _p, _p, _p],

@@ -53,7 +53,7 @@ const char* gens_last_error(void);
  *   11 = round 6: gens_blend_train_bwd_t + gens_blend_train_t_parts + gens_blend_train_bwd_t_dump (the colour branch's backward transposed: one
  *       wave per 16 rows, nothing shared between waves but the weights in LDS).
  *   12 = round 6: gens_upsample2d_cat (the warp features in one launch), gens_volume_build_levels_bits (the volume build leaves the masks as bits
- *       too). */
+ *       too), gens_select_views (the views of a fine-tune step out of the frozen maps and their layouts in one launch). */
 int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -770,6 +770,12 @@ int64_t gens_scene_cams_floats(int nv);
 int gens_scene_setup(const float* c2ws, const float* intrs, int nv, float* cams, void* stream);
 int gens_pack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
 int gens_unpack_maps(const float* const* src, float* const* dst, const int* nchw, int n_maps, void* stream);
+/* Views taken out of up to 16 per-scene maps in one launch (ABI 12): dst[k][j] = src[k][index[j]], j < n_sel, where a view of map k is
+ * floats_per_view[k] contiguous floats (a multiple of 4; both sides 16-byte aligned) and src[k] holds views_in_src[k] of them; index: n_sel int64 on the
+ * DEVICE (negative values count from the end, as torch's).  What fine-tuning's `self.features[i][view_ids]` (gens.py:151-153) does to the frozen
+ * pyramid -- here for the maps and their texel / warp layouts together. */
+int gens_select_views(const float* const* src, float* const* dst, const int* floats_per_view, const int* views_in_src, int n_maps,
+                      const int64_t* index, int n_sel, void* stream);
 int64_t gens_compact_points_scratch(int64_t n);   /* 4-byte words of scratch for n rows */
 int gens_compact_points(const uint8_t* valid, int64_t n_ray_pts, int64_t n_always, int64_t n, int64_t* idx, int32_t* counts,
                         float* y_fill, float* g_fill, float* s_fill, float* rgb_fill, uint8_t* vis_fill, int n_src, const float* z,

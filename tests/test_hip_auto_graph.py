@@ -203,6 +203,32 @@ def test_render_alone_is_captured_when_it_is_called_directly():
     assert ops is not None
 
 
+def test_the_views_of_a_step_come_out_of_the_frozen_maps_and_their_layouts_in_one_launch():
+    """GenS._select_frozen_views against torch.index_select on every frozen map and on the cached texel / warp layouts, bit for bit, for permuted
+    subsets of the views and a repeated one; one gens_select_views launch, no index_select."""
+    from gens_amd import lib as L, ops
+    from gens_amd.ops.base import pack_maps
+    model = _finetune_model(False)
+    feats = list(model.features)
+    nv = feats[0].shape[0]
+    for ids in ([2, 0, 1][:nv], [nv - 1, 0], [1, 1, 0]):
+        index = torch.tensor(ids, dtype=torch.long, device="cuda")
+        L.profile_begin()
+        got = model._select_frozen_views(index)
+        names = [name for name, _, _, _ in L.profile_end(raw=True)]
+        assert names.count("gens_select_views") == 1, names
+        full = pack_maps(feats)
+        for f, g, t in zip(feats, got, full):
+            assert torch.equal(g, f.index_select(0, index))
+            ver, _, tex = g._gens_tex
+            assert ver == g._version and torch.equal(tex, t.index_select(0, index))
+        if len(feats) >= 3:
+            warp_full, channels = ops.build_warp_features(feats[:3])
+            key, kept, (warp, ch) = got[0]._gens_warp
+            assert ch == channels and torch.equal(warp, warp_full.index_select(0, index))
+            assert key == tuple((id(f), f._version) for f in got[:3]) and all(a is b for a, b in zip(kept, got[1:3]))
+
+
 def test_masks_that_arrive_with_their_bits_keep_them_through_a_captured_step():
     """The volume build hands out its masks with their bit-packed copies (ops.volume_build -> `_gens_bits`): the captured step holds no packing launch,
     every replay copies the step's words beside the step's masks -- or packs them when a step's masks come bare.  The masks CHANGE from step to step
