@@ -179,7 +179,7 @@ class GenS(nn.Module):
         from .. import ops
         from ..ops.base import kernels, pack_maps
         feats = list(self.features)
-        if (not kernels.tex_cache or not feats or feats[0].device.type != "cuda" or any(f.requires_grad or f.dtype != torch.float32 for f in feats)
+        if (not kernels.tex_cache or not kernels.select_views or not feats or feats[0].device.type != "cuda" or any(f.requires_grad or f.dtype != torch.float32 for f in feats)
                 or index.dtype != torch.long or any((f[0].numel() & 3) or not f.is_contiguous() for f in feats)):
             features = [f.index_select(0, index) for f in feats]
             self._seed_frozen_layouts(features, index)

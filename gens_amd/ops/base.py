@@ -27,7 +27,8 @@ class KernelChoice:
                                32-row workgroups; always for other view counts)
         sdf_grad_f16           True: under sdf_precision "f16x2" the value + gradient pass runs on the split-half kernel too (k6gh) | False: float32
         k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
-        tex_cache              texel copies kept on the map tensors (pack_maps)"""
+        tex_cache              texel copies kept on the map tensors (pack_maps)
+        select_views           fine-tuning takes a step's views out of the frozen maps and their layouts in one launch (gens_select_views) | torch.index_select"""
 
     def __init__(self, env=os.environ):
         self.sdf_value = "rowmajor" if env.get("GENS_SDF_VALUE_ROWMAJOR") else "transposed"
@@ -39,6 +40,7 @@ class KernelChoice:
         self.blend_train_bwd = "rowmajor" if env.get("GENS_BLEND_TRAIN_BWD_ROWMAJOR") or env.get("GENS_K18_OPERAND_ROWS") else "transposed"
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
+        self.select_views = not env.get("GENS_NO_SELECT_VIEWS")
 
 
 kernels = KernelChoice()
