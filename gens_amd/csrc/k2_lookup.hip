@@ -337,6 +337,302 @@ static void launch_lookup_scatter(int layout, const LevelSet& vs, const float* p
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The scatter by BRICKS (round 6; gens_lookup_volume_bwd_bricks / _bwd2_bricks, caller's scratch).
+//
+// The scatter above sends one float atomic per (point, level, corner, channel) -- 96 per point at three levels -- and runs at 24 - 47 G atomics/s
+// depending on how the caller ordered its points (profiles/r06_k2_bwd_order_probe.txt): 2 - 4 ms per million points.  Here the points are first
+// counted into bricks of 8 x 8 x 8 cells of the FINEST level (a counting sort: key, histogram, scan, fill -- four small launches), and a workgroup per
+// brick then walks the levels: the brick's points can only touch a tile of <= 12^3 voxels of a level (<= 9^3 of the finest), the tile's sums live in
+// LDS as DOUBLES (ds_add_f64 costs 18 cycles per wave instruction, ds_add_f32 193: lds_atomic_probe.py), 32 lanes per point = (corner, channel), and
+// every touched voxel of the tile goes to memory ONCE, z-contiguous lanes on consecutive floats.  A corner that falls outside its brick's tile (points
+// far outside the cube, float rounding at a tile's edge) takes the direct atomic.  The sums are those of the direct scatter in another order (double
+// partial sums: closer to the exact value); NaN / infinity propagate.
+// ---------------------------------------------------------------------------------------------------------------
+#define BR_NB 32                 // bricks per axis at most
+#define BR_MAX (BR_NB * BR_NB * BR_NB)
+#define BR_EXT 10                // tile extent per axis at most (the finest level's is 9: eight cells and the + 1 neighbour)
+#define BR_TILE (BR_EXT * BR_EXT * BR_EXT * 4)
+#define BR_SEG 512               // points per work item
+struct BrickPlan {
+    int fine;                    // the level the bricks are cut from (the one with the most voxels)
+    int nb[3];                   // bricks per axis
+    uint32_t n_bricks;
+    uint32_t* count;             // [n_bricks + 1]   (zeroed per call)
+    uint32_t* offset;            // [n_bricks + 1]
+    uint32_t* order;             // [n] point indices, brick by brick
+    uint32_t* key;               // [n] a point's brick and
+    uint32_t* rank;              // [n] its rank among the brick's points (what the counting atomic returned: the fill needs no second one)
+    uint2* items;                // work items (brick, segment of <= BR_SEG of its points): a crowded brick is many workgroups' work
+    uint32_t* n_items;
+    uint32_t max_items;
+};
+__device__ __forceinline__ uint32_t brick_of(const LevelSet& vs, const BrickPlan& P, const float* __restrict__ pts, int64_t i) {
+    const int size[3] = {vs.dx[P.fine], vs.dy[P.fine], vs.dz[P.fine]};
+    uint32_t b[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const Cell c = axis_cell(pts[3 * i + ax], size[ax]);
+        const int cell = min(max(c.i0, 0), size[ax] - 1);                        // (NaN: axis_cell leaves i0 finite -- (int) of a clamped float)
+        b[ax] = (uint32_t)min(cell >> 3, P.nb[ax] - 1);
+    }
+    return (b[0] * (uint32_t)P.nb[1] + b[1]) * (uint32_t)P.nb[2] + b[2];
+}
+__global__ __launch_bounds__(256) void brick_zero_k(uint32_t* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void brick_count_k(LevelSet vs, BrickPlan P, const float* __restrict__ pts, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const uint32_t b = brick_of(vs, P, pts, i);
+        P.key[i] = b;
+        P.rank[i] = atomicAdd(P.count + b, 1u);
+    }
+}
+__global__ __launch_bounds__(1024) void brick_scan_k(BrickPlan P) {
+    __shared__ uint32_t part[1024], part_i[1024];
+    const uint32_t tid = threadIdx.x, per = (P.n_bricks + 1023u) / 1024u;
+    const uint32_t lo = min(tid * per, P.n_bricks), hi = min(lo + per, P.n_bricks);
+    // (a thread's bins through 16-byte loads where its range allows: 32 dependent 4-byte loads per thread were 70 us of a 1 ms call)
+    auto segs = [](uint32_t k) { return (k + BR_SEG - 1u) / BR_SEG; };
+    uint32_t c = 0, it = 0;
+    const bool quads = (per & 3u) == 0u && hi - lo == per && ((uintptr_t)(P.count + lo) & 15) == 0;
+    if (quads) {
+#pragma unroll 8
+        for (uint32_t b = lo; b < hi; b += 4u) {
+            const uint4 q = *(const uint4*)(P.count + b);
+            c += (q.x + q.y) + (q.z + q.w);
+            it += (segs(q.x) + segs(q.y)) + (segs(q.z) + segs(q.w));
+        }
+    } else {
+        for (uint32_t b = lo; b < hi; ++b) {
+            c += P.count[b];
+            it += segs(P.count[b]);
+        }
+    }
+    part[tid] = c;
+    part_i[tid] = it;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                                      // (inclusive scans of the 1 024 partial sums)
+        const uint32_t add = tid >= d ? part[tid - d] : 0u, add_i = tid >= d ? part_i[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        part_i[tid] += add_i;
+        __syncthreads();
+    }
+    if (tid == 1023u) {
+        P.offset[P.n_bricks] = part[1023];
+        *P.n_items = min(part_i[1023], P.max_items);
+    }
+    c = part[tid] - c;                                                              // exclusive
+    it = part_i[tid] - it;
+    auto emit = [&](uint32_t b, uint32_t k) {
+        for (uint32_t sg = 0; sg * BR_SEG < k; ++sg, ++it)
+            if (it < P.max_items) P.items[it] = make_uint2(b, sg);
+    };
+    if (quads) {
+#pragma unroll 4
+        for (uint32_t b = lo; b < hi; b += 4u) {
+            const uint4 q = *(const uint4*)(P.count + b);
+            const uint4 o = make_uint4(c, c + q.x, c + q.x + q.y, c + q.x + q.y + q.z);
+            *(uint4*)(P.offset + b) = o;
+            c = o.w + q.w;
+            emit(b, q.x); emit(b + 1u, q.y); emit(b + 2u, q.z); emit(b + 3u, q.w);
+        }
+    } else {
+        for (uint32_t b = lo; b < hi; ++b) {
+            const uint32_t k = P.count[b];
+            P.offset[b] = c;
+            c += k;
+            emit(b, k);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void brick_fill_k(BrickPlan P, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) P.order[P.offset[P.key[i]] + P.rank[i]] = (uint32_t)i;
+}
+
+#define BR_STAGE 64              // points of an item staged in LDS at a time (their coordinates and every level's cotangent: one round of gathers)
+template <int LAYOUT, bool SECOND>
+__global__ __launch_bounds__(256) void lookup_scatter_bricks_k(LevelSet vs, BrickPlan P, const float* __restrict__ pts, const float4* __restrict__ g_out,
+                                                               const float* __restrict__ gg_pts) {
+    __shared__ double tile[BR_TILE];
+    __shared__ float sp[BR_STAGE][3], se[BR_STAGE][3];
+    __shared__ float4 sg[BR_STAGE][GENS_MAX_LEVELS];
+    if (blockIdx.x >= *P.n_items) return;
+    const uint2 item = P.items[blockIdx.x];
+    const uint32_t brick = item.x, first = P.offset[brick] + item.y * BR_SEG, cnt = min((uint32_t)BR_SEG, P.offset[brick + 1] - first);
+    const int tid = threadIdx.x, slot = tid >> 5, sub = tid & 31;
+    const int ch = sub & 3, c = (sub >> 2) & 1, b = (sub >> 3) & 1, a = sub >> 4;
+    const uint32_t bz = brick % (uint32_t)P.nb[2], by = (brick / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1], bx = brick / (uint32_t)(P.nb[1] * P.nb[2]);
+    const int fine[3] = {vs.dx[P.fine], vs.dy[P.fine], vs.dz[P.fine]};
+    const uint32_t bc[3] = {bx, by, bz};
+    // one round of gathers for a chunk of the item's points: a thread per (point, level) for the cotangents, the level-0 threads for the coordinates
+    auto stage = [&](uint32_t base, int staged) {
+        for (int k = tid; k < staged * vs.n; k += 256) {
+            const int p = k / vs.n, l = k - p * vs.n;
+            const int64_t i = (int64_t)P.order[first + base + (uint32_t)p];
+            sg[p][l] = g_out[i * vs.n + l];
+            if (l == 0) {
+                sp[p][0] = pts[3 * i]; sp[p][1] = pts[3 * i + 1]; sp[p][2] = pts[3 * i + 2];
+                if (SECOND) { se[p][0] = gg_pts[3 * i]; se[p][1] = gg_pts[3 * i + 1]; se[p][2] = gg_pts[3 * i + 2]; }
+            }
+        }
+    };
+    const bool single = cnt <= BR_STAGE;                                             // (most items of a sparse cloud: staged once for all levels)
+    if (single) stage(0u, (int)cnt);
+    for (int l = 0; l < vs.n; ++l) {
+        float* __restrict__ gv = vs.grad[l];
+        if (!gv) continue;                                                          // (uniform)
+        const int size[3] = {vs.dx[l], vs.dy[l], vs.dz[l]};
+        const int64_t nvox = (int64_t)size[0] * size[1] * size[2];
+        // the voxels of this level the brick's points can touch: cells [8 b, 8 b + 8) of the finest level are positions [8 b, 8 b + 8) / (fine - 1) of
+        // the axis, i.e. cells floor(8 b r) .. floor((8 b + 8) r) of this one (r = (size - 1) / (fine - 1); a hundredth of a cell either way for the
+        // rounding of the two float expressions) and their + 1 neighbours; the last brick of an axis also holds what lies beyond it.  Whatever still
+        // falls outside takes the direct atomic below.
+        int lo[3], ext[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float r = fine[ax] > 1 ? (float)(size[ax] - 1) / (float)(fine[ax] - 1) : 0.0f;
+            const int cell_lo = (int)bc[ax] * 8, cell_hi = (int)bc[ax] + 1 == P.nb[ax] ? fine[ax] : cell_lo + 8;
+            const bool same = size[ax] == fine[ax];                                  // (the finest level itself: cells 8 b .. 8 b + 7 and their + 1 neighbours, exactly)
+            lo[ax] = same ? cell_lo : max((int)floorf((float)cell_lo * r - 0.01f), 0);
+            const int hi = min(same ? cell_hi : (int)floorf((float)cell_hi * r + 0.01f) + 1, size[ax] - 1);
+            ext[ax] = min(max(hi - lo[ax] + 1, 1), BR_EXT);
+        }
+        const int cells = ext[0] * ext[1] * ext[2];
+        for (int k = tid; k < 4 * cells; k += 256) tile[k] = 0.0;
+        __syncthreads();                                                            // (also: the staged chunk is complete)
+        for (uint32_t base = 0; base < cnt; base += BR_STAGE) {
+            const int staged = (int)min((uint32_t)BR_STAGE, cnt - base);
+            if (!single) {
+                stage(base, staged);
+                __syncthreads();
+            }
+            for (int p = slot; p < staged; p += 8) {
+                const Cell cx = axis_cell(sp[p][0], size[0]), cy = axis_cell(sp[p][1], size[1]), cz = axis_cell(sp[p][2], size[2]);
+                const bool ok = (a ? cx.in1 : cx.in0) && (b ? cy.in1 : cy.in0) && (c ? cz.in1 : cz.in0);
+                if (!ok) continue;
+                const float wx = a ? cx.w1 : cx.w0, wy = b ? cy.w1 : cy.w0, wz = c ? cz.w1 : cz.w0;
+                float coef;
+                if (!SECOND) {
+                    coef = wx * wy * wz;
+                } else {
+                    const float ex = se[p][0] * ((float)(size[0] - 1) / 2.0f), ey = se[p][1] * ((float)(size[1] - 1) / 2.0f), ez = se[p][2] * ((float)(size[2] - 1) / 2.0f);
+                    const float sx = a ? 1.0f : -1.0f, sy = b ? 1.0f : -1.0f, sz = c ? 1.0f : -1.0f;
+                    coef = ex * (sx * wy * wz) + ey * (wx * sy * wz) + ez * (wx * wy * sz);
+                }
+                const float val = ((const float*)&sg[p][l])[ch] * coef;
+                const int x = cx.i0 + a, y = cy.i0 + b, z = cz.i0 + c;
+                const int tx = x - lo[0], ty = y - lo[1], tz = z - lo[2];
+                if ((unsigned)tx < (unsigned)ext[0] && (unsigned)ty < (unsigned)ext[1] && (unsigned)tz < (unsigned)ext[2]) {
+                    const int at = LAYOUT == GENS_LAYOUT_PACKED ? ((tx * ext[1] + ty) * ext[2] + tz) * 4 + ch : ((ch * ext[0] + tx) * ext[1] + ty) * ext[2] + tz;
+                    atomicAdd(tile + at, (double)val);
+                } else {                                                            // outside the tile: the direct atomic
+                    const int64_t lin = ((int64_t)x * size[1] + y) * size[2] + z;
+                    atomicAdd(LAYOUT == GENS_LAYOUT_PACKED ? gv + lin * 4 + ch : gv + ch * nvox + lin, val);
+                }
+            }
+            if (!single) __syncthreads();                                           // (the next chunk overwrites the staged rows)
+        }
+        __syncthreads();
+        // the flush, a z-row of the tile per 16 lanes (no division per entry; the lanes of a row on consecutive floats): PLANAR rows = (channel, x, y),
+        // 16 lanes along z; PACKED rows = (x, y), lanes = (z, channel) pairs, 64 along a row of <= 10 x 4 floats
+        if (LAYOUT == GENS_LAYOUT_PACKED) {
+            const int rows = ext[0] * ext[1], lane = tid & 63, wave = tid >> 6;
+            for (int r = wave; r < rows; r += 4) {
+                const int tx = r / ext[1], ty = r - tx * ext[1];
+                if (lane < 4 * ext[2]) {
+                    const float v = (float)tile[r * ext[2] * 4 + lane];
+                    if (v != 0.0f) {                                                // (NaN != 0: travels on)
+                        const int64_t lin = ((int64_t)(lo[0] + tx) * size[1] + (lo[1] + ty)) * size[2] + lo[2];
+                        atomicAdd(gv + lin * 4 + lane, v);
+                    }
+                }
+            }
+        } else {
+            const int rows = 4 * ext[0] * ext[1], tz = tid & 15;
+            for (int r = tid >> 4; r < rows; r += 16) {
+                const int cc = r / (ext[0] * ext[1]), xy = r - cc * ext[0] * ext[1], tx = xy / ext[1], ty = xy - tx * ext[1];
+                if (tz < ext[2]) {
+                    const float v = (float)tile[r * ext[2] + tz];
+                    if (v != 0.0f) {
+                        const int64_t lin = ((int64_t)(lo[0] + tx) * size[1] + (lo[1] + ty)) * size[2] + (lo[2] + tz);
+                        atomicAdd(gv + cc * nvox + lin, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static bool brick_plan(const LevelSet& vs, int64_t n, void* scratch, int64_t scratch_bytes, BrickPlan* P, int64_t* need) {
+    int fine = 0;
+    int64_t most = 0;
+    for (int l = 0; l < vs.n; ++l) {
+        const int64_t v = (int64_t)vs.dx[l] * vs.dy[l] * vs.dz[l];
+        if (v > most) { most = v; fine = l; }
+    }
+    P->fine = fine;
+    const int size[3] = {vs.dx[fine], vs.dy[fine], vs.dz[fine]};
+    for (int ax = 0; ax < 3; ++ax) P->nb[ax] = std::min(BR_NB, std::max(1, (size[ax] + 7) / 8));
+    P->n_bricks = (uint32_t)(P->nb[0] * P->nb[1] * P->nb[2]);
+    const int64_t arr = ((int64_t)P->n_bricks + 1 + 3) / 4 * 4;                      // (each array a multiple of four words: 16-byte loads in the scan)
+    P->max_items = (uint32_t)std::min<int64_t>((int64_t)P->n_bricks + n / BR_SEG + 1, 0x7fffffff);
+    const int64_t n4 = (n + 3) / 4 * 4;
+    const int64_t words = 2 * arr + 3 * n4 + 2 * (int64_t)P->max_items + 4;
+    *need = words * 4;
+    if (!scratch || scratch_bytes < *need) return false;
+    uint32_t* w = (uint32_t*)scratch;
+    P->count = w;
+    P->offset = w + arr;
+    P->order = w + 2 * arr;
+    P->key = w + 2 * arr + n4;
+    P->rank = w + 2 * arr + 2 * n4;
+    P->n_items = w + 2 * arr + 3 * n4;
+    P->items = (uint2*)(w + 2 * arr + 3 * n4 + 4);
+    return true;
+}
+// bricks only where every level's tile fits: a level may be at most as fine as the finest per axis (always) and the finest at most 8 * BR_NB cells wide
+// per axis beyond which a brick is wider than 8 cells -- then its tile would not fit and the direct scatter serves the call
+static bool bricks_fit(const LevelSet& vs, const BrickPlan& P) {
+    const int size[3] = {vs.dx[P.fine], vs.dy[P.fine], vs.dz[P.fine]};
+    for (int ax = 0; ax < 3; ++ax)
+        if ((size[ax] + 7) / 8 > BR_NB) return false;
+    return true;
+}
+
+extern "C" int64_t gens_lookup_scatter_bricks_scratch_bytes(int64_t n) {
+    return n < 0 ? 0 : 4 * (2 * ((int64_t)BR_MAX + 4) + 3 * ((n + 3) / 4 * 4) + 2 * ((int64_t)BR_MAX + n / BR_SEG + 1) + 4);
+}
+
+template <bool SECOND>
+static int scatter_bricks(const char* who, int layout, const LevelSet& vs, const float* pts, const float* g_out, const float* gg_pts, int64_t n,
+                          void* scratch, int64_t scratch_bytes, void* stream) {
+    BrickPlan P;
+    int64_t need = 0;
+    const bool have = brick_plan(vs, n, scratch, scratch_bytes, &P, &need);
+    GENS_CHECK_ARG(have && ((uintptr_t)scratch & 15) == 0, GENS_EINVAL, "%s: scratch of %lld bytes needed (gens_lookup_scatter_bricks_scratch_bytes), got %lld", who,
+                   (long long)need, (long long)scratch_bytes);
+    if (!bricks_fit(vs, P) || n >= ((int64_t)1 << 31)) {                            // (sizes the bricks do not cover: the direct scatter)
+        launch_lookup_scatter<SECOND>(layout, vs, pts, g_out, gg_pts, n, stream);
+        return 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    brick_zero_k<<<(P.n_bricks + 1u + 255u) / 256u, 256, 0, st>>>(P.count, P.n_bricks + 1u);   // (a kernel: a captured memset node does not order, k1_volume.hip)
+    brick_count_k<<<gens_blocks(n, 256), 256, 0, st>>>(vs, P, pts, n);
+    brick_scan_k<<<1, 1024, 0, st>>>(P);
+    brick_fill_k<<<gens_blocks(n, 256), 256, 0, st>>>(P, n);
+    if (layout == GENS_LAYOUT_PACKED)
+        lookup_scatter_bricks_k<GENS_LAYOUT_PACKED, SECOND><<<P.max_items, 256, 0, st>>>(vs, P, pts, (const float4*)g_out, gg_pts);
+    else
+        lookup_scatter_bricks_k<GENS_LAYOUT_PLANAR, SECOND><<<P.max_items, 256, 0, st>>>(vs, P, pts, (const float4*)g_out, gg_pts);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K3 nearest mask + fused ray-point generation
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_nearest_k(LevelSet ms, const float* __restrict__ pts, int64_t n,
@@ -588,6 +884,47 @@ extern "C" int gens_lookup_volume_bwd2(const float* const* vols, const int* dims
         if (scatter) launch_lookup_scatter<true>(layout, vs, pts, g_out, gg_pts, n, stream);
     }
     return gens_launch_status("gens_lookup_volume_bwd2");
+}
+
+extern "C" int gens_lookup_volume_bwd_bricks(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                             const float* g_out, int64_t n, float* const* g_vols, float* g_pts, void* scratch, int64_t scratch_bytes,
+                                             void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_lookup_volume_bwd_bricks", &vs, vols, dims, n_levels)) return e;
+    GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_bwd_bricks: bad layout %d", layout);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out)), GENS_EINVAL, "gens_lookup_volume_bwd_bricks: null pts/g_out");
+    GENS_CHECK_ARG(g_vols || g_pts, GENS_EINVAL, "gens_lookup_volume_bwd_bricks: no output requested");
+    if (n == 0) return 0;
+    if (g_pts) DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts);
+    bool scatter = false;
+    for (int l = 0; g_vols && l < n_levels; ++l) {
+        vs.grad[l] = g_vols[l];
+        scatter = scatter || g_vols[l];
+    }
+    if (scatter)
+        if (int e = scatter_bricks<false>("gens_lookup_volume_bwd_bricks", layout, vs, pts, g_out, nullptr, n, scratch, scratch_bytes, stream)) return e;
+    return gens_launch_status("gens_lookup_volume_bwd_bricks");
+}
+
+extern "C" int gens_lookup_volume_bwd2_bricks(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                              const float* g_out, const float* gg_pts, const float* const* gg_vols, int64_t n,
+                                              float* gg_out, float* const* g_vols2, float* g_pts2, void* scratch, int64_t scratch_bytes, void* stream) {
+    LevelSet vs;
+    if (int e = gens_fill_levels("gens_lookup_volume_bwd2_bricks", &vs, vols, dims, n_levels)) return e;
+    GENS_CHECK_ARG(layout == 0 || layout == 1, GENS_EINVAL, "gens_lookup_volume_bwd2_bricks: bad layout %d", layout);
+    GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out && gg_pts && gg_out && g_pts2)), GENS_EINVAL, "gens_lookup_volume_bwd2_bricks: null pointer");
+    if (n == 0) return 0;
+    for (int l = 0; l < n_levels; ++l)
+        if (gg_vols) vs.aux[l] = gg_vols[l];
+    DISPATCH_LAYOUT(layout, lookup_bwd2_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, gg_pts, n, (float4*)gg_out, g_pts2);
+    bool scatter = false;
+    for (int l = 0; g_vols2 && l < n_levels; ++l) {
+        vs.grad[l] = g_vols2[l];
+        scatter = scatter || g_vols2[l];
+    }
+    if (scatter)
+        if (int e = scatter_bricks<true>("gens_lookup_volume_bwd2_bricks", layout, vs, pts, g_out, gg_pts, n, scratch, scratch_bytes, stream)) return e;
+    return gens_launch_status("gens_lookup_volume_bwd2_bricks");
 }
 
 extern "C" int gens_lookup_mask_nearest(const float* const* masks, const int* dims, int n_levels, const float* pts, int64_t n,

@@ -75,7 +75,9 @@ SIGNATURES = {
     "gens_instnorm_relu_bwd": [_p, _p, _p, _p, _i, _l, _p, _p],
     "gens_lookup_volume_fwd": [_pp, _ip, _i, _i, _p, _l, _p, _p],
     "gens_lookup_volume_bwd": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p],
+    "gens_lookup_volume_bwd_bricks": [_pp, _ip, _i, _i, _p, _p, _l, _pp, _p, _p, _l, _p],
     "gens_lookup_volume_bwd2": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p],
+    "gens_lookup_volume_bwd2_bricks": [_pp, _ip, _i, _i, _p, _p, _p, _pp, _l, _p, _pp, _p, _p, _l, _p],
     "gens_lookup_mask_nearest": [_pp, _ip, _i, _p, _l, _p, _p, _p],
     "gens_ray_points": [_p, _p, _p, _l, _i, _i, _f, _pp, _ip, _i, _i, _p, _p, _p],
     "gens_pack_mask_bits": [_p, _l, _p, _p],
@@ -193,6 +195,8 @@ def load():
     lib.gens_blend_train_acc_floats.argtypes = [_i]
     lib.gens_blend_train_t_parts.restype = _i
     lib.gens_blend_train_t_parts.argtypes = [_l, _i]
+    lib.gens_lookup_scatter_bricks_scratch_bytes.restype = _l
+    lib.gens_lookup_scatter_bricks_scratch_bytes.argtypes = [_l]
     lib.gens_gemm_tn_batch_workspace.restype = _l
     lib.gens_gemm_tn_batch_workspace.argtypes = [_i, _ip, _ip, _l]
     lib.gens_scene_cams_floats.restype = _l

@@ -28,7 +28,8 @@ class KernelChoice:
         sdf_grad_f16           True: under sdf_precision "f16x2" the value + gradient pass runs on the split-half kernel too (k6gh) | False: float32
         k1_bwd                 "auto" (all levels on the image-tile kernel) | "window" (the wave-window kernel, level by level)
         tex_cache              texel copies kept on the map tensors (pack_maps)
-        select_views           fine-tuning takes a step's views out of the frozen maps and their layouts in one launch (gens_select_views) | torch.index_select"""
+        select_views           fine-tuning takes a step's views out of the frozen maps and their layouts in one launch (gens_select_views) | torch.index_select
+        k2_bricks_min          points from which the stand-alone look-up's volume-gradient scatter runs brick by brick (gens_lookup_volume_bwd_bricks)"""
 
     def __init__(self, env=os.environ):
         self.sdf_value = "rowmajor" if env.get("GENS_SDF_VALUE_ROWMAJOR") else "transposed"
@@ -41,6 +42,7 @@ class KernelChoice:
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
         self.select_views = not env.get("GENS_NO_SELECT_VIEWS")
+        self.k2_bricks_min = int(env.get("GENS_K2_BRICKS_MIN", "262144"))
 
 
 kernels = KernelChoice()

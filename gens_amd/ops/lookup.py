@@ -31,6 +31,10 @@ class _Lookup(torch.autograd.Function):
         return (res[0], None) + tuple(res[1:])
 
 
+def _bricks_scratch(n, device):
+    return torch.empty(L.load().gens_lookup_scatter_bricks_scratch_bytes(n), device=device, dtype=torch.uint8)
+
+
 class _LookupBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g_out, pts, layout, want_vol, *vols):
@@ -40,8 +44,14 @@ class _LookupBwd(torch.autograd.Function):
         pts_c = _c(pts.detach().to(_f32))
         g_pts = torch.empty(n, 3, device=pts.device, dtype=_f32)
         g_vols = [torch.zeros_like(v) for v in vs.tensors] if want_vol else None
-        L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), L.ptr(g_out_c), n, L.ptr_table(g_vols),
-               L.ptr(g_pts), L.stream(), nbytes=n * (24 + 16 * vs.n))
+        if want_vol and n >= kernels.k2_bricks_min:
+            # large point sets: the volume-gradient scatter brick by brick (every touched voxel written once), not 32 atomics per point and level
+            scratch = _bricks_scratch(n, pts.device)
+            L.call("gens_lookup_volume_bwd_bricks", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), L.ptr(g_out_c), n, L.ptr_table(g_vols),
+                   L.ptr(g_pts), L.ptr(scratch, torch.uint8), scratch.numel(), L.stream(), nbytes=n * (24 + 16 * vs.n), label="gens_lookup_volume_bwd")
+        else:
+            L.call("gens_lookup_volume_bwd", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts_c), L.ptr(g_out_c), n, L.ptr_table(g_vols),
+                   L.ptr(g_pts), L.stream(), nbytes=n * (24 + 16 * vs.n))
         ctx.save_for_backward(g_out_c, pts_c, *vols)
         ctx.layout, ctx.want_vol = layout, want_vol
         if want_vol:
@@ -64,8 +74,14 @@ class _LookupBwd(torch.autograd.Function):
         g_vols2 = [torch.zeros_like(t) for t in vs.tensors] if want_vol else None
         gg_out = torch.empty_like(g_out)
         g_pts2 = torch.empty(n, 3, device=pts.device, dtype=_f32)
-        L.call("gens_lookup_volume_bwd2", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), L.ptr(_c(gg_pts.detach())),
-               L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.stream(), nbytes=n * (36 + 32 * vs.n))
+        if want_vol and n >= kernels.k2_bricks_min:
+            scratch = _bricks_scratch(n, pts.device)
+            L.call("gens_lookup_volume_bwd2_bricks", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), L.ptr(_c(gg_pts.detach())),
+                   L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.ptr(scratch, torch.uint8), scratch.numel(), L.stream(),
+                   nbytes=n * (36 + 32 * vs.n), label="gens_lookup_volume_bwd2")
+        else:
+            L.call("gens_lookup_volume_bwd2", vs.table, vs.dim_table, vs.n, layout, L.ptr(pts), L.ptr(g_out), L.ptr(_c(gg_pts.detach())),
+                   L.ptr_table(ggv), n, L.ptr(gg_out), L.ptr_table(g_vols2), L.ptr(g_pts2), L.stream(), nbytes=n * (36 + 32 * vs.n))
         # outputs are plain tensors: third order through the sampler is dropped, as in the reference (cuda_gridsample.py:110-123)
         if want_vol:
             gv = tuple(g.reshape(v.shape) for g, v in zip(g_vols2, vols))

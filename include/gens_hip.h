@@ -53,7 +53,8 @@ const char* gens_last_error(void);
  *   11 = round 6: gens_blend_train_bwd_t + gens_blend_train_t_parts + gens_blend_train_bwd_t_dump (the colour branch's backward transposed: one
  *       wave per 16 rows, nothing shared between waves but the weights in LDS).
  *   12 = round 6: gens_upsample2d_cat (the warp features in one launch), gens_volume_build_levels_bits (the volume build leaves the masks as bits
- *       too), gens_select_views (the views of a fine-tune step out of the frozen maps and their layouts in one launch). */
+ *       too), gens_select_views (the views of a fine-tune step out of the frozen maps and their layouts in one launch),
+ *       gens_lookup_volume_bwd_bricks / _bwd2_bricks + gens_lookup_scatter_bricks_scratch_bytes (K2's volume-gradient scatter brick by brick). */
 int gens_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -130,6 +131,19 @@ int gens_lookup_volume_bwd(const float* const* vols, const int* dims, int n_leve
 int gens_lookup_volume_bwd2(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
                             const float* g_out, const float* gg_pts, const float* const* gg_vols, int64_t n,
                             float* gg_out, float* const* g_vols2, float* g_pts2, void* stream);
+/* The same two with the scatter into the volume gradients done BRICK BY BRICK (ABI 12): the points are counted into bricks of 8^3 cells of the finest
+ * level, a workgroup per brick sums its points' corner contributions in LDS (double sums) and sends every touched voxel to memory once -- for large
+ * point sets whatever their order (the direct scatter of the entries above sends 32 atomics per point and level).  scratch:
+ * gens_lookup_scatter_bricks_scratch_bytes(n) bytes of device memory, 16-byte aligned.  Same results up to the order of the float sums.  Volumes
+ * wider than 256 cells per axis fall back to the direct scatter. */
+int64_t gens_lookup_scatter_bricks_scratch_bytes(int64_t n);
+int gens_lookup_volume_bwd_bricks(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                  const float* g_out, int64_t n, float* const* g_vols, float* g_pts, void* scratch,
+                                  int64_t scratch_bytes, void* stream);
+int gens_lookup_volume_bwd2_bricks(const float* const* vols, const int* dims, int n_levels, int layout, const float* pts,
+                                   const float* g_out, const float* gg_pts, const float* const* gg_vols, int64_t n,
+                                   float* gg_out, float* const* g_vols2, float* g_pts2, void* scratch, int64_t scratch_bytes,
+                                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K3  lookup_volume(pts, mask_volumes, "nearest").any(-1)        (projector.py:231,240; Q6, Q7)

@@ -46,7 +46,7 @@ def test_ctypes_table_covers_header(libpath):
     from gens_amd import lib as L
     declared = set(declared_functions()) - {"gens_last_error", "gens_abi_version", "gens_tv_blocks", "gens_sdf_train_stash_bytes", "gens_gemm_tn_batch_workspace", "gens_blend_train_rows",
                                               "gens_volume_build_bwd_levels_scratch_bytes", "gens_sdf_grad_stash_bytes", "gens_sdf_grad_f16_stash_bytes", "gens_scene_cams_floats", "gens_compact_points_scratch",
-                                              "gens_batchnorm2d_scratch_doubles", "gens_blend_train_acc_parts", "gens_blend_train_acc_floats", "gens_blend_train_t_parts"}
+                                              "gens_batchnorm2d_scratch_doubles", "gens_blend_train_acc_parts", "gens_blend_train_acc_floats", "gens_blend_train_t_parts", "gens_lookup_scatter_bricks_scratch_bytes"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     L.load()
 

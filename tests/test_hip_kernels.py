@@ -388,6 +388,99 @@ def test_k9_warp_feature_upsampling_vs_oracle(ops):
     close(tex.permute(0, 3, 1, 2)[:, 8:12], torch_ref, atol=1e-6, what="vs F.interpolate")
 
 
+@pytest.mark.parametrize("layout", ["planar", "packed"])
+@pytest.mark.parametrize("dims", [[64, 32, 16], [40, 24], [20]])
+def test_k2_brick_scatter_equals_the_direct_scatter(ops, dims, layout):
+    """gens_lookup_volume_bwd_bricks / _bwd2_bricks against the direct scatter of gens_lookup_volume_bwd / _bwd2: volume gradients (first and second
+    order) equal up to the order of the float sums; the point gradients are the same kernels'.  Points: uniform in the cube, a cluster that fills a
+    few bricks, points on the faces, outside the cube, far outside and a NaN -- every path of the brick kernel (tile, out-of-tile fallback, bounds)."""
+    from gens_amd import lib as L
+    g = torch.Generator().manual_seed(31)
+    n = 6000
+    pts = torch.rand(n, 3, generator=g) * 2 - 1
+    pts[1000:3000] = torch.randn(2000, 3, generator=g) * 0.03 + torch.tensor([0.31, -0.4, 0.77])
+    pts[4000:5500] = torch.randn(1500, 3, generator=g) * 0.004 + torch.tensor([-0.52, 0.13, -0.2])      # one crowded brick: several work items, several chunks each
+    pts[3000:3200] = pts[3000:3200].sign()
+    pts[3200:3400] = pts[3200:3400] * 1.2
+    pts[3400:3410] = 1e12
+    pts[3410] = float("nan")
+    pts = pts.cuda()
+    nl = len(dims)
+    if layout == "planar":
+        vols = [torch.randn(4, d, d + 2 * (d > 20), d, generator=g).cuda() for d in dims]
+        shapes = [v.shape[1:] for v in vols]
+    else:
+        vols = [torch.randn(d, d + 2 * (d > 20), d, 4, generator=g).cuda() for d in dims]
+        shapes = [v.shape[:3] for v in vols]
+    lay = 0 if layout == "planar" else 1
+    dim_table = L.int_table([x for s_ in shapes for x in s_])
+    g_out = torch.randn(n, nl, 4, generator=g).cuda()
+    gg_pts = torch.randn(n, 3, generator=g).cuda()
+    scratch = torch.empty(L.load().gens_lookup_scatter_bricks_scratch_bytes(n), device="cuda", dtype=torch.uint8)
+
+    def run(bricks, second):
+        gv = [torch.zeros_like(v) for v in vols]
+        gp = torch.empty(n, 3, device="cuda")
+        if not second:
+            if bricks:
+                L.call("gens_lookup_volume_bwd_bricks", L.ptr_table(vols), dim_table, nl, lay, L.ptr(pts), L.ptr(g_out), n, L.ptr_table(gv), L.ptr(gp),
+                       L.ptr(scratch, torch.uint8), scratch.numel(), L.stream())
+            else:
+                L.call("gens_lookup_volume_bwd", L.ptr_table(vols), dim_table, nl, lay, L.ptr(pts), L.ptr(g_out), n, L.ptr_table(gv), L.ptr(gp), L.stream())
+            return gv, gp
+        ggo = torch.empty_like(g_out)
+        if bricks:
+            L.call("gens_lookup_volume_bwd2_bricks", L.ptr_table(vols), dim_table, nl, lay, L.ptr(pts), L.ptr(g_out), L.ptr(gg_pts), None, n, L.ptr(ggo),
+                   L.ptr_table(gv), L.ptr(gp), L.ptr(scratch, torch.uint8), scratch.numel(), L.stream())
+        else:
+            L.call("gens_lookup_volume_bwd2", L.ptr_table(vols), dim_table, nl, lay, L.ptr(pts), L.ptr(g_out), L.ptr(gg_pts), None, n, L.ptr(ggo),
+                   L.ptr_table(gv), L.ptr(gp), L.stream())
+        return gv, torch.cat([gp.reshape(-1), ggo.reshape(-1)])
+
+    for second in (False, True):
+        ref_v, ref_p = run(False, second)
+        got_v, got_p = run(True, second)
+        assert torch.equal(torch.nan_to_num(got_p, nan=7.0), torch.nan_to_num(ref_p, nan=7.0))
+        for a_, b_ in zip(got_v, ref_v):
+            assert torch.equal(torch.isnan(a_), torch.isnan(b_))
+            a0, b0 = torch.nan_to_num(a_), torch.nan_to_num(b_)
+            assert float(b0.abs().max()) > 0.1
+            assert float((a0 - b0).abs().max()) <= 2e-5 * float(b0.abs().max()), (second, float((a0 - b0).abs().max()), float(b0.abs().max()))
+
+
+def test_k2_large_point_sets_take_the_brick_scatter_through_autograd(ops, monkeypatch):
+    """ops.lookup_volume's backward and double backward above kernels.k2_bricks_min points run the brick entries (asserted through the launch labels'
+    timing table: the direct entries are not called) and give the direct scatter's volume gradients."""
+    from gens_amd import lib as L
+    g = torch.Generator().manual_seed(5)
+    n = 40000
+    pts0 = (torch.rand(n, 3, generator=g) * 2 - 1)
+    pts0[:15000] = torch.randn(15000, 3, generator=g) * 0.05 + torch.tensor([0.2, 0.1, -0.3])
+    vols0 = [0.5 * torch.randn(1, 4, d, d, d, generator=g) for d in (48, 24)]
+    cot = torch.randn(n, 8, generator=g).cuda()
+    res = {}
+    for name, least in (("bricks", 1000), ("direct", 10 ** 9)):
+        monkeypatch.setattr(ops.kernels, "k2_bricks_min", least)
+        p = pts0.clone().cuda().requires_grad_(True)
+        vs = [v.clone().cuda().requires_grad_(True) for v in vols0]
+        calls = []
+        real = L.call
+        monkeypatch.setattr(L, "call", lambda nm, *a, **k: (calls.append(nm), real(nm, *a, **k))[1])
+        f = ops.lookup_volume(p, vs)
+        gp, = torch.autograd.grad((f * cot).sum(), p, create_graph=True)
+        ((gp * gp).sum() + (f * cot).sum()).backward()
+        monkeypatch.setattr(L, "call", real)
+        res[name] = [v.grad.clone() for v in vs]
+        if name == "bricks":
+            assert "gens_lookup_volume_bwd_bricks" in calls and "gens_lookup_volume_bwd2_bricks" in calls
+            assert "gens_lookup_volume_bwd" not in calls and "gens_lookup_volume_bwd2" not in calls
+        else:
+            assert "gens_lookup_volume_bwd_bricks" not in calls
+    for a_, b_ in zip(res["bricks"], res["direct"]):
+        assert float(b_.abs().max()) > 0.1
+        assert float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
+
+
 @pytest.mark.parametrize("chans", [(4, 4, 4), (3, 5, 2), (4, 4)])
 def test_k9_one_launch_upsampling_equals_the_launch_per_level(ops, chans):
     """gens_upsample2d_cat against gens_upsample2d_into level by level, bit for bit; the pad channels are written (zeros), not left to a fill."""

@@ -86,6 +86,7 @@ for name, restype, argsets in (
         ("gens_scene_cams_floats", C.c_int64, [(C.c_int(v),) for v in (0, 1, 5, 16, 17)]),
         ("gens_batchnorm2d_scratch_doubles", C.c_int64, [(C.c_int(a), C.c_int(b), C.c_int(c)) for a in (0, 1, 5) for b in (0, 3, 1152) for c in (0, 1, 300, 76800)]),
         ("gens_compact_points_scratch", C.c_int64, [(C.c_int64(n),) for n in (0, 1, 70000, 1 << 33)]),
+        ("gens_lookup_scatter_bricks_scratch_bytes", C.c_int64, [(C.c_int64(n),) for n in (-1, 0, 1, 70000, 1 << 33)]),
         ("gens_sdf_value_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
         ("gens_sdf_grad_groups", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
         ("gens_sdf_grad_f16_pieces", C.c_int, [(C.c_int(v),) for v in range(-1, 10)]),
