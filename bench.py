@@ -635,7 +635,7 @@ def main():
     if secondary and args.sdf_precision == "f32" and not args.chunk:
         try:
             from scripts.val_full_bench import measure_default_path
-            default_path = measure_default_path(repeats=SECONDARY_STEPS + 1, dims=tuple(args.dims))
+            default_path = measure_default_path(repeats=SECONDARY_STEPS + 5, dims=tuple(args.dims))      # (the first three items are left out)
             headline_ms = elapsed / args.steps * 1e3
             default_path.update({
                 "ms_per_step": default_path["render_ms"], "value": round(n_rays * n_final / default_path["render_ms"] * 1e3, 1), "unit": "ray-samples/s",
