@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256) void lookup_fwd_paired_k(LevelSet vs, const fl
 // ---------------------------------------------------------------------------------------------------------------
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void lookup_bwd_k(LevelSet vs, const float* __restrict__ pts,
-                                                    const float4* __restrict__ g_out, int64_t n, float* __restrict__ g_pts) {
+                                                    const float4* __restrict__ g_out, int64_t n, float* __restrict__ g_pts,
+                                                    const uint32_t* __restrict__ order = nullptr) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (order) i = (int64_t)order[i];      // (the brick entries: thread k takes the k-th point of the BRICK order -- neighbours in the volume, whose corners the wave then finds in L1)
     float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;
     for (int l = 0; l < vs.n; ++l) {
@@ -216,9 +218,11 @@ __global__ __launch_bounds__(256) void lookup_bwd_k(LevelSet vs, const float* __
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void lookup_bwd2_k(LevelSet vs, const float* __restrict__ pts,
                                                      const float4* __restrict__ g_out, const float* __restrict__ gg_pts,
-                                                     int64_t n, float4* __restrict__ gg_out, float* __restrict__ g_pts2) {
+                                                     int64_t n, float4* __restrict__ gg_out, float* __restrict__ g_pts2,
+                                                     const uint32_t* __restrict__ order = nullptr) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (order) i = (int64_t)order[i];
     float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     float qx = gg_pts[3 * i], qy = gg_pts[3 * i + 1], qz = gg_pts[3 * i + 2];
     float ox = 0.0f, oy = 0.0f, oz = 0.0f;
@@ -608,28 +612,34 @@ extern "C" int64_t gens_lookup_scatter_bricks_scratch_bytes(int64_t n) {
     return n < 0 ? 0 : 4 * (2 * ((int64_t)BR_MAX + 4) + 3 * ((n + 3) / 4 * 4) + 2 * ((int64_t)BR_MAX + n / BR_SEG + 1) + 4);
 }
 
-template <bool SECOND>
-static int scatter_bricks(const char* who, int layout, const LevelSet& vs, const float* pts, const float* g_out, const float* gg_pts, int64_t n,
-                          void* scratch, int64_t scratch_bytes, void* stream) {
-    BrickPlan P;
+// the counting sort of a call's points by brick; P.order == nullptr afterwards: sizes the bricks do not cover (the caller takes the direct scatter)
+static int bricks_sort(const char* who, const LevelSet& vs, const float* pts, int64_t n, void* scratch, int64_t scratch_bytes, void* stream, BrickPlan* P) {
     int64_t need = 0;
-    const bool have = brick_plan(vs, n, scratch, scratch_bytes, &P, &need);
+    const bool have = brick_plan(vs, n, scratch, scratch_bytes, P, &need);
     GENS_CHECK_ARG(have && ((uintptr_t)scratch & 15) == 0, GENS_EINVAL, "%s: scratch of %lld bytes needed (gens_lookup_scatter_bricks_scratch_bytes), got %lld", who,
                    (long long)need, (long long)scratch_bytes);
-    if (!bricks_fit(vs, P) || n >= ((int64_t)1 << 31)) {                            // (sizes the bricks do not cover: the direct scatter)
-        launch_lookup_scatter<SECOND>(layout, vs, pts, g_out, gg_pts, n, stream);
+    if (!bricks_fit(vs, *P) || n >= ((int64_t)1 << 31)) {
+        P->order = nullptr;
         return 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    brick_zero_k<<<(P.n_bricks + 1u + 255u) / 256u, 256, 0, st>>>(P.count, P.n_bricks + 1u);   // (a kernel: a captured memset node does not order, k1_volume.hip)
-    brick_count_k<<<gens_blocks(n, 256), 256, 0, st>>>(vs, P, pts, n);
-    brick_scan_k<<<1, 1024, 0, st>>>(P);
-    brick_fill_k<<<gens_blocks(n, 256), 256, 0, st>>>(P, n);
+    brick_zero_k<<<(P->n_bricks + 1u + 255u) / 256u, 256, 0, st>>>(P->count, P->n_bricks + 1u);   // (a kernel: a captured memset node does not order, k1_volume.hip)
+    brick_count_k<<<gens_blocks(n, 256), 256, 0, st>>>(vs, *P, pts, n);
+    brick_scan_k<<<1, 1024, 0, st>>>(*P);
+    brick_fill_k<<<gens_blocks(n, 256), 256, 0, st>>>(*P, n);
+    return 0;
+}
+template <bool SECOND>
+static void scatter_bricks(int layout, const LevelSet& vs, const BrickPlan& P, const float* pts, const float* g_out, const float* gg_pts, int64_t n, void* stream) {
+    if (!P.order) {                                                                 // (sizes the bricks do not cover: the direct scatter)
+        launch_lookup_scatter<SECOND>(layout, vs, pts, g_out, gg_pts, n, stream);
+        return;
+    }
+    hipStream_t st = (hipStream_t)stream;
     if (layout == GENS_LAYOUT_PACKED)
         lookup_scatter_bricks_k<GENS_LAYOUT_PACKED, SECOND><<<P.max_items, 256, 0, st>>>(vs, P, pts, (const float4*)g_out, gg_pts);
     else
         lookup_scatter_bricks_k<GENS_LAYOUT_PLANAR, SECOND><<<P.max_items, 256, 0, st>>>(vs, P, pts, (const float4*)g_out, gg_pts);
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -895,14 +905,16 @@ extern "C" int gens_lookup_volume_bwd_bricks(const float* const* vols, const int
     GENS_CHECK_ARG(n >= 0 && (n == 0 || (pts && g_out)), GENS_EINVAL, "gens_lookup_volume_bwd_bricks: null pts/g_out");
     GENS_CHECK_ARG(g_vols || g_pts, GENS_EINVAL, "gens_lookup_volume_bwd_bricks: no output requested");
     if (n == 0) return 0;
-    if (g_pts) DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts);
+    BrickPlan P;
+    if (int e = bricks_sort("gens_lookup_volume_bwd_bricks", vs, pts, n, scratch, scratch_bytes, stream, &P)) return e;
+    // the per-point kernel walks the points in BRICK order too: thread k's neighbours are its neighbours in the volume (the same sums per point)
+    if (g_pts) DISPATCH_LAYOUT(layout, lookup_bwd_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, n, g_pts, (const uint32_t*)P.order);
     bool scatter = false;
     for (int l = 0; g_vols && l < n_levels; ++l) {
         vs.grad[l] = g_vols[l];
         scatter = scatter || g_vols[l];
     }
-    if (scatter)
-        if (int e = scatter_bricks<false>("gens_lookup_volume_bwd_bricks", layout, vs, pts, g_out, nullptr, n, scratch, scratch_bytes, stream)) return e;
+    if (scatter) scatter_bricks<false>(layout, vs, P, pts, g_out, nullptr, n, stream);
     return gens_launch_status("gens_lookup_volume_bwd_bricks");
 }
 
@@ -916,14 +928,15 @@ extern "C" int gens_lookup_volume_bwd2_bricks(const float* const* vols, const in
     if (n == 0) return 0;
     for (int l = 0; l < n_levels; ++l)
         if (gg_vols) vs.aux[l] = gg_vols[l];
-    DISPATCH_LAYOUT(layout, lookup_bwd2_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, gg_pts, n, (float4*)gg_out, g_pts2);
+    BrickPlan P;
+    if (int e = bricks_sort("gens_lookup_volume_bwd2_bricks", vs, pts, n, scratch, scratch_bytes, stream, &P)) return e;
+    DISPATCH_LAYOUT(layout, lookup_bwd2_k, gens_blocks(n, 256), stream, vs, pts, (const float4*)g_out, gg_pts, n, (float4*)gg_out, g_pts2, (const uint32_t*)P.order);
     bool scatter = false;
     for (int l = 0; g_vols2 && l < n_levels; ++l) {
         vs.grad[l] = g_vols2[l];
         scatter = scatter || g_vols2[l];
     }
-    if (scatter)
-        if (int e = scatter_bricks<true>("gens_lookup_volume_bwd2_bricks", layout, vs, pts, g_out, gg_pts, n, scratch, scratch_bytes, stream)) return e;
+    if (scatter) scatter_bricks<true>(layout, vs, P, pts, g_out, gg_pts, n, stream);
     return gens_launch_status("gens_lookup_volume_bwd2_bricks");
 }
 
