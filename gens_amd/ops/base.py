@@ -42,7 +42,7 @@ class KernelChoice:
         self.k1_bwd = "window" if env.get("GENS_K1_BWD_WINDOW") else "auto"
         self.tex_cache = not env.get("GENS_NO_TEX_CACHE")
         self.select_views = not env.get("GENS_NO_SELECT_VIEWS")
-        self.k2_bricks_min = int(env.get("GENS_K2_BRICKS_MIN", "262144"))
+        self.k2_bricks_min = int(env.get("GENS_K2_BRICKS_MIN", "196608"))
 
 
 kernels = KernelChoice()
